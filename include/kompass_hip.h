@@ -1,0 +1,255 @@
+/*
+ * kompass_hip.h -- C ABI of libkompass_hip.so: the MI355X (gfx950) hot path of
+ * kompass_cpp's sampling controller (DWA sampler -> roll-out -> collision ->
+ * weighted cost -> argmin) and of the laserscan -> occupancy LocalMapper.
+ *
+ * The reference (automatika-robotics/kompass-core v0.8.1) has no C ABI: its
+ * boundary is a C++ class surface + a nanobind module.
+ * This header is the thin shim the host C++ classes
+ * (kompass-core_amd/csrc/host/) and any other binding call into.  Every entry
+ * point names the reference interface it replaces; paths are relative to
+ * <reference>/src/kompass_cpp/kompass_cpp/.
+ *
+ * Conventions
+ *  - plain C types only: pointers + sizes, caller-owned host buffers, opaque
+ *    contexts; no C++/torch types.
+ *  - every call returns KC_OK (0) or a negative kc_status; the message of the
+ *    last failure on the calling thread is kc_last_error().  A HIP failure
+ *    never crosses the boundary as UB.  There is NO CPU fallback: without a
+ *    usable HIP device every compute call returns KC_ERR_HIP.
+ *  - one HIP stream per context; calls on one context are serial, distinct
+ *    contexts may be driven from distinct threads (reference objects are not
+ *    thread-safe either: trajectory_sampler.cpp:18, local_mapper.cpp:15).
+ *  - results are bit-exact on integers/indices and on float costs w.r.t. the
+ *    reference CPU path with maxNumThreads = 1 ordering.
+ */
+#ifndef KOMPASS_HIP_H
+#define KOMPASS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KC_ABI_VERSION 1
+
+typedef enum {
+  KC_OK = 0,
+  KC_ERR_INVALID = -1,     /* bad argument (reference: std::invalid_argument) */
+  KC_ERR_RANGE = -2,       /* capacity / range (reference: std::out_of_range) */
+  KC_ERR_HIP = -3,         /* HIP runtime failure or no device */
+  KC_ERR_UNSUPPORTED = -4, /* outside the restated domain (e.g. non-planar
+                              sensor rotation for the collision checker) */
+  KC_ERR_STATE = -5        /* call order (e.g. evaluate before roll-out) */
+} kc_status;
+
+/* datatypes/control.h:12 */
+enum { KC_ACKERMANN = 0, KC_DIFFERENTIAL_DRIVE = 1, KC_OMNI = 2 };
+/* utils/collision_check.h:25 */
+enum { KC_CYLINDER = 0, KC_BOX = 1, KC_SPHERE = 2 };
+/* mapping/local_mapper.h:9 */
+enum { KC_UNEXPLORED = -1, KC_EMPTY = 0, KC_OCCUPIED = 100 };
+
+const char *kc_last_error(void);
+int kc_abi_version(void);
+/* number of visible HIP devices (0 when none; never fails) */
+int kc_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* plain structs                                                            */
+/* ------------------------------------------------------------------------ */
+typedef struct { /* Path::State, datatypes/path.h:14-22 */
+  double x, y, yaw, speed;
+} kc_state;
+
+typedef struct { /* ControlLimitsParams, datatypes/control.h:191-235 */
+  double vx_max, vx_acc, vx_dec;
+  double vy_max, vy_acc, vy_dec;
+  double omega_max_angle, omega_max, omega_acc, omega_dec;
+} kc_limits;
+
+typedef struct { /* TrajectoryCostsWeights, utils/cost_evaluator.h:22-50 */
+  double reference_path_distance_weight;
+  double goal_distance_weight;
+  double obstacles_distance_weight;
+  double smoothness_weight;
+  double jerk_weight;
+} kc_weights;
+
+typedef struct {
+  /* CollisionChecker ctor, utils/collision_check.h:46-50 */
+  int shape;                /* KC_CYLINDER / KC_BOX / KC_SPHERE */
+  float dims[3];            /* cylinder (r,h) / box (x,y,z) / sphere (r) */
+  int ndims;
+  float sensor_pos[3];      /* sensor position in the body frame */
+  float sensor_rot_xyzw[4]; /* Eigen coefficient order (x,y,z,w) */
+  double octree_res;
+  /* TrajectorySampler / CostEvaluator sizing, trajectory_sampler.h:75-83,
+   * cost_evaluator.h:69-71 (device buffers sized once, like
+   * cost_evaluator_gpu.cpp:54-120; segment / obstacle buffers grow) */
+  double time_step;
+  size_t max_samples;       /* capacity N (numTrajectories) */
+  size_t max_points;        /* capacity P (numPointsPerTrajectory) */
+  size_t max_segment;       /* initial tracked-segment capacity */
+  size_t max_obstacles;     /* initial obstacle capacity */
+  float acc_limits[3];      /* cost_evaluator.cpp:18-20 */
+  int device;               /* HIP device ordinal */
+} kc_dwa_params;
+
+typedef struct {
+  /* TrajSearchResult (trajectory.h:611-618) + LowestCost (:621-644) */
+  int found;           /* isTrajFound */
+  float cost;          /* trajCost (minCost) */
+  int64_t index;       /* index into the admissible-only list (reference
+                          numbering); -1 if not found */
+  int64_t raw_index;   /* index into the generated sample list (global, i.e.
+                          including the shard offset); -1 if not found */
+  int64_t n_admissible;/* samples->size() on this context's shard */
+  int64_t n_samples;   /* samples rolled out on this context's shard */
+} kc_result;
+
+/* ------------------------------------------------------------------------ */
+/* sampling controller                                                      */
+/* ------------------------------------------------------------------------ */
+typedef struct kc_dwa kc_dwa;
+
+/* TrajectorySampler::TrajectorySampler (trajectory_sampler.cpp:23-60) +
+ * CostEvaluator::CostEvaluator (cost_evaluator.cpp:23-37) */
+int kc_dwa_create(const kc_dwa_params *params, kc_dwa **out);
+void kc_dwa_destroy(kc_dwa *ctx);
+
+/* adopt an external hipStream_t (e.g. torch's current stream) for all work of
+ * this context; NULL restores the context's own stream */
+int kc_dwa_set_stream(kc_dwa *ctx, void *hip_stream);
+/* CollisionChecker::resetOctreeResolution, collision_check.cpp:70-75 */
+int kc_dwa_set_resolution(kc_dwa *ctx, double octree_res);
+/* CostEvaluator::updateCostWeights, cost_evaluator.cpp:39-41 */
+int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
+
+/* A1 on the host: TrajectorySampler::UpdateReachableVelocityRange
+ * (trajectory_sampler.cpp:328-372) + the lattice loops (:181-220 / :256-272,
+ * maxNumThreads = 1 ordering) with the all-zero filter of :122-125.
+ * max_angular_samples is the un-bumped constructor value.  The list becomes
+ * the context's sample set (uploaded); returns the count in *n_out.  Optional
+ * vx/vy/omega receive the list (capacity cap). */
+int kc_dwa_sample_window(kc_dwa *ctx, int ctr_type, const kc_limits *limits,
+                         double cur_vx, double cur_vy, double cur_omega,
+                         int max_linear_samples, int max_angular_samples,
+                         size_t *n_out, double *vx, double *vy, double *omega,
+                         size_t cap);
+/* explicit sample list in generation order (what getAdmissibleTrajsFromVel is
+ * called with, trajectory_sampler.cpp:213,260,268) */
+int kc_dwa_set_samples(kc_dwa *ctx, size_t n, const double *vx,
+                       const double *vy, const double *omega);
+/* multi-GPU sharding: this context rolls out only samples [first, first+count)
+ * of the list; raw indices and the packed key carry the global index */
+int kc_dwa_set_shard(kc_dwa *ctx, size_t first, size_t count);
+
+/* sensor data for BOTH consumers, once per cycle:
+ *  CollisionChecker::updateState + updateSensorData<T> (collision_check.cpp:
+ *  125-135, collision_check.h:91-136) and CostEvaluator::setPointScan
+ *  (cost_evaluator.h:174-223; maxObstaclesDist = max_sensor_range / 3). */
+int kc_dwa_set_scan(kc_dwa *ctx, const kc_state *state, const double *ranges,
+                    const double *angles, size_t n, float max_sensor_range);
+int kc_dwa_set_points(kc_dwa *ctx, const kc_state *state, const float *xyz,
+                      size_t n, float max_sensor_range);
+
+/* the (reference_path, tracked_segment) arguments of getMinTrajectoryCost
+ * (cost_evaluator.h:139-142): segment points (Path::View X/Y/Z, path.h:39-76),
+ * acc_at_seg[j] = reference_path->getDistanceAtIndex(seg_start + j)
+ * (path.h:190-194), ref_path_length = reference_path->totalPathLength(). */
+int kc_dwa_set_tracked_segment(kc_dwa *ctx, const float *x, const float *y,
+                               const float *z, const float *acc_at_seg,
+                               size_t seg_size, float ref_path_length);
+
+/* A2-A4: TrajectorySampler::generateTrajectories (trajectory_sampler.cpp:
+ * 295-314 -> :118-179) for the context's samples, drop_samples = true.
+ * num_points = numPointsPerTrajectory of this cycle (<= max_points). */
+int kc_dwa_rollout(kc_dwa *ctx, const kc_state *start, size_t num_points);
+/* A5-A10: CostEvaluator::getMinTrajectoryCost (cost_evaluator.cpp:49-109) on
+ * the rolled-out samples; result stays on the device until fetched */
+int kc_dwa_evaluate(kc_dwa *ctx);
+/* blocks until the cycle finished and copies the 32-byte result record */
+int kc_dwa_fetch_result(kc_dwa *ctx, kc_result *out);
+/* DWA::findBestPath body after the host glue (dwa.h:215-229):
+ * roll-out + evaluate + fetch */
+int kc_dwa_cycle(kc_dwa *ctx, const kc_state *start, size_t num_points,
+                 kc_result *out);
+
+/* winner row: TrajectorySamples2D::getIndex (trajectory.h:556-562).  path_* are
+ * num_points floats, vel_* are num_points-1 floats; any pointer may be NULL */
+int kc_dwa_get_best(kc_dwa *ctx, float *path_x, float *path_y, float *vel_vx,
+                    float *vel_vy, float *vel_omega);
+/* compacted samples in reference order (TrajectorySamples2D, trajectory.h:
+ * 506-603): paths_* [n_admissible x num_points] row-major, raw_index and costs
+ * [n_admissible]; any pointer may be NULL.  cap_rows bounds the rows copied. */
+int kc_dwa_get_samples(kc_dwa *ctx, float *paths_x, float *paths_y,
+                       int32_t *raw_index, float *costs, size_t cap_rows,
+                       size_t *n_rows_out);
+
+/* CostEvaluator::getMinTrajectoryCost on caller-provided trajectories
+ * (sample-major host matrices exactly as TrajectorySamples2D stores them;
+ * vel_* may all be NULL => constant-velocity samples).  Uses the context's
+ * tracked segment, obstacles and weights.  costs_out[N] may be NULL. */
+int kc_cost_evaluate(kc_dwa *ctx, const float *paths_x, const float *paths_y,
+                     const float *vel_vx, const float *vel_vy,
+                     const float *vel_omega, size_t n, size_t num_points,
+                     float *costs_out, kc_result *out);
+
+/* multi-GPU exchange: after kc_dwa_evaluate the context
+ * holds, on the device, int64 key = (sortable(cost) << 32) | global raw index
+ * (signed-comparable; INT64_MAX = nothing found) and int64 n_admissible.
+ * kc_dwa_result_device() returns the device address of that int64[2] record so
+ * the caller can all-reduce(min) / all-gather it on the same stream. */
+int kc_dwa_result_device(kc_dwa *ctx, void **dev_int64x2);
+/* number of admissible samples with raw index < raw_index on this shard (used
+ * to rebuild the reference's compacted index across shards) */
+int kc_dwa_count_admissible_before(kc_dwa *ctx, int64_t global_raw_index,
+                                   int64_t *count_out);
+/* decode helpers for the packed key (pure host functions) */
+float kc_key_cost(int64_t key);
+int64_t kc_key_index(int64_t key);
+int64_t kc_key_pack(float cost, int64_t index);
+
+/* HIP-event timing of the kernels launched by the last cycle, on the stream
+ * they were launched on (bench.py roofline leg).  enable=1 records events
+ * around each kernel; names/ms arrays of capacity cap, returns count. */
+int kc_dwa_timing_enable(kc_dwa *ctx, int enable);
+int kc_dwa_timing_get(kc_dwa *ctx, const char **names, float *ms, size_t cap,
+                      size_t *count_out);
+
+/* ------------------------------------------------------------------------ */
+/* LocalMapper                                                              */
+/* ------------------------------------------------------------------------ */
+typedef struct kc_mapper kc_mapper;
+
+/* LocalMapper / LocalMapperGPU ctor (mapping/local_mapper.h:14-56,
+ * local_mapper_gpu.h:15-66) -- the scan -> grid subset */
+int kc_mapper_create(int grid_height, int grid_width, float resolution,
+                     const float laserscan_position[3],
+                     float laserscan_orientation, size_t max_scan_size,
+                     int device, kc_mapper **out);
+void kc_mapper_destroy(kc_mapper *ctx);
+int kc_mapper_set_stream(kc_mapper *ctx, void *hip_stream);
+/* LocalMapper::scanToGrid (local_mapper.cpp:204-220) with the CPU semantics
+ * (super-cover Bresenham, line_drawing.h:55-124); grid_out is the
+ * Eigen::MatrixXi layout: int32, column-major, cell (i,j) at i + j*height.
+ * Same cell values as the reference CPU mapper, bit for bit. */
+int kc_mapper_scan_to_grid(kc_mapper *ctx, const double *angles,
+                           const double *ranges, size_t n, int32_t *grid_out);
+/* same, but the grid stays on the device (no D2H); the address of the int32
+ * column-major device grid is returned by kc_mapper_grid_device */
+int kc_mapper_scan_to_grid_device(kc_mapper *ctx, const double *angles,
+                                  const double *ranges, size_t n);
+int kc_mapper_grid_device(kc_mapper *ctx, void **dev_grid_int32);
+int kc_mapper_sync(kc_mapper *ctx);
+int kc_mapper_timing_enable(kc_mapper *ctx, int enable);
+int kc_mapper_timing_get(kc_mapper *ctx, const char **names, float *ms,
+                         size_t cap, size_t *count_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOMPASS_HIP_H */

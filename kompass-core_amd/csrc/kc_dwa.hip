@@ -1,0 +1,1371 @@
+// Sampling-controller hot path on gfx950: roll-out + collision, cost terms,
+// argmin.  C ABI in include/kompass_hip.h; reference citations are relative to
+// <reference>/src/kompass_cpp/kompass_cpp/.
+//
+// Numerics contract (DESIGN.md "Exactness"): every device expression repeats
+// the reference CPU expression with the same types and the same operation
+// order; the file is compiled with -ffp-contract=off so no mul+add pair is
+// fused, divisions and square roots use the correctly rounded forms, and the
+// only transcendental inputs (cos/sin of the rolled-out yaw) are produced on
+// the host by the same libm the reference calls (path.h:24-30) and handed to
+// the kernel as a table -- the device never evaluates a trig function.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <unordered_map>
+
+#include "kc_hostmath.h"
+#include "kc_internal.h"
+
+namespace kc {
+
+// ===========================================================================
+// device-side parameter blocks (passed by value)
+// ===========================================================================
+struct CollDev {
+  int shape;        // KC_CYLINDER / KC_BOX / KC_SPHERE
+  int enabled;      // 0 => no occupied cell inside the reachable window
+  int lds;          // stage the occupancy bits in LDS
+  int kx0, ky0;     // window origin (voxel keys, octree frame)
+  int W, H, wpr;    // window size in cells, 32-bit words per row
+  double r00, r01, r10, r11;  // octree-frame rotation (float values widened)
+  double tx, ty;              // octree-frame origin in the world
+  double res, inv;            // voxel edge, 1/res (octomap resolution_factor)
+  double radius, rr;          // cylinder / sphere radius, radius^2
+  double a, b;                // box half extents
+  const uint32_t *bits;       // [H][wpr] occupancy bits (global)
+  const double *ddz;          // sphere only: per-cell z gap [H][W]
+};
+
+struct RollArgs {
+  int n;            // samples in this launch (shard)
+  int first;        // offset of the shard in the sample arrays
+  int P;            // points per trajectory
+  int A;            // trig-table row count
+  int stage;        // LDS transposition of the outputs
+  double x0, y0, dt;
+  const double *vx, *vy;
+  const int32_t *row;
+  const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
+  float *px, *py;       // [n][P] sample-major
+  uint8_t *flags;       // [n] admissible
+  CollDev c;
+};
+
+// ===========================================================================
+// collision: analytic shape-vs-occupied-voxel test (restated A4 contract)
+// ===========================================================================
+template <typename BitsPtr>
+__device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
+                                          double x, double y) {
+  const double dx = x - c.tx, dy = y - c.ty;
+  const double xf = c.r00 * dx + c.r10 * dy;
+  const double yf = c.r01 * dx + c.r11 * dy;
+  const double r = c.radius;
+  int cx0 = static_cast<int>(floor((xf - r) * c.inv)) - 1 - c.kx0;
+  int cx1 = static_cast<int>(floor((xf + r) * c.inv)) + 1 - c.kx0;
+  int cy0 = static_cast<int>(floor((yf - r) * c.inv)) - 1 - c.ky0;
+  int cy1 = static_cast<int>(floor((yf + r) * c.inv)) + 1 - c.ky0;
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, c.W - 1);
+  cy1 = min(cy1, c.H - 1);
+  for (int cy = cy0; cy <= cy1; ++cy) {
+    const int ky = c.ky0 + cy;
+    const double ylo = static_cast<double>(ky) * c.res;
+    const double yhi = static_cast<double>(ky + 1) * c.res;
+    double gy = 0.0;
+    if (ylo - yf > gy) gy = ylo - yf;
+    if (yf - yhi > gy) gy = yf - yhi;
+    for (int wbase = cx0 & ~31; wbase <= cx1; wbase += 32) {
+      uint32_t m = bits[cy * c.wpr + (wbase >> 5)];
+      if (wbase < cx0) m &= 0xFFFFFFFFu << (cx0 - wbase);
+      if (cx1 - wbase < 31) m &= 0xFFFFFFFFu >> (31 - (cx1 - wbase));
+      while (m) {
+        const int b = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1;
+        const int cx = wbase + b;
+        const int kx = c.kx0 + cx;
+        const double xlo = static_cast<double>(kx) * c.res;
+        const double xhi = static_cast<double>(kx + 1) * c.res;
+        double gx = 0.0;
+        if (xlo - xf > gx) gx = xlo - xf;
+        if (xf - xhi > gx) gx = xf - xhi;
+        double zz = 0.0;
+        if (c.shape == KC_SPHERE) {
+          const double g = c.ddz[cy * c.W + cx];
+          zz = g * g;
+        }
+        const double d2 = gx * gx + gy * gy + zz;
+        if (d2 <= c.rr) return true;
+      }
+    }
+  }
+  return false;
+}
+
+template <typename BitsPtr>
+__device__ __forceinline__ bool hit_box(const CollDev &c, BitsPtr bits,
+                                        double x, double y, double cw,
+                                        double sw) {
+  const double dx = x - c.tx, dy = y - c.ty;
+  const double xf = c.r00 * dx + c.r10 * dy;
+  const double yf = c.r01 * dx + c.r11 * dy;
+  const double ux = c.r00 * cw + c.r10 * sw;
+  const double uy = c.r01 * cw + c.r11 * sw;
+  const double vx = -uy, vy = ux;
+  const double ex = c.a * fabs(ux) + c.b * fabs(vx);
+  const double ey = c.a * fabs(uy) + c.b * fabs(vy);
+  int cx0 = static_cast<int>(floor((xf - ex) * c.inv)) - 1 - c.kx0;
+  int cx1 = static_cast<int>(floor((xf + ex) * c.inv)) + 1 - c.kx0;
+  int cy0 = static_cast<int>(floor((yf - ey) * c.inv)) - 1 - c.ky0;
+  int cy1 = static_cast<int>(floor((yf + ey) * c.inv)) + 1 - c.ky0;
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, c.W - 1);
+  cy1 = min(cy1, c.H - 1);
+  const double h = c.res / 2.0;
+  const double hu = h * (fabs(ux) + fabs(uy));
+  const double hv = h * (fabs(vx) + fabs(vy));
+  for (int cy = cy0; cy <= cy1; ++cy) {
+    const int ky = c.ky0 + cy;
+    const double qy = (static_cast<double>(ky) + 0.5) * c.res - yf;
+    for (int wbase = cx0 & ~31; wbase <= cx1; wbase += 32) {
+      uint32_t m = bits[cy * c.wpr + (wbase >> 5)];
+      if (wbase < cx0) m &= 0xFFFFFFFFu << (cx0 - wbase);
+      if (cx1 - wbase < 31) m &= 0xFFFFFFFFu >> (31 - (cx1 - wbase));
+      while (m) {
+        const int b = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1;
+        const int kx = c.kx0 + wbase + b;
+        const double qx = (static_cast<double>(kx) + 0.5) * c.res - xf;
+        if (fabs(qx) > h + ex) continue;
+        if (fabs(qy) > h + ey) continue;
+        if (fabs(qx * ux + qy * uy) > c.a + hu) continue;
+        if (fabs(qx * vx + qy * vy) > c.b + hv) continue;
+        return true;
+      }
+    }
+  }
+  return false;
+}
+
+// ===========================================================================
+// K1: roll-out + collision gate.  One lane per sample (the recurrence
+// x_{k+1} = x_k + (...) is serial in k and must keep the reference's addition
+// order), 64-sample workgroups so N = 8192 already spreads over 128 CUs.
+// Occupancy bits of the reachable window are staged in LDS; outputs go through
+// an LDS tile so the sample-major rows are written as whole contiguous lines.
+// ===========================================================================
+constexpr int kRollBlock = 64;
+
+__global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);
+  const int nwords = a.c.lds ? a.c.H * a.c.wpr : 0;
+  const int P1 = a.P | 1;  // odd row pitch: conflict-free column writes
+  float *tx = reinterpret_cast<float *>(smem + (((size_t)nwords * 4 + 15) & ~(size_t)15));
+  float *ty = tx + (size_t)kRollBlock * P1;
+
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kRollBlock;
+  const int n = base + tid;
+
+  if (a.c.lds && a.c.enabled) {
+    for (int i = tid; i < nwords; i += kRollBlock) lbits[i] = a.c.bits[i];
+    __syncthreads();
+  }
+
+  bool ok = false;
+  if (n < a.n) {
+    ok = true;
+    const double vx = a.vx[a.first + n];
+    const double vy = a.vy[a.first + n];
+    const int r = a.row[a.first + n];
+    double x = a.x0, y = a.y0;
+    const float fx0 = static_cast<float>(x), fy0 = static_cast<float>(y);
+    if (a.stage) {
+      tx[tid * P1] = fx0;
+      ty[tid * P1] = fy0;
+    } else {
+      a.px[(size_t)n * a.P] = fx0;
+      a.py[(size_t)n * a.P] = fy0;
+    }
+    double2 cs = a.trig[r];
+    for (int k = 0; k + 1 < a.P; ++k) {
+      // yaw_{k+1} row: needed by the box test now, by the next step anyway
+      const double2 cs1 = a.trig[(size_t)(k + 1) * a.A + r];
+      // Path::State::update, datatypes/path.h:24-30
+      x += (vx * cs.x - vy * cs.y) * a.dt;
+      y += (vx * cs.y + vy * cs.x) * a.dt;
+      if (a.c.enabled) {
+        bool hit;
+        if (a.c.shape == KC_BOX) {
+          hit = a.c.lds ? hit_box(a.c, lbits, x, y, cs1.x, cs1.y)
+                        : hit_box(a.c, a.c.bits, x, y, cs1.x, cs1.y);
+        } else {
+          hit = a.c.lds ? hit_round(a.c, lbits, x, y)
+                        : hit_round(a.c, a.c.bits, x, y);
+        }
+        if (hit) {  // trajectory_sampler.cpp:147-152, drop_samples_ == true
+          ok = false;
+          break;
+        }
+      }
+      const float fx = static_cast<float>(x), fy = static_cast<float>(y);
+      if (a.stage) {
+        tx[tid * P1 + k + 1] = fx;
+        ty[tid * P1 + k + 1] = fy;
+      } else {
+        a.px[(size_t)n * a.P + k + 1] = fx;
+        a.py[(size_t)n * a.P + k + 1] = fy;
+      }
+      cs = cs1;
+    }
+    a.flags[n] = ok ? 1 : 0;
+  }
+
+  if (a.stage) {
+    __syncthreads();
+    // the block's 64 rows are one contiguous [64*P] range of each plane
+    const int rows = min(kRollBlock, a.n - base);
+    const int total = rows * a.P;
+    float *gx = a.px + (size_t)base * a.P;
+    float *gy = a.py + (size_t)base * a.P;
+    int s = 0, k = tid;
+    while (k >= a.P) {
+      k -= a.P;
+      ++s;
+    }
+    for (int i = tid; i < total; i += kRollBlock) {
+      gx[i] = tx[s * P1 + k];
+      gy[i] = ty[s * P1 + k];
+      k += kRollBlock;
+      while (k >= a.P) {
+        k -= a.P;
+        ++s;
+      }
+    }
+  }
+}
+
+// ===========================================================================
+// K2: per (sample, point) squared distance to the tracked segment, minimised
+// over the segment (pathCostFunc inner loops, cost_evaluator.cpp:120-130).
+// min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt, so one
+// sqrt per point.  Segment coordinates are wave-uniform: they come in through
+// scalar loads and feed VALU ops as SGPR operands.
+// ===========================================================================
+constexpr int kPairBlock = 256;
+
+__global__ __launch_bounds__(kPairBlock) void path_min_kernel(
+    const float *__restrict__ px, const float *__restrict__ py,
+    const uint8_t *__restrict__ flags, int n, int P,
+    const float *__restrict__ sx, const float *__restrict__ sy,
+    const float *__restrict__ szz, int S, float *__restrict__ mind) {
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  if (t >= (long)n * P) return;
+  const int s = static_cast<int>(t / P);
+  if (!flags[s]) return;
+  const float x = px[t], y = py[t];
+  float best = FLT_MAX;
+#pragma unroll 8
+  for (int j = 0; j < S; ++j) {
+    const float dx = sx[j] - x;
+    const float dy = sy[j] - y;
+    const float xx = dx * dx;
+    const float yy = dy * dy;
+    const float d = xx + (yy + szz[j]);  // Eigen 3-term order a + (b + c)
+    best = d < best ? d : best;
+  }
+  mind[t] = __fsqrt_rn(best);
+}
+
+// ===========================================================================
+// K3: per (sample, point) squared distance to the obstacle points, minimised
+// over the obstacles (TrajectoryPath::minDist2D, trajectory.h:218-235):
+// float difference, squares and sum in double, rounded to float once.  The
+// rounding is monotonic, so the minimum is taken in double and rounded later.
+// ===========================================================================
+__global__ __launch_bounds__(kPairBlock) void obstacle_min_kernel(
+    const float *__restrict__ px, const float *__restrict__ py,
+    const uint8_t *__restrict__ flags, int n, int P,
+    const float *__restrict__ ox, const float *__restrict__ oy, int O,
+    double *__restrict__ omin) {
+  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
+  if (t >= (long)n * P) return;
+  const int s = static_cast<int>(t / P);
+  if (!flags[s]) return;
+  const float x = px[t], y = py[t];
+  double best = DBL_MAX;
+#pragma unroll 4
+  for (int j = 0; j < O; ++j) {
+    const double dx = static_cast<double>(ox[j] - x);
+    const double dy = static_cast<double>(oy[j] - y);
+    const double d = dx * dx + dy * dy;
+    best = d < best ? d : best;
+  }
+  omin[t] = best;
+}
+
+// ===========================================================================
+// K4: one lane per sample: goal cost, ordered path-cost sum, obstacle cost,
+// smoothness / jerk, the weighted total in the reference's accumulation order
+// (cost_evaluator.cpp:59-100: float total, each += a double multiply-add
+// rounded once), then the packed (cost, index) key reduced with wave shuffles
+// and one atomic per workgroup.
+// ===========================================================================
+struct FinalArgs {
+  int n, first, P, S, O;
+  int have_vel;
+  const float *px, *py;
+  const uint8_t *flags;
+  const float *sx, *sy, *sz, *acc_seg;
+  float seg_len, ref_len;
+  const float *mind;
+  const double *omin;
+  const float *vvx, *vvy, *vom;  // [n][P-1] when have_vel
+  float max_obs_dist;
+  float acc0, acc1, acc2;
+  double w_path, w_goal, w_obs, w_smooth, w_jerk;
+  float *costs;
+  long long *result;  // [0] key (atomicMin), [1] admissible count (atomicAdd)
+};
+
+constexpr int kFinalBlock = 256;
+
+__device__ __forceinline__ float dist_sq3(float ax, float ay, float az,
+                                          float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return xx + (yy + zz);
+}
+__device__ __forceinline__ float accum(float total, double w, float c) {
+  return static_cast<float>(static_cast<double>(total) +
+                            w * static_cast<double>(c));
+}
+__device__ __forceinline__ float sq_over(float total, float d, float lim) {
+  // smoothness_cost += std::pow(delta, 2) / accLimits_[i]  (double, then float)
+  const double dd = static_cast<double>(d);
+  return static_cast<float>(static_cast<double>(total) +
+                            (dd * dd) / static_cast<double>(lim));
+}
+
+__global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
+  const int n = blockIdx.x * kFinalBlock + threadIdx.x;
+  long long key = KEY_NONE;
+  int adm = 0;
+  if (n < a.n && a.flags[n]) {
+    adm = 1;
+    const float *px = a.px + (size_t)n * a.P;
+    const float *py = a.py + (size_t)n * a.P;
+    float total = 0.0f;
+    if (a.ref_len > 0.0f) {
+      if (a.w_goal > 0.0) {
+        // goalCostFunc, cost_evaluator.cpp:150-177
+        const float ex = px[a.P - 1], ey = py[a.P - 1];
+        float best = FLT_MAX;
+        int arg = 0;
+        for (int j = 0; j < a.S; ++j) {
+          const float d = dist_sq3(ex, ey, 0.0f, a.sx[j], a.sy[j], a.sz[j]);
+          if (d < best) {
+            best = d;
+            arg = j;
+          }
+        }
+        const float arc = __fdiv_rn(a.ref_len - a.acc_seg[arg], a.ref_len);
+        const float c = arc + __fdiv_rn(__fsqrt_rn(best), a.ref_len);
+        total = accum(total, a.w_goal, c);
+      }
+      if (a.w_path > 0.0) {
+        // pathCostFunc, cost_evaluator.cpp:111-141
+        const float *m = a.mind + (size_t)n * a.P;
+        float sum = 0.0f;
+        for (int i = 0; i < a.P; ++i) sum += m[i];
+        const int e = a.S - 1;
+        const float end_err = __fdiv_rn(
+            __fsqrt_rn(dist_sq3(px[a.P - 1], py[a.P - 1], 0.0f, a.sx[e],
+                                a.sy[e], a.sz[e])),
+            a.seg_len);
+        const float c = __fdiv_rn(
+            __fdiv_rn(sum, static_cast<float>(a.P)) + end_err, 2.0f);
+        total = accum(total, a.w_path, c);
+      }
+    }
+    if (a.O > 0 && a.w_obs > 0.0) {
+      // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
+      const double *m = a.omin + (size_t)n * a.P;
+      double best = DBL_MAX;
+      for (int i = 0; i < a.P; ++i) best = m[i] < best ? m[i] : best;
+      const float min_d2 = static_cast<float>(best);
+      const float dist =
+          static_cast<float>(__dsqrt_rn(static_cast<double>(min_d2)));
+      float v = a.max_obs_dist - dist;
+      v = v < 0.0f ? 0.0f : v;
+      total = accum(total, a.w_obs, __fdiv_rn(v, a.max_obs_dist));
+    }
+    if (a.have_vel) {
+      const int nv = a.P - 1;
+      const float *vx = a.vvx + (size_t)n * nv;
+      const float *vy = a.vvy + (size_t)n * nv;
+      const float *om = a.vom + (size_t)n * nv;
+      const float div = static_cast<float>(3L * nv);
+      if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
+        float c = 0.0f;
+        for (int i = 1; i < nv; ++i) {
+          if (a.acc0 > 0) c = sq_over(c, vx[i] - vx[i - 1], a.acc0);
+          if (a.acc1 > 0) c = sq_over(c, vy[i] - vy[i - 1], a.acc1);
+          if (a.acc2 > 0) c = sq_over(c, om[i] - om[i - 1], a.acc2);
+        }
+        total = accum(total, a.w_smooth, __fdiv_rn(c, div));
+      }
+      if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
+        float c = 0.0f;
+        for (int i = 2; i < nv; ++i) {
+          if (a.acc0 > 0)
+            c = sq_over(c, vx[i] - 2 * vx[i - 1] + vx[i - 2], a.acc0);
+          if (a.acc1 > 0)
+            c = sq_over(c, vy[i] - 2 * vy[i - 1] + vy[i - 2], a.acc1);
+          if (a.acc2 > 0)
+            c = sq_over(c, om[i] - 2 * om[i - 1] + om[i - 2], a.acc2);
+        }
+        total = accum(total, a.w_jerk, __fdiv_rn(c, div));
+      }
+    }
+    // constant-velocity samples: both terms are exactly 0 and `total += w*0`
+    // leaves total unchanged, so nothing to do when !have_vel.
+    a.costs[n] = total;
+    if (total < FLT_MAX)  // `total_cost < minCost`, minCost starts at FLT_MAX
+      key = key_pack(total, static_cast<uint32_t>(a.first + n));
+  } else if (n < a.n) {
+    a.costs[n] = FLT_MAX;
+  }
+
+  // wave64 min / sum via shuffles, then one LDS hop across the 4 waves
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long ok = __shfl_down(key, off, 64);
+    key = ok < key ? ok : key;
+    adm += __shfl_down(adm, off, 64);
+  }
+  __shared__ long long wkey[kFinalBlock / 64];
+  __shared__ int wadm[kFinalBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    wkey[wave] = key;
+    wadm[wave] = adm;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long k = wkey[0];
+    int c = wadm[0];
+    for (int w = 1; w < kFinalBlock / 64; ++w) {
+      k = wkey[w] < k ? wkey[w] : k;
+      c += wadm[w];
+    }
+    if (k != KEY_NONE) atomicMin(&a.result[0], k);
+    if (c) atomicAdd(reinterpret_cast<unsigned long long *>(&a.result[1]),
+                     static_cast<unsigned long long>(c));
+  }
+}
+
+// K5: admissible samples in front of a raw index -> the reference's compacted
+// index (push_back order, trajectory.h:351,440).  target < 0: read the winner
+// from result[0].  One workgroup.
+__global__ __launch_bounds__(1024) void count_before_kernel(
+    const uint8_t *__restrict__ flags, int n, int first, long long target_raw,
+    long long *result, int slot) {
+  long long raw = target_raw;
+  if (raw < 0) {
+    const long long key = result[0];
+    if (key == KEY_NONE) {
+      if (threadIdx.x == 0) result[slot] = -1;
+      return;
+    }
+    raw = static_cast<long long>(static_cast<uint32_t>(key & 0xFFFFFFFFll));
+  }
+  long long lim = raw - first;  // local bound
+  if (lim > n) lim = n;
+  int c = 0;
+  for (long long i = threadIdx.x; i < lim; i += 1024) c += flags[i];
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  __shared__ int wsum[16];
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < 16; ++w) s += wsum[w];
+    result[slot] = s;
+  }
+}
+
+__global__ void init_result_kernel(long long *result) {
+  result[0] = KEY_NONE;
+  result[1] = 0;
+  result[2] = -1;
+  result[3] = 0;
+}
+
+__global__ void fill_u8_kernel(uint8_t *p, int n, uint8_t v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace kc
+
+// ===========================================================================
+// host context
+// ===========================================================================
+using namespace kc;
+
+struct kc_dwa {
+  kc_dwa_params prm{};
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  kc_weights w{1, 1, 1, 1, 1};
+  Timing timing;
+
+  // collision checker state (host)
+  hm::Rigid3f sensor_tf_body;
+  hm::Rigid3f frame;          // sensor_tf_world_ captured at set_scan/points
+  double radius = 0, height = 0, res = 0.1;
+  std::vector<int32_t> vox_kx, vox_ky;  // z-accepted occupied columns
+  std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
+  bool have_sensor = false;
+
+  // samples
+  hm::VelocityLattice lat;    // host copy (vx, vy, row, omega values)
+  size_t shard_first = 0, shard_count = 0;
+  double vmax_lin = 0.0;      // max hypot(vx, vy) over the list
+  DevBuf<double> d_vx, d_vy;
+  DevBuf<int32_t> d_row;
+
+  // per cycle
+  size_t P = 0;               // points of the last roll-out
+  size_t n_roll = 0;          // samples of the last roll-out (shard size)
+  bool rolled = false, evaluated = false, external = false;
+  PinBuf<double2> h_trig;
+  DevBuf<double2> d_trig;
+  PinBuf<uint32_t> h_bits;
+  DevBuf<uint32_t> d_bits;
+  PinBuf<double> h_ddz;
+  DevBuf<double> d_ddz;
+  DevBuf<float> d_px, d_py, d_mind, d_costs;
+  DevBuf<double> d_omin;
+  DevBuf<uint8_t> d_flags;
+  DevBuf<float> d_vvx, d_vvy, d_vom;  // kc_cost_evaluate velocities
+  bool have_vel = false;
+
+  // tracked segment + obstacles
+  size_t S = 0, O = 0;
+  float seg_len = 0.f, ref_len = 0.f, max_obs_dist = 0.f;
+  PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
+  DevBuf<float> d_seg;
+  PinBuf<float> h_obs;  // ox | oy
+  DevBuf<float> d_obs;
+
+  DevBuf<long long> d_result;  // key, n_adm, compact index, scratch
+  PinBuf<long long> h_result;
+  PinBuf<float> h_row;         // winner row staging
+  kc_result last{};
+  bool have_last = false;
+};
+
+namespace {
+
+int use_device(const kc_dwa *c) {
+  KC_HIP(hipSetDevice(c->prm.device));
+  return KC_OK;
+}
+
+inline unsigned blocks_for(size_t n, unsigned per) {
+  return static_cast<unsigned>((n + per - 1) / per);
+}
+
+// accept one octree-frame point into the voxel column list
+void add_voxel(kc_dwa *c, float px, float py, float pz) {
+  const double inv = 1.0 / c->res;
+  const double fx = std::floor(inv * static_cast<double>(px));
+  const double fy = std::floor(inv * static_cast<double>(py));
+  const double fz = std::floor(inv * static_cast<double>(pz));
+  if (!(std::fabs(fx) < 32768.0 && std::fabs(fy) < 32768.0 &&
+        std::fabs(fz) < 32768.0))
+    return;  // outside the 16-level octree: octomap drops the point
+  const int32_t kz = static_cast<int32_t>(fz);
+  const double zlo = static_cast<double>(kz) * c->res;
+  const double zhi = static_cast<double>(kz + 1) * c->res;
+  const double zc = -static_cast<double>(c->frame.t[2]);
+  if (c->prm.shape == KC_SPHERE) {
+    double ddz = 0.0;
+    if (zlo - zc > ddz) ddz = zlo - zc;
+    if (zc - zhi > ddz) ddz = zc - zhi;
+    if (ddz > c->radius) return;
+    c->vox_ddz.push_back(ddz);
+  } else {
+    const double hz = c->height / 2.0;
+    if (!(zlo <= zc + hz && zhi >= zc - hz)) return;
+  }
+  c->vox_kx.push_back(static_cast<int32_t>(fx));
+  c->vox_ky.push_back(static_cast<int32_t>(fy));
+}
+
+int upload_obstacles(kc_dwa *c, size_t n) {
+  c->O = n;
+  if (n == 0) return KC_OK;
+  KC_TRY(c->d_obs.reserve(2 * n));
+  KC_HIP(hipMemcpyAsync(c->d_obs.p, c->h_obs.p, 2 * n * sizeof(float),
+                        hipMemcpyHostToDevice, c->stream));
+  return KC_OK;
+}
+
+int upload_samples(kc_dwa *c) {
+  const size_t n = c->lat.size();
+  if (n > c->prm.max_samples)
+    KC_FAIL(KC_ERR_RANGE, "sample count %zu exceeds max_samples %zu", n,
+            c->prm.max_samples);
+  c->vmax_lin = 0.0;
+  for (size_t i = 0; i < n; ++i)
+    c->vmax_lin = std::max(c->vmax_lin, std::hypot(c->lat.vx[i], c->lat.vy[i]));
+  c->shard_first = 0;
+  c->shard_count = n;
+  if (n == 0) return KC_OK;
+  KC_TRY(c->d_vx.reserve(n));
+  KC_TRY(c->d_vy.reserve(n));
+  KC_TRY(c->d_row.reserve(n));
+  // pageable sources: hipMemcpy (synchronous) keeps the host vectors reusable
+  KC_HIP(hipMemcpyAsync(c->d_vx.p, c->lat.vx.data(), n * sizeof(double),
+                        hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipMemcpyAsync(c->d_vy.p, c->lat.vy.data(), n * sizeof(double),
+                        hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipMemcpyAsync(c->d_row.p, c->lat.row.data(), n * sizeof(int32_t),
+                        hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}
+
+// occupancy bits of every voxel the robot can reach this cycle
+int build_window(kc_dwa *c, const kc_state &start, CollDev &cd) {
+  std::memset(&cd, 0, sizeof(cd));
+  cd.shape = c->prm.shape;
+  const hm::Rigid3f &F = c->frame;
+  cd.r00 = F.R[0][0];
+  cd.r01 = F.R[0][1];
+  cd.r10 = F.R[1][0];
+  cd.r11 = F.R[1][1];
+  cd.tx = F.t[0];
+  cd.ty = F.t[1];
+  cd.res = c->res;
+  cd.inv = 1.0 / c->res;
+  cd.radius = c->radius;
+  cd.rr = c->radius * c->radius;
+  cd.a = static_cast<double>(c->prm.dims[0]) / 2.0;
+  cd.b = static_cast<double>(c->prm.dims[1]) / 2.0;
+  if (!c->have_sensor || c->vox_kx.empty()) return KC_OK;  // enabled = 0
+
+  // every pose of every sample stays within `reach` of the start
+  const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
+  const double reach = c->vmax_lin * dt * static_cast<double>(c->P) * 1.0001;
+  const double bound = (c->prm.shape == KC_BOX)
+                           ? std::sqrt(cd.a * cd.a + cd.b * cd.b)
+                           : c->radius;
+  const double dx = start.x - cd.tx, dy = start.y - cd.ty;
+  const double xf = cd.r00 * dx + cd.r10 * dy;
+  const double yf = cd.r01 * dx + cd.r11 * dy;
+  const long half = static_cast<long>(std::ceil((reach + bound) * cd.inv)) + 3;
+  if (half > 8190)
+    KC_FAIL(KC_ERR_RANGE,
+            "reachable collision window of %ld cells per side is too large "
+            "(octree resolution %g m, reach %g m)",
+            2 * half + 1, c->res, reach + bound);
+  cd.kx0 = static_cast<int>(std::floor(xf * cd.inv)) - static_cast<int>(half);
+  cd.ky0 = static_cast<int>(std::floor(yf * cd.inv)) - static_cast<int>(half);
+  cd.W = cd.H = static_cast<int>(2 * half + 1);
+  cd.wpr = (cd.W + 31) / 32;
+  const size_t nwords = static_cast<size_t>(cd.H) * cd.wpr;
+  KC_TRY(c->h_bits.reserve(nwords));
+  std::memset(c->h_bits.p, 0, nwords * sizeof(uint32_t));
+  const bool sphere = c->prm.shape == KC_SPHERE;
+  if (sphere) {
+    KC_TRY(c->h_ddz.reserve(static_cast<size_t>(cd.W) * cd.H));
+    std::fill(c->h_ddz.p, c->h_ddz.p + static_cast<size_t>(cd.W) * cd.H,
+              DBL_MAX);
+  }
+  size_t hits = 0;
+  for (size_t i = 0; i < c->vox_kx.size(); ++i) {
+    const long cx = static_cast<long>(c->vox_kx[i]) - cd.kx0;
+    const long cy = static_cast<long>(c->vox_ky[i]) - cd.ky0;
+    if (cx < 0 || cy < 0 || cx >= cd.W || cy >= cd.H) continue;
+    c->h_bits.p[cy * cd.wpr + (cx >> 5)] |= 1u << (cx & 31);
+    if (sphere) {
+      double &g = c->h_ddz.p[cy * cd.W + cx];
+      g = std::min(g, c->vox_ddz[i]);
+    }
+    ++hits;
+  }
+  if (hits == 0) return KC_OK;
+  cd.enabled = 1;
+  KC_TRY(c->d_bits.reserve(nwords));
+  KC_HIP(hipMemcpyAsync(c->d_bits.p, c->h_bits.p, nwords * sizeof(uint32_t),
+                        hipMemcpyHostToDevice, c->stream));
+  cd.bits = c->d_bits.p;
+  if (sphere) {
+    const size_t nc = static_cast<size_t>(cd.W) * cd.H;
+    KC_TRY(c->d_ddz.reserve(nc));
+    KC_HIP(hipMemcpyAsync(c->d_ddz.p, c->h_ddz.p, nc * sizeof(double),
+                          hipMemcpyHostToDevice, c->stream));
+    cd.ddz = c->d_ddz.p;
+  }
+  cd.lds = (nwords * 4 <= 48 * 1024) ? 1 : 0;
+  return KC_OK;
+}
+
+int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
+  KC_TRY(c->d_px.reserve(n * P));
+  KC_TRY(c->d_py.reserve(n * P));
+  KC_TRY(c->d_flags.reserve(n));
+  KC_TRY(c->d_costs.reserve(n));
+  return KC_OK;
+}
+
+int run_evaluate(kc_dwa *c, size_t n, size_t first) {
+  const size_t P = c->P;
+  hipStream_t s = c->stream;
+  hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, s,
+                     c->d_result.p);
+  if (n == 0) return KC_OK;
+  const bool use_path = c->ref_len > 0.0f &&
+                        c->w.reference_path_distance_weight > 0.0;
+  const bool use_goal = c->ref_len > 0.0f && c->w.goal_distance_weight > 0.0;
+  if ((use_path || use_goal) && c->S == 0)
+    KC_FAIL(KC_ERR_STATE, "tracked segment not set");
+  const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
+  const float *seg = c->d_seg.p;
+  const size_t S = c->S;
+  if (use_path) {
+    KC_TRY(c->d_mind.reserve(n * P));
+    KC_TRY(c->timing.start("path_min_kernel", s));
+    hipLaunchKernelGGL(path_min_kernel, dim3(blocks_for(n * P, kPairBlock)),
+                       dim3(kPairBlock), 0, s, c->d_px.p, c->d_py.p,
+                       c->d_flags.p, static_cast<int>(n), static_cast<int>(P),
+                       seg, seg + S, seg + 3 * S, static_cast<int>(S),
+                       c->d_mind.p);
+    KC_TRY(c->timing.stop(s));
+  }
+  if (use_obs) {
+    KC_TRY(c->d_omin.reserve(n * P));
+    KC_TRY(c->timing.start("obstacle_min_kernel", s));
+    hipLaunchKernelGGL(obstacle_min_kernel,
+                       dim3(blocks_for(n * P, kPairBlock)), dim3(kPairBlock),
+                       0, s, c->d_px.p, c->d_py.p, c->d_flags.p,
+                       static_cast<int>(n), static_cast<int>(P), c->d_obs.p,
+                       c->d_obs.p + c->O, static_cast<int>(c->O),
+                       c->d_omin.p);
+    KC_TRY(c->timing.stop(s));
+  }
+  FinalArgs fa{};
+  fa.n = static_cast<int>(n);
+  fa.first = static_cast<int>(first);
+  fa.P = static_cast<int>(P);
+  fa.S = static_cast<int>(S);
+  fa.O = static_cast<int>(c->O);
+  fa.have_vel = c->have_vel ? 1 : 0;
+  fa.px = c->d_px.p;
+  fa.py = c->d_py.p;
+  fa.flags = c->d_flags.p;
+  fa.sx = seg;
+  fa.sy = seg + S;
+  fa.sz = seg + 2 * S;
+  fa.acc_seg = seg + 4 * S;
+  fa.seg_len = c->seg_len;
+  fa.ref_len = c->ref_len;
+  fa.mind = c->d_mind.p;
+  fa.omin = c->d_omin.p;
+  fa.vvx = c->d_vvx.p;
+  fa.vvy = c->d_vvy.p;
+  fa.vom = c->d_vom.p;
+  fa.max_obs_dist = c->max_obs_dist;
+  fa.acc0 = c->prm.acc_limits[0];
+  fa.acc1 = c->prm.acc_limits[1];
+  fa.acc2 = c->prm.acc_limits[2];
+  fa.w_path = c->w.reference_path_distance_weight;
+  fa.w_goal = c->w.goal_distance_weight;
+  fa.w_obs = c->w.obstacles_distance_weight;
+  fa.w_smooth = c->w.smoothness_weight;
+  fa.w_jerk = c->w.jerk_weight;
+  fa.costs = c->d_costs.p;
+  fa.result = c->d_result.p;
+  KC_TRY(c->timing.start("finalize_kernel", s));
+  hipLaunchKernelGGL(finalize_kernel, dim3(blocks_for(n, kFinalBlock)),
+                     dim3(kFinalBlock), 0, s, fa);
+  KC_TRY(c->timing.stop(s));
+  KC_TRY(c->timing.start("count_before_kernel", s));
+  hipLaunchKernelGGL(count_before_kernel, dim3(1), dim3(1024), 0, s,
+                     c->d_flags.p, static_cast<int>(n),
+                     static_cast<int>(first), -1ll, c->d_result.p, 2);
+  KC_TRY(c->timing.stop(s));
+  KC_HIP(hipGetLastError());
+  return KC_OK;
+}
+
+int fetch(kc_dwa *c, kc_result *out, size_t n) {
+  KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
+                        hipMemcpyDeviceToHost, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  kc_result r{};
+  const long long key = c->h_result.p[0];
+  r.n_admissible = c->h_result.p[1];
+  r.n_samples = static_cast<int64_t>(n);
+  if (key == KEY_NONE) {
+    r.found = 0;
+    r.cost = 0.0f;
+    r.index = -1;
+    r.raw_index = -1;
+  } else {
+    r.found = 1;
+    r.cost = kc_key_cost(key);
+    r.raw_index = kc_key_index(key);
+    r.index = c->h_result.p[2];
+  }
+  c->last = r;
+  c->have_last = true;
+  if (out) *out = r;
+  return KC_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
+  if (!p || !out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (p->shape != KC_CYLINDER && p->shape != KC_BOX && p->shape != KC_SPHERE)
+    KC_FAIL(KC_ERR_INVALID, "Invalid robot geometry type");
+  if (!(p->octree_res > 0.0) || !(p->time_step > 0.0))
+    KC_FAIL(KC_ERR_INVALID, "octree_res and time_step must be positive");
+  if (p->max_samples == 0 || p->max_points < 2)
+    KC_FAIL(KC_ERR_INVALID, "max_samples >= 1 and max_points >= 2 required");
+  if (p->max_samples > 0x7FFFFFFFu / std::max<size_t>(p->max_points, 1))
+    KC_FAIL(KC_ERR_RANGE, "max_samples * max_points exceeds 2^31");
+  int ndev = 0;
+  KC_HIP(hipGetDeviceCount(&ndev));
+  if (p->device < 0 || p->device >= ndev)
+    KC_FAIL(KC_ERR_HIP, "HIP device %d not available (%d visible)", p->device,
+            ndev);
+  auto *c = new kc_dwa();
+  c->prm = *p;
+  for (int i = p->ndims; i < 3; ++i) c->prm.dims[i] = 0.0f;
+  // collision_check.cpp:38-58
+  if (p->shape == KC_CYLINDER) {
+    c->radius = c->prm.dims[0];
+    c->height = c->prm.dims[1];
+  } else if (p->shape == KC_BOX) {
+    c->height = c->prm.dims[2];
+    c->radius = std::sqrt(std::pow(c->prm.dims[0], 2) +
+                          std::pow(c->prm.dims[1], 2)) /
+                2;
+  } else {
+    c->radius = c->prm.dims[0];
+    c->height = 2 * c->prm.dims[0];
+  }
+  c->res = p->octree_res;
+  hm::Quat q{p->sensor_rot_xyzw[3], p->sensor_rot_xyzw[0],
+             p->sensor_rot_xyzw[1], p->sensor_rot_xyzw[2]};
+  c->sensor_tf_body = hm::Rigid3f::from_quat(q, p->sensor_pos);
+  c->frame = c->sensor_tf_body;
+  auto fail = [&](int rc) {
+    kc_dwa_destroy(c);
+    return rc;
+  };
+  if (hipSetDevice(p->device) != hipSuccess) {
+    set_error("hipSetDevice(%d) failed", p->device);
+    return fail(KC_ERR_HIP);
+  }
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) !=
+      hipSuccess) {
+    set_error("hipStreamCreate failed");
+    return fail(KC_ERR_HIP);
+  }
+  c->stream = c->own_stream;
+  int rc;
+  if ((rc = c->d_result.reserve(4)) || (rc = c->h_result.reserve(4)) ||
+      (rc = ensure_cycle_buffers(c, p->max_samples, p->max_points)) ||
+      (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
+      (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
+      (rc = c->d_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
+      (rc = c->h_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
+    return fail(rc);
+  *out = c;
+  return KC_OK;
+}
+
+void kc_dwa_destroy(kc_dwa *c) {
+  if (!c) return;
+  hipError_t e = hipSetDevice(c->prm.device);
+  if (c->own_stream) {
+    e = hipStreamSynchronize(c->own_stream);
+    e = hipStreamDestroy(c->own_stream);
+  }
+  (void)e;
+  c->timing.release();
+  c->d_vx.release();
+  c->d_vy.release();
+  c->d_row.release();
+  c->h_trig.release();
+  c->d_trig.release();
+  c->h_bits.release();
+  c->d_bits.release();
+  c->h_ddz.release();
+  c->d_ddz.release();
+  c->d_px.release();
+  c->d_py.release();
+  c->d_mind.release();
+  c->d_costs.release();
+  c->d_omin.release();
+  c->d_flags.release();
+  c->d_vvx.release();
+  c->d_vvy.release();
+  c->d_vom.release();
+  c->h_seg.release();
+  c->d_seg.release();
+  c->h_obs.release();
+  c->d_obs.release();
+  c->d_result.release();
+  c->h_result.release();
+  c->h_row.release();
+  delete c;
+}
+
+int kc_dwa_set_stream(kc_dwa *c, void *hip_stream) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  KC_TRY(use_device(c));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return KC_OK;
+}
+
+int kc_dwa_set_resolution(kc_dwa *c, double res) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!(res > 0.0)) KC_FAIL(KC_ERR_RANGE, "octree resolution must be > 0");
+  c->res = res;
+  return KC_OK;
+}
+
+int kc_dwa_set_weights(kc_dwa *c, const kc_weights *w) {
+  if (!c || !w) KC_FAIL(KC_ERR_INVALID, "null argument");
+  c->w = *w;
+  return KC_OK;
+}
+
+int kc_dwa_sample_window(kc_dwa *c, int ctr_type, const kc_limits *limits,
+                         double cvx, double cvy, double com, int max_lin,
+                         int max_ang, size_t *n_out, double *vx, double *vy,
+                         double *omega, size_t cap) {
+  if (!c || !limits) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (ctr_type < KC_ACKERMANN || ctr_type > KC_OMNI)
+    KC_FAIL(KC_ERR_INVALID, "Invalid control type");
+  if (max_lin < 1 || max_ang < 1)
+    KC_FAIL(KC_ERR_RANGE, "sample counts must be >= 1");
+  KC_TRY(use_device(c));
+  hm::build_window_lattice(ctr_type, *limits, cvx, cvy, com, c->prm.time_step,
+                           max_lin, max_ang, c->lat);
+  KC_TRY(upload_samples(c));
+  const size_t n = c->lat.size();
+  if (n_out) *n_out = n;
+  if (vx || vy || omega) {
+    if (cap < n) KC_FAIL(KC_ERR_RANGE, "output capacity %zu < %zu", cap, n);
+    for (size_t i = 0; i < n; ++i) {
+      if (vx) vx[i] = c->lat.vx[i];
+      if (vy) vy[i] = c->lat.vy[i];
+      if (omega) omega[i] = c->lat.omega_values[c->lat.row[i]];
+    }
+  }
+  return KC_OK;
+}
+
+int kc_dwa_set_samples(kc_dwa *c, size_t n, const double *vx, const double *vy,
+                       const double *omega) {
+  if (!c || (n && (!vx || !vy || !omega)))
+    KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_TRY(use_device(c));
+  c->lat.clear();
+  std::unordered_map<uint64_t, int32_t> rows;
+  rows.reserve(1024);
+  for (size_t i = 0; i < n; ++i) {
+    const double o = omega[i] + 0.0;  // -0.0 and +0.0 share a row
+    uint64_t bits;
+    std::memcpy(&bits, &o, 8);
+    auto it = rows.find(bits);
+    int32_t r;
+    if (it == rows.end()) {
+      r = static_cast<int32_t>(c->lat.omega_values.size());
+      c->lat.omega_values.push_back(omega[i]);
+      rows.emplace(bits, r);
+    } else {
+      r = it->second;
+    }
+    c->lat.push(vx[i], vy[i], r);
+  }
+  return upload_samples(c);
+}
+
+int kc_dwa_set_shard(kc_dwa *c, size_t first, size_t count) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (first + count > c->lat.size())
+    KC_FAIL(KC_ERR_RANGE, "shard [%zu, %zu) outside the %zu samples", first,
+            first + count, c->lat.size());
+  c->shard_first = first;
+  c->shard_count = count;
+  return KC_OK;
+}
+
+int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
+                    const double *angles, size_t n, float max_range) {
+  if (!c || !st || (n && (!ranges || !angles)))
+    KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_TRY(use_device(c));
+  KC_HIP(hipStreamSynchronize(c->stream));  // staging buffers are reused
+  // CollisionChecker::updateState + updateSensorData<LaserScan>
+  const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
+  c->frame = body * c->sensor_tf_body;
+  if (!c->frame.planar())
+    KC_FAIL(KC_ERR_UNSUPPORTED,
+            "sensor rotation must be about the z axis (planar octree frame)");
+  c->vox_kx.clear();
+  c->vox_ky.clear();
+  c->vox_ddz.clear();
+  const float hz = static_cast<float>(
+      -static_cast<double>(c->sensor_tf_body.t[2]) / 2.0);
+  // CostEvaluator::setPointScan(LaserScan): sensor_tf_body * body_tf_world
+  const hm::Rigid3f T = c->sensor_tf_body * body;
+  KC_TRY(c->h_obs.reserve(2 * std::max<size_t>(n, 1)));
+  for (size_t i = 0; i < n; ++i) {
+    const double r = ranges[i], a = angles[i];
+    const double ca = std::cos(a), sa = std::sin(a);
+    const double px = r * ca, py = r * sa;
+    if (std::isfinite(r))  // collision_check.h:110-115 (cost path: no filter)
+      add_voxel(c, static_cast<float>(px), static_cast<float>(py), hz);
+    float o[3];
+    T.apply(static_cast<float>(px), static_cast<float>(py), 0.0f, o);
+    c->h_obs.p[i] = o[0];
+    c->h_obs.p[n + i] = o[1];
+  }
+  c->have_sensor = true;
+  c->max_obs_dist = max_range / 3.0f;  // cost_evaluator.h:179
+  return upload_obstacles(c, n);
+}
+
+int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
+                      float max_range) {
+  if (!c || !st || (n && !xyz)) KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_TRY(use_device(c));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  // updateSensorData<std::vector<Path::Point>>(cloud, global_frame = true)
+  c->frame = hm::Rigid3f::identity();
+  c->vox_kx.clear();
+  c->vox_ky.clear();
+  c->vox_ddz.clear();
+  const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
+  const hm::Rigid3f T = c->sensor_tf_body * body;
+  KC_TRY(c->h_obs.reserve(2 * std::max<size_t>(n, 1)));
+  for (size_t i = 0; i < n; ++i) {
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    add_voxel(c, x, y, z);
+    float o[3];
+    T.apply(x, y, z, o);
+    c->h_obs.p[i] = o[0];
+    c->h_obs.p[n + i] = o[1];
+  }
+  c->have_sensor = true;
+  c->max_obs_dist = max_range / 3.0f;
+  return upload_obstacles(c, n);
+}
+
+int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
+                               const float *z, const float *acc, size_t S,
+                               float ref_len) {
+  if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_TRY(use_device(c));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  c->S = S;
+  c->ref_len = ref_len;
+  if (S == 0) return KC_OK;
+  KC_TRY(c->h_seg.reserve(5 * S));
+  KC_TRY(c->d_seg.reserve(5 * S));
+  float *h = c->h_seg.p;
+  for (size_t j = 0; j < S; ++j) {
+    const float zz = z ? z[j] : 0.0f;
+    h[j] = x[j];
+    h[S + j] = y[j];
+    h[2 * S + j] = zz;
+    h[3 * S + j] = zz * zz;  // (seg.z - 0)^2 of Path::distance
+    h[4 * S + j] = acc[j];
+  }
+  // View::totalSegmentLength, path.h:85-91
+  float len = 0.0f;
+  for (size_t j = 0; j + 1 < S; ++j) {
+    const float dx = h[j] - h[j + 1], dy = h[S + j] - h[S + j + 1],
+                dz = h[2 * S + j] - h[2 * S + j + 1];
+    len += std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
+  }
+  c->seg_len = len;
+  KC_HIP(hipMemcpyAsync(c->d_seg.p, h, 5 * S * sizeof(float),
+                        hipMemcpyHostToDevice, c->stream));
+  return KC_OK;
+}
+
+int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
+  if (!c || !start) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (P < 2 || P > c->prm.max_points)
+    KC_FAIL(KC_ERR_RANGE, "num_points %zu outside [2, %zu]", P,
+            c->prm.max_points);
+  KC_TRY(use_device(c));
+  hipStream_t s = c->stream;
+  KC_HIP(hipStreamSynchronize(s));  // pinned staging of the last cycle is free
+  c->timing.begin_cycle();
+  c->P = P;
+  c->rolled = false;
+  c->evaluated = false;
+  c->external = false;
+  c->have_vel = false;
+  const size_t n = c->shard_count;
+  c->n_roll = n;
+  if (n == 0) {
+    c->rolled = true;
+    return KC_OK;
+  }
+  // trig table: cos/sin of yaw_k for every omega row, from the host libm the
+  // reference calls (path.h:24-30); yaw_k by repeated addition of omega * dt
+  const size_t A = c->lat.omega_values.size();
+  KC_TRY(c->h_trig.reserve(A * P));
+  KC_TRY(c->d_trig.reserve(A * P));
+  const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
+  for (size_t r = 0; r < A; ++r) {
+    double yaw = start->yaw;
+    const double om = c->lat.omega_values[r];
+    for (size_t k = 0; k < P; ++k) {
+      c->h_trig.p[k * A + r] = make_double2(std::cos(yaw), std::sin(yaw));
+      yaw += om * dt;
+    }
+  }
+  KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
+                        hipMemcpyHostToDevice, s));
+  RollArgs a{};
+  KC_TRY(build_window(c, *start, a.c));
+  KC_TRY(ensure_cycle_buffers(c, n, P));
+  a.n = static_cast<int>(n);
+  a.first = static_cast<int>(c->shard_first);
+  a.P = static_cast<int>(P);
+  a.A = static_cast<int>(A);
+  a.x0 = start->x;
+  a.y0 = start->y;
+  a.dt = dt;
+  a.vx = c->d_vx.p;
+  a.vy = c->d_vy.p;
+  a.row = c->d_row.p;
+  a.trig = c->d_trig.p;
+  a.px = c->d_px.p;
+  a.py = c->d_py.p;
+  a.flags = c->d_flags.p;
+  const size_t bits_bytes =
+      (a.c.lds && a.c.enabled)
+          ? ((static_cast<size_t>(a.c.H) * a.c.wpr * 4 + 15) & ~size_t(15))
+          : 0;
+  if (!(a.c.lds && a.c.enabled)) a.c.lds = 0;
+  const size_t tile_bytes = 2 * static_cast<size_t>(kRollBlock) * (P | 1) * 4;
+  a.stage = (bits_bytes + tile_bytes <= 64 * 1024) ? 1 : 0;
+  const size_t smem = bits_bytes + (a.stage ? tile_bytes : 0);
+  KC_TRY(c->timing.start("rollout_kernel", s));
+  hipLaunchKernelGGL(rollout_kernel, dim3(blocks_for(n, kRollBlock)),
+                     dim3(kRollBlock), smem, s, a);
+  KC_TRY(c->timing.stop(s));
+  KC_HIP(hipGetLastError());
+  c->rolled = true;
+  return KC_OK;
+}
+
+int kc_dwa_evaluate(kc_dwa *c) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
+  KC_TRY(use_device(c));
+  KC_TRY(run_evaluate(c, c->n_roll, c->shard_first));
+  c->evaluated = true;
+  return KC_OK;
+}
+
+int kc_dwa_fetch_result(kc_dwa *c, kc_result *out) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!c->evaluated) KC_FAIL(KC_ERR_STATE, "kc_dwa_evaluate has not run");
+  KC_TRY(use_device(c));
+  return fetch(c, out, c->n_roll);
+}
+
+int kc_dwa_cycle(kc_dwa *c, const kc_state *start, size_t P, kc_result *out) {
+  KC_TRY(kc_dwa_rollout(c, start, P));
+  KC_TRY(kc_dwa_evaluate(c));
+  return kc_dwa_fetch_result(c, out);
+}
+
+int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
+                    float *vvy, float *vom) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!c->have_last || !c->last.found)
+    KC_FAIL(KC_ERR_STATE, "no trajectory found in the last cycle");
+  KC_TRY(use_device(c));
+  const size_t P = c->P;
+  const size_t local = static_cast<size_t>(c->last.raw_index) -
+                       (c->external ? 0 : c->shard_first);
+  if (local >= c->n_roll)
+    KC_FAIL(KC_ERR_STATE, "winner %lld is not on this shard",
+            static_cast<long long>(c->last.raw_index));
+  KC_TRY(c->h_row.reserve(2 * P));
+  KC_HIP(hipMemcpyAsync(c->h_row.p, c->d_px.p + local * P, P * sizeof(float),
+                        hipMemcpyDeviceToHost, c->stream));
+  KC_HIP(hipMemcpyAsync(c->h_row.p + P, c->d_py.p + local * P,
+                        P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  if (path_x) std::memcpy(path_x, c->h_row.p, P * sizeof(float));
+  if (path_y) std::memcpy(path_y, c->h_row.p + P, P * sizeof(float));
+  if (vvx || vvy || vom) {
+    if (c->external)
+      KC_FAIL(KC_ERR_STATE, "velocities belong to the caller in evaluate mode");
+    const size_t g = static_cast<size_t>(c->last.raw_index);
+    // TrajectoryVelocities2D::add: float = double (trajectory.h:96-103)
+    const float fx = static_cast<float>(c->lat.vx[g]);
+    const float fy = static_cast<float>(c->lat.vy[g]);
+    const float fo = static_cast<float>(c->lat.omega_values[c->lat.row[g]]);
+    for (size_t i = 0; i + 1 < P; ++i) {
+      if (vvx) vvx[i] = fx;
+      if (vvy) vvy[i] = fy;
+      if (vom) vom[i] = fo;
+    }
+  }
+  return KC_OK;
+}
+
+int kc_dwa_get_samples(kc_dwa *c, float *paths_x, float *paths_y,
+                       int32_t *raw_index, float *costs, size_t cap_rows,
+                       size_t *n_rows_out) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
+  KC_TRY(use_device(c));
+  const size_t n = c->n_roll, P = c->P;
+  std::vector<uint8_t> flags(n);
+  std::vector<float> hx, hy, hc;
+  KC_HIP(hipStreamSynchronize(c->stream));
+  if (n) {
+    KC_HIP(hipMemcpy(flags.data(), c->d_flags.p, n, hipMemcpyDeviceToHost));
+    if (paths_x) {
+      hx.resize(n * P);
+      KC_HIP(hipMemcpy(hx.data(), c->d_px.p, n * P * 4, hipMemcpyDeviceToHost));
+    }
+    if (paths_y) {
+      hy.resize(n * P);
+      KC_HIP(hipMemcpy(hy.data(), c->d_py.p, n * P * 4, hipMemcpyDeviceToHost));
+    }
+    if (costs) {
+      if (!c->evaluated) KC_FAIL(KC_ERR_STATE, "costs need kc_dwa_evaluate");
+      hc.resize(n);
+      KC_HIP(hipMemcpy(hc.data(), c->d_costs.p, n * 4, hipMemcpyDeviceToHost));
+    }
+  }
+  size_t row = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (!flags[i]) continue;
+    if (row < cap_rows) {
+      if (paths_x) std::memcpy(paths_x + row * P, hx.data() + i * P, P * 4);
+      if (paths_y) std::memcpy(paths_y + row * P, hy.data() + i * P, P * 4);
+      if (raw_index)
+        raw_index[row] = static_cast<int32_t>(
+            i + (c->external ? 0 : c->shard_first));
+      if (costs) costs[row] = hc[i];
+    }
+    ++row;
+  }
+  if (n_rows_out) *n_rows_out = row;
+  return KC_OK;
+}
+
+int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
+                     const float *vvx, const float *vvy, const float *vom,
+                     size_t n, size_t P, float *costs_out, kc_result *out) {
+  if (!c || (n && (!paths_x || !paths_y)))
+    KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (P < 2) KC_FAIL(KC_ERR_RANGE, "num_points must be >= 2");
+  if (n * P > 0x7FFFFFFFul) KC_FAIL(KC_ERR_RANGE, "n * num_points >= 2^31");
+  const bool vel = vvx && vvy && vom;
+  KC_TRY(use_device(c));
+  hipStream_t s = c->stream;
+  KC_HIP(hipStreamSynchronize(s));
+  c->timing.begin_cycle();
+  c->P = P;
+  c->n_roll = n;
+  c->external = true;
+  c->have_vel = vel;
+  c->rolled = true;
+  c->evaluated = false;
+  KC_TRY(ensure_cycle_buffers(c, std::max<size_t>(n, 1), P));
+  if (n) {
+    KC_HIP(hipMemcpyAsync(c->d_px.p, paths_x, n * P * 4, hipMemcpyHostToDevice, s));
+    KC_HIP(hipMemcpyAsync(c->d_py.p, paths_y, n * P * 4, hipMemcpyHostToDevice, s));
+    if (vel) {
+      const size_t nv = n * (P - 1);
+      KC_TRY(c->d_vvx.reserve(nv));
+      KC_TRY(c->d_vvy.reserve(nv));
+      KC_TRY(c->d_vom.reserve(nv));
+      KC_HIP(hipMemcpyAsync(c->d_vvx.p, vvx, nv * 4, hipMemcpyHostToDevice, s));
+      KC_HIP(hipMemcpyAsync(c->d_vvy.p, vvy, nv * 4, hipMemcpyHostToDevice, s));
+      KC_HIP(hipMemcpyAsync(c->d_vom.p, vom, nv * 4, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(fill_u8_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                       s, c->d_flags.p, static_cast<int>(n), uint8_t(1));
+  }
+  KC_TRY(run_evaluate(c, n, 0));
+  c->evaluated = true;
+  KC_TRY(fetch(c, out, n));
+  if (costs_out && n)
+    KC_HIP(hipMemcpy(costs_out, c->d_costs.p, n * 4, hipMemcpyDeviceToHost));
+  return KC_OK;
+}
+
+int kc_dwa_result_device(kc_dwa *c, void **dev) {
+  if (!c || !dev) KC_FAIL(KC_ERR_INVALID, "null argument");
+  *dev = c->d_result.p;
+  return KC_OK;
+}
+
+int kc_dwa_count_admissible_before(kc_dwa *c, int64_t raw, int64_t *count) {
+  if (!c || !count) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
+  KC_TRY(use_device(c));
+  if (c->n_roll == 0 || raw < 0) {
+    *count = 0;
+    return KC_OK;
+  }
+  hipLaunchKernelGGL(count_before_kernel, dim3(1), dim3(1024), 0, c->stream,
+                     c->d_flags.p, static_cast<int>(c->n_roll),
+                     static_cast<int>(c->external ? 0 : c->shard_first),
+                     static_cast<long long>(raw), c->d_result.p, 3);
+  KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
+                        hipMemcpyDeviceToHost, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  *count = c->h_result.p[3];
+  return KC_OK;
+}
+
+int kc_dwa_timing_enable(kc_dwa *c, int enable) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  c->timing.enabled = enable != 0;
+  return KC_OK;
+}
+
+int kc_dwa_timing_get(kc_dwa *c, const char **names, float *ms, size_t cap,
+                      size_t *count) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  KC_TRY(use_device(c));
+  return c->timing.get(names, ms, cap, count);
+}
+
+}  // extern "C"

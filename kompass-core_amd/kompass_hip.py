@@ -1,0 +1,393 @@
+"""ctypes binding of libkompass_hip.so (C ABI: include/kompass_hip.h).
+
+Thin, typed access to the HIP hot path for Python callers (tests, bench.py and
+the kompass_core-style wrappers).  There is no CPU fallback: loading fails
+loudly when the library has not been built, and every compute call raises
+`KompassHipError` when no HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libkompass_hip.so"
+
+ACKERMANN, DIFFERENTIAL_DRIVE, OMNI = 0, 1, 2
+CYLINDER, BOX, SPHERE = 0, 1, 2
+UNEXPLORED, EMPTY, OCCUPIED = -1, 0, 100
+
+KC_OK = 0
+_ERR_TO_EXC = {-1: ValueError, -2: IndexError, -3: RuntimeError, -4: NotImplementedError, -5: RuntimeError}
+
+
+class KompassHipError(RuntimeError):
+    pass
+
+
+class State(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("yaw", C.c_double), ("speed", C.c_double)]
+
+
+class Limits(C.Structure):
+    _fields_ = [
+        ("vx_max", C.c_double), ("vx_acc", C.c_double), ("vx_dec", C.c_double),
+        ("vy_max", C.c_double), ("vy_acc", C.c_double), ("vy_dec", C.c_double),
+        ("omega_max_angle", C.c_double), ("omega_max", C.c_double),
+        ("omega_acc", C.c_double), ("omega_dec", C.c_double),
+    ]
+
+
+class Weights(C.Structure):
+    _fields_ = [
+        ("reference_path_distance_weight", C.c_double),
+        ("goal_distance_weight", C.c_double),
+        ("obstacles_distance_weight", C.c_double),
+        ("smoothness_weight", C.c_double),
+        ("jerk_weight", C.c_double),
+    ]
+
+
+class DwaParams(C.Structure):
+    _fields_ = [
+        ("shape", C.c_int), ("dims", C.c_float * 3), ("ndims", C.c_int),
+        ("sensor_pos", C.c_float * 3), ("sensor_rot_xyzw", C.c_float * 4),
+        ("octree_res", C.c_double), ("time_step", C.c_double),
+        ("max_samples", C.c_size_t), ("max_points", C.c_size_t),
+        ("max_segment", C.c_size_t), ("max_obstacles", C.c_size_t),
+        ("acc_limits", C.c_float * 3), ("device", C.c_int),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("found", C.c_int), ("cost", C.c_float), ("index", C.c_int64),
+        ("raw_index", C.c_int64), ("n_admissible", C.c_int64), ("n_samples", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+_sz = C.c_size_t
+
+# every symbol include/kompass_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "kc_last_error": (C.c_char_p, []),
+    "kc_abi_version": (C.c_int, []),
+    "kc_device_count": (C.c_int, []),
+    "kc_dwa_create": (C.c_int, [C.POINTER(DwaParams), C.POINTER(_vp)]),
+    "kc_dwa_destroy": (None, [_vp]),
+    "kc_dwa_set_stream": (C.c_int, [_vp, _vp]),
+    "kc_dwa_set_resolution": (C.c_int, [_vp, C.c_double]),
+    "kc_dwa_set_weights": (C.c_int, [_vp, C.POINTER(Weights)]),
+    "kc_dwa_sample_window": (C.c_int, [_vp, C.c_int, C.POINTER(Limits), C.c_double, C.c_double, C.c_double,
+                                       C.c_int, C.c_int, C.POINTER(_sz), _dp, _dp, _dp, _sz]),
+    "kc_dwa_set_samples": (C.c_int, [_vp, _sz, _dp, _dp, _dp]),
+    "kc_dwa_set_shard": (C.c_int, [_vp, _sz, _sz]),
+    "kc_dwa_set_scan": (C.c_int, [_vp, C.POINTER(State), _dp, _dp, _sz, C.c_float]),
+    "kc_dwa_set_points": (C.c_int, [_vp, C.POINTER(State), _fp, _sz, C.c_float]),
+    "kc_dwa_set_tracked_segment": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _sz, C.c_float]),
+    "kc_dwa_rollout": (C.c_int, [_vp, C.POINTER(State), _sz]),
+    "kc_dwa_evaluate": (C.c_int, [_vp]),
+    "kc_dwa_fetch_result": (C.c_int, [_vp, C.POINTER(Result)]),
+    "kc_dwa_cycle": (C.c_int, [_vp, C.POINTER(State), _sz, C.POINTER(Result)]),
+    "kc_dwa_get_best": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
+    "kc_dwa_get_samples": (C.c_int, [_vp, _fp, _fp, _ip, _fp, _sz, C.POINTER(_sz)]),
+    "kc_cost_evaluate": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _sz, _sz, _fp, C.POINTER(Result)]),
+    "kc_dwa_result_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "kc_dwa_count_admissible_before": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "kc_key_cost": (C.c_float, [C.c_int64]),
+    "kc_key_index": (C.c_int64, [C.c_int64]),
+    "kc_key_pack": (C.c_int64, [C.c_float, C.c_int64]),
+    "kc_dwa_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "kc_dwa_timing_get": (C.c_int, [_vp, C.POINTER(C.c_char_p), _fp, _sz, C.POINTER(_sz)]),
+    "kc_mapper_create": (C.c_int, [C.c_int, C.c_int, C.c_float, _fp, C.c_float, _sz, C.c_int, C.POINTER(_vp)]),
+    "kc_mapper_destroy": (None, [_vp]),
+    "kc_mapper_set_stream": (C.c_int, [_vp, _vp]),
+    "kc_mapper_scan_to_grid": (C.c_int, [_vp, _dp, _dp, _sz, _ip]),
+    "kc_mapper_scan_to_grid_device": (C.c_int, [_vp, _dp, _dp, _sz]),
+    "kc_mapper_grid_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "kc_mapper_sync": (C.c_int, [_vp]),
+    "kc_mapper_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "kc_mapper_timing_get": (C.c_int, [_vp, C.POINTER(C.c_char_p), _fp, _sz, C.POINTER(_sz)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libkompass_hip.so (raises if it was not built -- no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise KompassHipError(
+            f"{LIB_PATH} is missing: build it with `make -C {_HERE}` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)  # AttributeError if the symbol is not exported
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != KC_OK:
+        msg = lib().kc_last_error().decode("utf-8", "replace")
+        exc = _ERR_TO_EXC.get(rc, KompassHipError)
+        if exc is RuntimeError:
+            exc = KompassHipError
+        raise exc(f"[kc {rc}] {msg}")
+
+
+def device_count() -> int:
+    return lib().kc_device_count()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _pf(a):
+    return a.ctypes.data_as(_fp) if a is not None else None
+
+
+def _pd(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def make_limits(vx=(1.0, 10.0, 10.0), vy=(1.0, 10.0, 10.0), omega=(np.pi, 1.0, 10.0, 10.0)) -> Limits:
+    return Limits(vx[0], vx[1], vx[2], vy[0], vy[1], vy[2], omega[0], omega[1], omega[2], omega[3])
+
+
+def make_weights(path=1.0, goal=1.0, obstacles=1.0, smoothness=1.0, jerk=1.0) -> Weights:
+    return Weights(path, goal, obstacles, smoothness, jerk)
+
+
+class DwaContext:
+    """Owner of one kc_dwa context (one HIP stream, persistent device buffers)."""
+
+    def __init__(self, shape, dims, sensor_pos=(0, 0, 0), sensor_rot_xyzw=(0, 0, 0, 1), octree_res=0.1,
+                 time_step=0.1, max_samples=1024, max_points=64, max_segment=512, max_obstacles=1024,
+                 acc_limits=(1.0, 1.0, 1.0), device=0):
+        p = DwaParams()
+        p.shape = int(shape)
+        d = list(dims) + [0.0] * (3 - len(dims))
+        for i in range(3):
+            p.dims[i] = float(np.float32(d[i]))
+            p.sensor_pos[i] = float(np.float32(sensor_pos[i]))
+            p.acc_limits[i] = float(np.float32(acc_limits[i]))
+        p.ndims = len(dims)
+        for i in range(4):
+            p.sensor_rot_xyzw[i] = float(np.float32(sensor_rot_xyzw[i]))
+        p.octree_res = float(octree_res)
+        p.time_step = float(time_step)
+        p.max_samples, p.max_points = int(max_samples), int(max_points)
+        p.max_segment, p.max_obstacles = int(max_segment), int(max_obstacles)
+        p.device = int(device)
+        self.params = p
+        self.h = _vp()
+        _check(lib().kc_dwa_create(C.byref(p), C.byref(self.h)))
+        self._P = 0
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().kc_dwa_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        _check(lib().kc_dwa_set_stream(self.h, _vp(stream_ptr) if stream_ptr else None))
+
+    def set_resolution(self, res):
+        _check(lib().kc_dwa_set_resolution(self.h, float(res)))
+
+    def set_weights(self, w: Weights):
+        _check(lib().kc_dwa_set_weights(self.h, C.byref(w)))
+
+    def sample_window(self, ctr_type, limits: Limits, cur_vel, max_lin, max_ang, want_list=True):
+        n = _sz(0)
+        if want_list:
+            cap = int(self.params.max_samples)
+            vx, vy, om = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+            _check(lib().kc_dwa_sample_window(self.h, ctr_type, C.byref(limits), cur_vel[0], cur_vel[1],
+                                              cur_vel[2], max_lin, max_ang, C.byref(n), _pd(vx), _pd(vy),
+                                              _pd(om), cap))
+            k = n.value
+            return vx[:k].copy(), vy[:k].copy(), om[:k].copy()
+        _check(lib().kc_dwa_sample_window(self.h, ctr_type, C.byref(limits), cur_vel[0], cur_vel[1],
+                                          cur_vel[2], max_lin, max_ang, C.byref(n), None, None, None, 0))
+        return n.value
+
+    def set_samples(self, vx, vy, omega):
+        vx, vy, omega = _f64(vx), _f64(vy), _f64(omega)
+        _check(lib().kc_dwa_set_samples(self.h, len(vx), _pd(vx), _pd(vy), _pd(omega)))
+
+    def set_shard(self, first, count):
+        _check(lib().kc_dwa_set_shard(self.h, int(first), int(count)))
+
+    def set_scan(self, state, ranges, angles, max_sensor_range=10.0):
+        r, a = _f64(ranges), _f64(angles)
+        st = State(*state)
+        _check(lib().kc_dwa_set_scan(self.h, C.byref(st), _pd(r), _pd(a), len(r), float(max_sensor_range)))
+
+    def set_points(self, state, xyz, max_sensor_range=10.0):
+        p = _f32(xyz).reshape(-1, 3)
+        st = State(*state)
+        _check(lib().kc_dwa_set_points(self.h, C.byref(st), _pf(p), len(p), float(max_sensor_range)))
+
+    def set_tracked_segment(self, seg_xyz, acc_at_seg, ref_path_length):
+        seg = _f32(seg_xyz).reshape(-1, 3)
+        x, y, z = _f32(seg[:, 0]), _f32(seg[:, 1]), _f32(seg[:, 2])
+        acc = _f32(acc_at_seg)
+        assert len(acc) == len(x)
+        _check(lib().kc_dwa_set_tracked_segment(self.h, _pf(x), _pf(y), _pf(z), _pf(acc), len(x),
+                                                float(np.float32(ref_path_length))))
+
+    # -- cycle --------------------------------------------------------------
+    def rollout(self, state, P):
+        st = State(*state)
+        self._P = int(P)
+        _check(lib().kc_dwa_rollout(self.h, C.byref(st), int(P)))
+
+    def evaluate(self):
+        _check(lib().kc_dwa_evaluate(self.h))
+
+    def fetch_result(self) -> Result:
+        r = Result()
+        _check(lib().kc_dwa_fetch_result(self.h, C.byref(r)))
+        return r
+
+    def cycle(self, state, P) -> Result:
+        st = State(*state)
+        self._P = int(P)
+        r = Result()
+        _check(lib().kc_dwa_cycle(self.h, C.byref(st), int(P), C.byref(r)))
+        return r
+
+    def get_best(self):
+        P = self._P
+        px, py = np.zeros(P, np.float32), np.zeros(P, np.float32)
+        v = [np.zeros(P - 1, np.float32) for _ in range(3)]
+        _check(lib().kc_dwa_get_best(self.h, _pf(px), _pf(py), _pf(v[0]), _pf(v[1]), _pf(v[2])))
+        return px, py, v
+
+    def get_samples(self, with_costs=False):
+        P = self._P
+        n = _sz(0)
+        _check(lib().kc_dwa_get_samples(self.h, None, None, None, None, 0, C.byref(n)))
+        k = n.value
+        px, py = np.zeros((max(k, 1), P), np.float32), np.zeros((max(k, 1), P), np.float32)
+        raw = np.zeros(max(k, 1), np.int32)
+        costs = np.zeros(max(k, 1), np.float32) if with_costs else None
+        _check(lib().kc_dwa_get_samples(self.h, _pf(px), _pf(py), raw.ctypes.data_as(_ip), _pf(costs), k,
+                                        C.byref(n)))
+        out = (px[:k], py[:k], raw[:k])
+        return out + (costs[:k],) if with_costs else out
+
+    def cost_evaluate(self, paths_x, paths_y, vel=None):
+        px, py = _f32(paths_x), _f32(paths_y)
+        N, P = px.shape
+        self._P = P
+        costs = np.zeros(max(N, 1), np.float32)
+        r = Result()
+        v = [_f32(a) for a in vel] if vel is not None else [None, None, None]
+        _check(lib().kc_cost_evaluate(self.h, _pf(px), _pf(py), _pf(v[0]), _pf(v[1]), _pf(v[2]), N, P,
+                                      _pf(costs), C.byref(r)))
+        return r, costs[:N]
+
+    def result_device_ptr(self) -> int:
+        p = _vp()
+        _check(lib().kc_dwa_result_device(self.h, C.byref(p)))
+        return p.value
+
+    def count_admissible_before(self, raw_index) -> int:
+        c = C.c_int64(0)
+        _check(lib().kc_dwa_count_admissible_before(self.h, int(raw_index), C.byref(c)))
+        return c.value
+
+    def timing_enable(self, on=True):
+        _check(lib().kc_dwa_timing_enable(self.h, int(bool(on))))
+
+    def timings(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = _sz(0)
+        _check(lib().kc_dwa_timing_get(self.h, names, ms, 32, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+class MapperContext:
+    """Owner of one kc_mapper context (LocalMapper scan -> grid)."""
+
+    def __init__(self, grid_height, grid_width, resolution, laserscan_position=(0, 0, 0),
+                 laserscan_orientation=0.0, max_scan_size=4096, device=0):
+        pos = _f32(laserscan_position)
+        self.H, self.W = int(grid_height), int(grid_width)
+        self.h = _vp()
+        _check(lib().kc_mapper_create(self.H, self.W, float(np.float32(resolution)), _pf(pos),
+                                      float(np.float32(laserscan_orientation)), int(max_scan_size),
+                                      int(device), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().kc_mapper_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(lib().kc_mapper_set_stream(self.h, _vp(stream_ptr) if stream_ptr else None))
+
+    def scan_to_grid(self, angles, ranges):
+        """-> int32 [H, W] with the Eigen column-major storage undone."""
+        a, r = _f64(angles), _f64(ranges)
+        g = np.empty(self.H * self.W, np.int32)
+        _check(lib().kc_mapper_scan_to_grid(self.h, _pd(a), _pd(r), len(a), g.ctypes.data_as(_ip)))
+        return g.reshape(self.W, self.H).T
+
+    def scan_to_grid_device(self, angles, ranges):
+        a, r = _f64(angles), _f64(ranges)
+        _check(lib().kc_mapper_scan_to_grid_device(self.h, _pd(a), _pd(r), len(a)))
+
+    def sync(self):
+        _check(lib().kc_mapper_sync(self.h))
+
+    def grid_device_ptr(self) -> int:
+        p = _vp()
+        _check(lib().kc_mapper_grid_device(self.h, C.byref(p)))
+        return p.value
+
+    def timing_enable(self, on=True):
+        _check(lib().kc_mapper_timing_enable(self.h, int(bool(on))))
+
+    def timings(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = _sz(0)
+        _check(lib().kc_mapper_timing_get(self.h, names, ms, 16, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]

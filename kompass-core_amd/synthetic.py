@@ -1,0 +1,138 @@
+"""Seeded synthetic inputs of the BASELINE.json configurations.
+
+Plain numpy; shared by tests/ and bench.py so the HIP path and the CPU oracle
+are always fed the same bytes.  Nothing here computes a result.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+ACKERMANN, DIFFERENTIAL_DRIVE, OMNI = 0, 1, 2
+CYLINDER, BOX, SPHERE = 0, 1, 2
+
+# dwa_test.cpp:173-177,206-207 (robot + limits used by the reference's own
+# closed-loop scenarios)
+ROBOT_CYLINDER = dict(shape=CYLINDER, dims=[0.1, 0.4])
+LIMITS = dict(vx=(1.0, 2.0, 2.0), vy=(1.0, 2.0, 2.0), omega=(2.0, 2.0, 3.0, 3.0))
+
+
+def costmap_points(n_side: int, res: float = 0.05, seed: int = 0, p_occ: float = 0.02,
+                   free_radius: float = 1.0, border: int = 2) -> np.ndarray:
+    """Occupied cell centres (x, y, 0) of an n_side x n_side costmap centred on
+    the robot: Bernoulli(p_occ) outside a free disc, plus a solid border."""
+    rng = np.random.default_rng(seed)
+    occ = rng.random((n_side, n_side)) < p_occ
+    c = (np.arange(n_side) - n_side / 2.0 + 0.5) * res
+    X, Y = np.meshgrid(c, c, indexing="ij")
+    occ &= (X * X + Y * Y) > free_radius * free_radius
+    occ[:border, :] = True
+    occ[-border:, :] = True
+    occ[:, :border] = True
+    occ[:, -border:] = True
+    pts = np.stack([X[occ], Y[occ], np.zeros(int(occ.sum()))], axis=1)
+    return np.ascontiguousarray(pts, dtype=np.float32)
+
+
+def window(cur, limits, dt):
+    """Dynamic window of trajectory_sampler.cpp:328-372 (plain formula)."""
+    vmax, acc, dec = limits
+    return max(-vmax, cur - dec * dt), min(vmax, cur + acc * dt)
+
+
+def lattice_nonholonomic(n_vx: int, n_omega: int, cur_vel=(0.5, 0.0, 0.0), dt: float = 0.1,
+                         limits=LIMITS):
+    """Exactly n_vx * n_omega (vx, 0, omega) samples inside the dynamic window,
+    vx-major / omega-minor like trajectory_sampler.cpp:207-217; the vx axis is
+    kept away from |vx| < 0.01 so no row is skipped."""
+    lo, hi = window(cur_vel[0], limits["vx"], dt)
+    lo = max(lo, 0.02)
+    olo, ohi = window(cur_vel[2], (limits["omega"][1], limits["omega"][2], limits["omega"][3]), dt)
+    vxs = lo + (hi - lo) * np.arange(n_vx) / max(n_vx - 1, 1)
+    oms = olo + (ohi - olo) * np.arange(n_omega) / max(n_omega - 1, 1)
+    vx = np.repeat(vxs, n_omega)
+    om = np.tile(oms, n_vx)
+    return vx.astype(np.float64), np.zeros_like(vx), om.astype(np.float64)
+
+
+def lattice_omni(n_vx: int, n_vy: int, n_omega: int, cur_vel=(0.5, 0.0, 0.0), dt: float = 0.1,
+                 limits=LIMITS):
+    """Per vx: the (vx, vy, 0) block then the (vx, 0, omega) block
+    (trajectory_sampler.cpp:256-272); n_vx * (n_vy + n_omega) samples."""
+    lo, hi = window(cur_vel[0], limits["vx"], dt)
+    lo = max(lo, 0.02)
+    ylo, yhi = window(cur_vel[1], limits["vy"], dt)
+    olo, ohi = window(cur_vel[2], (limits["omega"][1], limits["omega"][2], limits["omega"][3]), dt)
+    vxs = lo + (hi - lo) * np.arange(n_vx) / max(n_vx - 1, 1)
+    vys = ylo + (yhi - ylo) * np.arange(n_vy) / max(n_vy - 1, 1)
+    oms = olo + (ohi - olo) * np.arange(n_omega) / max(n_omega - 1, 1)
+    vx, vy, om = [], [], []
+    for v in vxs:
+        vx += [v] * n_vy
+        vy += list(vys)
+        om += [0.0] * n_vy
+        vx += [v] * n_omega
+        vy += [0.0] * n_omega
+        om += list(oms)
+    return np.array(vx), np.array(vy), np.array(om)
+
+
+def straight_segment(n_points: int, spacing: float = 0.01, y: float = 0.0):
+    """Tracked segment of a straight reference path along +x starting at the
+    robot: (xyz [S,3] float32, acc_at_seg [S] float32, ref_len, seg)."""
+    s = np.arange(n_points, dtype=np.float64) * spacing
+    xyz = np.stack([s, np.full_like(s, y), np.zeros_like(s)], axis=1).astype(np.float32)
+    return xyz, s.astype(np.float32)
+
+
+def arc_segment(n_points: int, radius: float = 10.0, spacing: float = 0.01):
+    """Tracked segment of the 3/4-circle path of controller_test_helpers.h:63-72
+    starting at the robot pose (0, 0, yaw 0): circle centred at (0, radius)."""
+    s = np.arange(n_points, dtype=np.float64) * spacing
+    th = s / radius
+    xyz = np.stack([radius * np.sin(th), radius * (1 - np.cos(th)), np.zeros_like(s)], axis=1)
+    return xyz.astype(np.float32), s.astype(np.float32)
+
+
+def dense_scan(n_beams: int, scale: float = 1.0):
+    """benchmark_runner.cpp:112-121 generator: angles -pi + i*2pi/n, ranges
+    5 + 2 sin(20 angle), optionally scaled to fill a larger grid."""
+    ang = -math.pi + np.arange(n_beams, dtype=np.float64) * (2 * math.pi / n_beams)
+    rng = (5.0 + 2.0 * np.sin(20.0 * ang)) * scale
+    return ang, rng
+
+
+# name -> parameters of the BASELINE.json configs (kernel-level sample counts)
+CONFIGS = {
+    "cfg1": dict(ctr=DIFFERENTIAL_DRIVE, n_vx=8, n_om=16, P=20, map_side=200, seg=201, path="straight",
+                 weights=(1.0, 1.0, 1.0, 0.0, 0.0)),
+    "cfg2": dict(ctr=DIFFERENTIAL_DRIVE, n_vx=64, n_om=128, P=50, map_side=500, seg=501, path="straight",
+                 weights=(1.0, 1.0, 1.0, 0.0, 0.0)),
+    "cfg3": dict(ctr=ACKERMANN, n_vx=128, n_om=256, P=100, map_side=1000, seg=1001, path="arc",
+                 weights=(1.0, 1.0, 1.0, 0.0, 0.0)),
+    "cfg5": dict(ctr=OMNI, n_vx=256, n_vy=64, n_om=192, P=50, map_side=500, seg=501, path="straight",
+                 weights=(1.0, 1.0, 1.0, 1.0, 1.0)),
+}
+
+
+def make_controller_inputs(name: str, seed: int = 0, scale: float = 1.0):
+    """Everything one controller cycle of a BASELINE config consumes.
+    scale < 1 shrinks the sample lattice (parity tests at oracle-friendly size)."""
+    c = CONFIGS[name]
+    nvx = max(2, int(round(c["n_vx"] * scale)))
+    nom = max(3, int(round(c["n_om"] * scale)))
+    if c["ctr"] == OMNI:
+        nvy = max(3, int(round(c["n_vy"] * scale)))
+        vx, vy, om = lattice_omni(nvx, nvy, nom)
+    else:
+        vx, vy, om = lattice_nonholonomic(nvx, nom)
+    seg, acc = (straight_segment if c["path"] == "straight" else arc_segment)(c["seg"])
+    pts = costmap_points(c["map_side"], 0.05, seed)
+    return dict(
+        name=name, ctr=c["ctr"], vx=vx, vy=vy, omega=om, P=c["P"], dt=0.1,
+        state=(0.0, 0.0, 0.0, 0.0), points=pts, octree_res=0.05,
+        seg_xyz=seg, acc_at_seg=acc, ref_len=12.0 if c["path"] == "straight" else 47.12389,
+        weights=c["weights"], max_range=10.0, robot=ROBOT_CYLINDER,
+        acc_limits=(LIMITS["vx"][1], LIMITS["vy"][1], LIMITS["omega"][2]),
+    )

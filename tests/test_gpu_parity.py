@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path through the C ABI vs the CPU oracle on the
+same seeded inputs.  Bit-exact on admissible set, float paths, float costs and
+the selected index (tolerance 0; north_star allows 1e-5 on costs).
+
+Run with `pytest -m gpu` on an MI355X.
+"""
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kompass_hip as kh  # noqa: E402
+import synthetic as syn  # noqa: E402
+from oracle import ko  # noqa: E402
+
+from helpers import assert_cycle_equal, hip_context, hip_cycle, oracle_cycle  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert kh.device_count() >= 1, "no HIP device visible: the -m gpu tests need an MI355X"
+
+
+# ---------------------------------------------------------------------------
+# controller: full cycle on scaled-down BASELINE configs
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name,scale", [("cfg1", 1.0), ("cfg2", 0.25), ("cfg3", 0.08), ("cfg5", 0.08)])
+def test_cycle_parity_configs(name, scale):
+    inp = syn.make_controller_inputs(name, seed=1, scale=scale)
+    o = oracle_cycle(inp)
+    h = hip_cycle(kh, inp)
+    assert len(o["raw"]) > 0, "scenario must leave admissible samples"
+    assert len(o["raw"]) < len(inp["vx"]), "scenario must drop colliding samples"
+    assert_cycle_equal(o, h)
+
+
+@pytest.mark.parametrize("shape,dims", [(syn.CYLINDER, [0.2, 0.5]), (syn.BOX, [0.5, 0.3, 0.4]),
+                                        (syn.SPHERE, [0.25])])
+@pytest.mark.parametrize("yaw", [0.0, 0.7, -2.3])
+def test_cycle_parity_shapes_points(shape, dims, yaw):
+    inp = syn.make_controller_inputs("cfg1", seed=3)
+    inp["robot"] = dict(shape=shape, dims=dims)
+    inp["state"] = (0.3, -0.2, yaw, 0.0)
+    # points at several heights: exercises the z-interval / sphere z-gap logic
+    rng = np.random.default_rng(7)
+    pts = inp["points"].copy()
+    pts[:, 2] = rng.choice([-0.3, -0.05, 0.0, 0.12, 0.31, 0.6], size=len(pts)).astype(np.float32)
+    inp["points"] = pts
+    o = oracle_cycle(inp)
+    h = hip_cycle(kh, inp)
+    assert_cycle_equal(o, h)
+
+
+@pytest.mark.parametrize("shape,dims", [(syn.CYLINDER, [0.15, 0.4]), (syn.BOX, [0.4, 0.4, 1.0])])
+def test_cycle_parity_laserscan_sensor_frame(shape, dims):
+    """LaserScan input: octree lives in the (rotated, offset) sensor frame."""
+    inp = syn.make_controller_inputs("cfg1", seed=5)
+    inp["robot"] = dict(shape=shape, dims=dims)
+    inp["state"] = (1.0, 2.0, 0.4, 0.0)
+    inp["seg_xyz"] = inp["seg_xyz"] + np.float32([1.0, 2.0, 0.0])
+    ang = np.linspace(0, 2 * math.pi, 360, endpoint=False)
+    rng = np.random.default_rng(11)
+    ranges = 1.2 + 1.5 * rng.random(360)
+    ranges[5] = np.inf  # filtered by the collision path only (Q7 excluded: finite elsewhere)
+    ranges[5] = 3.0
+    spos = (0.1, -0.05, 0.3)
+    half = 0.35  # sensor yawed by 0.7 rad
+    srot = (0.0, 0.0, math.sin(half), math.cos(half))
+    o = oracle_cycle(inp, scan=(ranges, ang), sensor_pos=spos, sensor_rot=srot)
+    h = hip_cycle(kh, inp, scan=(ranges, ang), sensor_pos=spos, sensor_rot=srot)
+    assert 0 < len(o["raw"]) < len(inp["vx"])
+    assert_cycle_equal(o, h)
+
+
+def test_cycle_no_obstacles_and_all_blocked():
+    inp = syn.make_controller_inputs("cfg1", seed=2)
+    inp["points"] = np.zeros((0, 3), np.float32)
+    o = oracle_cycle(inp)
+    h = hip_cycle(kh, inp)
+    assert len(o["raw"]) == len(inp["vx"])
+    assert_cycle_equal(o, h)
+    # a wall of points right in front of the robot: nothing admissible
+    ys = np.arange(-3, 3, 0.02)
+    wall = np.stack([np.full_like(ys, 0.12), ys, np.zeros_like(ys)], axis=1).astype(np.float32)
+    inp["points"] = wall
+    o = oracle_cycle(inp)
+    h = hip_cycle(kh, inp)
+    assert len(o["raw"]) == 0 and not h["res"]["found"] and h["res"]["index"] == -1
+    assert_cycle_equal(o, h)
+
+
+def test_sample_window_matches_oracle():
+    """A1: host lattice (kc_dwa_sample_window) == oracle list, all robot types."""
+    lim_o = ko.make_limits(**syn.LIMITS)
+    lim_h = kh.make_limits(**syn.LIMITS)
+    for ctr in (syn.ACKERMANN, syn.DIFFERENTIAL_DRIVE, syn.OMNI):
+        for cur in [(0.5, 0.0, 0.0), (0.0, 0.0, 0.0), (-0.3, 0.2, 1.9), (1.0, -1.0, -2.0)]:
+            for L, A in [(4, 4), (11, 11), (20, 7)]:
+                ovx, ovy, oom = ko.sample_velocities(ctr, lim_o, cur, 0.1, L, A)
+                ctx = kh.DwaContext(syn.CYLINDER, [0.1, 0.4], max_samples=4096, max_points=8)
+                hvx, hvy, hom = ctx.sample_window(ctr, lim_h, cur, L, A)
+                np.testing.assert_array_equal(hvx, ovx)
+                np.testing.assert_array_equal(hvy, ovy)
+                np.testing.assert_array_equal(hom, oom)
+                ctx.close()
+
+
+# ---------------------------------------------------------------------------
+# cost evaluator: the reference's closed-form cases through kc_cost_evaluate
+# ---------------------------------------------------------------------------
+GOLD = json.loads((Path(__file__).parent / "golden" / "cost_kat.json").read_text())
+
+
+def _kat_eval(weights, path_pts, vels=None, obstacles=None):
+    ref = ko.Path([[0, 0, 0], [10.0, 0, 0]])
+    ref.interpolate(1.0)
+    ref.segment(5.0, 10000)
+    s0, s1 = ref.segment_range(0)
+    seg = np.stack([ref.x[s0:s1 + 1], ref.y[s0:s1 + 1], ref.z[s0:s1 + 1]], axis=1)
+    acc = ref.acc[s0:s1 + 1]
+    ctx = kh.DwaContext(syn.CYLINDER, [0.1, 0.4], max_samples=4, max_points=8, acc_limits=(1, 1, 1))
+    ctx.set_weights(kh.make_weights(**weights))
+    ctx.set_tracked_segment(seg, acc, ref.total_length)
+    if obstacles:
+        ctx.set_points((0, 0, 0, 0), np.float32(obstacles), 30.0)
+    pts = np.float32(path_pts).reshape(-1, 3)
+    n = len(pts)
+    v = np.float32(vels if vels is not None else [(0, 0, 0)] * (n - 1)).reshape(n - 1, 3)
+    r, costs = ctx.cost_evaluate(pts[:, 0][None], pts[:, 1][None], [v[:, 0][None], v[:, 1][None], v[:, 2][None]])
+    assert r.found and r.index == 0
+    ctx.close()
+    return float(costs[0])
+
+
+def _solo(name):
+    w = dict(path=0.0, goal=0.0, obstacles=0.0, smoothness=0.0, jerk=0.0)
+    w[name] = 1.0
+    return w
+
+
+def test_cost_known_answers_on_gpu():
+    z5 = [(0.0, 0.0, 0.0)] * 5
+    got = {
+        "goal_cost_on_straight_path": [_kat_eval(_solo("goal"), [(4.0, 0, 0)] * 5)],
+        "goal_cost_tie_breaker": [_kat_eval(_solo("goal"), [(4.0, 0.1, 0)] * 5),
+                                  _kat_eval(_solo("goal"), [(4.0, 0.5, 0)] * 5)],
+        "path_cost_centered_sample": [_kat_eval(_solo("path"), [(float(i), 0, 0) for i in range(5)])],
+        "path_cost_constant_lateral_offset": [_kat_eval(_solo("path"), [(float(i), 0.5, 0) for i in range(5)])],
+        "smoothness_cost_constant_velocity": [_kat_eval(_solo("smoothness"), z5, [(1.0, 0, 0)] * 4)],
+        "smoothness_cost_single_step_change": [
+            _kat_eval(_solo("smoothness"), z5, [(0, 0, 0), (1, 0, 0), (1, 0, 0), (1, 0, 0)])],
+        "jerk_cost_known_second_diff": [_kat_eval(_solo("jerk"), z5, [(0, 0, 0), (1, 0, 0), (3, 0, 0), (6, 0, 0)])],
+        "obstacles_cost_at_max_range": [_kat_eval(_solo("obstacles"), z5, obstacles=[(20.0, 0, 0)])],
+        "obstacles_cost_at_zero_distance": [_kat_eval(_solo("obstacles"), z5, obstacles=[(0.0, 0, 0)])],
+        "obstacles_cost_at_half_range": [_kat_eval(_solo("obstacles"), z5, obstacles=[(5.0, 0, 0)])],
+    }
+    for name, vals in got.items():
+        g = GOLD["cost"][name]
+        for v, e in zip(vals, g["expected"]):
+            if e == 0.0:
+                assert abs(v) <= 1e-12, (name, v)
+            else:
+                assert abs(v - e) <= g["tol"] * min(abs(v), abs(e)), (name, v, e)
+
+
+def test_cost_evaluate_random_with_velocities():
+    """Generic evaluator (arbitrary paths + velocity profiles, all 5 weights)."""
+    rng = np.random.default_rng(21)
+    N, P, S, O = 300, 37, 260, 500
+    px = (rng.random((N, P)) * 6 - 1).astype(np.float32)
+    py = (rng.random((N, P)) * 4 - 2).astype(np.float32)
+    vel = [(rng.random((N, P - 1)) * 2 - 1).astype(np.float32) for _ in range(3)]
+    seg, acc = syn.arc_segment(S, radius=4.0, spacing=0.02)
+    seg[:, 2] = (0.01 * np.arange(S)).astype(np.float32)  # non-zero z path
+    obs = (rng.random((O, 3)) * 8 - 3).astype(np.float32)
+    state = (0.2, -0.1, 0.3, 0.0)
+    w = (0.7, 1.3, 2.0, 0.5, 0.25)
+    ox, oy = ko.obstacles_from_points((0, 0, 0), (0, 0, 0, 1), state, obs)
+    ci = ko.CostInputs(seg, 40, np.concatenate([np.zeros(40, np.float32), acc]), 7.5,
+                       np.stack([ox, oy], 1), np.float32(10.0) / np.float32(3.0), (2.0, 0.0, 3.0),
+                       ko.make_weights(*w))
+    oi, oc, ocosts = ko.min_trajectory_cost(ci, px, py, vel)
+    ctx = kh.DwaContext(syn.CYLINDER, [0.1, 0.4], max_samples=N, max_points=P, acc_limits=(2.0, 0.0, 3.0))
+    ctx.set_weights(kh.make_weights(*w))
+    ctx.set_tracked_segment(seg, acc, 7.5)
+    ctx.set_points(state, obs, 10.0)
+    r, hcosts = ctx.cost_evaluate(px, py, vel)
+    np.testing.assert_array_equal(hcosts.view(np.uint32), ocosts.view(np.uint32))
+    assert r.found and r.index == oi and np.float32(r.cost) == np.float32(oc)
+    # lowest-index tie-break: duplicate the winner in front of itself
+    px2 = np.concatenate([px[oi:oi + 1], px]); py2 = np.concatenate([py[oi:oi + 1], py])
+    vel2 = [np.concatenate([v[oi:oi + 1], v]) for v in vel]
+    ctx2 = kh.DwaContext(syn.CYLINDER, [0.1, 0.4], max_samples=N + 1, max_points=P, acc_limits=(2.0, 0.0, 3.0))
+    ctx2.set_weights(kh.make_weights(*w))
+    ctx2.set_tracked_segment(seg, acc, 7.5)
+    ctx2.set_points(state, obs, 10.0)
+    r2, _ = ctx2.cost_evaluate(px2, py2, vel2)
+    assert r2.index == 0
+
+
+# ---------------------------------------------------------------------------
+# mapper
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W,res,pos,orient,n,scale", [
+    (400, 400, 0.05, (0, 0, 0), 0.0, 3600, 1.0),
+    (200, 300, 0.1, (0.35, -0.2, 0.1), 0.6, 777, 1.0),
+    (101, 77, 0.07, (-0.5, 0.4, 0), -2.0, 360, 0.5),
+    (1000, 1000, 0.05, (0, 0, 0), 0.0, 4096, 4.0),
+])
+def test_mapper_parity(H, W, res, pos, orient, n, scale):
+    ang, rng = syn.dense_scan(n, scale)
+    r = np.random.default_rng(5)
+    rng = rng * (0.6 + 0.8 * r.random(n))
+    rng[::17] = 0.0          # zero-length rays
+    rng[::29] *= 10.0        # rays leaving the grid
+    want = ko.scan_to_grid(H, W, res, pos, orient, ang, rng)
+    m = kh.MapperContext(H, W, res, pos, orient, n)
+    got = m.scan_to_grid(ang, rng)
+    assert got.shape == (H, W) and got.dtype == np.int32
+    assert set(np.unique(got)) <= {-1, 0, 100}
+    np.testing.assert_array_equal(got, want)
+    # second call with new ranges, same angles (trig table reuse path)
+    rng2 = rng[::-1].copy()
+    np.testing.assert_array_equal(m.scan_to_grid(ang, rng2), ko.scan_to_grid(H, W, res, pos, orient, ang, rng2))
+    m.close()
+
+
+def test_mapper_fixture_scan():
+    """The reference's own 360-beam fixture (tests/resources/mapping/laserscan_data.json)."""
+    data = json.loads((Path(__file__).parent / "golden" / "laserscan_data.json").read_text())
+    rng = np.array(data["ranges"], dtype=np.float64)
+    ang = data["angle_min"] + np.arange(len(rng)) * data["angle_increment"]
+    rng = np.clip(np.nan_to_num(rng, posinf=20.0), 0, 20.0)
+    want = ko.scan_to_grid(200, 200, 0.1, (0, 0, 0), 0.0, ang, rng)
+    m = kh.MapperContext(200, 200, 0.1, (0, 0, 0), 0.0, len(rng))
+    np.testing.assert_array_equal(m.scan_to_grid(ang, rng), want)
+    assert (want == 100).sum() > 0
+
+
+def test_mapper_empty_scan():
+    m = kh.MapperContext(50, 60, 0.1)
+    g = m.scan_to_grid(np.zeros(0), np.zeros(0))
+    assert (g == -1).all()
+
+
+# ---------------------------------------------------------------------------
+# device arithmetic self-check: correctly rounded f32 div/sqrt
+# ---------------------------------------------------------------------------
+def test_full_size_cfg2_properties():
+    """cfg2 at BASELINE size: properties that need no oracle run -- winner is
+    admissible, its cost is the minimum of the per-sample costs, index is the
+    first minimum, shard union == unsharded."""
+    inp = syn.make_controller_inputs("cfg2", seed=0)
+    h = hip_cycle(kh, inp)
+    res = h["res"]
+    assert res["n_samples"] == 8192 and 0 < res["n_admissible"] < 8192
+    costs = h["costs"]
+    assert res["found"] and res["index"] == int(np.argmin(costs))
+    assert np.float32(res["cost"]) == costs.min()
+    assert (np.diff(h["raw"]) > 0).all()
+    # two shards: min over shard keys == unsharded key
+    ctx = h["ctx"]
+    keys, counts = [], []
+    for first, count in [(0, 5000), (5000, 3192)]:
+        ctx.set_shard(first, count)
+        r = ctx.cycle(inp["state"], inp["P"])
+        keys.append((np.float32(r.cost), r.raw_index) if r.found else (np.float32(np.inf), 1 << 40))
+        counts.append(r.n_admissible)
+    assert sum(counts) == res["n_admissible"]
+    best = min(keys)
+    assert best[1] == res["raw_index"] and best[0] == np.float32(res["cost"])
+    # admissible samples never touch an occupied voxel: re-check 64 rows on CPU
+    o = oracle_cycle(dict(inp, vx=inp["vx"][h["raw"][:64]], vy=inp["vy"][h["raw"][:64]],
+                          omega=inp["omega"][h["raw"][:64]]))
+    assert len(o["raw"]) == 64
+    np.testing.assert_array_equal(o["px"], h["px"][:64])
+    np.testing.assert_array_equal(o["costs"].view(np.uint32), costs[:64].view(np.uint32))
