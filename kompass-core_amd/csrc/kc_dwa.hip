@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kPairBlock) void path_min_kernel(
     const float d = xx + (yy + szz[j]);  // Eigen 3-term order a + (b + c)
     best = d < best ? d : best;
   }
-  mind[t] = __fsqrt_rn(best);
+  mind[t] = kc::sqrt_rn(best);
 }
 
 // ===========================================================================
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
             arg = j;
           }
         }
-        const float arc = __fdiv_rn(a.ref_len - a.acc_seg[arg], a.ref_len);
-        const float c = arc + __fdiv_rn(__fsqrt_rn(best), a.ref_len);
+        const float arc = kc::div_rn(a.ref_len - a.acc_seg[arg], a.ref_len);
+        const float c = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
         total = accum(total, a.w_goal, c);
       }
       if (a.w_path > 0.0) {
@@ -383,12 +383,12 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
         float sum = 0.0f;
         for (int i = 0; i < a.P; ++i) sum += m[i];
         const int e = a.S - 1;
-        const float end_err = __fdiv_rn(
-            __fsqrt_rn(dist_sq3(px[a.P - 1], py[a.P - 1], 0.0f, a.sx[e],
+        const float end_err = kc::div_rn(
+            kc::sqrt_rn(dist_sq3(px[a.P - 1], py[a.P - 1], 0.0f, a.sx[e],
                                 a.sy[e], a.sz[e])),
             a.seg_len);
-        const float c = __fdiv_rn(
-            __fdiv_rn(sum, static_cast<float>(a.P)) + end_err, 2.0f);
+        const float c = kc::div_rn(
+            kc::div_rn(sum, static_cast<float>(a.P)) + end_err, 2.0f);
         total = accum(total, a.w_path, c);
       }
     }
@@ -399,10 +399,10 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
       for (int i = 0; i < a.P; ++i) best = m[i] < best ? m[i] : best;
       const float min_d2 = static_cast<float>(best);
       const float dist =
-          static_cast<float>(__dsqrt_rn(static_cast<double>(min_d2)));
+          static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
       float v = a.max_obs_dist - dist;
       v = v < 0.0f ? 0.0f : v;
-      total = accum(total, a.w_obs, __fdiv_rn(v, a.max_obs_dist));
+      total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
     }
     if (a.have_vel) {
       const int nv = a.P - 1;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
           if (a.acc1 > 0) c = sq_over(c, vy[i] - vy[i - 1], a.acc1);
           if (a.acc2 > 0) c = sq_over(c, om[i] - om[i - 1], a.acc2);
         }
-        total = accum(total, a.w_smooth, __fdiv_rn(c, div));
+        total = accum(total, a.w_smooth, kc::div_rn(c, div));
       }
       if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
         float c = 0.0f;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
           if (a.acc2 > 0)
             c = sq_over(c, om[i] - 2 * om[i - 1] + om[i - 2], a.acc2);
         }
-        total = accum(total, a.w_jerk, __fdiv_rn(c, div));
+        total = accum(total, a.w_jerk, kc::div_rn(c, div));
       }
     }
     // constant-velocity samples: both terms are exactly 0 and `total += w*0`

@@ -149,6 +149,14 @@ struct Timing {
   }
 };
 
+// ---- correctly rounded f32 divide / sqrt on the device ----------------------
+// HIP's __fsqrt_rn lowers to the *native* (approximate) sqrt unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined; the plain operators are IEEE
+// correctly rounded under -fhip-fp32-correctly-rounded-divide-sqrt (on here).
+__host__ __device__ inline float div_rn(float a, float b) { return a / b; }
+__host__ __device__ inline float sqrt_rn(float a) { return __builtin_sqrtf(a); }
+__host__ __device__ inline double dsqrt_rn(double a) { return __builtin_sqrt(a); }
+
 // ---- packed (cost, index) key: signed-comparable int64 ---------------------
 // LowestCost::combine (datatypes/trajectory.h:630-636): lower cost wins, ties
 // go to the lower index.  key = (sortable_i32(cost) << 32) | u32 index; signed

@@ -37,8 +37,8 @@ __global__ void beam_endpoints_kernel(MapGeom g, const float *__restrict__ range
   const float x = static_cast<float>(static_cast<double>(g.pos0) + r * cs.x);
   const float y = static_cast<float>(static_cast<double>(g.pos1) + r * cs.y);
   int2 t;
-  t.x = g.c0 + static_cast<int>(__fdiv_rn(x, g.res));  // trunc toward zero
-  t.y = g.c1 + static_cast<int>(__fdiv_rn(y, g.res));
+  t.x = g.c0 + static_cast<int>(kc::div_rn(x, g.res));  // trunc toward zero
+  t.y = g.c1 + static_cast<int>(kc::div_rn(y, g.res));
   to[b] = t;
 }
 
