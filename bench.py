@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""bench.py -- one controller cycle of kompass_cpp's sampling-controller hot path
+(BASELINE.json configs[1]: DWA diff-drive, 8192 samples x 50 steps, 500x500
+costmap) on N MI355X, through the C ABI of libkompass_hip.so.
+
+A "step" is one full cycle over one batch of synthetic input: host trig table
++ reachable-window occupancy bits (H2D), roll-out + collision kernel, path /
+obstacle cost kernels, ordered cost finalisation + argmin, [N>1: one 8-byte
+RCCL all-reduce(min)], result to the host.  Sensor data, tracked segment and
+the sample lattice are resident in HBM before the timed region starts.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "kompass-core_amd"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(N, P, map_side, S, O):
+    """16 B per trajectory-step (8 B x,y written by the
+    roll-out + 8 B read back by the cost pass) + 20 B per sample (12 B velocity
+    in, 4 B cost out, 4 B admissible flag) + per-cycle constants (bit-packed
+    costmap, tracked segment, obstacle list)."""
+    return 16 * N * P + 20 * N + map_side * map_side // 8 + 12 * S + 8 * O
+
+
+def controller_bench(args, rank, world, local_rank):
+    import kompass_hip as kh
+    import sharding
+    import synthetic as syn
+
+    use_dist = world > 1
+    torch = None
+    if use_dist:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if kh.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device; none visible (no CPU fallback)")
+
+    cfg = args.config
+    base = syn.CONFIGS[cfg]
+    # weak scaling: every rank owns one BASELINE-sized block of the lattice
+    inp = syn.make_controller_inputs(cfg, seed=0)
+    n_vx, n_om = base["n_vx"], base["n_om"]
+    if base["ctr"] == syn.OMNI:
+        vx, vy, om = syn.lattice_omni(n_vx * world, base["n_vy"], n_om)
+    else:
+        vx, vy, om = syn.lattice_nonholonomic(n_vx * world, n_om)
+    n_total = len(vx)
+    first, count = sharding.shard_range(n_total, rank, world)
+    P, S, O = inp["P"], len(inp["seg_xyz"]), len(inp["points"])
+
+    ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1),
+                        inp["octree_res"], inp["dt"], max_samples=n_total, max_points=P,
+                        max_segment=S, max_obstacles=O, acc_limits=inp["acc_limits"], device=local_rank)
+    ctx.set_weights(kh.make_weights(*inp["weights"]))
+    ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+    ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+    ctx.set_samples(vx, vy, om)
+    ctx.set_shard(first, count)
+
+    key_t = None
+    if use_dist:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        key_t = sharding.as_torch_int64(ctx.result_device_ptr(), 4, torch.device("cuda", local_rank))[:1]
+
+    def pose(i):  # a new pose every cycle: nothing can be reused between steps
+        return (0.0, 0.0, 1e-3 * ((i % 7) - 3), 0.0)
+
+    def one_cycle(i):
+        ctx.rollout(pose(i), P)
+        ctx.evaluate()
+        if use_dist:
+            sharding.allreduce_best(key_t)
+            return int(key_t.item())  # D2H + sync, like fetch_result
+        r = ctx.fetch_result()
+        return r
+
+    def barrier():
+        if use_dist:
+            import torch.distributed as dist
+
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_cycle(i)
+    # ---- timed region -----------------------------------------------------
+    ctx.timing_enable(True)
+    kernel_ms = {}
+    lat = []
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        last = one_cycle(i)
+        lat.append(time.perf_counter() - ts)
+        for name, ms in ctx.timings():  # HIP events on the launch stream
+            kernel_ms.setdefault(name, []).append(ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.timing_enable(False)
+    if use_dist:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- result of the last cycle (for the parity check below) -------------
+    if use_dist:
+        found, cost, raw = sharding.key_unpack(last)
+    else:
+        found, cost, raw = bool(last.found), float(last.cost), int(last.raw_index)
+
+    out = None
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        steps_total = n_total * P  # trajectory-steps per cycle over all ranks
+        value = steps_total * args.steps / elapsed
+        dom = max(kernel_ms, key=lambda k: np.mean(kernel_ms[k]))
+        dom_ms = float(np.mean(kernel_ms[dom]))
+        bytes_launch = algorithmic_bytes(count, P, base["map_side"], S, O)
+        achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "trajectory-steps/s", "value": value, "unit": "trajectory-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 roll-out / f32 costs", "data": "synthetic",
+            "config": {
+                "workload": f"{cfg}: DWA {'omni' if base['ctr'] == 2 else 'diff-drive' if base['ctr'] == 1 else 'Ackermann'}, "
+                            f"{count} samples x {P} steps per GPU, {base['map_side']}x{base['map_side']}@0.05 costmap "
+                            f"({O} occupied cells), tracked segment {S} pts, weights path/goal/obstacles",
+                "samples_per_gpu": count, "global_samples": n_total, "points": P,
+                "parallelism": f"sample-shard x{world}" if world > 1 else "single GPU",
+            },
+            "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
+            "latency_min_ms": float(np.min(lat) * 1e3), "latency_max_ms": float(np.max(lat) * 1e3),
+            "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": dom_ms,
+                "note": "VALU/latency-bound path: ~8 MB per cycle (SURVEY 8d); PMC HBM bytes in profiles/",
+            },
+            "winner": {"found": found, "cost": cost, "raw_index": raw},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(inp, vx, vy, om, pose(args.steps - 1), found, cost, raw, args)
+    if use_dist:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return out
+
+
+def cpu_baseline(inp, vx, vy, om, state, found, cost, raw, args):
+    """The oracle (a port of the reference CPU path, `kind: port`) timed on this
+    host's cores on a bounded sample of the same workload, 1 thread (the
+    reference default max_num_threads=1, dwa.py:131) and all cores; also checks
+    the GPU winner of the last timed cycle against it."""
+    from oracle import ko
+
+    rb = inp["robot"]
+    coll = ko.Collision(rb["shape"], rb["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"])
+    coll.update_state(*inp["state"][:3])
+    coll.update_points(inp["points"], True)
+    ox, oy = ko.obstacles_from_points((0, 0, 0), (0, 0, 0, 1), inp["state"], inp["points"])
+    ci = ko.CostInputs(inp["seg_xyz"], 0, inp["acc_at_seg"], inp["ref_len"], np.stack([ox, oy], 1),
+                       np.float32(inp["max_range"]) / np.float32(3.0), inp["acc_limits"],
+                       ko.make_weights(*inp["weights"]))
+    P = inp["P"]
+    ncores = os.cpu_count() or 1
+    n = len(vx)
+    # full-batch parity of the last GPU cycle, all cores
+    t0 = time.perf_counter()
+    oi, oc, na = ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx, vy, om, threads=ncores)
+    t_mt = time.perf_counter() - t0
+    parity = bool((oi >= 0) == found and (not found or (oi == raw and np.float32(oc) == np.float32(cost))))
+    # 1-thread timing on a bounded sample: whole cycles until ~args.cpu_seconds
+    t0 = time.perf_counter()
+    cycles = 0
+    while cycles < 3 or (time.perf_counter() - t0 < args.cpu_seconds and cycles < 1000):
+        ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx, vy, om, threads=1)
+        cycles += 1
+    t_1 = (time.perf_counter() - t0) / cycles
+    return {
+        "value": n * P / t_1, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{cycles} full cycles ({n} samples x {P} steps each), {t_1 * 1e3:.1f} ms per cycle on 1 thread",
+        "all_cores": {"value": n * P / t_mt, "cores": ncores, "seconds": t_mt,
+                      "sample": f"1 full cycle ({n} samples)"},
+        "gpu_matches_cpu_winner": parity, "cpu_winner": {"raw_index": int(oi), "cost": float(oc),
+                                                         "n_admissible": int(na)},
+        "note": "oracle uses a hashed voxel set instead of FCL's octree traversal, so it is faster than the "
+                "real reference CPU path; the ratio is conservative",
+    }
+
+
+def mapper_bench(args):
+    """BASELINE configs[3]: 4096-beam scan into a 1000x1000 grid (not the
+    default bench line; `--mapper`)."""
+    import kompass_hip as kh
+    import synthetic as syn
+    from oracle import ko
+
+    H = W = 1000
+    n = 4096
+    ang, rng = syn.dense_scan(n, 4.0)
+    m = kh.MapperContext(H, W, 0.05, (0, 0, 0), 0.0, n)
+    scans = [rng * (1.0 + 0.01 * ((i % 5) - 2)) for i in range(8)]
+    for i in range(args.warmup):
+        m.scan_to_grid_device(ang, scans[i % 8])
+    m.sync()
+    m.timing_enable(True)
+    kms = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        m.scan_to_grid_device(ang, scans[i % 8])
+        m.sync()
+        for k, v in m.timings():
+            kms.setdefault(k, []).append(v)
+    el = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        g = m.scan_to_grid(ang, scans[i % 8])
+    el_host = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    want = ko.scan_to_grid(H, W, 0.05, (0, 0, 0), 0.0, ang, scans[(args.steps - 1) % 8])
+    t_cpu = time.perf_counter() - t2
+    ray_cells = int((want >= 0).sum())
+    bytes_scan = 4 * H * W + 12 * n + 12 * ray_cells
+    dom = max(kms, key=lambda k: np.mean(kms[k]))
+    dom_ms = float(np.mean(kms[dom]))
+    return {
+        "metric": "scans/s", "value": args.steps / el, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32 grid / f32 endpoints", "data": "synthetic",
+        "config": {"workload": "cfg4: LocalMapper 4096 beams -> 1000x1000@0.05 grid, grid resident on device"},
+        "pcie_inclusive_scans_per_s": args.steps / el_host,
+        "kernels_ms": {k: float(np.mean(v)) for k, v in kms.items()},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_scan / (dom_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_scan / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "scans/s", "cores": 1, "kind": "port",
+                         "sample": "1 scan", "grid_matches": bool(np.array_equal(g, want))},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--mapper", action="store_true", help="bench the LocalMapper (cfg4) instead")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    out = mapper_bench(args) if args.mapper else controller_bench(args, rank, world, local_rank)
+    if rank == 0 and out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

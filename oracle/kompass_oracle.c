@@ -1590,7 +1590,7 @@ typedef struct {
   double dt;
   size_t P;
   const double *vx, *vy, *om;
-  size_t lo, hi;
+  size_t lo, hi, stride;
   float best_cost;
   long best_idx, n_adm;
 } bl_job;
@@ -1602,7 +1602,7 @@ static void *bl_worker(void *arg) {
   j->best_cost = KO_DEFAULT_MIN_DIST;
   j->best_idx = -1;
   j->n_adm = 0;
-  for (size_t k = j->lo; k < j->hi; ++k) {
+  for (size_t k = j->lo; k < j->hi; k += j->stride) {
     if (!rollout_one(j->coll, j->start, j->dt, j->P, j->vx[k], j->vy[k],
                      j->om[k], px, py))
       continue;
@@ -1636,8 +1636,11 @@ long ko_baseline_cycle(ko_coll *coll, const ko_cost_ctx *cx,
     jobs[t].vx = vx;
     jobs[t].vy = vy;
     jobs[t].om = om;
-    jobs[t].lo = n * (size_t)t / (size_t)threads;
-    jobs[t].hi = n * (size_t)(t + 1) / (size_t)threads;
+    /* interleaved assignment (dynamic-like balance of the per-sample tasks of
+     * trajectory_sampler.cpp:192-205) */
+    jobs[t].lo = (size_t)t;
+    jobs[t].hi = n;
+    jobs[t].stride = (size_t)threads;
     if (threads == 1)
       bl_worker(&jobs[t]);
     else
@@ -1648,7 +1651,9 @@ long ko_baseline_cycle(ko_coll *coll, const ko_cost_ctx *cx,
   for (int t = 0; t < threads; ++t) {
     if (threads > 1) pthread_join(tid[t], NULL);
     na += jobs[t].n_adm;
-    if (jobs[t].best_idx >= 0 && jobs[t].best_cost < best) {
+    if (jobs[t].best_idx >= 0 &&
+        (jobs[t].best_cost < best ||
+         (jobs[t].best_cost == best && jobs[t].best_idx < bi))) {
       best = jobs[t].best_cost;
       bi = jobs[t].best_idx;
     }
