@@ -48,6 +48,7 @@ struct RollArgs {
   const int32_t *row;
   const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
   float *px, *py;       // [n][P] sample-major
+  double2 *pos;         // [P][n] step-major double poses (collision pass input)
   uint8_t *flags;       // [n] admissible
   CollDev c;
 };
@@ -151,34 +152,25 @@ __device__ __forceinline__ bool hit_box(const CollDev &c, BitsPtr bits,
 }
 
 // ===========================================================================
-// K1: roll-out + collision gate.  One lane per sample (the recurrence
-// x_{k+1} = x_k + (...) is serial in k and must keep the reference's addition
-// order), 64-sample workgroups so N = 8192 already spreads over 128 CUs.
-// Occupancy bits of the reachable window are staged in LDS; outputs go through
-// an LDS tile so the sample-major rows are written as whole contiguous lines.
+// K1a: roll-out.  One lane per sample: the recurrence x_{k+1} = x_k + (...) is
+// serial in k and keeps the reference's addition order (path.h:24-30).  The
+// float path leaves through an LDS tile so the sample-major rows are written as
+// whole contiguous lines; the double poses go out step-major (coalesced) for
+// the collision pass.
 // ===========================================================================
 constexpr int kRollBlock = 64;
 
 __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);
-  const int nwords = a.c.lds ? a.c.H * a.c.wpr : 0;
   const int P1 = a.P | 1;  // odd row pitch: conflict-free column writes
-  float *tx = reinterpret_cast<float *>(smem + (((size_t)nwords * 4 + 15) & ~(size_t)15));
+  float *tx = reinterpret_cast<float *>(smem);
   float *ty = tx + (size_t)kRollBlock * P1;
 
   const int tid = threadIdx.x;
   const int base = blockIdx.x * kRollBlock;
   const int n = base + tid;
 
-  if (a.c.lds && a.c.enabled) {
-    for (int i = tid; i < nwords; i += kRollBlock) lbits[i] = a.c.bits[i];
-    __syncthreads();
-  }
-
-  bool ok = false;
   if (n < a.n) {
-    ok = true;
     const double vx = a.vx[a.first + n];
     const double vy = a.vy[a.first + n];
     const int r = a.row[a.first + n];
@@ -191,27 +183,13 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
       a.px[(size_t)n * a.P] = fx0;
       a.py[(size_t)n * a.P] = fy0;
     }
-    double2 cs = a.trig[r];
+    const bool want_pos = a.c.enabled != 0;
     for (int k = 0; k + 1 < a.P; ++k) {
-      // yaw_{k+1} row: needed by the box test now, by the next step anyway
-      const double2 cs1 = a.trig[(size_t)(k + 1) * a.A + r];
+      const double2 cs = a.trig[(size_t)k * a.A + r];
       // Path::State::update, datatypes/path.h:24-30
       x += (vx * cs.x - vy * cs.y) * a.dt;
       y += (vx * cs.y + vy * cs.x) * a.dt;
-      if (a.c.enabled) {
-        bool hit;
-        if (a.c.shape == KC_BOX) {
-          hit = a.c.lds ? hit_box(a.c, lbits, x, y, cs1.x, cs1.y)
-                        : hit_box(a.c, a.c.bits, x, y, cs1.x, cs1.y);
-        } else {
-          hit = a.c.lds ? hit_round(a.c, lbits, x, y)
-                        : hit_round(a.c, a.c.bits, x, y);
-        }
-        if (hit) {  // trajectory_sampler.cpp:147-152, drop_samples_ == true
-          ok = false;
-          break;
-        }
-      }
+      if (want_pos) a.pos[(size_t)(k + 1) * a.n + n] = make_double2(x, y);
       const float fx = static_cast<float>(x), fy = static_cast<float>(y);
       if (a.stage) {
         tx[tid * P1 + k + 1] = fx;
@@ -220,9 +198,8 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
         a.px[(size_t)n * a.P + k + 1] = fx;
         a.py[(size_t)n * a.P + k + 1] = fy;
       }
-      cs = cs1;
     }
-    a.flags[n] = ok ? 1 : 0;
+    a.flags[n] = 1;
   }
 
   if (a.stage) {
@@ -250,11 +227,47 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
 }
 
 // ===========================================================================
+// K1b: collision gate.  A sample is dropped as soon as ANY of its poses
+// collides (trajectory_sampler.cpp:147-152 with drop_samples_ == true), so the
+// (step, sample) pairs are independent: one lane per pose, occupancy bits of
+// the reachable window staged in LDS, a hit clears the sample's flag (every
+// writer stores the same 0).
+// ===========================================================================
+constexpr int kCollBlock = 256;
+
+__global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);
+  if (a.c.lds) {
+    const int nwords = a.c.H * a.c.wpr;
+    for (int i = threadIdx.x; i < nwords; i += kCollBlock) lbits[i] = a.c.bits[i];
+    __syncthreads();
+  }
+  const long t = (long)blockIdx.x * kCollBlock + threadIdx.x;
+  if (t >= (long)a.n * (a.P - 1)) return;
+  const int k = static_cast<int>(t / a.n) + 1;  // pose index 1..P-1
+  const int n = static_cast<int>(t - (long)(k - 1) * a.n);
+  const double2 p = a.pos[(size_t)k * a.n + n];
+  bool hit;
+  if (a.c.shape == KC_BOX) {
+    const double2 cs = a.trig[(size_t)k * a.A + a.row[a.first + n]];  // yaw_k
+    hit = a.c.lds ? hit_box(a.c, lbits, p.x, p.y, cs.x, cs.y)
+                  : hit_box(a.c, a.c.bits, p.x, p.y, cs.x, cs.y);
+  } else {
+    hit = a.c.lds ? hit_round(a.c, lbits, p.x, p.y)
+                  : hit_round(a.c, a.c.bits, p.x, p.y);
+  }
+  if (hit) a.flags[n] = 0;
+}
+
+// ===========================================================================
 // K2: per (sample, point) squared distance to the tracked segment, minimised
 // over the segment (pathCostFunc inner loops, cost_evaluator.cpp:120-130).
 // min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt, so one
-// sqrt per point.  Segment coordinates are wave-uniform: they come in through
-// scalar loads and feed VALU ops as SGPR operands.
+// sqrt per point.  The lane of a sample's END point also keeps the first
+// argmin: that is exactly goalCostFunc's closest-point search
+// (cost_evaluator.cpp:157-166; (a-b)^2 == (b-a)^2 bit for bit).  Segment
+// coordinates are wave-uniform: scalar loads feeding VALU ops as SGPRs.
 // ===========================================================================
 constexpr int kPairBlock = 256;
 
@@ -262,13 +275,15 @@ __global__ __launch_bounds__(kPairBlock) void path_min_kernel(
     const float *__restrict__ px, const float *__restrict__ py,
     const uint8_t *__restrict__ flags, int n, int P,
     const float *__restrict__ sx, const float *__restrict__ sy,
-    const float *__restrict__ szz, int S, float *__restrict__ mind) {
+    const float *__restrict__ szz, int S, float *__restrict__ mind,
+    float *__restrict__ goal_d2, int *__restrict__ goal_arg) {
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
   if (t >= (long)n * P) return;
   const int s = static_cast<int>(t / P);
   if (!flags[s]) return;
   const float x = px[t], y = py[t];
   float best = FLT_MAX;
+  int arg = 0;
 #pragma unroll 8
   for (int j = 0; j < S; ++j) {
     const float dx = sx[j] - x;
@@ -276,34 +291,85 @@ __global__ __launch_bounds__(kPairBlock) void path_min_kernel(
     const float xx = dx * dx;
     const float yy = dy * dy;
     const float d = xx + (yy + szz[j]);  // Eigen 3-term order a + (b + c)
-    best = d < best ? d : best;
+    const bool lt = d < best;
+    best = lt ? d : best;
+    arg = lt ? j : arg;
   }
   mind[t] = kc::sqrt_rn(best);
+  if (t - (long)s * P == P - 1) {
+    goal_d2[s] = best;
+    goal_arg[s] = arg;
+  }
 }
 
 // ===========================================================================
-// K3: per (sample, point) squared distance to the obstacle points, minimised
-// over the obstacles (TrajectoryPath::minDist2D, trajectory.h:218-235):
-// float difference, squares and sum in double, rounded to float once.  The
-// rounding is monotonic, so the minimum is taken in double and rounded later.
+// K3: per (sample, point) squared distance to the nearest obstacle point
+// (TrajectoryPath::minDist2D, trajectory.h:218-235): float difference, squares
+// and sum in double, rounded to float once; the rounding is monotonic, so the
+// minimum is taken in double and rounded later.  Instead of the reference's
+// brute force over all O obstacles the points are bucketed on a uniform grid
+// (host, once per sensor update) and searched outwards in growing square
+// blocks of cells.  The result is the SAME minimum: a block of half-width m
+// cells contains every obstacle closer than m*g to the query, so once the best
+// squared distance is below (m*g)^2 (minus a 1e-6 relative guard, four orders
+// above the float rounding of the differences) nothing outside can beat it;
+// distances >= max_obstacles_dist all give cost 0, so the search also stops
+// once m*g covers that range.
 // ===========================================================================
+struct BucketDev {
+  int W, H;            // cells
+  double gx0, gy0;     // origin
+  double g, inv_g;     // cell edge
+  double cap;          // max_obstacles_dist * 1.001 (search never needs more)
+  const int *cell_start;   // [W*H + 1]
+  const float *bx, *by;    // obstacle coordinates in cell order
+};
+
 __global__ __launch_bounds__(kPairBlock) void obstacle_min_kernel(
     const float *__restrict__ px, const float *__restrict__ py,
-    const uint8_t *__restrict__ flags, int n, int P,
-    const float *__restrict__ ox, const float *__restrict__ oy, int O,
+    const uint8_t *__restrict__ flags, int n, int P, BucketDev b,
     double *__restrict__ omin) {
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
   if (t >= (long)n * P) return;
   const int s = static_cast<int>(t / P);
   if (!flags[s]) return;
   const float x = px[t], y = py[t];
+  // query cell (clamped: a query outside the grid searches from the border,
+  // which only makes the block guarantee more conservative)
+  const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+  const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+  int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+  // distance from the query to the grid (0 inside): cells start that far away
+  double off = 0.0;
+  if (fx < 0.0) off = fmax(off, -fx);
+  if (fy < 0.0) off = fmax(off, -fy);
+  if (fx > b.W) off = fmax(off, fx - b.W);
+  if (fy > b.H) off = fmax(off, fy - b.H);
+  cx = min(max(cx, 0), b.W - 1);
+  cy = min(max(cy, 0), b.H - 1);
   double best = DBL_MAX;
-#pragma unroll 4
-  for (int j = 0; j < O; ++j) {
-    const double dx = static_cast<double>(ox[j] - x);
-    const double dy = static_cast<double>(oy[j] - y);
-    const double d = dx * dx + dy * dy;
-    best = d < best ? d : best;
+  const int mmax = max(b.W, b.H);
+  for (int m = 1;; m = 2 * m + 1) {
+    const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+    const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+    for (int row = y0; row <= y1; ++row) {
+      const int beg = b.cell_start[row * b.W + x0];
+      const int end = b.cell_start[row * b.W + x1 + 1];
+      for (int j = beg; j < end; ++j) {
+        const double dx = static_cast<double>(b.bx[j] - x);
+        const double dy = static_cast<double>(b.by[j] - y);
+        const double d = dx * dx + dy * dy;
+        best = d < best ? d : best;
+      }
+    }
+    // every obstacle closer than `reach` (true distance) has been visited
+    const double reach = (static_cast<double>(m) - off) * b.g;
+    if (reach > 0.0) {
+      const double r2 = reach * reach * (1.0 - 1e-6);
+      if (best < r2) break;
+      if (reach >= b.cap) break;
+    }
+    if (m >= mmax) break;  // whole grid visited
   }
   omin[t] = best;
 }
@@ -323,6 +389,8 @@ struct FinalArgs {
   const float *sx, *sy, *sz, *acc_seg;
   float seg_len, ref_len;
   const float *mind;
+  const float *goal_d2;
+  const int *goal_arg;
   const double *omin;
   const float *vvx, *vvy, *vom;  // [n][P-1] when have_vel
   float max_obs_dist;
@@ -362,17 +430,10 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
     float total = 0.0f;
     if (a.ref_len > 0.0f) {
       if (a.w_goal > 0.0) {
-        // goalCostFunc, cost_evaluator.cpp:150-177
-        const float ex = px[a.P - 1], ey = py[a.P - 1];
-        float best = FLT_MAX;
-        int arg = 0;
-        for (int j = 0; j < a.S; ++j) {
-          const float d = dist_sq3(ex, ey, 0.0f, a.sx[j], a.sy[j], a.sz[j]);
-          if (d < best) {
-            best = d;
-            arg = j;
-          }
-        }
+        // goalCostFunc, cost_evaluator.cpp:150-177; the closest-point search
+        // ran in K2 (first minimum, strict <)
+        const float best = a.goal_d2[n];
+        const int arg = a.goal_arg[n];
         const float arc = kc::div_rn(a.ref_len - a.acc_seg[arg], a.ref_len);
         const float c = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
         total = accum(total, a.w_goal, c);
@@ -549,7 +610,9 @@ struct kc_dwa {
   DevBuf<uint32_t> d_bits;
   PinBuf<double> h_ddz;
   DevBuf<double> d_ddz;
-  DevBuf<float> d_px, d_py, d_mind, d_costs;
+  DevBuf<float> d_px, d_py, d_mind, d_costs, d_goal_d2;
+  DevBuf<int> d_goal_arg;
+  DevBuf<double2> d_pos;
   DevBuf<double> d_omin;
   DevBuf<uint8_t> d_flags;
   DevBuf<float> d_vvx, d_vvy, d_vom;  // kc_cost_evaluate velocities
@@ -560,8 +623,14 @@ struct kc_dwa {
   float seg_len = 0.f, ref_len = 0.f, max_obs_dist = 0.f;
   PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
   DevBuf<float> d_seg;
-  PinBuf<float> h_obs;  // ox | oy
-  DevBuf<float> d_obs;
+  PinBuf<float> h_obs;  // ox | oy (sensor order, as setPointScan stores them)
+  // obstacle buckets for the exact nearest-obstacle search (K3)
+  BucketDev bucket{};
+  PinBuf<int> h_cells;
+  DevBuf<int> d_cells;
+  PinBuf<float> h_bobs;  // bx | by in cell order
+  DevBuf<float> d_bobs;
+  size_t n_bucketed = 0;
 
   DevBuf<long long> d_result;  // key, n_adm, compact index, scratch
   PinBuf<long long> h_result;
@@ -608,12 +677,83 @@ void add_voxel(kc_dwa *c, float px, float py, float pz) {
   c->vox_ky.push_back(static_cast<int32_t>(fy));
 }
 
+// Bucket the world-frame obstacle points (h_obs) on a uniform grid and upload
+// them in cell order.  Non-finite points can never win `dist < minDist`
+// (trajectory.h:229) and are left out.
 int upload_obstacles(kc_dwa *c, size_t n) {
   c->O = n;
+  c->n_bucketed = 0;
   if (n == 0) return KC_OK;
-  KC_TRY(c->d_obs.reserve(2 * n));
-  KC_HIP(hipMemcpyAsync(c->d_obs.p, c->h_obs.p, 2 * n * sizeof(float),
+  const float *ox = c->h_obs.p, *oy = c->h_obs.p + n;
+  double lox = DBL_MAX, loy = DBL_MAX, hix = -DBL_MAX, hiy = -DBL_MAX;
+  size_t nf = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (!std::isfinite(ox[i]) || !std::isfinite(oy[i])) continue;
+    lox = std::min(lox, static_cast<double>(ox[i]));
+    loy = std::min(loy, static_cast<double>(oy[i]));
+    hix = std::max(hix, static_cast<double>(ox[i]));
+    hiy = std::max(hiy, static_cast<double>(oy[i]));
+    ++nf;
+  }
+  BucketDev &b = c->bucket;
+  std::memset(&b, 0, sizeof(b));
+  b.cap = static_cast<double>(c->max_obs_dist) * 1.001;
+  if (nf == 0) {  // nothing can ever be closer than FLT_MAX
+    b.W = b.H = 1;
+    b.g = 1.0;
+    b.inv_g = 1.0;
+    KC_TRY(c->h_cells.reserve(2));
+    KC_TRY(c->d_cells.reserve(2));
+    c->h_cells.p[0] = c->h_cells.p[1] = 0;
+    KC_HIP(hipMemcpyAsync(c->d_cells.p, c->h_cells.p, 2 * sizeof(int),
+                          hipMemcpyHostToDevice, c->stream));
+    KC_TRY(c->d_bobs.reserve(2));
+    b.cell_start = c->d_cells.p;
+    b.bx = c->d_bobs.p;
+    b.by = c->d_bobs.p + 1;
+    return KC_OK;
+  }
+  constexpr int kMaxSide = 128;
+  const double ext = std::max(hix - lox, hiy - loy);
+  b.g = std::max(0.25, ext / (kMaxSide - 1));
+  b.inv_g = 1.0 / b.g;
+  b.gx0 = lox;
+  b.gy0 = loy;
+  b.W = std::min(kMaxSide, static_cast<int>(std::floor((hix - lox) * b.inv_g)) + 1);
+  b.H = std::min(kMaxSide, static_cast<int>(std::floor((hiy - loy) * b.inv_g)) + 1);
+  const size_t ncell = static_cast<size_t>(b.W) * b.H;
+  KC_TRY(c->h_cells.reserve(ncell + 1));
+  KC_TRY(c->d_cells.reserve(ncell + 1));
+  KC_TRY(c->h_bobs.reserve(2 * nf));
+  KC_TRY(c->d_bobs.reserve(2 * nf));
+  int *cs = c->h_cells.p;
+  std::fill(cs, cs + ncell + 1, 0);
+  auto cell_of = [&](size_t i) {
+    int cx = static_cast<int>(std::floor((static_cast<double>(ox[i]) - b.gx0) * b.inv_g));
+    int cy = static_cast<int>(std::floor((static_cast<double>(oy[i]) - b.gy0) * b.inv_g));
+    cx = std::min(std::max(cx, 0), b.W - 1);
+    cy = std::min(std::max(cy, 0), b.H - 1);
+    return static_cast<size_t>(cy) * b.W + cx;
+  };
+  for (size_t i = 0; i < n; ++i)
+    if (std::isfinite(ox[i]) && std::isfinite(oy[i])) cs[cell_of(i) + 1]++;
+  for (size_t k = 0; k < ncell; ++k) cs[k + 1] += cs[k];
+  std::vector<int> cursor(cs, cs + ncell);
+  float *bx = c->h_bobs.p, *by = c->h_bobs.p + nf;
+  for (size_t i = 0; i < n; ++i) {
+    if (!std::isfinite(ox[i]) || !std::isfinite(oy[i])) continue;
+    const int dst = cursor[cell_of(i)]++;
+    bx[dst] = ox[i];
+    by[dst] = oy[i];
+  }
+  KC_HIP(hipMemcpyAsync(c->d_cells.p, cs, (ncell + 1) * sizeof(int),
                         hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipMemcpyAsync(c->d_bobs.p, c->h_bobs.p, 2 * nf * sizeof(float),
+                        hipMemcpyHostToDevice, c->stream));
+  b.cell_start = c->d_cells.p;
+  b.bx = c->d_bobs.p;
+  b.by = c->d_bobs.p + nf;
+  c->n_bucketed = nf;
   return KC_OK;
 }
 
@@ -740,14 +880,16 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
   const float *seg = c->d_seg.p;
   const size_t S = c->S;
-  if (use_path) {
+  if (use_path || use_goal) {
     KC_TRY(c->d_mind.reserve(n * P));
+    KC_TRY(c->d_goal_d2.reserve(n));
+    KC_TRY(c->d_goal_arg.reserve(n));
     KC_TRY(c->timing.start("path_min_kernel", s));
     hipLaunchKernelGGL(path_min_kernel, dim3(blocks_for(n * P, kPairBlock)),
                        dim3(kPairBlock), 0, s, c->d_px.p, c->d_py.p,
                        c->d_flags.p, static_cast<int>(n), static_cast<int>(P),
                        seg, seg + S, seg + 3 * S, static_cast<int>(S),
-                       c->d_mind.p);
+                       c->d_mind.p, c->d_goal_d2.p, c->d_goal_arg.p);
     KC_TRY(c->timing.stop(s));
   }
   if (use_obs) {
@@ -756,8 +898,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     hipLaunchKernelGGL(obstacle_min_kernel,
                        dim3(blocks_for(n * P, kPairBlock)), dim3(kPairBlock),
                        0, s, c->d_px.p, c->d_py.p, c->d_flags.p,
-                       static_cast<int>(n), static_cast<int>(P), c->d_obs.p,
-                       c->d_obs.p + c->O, static_cast<int>(c->O),
+                       static_cast<int>(n), static_cast<int>(P), c->bucket,
                        c->d_omin.p);
     KC_TRY(c->timing.stop(s));
   }
@@ -778,6 +919,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   fa.seg_len = c->seg_len;
   fa.ref_len = c->ref_len;
   fa.mind = c->d_mind.p;
+  fa.goal_d2 = c->d_goal_d2.p;
+  fa.goal_arg = c->d_goal_arg.p;
   fa.omin = c->d_omin.p;
   fa.vvx = c->d_vvx.p;
   fa.vvy = c->d_vvy.p;
@@ -894,8 +1037,9 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       (rc = ensure_cycle_buffers(c, p->max_samples, p->max_points)) ||
       (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
       (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
-      (rc = c->d_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
-      (rc = c->h_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
+      (rc = c->h_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
+      (rc = c->d_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
+      (rc = c->h_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
     return fail(rc);
   *out = c;
   return KC_OK;
@@ -931,7 +1075,13 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_seg.release();
   c->d_seg.release();
   c->h_obs.release();
-  c->d_obs.release();
+  c->h_cells.release();
+  c->d_cells.release();
+  c->h_bobs.release();
+  c->d_bobs.release();
+  c->d_goal_d2.release();
+  c->d_goal_arg.release();
+  c->d_pos.release();
   c->d_result.release();
   c->h_result.release();
   c->h_row.release();
@@ -1169,18 +1319,24 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   a.px = c->d_px.p;
   a.py = c->d_py.p;
   a.flags = c->d_flags.p;
-  const size_t bits_bytes =
-      (a.c.lds && a.c.enabled)
-          ? ((static_cast<size_t>(a.c.H) * a.c.wpr * 4 + 15) & ~size_t(15))
-          : 0;
-  if (!(a.c.lds && a.c.enabled)) a.c.lds = 0;
+  if (a.c.enabled) {
+    KC_TRY(c->d_pos.reserve(n * P));
+    a.pos = c->d_pos.p;
+  }
   const size_t tile_bytes = 2 * static_cast<size_t>(kRollBlock) * (P | 1) * 4;
-  a.stage = (bits_bytes + tile_bytes <= 64 * 1024) ? 1 : 0;
-  const size_t smem = bits_bytes + (a.stage ? tile_bytes : 0);
+  a.stage = (tile_bytes <= 64 * 1024) ? 1 : 0;
   KC_TRY(c->timing.start("rollout_kernel", s));
   hipLaunchKernelGGL(rollout_kernel, dim3(blocks_for(n, kRollBlock)),
-                     dim3(kRollBlock), smem, s, a);
+                     dim3(kRollBlock), a.stage ? tile_bytes : 0, s, a);
   KC_TRY(c->timing.stop(s));
+  if (a.c.enabled) {
+    const size_t bits_bytes = static_cast<size_t>(a.c.H) * a.c.wpr * 4;
+    KC_TRY(c->timing.start("collision_kernel", s));
+    hipLaunchKernelGGL(collision_kernel,
+                       dim3(blocks_for(n * (P - 1), kCollBlock)),
+                       dim3(kCollBlock), a.c.lds ? bits_bytes : 0, s, a);
+    KC_TRY(c->timing.stop(s));
+  }
   KC_HIP(hipGetLastError());
   c->rolled = true;
   return KC_OK;
