@@ -106,7 +106,7 @@ def controller_bench(args, rank, world, local_rank):
         one_cycle(i)
     # ---- timed region -----------------------------------------------------
     ctx.timing_enable(True)
-    kernel_ms = {}
+    kernel_ms, host_ms = {}, {}
     lat = []
     barrier()
     t0 = time.perf_counter()
@@ -115,8 +115,8 @@ def controller_bench(args, rank, world, local_rank):
         ts = time.perf_counter()
         last = one_cycle(i)
         lat.append(time.perf_counter() - ts)
-        for name, ms in ctx.timings():  # HIP events on the launch stream
-            kernel_ms.setdefault(name, []).append(ms)
+        for name, ms in ctx.timings():  # HIP events on the launch stream (+ host phases)
+            (host_ms if name.startswith("host:") else kernel_ms).setdefault(name, []).append(ms)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.timing_enable(False)
@@ -157,6 +157,7 @@ def controller_bench(args, rank, world, local_rank):
             "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
             "latency_min_ms": float(np.min(lat) * 1e3), "latency_max_ms": float(np.max(lat) * 1e3),
             "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
+            "host_phases_ms": {k: float(np.mean(v)) for k, v in host_ms.items()},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,

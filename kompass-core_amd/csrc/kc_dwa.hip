@@ -16,6 +16,7 @@
 
 #include "kc_hostmath.h"
 #include "kc_internal.h"
+#include "kc_pool.h"
 
 namespace kc {
 
@@ -184,19 +185,33 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
       a.py[(size_t)n * a.P] = fy0;
     }
     const bool want_pos = a.c.enabled != 0;
-    for (int k = 0; k + 1 < a.P; ++k) {
-      const double2 cs = a.trig[(size_t)k * a.A + r];
-      // Path::State::update, datatypes/path.h:24-30
-      x += (vx * cs.x - vy * cs.y) * a.dt;
-      y += (vx * cs.y + vy * cs.x) * a.dt;
-      if (want_pos) a.pos[(size_t)(k + 1) * a.n + n] = make_double2(x, y);
-      const float fx = static_cast<float>(x), fy = static_cast<float>(y);
-      if (a.stage) {
-        tx[tid * P1 + k + 1] = fx;
-        ty[tid * P1 + k + 1] = fy;
-      } else {
-        a.px[(size_t)n * a.P + k + 1] = fx;
-        a.py[(size_t)n * a.P + k + 1] = fy;
+    // all trig rows of (up to) 64 steps are requested at once and held in
+    // registers, so the serial recurrence pays the memory latency once
+    constexpr int CH = 64;
+    double2 tr[CH];
+    const int steps = a.P - 1;
+    for (int k0 = 0; k0 < steps; k0 += CH) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        tr[j] = a.trig[(size_t)min(k0 + j, steps - 1) * a.A + r];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int k = k0 + j;
+        if (k < steps) {
+          const double2 cs = tr[j];
+          // Path::State::update, datatypes/path.h:24-30
+          x += (vx * cs.x - vy * cs.y) * a.dt;
+          y += (vx * cs.y + vy * cs.x) * a.dt;
+          if (want_pos) a.pos[(size_t)(k + 1) * a.n + n] = make_double2(x, y);
+          const float fx = static_cast<float>(x), fy = static_cast<float>(y);
+          if (a.stage) {
+            tx[tid * P1 + k + 1] = fx;
+            ty[tid * P1 + k + 1] = fy;
+          } else {
+            a.px[(size_t)n * a.P + k + 1] = fx;
+            a.py[(size_t)n * a.P + k + 1] = fy;
+          }
+        }
       }
     }
     a.flags[n] = 1;
@@ -261,61 +276,34 @@ __global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
 }
 
 // ===========================================================================
-// K2: per (sample, point) squared distance to the tracked segment, minimised
-// over the segment (pathCostFunc inner loops, cost_evaluator.cpp:120-130).
-// min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt, so one
-// sqrt per point.  The lane of a sample's END point also keeps the first
-// argmin: that is exactly goalCostFunc's closest-point search
-// (cost_evaluator.cpp:157-166; (a-b)^2 == (b-a)^2 bit for bit).  Segment
-// coordinates are wave-uniform: scalar loads feeding VALU ops as SGPRs.
-// ===========================================================================
-constexpr int kPairBlock = 256;
-
-__global__ __launch_bounds__(kPairBlock) void path_min_kernel(
-    const float *__restrict__ px, const float *__restrict__ py,
-    const uint8_t *__restrict__ flags, int n, int P,
-    const float *__restrict__ sx, const float *__restrict__ sy,
-    const float *__restrict__ szz, int S, float *__restrict__ mind,
-    float *__restrict__ goal_d2, int *__restrict__ goal_arg) {
-  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  if (t >= (long)n * P) return;
-  const int s = static_cast<int>(t / P);
-  if (!flags[s]) return;
-  const float x = px[t], y = py[t];
-  float best = FLT_MAX;
-  int arg = 0;
-#pragma unroll 8
-  for (int j = 0; j < S; ++j) {
-    const float dx = sx[j] - x;
-    const float dy = sy[j] - y;
-    const float xx = dx * dx;
-    const float yy = dy * dy;
-    const float d = xx + (yy + szz[j]);  // Eigen 3-term order a + (b + c)
-    const bool lt = d < best;
-    best = lt ? d : best;
-    arg = lt ? j : arg;
-  }
-  mind[t] = kc::sqrt_rn(best);
-  if (t - (long)s * P == P - 1) {
-    goal_d2[s] = best;
-    goal_arg[s] = arg;
-  }
-}
-
-// ===========================================================================
-// K3: per (sample, point) squared distance to the nearest obstacle point
-// (TrajectoryPath::minDist2D, trajectory.h:218-235): float difference, squares
-// and sum in double, rounded to float once; the rounding is monotonic, so the
-// minimum is taken in double and rounded later.  Instead of the reference's
-// brute force over all O obstacles the points are bucketed on a uniform grid
-// (host, once per sensor update) and searched outwards in growing square
-// blocks of cells.  The result is the SAME minimum: a block of half-width m
-// cells contains every obstacle closer than m*g to the query, so once the best
-// squared distance is below (m*g)^2 (minus a 1e-6 relative guard, four orders
-// above the float rounding of the differences) nothing outside can beat it;
+// K2+K3: per (sample, point) nearest tracked-segment point and nearest
+// obstacle point, one lane per trajectory point.
+//
+// Segment part (pathCostFunc inner loops, cost_evaluator.cpp:120-130, and
+// goalCostFunc's closest-point search, :157-166): d2 = dx*dx + (dy*dy + dz*dz)
+// in float, minimised over the segment; min_j sqrt(d2_j) == sqrt(min_j d2_j)
+// for the correctly rounded sqrt, so one sqrt per point; the lane of a sample's
+// END point also keeps the first argmin ((a-b)^2 == (b-a)^2 bit for bit).
+// The reference scans all S segment points; here consecutive runs of 16 points
+// carry a bounding sphere (host, once per segment) and a run is skipped when
+// its sphere cannot contain a point at or below the best distance so far
+// (1e-6 relative guard, four orders above the float rounding) -- the minimum
+// and its first index are unchanged.
+//
+// Obstacle part (TrajectoryPath::minDist2D, trajectory.h:218-235): float
+// difference, squares and sum in double, rounded to float once; the rounding
+// is monotonic, so the minimum is taken in double and rounded later.  Instead
+// of the reference's brute force over all O obstacles the points are bucketed
+// on a uniform grid (host, once per sensor update) and searched outwards in
+// growing square blocks of cells.  A block of half-width m cells contains
+// every obstacle closer than m*g to the query, so once the best squared
+// distance is below (m*g)^2 (same guard) nothing outside can beat it;
 // distances >= max_obstacles_dist all give cost 0, so the search also stops
 // once m*g covers that range.
 // ===========================================================================
+constexpr int kPairBlock = 256;
+constexpr int kSegRun = 16;
+
 struct BucketDev {
   int W, H;            // cells
   double gx0, gy0;     // origin
@@ -325,61 +313,132 @@ struct BucketDev {
   const float *bx, *by;    // obstacle coordinates in cell order
 };
 
-__global__ __launch_bounds__(kPairBlock) void obstacle_min_kernel(
-    const float *__restrict__ px, const float *__restrict__ py,
-    const uint8_t *__restrict__ flags, int n, int P, BucketDev b,
-    double *__restrict__ omin) {
+struct PairArgs {
+  const float *px, *py;
+  const uint8_t *flags;
+  int n, P;
+  int use_seg, use_obs;
+  // tracked segment
+  const float *sx, *sy, *szz;
+  int S, nruns;
+  const double4 *runs;  // per run: centre (x, y, z) and radius
+  float *mind, *goal_d2;
+  int *goal_arg;
+  // obstacles
+  BucketDev b;
+  double *omin;
+};
+
+__global__ __launch_bounds__(kPairBlock) void pair_cost_kernel(PairArgs a) {
   const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  if (t >= (long)n * P) return;
-  const int s = static_cast<int>(t / P);
-  if (!flags[s]) return;
-  const float x = px[t], y = py[t];
-  // query cell (clamped: a query outside the grid searches from the border,
-  // which only makes the block guarantee more conservative)
-  const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-  const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-  int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-  // distance from the query to the grid (0 inside): cells start that far away
-  double off = 0.0;
-  if (fx < 0.0) off = fmax(off, -fx);
-  if (fy < 0.0) off = fmax(off, -fy);
-  if (fx > b.W) off = fmax(off, fx - b.W);
-  if (fy > b.H) off = fmax(off, fy - b.H);
-  cx = min(max(cx, 0), b.W - 1);
-  cy = min(max(cy, 0), b.H - 1);
-  double best = DBL_MAX;
-  const int mmax = max(b.W, b.H);
-  for (int m = 1;; m = 2 * m + 1) {
-    const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-    const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-    for (int row = y0; row <= y1; ++row) {
-      const int beg = b.cell_start[row * b.W + x0];
-      const int end = b.cell_start[row * b.W + x1 + 1];
-      for (int j = beg; j < end; ++j) {
-        const double dx = static_cast<double>(b.bx[j] - x);
-        const double dy = static_cast<double>(b.by[j] - y);
-        const double d = dx * dx + dy * dy;
-        best = d < best ? d : best;
+  if (t >= (long)a.n * a.P) return;
+  const int s = static_cast<int>(t / a.P);
+  if (!a.flags[s]) return;
+  const float x = a.px[t], y = a.py[t];
+
+  if (a.use_seg) {
+    const double qx = static_cast<double>(x), qy = static_cast<double>(y);
+    // nearest run centre first: a good bound before anything is skipped
+    int r0 = 0;
+    double c0 = DBL_MAX;
+    for (int r = 0; r < a.nruns; ++r) {
+      const double4 c = a.runs[r];
+      const double dx = c.x - qx, dy = c.y - qy;
+      const double d = dx * dx + dy * dy + c.z * c.z;
+      if (d < c0) {
+        c0 = d;
+        r0 = r;
       }
     }
-    // every obstacle closer than `reach` (true distance) has been visited
-    const double reach = (static_cast<double>(m) - off) * b.g;
-    if (reach > 0.0) {
-      const double r2 = reach * reach * (1.0 - 1e-6);
-      if (best < r2) break;
-      if (reach >= b.cap) break;
+    float best = FLT_MAX;
+    int arg = 0;
+    double sb = DBL_MAX;  // sqrt(best) with the guard
+    for (int pass = 0; pass < 2; ++pass) {
+      const int rb = pass == 0 ? r0 : 0;
+      const int re = pass == 0 ? r0 + 1 : a.nruns;
+      for (int r = rb; r < re; ++r) {
+        if (pass == 1) {
+          if (r == r0) continue;
+          const double4 c = a.runs[r];
+          const double dx = c.x - qx, dy = c.y - qy;
+          const double dc2 = dx * dx + dy * dy + c.z * c.z;
+          const double lim = c.w + sb;
+          if (sb < 1e300 && dc2 > lim * lim) continue;  // cannot reach best
+        }
+        const int j0 = r * kSegRun, j1 = min(j0 + kSegRun, a.S);
+        bool improved = false;
+        for (int j = j0; j < j1; ++j) {
+          const float dx = a.sx[j] - x;
+          const float dy = a.sy[j] - y;
+          const float xx = dx * dx;
+          const float yy = dy * dy;
+          const float d = xx + (yy + a.szz[j]);  // Eigen order a + (b + c)
+          // first minimum in index order, whatever the visiting order
+          if (d < best || (d == best && j < arg)) {
+            best = d;
+            arg = j;
+            improved = true;
+          }
+        }
+        if (improved)
+          sb = kc::dsqrt_rn(static_cast<double>(best)) * (1.0 + 1e-6) + 1e-30;
+      }
     }
-    if (m >= mmax) break;  // whole grid visited
+    a.mind[t] = kc::sqrt_rn(best);
+    if (t - (long)s * a.P == a.P - 1) {
+      a.goal_d2[s] = best;
+      a.goal_arg[s] = arg;
+    }
   }
-  omin[t] = best;
+
+  if (a.use_obs) {
+    const BucketDev &b = a.b;
+    // query cell (clamped: a query outside the grid searches from the border
+    // and the guarantee radius shrinks by its distance to the grid)
+    const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+    const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+    int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+    double off = 0.0;
+    if (fx < 0.0) off = fmax(off, -fx);
+    if (fy < 0.0) off = fmax(off, -fy);
+    if (fx > b.W) off = fmax(off, fx - b.W);
+    if (fy > b.H) off = fmax(off, fy - b.H);
+    cx = min(max(cx, 0), b.W - 1);
+    cy = min(max(cy, 0), b.H - 1);
+    double best = DBL_MAX;
+    const int mmax = max(b.W, b.H);
+    for (int m = 1;; m = 2 * m + 1) {
+      const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+      const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+      for (int row = y0; row <= y1; ++row) {
+        const int beg = b.cell_start[row * b.W + x0];
+        const int end = b.cell_start[row * b.W + x1 + 1];
+        for (int j = beg; j < end; ++j) {
+          const double dx = static_cast<double>(b.bx[j] - x);
+          const double dy = static_cast<double>(b.by[j] - y);
+          const double dd = dx * dx + dy * dy;
+          best = dd < best ? dd : best;
+        }
+      }
+      // every obstacle closer than `reach` (true distance) has been visited
+      const double reach = (static_cast<double>(m) - off) * b.g;
+      if (reach > 0.0) {
+        const double r2 = reach * reach * (1.0 - 1e-6);
+        if (best < r2) break;
+        if (reach >= b.cap) break;
+      }
+      if (m >= mmax) break;  // whole grid visited
+    }
+    a.omin[t] = best;
+  }
 }
 
 // ===========================================================================
-// K4: one lane per sample: goal cost, ordered path-cost sum, obstacle cost,
-// smoothness / jerk, the weighted total in the reference's accumulation order
-// (cost_evaluator.cpp:59-100: float total, each += a double multiply-add
-// rounded once), then the packed (cost, index) key reduced with wave shuffles
-// and one atomic per workgroup.
+// K4: one wavefront per sample: goal cost, ordered path-cost sum, obstacle
+// cost, smoothness / jerk, the weighted total in the reference's accumulation
+// order (cost_evaluator.cpp:59-100: float total, each += a double multiply-add
+// rounded once), then the packed (cost, index) key: LDS across the block's
+// wavefronts, one atomic per workgroup, last block publishes.
 // ===========================================================================
 struct FinalArgs {
   int n, first, P, S, O;
@@ -397,10 +456,16 @@ struct FinalArgs {
   float acc0, acc1, acc2;
   double w_path, w_goal, w_obs, w_smooth, w_jerk;
   float *costs;
-  long long *result;  // [0] key (atomicMin), [1] admissible count (atomicAdd)
+  long long *result;  // R_* published record + W_* working area (see enum)
 };
 
-constexpr int kFinalBlock = 256;
+constexpr int kFinalBlock = 256;           // 4 wavefronts
+constexpr int kFinalSamples = kFinalBlock / 64;  // one wavefront per sample
+
+// device result record (long long slots)
+enum { R_KEY = 0, R_NADM = 1, R_COMPACT = 2, R_SPARE = 3,   // published
+       W_KEY = 4, W_NADM = 5, W_TICKET = 6, W_SPARE = 7,    // working area
+       R_SCRATCH = 8, R_SLOTS = 10 };
 
 __device__ __forceinline__ float dist_sq3(float ax, float ay, float az,
                                           float bx, float by, float bz) {
@@ -418,13 +483,27 @@ __device__ __forceinline__ float sq_over(float total, float d, float lim) {
   return static_cast<float>(static_cast<double>(total) +
                             (dd * dd) / static_cast<double>(lim));
 }
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 
+// One wavefront per sample.  The per-point values of K2/K3 arrive with one
+// coalesced load per 64 points; the path-cost sum must keep the reference's
+// order (float, i = 0..P-1), so it walks the lanes with v_readlane; the
+// obstacle minimum is order-free and uses shuffles.  All lanes then hold the
+// same (wave-uniform) total.  Keys are reduced across the block's wavefronts
+// through LDS and published with one atomic per block; the block that arrives
+// last turns the winner's raw index into the reference's compacted index
+// (admissible samples in front of it) and re-arms the working area.
 __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
-  const int n = blockIdx.x * kFinalBlock + threadIdx.x;
-  long long key = KEY_NONE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long key = KEY_NONE;  // best of this wavefront's samples
   int adm = 0;
-  if (n < a.n && a.flags[n]) {
-    adm = 1;
+  // few, fat workgroups: the per-block atomics below all hit the same words
+  for (int n = blockIdx.x * kFinalSamples + wave; n < a.n;
+       n += gridDim.x * kFinalSamples) {
+  if (a.flags[n]) {  // wave-uniform
+    adm += 1;
     const float *px = a.px + (size_t)n * a.P;
     const float *py = a.py + (size_t)n * a.P;
     float total = 0.0f;
@@ -442,7 +521,11 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
         // pathCostFunc, cost_evaluator.cpp:111-141
         const float *m = a.mind + (size_t)n * a.P;
         float sum = 0.0f;
-        for (int i = 0; i < a.P; ++i) sum += m[i];
+        for (int base = 0; base < a.P; base += 64) {
+          const int cnt = min(64, a.P - base);
+          const float v = (lane < cnt) ? m[base + lane] : 0.0f;
+          for (int i = 0; i < cnt; ++i) sum += lane_value(v, i);
+        }
         const int e = a.S - 1;
         const float end_err = kc::div_rn(
             kc::sqrt_rn(dist_sq3(px[a.P - 1], py[a.P - 1], 0.0f, a.sx[e],
@@ -457,7 +540,11 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
       // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
       const double *m = a.omin + (size_t)n * a.P;
       double best = DBL_MAX;
-      for (int i = 0; i < a.P; ++i) best = m[i] < best ? m[i] : best;
+      for (int i = lane; i < a.P; i += 64) best = m[i] < best ? m[i] : best;
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(best, off, 64);
+        best = o < best ? o : best;
+      }
       const float min_d2 = static_cast<float>(best);
       const float dist =
           static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
@@ -466,6 +553,8 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
       total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
     }
     if (a.have_vel) {
+      // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
+      // evaluated redundantly by every lane (wave-uniform addresses)
       const int nv = a.P - 1;
       const float *vx = a.vvx + (size_t)n * nv;
       const float *vy = a.vvy + (size_t)n * nv;
@@ -495,22 +584,19 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
     }
     // constant-velocity samples: both terms are exactly 0 and `total += w*0`
     // leaves total unchanged, so nothing to do when !have_vel.
-    a.costs[n] = total;
-    if (total < FLT_MAX)  // `total_cost < minCost`, minCost starts at FLT_MAX
-      key = key_pack(total, static_cast<uint32_t>(a.first + n));
-  } else if (n < a.n) {
-    a.costs[n] = FLT_MAX;
+    if (lane == 0) a.costs[n] = total;
+    if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
+      const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
+      key = k < key ? k : key;
+    }
+  } else {
+    if (lane == 0) a.costs[n] = FLT_MAX;
   }
+  }  // sample loop
 
-  // wave64 min / sum via shuffles, then one LDS hop across the 4 waves
-  for (int off = 32; off > 0; off >>= 1) {
-    const long long ok = __shfl_down(key, off, 64);
-    key = ok < key ? ok : key;
-    adm += __shfl_down(adm, off, 64);
-  }
-  __shared__ long long wkey[kFinalBlock / 64];
-  __shared__ int wadm[kFinalBlock / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ long long wkey[kFinalSamples];
+  __shared__ int wadm[kFinalSamples];
+  __shared__ int is_last;
   if (lane == 0) {
     wkey[wave] = key;
     wadm[wave] = adm;
@@ -519,32 +605,56 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
   if (threadIdx.x == 0) {
     long long k = wkey[0];
     int c = wadm[0];
-    for (int w = 1; w < kFinalBlock / 64; ++w) {
+    for (int w = 1; w < kFinalSamples; ++w) {
       k = wkey[w] < k ? wkey[w] : k;
       c += wadm[w];
     }
-    if (k != KEY_NONE) atomicMin(&a.result[0], k);
-    if (c) atomicAdd(reinterpret_cast<unsigned long long *>(&a.result[1]),
+    if (k != KEY_NONE) atomicMin(&a.result[W_KEY], k);
+    if (c) atomicAdd(reinterpret_cast<unsigned long long *>(&a.result[W_NADM]),
                      static_cast<unsigned long long>(c));
+    __threadfence();
+    const unsigned long long ticket = atomicAdd(
+        reinterpret_cast<unsigned long long *>(&a.result[W_TICKET]), 1ull);
+    is_last = (ticket == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  // ---- last block: publish + compacted index + re-arm -----------------------
+  __threadfence();
+  // atomics are performed at the memory side: these reads see every block
+  const long long fkey = atomicMin(&a.result[W_KEY], KEY_NONE);
+  const long long fadm = static_cast<long long>(atomicAdd(
+      reinterpret_cast<unsigned long long *>(&a.result[W_NADM]), 0ull));
+  int cnt = 0;
+  if (fkey != KEY_NONE) {
+    const long long raw =
+        static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll));
+    long long lim = raw - a.first;
+    if (lim > a.n) lim = a.n;
+    for (long long i = threadIdx.x; i < lim; i += kFinalBlock) cnt += a.flags[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  __shared__ int wsum[kFinalSamples];
+  if (lane == 0) wsum[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kFinalSamples; ++w) s += wsum[w];
+    a.result[R_KEY] = fkey;
+    a.result[R_NADM] = fadm;
+    a.result[R_COMPACT] = (fkey == KEY_NONE) ? -1 : s;
+    a.result[W_KEY] = KEY_NONE;
+    a.result[W_NADM] = 0;
+    a.result[W_TICKET] = 0;
   }
 }
 
-// K5: admissible samples in front of a raw index -> the reference's compacted
-// index (push_back order, trajectory.h:351,440).  target < 0: read the winner
-// from result[0].  One workgroup.
+// admissible samples in front of a raw index (multi-GPU: rebuilds the
+// reference's compacted index across shards).  One workgroup.
 __global__ __launch_bounds__(1024) void count_before_kernel(
     const uint8_t *__restrict__ flags, int n, int first, long long target_raw,
     long long *result, int slot) {
-  long long raw = target_raw;
-  if (raw < 0) {
-    const long long key = result[0];
-    if (key == KEY_NONE) {
-      if (threadIdx.x == 0) result[slot] = -1;
-      return;
-    }
-    raw = static_cast<long long>(static_cast<uint32_t>(key & 0xFFFFFFFFll));
-  }
-  long long lim = raw - first;  // local bound
+  long long lim = target_raw - first;  // local bound
   if (lim > n) lim = n;
   int c = 0;
   for (long long i = threadIdx.x; i < lim; i += 1024) c += flags[i];
@@ -559,11 +669,17 @@ __global__ __launch_bounds__(1024) void count_before_kernel(
   }
 }
 
+// arms the result record (context creation, and the empty-batch case)
 __global__ void init_result_kernel(long long *result) {
-  result[0] = KEY_NONE;
-  result[1] = 0;
-  result[2] = -1;
-  result[3] = 0;
+  result[R_KEY] = KEY_NONE;
+  result[R_NADM] = 0;
+  result[R_COMPACT] = -1;
+  result[R_SPARE] = 0;
+  result[W_KEY] = KEY_NONE;
+  result[W_NADM] = 0;
+  result[W_TICKET] = 0;
+  result[W_SPARE] = 0;
+  result[R_SCRATCH] = 0;
 }
 
 __global__ void fill_u8_kernel(uint8_t *p, int n, uint8_t v) {
@@ -623,6 +739,9 @@ struct kc_dwa {
   float seg_len = 0.f, ref_len = 0.f, max_obs_dist = 0.f;
   PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
   DevBuf<float> d_seg;
+  PinBuf<double4> h_runs;  // bounding spheres of runs of kSegRun segment points
+  DevBuf<double4> d_runs;
+  size_t nruns = 0;
   PinBuf<float> h_obs;  // ox | oy (sensor order, as setPointScan stores them)
   // obstacle buckets for the exact nearest-obstacle search (K3)
   BucketDev bucket{};
@@ -869,9 +988,11 @@ int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
 int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const size_t P = c->P;
   hipStream_t s = c->stream;
-  hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, s,
-                     c->d_result.p);
-  if (n == 0) return KC_OK;
+  if (n == 0) {  // empty batch: publish "nothing found"
+    hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, s,
+                       c->d_result.p);
+    return KC_OK;
+  }
   const bool use_path = c->ref_len > 0.0f &&
                         c->w.reference_path_distance_weight > 0.0;
   const bool use_goal = c->ref_len > 0.0f && c->w.goal_distance_weight > 0.0;
@@ -880,26 +1001,37 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
   const float *seg = c->d_seg.p;
   const size_t S = c->S;
-  if (use_path || use_goal) {
-    KC_TRY(c->d_mind.reserve(n * P));
-    KC_TRY(c->d_goal_d2.reserve(n));
-    KC_TRY(c->d_goal_arg.reserve(n));
-    KC_TRY(c->timing.start("path_min_kernel", s));
-    hipLaunchKernelGGL(path_min_kernel, dim3(blocks_for(n * P, kPairBlock)),
-                       dim3(kPairBlock), 0, s, c->d_px.p, c->d_py.p,
-                       c->d_flags.p, static_cast<int>(n), static_cast<int>(P),
-                       seg, seg + S, seg + 3 * S, static_cast<int>(S),
-                       c->d_mind.p, c->d_goal_d2.p, c->d_goal_arg.p);
-    KC_TRY(c->timing.stop(s));
-  }
-  if (use_obs) {
-    KC_TRY(c->d_omin.reserve(n * P));
-    KC_TRY(c->timing.start("obstacle_min_kernel", s));
-    hipLaunchKernelGGL(obstacle_min_kernel,
-                       dim3(blocks_for(n * P, kPairBlock)), dim3(kPairBlock),
-                       0, s, c->d_px.p, c->d_py.p, c->d_flags.p,
-                       static_cast<int>(n), static_cast<int>(P), c->bucket,
-                       c->d_omin.p);
+  if (use_path || use_goal || use_obs) {
+    PairArgs pa{};
+    pa.px = c->d_px.p;
+    pa.py = c->d_py.p;
+    pa.flags = c->d_flags.p;
+    pa.n = static_cast<int>(n);
+    pa.P = static_cast<int>(P);
+    pa.use_seg = (use_path || use_goal) ? 1 : 0;
+    pa.use_obs = use_obs ? 1 : 0;
+    if (pa.use_seg) {
+      KC_TRY(c->d_mind.reserve(n * P));
+      KC_TRY(c->d_goal_d2.reserve(n));
+      KC_TRY(c->d_goal_arg.reserve(n));
+      pa.sx = seg;
+      pa.sy = seg + S;
+      pa.szz = seg + 3 * S;
+      pa.S = static_cast<int>(S);
+      pa.nruns = static_cast<int>(c->nruns);
+      pa.runs = c->d_runs.p;
+      pa.mind = c->d_mind.p;
+      pa.goal_d2 = c->d_goal_d2.p;
+      pa.goal_arg = c->d_goal_arg.p;
+    }
+    if (use_obs) {
+      KC_TRY(c->d_omin.reserve(n * P));
+      pa.b = c->bucket;
+      pa.omin = c->d_omin.p;
+    }
+    KC_TRY(c->timing.start("pair_cost_kernel", s));
+    hipLaunchKernelGGL(pair_cost_kernel, dim3(blocks_for(n * P, kPairBlock)),
+                       dim3(kPairBlock), 0, s, pa);
     KC_TRY(c->timing.stop(s));
   }
   FinalArgs fa{};
@@ -937,13 +1069,9 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   fa.costs = c->d_costs.p;
   fa.result = c->d_result.p;
   KC_TRY(c->timing.start("finalize_kernel", s));
-  hipLaunchKernelGGL(finalize_kernel, dim3(blocks_for(n, kFinalBlock)),
+  hipLaunchKernelGGL(finalize_kernel,
+                     dim3(std::min(blocks_for(n, kFinalSamples), 256u)),
                      dim3(kFinalBlock), 0, s, fa);
-  KC_TRY(c->timing.stop(s));
-  KC_TRY(c->timing.start("count_before_kernel", s));
-  hipLaunchKernelGGL(count_before_kernel, dim3(1), dim3(1024), 0, s,
-                     c->d_flags.p, static_cast<int>(n),
-                     static_cast<int>(first), -1ll, c->d_result.p, 2);
   KC_TRY(c->timing.stop(s));
   KC_HIP(hipGetLastError());
   return KC_OK;
@@ -953,6 +1081,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
   KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
                         hipMemcpyDeviceToHost, c->stream));
   KC_HIP(hipStreamSynchronize(c->stream));
+  c->timing.mark("host:wait_result");
   kc_result r{};
   const long long key = c->h_result.p[0];
   r.n_admissible = c->h_result.p[1];
@@ -1033,7 +1162,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
   }
   c->stream = c->own_stream;
   int rc;
-  if ((rc = c->d_result.reserve(4)) || (rc = c->h_result.reserve(4)) ||
+  if ((rc = c->d_result.reserve(R_SLOTS)) ||
+      (rc = c->h_result.reserve(R_SLOTS)) ||
       (rc = ensure_cycle_buffers(c, p->max_samples, p->max_points)) ||
       (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
       (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
@@ -1041,6 +1171,13 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       (rc = c->d_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->h_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
     return fail(rc);
+  hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, c->stream,
+                     c->d_result.p);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) {
+    set_error("result record initialisation failed: %s",
+              hipGetErrorString(hipGetLastError()));
+    return fail(KC_ERR_HIP);
+  }
   *out = c;
   return KC_OK;
 }
@@ -1074,6 +1211,8 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_vom.release();
   c->h_seg.release();
   c->d_seg.release();
+  c->h_runs.release();
+  c->d_runs.release();
   c->h_obs.release();
   c->h_cells.release();
   c->d_cells.release();
@@ -1263,6 +1402,32 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   c->seg_len = len;
   KC_HIP(hipMemcpyAsync(c->d_seg.p, h, 5 * S * sizeof(float),
                         hipMemcpyHostToDevice, c->stream));
+  // bounding sphere of every run of kSegRun consecutive points (K2 pruning):
+  // centre = mid-point of the run's bounding box, radius inflated by 1e-6
+  c->nruns = (S + kSegRun - 1) / kSegRun;
+  KC_TRY(c->h_runs.reserve(c->nruns));
+  KC_TRY(c->d_runs.reserve(c->nruns));
+  for (size_t r = 0; r < c->nruns; ++r) {
+    const size_t j0 = r * kSegRun, j1 = std::min(j0 + kSegRun, S);
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (size_t j = j0; j < j1; ++j)
+      for (int k = 0; k < 3; ++k) {
+        const double v = h[k * S + j];
+        lo[k] = std::min(lo[k], v);
+        hi[k] = std::max(hi[k], v);
+      }
+    const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]),
+                 cz = 0.5 * (lo[2] + hi[2]);
+    double rad = 0.0;
+    for (size_t j = j0; j < j1; ++j) {
+      const double dx = h[j] - cx, dy = h[S + j] - cy, dz = h[2 * S + j] - cz;
+      rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz));
+    }
+    if (!std::isfinite(rad)) rad = 1e300;  // never skipped
+    c->h_runs.p[r] = make_double4(cx, cy, cz, rad * (1.0 + 1e-6) + 1e-9);
+  }
+  KC_HIP(hipMemcpyAsync(c->d_runs.p, c->h_runs.p, c->nruns * sizeof(double4),
+                        hipMemcpyHostToDevice, c->stream));
   return KC_OK;
 }
 
@@ -1292,18 +1457,29 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   KC_TRY(c->h_trig.reserve(A * P));
   KC_TRY(c->d_trig.reserve(A * P));
   const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
-  for (size_t r = 0; r < A; ++r) {
-    double yaw = start->yaw;
-    const double om = c->lat.omega_values[r];
-    for (size_t k = 0; k < P; ++k) {
-      c->h_trig.p[k * A + r] = make_double2(std::cos(yaw), std::sin(yaw));
-      yaw += om * dt;
-    }
+  {
+    const double yaw0 = start->yaw;
+    const double *om_v = c->lat.omega_values.data();
+    double2 *tab = c->h_trig.p;
+    WorkerPool::instance().parallel_for(A, 8, [=](size_t r0, size_t r1) {
+      for (size_t r = r0; r < r1; ++r) {
+        double yaw = yaw0;
+        const double om = om_v[r];
+        for (size_t k = 0; k < P; ++k) {
+          double sn, cs;
+          ::sincos(yaw, &sn, &cs);  // bit-identical to sin()/cos() (tested)
+          tab[k * A + r] = make_double2(cs, sn);
+          yaw += om * dt;
+        }
+      }
+    });
   }
+  c->timing.mark("host:trig_table");
   KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
                         hipMemcpyHostToDevice, s));
   RollArgs a{};
   KC_TRY(build_window(c, *start, a.c));
+  c->timing.mark("host:window_bits");
   KC_TRY(ensure_cycle_buffers(c, n, P));
   a.n = static_cast<int>(n);
   a.first = static_cast<int>(c->shard_first);
@@ -1338,6 +1514,7 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
     KC_TRY(c->timing.stop(s));
   }
   KC_HIP(hipGetLastError());
+  c->timing.mark("host:launch_rollout");
   c->rolled = true;
   return KC_OK;
 }
@@ -1347,6 +1524,7 @@ int kc_dwa_evaluate(kc_dwa *c) {
   if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
   KC_TRY(use_device(c));
   KC_TRY(run_evaluate(c, c->n_roll, c->shard_first));
+  c->timing.mark("host:launch_evaluate");
   c->evaluated = true;
   return KC_OK;
 }
@@ -1503,11 +1681,11 @@ int kc_dwa_count_admissible_before(kc_dwa *c, int64_t raw, int64_t *count) {
   hipLaunchKernelGGL(count_before_kernel, dim3(1), dim3(1024), 0, c->stream,
                      c->d_flags.p, static_cast<int>(c->n_roll),
                      static_cast<int>(c->external ? 0 : c->shard_first),
-                     static_cast<long long>(raw), c->d_result.p, 3);
-  KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
-                        hipMemcpyDeviceToHost, c->stream));
+                     static_cast<long long>(raw), c->d_result.p, R_SCRATCH);
+  KC_HIP(hipMemcpyAsync(c->h_result.p + R_SCRATCH, c->d_result.p + R_SCRATCH,
+                        sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   KC_HIP(hipStreamSynchronize(c->stream));
-  *count = c->h_result.p[3];
+  *count = c->h_result.p[R_SCRATCH];
   return KC_OK;
 }
 

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -106,7 +107,25 @@ struct Timing {
   };
   std::vector<Rec> pool;  // events are created once and reused
   size_t used = 0;
-  void begin_cycle() { used = 0; }
+  // host-side phases of the same cycle (wall clock), reported as "host:<name>"
+  struct HostRec {
+    const char *name;
+    double ms;
+  };
+  std::vector<HostRec> host;
+  std::chrono::steady_clock::time_point t_mark;
+  void begin_cycle() {
+    used = 0;
+    host.clear();
+    if (enabled) t_mark = std::chrono::steady_clock::now();
+  }
+  // closes the host phase that started at the previous mark
+  void mark(const char *name) {
+    if (!enabled) return;
+    const auto now = std::chrono::steady_clock::now();
+    host.push_back({name, std::chrono::duration<double, std::milli>(now - t_mark).count()});
+    t_mark = now;
+  }
   int start(const char *name, hipStream_t s) {
     if (!enabled) return KC_OK;
     if (used == pool.size()) {
@@ -133,6 +152,11 @@ struct Timing {
       KC_HIP(hipEventElapsedTime(&t, pool[i].a, pool[i].b));
       if (names) names[n] = pool[i].name;
       if (ms) ms[n] = t;
+      n++;
+    }
+    for (size_t i = 0; i < host.size() && n < cap; ++i) {
+      if (names) names[n] = host[i].name;
+      if (ms) ms[n] = static_cast<float>(host[i].ms);
       n++;
     }
     if (count) *count = n;
