@@ -168,6 +168,14 @@ int kc_dwa_set_tracked_segment(kc_dwa *ctx, const float *x, const float *y,
  * 295-314 -> :118-179) for the context's samples, drop_samples = true.
  * num_points = numPointsPerTrajectory of this cycle (<= max_points). */
 int kc_dwa_rollout(kc_dwa *ctx, const kc_state *start, size_t num_points);
+/* CollisionChecker::checkCollisions (collision_check.cpp:149-162, 225-246) /
+ * TrajectorySampler::checkStatesFeasibility (trajectory_sampler.cpp:378-407)
+ * for a batch of poses against the sensor data of the last kc_dwa_set_scan /
+ * kc_dwa_set_points: hit_out[i] = 1 when the robot shape at pose i touches an
+ * occupied voxel. */
+int kc_dwa_check_poses(kc_dwa *ctx, const double *x, const double *y,
+                       const double *yaw, size_t n, uint8_t *hit_out);
+
 /* A5-A10: CostEvaluator::getMinTrajectoryCost (cost_evaluator.cpp:49-109) on
  * the rolled-out samples; result stays on the device until fetched */
 int kc_dwa_evaluate(kc_dwa *ctx);
@@ -182,6 +190,9 @@ int kc_dwa_cycle(kc_dwa *ctx, const kc_state *start, size_t num_points,
  * num_points floats, vel_* are num_points-1 floats; any pointer may be NULL */
 int kc_dwa_get_best(kc_dwa *ctx, float *path_x, float *path_y, float *vel_vx,
                     float *vel_vy, float *vel_omega);
+/* velocity triple of sample raw_index (global numbering) of the current list */
+int kc_dwa_get_sample_velocity(kc_dwa *ctx, int64_t raw_index, double *vx,
+                               double *vy, double *omega);
 /* compacted samples in reference order (TrajectorySamples2D, trajectory.h:
  * 506-603): paths_* [n_admissible x num_points] row-major, raw_index and costs
  * [n_admissible]; any pointer may be NULL.  cap_rows bounds the rows copied. */

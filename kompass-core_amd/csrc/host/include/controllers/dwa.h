@@ -1,0 +1,141 @@
+// Dynamic Window Approach local planner of the kompass_cpp surface (reference:
+// controllers/dwa.{h,cpp}).  The host keeps target tracking, adaptive horizon
+// and tracked-segment selection; sampling, roll-out, collision gate, costs and
+// argmin run as one device cycle.
+#pragma once
+
+#include <memory>
+#include <stdexcept>
+#include <tuple>
+#include <vector>
+
+#include "controllers/follower.h"
+#include "datatypes/trajectory.h"
+#include "utils/cost_evaluator.h"
+#include "utils/logger.h"
+#include "utils/trajectory_sampler.h"
+
+namespace Kompass {
+namespace Control {
+
+class DWA : public Follower {
+ public:
+  DWA(ControlLimitsParams controlLimits, ControlType controlType, double timeStep,
+      double predictionHorizon, double controlHorizon, int maxLinearSamples,
+      int maxAngularSamples, const CollisionChecker::ShapeType robotShapeType,
+      const std::vector<float> robotDimensions,
+      const Eigen::Vector3f &sensor_position_body,
+      const Eigen::Vector4f &sensor_rotation_body, const double octreeRes,
+      CostEvaluator::TrajectoryCostsWeights costWeights, const int maxNumThreads = 1);
+
+  DWA(TrajectorySampler::TrajectorySamplerParameters config,
+      ControlLimitsParams controlLimits, ControlType controlType,
+      const CollisionChecker::ShapeType robotShapeType,
+      const std::vector<float> robotDimensions,
+      const Eigen::Vector3f &sensor_position_body,
+      const Eigen::Vector4f &sensor_rotation_body,
+      CostEvaluator::TrajectoryCostsWeights costWeights, const int maxNumThreads = 1);
+  ~DWA() = default;
+
+  void configure(ControlLimitsParams controlLimits, ControlType controlType,
+                 double timeStep, double predictionHorizon, double controlHorizon,
+                 int maxLinearSamples, int maxAngularSamples,
+                 const CollisionChecker::ShapeType robotShapeType,
+                 const std::vector<float> robotDimensions,
+                 const Eigen::Vector3f &sensor_position_body,
+                 const Eigen::Vector4f &sensor_rotation_body, const double octreeRes,
+                 CostEvaluator::TrajectoryCostsWeights costWeights,
+                 const int maxNumThreads = 1);
+  void configure(TrajectorySampler::TrajectorySamplerParameters config,
+                 ControlLimitsParams controlLimits, ControlType controlType,
+                 const CollisionChecker::ShapeType robotShapeType,
+                 const std::vector<float> robotDimensions,
+                 const Eigen::Vector3f &sensor_position_body,
+                 const Eigen::Vector4f &sensor_rotation_body,
+                 CostEvaluator::TrajectoryCostsWeights costWeights,
+                 const int maxNumThreads = 1);
+
+  void resetOctreeResolution(const double octreeRes);
+  void setSensorMaxRange(const float max_range);
+  void setCurrentState(const Path::State &position);
+  void addCustomCost(double weight, CostEvaluator::CustomCostFunction custom_cost_function);
+
+  template <typename T>
+  Controller::Result computeVelocityCommand(const Velocity2D &global_vel, const T &scan_points) {
+    TrajSearchResult r = findBestPath(global_vel, scan_points);
+    Controller::Result out;
+    if (r.isTrajFound) {
+      out.status = Controller::Result::Status::COMMAND_FOUND;
+      out.velocity_command = r.trajectory.velocities.getFront();
+      latest_velocity_command_ = out.velocity_command;
+    } else {
+      out.status = Controller::Result::Status::NO_COMMAND_POSSIBLE;
+    }
+    return out;
+  }
+
+  template <typename T>
+  TrajSearchResult computeVelocityCommandsSet(const Velocity2D &global_vel, const T &scan_points) {
+    TrajSearchResult r = findBestPath(global_vel, scan_points);
+    if (r.isTrajFound) latest_velocity_command_ = r.trajectory.velocities.getFront();
+    return r;
+  }
+
+  std::tuple<MatrixXfR, MatrixXfR> getDebuggingSamples() const;
+  Control::TrajectorySamples2D getDebuggingSamplesPure() const;
+
+  template <typename T>
+  void debugVelocitySearch(const Velocity2D &global_vel, const T &scan_points, const bool &drop_samples) {
+    requirePath();
+    determineTarget();
+    trajSampler->setSampleDroppingMode(drop_samples);
+    debuggingSamples_ = trajSampler->generateTrajectories(global_vel, currentState, scan_points);
+  }
+
+ protected:
+  std::unique_ptr<TrajectorySampler> trajSampler;
+  std::unique_ptr<CostEvaluator> trajCostEvaluator;
+
+  template <typename T>
+  TrajSearchResult findBestPath(const Velocity2D &global_vel, const T &scan_points) {
+    requirePath();
+    determineTarget();
+    if (rotate_in_place &&
+        std::abs(currentTrackedTarget_->heading_error) > goal_orientation_tolerance * 10.0) {
+      LOG_DEBUG("Rotating In Place ...");
+      auto trajectory = trajSampler->generateSingleSampleFromVel(Velocity2D(
+          0.0, 0.0,
+          -currentTrackedTarget_->heading_error * ctrlimitsParams.omegaParams.maxOmega / M_PI));
+      return TrajSearchResult{trajectory, true, 0.0};
+    }
+    adaptPredictionHorizonToCurvature();
+    // one device cycle: lattice + sensor upload + roll-out + collision gate ...
+    const size_t generated =
+        trajSampler->rolloutOnDevice(global_vel, currentState, scan_points, maxLocalRange_);
+    if (generated == 0) return TrajSearchResult{Trajectory2D(), false, 0.0};
+    // ... + costs + argmin against the tracked segment
+    trajCostEvaluator->sensorDataResident = true;
+    auto tracked = findTrackedPathSegment();
+    return trajCostEvaluator->getMinTrajectoryCostOnDevice(
+        currentPath.get(), tracked, trajSampler->numPointsPerTrajectory);
+  }
+
+ private:
+  double max_forward_distance_ = 0.0;
+  int maxNumThreads;
+  std::unique_ptr<TrajectorySamples2D> debuggingSamples_ = nullptr;
+  float maxLocalRange_ = 10.0;
+
+  void requirePath() const {
+    if (!currentPath)
+      throw std::invalid_argument(
+          "Pointer to global path is NULL. Cannot use DWA local planner "
+          "without setting a global path");
+  }
+  Path::Path::View findTrackedPathSegment();
+  void adaptPredictionHorizonToCurvature();
+  void initJitCompile();
+};
+
+}  // namespace Control
+}  // namespace Kompass

@@ -1,0 +1,58 @@
+// Robot-shape vs sensor-data collision checker of the kompass_cpp surface
+// (reference: utils/collision_check.{h,cpp}, FCL + octomap).  Here the octree
+// is a voxel-key set and the shape test is analytic, both evaluated on the
+// device (DESIGN.md "A4").  Same public methods, same ShapeType enum.
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "datatypes/control.h"
+#include "datatypes/path.h"
+#include "kc_linalg.h"
+#include "utils/hip_backend.h"
+
+namespace Kompass {
+
+class CollisionChecker {
+ public:
+  enum class ShapeType { CYLINDER, BOX, SPHERE };
+
+  CollisionChecker(const ShapeType robot_shape_type,
+                   const std::vector<float> &robot_dimensions,
+                   const Eigen::Vector3f &sensor_position_body,
+                   const Eigen::Quaternionf &sensor_rotation_body,
+                   const double octree_resolution = 0.01);
+  // shares the device context of a sampler / controller
+  CollisionChecker(hip::DwaHandle ctx, ShapeType shape,
+                   const std::vector<float> &dims, double octree_resolution);
+  ~CollisionChecker() = default;
+
+  void resetOctreeResolution(const double resolution);
+  void updateState(const Path::State current_state);
+  void updateState(const double x, const double y, const double yaw);
+
+  // LaserScan (sensor frame) or point list (world frame when global_frame)
+  void updateSensorData(const Control::LaserScan &scan, const bool global_frame = true);
+  void updateSensorData(const std::vector<Path::Point> &cloud, const bool global_frame = true);
+
+  bool checkCollisions();
+  bool checkCollisions(const Path::State current_state);
+  bool checkCollisions(const std::vector<double> &ranges,
+                       const std::vector<double> &angles, double height = 0.1);
+  // batch form used by TrajectorySampler::checkStatesFeasibility
+  std::vector<bool> checkCollisions(const std::vector<Path::State> &states);
+  float getRadius() const;
+  const hip::DwaHandle &context() const { return ctx_; }
+  float maxSensorRange = 10.0f;  // forwarded to the obstacle-cost side
+
+ protected:
+  double robotHeight_{1.0}, robotRadius_{0.0};
+
+ private:
+  hip::DwaHandle ctx_;
+  Path::State state_;
+  double octree_resolution_{0.01};
+};
+
+}  // namespace Kompass

@@ -1,0 +1,106 @@
+// Weighted trajectory cost evaluator of the kompass_cpp surface (reference:
+// utils/cost_evaluator.{h,cpp} CPU semantics; the reference's SYCL variant,
+// cost_evaluator_gpu.cpp, is the behavioural precedent for running it on a
+// device).  All five built-in costs + argmin run in HIP kernels; custom host
+// callbacks are added on the host afterwards, like the reference's GPU build.
+#pragma once
+
+#include <array>
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "datatypes/control.h"
+#include "datatypes/parameter.h"
+#include "datatypes/path.h"
+#include "datatypes/trajectory.h"
+#include "utils/hip_backend.h"
+
+namespace Kompass {
+namespace Control {
+
+class CostEvaluator {
+ public:
+  class TrajectoryCostsWeights : public Parameters {
+   public:
+    TrajectoryCostsWeights() : Parameters() {
+      addParameter("reference_path_distance_weight", Parameter(1.0, 0.0, 1000.0,
+                   "Weight of the cost for the distance between a trajectory sample and the reference global path"));
+      addParameter("goal_distance_weight", Parameter(1.0, 0.0, 1000.0,
+                   "Weight of the cost for the distance between the end of a trajectory sample and the end goal point"));
+      addParameter("obstacles_distance_weight", Parameter(1.0, 0.0, 1000.0,
+                   "Weight of the cost for the distance between a trajectory sample and the closest obstacle"));
+      addParameter("smoothness_weight", Parameter(1.0, 0.0, 1000.0,
+                   "Weight of the cost for the non-smoothness of the trajectory sample"));
+      addParameter("jerk_weight", Parameter(1.0, 0.0, 1000.0,
+                   "Weight of the cost for the trajectory sample jerk"));
+    }
+  };
+
+  CostEvaluator(TrajectoryCostsWeights &costsWeights, ControlLimitsParams ctrLimits,
+                size_t maxNumTrajectories, size_t numPointsPerTrajectory,
+                size_t maxRefPathSegmentSize);
+  CostEvaluator(TrajectoryCostsWeights &costsWeights,
+                const Eigen::Vector3f &sensor_position_body,
+                const Eigen::Quaternionf &sensor_rotation_body,
+                ControlLimitsParams ctrLimits, size_t maxNumTrajectories,
+                size_t numPointsPerTrajectory, size_t maxRefPathSegmentSize);
+  // shares the device context of a sampler (DWA)
+  CostEvaluator(TrajectoryCostsWeights &costsWeights, hip::DwaHandle ctx);
+  ~CostEvaluator();
+
+  using CustomCostFunction =
+      std::function<float(const Trajectory2D &, const Path::Path &)>;
+  struct CustomTrajectoryCost {
+    double weight;
+    CustomCostFunction evaluator_;
+    CustomTrajectoryCost(double w, CustomCostFunction f)
+        : weight(w), evaluator_(std::move(f)) {}
+  };
+
+  TrajSearchResult
+  getMinTrajectoryCost(const std::unique_ptr<TrajectorySamples2D> &trajs,
+                       const Path::Path *reference_path,
+                       const Path::Path::View &tracked_segment);
+
+  // samples already rolled out on this evaluator's device context
+  // (TrajectorySampler::rolloutOnDevice); nothing is copied to the host except
+  // the winner row.  sample velocities are needed for the result record.
+  TrajSearchResult getMinTrajectoryCostOnDevice(
+      const Path::Path *reference_path, const Path::Path::View &tracked_segment,
+      size_t numPointsPerTrajectory);
+
+  void addCustomCost(double weight, CustomCostFunction custom_cost_function) {
+    customTrajCostsPtrs_.push_back(std::make_unique<CustomTrajectoryCost>(
+        weight, std::move(custom_cost_function)));
+  }
+
+  void setPointScan(const LaserScan &scan, const Path::State &current_state,
+                    const float max_sensor_range,
+                    const float max_obstacle_cost_range_multiple = 3.0);
+  void setPointScan(const std::vector<Path::Point> &cloud,
+                    const Path::State &current_state,
+                    const float max_sensor_range,
+                    const float max_obstacle_cost_range_multiple = 3.0);
+  void updateCostWeights(TrajectoryCostsWeights &costsWeights);
+  bool hasCustomCosts() const { return !customTrajCostsPtrs_.empty(); }
+  const hip::DwaHandle &context() const { return ctx_; }
+  // set by a sampler that already uploaded this cycle's sensor data to the
+  // shared context (setPointScan then has nothing left to do)
+  bool sensorDataResident = false;
+
+ protected:
+  std::array<float, 3> accLimits_;
+  std::vector<std::unique_ptr<CustomTrajectoryCost>> customTrajCostsPtrs_;
+
+ private:
+  void uploadSegment(const Path::Path *reference_path,
+                     const Path::Path::View &tracked_segment);
+  TrajSearchResult finishWithCustomCosts(const Path::Path *reference_path,
+                                         size_t P);
+  std::unique_ptr<TrajectoryCostsWeights> costWeights;
+  hip::DwaHandle ctx_;
+};
+
+}  // namespace Control
+}  // namespace Kompass

@@ -1,0 +1,314 @@
+// CollisionChecker + TrajectorySampler host side (reference: src/utils/
+// collision_check.cpp, trajectory_sampler.cpp).  Everything batch-shaped is a
+// call into libkompass_hip.so.
+#include "utils/trajectory_sampler.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace Kompass {
+
+namespace {
+kc_dwa_params baseParams(CollisionChecker::ShapeType shape, const std::vector<float> &dims,
+                         const Eigen::Vector3f &spos, const Eigen::Quaternionf &srot,
+                         double res) {
+  kc_dwa_params p;
+  std::memset(&p, 0, sizeof(p));
+  p.shape = static_cast<int>(shape);
+  p.ndims = static_cast<int>(std::min<size_t>(dims.size(), 3));
+  for (int i = 0; i < p.ndims; ++i) p.dims[i] = dims[static_cast<size_t>(i)];
+  for (int i = 0; i < 3; ++i) p.sensor_pos[i] = spos(i);
+  p.sensor_rot_xyzw[0] = srot.x();
+  p.sensor_rot_xyzw[1] = srot.y();
+  p.sensor_rot_xyzw[2] = srot.z();
+  p.sensor_rot_xyzw[3] = srot.w();
+  p.octree_res = res;
+  p.time_step = 0.1;
+  p.max_samples = 1;
+  p.max_points = 2;
+  p.max_segment = 16;
+  p.max_obstacles = 1024;
+  p.acc_limits[0] = p.acc_limits[1] = p.acc_limits[2] = 1.0f;
+  p.device = 0;
+  return p;
+}
+void shapeExtents(CollisionChecker::ShapeType shape, const std::vector<float> &d,
+                  double &radius, double &height) {
+  // collision_check.cpp:38-58
+  switch (shape) {
+    case CollisionChecker::ShapeType::CYLINDER:
+      radius = d.at(0);
+      height = d.at(1);
+      break;
+    case CollisionChecker::ShapeType::BOX:
+      height = d.at(2);
+      radius = std::sqrt(std::pow(d.at(0), 2) + std::pow(d.at(1), 2)) / 2;
+      break;
+    case CollisionChecker::ShapeType::SPHERE:
+      radius = d.at(0);
+      height = 2 * d.at(0);
+      break;
+    default:
+      throw std::invalid_argument("Invalid robot geometry type");
+  }
+}
+kc_state toKc(const Path::State &s) { return kc_state{s.x, s.y, s.yaw, s.speed}; }
+}  // namespace
+
+// ---------------------------------------------------------------------------
+CollisionChecker::CollisionChecker(const ShapeType shape, const std::vector<float> &dims,
+                                   const Eigen::Vector3f &spos,
+                                   const Eigen::Quaternionf &srot, const double res)
+    : octree_resolution_(res) {
+  shapeExtents(shape, dims, robotRadius_, robotHeight_);
+  ctx_ = hip::makeDwa(baseParams(shape, dims, spos, srot, res));
+}
+CollisionChecker::CollisionChecker(hip::DwaHandle ctx, ShapeType shape,
+                                   const std::vector<float> &dims, double res)
+    : ctx_(std::move(ctx)), octree_resolution_(res) {
+  shapeExtents(shape, dims, robotRadius_, robotHeight_);
+}
+
+void CollisionChecker::resetOctreeResolution(const double r) {
+  if (r != octree_resolution_) {
+    octree_resolution_ = r;
+    hip::check(kc_dwa_set_resolution(ctx_.get(), r));
+  }
+}
+float CollisionChecker::getRadius() const { return static_cast<float>(robotRadius_); }
+void CollisionChecker::updateState(const Path::State s) { state_ = s; }
+void CollisionChecker::updateState(const double x, const double y, const double yaw) {
+  state_ = Path::State(x, y, yaw);
+}
+void CollisionChecker::updateSensorData(const Control::LaserScan &scan, const bool) {
+  const kc_state st = toKc(state_);
+  hip::check(kc_dwa_set_scan(ctx_.get(), &st, scan.ranges.data(), scan.angles.data(),
+                             std::min(scan.ranges.size(), scan.angles.size()), maxSensorRange));
+}
+void CollisionChecker::updateSensorData(const std::vector<Path::Point> &cloud,
+                                        const bool global_frame) {
+  if (!global_frame)
+    throw std::runtime_error(
+        "CollisionChecker: sensor-frame point lists are not supported by this "
+        "build (the controllers always pass global_frame = true)");
+  const kc_state st = toKc(state_);
+  std::vector<float> xyz(cloud.size() * 3);
+  for (size_t i = 0; i < cloud.size(); ++i) {
+    xyz[3 * i] = cloud[i].x();
+    xyz[3 * i + 1] = cloud[i].y();
+    xyz[3 * i + 2] = cloud[i].z();
+  }
+  hip::check(kc_dwa_set_points(ctx_.get(), &st, xyz.data(), cloud.size(), maxSensorRange));
+}
+std::vector<bool> CollisionChecker::checkCollisions(const std::vector<Path::State> &states) {
+  const size_t n = states.size();
+  std::vector<double> x(n), y(n), yaw(n);
+  for (size_t i = 0; i < n; ++i) {
+    x[i] = states[i].x;
+    y[i] = states[i].y;
+    yaw[i] = states[i].yaw;
+  }
+  std::vector<uint8_t> hit(n);
+  hip::check(kc_dwa_check_poses(ctx_.get(), x.data(), y.data(), yaw.data(), n, hit.data()));
+  return std::vector<bool>(hit.begin(), hit.end());
+}
+bool CollisionChecker::checkCollisions(const Path::State s) {
+  return checkCollisions(std::vector<Path::State>{s})[0];
+}
+bool CollisionChecker::checkCollisions() { return checkCollisions(state_); }
+bool CollisionChecker::checkCollisions(const std::vector<double> &ranges,
+                                       const std::vector<double> &angles, double) {
+  updateSensorData(Control::LaserScan(ranges, angles));
+  return checkCollisions();
+}
+
+namespace Control {
+
+// ---------------------------------------------------------------------------
+TrajectorySampler::TrajectorySampler(
+    ControlLimitsParams controlLimits, ControlType controlType, double timeStep,
+    double predictionHorizon, double controlHorizon, int maxLinearSamples,
+    int maxAngularSamples, const CollisionChecker::ShapeType robotShapeType,
+    const std::vector<float> robotDimensions, const Eigen::Vector3f &spos,
+    const Eigen::Quaternionf &srot, const double octreeRes, const int maxNumThreads) {
+  ctrlimits = controlLimits;
+  ctrType = controlType;
+  time_step_ = timeStep;
+  max_time_ = base_max_time_ = predictionHorizon;
+  control_time_ = controlHorizon;
+  lin_samples_max_ = maxLinearSamples;
+  ang_samples_max_raw_ = maxAngularSamples;
+  this->maxNumThreads = maxNumThreads;
+  init(robotShapeType, robotDimensions, spos, srot, octreeRes);
+}
+
+TrajectorySampler::TrajectorySampler(
+    TrajectorySamplerParameters config, ControlLimitsParams controlLimits,
+    ControlType controlType, const CollisionChecker::ShapeType robotShapeType,
+    const std::vector<float> robotDimensions, const Eigen::Vector3f &spos,
+    const Eigen::Quaternionf &srot, const int maxNumThreads) {
+  ctrlimits = controlLimits;
+  ctrType = controlType;
+  time_step_ = config.getParameter<double>("time_step");
+  max_time_ = base_max_time_ = config.getParameter<double>("prediction_horizon");
+  control_time_ = config.getParameter<double>("control_horizon");
+  lin_samples_max_ = config.getParameter<int>("max_linear_samples");
+  ang_samples_max_raw_ = config.getParameter<int>("max_angular_samples");
+  this->maxNumThreads = maxNumThreads;
+  drop_samples_ = config.getParameter<bool>("drop_samples");
+  init(robotShapeType, robotDimensions, spos, srot,
+       config.getParameter<double>("octree_map_resolution"));
+  setSampleDroppingMode(drop_samples_);
+}
+
+void TrajectorySampler::init(const CollisionChecker::ShapeType shape,
+                             const std::vector<float> &dims, const Eigen::Vector3f &spos,
+                             const Eigen::Quaternionf &srot, double octreeRes) {
+  const int ang = ang_samples_max_raw_ + 1 - (ang_samples_max_raw_ % 2);
+  numPointsPerTrajectory = getNumPointsPerTrajectory(time_step_, max_time_);
+  numTrajectories = getNumTrajectories(ctrType, lin_samples_max_, ang);
+  kc_dwa_params p = baseParams(shape, dims, spos, srot, octreeRes);
+  p.time_step = time_step_;
+  p.max_samples = numTrajectories + 8;
+  p.max_points = std::max<size_t>(numPointsPerTrajectory, 2);
+  p.max_segment = 512;
+  p.acc_limits[0] = static_cast<float>(ctrlimits.velXParams.maxAcceleration);
+  p.acc_limits[1] = static_cast<float>(ctrlimits.velYParams.maxAcceleration);
+  p.acc_limits[2] = static_cast<float>(ctrlimits.omegaParams.maxAcceleration);
+  ctx_ = hip::makeDwa(p);
+  collChecker = std::make_unique<CollisionChecker>(ctx_, shape, dims, octreeRes);
+  if (ctrType != ControlType::OMNI)  // trajectory_sampler.cpp:51-54
+    ctrlimits.velYParams = LinearVelocityControlParams(0.0, 0.0, 0.0);
+}
+
+void TrajectorySampler::updateState(const Path::State &s) { collChecker->updateState(s); }
+void TrajectorySampler::setSampleDroppingMode(const bool drop) {
+  if (!drop)
+    throw std::invalid_argument(
+        "drop_samples = false (keep the collision-free prefix of a sample) is "
+        "outside this build's parity domain (reference quirk Q3: the prefix "
+        "length depends on an uninitialised member)");
+  drop_samples_ = drop;
+}
+void TrajectorySampler::resetOctreeResolution(const double r) {
+  collChecker->resetOctreeResolution(r);
+}
+float TrajectorySampler::getRobotRadius() const { return collChecker->getRadius(); }
+
+void TrajectorySampler::setPredictionHorizon(double horizon) {
+  const double min_h = 2.0 * time_step_;
+  horizon = std::max(horizon, min_h);
+  horizon = std::min(horizon, base_max_time_);
+  max_time_ = horizon;
+  numPointsPerTrajectory = getNumPointsPerTrajectory(time_step_, max_time_);
+}
+
+size_t TrajectorySampler::launch(const Velocity2D &vel, const Path::State &pose) {
+  kc_limits L;
+  L.vx_max = ctrlimits.velXParams.maxVel;
+  L.vx_acc = ctrlimits.velXParams.maxAcceleration;
+  L.vx_dec = ctrlimits.velXParams.maxDeceleration;
+  L.vy_max = ctrlimits.velYParams.maxVel;
+  L.vy_acc = ctrlimits.velYParams.maxAcceleration;
+  L.vy_dec = ctrlimits.velYParams.maxDeceleration;
+  L.omega_max_angle = ctrlimits.omegaParams.maxAngle;
+  L.omega_max = ctrlimits.omegaParams.maxOmega;
+  L.omega_acc = ctrlimits.omegaParams.maxAcceleration;
+  L.omega_dec = ctrlimits.omegaParams.maxDeceleration;
+  size_t n = 0;
+  last_vx_.resize(numTrajectories + 8);
+  last_vy_.resize(numTrajectories + 8);
+  last_omega_.resize(numTrajectories + 8);
+  hip::check(kc_dwa_sample_window(ctx_.get(), static_cast<int>(ctrType), &L, vel.vx(), vel.vy(),
+                                  vel.omega(), lin_samples_max_, ang_samples_max_raw_, &n,
+                                  last_vx_.data(), last_vy_.data(), last_omega_.data(),
+                                  last_vx_.size()));
+  const kc_state st = toKc(pose);
+  hip::check(kc_dwa_rollout(ctx_.get(), &st, numPointsPerTrajectory));
+  return n;
+}
+
+size_t TrajectorySampler::rolloutOnDevice(const Velocity2D &vel, const Path::State &pose,
+                                          const LaserScan &scan, float max_range) {
+  collChecker->maxSensorRange = max_range;
+  collChecker->updateState(pose);
+  collChecker->updateSensorData(scan);
+  return launch(vel, pose);
+}
+size_t TrajectorySampler::rolloutOnDevice(const Velocity2D &vel, const Path::State &pose,
+                                          const std::vector<Path::Point> &cloud, float max_range) {
+  collChecker->maxSensorRange = max_range;
+  collChecker->updateState(pose);
+  collChecker->updateSensorData(cloud);
+  return launch(vel, pose);
+}
+
+std::unique_ptr<TrajectorySamples2D> TrajectorySampler::collect() {
+  const size_t P = numPointsPerTrajectory;
+  auto out = std::make_unique<TrajectorySamples2D>(numTrajectories, P);
+  size_t rows = 0;
+  hip::check(kc_dwa_get_samples(ctx_.get(), nullptr, nullptr, nullptr, nullptr, 0, &rows));
+  if (rows > numTrajectories)
+    throw std::out_of_range("more admissible samples than numTrajectories");
+  std::vector<int32_t> raw(rows ? rows : 1);
+  hip::check(kc_dwa_get_samples(ctx_.get(), out->paths.x.data(), out->paths.y.data(), raw.data(),
+                                nullptr, rows, &rows));
+  out->paths.z.fill(0.0f);
+  for (size_t r = 0; r < rows; ++r) {
+    const size_t g = static_cast<size_t>(raw[r]);
+    for (size_t i = 0; i + 1 < P; ++i) {  // TrajectoryVelocities2D::add: float = double
+      out->velocities.vx((Eigen::Index)r, (Eigen::Index)i) = last_vx_[g];
+      out->velocities.vy((Eigen::Index)r, (Eigen::Index)i) = last_vy_[g];
+      out->velocities.omega((Eigen::Index)r, (Eigen::Index)i) = last_omega_[g];
+    }
+  }
+  out->paths.pathIndex_ = static_cast<Eigen::Index>(rows) - 1;
+  out->velocities.velocitiesIndex_ = static_cast<Eigen::Index>(rows) - 1;
+  return out;
+}
+
+std::unique_ptr<TrajectorySamples2D>
+TrajectorySampler::generateTrajectories(const Velocity2D &vel, const Path::State &pose,
+                                        const LaserScan &scan) {
+  rolloutOnDevice(vel, pose, scan, collChecker->maxSensorRange);
+  return collect();
+}
+std::unique_ptr<TrajectorySamples2D>
+TrajectorySampler::generateTrajectories(const Velocity2D &vel, const Path::State &pose,
+                                        const std::vector<Path::Point> &cloud) {
+  rolloutOnDevice(vel, pose, cloud, collChecker->maxSensorRange);
+  return collect();
+}
+
+// single un-checked sample (trajectory_sampler.cpp:409-445): one trajectory,
+// used only by the rotate-in-place shortcut -- not batch work
+Trajectory2D TrajectorySampler::generateSingleSampleFromVel(const Velocity2D &vel,
+                                                            const Path::State &pose) {
+  Path::State s = pose;
+  Trajectory2D t(numPointsPerTrajectory);
+  t.path.add(0, s.x, s.y);
+  const bool rotate_then_move = ctrType == ControlType::DIFFERENTIAL_DRIVE;
+  for (size_t i = 0; i + 1 < numPointsPerTrajectory; ++i) {
+    if (rotate_then_move && std::abs(vel.vx()) > MIN_VEL && std::abs(vel.omega()) > MIN_VEL) {
+      Velocity2D tmp = vel;
+      tmp.setVx(0.0);
+      s.update(tmp, time_step_);
+      t.path.add(i + 1, s.x, s.y);
+      t.velocities.add(i, vel);
+      tmp.setVx(vel.vx());
+      tmp.setOmega(0.0);
+      s.update(tmp, time_step_);
+      t.path.add(i + 1, s.x, s.y);
+      t.velocities.add(i, vel);
+      i++;
+      if (i + 1 >= numPointsPerTrajectory) break;
+    }
+    s.update(vel, time_step_);
+    t.path.add(i + 1, s.x, s.y);
+    t.velocities.add(i, vel);
+  }
+  return t;
+}
+
+}  // namespace Control
+}  // namespace Kompass

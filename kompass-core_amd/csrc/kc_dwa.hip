@@ -275,6 +275,24 @@ __global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
   if (hit) a.flags[n] = 0;
 }
 
+// batch pose check (CollisionChecker::checkCollisions for arbitrary poses):
+// occupancy bits read from global memory, cos/sin(yaw) from the host table
+__global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
+                                  const double2 *__restrict__ cs, int n,
+                                  uint8_t *__restrict__ hit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double2 p = pos[i];
+  bool h;
+  if (c.shape == KC_BOX) {
+    const double2 t = cs[i];
+    h = hit_box(c, c.bits, p.x, p.y, t.x, t.y);
+  } else {
+    h = hit_round(c, c.bits, p.x, p.y);
+  }
+  hit[i] = h ? 1 : 0;
+}
+
 // ===========================================================================
 // K2+K3: per (sample, point) nearest tracked-segment point and nearest
 // obstacle point, one lane per trajectory point.
@@ -901,8 +919,18 @@ int upload_samples(kc_dwa *c) {
   return KC_OK;
 }
 
+int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd);
+
 // occupancy bits of every voxel the robot can reach this cycle
 int build_window(kc_dwa *c, const kc_state &start, CollDev &cd) {
+  // every pose of every sample stays within `reach` of the start
+  const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
+  const double reach = c->vmax_lin * dt * static_cast<double>(c->P) * 1.0001;
+  return build_window_at(c, start.x, start.y, reach, cd);
+}
+
+// occupancy bits of every voxel within reach (+ robot bound) of (wx, wy)
+int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) {
   std::memset(&cd, 0, sizeof(cd));
   cd.shape = c->prm.shape;
   const hm::Rigid3f &F = c->frame;
@@ -920,13 +948,10 @@ int build_window(kc_dwa *c, const kc_state &start, CollDev &cd) {
   cd.b = static_cast<double>(c->prm.dims[1]) / 2.0;
   if (!c->have_sensor || c->vox_kx.empty()) return KC_OK;  // enabled = 0
 
-  // every pose of every sample stays within `reach` of the start
-  const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
-  const double reach = c->vmax_lin * dt * static_cast<double>(c->P) * 1.0001;
   const double bound = (c->prm.shape == KC_BOX)
                            ? std::sqrt(cd.a * cd.a + cd.b * cd.b)
                            : c->radius;
-  const double dx = start.x - cd.tx, dy = start.y - cd.ty;
+  const double dx = wx - cd.tx, dy = wy - cd.ty;
   const double xf = cd.r00 * dx + cd.r10 * dy;
   const double yf = cd.r01 * dx + cd.r11 * dy;
   const long half = static_cast<long>(std::ceil((reach + bound) * cd.inv)) + 3;
@@ -1478,8 +1503,6 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
                         hipMemcpyHostToDevice, s));
   RollArgs a{};
-  KC_TRY(build_window(c, *start, a.c));
-  c->timing.mark("host:window_bits");
   KC_TRY(ensure_cycle_buffers(c, n, P));
   a.n = static_cast<int>(n);
   a.first = static_cast<int>(c->shard_first);
@@ -1495,27 +1518,75 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   a.px = c->d_px.p;
   a.py = c->d_py.p;
   a.flags = c->d_flags.p;
-  if (a.c.enabled) {
+  // the roll-out does not need the occupancy window: launch it first and
+  // build the window bits on the host while it runs
+  const bool may_collide = c->have_sensor && !c->vox_kx.empty();
+  if (may_collide) {
     KC_TRY(c->d_pos.reserve(n * P));
     a.pos = c->d_pos.p;
   }
+  a.c.enabled = may_collide ? 1 : 0;  // roll-out: "store the double poses"
   const size_t tile_bytes = 2 * static_cast<size_t>(kRollBlock) * (P | 1) * 4;
   a.stage = (tile_bytes <= 64 * 1024) ? 1 : 0;
   KC_TRY(c->timing.start("rollout_kernel", s));
   hipLaunchKernelGGL(rollout_kernel, dim3(blocks_for(n, kRollBlock)),
                      dim3(kRollBlock), a.stage ? tile_bytes : 0, s, a);
   KC_TRY(c->timing.stop(s));
-  if (a.c.enabled) {
-    const size_t bits_bytes = static_cast<size_t>(a.c.H) * a.c.wpr * 4;
-    KC_TRY(c->timing.start("collision_kernel", s));
-    hipLaunchKernelGGL(collision_kernel,
-                       dim3(blocks_for(n * (P - 1), kCollBlock)),
-                       dim3(kCollBlock), a.c.lds ? bits_bytes : 0, s, a);
-    KC_TRY(c->timing.stop(s));
+  c->timing.mark("host:launch_rollout");
+  if (may_collide) {
+    KC_TRY(build_window(c, *start, a.c));
+    c->timing.mark("host:window_bits");
+    if (a.c.enabled) {
+      const size_t bits_bytes = static_cast<size_t>(a.c.H) * a.c.wpr * 4;
+      KC_TRY(c->timing.start("collision_kernel", s));
+      hipLaunchKernelGGL(collision_kernel,
+                         dim3(blocks_for(n * (P - 1), kCollBlock)),
+                         dim3(kCollBlock), a.c.lds ? bits_bytes : 0, s, a);
+      KC_TRY(c->timing.stop(s));
+    }
   }
   KC_HIP(hipGetLastError());
-  c->timing.mark("host:launch_rollout");
+  c->timing.mark("host:launch_collision");
   c->rolled = true;
+  return KC_OK;
+}
+
+int kc_dwa_check_poses(kc_dwa *c, const double *x, const double *y,
+                       const double *yaw, size_t n, uint8_t *hit_out) {
+  if (!c || (n && (!x || !y || !yaw || !hit_out)))
+    KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (n == 0) return KC_OK;
+  if (n > 0x7FFFFFFFul) KC_FAIL(KC_ERR_RANGE, "too many poses");
+  KC_TRY(use_device(c));
+  hipStream_t s = c->stream;
+  KC_HIP(hipStreamSynchronize(s));
+  double reach = 0.0;
+  for (size_t i = 1; i < n; ++i)
+    reach = std::max(reach, std::hypot(x[i] - x[0], y[i] - y[0]));
+  CollDev cd;
+  KC_TRY(build_window_at(c, x[0], y[0], reach * 1.0001 + 1e-9, cd));
+  if (!cd.enabled) {
+    std::memset(hit_out, 0, n);
+    return KC_OK;
+  }
+  cd.lds = 0;
+  KC_TRY(c->h_trig.reserve(2 * n));
+  KC_TRY(c->d_trig.reserve(2 * n));
+  for (size_t i = 0; i < n; ++i) {
+    c->h_trig.p[i] = make_double2(x[i], y[i]);
+    c->h_trig.p[n + i] = make_double2(std::cos(yaw[i]), std::sin(yaw[i]));
+  }
+  KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, 2 * n * sizeof(double2),
+                        hipMemcpyHostToDevice, s));
+  KC_TRY(c->d_flags.reserve(n));
+  hipLaunchKernelGGL(pose_check_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                     s, cd, c->d_trig.p, c->d_trig.p + n, static_cast<int>(n),
+                     c->d_flags.p);
+  KC_HIP(hipGetLastError());
+  KC_HIP(hipMemcpyAsync(hit_out, c->d_flags.p, n, hipMemcpyDeviceToHost, s));
+  KC_HIP(hipStreamSynchronize(s));
+  c->rolled = false;  // the flag buffer no longer describes a roll-out
+  c->evaluated = false;
   return KC_OK;
 }
 
@@ -1576,6 +1647,19 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
       if (vom) vom[i] = fo;
     }
   }
+  return KC_OK;
+}
+
+int kc_dwa_get_sample_velocity(kc_dwa *c, int64_t raw, double *vx, double *vy,
+                               double *omega) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (raw < 0 || static_cast<size_t>(raw) >= c->lat.size())
+    KC_FAIL(KC_ERR_RANGE, "sample %lld outside the %zu samples",
+            static_cast<long long>(raw), c->lat.size());
+  const size_t g = static_cast<size_t>(raw);
+  if (vx) *vx = c->lat.vx[g];
+  if (vy) *vy = c->lat.vy[g];
+  if (omega) *omega = c->lat.omega_values[c->lat.row[g]];
   return KC_OK;
 }
 

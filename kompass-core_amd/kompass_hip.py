@@ -96,10 +96,12 @@ SIGNATURES = {
     "kc_dwa_set_points": (C.c_int, [_vp, C.POINTER(State), _fp, _sz, C.c_float]),
     "kc_dwa_set_tracked_segment": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _sz, C.c_float]),
     "kc_dwa_rollout": (C.c_int, [_vp, C.POINTER(State), _sz]),
+    "kc_dwa_check_poses": (C.c_int, [_vp, _dp, _dp, _dp, _sz, C.POINTER(C.c_uint8)]),
     "kc_dwa_evaluate": (C.c_int, [_vp]),
     "kc_dwa_fetch_result": (C.c_int, [_vp, C.POINTER(Result)]),
     "kc_dwa_cycle": (C.c_int, [_vp, C.POINTER(State), _sz, C.POINTER(Result)]),
     "kc_dwa_get_best": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
+    "kc_dwa_get_sample_velocity": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),
     "kc_dwa_get_samples": (C.c_int, [_vp, _fp, _fp, _ip, _fp, _sz, C.POINTER(_sz)]),
     "kc_cost_evaluate": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _sz, _sz, _fp, C.POINTER(Result)]),
     "kc_dwa_result_device": (C.c_int, [_vp, C.POINTER(_vp)]),
@@ -269,6 +271,13 @@ class DwaContext:
         st = State(*state)
         self._P = int(P)
         _check(lib().kc_dwa_rollout(self.h, C.byref(st), int(P)))
+
+    def check_poses(self, x, y, yaw):
+        x, y, yaw = _f64(x), _f64(y), _f64(yaw)
+        hit = np.zeros(len(x), np.uint8)
+        _check(lib().kc_dwa_check_poses(self.h, _pd(x), _pd(y), _pd(yaw), len(x),
+                                        hit.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return hit.astype(bool)
 
     def evaluate(self):
         _check(lib().kc_dwa_evaluate(self.h))

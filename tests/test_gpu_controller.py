@@ -1,0 +1,226 @@
+"""Closed-loop tests of the drop-in surface on the GPU: kompass_core.control.DWA
+(-> kompass_cpp.control.DWA -> C ABI -> HIP) in lockstep with the CPU oracle's
+controller restatement.  Mirrors the reference's tests/test_controllers.py::
+test_dwa and src/kompass_cpp/tests/dwa_test.cpp scenarios."""
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kompass_cpp  # noqa: E402
+import kompass_hip as kh  # noqa: E402
+from kompass_core.control import DWA, DWAConfig, TrajectoryCostsWeights  # noqa: E402
+from kompass_core.datatypes import LaserScanData  # noqa: E402
+from kompass_core.mapping import LocalMapper, MapConfig  # noqa: E402
+from kompass_core.models import (AngularCtrlLimits, LinearCtrlLimits, Robot, RobotCtrlLimits,  # noqa: E402
+                                 RobotGeometry, RobotType)
+from oracle import ko  # noqa: E402
+
+GOLD = Path(__file__).parent / "golden"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert kh.device_count() >= 1, "no HIP device visible"
+
+
+class _P:  # nav_msgs/Path shaped stand-in, like tests/test_controllers.py:47-80
+    def __init__(self, pts):
+        mk = lambda x, y: type("Pose", (), {"pose": type("I", (), {"position": type("Pt", (), {"x": x, "y": y})()})()})()
+        self.poses = [mk(float(x), float(y)) for x, y in pts]
+
+
+def ref_path():
+    d = json.loads((GOLD / "global_path.json").read_text())
+    return [(p["pose"]["position"]["x"], p["pose"]["position"]["y"]) for p in d["poses"]]
+
+
+CTR = {RobotType.ACKERMANN: ko.ACKERMANN, RobotType.DIFFERENTIAL_DRIVE: ko.DIFFERENTIAL_DRIVE, RobotType.OMNI: ko.OMNI}
+SHP = {RobotGeometry.Type.CYLINDER: ko.CYLINDER, RobotGeometry.Type.BOX: ko.BOX, RobotGeometry.Type.SPHERE: ko.SPHERE}
+
+
+def make_pair(robot_type, geom, dims, vx_lim, om_lim, cfg: DWAConfig, vy_lim=None):
+    robot = Robot(robot_type=robot_type, geometry_type=geom, geometry_params=np.array(dims))
+    vy = vy_lim or LinearCtrlLimits(max_vel=0.0, max_acc=0.0, max_decel=0.0)
+    limits = RobotCtrlLimits(vx_limits=vx_lim, omega_limits=om_lim, vy_limits=vy)
+    gpu = DWA(robot=robot, ctrl_limits=limits, config=cfg)
+    w = cfg.costs_weights
+    cpu = ko.DWA(
+        ko.make_limits((vx_lim.max_vel, vx_lim.max_acc, vx_lim.max_decel), (vy.max_vel, vy.max_acc, vy.max_decel),
+                       (om_lim.max_steer, om_lim.max_vel, om_lim.max_acc, om_lim.max_decel)),
+        CTR[robot_type], cfg.control_time_step, cfg.prediction_horizon * cfg.control_time_step,
+        cfg.control_horizon * cfg.control_time_step, cfg.max_linear_samples, cfg.max_angular_samples,
+        SHP[geom], dims, tuple(cfg.proximity_sensor_position_to_robot), tuple(cfg.proximity_sensor_rotation_to_robot),
+        cfg.octree_resolution,
+        ko.make_weights(w.reference_path_distance_weight, w.goal_distance_weight, w.obstacles_distance_weight,
+                        w.smoothness_weight, w.jerk_weight))
+    return robot, gpu, cpu
+
+
+def lockstep(robot, gpu, cpu, pts, start, scan=None, cloud=None, max_controls=100, dt=0.1):
+    """run_control() of tests/test_controllers.py:167-240 with the oracle stepping beside it."""
+    gpu.set_path(_P(pts))
+    cpu.set_path(np.array([[x, y, 0.0] for x, y in pts], np.float32))
+    robot.state.x, robot.state.y, robot.state.yaw = start
+    i, cycles = 0, 0
+    end = False
+    while not end and i < max_controls:
+        s = robot.state
+        ok = gpu.loop_step(current_state=s, laser_scan=scan, local_map=cloud)
+        cpu.set_state(s.x, s.y, s.yaw, s.speed)
+        if cpu.is_goal_reached():
+            assert not ok
+            end = gpu.reached_end()
+            break
+        o = cpu.compute((s.vx, s.vy, s.omega), scan=(scan.ranges, scan.angles) if scan is not None else None,
+                        points=cloud)
+        assert ok
+        assert gpu.has_result() == bool(o["found"]), f"cycle {cycles}"
+        if not o["found"]:
+            break
+        assert np.float32(gpu.result_cost) == np.float32(o["cost"]), f"cycle {cycles}"
+        np.testing.assert_array_equal(np.asarray(gpu.optimal_path().x), o["path_x"])
+        np.testing.assert_array_equal(np.asarray(gpu.optimal_path().y), o["path_y"])
+        np.testing.assert_array_equal(np.asarray(gpu.control_till_horizon.vx), o["vel"][0])
+        np.testing.assert_array_equal(np.asarray(gpu.control_till_horizon.omega), o["vel"][2])
+        cycles += 1
+        for vx, vy, om in zip(gpu.linear_x_control, gpu.linear_y_control, gpu.angular_control):
+            robot.set_control(velocity_x=vx, velocity_y=vy, omega=om)
+            robot.get_state(dt=dt)
+            i += 1
+            end = gpu.reached_end()
+    return end, i, cycles
+
+
+def test_dwa_reference_python_scenario():
+    """tests/test_controllers.py::test_dwa: Ackermann, global_path.json, L = A = 4,
+    10-step horizon, weights path 3 / goal 1, empty 201-beam scan at 20 m."""
+    cfg = DWAConfig(max_linear_samples=4, max_angular_samples=4, octree_resolution=0.1,
+                    costs_weights=TrajectoryCostsWeights(reference_path_distance_weight=3.0, goal_distance_weight=1.0,
+                                                         smoothness_weight=0.0, jerk_weight=0.0,
+                                                         obstacles_distance_weight=0.0),
+                    prediction_horizon=10, control_horizon=2, control_time_step=0.1, max_num_threads=1)
+    robot, gpu, cpu = make_pair(RobotType.ACKERMANN, RobotGeometry.Type.CYLINDER, [0.1, 0.4],
+                                LinearCtrlLimits(max_vel=1.0, max_acc=5.0, max_decel=10.0),
+                                AngularCtrlLimits(max_vel=4.0, max_acc=3.0, max_decel=3.0, max_steer=np.pi), cfg)
+    end, n, cycles = lockstep(robot, gpu, cpu, ref_path(), (-0.51731912, 0.0, np.pi / 2), scan=LaserScanData())
+    assert end is True and n <= 100 and cycles > 5
+
+
+def _round_obstacle(x, y, radius, res=0.1):
+    pts = []
+    r = 0.0
+    while r <= radius:
+        if r == 0:
+            pts.append((x, y, 0.0))
+        else:
+            th = 0.0
+            while th < 2 * math.pi:
+                pts.append((x + r * math.cos(th), y + r * math.sin(th), 0.0))
+                th += res / r
+        r += res
+    return np.array(pts, np.float32)
+
+
+@pytest.mark.parametrize("rtype", [RobotType.ACKERMANN, RobotType.DIFFERENTIAL_DRIVE, RobotType.OMNI])
+@pytest.mark.parametrize("with_obstacle", [False, True])
+def test_dwa_cpp_scenarios(rtype, with_obstacle):
+    """src/kompass_cpp/tests/dwa_test.cpp:161-362: straight path, 3 robot types,
+    with / without a round obstacle beside the path (point-cloud input); the
+    robot must keep a clearance >= its radius and the GPU controller must agree
+    with the oracle every cycle."""
+    cfg = DWAConfig(max_linear_samples=11, max_angular_samples=11, octree_resolution=0.1,
+                    costs_weights=TrajectoryCostsWeights(reference_path_distance_weight=1.0, goal_distance_weight=3.0,
+                                                         obstacles_distance_weight=1.0, smoothness_weight=0.0,
+                                                         jerk_weight=0.0),
+                    prediction_horizon=20, control_horizon=2, control_time_step=0.1)
+    robot, gpu, cpu = make_pair(rtype, RobotGeometry.Type.CYLINDER, [0.1, 0.4],
+                                LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0),
+                                AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0), cfg,
+                                vy_lim=LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0))
+    pts = [(x, 0.0) for x in np.arange(0.0, 10.01, 0.5)]
+    cloud = _round_obstacle(3.0, 0.35, 0.2) if with_obstacle else np.array([[50.0, 50.0, 0.0]], np.float32)
+    end, n, cycles = lockstep(robot, gpu, cpu, pts, (0.0, 0.1, 0.0), cloud=cloud, max_controls=400)
+    assert cycles > 10
+    assert end is True, f"goal not reached after {n} controls"
+
+
+def test_debug_samples_and_custom_cost():
+    cfg = DWAConfig(max_linear_samples=7, max_angular_samples=7, octree_resolution=0.1, prediction_horizon=10,
+                    control_horizon=2, control_time_step=0.1,
+                    costs_weights=TrajectoryCostsWeights(reference_path_distance_weight=1.0, goal_distance_weight=1.0,
+                                                         obstacles_distance_weight=0.0))
+    robot, gpu, cpu = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.BOX, [0.4, 0.3, 0.5],
+                                LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0),
+                                AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0), cfg)
+    pts = [(x, 0.0) for x in np.arange(0.0, 6.01, 0.5)]
+    gpu.set_path(_P(pts))
+    cpu.set_path(np.array([[x, y, 0.0] for x, y in pts], np.float32))
+    robot.state.x, robot.state.y, robot.state.yaw = 0.0, 0.2, 0.1
+    robot.state.vx = 0.4
+    cloud = _round_obstacle(0.8, 0.35, 0.2)
+    s = robot.state
+    assert gpu.loop_step(current_state=s, local_map=cloud, debug=True)
+    cpu.set_state(s.x, s.y, s.yaw, s.speed)
+    o = cpu.compute((s.vx, s.vy, s.omega), points=cloud)
+    px, py = gpu.planner.get_debugging_samples()
+    assert 0 < len(o["samples_x"]) < o["n_generated"]
+    np.testing.assert_array_equal(px, o["samples_x"])
+    np.testing.assert_array_equal(py, o["samples_y"])
+    # custom cost: prefer trajectories ending far to the left (+y); host callback
+    calls = []
+
+    def custom(traj, path):
+        calls.append(1)
+        return float(-traj.path.y[-1])
+
+    gpu.planner.add_custom_cost(5.0, custom)
+    assert gpu.loop_step(current_state=s, local_map=cloud)
+    assert len(calls) == len(o["samples_x"])
+    want = (o["costs"].astype(np.float64) + 5.0 * (-o["samples_y"][:, -1]).astype(np.float32).astype(np.float64)).astype(np.float32)
+    k = int(np.argmin(want))
+    assert np.float32(gpu.result_cost) == want[k]
+    np.testing.assert_array_equal(np.asarray(gpu.optimal_path().y), o["samples_y"][k])
+
+
+def test_local_mapper_frontend():
+    """kompass_core.mapping.LocalMapper.update_from_scan (tests/test_local_mapper_
+    pytest.py invariants) + cell-exact agreement with the CPU mapper semantics."""
+    d = json.loads((GOLD / "laserscan_data.json").read_text())
+    scan = LaserScanData(angle_min=d["angle_min"], angle_max=d["angle_max"], angle_increment=d["angle_increment"],
+                         range_max=d["range_max"], ranges=np.array(d["ranges"], float),
+                         angles=d["angle_min"] + np.arange(len(d["ranges"])) * d["angle_increment"])
+    scan.ranges = np.nan_to_num(scan.ranges, posinf=scan.range_max)
+    m = LocalMapper(MapConfig(width=8.0, height=6.0, resolution=0.05))
+    m.update_from_scan(None, scan)
+    g = m.occupancy
+    assert g.shape == (120, 160) and g.dtype == np.int32
+    assert set(np.unique(g)) <= {-1, 0, 100} and (g == 100).sum() > 0 and (g == 0).sum() > 0
+    want = ko.scan_to_grid(120, 160, 0.05, (0, 0, 0), 0.0, scan.angles, np.clip(scan.ranges, 0, 20.0))
+    np.testing.assert_array_equal(g, want)
+    # out-of-grid scan => (almost) no OCCUPIED cells (test_local_mapper_pytest.py:198-230)
+    far = LaserScanData(ranges=np.full(360, 50.0), angles=np.linspace(0, 2 * np.pi, 360, endpoint=False), range_max=60.0)
+    m2 = LocalMapper(MapConfig(width=4.0, height=4.0, resolution=0.05, filter_limit=60.0))
+    m2.update_from_scan(None, far)
+    assert (m2.occupancy == 100).mean() < 0.01
+
+
+def test_collision_checker_batch_poses():
+    """kc_dwa_check_poses == oracle check_at for all shapes (checkStatesFeasibility path)."""
+    rng = np.random.default_rng(9)
+    cloud = (rng.random((400, 3)) * [6, 6, 0.6] - [3, 3, 0.3]).astype(np.float32)
+    for shape, dims in [(kh.CYLINDER, [0.2, 0.5]), (kh.BOX, [0.5, 0.3, 0.4]), (kh.SPHERE, [0.25])]:
+        ctx = kh.DwaContext(shape, dims, octree_res=0.1, max_samples=4, max_points=4)
+        ctx.set_points((0.5, -0.5, 0.3, 0), cloud)
+        x, y, yaw = rng.random(500) * 6 - 3, rng.random(500) * 6 - 3, rng.random(500) * 6.28 - 3.14
+        got = ctx.check_poses(x, y, yaw)
+        c = ko.Collision(shape, dims, res=0.1)
+        c.update_state(0.5, -0.5, 0.3)
+        c.update_points(cloud, True)
+        want = np.array([c.check_at(a, b, t) for a, b, t in zip(x, y, yaw)])
+        assert 0 < want.sum() < 500
+        np.testing.assert_array_equal(got, want)
