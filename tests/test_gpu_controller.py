@@ -76,8 +76,9 @@ def lockstep(robot, gpu, cpu, pts, start, scan=None, cloud=None, max_controls=10
             assert not ok
             end = gpu.reached_end()
             break
-        o = cpu.compute((s.vx, s.vy, s.omega), scan=(scan.ranges, scan.angles) if scan is not None else None,
-                        points=cloud)
+        # kompass_cpp.types.Velocity2D takes float arguments (bindings_types.cpp:63-67)
+        vel = tuple(float(np.float32(v)) for v in (s.vx, s.vy, s.omega))
+        o = cpu.compute(vel, scan=(scan.ranges, scan.angles) if scan is not None else None, points=cloud)
         assert ok
         assert gpu.has_result() == bool(o["found"]), f"cycle {cycles}"
         if not o["found"]:
@@ -166,7 +167,8 @@ def test_debug_samples_and_custom_cost():
     s = robot.state
     assert gpu.loop_step(current_state=s, local_map=cloud, debug=True)
     cpu.set_state(s.x, s.y, s.yaw, s.speed)
-    o = cpu.compute((s.vx, s.vy, s.omega), points=cloud)
+    vel = tuple(float(np.float32(v)) for v in (s.vx, s.vy, s.omega))  # Velocity2D(float, ...)
+    o = cpu.compute(vel, points=cloud)
     px, py = gpu.planner.get_debugging_samples()
     assert 0 < len(o["samples_x"]) < o["n_generated"]
     np.testing.assert_array_equal(px, o["samples_x"])
