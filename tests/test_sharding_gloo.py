@@ -1,0 +1,64 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharded cycle (contiguous
+sample blocks, ONE all-reduce(min) of the packed key, compacted index rebuilt
+with one all-reduce(sum)) must reproduce the unsharded oracle result."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import sharding
+import synthetic as syn
+from helpers import oracle_cycle
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_shard_range_partitions():
+    for n in [0, 1, 7, 8192, 65250]:
+        for w in [1, 2, 3, 8]:
+            parts = [sharding.shard_range(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+            for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_key_order_is_lowest_cost_then_lowest_index():
+    rng = np.random.default_rng(0)
+    costs = np.float32(rng.random(200) * 3 - 0.5)
+    costs[17] = costs[5]  # tie
+    costs[33] = np.float32(0.0); costs[34] = np.float32(-0.0)
+    keys = [sharding.key_pack(c, i) for i, c in enumerate(costs)]
+    best = min(range(200), key=lambda i: keys[i])
+    want = min(range(200), key=lambda i: (float(costs[i]), i))
+    assert best == want
+    found, cost, idx = sharding.key_unpack(keys[best])
+    assert found and idx == best and np.float32(cost) == costs[best]
+    assert sharding.key_pack(np.inf, 3) == sharding.KEY_NONE
+    assert sharding.key_unpack(sharding.KEY_NONE) == (False, 0.0, -1)
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_matches_unsharded(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "res.json"
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(ROOT / "tests" / "_gloo_worker.py"), str(out)]
+    subprocess.run(cmd, check=True, env=env, timeout=280, capture_output=True)
+    got = json.loads(out.read_text())
+    for g, (name, scale, seed) in zip(got, [("cfg1", 1.0, 1), ("cfg2", 0.25, 2), ("cfg5", 0.08, 3)]):
+        o = oracle_cycle(syn.make_controller_inputs(name, seed=seed, scale=scale))
+        assert g["found"] == (o["index"] >= 0)
+        assert g["index"] == o["index"], name
+        assert g["raw"] == int(o["raw"][o["index"]])
+        assert np.float32(g["cost"]) == np.float32(o["cost"])
