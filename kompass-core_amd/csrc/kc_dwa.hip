@@ -333,7 +333,8 @@ struct BucketDev {
 
 struct PairArgs {
   const float *px, *py;
-  const uint8_t *flags;
+  const int *adm_list;   // admissible sample ids (local), ascending
+  const int *adm_count;  // device-side count
   int n, P;
   int use_seg, use_obs;
   // tracked segment
@@ -347,108 +348,207 @@ struct PairArgs {
   double *omin;
 };
 
-__global__ __launch_bounds__(kPairBlock) void pair_cost_kernel(PairArgs a) {
-  const long t = (long)blockIdx.x * kPairBlock + threadIdx.x;
-  if (t >= (long)a.n * a.P) return;
-  const int s = static_cast<int>(t / a.P);
-  if (!a.flags[s]) return;
-  const float x = a.px[t], y = a.py[t];
-
-  if (a.use_seg) {
-    const double qx = static_cast<double>(x), qy = static_cast<double>(y);
-    // nearest run centre first: a good bound before anything is skipped
-    int r0 = 0;
-    double c0 = DBL_MAX;
-    for (int r = 0; r < a.nruns; ++r) {
-      const double4 c = a.runs[r];
-      const double dx = c.x - qx, dy = c.y - qy;
-      const double d = dx * dx + dy * dy + c.z * c.z;
-      if (d < c0) {
-        c0 = d;
-        r0 = r;
-      }
+// nearest tracked-segment point, one lane per trajectory point (G == 1):
+// run-pruned exact search
+__device__ __forceinline__ void seg_search_pruned(const PairArgs &a, float x,
+                                                  float y, float &best_out,
+                                                  int &arg_out) {
+  const double qx = static_cast<double>(x), qy = static_cast<double>(y);
+  // nearest run centre first: a good bound before anything is skipped
+  int r0 = 0;
+  double c0 = DBL_MAX;
+  for (int r = 0; r < a.nruns; ++r) {
+    const double4 c = a.runs[r];
+    const double dx = c.x - qx, dy = c.y - qy;
+    const double d = dx * dx + dy * dy + c.z * c.z;
+    if (d < c0) {
+      c0 = d;
+      r0 = r;
     }
-    float best = FLT_MAX;
-    int arg = 0;
-    double sb = DBL_MAX;  // sqrt(best) with the guard
-    for (int pass = 0; pass < 2; ++pass) {
-      const int rb = pass == 0 ? r0 : 0;
-      const int re = pass == 0 ? r0 + 1 : a.nruns;
-      for (int r = rb; r < re; ++r) {
-        if (pass == 1) {
-          if (r == r0) continue;
-          const double4 c = a.runs[r];
-          const double dx = c.x - qx, dy = c.y - qy;
-          const double dc2 = dx * dx + dy * dy + c.z * c.z;
-          const double lim = c.w + sb;
-          if (sb < 1e300 && dc2 > lim * lim) continue;  // cannot reach best
+  }
+  float best = FLT_MAX;
+  int arg = 0;
+  double sb = DBL_MAX;  // sqrt(best) with the guard
+  for (int pass = 0; pass < 2; ++pass) {
+    const int rb = pass == 0 ? r0 : 0;
+    const int re = pass == 0 ? r0 + 1 : a.nruns;
+    for (int r = rb; r < re; ++r) {
+      if (pass == 1) {
+        if (r == r0) continue;
+        const double4 c = a.runs[r];
+        const double dx = c.x - qx, dy = c.y - qy;
+        const double dc2 = dx * dx + dy * dy + c.z * c.z;
+        const double lim = c.w + sb;
+        if (sb < 1e300 && dc2 > lim * lim) continue;  // cannot reach best
+      }
+      const int j0 = r * kSegRun, j1 = min(j0 + kSegRun, a.S);
+      bool improved = false;
+      for (int j = j0; j < j1; ++j) {
+        const float dx = a.sx[j] - x;
+        const float dy = a.sy[j] - y;
+        const float xx = dx * dx;
+        const float yy = dy * dy;
+        const float d = xx + (yy + a.szz[j]);  // Eigen order a + (b + c)
+        // first minimum in index order, whatever the visiting order
+        if (d < best || (d == best && j < arg)) {
+          best = d;
+          arg = j;
+          improved = true;
         }
-        const int j0 = r * kSegRun, j1 = min(j0 + kSegRun, a.S);
-        bool improved = false;
-        for (int j = j0; j < j1; ++j) {
+      }
+      if (improved)
+        sb = kc::dsqrt_rn(static_cast<double>(best)) * (1.0 + 1e-6) + 1e-30;
+    }
+  }
+  best_out = best;
+  arg_out = arg;
+}
+
+// G lanes per trajectory point (G = 1, 8 or 64, picked on the device from the
+// number of admissible samples so that the chip stays full whether 5 % or
+// 100 % of the samples survive the collision gate).
+template <int G>
+__device__ __forceinline__ void pair_body(const PairArgs &a, int na) {
+  constexpr int kGroupsPerBlock = kPairBlock / G;
+  const int gl = threadIdx.x % G;  // lane within the group
+  const long group0 = (long)blockIdx.x * kGroupsPerBlock + threadIdx.x / G;
+  const long ngroups = (long)gridDim.x * kGroupsPerBlock;
+  const long total = (long)na * a.P;
+  for (long w = group0; w < total; w += ngroups) {
+    const int i = static_cast<int>(w / a.P);
+    const int p = static_cast<int>(w - (long)i * a.P);
+    const int s = a.adm_list[i];
+    const long t = (long)s * a.P + p;
+    const float x = a.px[t], y = a.py[t];
+
+    if (a.use_seg) {
+      float best;
+      int arg;
+      if (G == 1) {
+        seg_search_pruned(a, x, y, best, arg);
+      } else {
+        // cooperative brute force: lane gl scans j = gl, gl + G, ...
+        best = FLT_MAX;
+        arg = 0;
+        for (int j = gl; j < a.S; j += G) {
           const float dx = a.sx[j] - x;
           const float dy = a.sy[j] - y;
           const float xx = dx * dx;
           const float yy = dy * dy;
-          const float d = xx + (yy + a.szz[j]);  // Eigen order a + (b + c)
-          // first minimum in index order, whatever the visiting order
-          if (d < best || (d == best && j < arg)) {
+          const float d = xx + (yy + a.szz[j]);
+          if (d < best) {  // j ascending per lane: first index per lane
             best = d;
             arg = j;
-            improved = true;
           }
         }
-        if (improved)
-          sb = kc::dsqrt_rn(static_cast<double>(best)) * (1.0 + 1e-6) + 1e-30;
-      }
-    }
-    a.mind[t] = kc::sqrt_rn(best);
-    if (t - (long)s * a.P == a.P - 1) {
-      a.goal_d2[s] = best;
-      a.goal_arg[s] = arg;
-    }
-  }
-
-  if (a.use_obs) {
-    const BucketDev &b = a.b;
-    // query cell (clamped: a query outside the grid searches from the border
-    // and the guarantee radius shrinks by its distance to the grid)
-    const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-    const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-    int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-    double off = 0.0;
-    if (fx < 0.0) off = fmax(off, -fx);
-    if (fy < 0.0) off = fmax(off, -fy);
-    if (fx > b.W) off = fmax(off, fx - b.W);
-    if (fy > b.H) off = fmax(off, fy - b.H);
-    cx = min(max(cx, 0), b.W - 1);
-    cy = min(max(cy, 0), b.H - 1);
-    double best = DBL_MAX;
-    const int mmax = max(b.W, b.H);
-    for (int m = 1;; m = 2 * m + 1) {
-      const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-      const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-      for (int row = y0; row <= y1; ++row) {
-        const int beg = b.cell_start[row * b.W + x0];
-        const int end = b.cell_start[row * b.W + x1 + 1];
-        for (int j = beg; j < end; ++j) {
-          const double dx = static_cast<double>(b.bx[j] - x);
-          const double dy = static_cast<double>(b.by[j] - y);
-          const double dd = dx * dx + dy * dy;
-          best = dd < best ? dd : best;
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+          const float ob = __shfl_xor(best, off, 64);
+          const int oa = __shfl_xor(arg, off, 64);
+          if (ob < best || (ob == best && oa < arg)) {
+            best = ob;
+            arg = oa;
+          }
         }
       }
-      // every obstacle closer than `reach` (true distance) has been visited
-      const double reach = (static_cast<double>(m) - off) * b.g;
-      if (reach > 0.0) {
-        const double r2 = reach * reach * (1.0 - 1e-6);
-        if (best < r2) break;
-        if (reach >= b.cap) break;
+      if (gl == 0) {
+        a.mind[t] = kc::sqrt_rn(best);
+        if (p == a.P - 1) {
+          a.goal_d2[s] = best;
+          a.goal_arg[s] = arg;
+        }
       }
-      if (m >= mmax) break;  // whole grid visited
     }
-    a.omin[t] = best;
+
+    if (a.use_obs) {
+      const BucketDev &b = a.b;
+      // query cell (clamped: a query outside the grid searches from the border
+      // and the guarantee radius shrinks by its distance to the grid)
+      const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+      const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+      int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+      double off = 0.0;
+      if (fx < 0.0) off = fmax(off, -fx);
+      if (fy < 0.0) off = fmax(off, -fy);
+      if (fx > b.W) off = fmax(off, fx - b.W);
+      if (fy > b.H) off = fmax(off, fy - b.H);
+      cx = min(max(cx, 0), b.W - 1);
+      cy = min(max(cy, 0), b.H - 1);
+      double best = DBL_MAX;
+      const int mmax = max(b.W, b.H);
+      for (int m = 1;; m = 2 * m + 1) {
+        const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+        const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+        // the rows of the block are spread over the lanes of the group
+        for (int row = y0 + gl; row <= y1; row += G) {
+          const int beg = b.cell_start[row * b.W + x0];
+          const int end = b.cell_start[row * b.W + x1 + 1];
+          for (int j = beg; j < end; ++j) {
+            const double dx = static_cast<double>(b.bx[j] - x);
+            const double dy = static_cast<double>(b.by[j] - y);
+            const double dd = dx * dx + dy * dy;
+            best = dd < best ? dd : best;
+          }
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+          const double ob = __shfl_xor(best, o, 64);
+          best = ob < best ? ob : best;
+        }
+        // every obstacle closer than `reach` (true distance) has been visited
+        const double reach = (static_cast<double>(m) - off) * b.g;
+        if (reach > 0.0) {
+          const double r2 = reach * reach * (1.0 - 1e-6);
+          if (best < r2) break;
+          if (reach >= b.cap) break;
+        }
+        if (m >= mmax) break;  // whole grid visited
+      }
+      if (gl == 0) a.omin[t] = best;
+    }
   }
+}
+
+__global__ __launch_bounds__(kPairBlock) void pair_cost_kernel(PairArgs a) {
+  const int na = *a.adm_count;
+  const long points = (long)na * a.P;
+  const long lanes = (long)gridDim.x * kPairBlock;
+  // widest group that still leaves every group at most ~2 points
+  if (points * 64 <= 2 * lanes) pair_body<64>(a, na);
+  else if (points * 8 <= 2 * lanes) pair_body<8>(a, na);
+  else pair_body<1>(a, na);
+}
+
+// ordered compaction of the admissible flags (one workgroup): adm_list[i] =
+// i-th admissible local sample id, adm_count = how many.  Runs after the
+// collision pass; a kernel boundary is the cheapest agent-scope hand-off.
+__global__ __launch_bounds__(1024) void compact_kernel(
+    const uint8_t *__restrict__ flags, int n, int *__restrict__ adm_list,
+    int *__restrict__ adm_count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int tile = 0; tile < n; tile += 1024) {
+    const int i = tile + threadIdx.x;
+    const bool f = i < n && flags[i] != 0;
+    const unsigned long long bal = __ballot(f);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) woff += wave_tot[w];
+      tot += wave_tot[w];
+    }
+    const int base = base_s;
+    if (f) adm_list[base + woff + before] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s = base + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *adm_count = base_s;
 }
 
 // ===========================================================================
@@ -463,6 +563,7 @@ struct FinalArgs {
   int have_vel;
   const float *px, *py;
   const uint8_t *flags;
+  const int *adm_list, *adm_count;
   const float *sx, *sy, *sz, *acc_seg;
   float seg_len, ref_len;
   const float *mind;
@@ -517,10 +618,13 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long key = KEY_NONE;  // best of this wavefront's samples
   int adm = 0;
-  // few, fat workgroups: the per-block atomics below all hit the same words
-  for (int n = blockIdx.x * kFinalSamples + wave; n < a.n;
-       n += gridDim.x * kFinalSamples) {
-  if (a.flags[n]) {  // wave-uniform
+  // few, fat workgroups: the per-block atomics below all hit the same words;
+  // only admissible samples are visited (compacted list)
+  const int na = *a.adm_count;
+  for (int i = blockIdx.x * kFinalSamples + wave; i < na;
+       i += gridDim.x * kFinalSamples) {
+  const int n = a.adm_list[i];
+  {
     adm += 1;
     const float *px = a.px + (size_t)n * a.P;
     const float *py = a.py + (size_t)n * a.P;
@@ -607,8 +711,6 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
       const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
       key = k < key ? k : key;
     }
-  } else {
-    if (lane == 0) a.costs[n] = FLT_MAX;
   }
   }  // sample loop
 
@@ -639,28 +741,29 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
   if (!is_last) return;
   // ---- last block: publish + compacted index + re-arm -----------------------
   __threadfence();
-  // atomics are performed at the memory side: these reads see every block
-  const long long fkey = atomicMin(&a.result[W_KEY], KEY_NONE);
-  const long long fadm = static_cast<long long>(atomicAdd(
-      reinterpret_cast<unsigned long long *>(&a.result[W_NADM]), 0ull));
-  int cnt = 0;
-  if (fkey != KEY_NONE) {
-    const long long raw =
-        static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll));
-    long long lim = raw - a.first;
-    if (lim > a.n) lim = a.n;
-    for (long long i = threadIdx.x; i < lim; i += kFinalBlock) cnt += a.flags[i];
-  }
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-  __shared__ int wsum[kFinalSamples];
-  if (lane == 0) wsum[wave] = cnt;
-  __syncthreads();
   if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < kFinalSamples; ++w) s += wsum[w];
+    // atomics are performed at the memory side: these reads see every block
+    const long long fkey = atomicMin(&a.result[W_KEY], KEY_NONE);
+    const long long fadm = static_cast<long long>(atomicAdd(
+        reinterpret_cast<unsigned long long *>(&a.result[W_NADM]), 0ull));
+    int s = -1;
+    if (fkey != KEY_NONE) {
+      // position of the winner in the ordered admissible list = the
+      // reference's index into its admissible-only container
+      const int local = static_cast<int>(
+          static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) -
+          a.first);
+      int lo = 0, hi = na;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a.adm_list[mid] < local) lo = mid + 1;
+        else hi = mid;
+      }
+      s = lo;
+    }
     a.result[R_KEY] = fkey;
     a.result[R_NADM] = fadm;
-    a.result[R_COMPACT] = (fkey == KEY_NONE) ? -1 : s;
+    a.result[R_COMPACT] = s;
     a.result[W_KEY] = KEY_NONE;
     a.result[W_NADM] = 0;
     a.result[W_TICKET] = 0;
@@ -746,6 +849,7 @@ struct kc_dwa {
   DevBuf<double> d_ddz;
   DevBuf<float> d_px, d_py, d_mind, d_costs, d_goal_d2;
   DevBuf<int> d_goal_arg;
+  DevBuf<int> d_adm;  // [0] count, [1..] ordered admissible sample ids
   DevBuf<double2> d_pos;
   DevBuf<double> d_omin;
   DevBuf<uint8_t> d_flags;
@@ -1007,6 +1111,7 @@ int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
   KC_TRY(c->d_py.reserve(n * P));
   KC_TRY(c->d_flags.reserve(n));
   KC_TRY(c->d_costs.reserve(n));
+  KC_TRY(c->d_adm.reserve(n + 1));
   return KC_OK;
 }
 
@@ -1026,11 +1131,16 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
   const float *seg = c->d_seg.p;
   const size_t S = c->S;
+  KC_TRY(c->timing.start("compact_kernel", s));
+  hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, c->d_flags.p,
+                     static_cast<int>(n), c->d_adm.p + 1, c->d_adm.p);
+  KC_TRY(c->timing.stop(s));
   if (use_path || use_goal || use_obs) {
     PairArgs pa{};
     pa.px = c->d_px.p;
     pa.py = c->d_py.p;
-    pa.flags = c->d_flags.p;
+    pa.adm_list = c->d_adm.p + 1;
+    pa.adm_count = c->d_adm.p;
     pa.n = static_cast<int>(n);
     pa.P = static_cast<int>(P);
     pa.use_seg = (use_path || use_goal) ? 1 : 0;
@@ -1055,8 +1165,12 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
       pa.omin = c->d_omin.p;
     }
     KC_TRY(c->timing.start("pair_cost_kernel", s));
-    hipLaunchKernelGGL(pair_cost_kernel, dim3(blocks_for(n * P, kPairBlock)),
-                       dim3(kPairBlock), 0, s, pa);
+    // fixed-size grid: the kernel sizes its lane groups from the device-side
+    // admissible count
+    const unsigned pair_blocks =
+        std::min(2048u, std::max(64u, blocks_for(n * P * 64, kPairBlock)));
+    hipLaunchKernelGGL(pair_cost_kernel, dim3(pair_blocks), dim3(kPairBlock), 0,
+                       s, pa);
     KC_TRY(c->timing.stop(s));
   }
   FinalArgs fa{};
@@ -1069,6 +1183,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   fa.px = c->d_px.p;
   fa.py = c->d_py.p;
   fa.flags = c->d_flags.p;
+  fa.adm_list = c->d_adm.p + 1;
+  fa.adm_count = c->d_adm.p;
   fa.sx = seg;
   fa.sy = seg + S;
   fa.sz = seg + 2 * S;
@@ -1245,6 +1361,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_bobs.release();
   c->d_goal_d2.release();
   c->d_goal_arg.release();
+  c->d_adm.release();
   c->d_pos.release();
   c->d_result.release();
   c->h_result.release();
