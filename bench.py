@@ -87,13 +87,12 @@ def controller_bench(args, rank, world, local_rank):
         return (0.0, 0.0, 1e-3 * ((i % 7) - 3), 0.0)
 
     def one_cycle(i):
+        if not use_dist:
+            return ctx.cycle(pose(i), P)  # roll-out + evaluate + fetch in one ABI call
         ctx.rollout(pose(i), P)
         ctx.evaluate()
-        if use_dist:
-            sharding.allreduce_best(key_t)
-            return int(key_t.item())  # D2H + sync, like fetch_result
-        r = ctx.fetch_result()
-        return r
+        sharding.allreduce_best(key_t)
+        return int(key_t.item())  # D2H + sync, like fetch_result
 
     def barrier():
         if use_dist:
@@ -104,9 +103,7 @@ def controller_bench(args, rank, world, local_rank):
 
     for i in range(args.warmup):
         one_cycle(i)
-    # ---- timed region -----------------------------------------------------
-    ctx.timing_enable(True)
-    kernel_ms, host_ms = {}, {}
+    # ---- timed region: EXACTLY args.steps cycles, barrier + sync on both sides
     lat = []
     barrier()
     t0 = time.perf_counter()
@@ -115,17 +112,25 @@ def controller_bench(args, rank, world, local_rank):
         ts = time.perf_counter()
         last = one_cycle(i)
         lat.append(time.perf_counter() - ts)
-        for name, ms in ctx.timings():  # HIP events on the launch stream (+ host phases)
-            (host_ms if name.startswith("host:") else kernel_ms).setdefault(name, []).append(ms)
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.timing_enable(False)
     if use_dist:
         import torch.distributed as dist
 
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- same cycles again with HIP events around every kernel, recorded on the
+    # stream the kernels are launched on (roofline leg; events cost a few us per
+    # cycle, so they stay out of `value`)
+    ctx.timing_enable(True)
+    kernel_ms, host_ms = {}, {}
+    for i in range(args.steps):
+        one_cycle(i)
+        for name, ms in ctx.timings():
+            (host_ms if name.startswith("host:") else kernel_ms).setdefault(name, []).append(ms)
+    ctx.timing_enable(False)
+    last = one_cycle(args.steps - 1)
 
     # ---- result of the last cycle (for the parity check below) -------------
     if use_dist:

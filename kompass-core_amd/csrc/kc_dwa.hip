@@ -10,7 +10,9 @@
 // the host by the same libm the reference calls (path.h:24-30) and handed to
 // the kernel as a table -- the device never evaluates a trig function.
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <unordered_map>
 
@@ -343,6 +345,9 @@ struct PairArgs {
   const double4 *runs;  // per run: centre (x, y, z) and radius
   float *mind, *goal_d2;
   int *goal_arg;
+  const float *sz_raw, *acc_seg;  // un-squared z, prefix arc length per point
+  float seg_len, ref_len;
+  float *goal_cost, *end_err;     // per sample, written by its END-point lane
   // obstacles
   BucketDev b;
   double *omin;
@@ -456,6 +461,14 @@ __device__ __forceinline__ void pair_body(const PairArgs &a, int na) {
         if (p == a.P - 1) {
           a.goal_d2[s] = best;
           a.goal_arg[s] = arg;
+          // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
+          const float arc = kc::div_rn(a.ref_len - a.acc_seg[arg], a.ref_len);
+          a.goal_cost[s] = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
+          // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
+          const int e = a.S - 1;
+          const float dx = x - a.sx[e], dy = y - a.sy[e], dz = 0.0f - a.sz_raw[e];
+          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+          a.end_err[s] = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
         }
       }
     }
@@ -522,33 +535,43 @@ __global__ __launch_bounds__(kPairBlock) void pair_cost_kernel(PairArgs a) {
 // ordered compaction of the admissible flags (one workgroup): adm_list[i] =
 // i-th admissible local sample id, adm_count = how many.  Runs after the
 // collision pass; a kernel boundary is the cheapest agent-scope hand-off.
+// Every thread owns a contiguous chunk (all its flags are requested up front:
+// one memory latency), a block-wide scan of the chunk counts gives the offsets.
+constexpr int kCompactMaxPer = 64;  // 1024 threads x 64 = 65536 samples
+
 __global__ __launch_bounds__(1024) void compact_kernel(
     const uint8_t *__restrict__ flags, int n, int *__restrict__ adm_list,
     int *__restrict__ adm_count) {
   __shared__ int wave_tot[16];
-  __shared__ int base_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base_s = 0;
-  __syncthreads();
-  for (int tile = 0; tile < n; tile += 1024) {
-    const int i = tile + threadIdx.x;
-    const bool f = i < n && flags[i] != 0;
-    const unsigned long long bal = __ballot(f);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wave] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-      if (w < wave) woff += wave_tot[w];
-      tot += wave_tot[w];
-    }
-    const int base = base_s;
-    if (f) adm_list[base + woff + before] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) base_s = base + tot;
-    __syncthreads();
+  const int per = (n + 1023) / 1024;  // <= kCompactMaxPer (checked on the host)
+  const int i0 = threadIdx.x * per;
+  unsigned long long bits = 0;  // per <= 64 flags of this thread
+  for (int k = 0; k < per; ++k) {
+    const int i = i0 + k;
+    if (i < n && flags[i] != 0) bits |= 1ull << k;
   }
-  if (threadIdx.x == 0) *adm_count = base_s;
+  const int mine = __popcll(bits);
+  // inclusive scan of `mine` inside the wave, then across the 16 waves
+  int incl = mine;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int woff = 0, tot = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) woff += wave_tot[w];
+    tot += wave_tot[w];
+  }
+  int dst = woff + incl - mine;
+  while (bits) {
+    const int k = __ffsll(static_cast<long long>(bits)) - 1;
+    bits &= bits - 1;
+    adm_list[dst++] = i0 + k;
+  }
+  if (threadIdx.x == 0) *adm_count = tot;
 }
 
 // ===========================================================================
@@ -567,8 +590,7 @@ struct FinalArgs {
   const float *sx, *sy, *sz, *acc_seg;
   float seg_len, ref_len;
   const float *mind;
-  const float *goal_d2;
-  const int *goal_arg;
+  const float *goal_cost, *end_err;
   const double *omin;
   const float *vvx, *vvy, *vom;  // [n][P-1] when have_vel
   float max_obs_dist;
@@ -576,6 +598,8 @@ struct FinalArgs {
   double w_path, w_goal, w_obs, w_smooth, w_jerk;
   float *costs;
   long long *result;  // R_* published record + W_* working area (see enum)
+  long long *host_pub;  // pinned host mirror {key, n_adm, compact, seq} or null
+  long long seq;        // cycle sequence number the host waits for
 };
 
 constexpr int kFinalBlock = 256;           // 4 wavefronts
@@ -626,17 +650,12 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
   const int n = a.adm_list[i];
   {
     adm += 1;
-    const float *px = a.px + (size_t)n * a.P;
-    const float *py = a.py + (size_t)n * a.P;
     float total = 0.0f;
     if (a.ref_len > 0.0f) {
       if (a.w_goal > 0.0) {
-        // goalCostFunc, cost_evaluator.cpp:150-177; the closest-point search
-        // ran in K2 (first minimum, strict <)
-        const float best = a.goal_d2[n];
-        const int arg = a.goal_arg[n];
-        const float arc = kc::div_rn(a.ref_len - a.acc_seg[arg], a.ref_len);
-        const float c = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
+        // goalCostFunc, cost_evaluator.cpp:150-177: evaluated by the END-point
+        // lane of the pair kernel
+        const float c = a.goal_cost[n];
         total = accum(total, a.w_goal, c);
       }
       if (a.w_path > 0.0) {
@@ -648,11 +667,7 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
           const float v = (lane < cnt) ? m[base + lane] : 0.0f;
           for (int i = 0; i < cnt; ++i) sum += lane_value(v, i);
         }
-        const int e = a.S - 1;
-        const float end_err = kc::div_rn(
-            kc::sqrt_rn(dist_sq3(px[a.P - 1], py[a.P - 1], 0.0f, a.sx[e],
-                                a.sy[e], a.sz[e])),
-            a.seg_len);
+        const float end_err = a.end_err[n];
         const float c = kc::div_rn(
             kc::div_rn(sum, static_cast<float>(a.P)) + end_err, 2.0f);
         total = accum(total, a.w_path, c);
@@ -764,6 +779,17 @@ __global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
     a.result[R_KEY] = fkey;
     a.result[R_NADM] = fadm;
     a.result[R_COMPACT] = s;
+    if (a.host_pub) {
+      // zero-copy hand-off: the host polls the sequence word instead of
+      // waiting on a D2H copy + stream sync
+      volatile long long *hp = a.host_pub;
+      hp[0] = fkey;
+      hp[1] = fadm;
+      hp[2] = s;
+      __threadfence_system();
+      hp[3] = a.seq;
+      __threadfence_system();
+    }
     a.result[W_KEY] = KEY_NONE;
     a.result[W_NADM] = 0;
     a.result[W_TICKET] = 0;
@@ -847,7 +873,7 @@ struct kc_dwa {
   DevBuf<uint32_t> d_bits;
   PinBuf<double> h_ddz;
   DevBuf<double> d_ddz;
-  DevBuf<float> d_px, d_py, d_mind, d_costs, d_goal_d2;
+  DevBuf<float> d_px, d_py, d_mind, d_costs, d_goal_d2, d_goal_cost, d_end_err;
   DevBuf<int> d_goal_arg;
   DevBuf<int> d_adm;  // [0] count, [1..] ordered admissible sample ids
   DevBuf<double2> d_pos;
@@ -875,6 +901,9 @@ struct kc_dwa {
 
   DevBuf<long long> d_result;  // key, n_adm, compact index, scratch
   PinBuf<long long> h_result;
+  PinBuf<long long> h_pub;     // {key, n_adm, compact, seq} written by the GPU
+  long long seq = 0;           // last cycle sequence handed to finalize
+  bool pub_pending = false;
   PinBuf<float> h_row;         // winner row staging
   kc_result last{};
   bool have_last = false;
@@ -1121,8 +1150,11 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   if (n == 0) {  // empty batch: publish "nothing found"
     hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, s,
                        c->d_result.p);
+    c->pub_pending = false;
     return KC_OK;
   }
+  if (n > 1024u * kCompactMaxPer)
+    KC_FAIL(KC_ERR_RANGE, "more than %d samples per context", 1024 * kCompactMaxPer);
   const bool use_path = c->ref_len > 0.0f &&
                         c->w.reference_path_distance_weight > 0.0;
   const bool use_goal = c->ref_len > 0.0f && c->w.goal_distance_weight > 0.0;
@@ -1149,6 +1181,14 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
       KC_TRY(c->d_mind.reserve(n * P));
       KC_TRY(c->d_goal_d2.reserve(n));
       KC_TRY(c->d_goal_arg.reserve(n));
+      KC_TRY(c->d_goal_cost.reserve(n));
+      KC_TRY(c->d_end_err.reserve(n));
+      pa.sz_raw = seg + 2 * S;
+      pa.acc_seg = seg + 4 * S;
+      pa.seg_len = c->seg_len;
+      pa.ref_len = c->ref_len;
+      pa.goal_cost = c->d_goal_cost.p;
+      pa.end_err = c->d_end_err.p;
       pa.sx = seg;
       pa.sy = seg + S;
       pa.szz = seg + 3 * S;
@@ -1192,8 +1232,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   fa.seg_len = c->seg_len;
   fa.ref_len = c->ref_len;
   fa.mind = c->d_mind.p;
-  fa.goal_d2 = c->d_goal_d2.p;
-  fa.goal_arg = c->d_goal_arg.p;
+  fa.goal_cost = c->d_goal_cost.p;
+  fa.end_err = c->d_end_err.p;
   fa.omin = c->d_omin.p;
   fa.vvx = c->d_vvx.p;
   fa.vvy = c->d_vvy.p;
@@ -1209,9 +1249,12 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   fa.w_jerk = c->w.jerk_weight;
   fa.costs = c->d_costs.p;
   fa.result = c->d_result.p;
+  fa.host_pub = c->h_pub.p;
+  fa.seq = ++c->seq;
+  c->pub_pending = true;
   KC_TRY(c->timing.start("finalize_kernel", s));
   hipLaunchKernelGGL(finalize_kernel,
-                     dim3(std::min(blocks_for(n, kFinalSamples), 256u)),
+                     dim3(std::min(blocks_for(n, kFinalSamples), 64u)),
                      dim3(kFinalBlock), 0, s, fa);
   KC_TRY(c->timing.stop(s));
   KC_HIP(hipGetLastError());
@@ -1219,9 +1262,32 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
 }
 
 int fetch(kc_dwa *c, kc_result *out, size_t n) {
-  KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
-                        hipMemcpyDeviceToHost, c->stream));
-  KC_HIP(hipStreamSynchronize(c->stream));
+  bool got = false;
+  if (c->pub_pending) {
+    // spin on the sequence word the last finalize block writes into pinned
+    // host memory (bounded: fall back to a stream sync + D2H)
+    volatile long long *hp = c->h_pub.p;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+      if (hp[3] == c->seq) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        c->h_result.p[0] = hp[0];
+        c->h_result.p[1] = hp[1];
+        c->h_result.p[2] = hp[2];
+        got = true;
+        break;
+      }
+      if ((spins & 1023) == 1023 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200))
+        break;
+    }
+    c->pub_pending = false;
+  }
+  if (!got) {
+    KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
+                          hipMemcpyDeviceToHost, c->stream));
+    KC_HIP(hipStreamSynchronize(c->stream));
+  }
   c->timing.mark("host:wait_result");
   kc_result r{};
   const long long key = c->h_result.p[0];
@@ -1303,6 +1369,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
   }
   c->stream = c->own_stream;
   int rc;
+  if ((rc = c->h_pub.reserve(8))) return fail(rc);
+  for (int i = 0; i < 8; ++i) c->h_pub.p[i] = 0;
   if ((rc = c->d_result.reserve(R_SLOTS)) ||
       (rc = c->h_result.reserve(R_SLOTS)) ||
       (rc = ensure_cycle_buffers(c, p->max_samples, p->max_points)) ||
@@ -1360,11 +1428,14 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_bobs.release();
   c->d_bobs.release();
   c->d_goal_d2.release();
+  c->d_goal_cost.release();
+  c->d_end_err.release();
   c->d_goal_arg.release();
   c->d_adm.release();
   c->d_pos.release();
   c->d_result.release();
   c->h_result.release();
+  c->h_pub.release();
   c->h_row.release();
   delete c;
 }
@@ -1603,7 +1674,7 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
     const double yaw0 = start->yaw;
     const double *om_v = c->lat.omega_values.data();
     double2 *tab = c->h_trig.p;
-    WorkerPool::instance().parallel_for(A, 8, [=](size_t r0, size_t r1) {
+    WorkerPool::instance().parallel_for(A, 2, [=](size_t r0, size_t r1) {
       for (size_t r = r0; r < r1; ++r) {
         double yaw = yaw0;
         const double om = om_v[r];

@@ -1,11 +1,16 @@
 // Small low-latency worker pool for the per-cycle host prep (the libm trig
-// table).  Workers spin briefly on a generation counter before sleeping, so a
-// controller running at a steady rate wakes them in well under a microsecond;
-// an idle controller costs nothing.
+// table).  Static partition: worker w always takes part w+1 of the range and
+// owns a cache line for its "done" word, so a job costs no contended atomic
+// (on a two-socket host a shared work counter bounces between sockets and
+// costs more than the work itself).  Workers spin briefly on a generation
+// word before sleeping, so a controller running at a steady rate finds them
+// hot; an idle controller costs nothing.
 #pragma once
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -23,8 +28,8 @@ class WorkerPool {
 
   int workers() const { return static_cast<int>(threads_.size()); }
 
-  // fn(begin, end) over [0, n) split into contiguous chunks; the caller takes
-  // part.  Serial when n is small or the pool has no workers.
+  // fn(begin, end) over [0, n) split into one contiguous chunk per thread; the
+  // caller takes the first chunk.  Serial when n is small or no workers exist.
   template <typename F>
   void parallel_for(size_t n, size_t min_chunk, F &&fn) {
     const size_t parts =
@@ -34,35 +39,42 @@ class WorkerPool {
       return;
     }
     std::lock_guard<std::mutex> serial(run_mu_);  // one job at a time
-    auto job = std::make_shared<Job>();
-    job->parts = parts;
-    job->fn = [&fn, n, parts](size_t part) {
+    job_fn_ = [&fn, n, parts](size_t part) {
       const size_t b = n * part / parts, e = n * (part + 1) / parts;
       if (b < e) fn(b, e);
     };
-    job->next.store(1, std::memory_order_relaxed);  // part 0 is the caller's
-    job->pending.store(parts - 1, std::memory_order_relaxed);
-    std::atomic_store(&cur_, job);
+    job_parts_ = parts;
+    const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      gen_.fetch_add(1, std::memory_order_release);
+      gen_.store(g, std::memory_order_release);
     }
-    cv_.notify_all();
-    job->fn(0);
-    run_parts(*job);  // help with whatever is left, then wait for stragglers
-    while (job->pending.load(std::memory_order_acquire) != 0) cpu_relax();
+    if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+    job_fn_(0);
+    // every worker acknowledges the generation (those without a part at once)
+    for (size_t w = 0; w < threads_.size(); ++w)
+      while (slots_[w].done.load(std::memory_order_acquire) != g) cpu_relax();
   }
 
  private:
+  struct alignas(64) Slot {
+    std::atomic<uint64_t> done{0};
+  };
+
   WorkerPool() {
     unsigned hw = std::thread::hardware_concurrency();
-    int n = hw >= 32 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;
-    for (int i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
+    int n = hw >= 64 ? 11 : hw >= 32 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;
+    if (const char *e = std::getenv("KC_HOST_THREADS")) {
+      const int want = std::atoi(e);
+      if (want >= 1 && want <= 64) n = want - 1;
+    }
+    slots_ = std::unique_ptr<Slot[]>(new Slot[n > 0 ? n : 1]);
+    for (int i = 0; i < n; ++i) threads_.emplace_back([this, i] { loop(i); });
   }
   ~WorkerPool() {
     {
       std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
+      stop_.store(true);
       gen_.fetch_add(1, std::memory_order_release);
     }
     cv_.notify_all();
@@ -73,50 +85,44 @@ class WorkerPool {
     __builtin_ia32_pause();
 #endif
   }
-  void loop() {
-    uint64_t seen = gen_.load(std::memory_order_acquire);
+  void loop(int w) {
+    // generation 0 = "nothing published yet"; a job published before this
+    // thread got to run must still be seen (and acknowledged)
+    uint64_t seen = 0;
     for (;;) {
-      // spin for a while (~50-100 us), then sleep
+      // spin for up to ~2 ms of wall time, then sleep on the condition variable
       int spins = 0;
+      auto t_spin = std::chrono::steady_clock::now();
       while (gen_.load(std::memory_order_acquire) == seen) {
-        if (++spins < 40000) {
-          cpu_relax();
-        } else {
+        cpu_relax();
+        if ((++spins & 255) == 0 &&
+            std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) {
           std::unique_lock<std::mutex> lk(mu_);
+          sleepers_.fetch_add(1, std::memory_order_acq_rel);
           cv_.wait(lk, [&] {
-            return gen_.load(std::memory_order_acquire) != seen || stop_;
+            return gen_.load(std::memory_order_acquire) != seen || stop_.load();
           });
+          sleepers_.fetch_sub(1, std::memory_order_acq_rel);
         }
-        if (stop_) return;
+        if (stop_.load(std::memory_order_relaxed)) return;
       }
-      if (stop_) return;
+      if (stop_.load()) return;
       seen = gen_.load(std::memory_order_acquire);
-      // a late worker may pick up an already finished job: its part counter
-      // is exhausted, so it never calls into a dead caller frame
-      std::shared_ptr<Job> job = std::atomic_load(&cur_);
-      if (job) run_parts(*job);
-    }
-  }
-
-  struct Job {
-    std::function<void(size_t)> fn;
-    size_t parts = 0;
-    std::atomic<size_t> next{0}, pending{0};
-  };
-  static void run_parts(Job &j) {
-    for (;;) {
-      const size_t p = j.next.fetch_add(1, std::memory_order_acq_rel);
-      if (p >= j.parts) break;
-      j.fn(p);
-      j.pending.fetch_sub(1, std::memory_order_acq_rel);
+      // the job description is published before gen_ (release/acquire)
+      const size_t part = static_cast<size_t>(w) + 1;
+      if (part < job_parts_) job_fn_(part);
+      slots_[w].done.store(seen, std::memory_order_release);
     }
   }
 
   std::vector<std::thread> threads_;
+  std::unique_ptr<Slot[]> slots_;
   std::mutex mu_, run_mu_;
   std::condition_variable cv_;
-  std::atomic<uint64_t> gen_{0};
-  std::shared_ptr<Job> cur_;
+  alignas(64) std::atomic<uint64_t> gen_{0};
+  alignas(64) std::atomic<int> sleepers_{0};
+  std::function<void(size_t)> job_fn_;
+  size_t job_parts_ = 0;
   std::atomic<bool> stop_{false};
 };
 
