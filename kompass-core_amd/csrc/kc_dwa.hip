@@ -14,6 +14,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <unordered_map>
 
 #include "kc_hostmath.h"
@@ -38,6 +39,10 @@ struct CollDev {
   double a, b;                // box half extents
   const uint32_t *bits;       // [H][wpr] occupancy bits (global)
   const double *ddz;          // sphere only: per-cell z gap [H][W]
+  // occupancy bits of ALL accepted voxel columns (built once per sensor
+  // update); the fused kernel copies its window out of it, word aligned
+  const uint32_t *gbits;      // [gH][gwpr]
+  int gkx0, gky0, gH, gwpr;   // origin (keys), rows, words per row
 };
 
 struct RollArgs {
@@ -241,6 +246,107 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
       }
     }
   }
+}
+
+// ===========================================================================
+// K1 (fused): roll-out + collision gate of 32 samples per workgroup, no global
+// round trip in between.  512 lanes: (A) copy the occupancy bits of the
+// reachable window into LDS (word aligned with the sensor bitmap) and fetch the trig
+// rows into LDS (every load in flight at once), (B) wavefront 0 runs the 64
+// serial recurrences LDS -> LDS (pose k+1 replaces trig row k in place),
+// (C) all lanes convert the poses to the float sample-major rows (coalesced)
+// and test one pose each against the LDS bits; a hit marks the sample.
+// ===========================================================================
+template <int kFusedSamples, int kFusedBlock>
+__global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int PP = a.P | 1;  // pitch of a sample's row in 16-byte slots
+  double2 *lpos = reinterpret_cast<double2 *>(smem);
+  uint32_t *lbits = reinterpret_cast<uint32_t *>(
+      smem + (size_t)kFusedSamples * PP * sizeof(double2));
+  __shared__ int lhit[kFusedSamples];
+
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kFusedSamples;
+  const int rows = min(kFusedSamples, a.n - base);
+  const int steps = a.P - 1;
+
+  // ---- A: window bits + trig rows -----------------------------------------
+  if (tid < kFusedSamples) lhit[tid] = 0;
+  if (a.c.enabled) {
+    // window origin is word aligned with the sensor bitmap: whole-word copies
+    const int nwords = a.c.H * a.c.wpr;
+    const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;  // exact: difference is a multiple of 32
+    for (int i = tid; i < nwords; i += kFusedBlock) {
+      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
+      const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
+      uint32_t v = 0u;
+      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr)
+        v = a.c.gbits[(size_t)gy * a.c.gwpr + gw];
+      lbits[i] = v;
+    }
+  }
+  {
+    const int s = tid & (kFusedSamples - 1);
+    if (s < rows) {
+      const int r = a.row[a.first + base + s];
+      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples)
+        lpos[s * PP + k] = a.trig[(size_t)k * a.A + r];
+    }
+  }
+  __syncthreads();
+  // ---- B: serial recurrences (wavefront 0) ----------------------------------
+  if (tid < rows) {
+    const double vx = a.vx[a.first + base + tid];
+    const double vy = a.vy[a.first + base + tid];
+    double x = a.x0, y = a.y0;
+    double2 *mine = lpos + tid * PP;
+    double2 cs = mine[0];
+    for (int k = 0; k < steps; ++k) {
+      const double2 nxt = mine[min(k + 1, steps - 1)];  // ahead of the chain
+      // Path::State::update, datatypes/path.h:24-30
+      x += (vx * cs.x - vy * cs.y) * a.dt;
+      y += (vx * cs.y + vy * cs.x) * a.dt;
+      mine[k] = make_double2(x, y);  // pose k+1
+      cs = nxt;
+    }
+  }
+  __syncthreads();
+  // ---- C: float rows out + one pose per lane against the window bits ---------
+  {
+    const int total = rows * a.P;
+    float *gx = a.px + (size_t)base * a.P;
+    float *gy = a.py + (size_t)base * a.P;
+    int s = 0, k = tid;
+    while (k >= a.P) {
+      k -= a.P;
+      ++s;
+    }
+    for (int i = tid; i < total; i += kFusedBlock) {
+      double2 p;
+      if (k == 0) p = make_double2(a.x0, a.y0);
+      else p = lpos[s * PP + k - 1];
+      gx[i] = static_cast<float>(p.x);
+      gy[i] = static_cast<float>(p.y);
+      if (a.c.enabled && k > 0) {
+        bool hit;
+        if (a.c.shape == KC_BOX) {
+          const double2 t = a.trig[(size_t)k * a.A + a.row[a.first + base + s]];  // yaw_k
+          hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y);
+        } else {
+          hit = hit_round(a.c, lbits, p.x, p.y);
+        }
+        if (hit) lhit[s] = 1;  // every writer stores the same value
+      }
+      k += kFusedBlock;
+      while (k >= a.P) {
+        k -= a.P;
+        ++s;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < rows) a.flags[base + tid] = lhit[tid] ? 0 : 1;
 }
 
 // ===========================================================================
@@ -854,6 +960,13 @@ struct kc_dwa {
   double radius = 0, height = 0, res = 0.1;
   std::vector<int32_t> vox_kx, vox_ky;  // z-accepted occupied columns
   std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
+  // occupancy bits of all accepted voxel columns over their bounding box
+  PinBuf<uint32_t> h_gbits;
+  DevBuf<uint32_t> d_gbits;
+  int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
+  bool have_gbits = false;
+  size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
+  int fused_samples = 32, fused_block = 512;
   bool have_sensor = false;
 
   // samples
@@ -945,6 +1058,40 @@ void add_voxel(kc_dwa *c, float px, float py, float pz) {
   }
   c->vox_kx.push_back(static_cast<int32_t>(fx));
   c->vox_ky.push_back(static_cast<int32_t>(fy));
+}
+
+// occupancy bits of the accepted voxel columns over their bounding box ->
+// device, once per sensor update (the fused roll-out kernel copies its
+// reachable window out of it)
+int upload_voxels(kc_dwa *c) {
+  c->have_gbits = false;
+  const size_t nv = c->vox_kx.size();
+  if (nv == 0) return KC_OK;
+  int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN;
+  for (size_t i = 0; i < nv; ++i) {
+    lox = std::min(lox, c->vox_kx[i]);
+    hix = std::max(hix, c->vox_kx[i]);
+    loy = std::min(loy, c->vox_ky[i]);
+    hiy = std::max(hiy, c->vox_ky[i]);
+  }
+  const long W = static_cast<long>(hix) - lox + 1, H = static_cast<long>(hiy) - loy + 1;
+  if (W > 8192 || H > 8192) return KC_OK;  // too sparse/far: split path only
+  c->gkx0 = lox;
+  c->gky0 = loy;
+  c->gH = static_cast<int>(H);
+  c->gwpr = static_cast<int>((W + 31) / 32);
+  const size_t nwords = static_cast<size_t>(c->gH) * c->gwpr;
+  KC_TRY(c->h_gbits.reserve(nwords));
+  KC_TRY(c->d_gbits.reserve(nwords));
+  std::memset(c->h_gbits.p, 0, nwords * sizeof(uint32_t));
+  for (size_t i = 0; i < nv; ++i) {
+    const int cx = c->vox_kx[i] - lox, cy = c->vox_ky[i] - loy;
+    c->h_gbits.p[static_cast<size_t>(cy) * c->gwpr + (cx >> 5)] |= 1u << (cx & 31);
+  }
+  KC_HIP(hipMemcpyAsync(c->d_gbits.p, c->h_gbits.p, nwords * sizeof(uint32_t),
+                        hipMemcpyHostToDevice, c->stream));
+  c->have_gbits = true;
+  return KC_OK;
 }
 
 // Bucket the world-frame obstacle points (h_obs) on a uniform grid and upload
@@ -1053,17 +1200,18 @@ int upload_samples(kc_dwa *c) {
 }
 
 int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd);
+int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd);
+int window_bits_host(kc_dwa *c, CollDev &cd);
 
-// occupancy bits of every voxel the robot can reach this cycle
-int build_window(kc_dwa *c, const kc_state &start, CollDev &cd) {
-  // every pose of every sample stays within `reach` of the start
+// every pose of every sample stays within this distance of the start
+double cycle_reach(const kc_dwa *c) {
   const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
-  const double reach = c->vmax_lin * dt * static_cast<double>(c->P) * 1.0001;
-  return build_window_at(c, start.x, start.y, reach, cd);
+  return c->vmax_lin * dt * static_cast<double>(c->P) * 1.0001;
 }
 
-// occupancy bits of every voxel within reach (+ robot bound) of (wx, wy)
-int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) {
+// frame + extent of the window of voxels within reach (+ robot bound) of
+// (wx, wy); enabled = there is sensor data at all
+int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) {
   std::memset(&cd, 0, sizeof(cd));
   cd.shape = c->prm.shape;
   const hm::Rigid3f &F = c->frame;
@@ -1080,7 +1228,6 @@ int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
   cd.a = static_cast<double>(c->prm.dims[0]) / 2.0;
   cd.b = static_cast<double>(c->prm.dims[1]) / 2.0;
   if (!c->have_sensor || c->vox_kx.empty()) return KC_OK;  // enabled = 0
-
   const double bound = (c->prm.shape == KC_BOX)
                            ? std::sqrt(cd.a * cd.a + cd.b * cd.b)
                            : c->radius;
@@ -1096,7 +1243,28 @@ int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
   cd.kx0 = static_cast<int>(std::floor(xf * cd.inv)) - static_cast<int>(half);
   cd.ky0 = static_cast<int>(std::floor(yf * cd.inv)) - static_cast<int>(half);
   cd.W = cd.H = static_cast<int>(2 * half + 1);
+  if (c->have_gbits) {
+    // shift the origin left to a word boundary of the sensor bitmap
+    const long rel = static_cast<long>(cd.kx0) - c->gkx0;
+    const long aligned = (rel >= 0 ? rel / 32 : -((-rel + 31) / 32)) * 32;
+    cd.W += static_cast<int>(rel - aligned);
+    cd.kx0 = static_cast<int>(c->gkx0 + aligned);
+    cd.gbits = c->d_gbits.p;
+    cd.gkx0 = c->gkx0;
+    cd.gky0 = c->gky0;
+    cd.gH = c->gH;
+    cd.gwpr = c->gwpr;
+  }
   cd.wpr = (cd.W + 31) / 32;
+  cd.enabled = 1;
+  return KC_OK;
+}
+
+// host-built occupancy bits (+ sphere z gaps) of the window, uploaded to global
+// memory: the path for windows that do not fit LDS, spheres and pose batches
+int window_bits_host(kc_dwa *c, CollDev &cd) {
+  if (!cd.enabled) return KC_OK;
+  cd.enabled = 0;
   const size_t nwords = static_cast<size_t>(cd.H) * cd.wpr;
   KC_TRY(c->h_bits.reserve(nwords));
   std::memset(c->h_bits.p, 0, nwords * sizeof(uint32_t));
@@ -1133,6 +1301,11 @@ int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
   }
   cd.lds = (nwords * 4 <= 48 * 1024) ? 1 : 0;
   return KC_OK;
+}
+
+int build_window_at(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) {
+  KC_TRY(window_geometry(c, wx, wy, reach, cd));
+  return window_bits_host(c, cd);
 }
 
 int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
@@ -1380,6 +1553,31 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       (rc = c->d_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->h_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
     return fail(rc);
+  // opt in to more than 64 KB of dynamic LDS for the fused kernel (gfx950: 160 KB)
+  {
+    bool ok = true;
+    auto optin = [&](const void *f) {
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        ok = false;
+      }
+    };
+    optin(reinterpret_cast<const void *>(rollout_collide_kernel<32, 512>));
+    optin(reinterpret_cast<const void *>(rollout_collide_kernel<16, 256>));
+    optin(reinterpret_cast<const void *>(rollout_collide_kernel<16, 512>));
+    optin(reinterpret_cast<const void *>(rollout_collide_kernel<32, 1024>));
+    optin(reinterpret_cast<const void *>(rollout_collide_kernel<64, 1024>));
+    if (ok) c->lds_limit = 150 * 1024;
+  }
+  if (const char *e = std::getenv("KC_FUSED_CFG")) {  // tuning hook: "samples,threads"
+    int sa = 0, th = 0;
+    if (std::sscanf(e, "%d,%d", &sa, &th) == 2) {
+      c->fused_samples = sa;
+      c->fused_block = th;
+    }
+  }
+  if (const char *e = std::getenv("KC_FORCE_SPLIT"))
+    if (e[0] == '1') c->lds_limit = 0;  // test hook: exercise the split path
   hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, c->stream,
                      c->d_result.p);
   if (hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -1429,6 +1627,8 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_bobs.release();
   c->d_goal_d2.release();
   c->d_goal_cost.release();
+  c->h_gbits.release();
+  c->d_gbits.release();
   c->d_end_err.release();
   c->d_goal_arg.release();
   c->d_adm.release();
@@ -1556,6 +1756,7 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   }
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;  // cost_evaluator.h:179
+  KC_TRY(upload_voxels(c));
   return upload_obstacles(c, n);
 }
 
@@ -1582,6 +1783,7 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   }
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;
+  KC_TRY(upload_voxels(c));
   return upload_obstacles(c, n);
 }
 
@@ -1706,31 +1908,55 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   a.px = c->d_px.p;
   a.py = c->d_py.p;
   a.flags = c->d_flags.p;
-  // the roll-out does not need the occupancy window: launch it first and
-  // build the window bits on the host while it runs
   const bool may_collide = c->have_sensor && !c->vox_kx.empty();
-  if (may_collide) {
-    KC_TRY(c->d_pos.reserve(n * P));
-    a.pos = c->d_pos.p;
-  }
-  a.c.enabled = may_collide ? 1 : 0;  // roll-out: "store the double poses"
-  const size_t tile_bytes = 2 * static_cast<size_t>(kRollBlock) * (P | 1) * 4;
-  a.stage = (tile_bytes <= 64 * 1024) ? 1 : 0;
-  KC_TRY(c->timing.start("rollout_kernel", s));
-  hipLaunchKernelGGL(rollout_kernel, dim3(blocks_for(n, kRollBlock)),
-                     dim3(kRollBlock), a.stage ? tile_bytes : 0, s, a);
-  KC_TRY(c->timing.stop(s));
-  c->timing.mark("host:launch_rollout");
-  if (may_collide) {
-    KC_TRY(build_window(c, *start, a.c));
-    c->timing.mark("host:window_bits");
-    if (a.c.enabled) {
-      const size_t bits_bytes = static_cast<size_t>(a.c.H) * a.c.wpr * 4;
-      KC_TRY(c->timing.start("collision_kernel", s));
-      hipLaunchKernelGGL(collision_kernel,
-                         dim3(blocks_for(n * (P - 1), kCollBlock)),
-                         dim3(kCollBlock), a.c.lds ? bits_bytes : 0, s, a);
-      KC_TRY(c->timing.stop(s));
+  KC_TRY(window_geometry(c, start->x, start->y, cycle_reach(c), a.c));
+  // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
+  const int fs = c->fused_samples, fb = c->fused_block;
+  const size_t pos_bytes = static_cast<size_t>(fs) * (P | 1) * sizeof(double2);
+  const size_t bits_bytes = a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 : 0;
+  const bool fused = c->prm.shape != KC_SPHERE && (!a.c.enabled || c->have_gbits) &&
+                     pos_bytes + bits_bytes + 512 <= c->lds_limit;
+  if (fused) {
+    a.c.lds = 1;
+    KC_TRY(c->timing.start("rollout_collide_kernel", s));
+    const dim3 grid(blocks_for(n, fs)), block(fb);
+    const size_t smem = pos_bytes + bits_bytes;
+    if (fs == 16 && fb == 256) hipLaunchKernelGGL((rollout_collide_kernel<16, 256>), grid, block, smem, s, a);
+    else if (fs == 16 && fb == 512) hipLaunchKernelGGL((rollout_collide_kernel<16, 512>), grid, block, smem, s, a);
+    else if (fs == 32 && fb == 1024) hipLaunchKernelGGL((rollout_collide_kernel<32, 1024>), grid, block, smem, s, a);
+    else if (fs == 64 && fb == 1024) hipLaunchKernelGGL((rollout_collide_kernel<64, 1024>), grid, block, smem, s, a);
+    else hipLaunchKernelGGL((rollout_collide_kernel<32, 512>), grid, block, smem, s, a);
+    KC_TRY(c->timing.stop(s));
+    c->timing.mark("host:launch_rollout");
+  } else {
+    // split path (sphere, very long horizons, windows beyond LDS): roll-out
+    // first, window bits built on the host while it runs, then the pose-
+    // parallel collision pass
+    CollDev geom = a.c;
+    if (may_collide) {
+      KC_TRY(c->d_pos.reserve(n * P));
+      a.pos = c->d_pos.p;
+    }
+    a.c.enabled = may_collide ? 1 : 0;  // roll-out: "store the double poses"
+    const size_t tile_bytes = 2 * static_cast<size_t>(kRollBlock) * (P | 1) * 4;
+    a.stage = (tile_bytes <= 64 * 1024) ? 1 : 0;
+    KC_TRY(c->timing.start("rollout_kernel", s));
+    hipLaunchKernelGGL(rollout_kernel, dim3(blocks_for(n, kRollBlock)),
+                       dim3(kRollBlock), a.stage ? tile_bytes : 0, s, a);
+    KC_TRY(c->timing.stop(s));
+    c->timing.mark("host:launch_rollout");
+    if (may_collide) {
+      a.c = geom;
+      KC_TRY(window_bits_host(c, a.c));
+      c->timing.mark("host:window_bits");
+      if (a.c.enabled) {
+        const size_t bb = static_cast<size_t>(a.c.H) * a.c.wpr * 4;
+        KC_TRY(c->timing.start("collision_kernel", s));
+        hipLaunchKernelGGL(collision_kernel,
+                           dim3(blocks_for(n * (P - 1), kCollBlock)),
+                           dim3(kCollBlock), a.c.lds ? bb : 0, s, a);
+        KC_TRY(c->timing.stop(s));
+      }
     }
   }
   KC_HIP(hipGetLastError());

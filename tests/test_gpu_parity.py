@@ -279,3 +279,40 @@ def test_full_size_cfg2_properties():
     assert len(o["raw"]) == 64
     np.testing.assert_array_equal(o["px"], h["px"][:64])
     np.testing.assert_array_equal(o["costs"].view(np.uint32), costs[:64].view(np.uint32))
+
+
+def test_split_path_equals_fused_path(tmp_path):
+    """The split pipeline (roll-out kernel + host-built window bits + pose-parallel
+    collision kernel: spheres, long horizons, windows beyond LDS) must agree with
+    the fused LDS kernel bit for bit.  KC_FORCE_SPLIT=1 selects it in a child
+    process (the switch is read at context creation)."""
+    import os
+    import subprocess
+    import sys
+
+    out = tmp_path / "split.npz"
+    code = f"""
+import sys; sys.path[:0] = [{str(Path(__file__).resolve().parent.parent)!r}, {str(Path(__file__).resolve().parent.parent / 'kompass-core_amd')!r}, {str(Path(__file__).resolve().parent)!r}]
+import numpy as np, kompass_hip as kh, synthetic as syn
+from helpers import hip_cycle
+res = {{}}
+for name, scale, shape, dims in [("cfg1", 1.0, syn.CYLINDER, [0.1, 0.4]), ("cfg2", 0.25, syn.BOX, [0.3, 0.2, 0.4])]:
+    inp = syn.make_controller_inputs(name, seed=4, scale=scale)
+    inp["robot"] = dict(shape=shape, dims=dims)
+    h = hip_cycle(kh, inp)
+    res[name + "_px"] = h["px"]; res[name + "_raw"] = h["raw"]; res[name + "_costs"] = h["costs"]
+    res[name + "_idx"] = np.int64(h["res"]["index"])
+np.savez({str(out)!r}, **res)
+"""
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, KC_FORCE_SPLIT="1"), timeout=240)
+    got = np.load(out)
+    for name, scale, shape, dims in [("cfg1", 1.0, syn.CYLINDER, [0.1, 0.4]), ("cfg2", 0.25, syn.BOX, [0.3, 0.2, 0.4])]:
+        inp = syn.make_controller_inputs(name, seed=4, scale=scale)
+        inp["robot"] = dict(shape=shape, dims=dims)
+        h = hip_cycle(kh, inp)
+        o = oracle_cycle(inp)
+        assert_cycle_equal(o, h)
+        np.testing.assert_array_equal(got[name + "_raw"], h["raw"])
+        np.testing.assert_array_equal(got[name + "_px"].view(np.uint32), h["px"].view(np.uint32))
+        np.testing.assert_array_equal(got[name + "_costs"].view(np.uint32), h["costs"].view(np.uint32))
+        assert int(got[name + "_idx"]) == h["res"]["index"]
