@@ -58,6 +58,8 @@ struct RollArgs {
   float *px, *py;       // [n][P] sample-major
   double2 *pos;         // [P][n] step-major double poses (collision pass input)
   uint8_t *flags;       // [n] admissible
+  int *adm_list;        // admissible local sample ids, appended (any order)
+  long long *adm_count; // device counter (re-armed by the cost kernel)
   CollDev c;
 };
 
@@ -346,7 +348,19 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   }
   __syncthreads();
-  if (tid < rows) a.flags[base + tid] = lhit[tid] ? 0 : 1;
+  if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
+    const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
+    if (tid < rows) a.flags[base + tid] = ok ? 1 : 0;
+    const unsigned long long bal = __ballot(ok);
+    const int cnt = __popcll(bal);
+    int start = 0;
+    if (tid == 0 && cnt)
+      start = static_cast<int>(atomicAdd(
+          reinterpret_cast<unsigned long long *>(a.adm_count),
+          static_cast<unsigned long long>(cnt)));
+    start = __shfl(start, 0, 64);
+    if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = base + tid;
+  }
 }
 
 // ===========================================================================
@@ -402,33 +416,42 @@ __global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
 }
 
 // ===========================================================================
-// K2+K3: per (sample, point) nearest tracked-segment point and nearest
-// obstacle point, one lane per trajectory point.
+// K2: cost of every admissible sample + argmin, one workgroup per sample,
+// one WAVEFRONT per trajectory point, 64 lanes per search.
 //
-// Segment part (pathCostFunc inner loops, cost_evaluator.cpp:120-130, and
+// Tracked segment (pathCostFunc inner loops, cost_evaluator.cpp:120-130, and
 // goalCostFunc's closest-point search, :157-166): d2 = dx*dx + (dy*dy + dz*dz)
-// in float, minimised over the segment; min_j sqrt(d2_j) == sqrt(min_j d2_j)
-// for the correctly rounded sqrt, so one sqrt per point; the lane of a sample's
-// END point also keeps the first argmin ((a-b)^2 == (b-a)^2 bit for bit).
-// The reference scans all S segment points; here consecutive runs of 16 points
-// carry a bounding sphere (host, once per segment) and a run is skipped when
-// its sphere cannot contain a point at or below the best distance so far
-// (1e-6 relative guard, four orders above the float rounding) -- the minimum
-// and its first index are unchanged.
+// in float over all S segment points, 64 at a time, then a wave reduction with
+// the lowest index winning ties (the reference's strict `<` in index order);
+// min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt, so one
+// sqrt per point; the END point's search also yields the goal cost
+// ((a-b)^2 == (b-a)^2 bit for bit).
 //
-// Obstacle part (TrajectoryPath::minDist2D, trajectory.h:218-235): float
+// Obstacles (TrajectoryPath::minDist2D, trajectory.h:218-235): float
 // difference, squares and sum in double, rounded to float once; the rounding
 // is monotonic, so the minimum is taken in double and rounded later.  Instead
 // of the reference's brute force over all O obstacles the points are bucketed
 // on a uniform grid (host, once per sensor update) and searched outwards in
-// growing square blocks of cells.  A block of half-width m cells contains
-// every obstacle closer than m*g to the query, so once the best squared
-// distance is below (m*g)^2 (same guard) nothing outside can beat it;
-// distances >= max_obstacles_dist all give cost 0, so the search also stops
-// once m*g covers that range.
+// growing square blocks of cells, one cell row per lane.  A block of
+// half-width m cells contains every obstacle closer than m*g to the query, so
+// once the best squared distance is below (m*g)^2 (1e-6 relative guard, four
+// orders above the float rounding of the differences) nothing outside can beat
+// it; distances >= max_obstacles_dist all give cost 0, so the search also
+// stops once m*g covers that range.
+//
+// The per-point minima stay in LDS; wavefront 0 then forms the weighted total
+// in the reference's accumulation order (cost_evaluator.cpp:59-100: float
+// total, each += a double multiply-add rounded once; the path-cost sum walks
+// the points in order with v_readlane), packs the (cost, index) key, and the
+// block publishes its best key with one atomic.  The block that arrives last
+// turns the winner's raw index into the reference's compacted index, hands the
+// record to the host through pinned memory and re-arms the working area.
 // ===========================================================================
-constexpr int kPairBlock = 256;
-constexpr int kSegRun = 16;
+constexpr int kCostBlock = 512;  // 8 wavefronts, two workgroups per CU
+constexpr int kCostWaves = kCostBlock / 64;
+// LDS the search structures of one workgroup may take (two workgroups share
+// the 160 KB of a CU)
+constexpr size_t kCostLdsBudget = 78 * 1024;
 
 struct BucketDev {
   int W, H;            // cells
@@ -437,217 +460,439 @@ struct BucketDev {
   double cap;          // max_obstacles_dist * 1.001 (search never needs more)
   const int *cell_start;   // [W*H + 1]
   const float *bx, *by;    // obstacle coordinates in cell order
+  const uint8_t *skip;     // [W*H] Chebyshev distance (cells, saturated at 255)
+                           // to the nearest non-empty cell: the first block
+                           // searched is the smallest that can contain a point
+  int nobs;                // finite obstacles in bx/by
 };
 
-struct PairArgs {
+// device result record (long long slots)
+enum { R_KEY = 0, R_NADM = 1, R_COMPACT = 2, R_SPARE = 3,   // published
+       W_KEY = 4, W_NADM = 5, W_TICKET = 6, W_LIST = 7,     // working area
+       R_SCRATCH = 8, R_SLOTS = 10 };
+
+struct CostArgs {
+  int n, first, P, S, O;
+  int use_seg, use_obs, have_vel;
   const float *px, *py;
-  const int *adm_list;   // admissible sample ids (local), ascending
-  const int *adm_count;  // device-side count
-  int n, P;
-  int use_seg, use_obs;
-  // tracked segment
-  const float *sx, *sy, *szz;
-  int S, nruns;
-  const double4 *runs;  // per run: centre (x, y, z) and radius
-  float *mind, *goal_d2;
-  int *goal_arg;
-  const float *sz_raw, *acc_seg;  // un-squared z, prefix arc length per point
+  const uint8_t *flags;
+  const int *adm_list;            // admissible local sample ids (any order)
+  const long long *adm_count;     // device-side count (result[W_LIST])
+  const float *sx, *sy, *sz, *szz, *acc_seg;
   float seg_len, ref_len;
-  float *goal_cost, *end_err;     // per sample, written by its END-point lane
-  // obstacles
   BucketDev b;
-  double *omin;
+  const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
+  float max_obs_dist;
+  float acc0, acc1, acc2;
+  double w_path, w_goal, w_obs, w_smooth, w_jerk;
+  float *costs;
+  long long *result;    // R_* published record + W_* working area
+  long long *host_pub;  // pinned host mirror {key, n_adm, compact, seq} or null
+  long long seq;        // cycle sequence number the host waits for
+  unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS): per-block phase clocks
 };
 
-// nearest tracked-segment point, one lane per trajectory point (G == 1):
-// run-pruned exact search
-__device__ __forceinline__ void seg_search_pruned(const PairArgs &a, float x,
-                                                  float y, float &best_out,
-                                                  int &arg_out) {
-  const double qx = static_cast<double>(x), qy = static_cast<double>(y);
-  // nearest run centre first: a good bound before anything is skipped
-  int r0 = 0;
-  double c0 = DBL_MAX;
-  for (int r = 0; r < a.nruns; ++r) {
-    const double4 c = a.runs[r];
-    const double dx = c.x - qx, dy = c.y - qy;
-    const double d = dx * dx + dy * dy + c.z * c.z;
-    if (d < c0) {
-      c0 = d;
-      r0 = r;
-    }
-  }
-  float best = FLT_MAX;
-  int arg = 0;
-  double sb = DBL_MAX;  // sqrt(best) with the guard
-  for (int pass = 0; pass < 2; ++pass) {
-    const int rb = pass == 0 ? r0 : 0;
-    const int re = pass == 0 ? r0 + 1 : a.nruns;
-    for (int r = rb; r < re; ++r) {
-      if (pass == 1) {
-        if (r == r0) continue;
-        const double4 c = a.runs[r];
-        const double dx = c.x - qx, dy = c.y - qy;
-        const double dc2 = dx * dx + dy * dy + c.z * c.z;
-        const double lim = c.w + sb;
-        if (sb < 1e300 && dc2 > lim * lim) continue;  // cannot reach best
-      }
-      const int j0 = r * kSegRun, j1 = min(j0 + kSegRun, a.S);
-      bool improved = false;
-      for (int j = j0; j < j1; ++j) {
-        const float dx = a.sx[j] - x;
-        const float dy = a.sy[j] - y;
-        const float xx = dx * dx;
-        const float yy = dy * dy;
-        const float d = xx + (yy + a.szz[j]);  // Eigen order a + (b + c)
-        // first minimum in index order, whatever the visiting order
-        if (d < best || (d == best && j < arg)) {
-          best = d;
-          arg = j;
-          improved = true;
-        }
-      }
-      if (improved)
-        sb = kc::dsqrt_rn(static_cast<double>(best)) * (1.0 + 1e-6) + 1e-30;
-    }
-  }
-  best_out = best;
-  arg_out = arg;
+#define KC_STAMP_CLK(slot)                                                 \
+  do {                                                                     \
+    if (a.dbg && threadIdx.x == 0)                                         \
+      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define KC_STAMP(slot)                                                     \
+  do {                                                                     \
+    if (a.dbg && threadIdx.x == 0)                                         \
+      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
+__device__ __forceinline__ float accum(float total, double w, float c) {
+  return static_cast<float>(static_cast<double>(total) +
+                            w * static_cast<double>(c));
+}
+__device__ __forceinline__ float sq_over(float total, float d, float lim) {
+  // smoothness_cost += std::pow(delta, 2) / accLimits_[i]  (double, then float)
+  const double dd = static_cast<double>(d);
+  return static_cast<float>(static_cast<double>(total) +
+                            (dd * dd) / static_cast<double>(lim));
+}
+// Wave-wide unsigned minimum on the DPP path (four cross-lane ALU steps inside
+// each row of 16, then four scalar row reads) instead of six ds_bpermute round
+// trips: the searches are latency chains, and a bpermute costs about as much
+// as an LDS access.  All 64 lanes must be active; the result is wave-uniform.
+template <int kCtrl>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return static_cast<uint32_t>(
+      __builtin_amdgcn_update_dpp(0, static_cast<int>(v), kCtrl, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
+  v = min(v, dpp_u32<0x140>(v));  // row_mirror
+  const uint32_t r0 = __builtin_amdgcn_readlane(static_cast<int>(v), 0);
+  const uint32_t r1 = __builtin_amdgcn_readlane(static_cast<int>(v), 16);
+  const uint32_t r2 = __builtin_amdgcn_readlane(static_cast<int>(v), 32);
+  const uint32_t r3 = __builtin_amdgcn_readlane(static_cast<int>(v), 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+// the same inside each aligned group of eight lanes (three DPP steps; every
+// lane of the group ends up with the group's minimum)
+__device__ __forceinline__ uint32_t group8_min_u32(uint32_t v) {
+  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
+  return v;
+}
+__device__ __forceinline__ double group8_min_nonneg(double v) {
+  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t hi = static_cast<uint32_t>(u >> 32), lo = static_cast<uint32_t>(u);
+  const uint32_t mh = group8_min_u32(hi);
+  const uint32_t ml = group8_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(mh) << 32) | ml));
+}
+// minimum of non-negative, non-NaN doubles (their bit patterns order like the
+// values): high words first, then the low words of the lanes that tie
+__device__ __forceinline__ double wave_min_nonneg(double v) {
+  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t hi = static_cast<uint32_t>(u >> 32), lo = static_cast<uint32_t>(u);
+  const uint32_t mh = wave_min_u32(hi);
+  const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(mh) << 32) | ml));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// G lanes per trajectory point (G = 1, 8 or 64, picked on the device from the
-// number of admissible samples so that the chip stays full whether 5 % or
-// 100 % of the samples survive the collision gate).
-template <int G>
-__device__ __forceinline__ void pair_body(const PairArgs &a, int na) {
-  constexpr int kGroupsPerBlock = kPairBlock / G;
-  const int gl = threadIdx.x % G;  // lane within the group
-  const long group0 = (long)blockIdx.x * kGroupsPerBlock + threadIdx.x / G;
-  const long ngroups = (long)gridDim.x * kGroupsPerBlock;
-  const long total = (long)na * a.P;
-  for (long w = group0; w < total; w += ngroups) {
-    const int i = static_cast<int>(w / a.P);
-    const int p = static_cast<int>(w - (long)i * a.P);
-    const int s = a.adm_list[i];
-    const long t = (long)s * a.P + p;
-    const float x = a.px[t], y = a.py[t];
+// kLds: the tracked segment, the bucket cell table and the skip table are
+// copied into LDS once per workgroup; kObsLds: the obstacle coordinates too.
+// The searches are chains of dependent loads, so where the tables sit decides
+// the latency of every step.
+template <bool kLds, bool kObsLds>
+__global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float *s_mind = reinterpret_cast<float *>(smem);               // [P]
+  float *s_px = s_mind + a.P;                                    // [P]
+  float *s_py = s_px + a.P;                                      // [P]
+  __shared__ float s_goal, s_end;
+  __shared__ long long s_key;
+  __shared__ unsigned long long s_obest;  // sample-wide min squared obstacle distance (double bits)
+  __shared__ int is_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
+  KC_STAMP(0);
+  KC_STAMP_CLK(13);
+  const int na = static_cast<int>(*a.adm_count);
+  KC_STAMP(1);
+  // blocks beyond the admissible count have nothing to do and take no ticket
+  const unsigned working = static_cast<unsigned>(min(static_cast<int>(gridDim.x), max(na, 1)));
+  if (blockIdx.x >= working) return;
+  if (threadIdx.x == 0) s_key = KEY_NONE;
 
+  const BucketDev &b = a.b;
+  // LDS layout after the per-sample arrays: five segment rows, the cell table,
+  // the skip table (padded to words), the obstacle coordinates.  The pointers
+  // are chosen at compile time so that the LDS variants issue ds_read, not
+  // flat loads.
+  const int ncell = b.W * b.H;
+  float *const l_seg = s_py + a.P;
+  int *const l_cells = reinterpret_cast<int *>(l_seg + (a.use_seg ? 5 * a.S : 0));
+  uint8_t *const l_skip = reinterpret_cast<uint8_t *>(l_cells + (a.use_obs ? ncell + 1 : 0));
+  float *const l_obs = reinterpret_cast<float *>(l_skip + (a.use_obs ? ((ncell + 3) & ~3) : 0));
+  const int *const cells = kLds ? l_cells : b.cell_start;
+  const uint8_t *const skip = kLds ? l_skip : b.skip;
+  const float *const obx = kObsLds ? l_obs : b.bx;
+  const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
+  const float *const sx = kLds ? l_seg : a.sx;
+  const float *const sy = kLds ? l_seg + a.S : a.sy;
+  const float *const sz = kLds ? l_seg + 2 * a.S : a.sz;
+  const float *const szz = kLds ? l_seg + 3 * a.S : a.szz;
+  const float *const sacc = kLds ? l_seg + 4 * a.S : a.acc_seg;
+  if (kLds) {
     if (a.use_seg) {
-      float best;
-      int arg;
-      if (G == 1) {
-        seg_search_pruned(a, x, y, best, arg);
-      } else {
-        // cooperative brute force: lane gl scans j = gl, gl + G, ...
-        best = FLT_MAX;
-        arg = 0;
-        for (int j = gl; j < a.S; j += G) {
-          const float dx = a.sx[j] - x;
-          const float dy = a.sy[j] - y;
+      // the five rows are contiguous in global memory too (d_seg)
+#pragma unroll 4
+      for (int j = threadIdx.x; j < 5 * a.S; j += kCostBlock) l_seg[j] = a.sx[j];
+    }
+    if (a.use_obs) {
+#pragma unroll 4
+      for (int j = threadIdx.x; j <= ncell; j += kCostBlock) l_cells[j] = b.cell_start[j];
+      // the skip table is padded to a multiple of 4 bytes on the host
+      const uint32_t *gs = reinterpret_cast<const uint32_t *>(b.skip);
+      uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
+      for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kCostBlock) ls[j] = gs[j];
+      if (kObsLds) {
+#pragma unroll 4
+        for (int j = threadIdx.x; j < b.nobs; j += kCostBlock) {
+          l_obs[j] = b.bx[j];
+          l_obs[b.nobs + j] = b.by[j];
+        }
+      }
+    }
+  }
+
+  for (int i = blockIdx.x; i < na; i += gridDim.x) {
+    const int n = a.adm_list[i];
+    if (threadIdx.x == 0)
+      s_obest = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
+    if (threadIdx.x < a.P) {
+      s_px[threadIdx.x] = a.px[(size_t)n * a.P + threadIdx.x];
+      s_py[threadIdx.x] = a.py[(size_t)n * a.P + threadIdx.x];
+    }
+    for (int k = kCostBlock + threadIdx.x; k < a.P; k += kCostBlock) {
+      s_px[k] = a.px[(size_t)n * a.P + k];
+      s_py[k] = a.py[(size_t)n * a.P + k];
+    }
+    __syncthreads();  // also covers the structure copy above
+    KC_STAMP(6);
+    // ---- eight lanes per trajectory point (64 points per pass) ----------------
+    // Idle groups (beyond P) work on a clamped point and write nothing, so
+    // the cross-lane steps always see active lanes.
+    const int sub = threadIdx.x & 7;
+    for (int p0 = 0; p0 < a.P; p0 += kCostBlock / 8) {
+      const int pp = p0 + (threadIdx.x >> 3);
+      const bool live = pp < a.P;
+      const int p = live ? pp : a.P - 1;
+      const float x = s_px[p], y = s_py[p];
+      if (a.use_seg) {
+        float best = FLT_MAX;
+        int arg = 0;
+#pragma unroll 4
+        for (int j = sub; j < a.S; j += 8) {  // j ascending per lane
+          const float dx = sx[j] - x;
+          const float dy = sy[j] - y;
           const float xx = dx * dx;
           const float yy = dy * dy;
-          const float d = xx + (yy + a.szz[j]);
-          if (d < best) {  // j ascending per lane: first index per lane
+          const float d = xx + (yy + szz[j]);  // Eigen order a + (b + c)
+          if (d < best) {
             best = d;
             arg = j;
           }
         }
-#pragma unroll
-        for (int off = G / 2; off > 0; off >>= 1) {
-          const float ob = __shfl_xor(best, off, 64);
-          const int oa = __shfl_xor(arg, off, 64);
-          if (ob < best || (ob == best && oa < arg)) {
-            best = ob;
-            arg = oa;
+        if (p0 == 0) KC_STAMP(9);
+        // non-negative floats order like their bit patterns; ties go to the
+        // lowest segment index (the reference's strict `<` in index order)
+        const uint32_t mine = __float_as_uint(best);
+        const uint32_t mbits = group8_min_u32(mine);
+        arg = static_cast<int>(
+            group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
+        best = __uint_as_float(mbits);
+        if (p0 == 0) KC_STAMP(10);
+        if (sub == 0 && live) {
+          s_mind[p] = kc::sqrt_rn(best);
+          if (p == a.P - 1) {
+            // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
+            const float arc = kc::div_rn(a.ref_len - sacc[arg], a.ref_len);
+            s_goal = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
+            // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
+            const int e = a.S - 1;
+            const float dx = x - sx[e], dy = y - sy[e], dz = 0.0f - sz[e];
+            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            s_end = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
           }
         }
       }
-      if (gl == 0) {
-        a.mind[t] = kc::sqrt_rn(best);
-        if (p == a.P - 1) {
-          a.goal_d2[s] = best;
-          a.goal_arg[s] = arg;
-          // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
-          const float arc = kc::div_rn(a.ref_len - a.acc_seg[arg], a.ref_len);
-          a.goal_cost[s] = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
-          // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
-          const int e = a.S - 1;
-          const float dx = x - a.sx[e], dy = y - a.sy[e], dz = 0.0f - a.sz_raw[e];
-          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-          a.end_err[s] = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
-        }
-      }
-    }
-
-    if (a.use_obs) {
-      const BucketDev &b = a.b;
-      // query cell (clamped: a query outside the grid searches from the border
-      // and the guarantee radius shrinks by its distance to the grid)
-      const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-      const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-      int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-      double off = 0.0;
-      if (fx < 0.0) off = fmax(off, -fx);
-      if (fy < 0.0) off = fmax(off, -fy);
-      if (fx > b.W) off = fmax(off, fx - b.W);
-      if (fy > b.H) off = fmax(off, fy - b.H);
-      cx = min(max(cx, 0), b.W - 1);
-      cy = min(max(cy, 0), b.H - 1);
-      double best = DBL_MAX;
-      const int mmax = max(b.W, b.H);
-      for (int m = 1;; m = 2 * m + 1) {
-        const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-        const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-        // the rows of the block are spread over the lanes of the group
-        for (int row = y0 + gl; row <= y1; row += G) {
-          const int beg = b.cell_start[row * b.W + x0];
-          const int end = b.cell_start[row * b.W + x1 + 1];
-          for (int j = beg; j < end; ++j) {
-            const double dx = static_cast<double>(b.bx[j] - x);
-            const double dy = static_cast<double>(b.by[j] - y);
-            const double dd = dx * dx + dy * dy;
-            best = dd < best ? dd : best;
+      if (p0 == 0) KC_STAMP(8);
+      if (a.use_obs) {
+        // query cell (clamped: a query outside the grid searches from the
+        // border and the guarantee radius shrinks by its distance to the grid)
+        const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+        const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+        int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+        double off = 0.0;
+        if (fx < 0.0) off = fmax(off, -fx);
+        if (fy < 0.0) off = fmax(off, -fy);
+        if (fx > b.W) off = fmax(off, fx - b.W);
+        if (fy > b.H) off = fmax(off, fy - b.H);
+        cx = min(max(cx, 0), b.W - 1);
+        cy = min(max(cy, 0), b.H - 1);
+        double best = DBL_MAX;
+        const int mmax = max(b.W, b.H);
+        // first block: just large enough to contain the nearest non-empty cell;
+        // following blocks: just large enough to prove the best distance found
+        int m = max(1, static_cast<int>(skip[cy * b.W + cx]));
+        for (;;) {  // uniform within the group of eight, divergent between groups
+          const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+          const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+          // a row of the block is a contiguous run of the cell-ordered obstacle
+          // list: four rows per pass, two lanes per row
+          for (int row = y0 + (sub >> 1); row <= y1; row += 4) {
+            const int beg = cells[row * b.W + x0];
+            const int end = cells[row * b.W + x1 + 1];
+            for (int j = beg + (sub & 1); j < end; j += 2) {
+              const double dx = static_cast<double>(obx[j] - x);
+              const double dy = static_cast<double>(oby[j] - y);
+              const double dd = dx * dx + dy * dy;
+              best = dd < best ? dd : best;
+            }
           }
+          best = group8_min_nonneg(best);
+          // Only the minimum over the whole sample is used (trajectory.h:218-235
+          // inside obstaclesDistCostFunc), so the points of a sample share
+          // their best distance: a point stops as soon as everything it has
+          // not visited yet is farther than what some point already found.
+          if (sub == 0 && live)
+            atomicMin(&s_obest, static_cast<unsigned long long>(__double_as_longlong(best)));
+          const double shared = __longlong_as_double(static_cast<long long>(
+              *const_cast<volatile unsigned long long *>(&s_obest)));
+          // every obstacle closer than `reach` (true distance) was visited
+          const double reach = (static_cast<double>(m) - off) * b.g;
+          if (reach > 0.0) {
+            const double r2 = reach * reach * (1.0 - 1e-6);
+            if (shared < r2) break;
+            if (reach >= b.cap) break;
+          }
+          if (m >= mmax) break;  // whole grid visited
+          // next half-width: enough cells to cover sqrt(shared) (+ guard), or
+          // the cap radius when nothing has been found yet (any over-estimate
+          // only visits more cells: float sqrt is enough)
+          const double need =
+              shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
+                               : b.cap;
+          const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
+          m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
         }
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {
-          const double ob = __shfl_xor(best, o, 64);
-          best = ob < best ? ob : best;
-        }
-        // every obstacle closer than `reach` (true distance) has been visited
-        const double reach = (static_cast<double>(m) - off) * b.g;
-        if (reach > 0.0) {
-          const double r2 = reach * reach * (1.0 - 1e-6);
-          if (best < r2) break;
-          if (reach >= b.cap) break;
-        }
-        if (m >= mmax) break;  // whole grid visited
       }
-      if (gl == 0) a.omin[t] = best;
+      if (p0 == 0) KC_STAMP(7);
     }
+    __syncthreads();
+    KC_STAMP(2);
+    KC_STAMP_CLK(14);
+    // ---- wavefront 0: weighted total of this sample ---------------------------
+    if (wave == 0) {
+      float total = 0.0f;
+      if (a.ref_len > 0.0f) {
+        if (a.w_goal > 0.0) total = accum(total, a.w_goal, s_goal);
+        if (a.w_path > 0.0) {
+          // pathCostFunc, cost_evaluator.cpp:111-141: ordered float sum
+          float sum = 0.0f;
+          for (int base = 0; base < a.P; base += 64) {
+            const int cnt = min(64, a.P - base);
+            const float v = (lane < cnt) ? s_mind[base + lane] : 0.0f;
+            for (int k = 0; k < cnt; ++k) sum += lane_value(v, k);
+          }
+          const float c = kc::div_rn(
+              kc::div_rn(sum, static_cast<float>(a.P)) + s_end, 2.0f);
+          total = accum(total, a.w_path, c);
+        }
+      }
+      if (a.O > 0 && a.w_obs > 0.0) {
+        // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
+        const double best = __longlong_as_double(static_cast<long long>(s_obest));
+        const float min_d2 = static_cast<float>(best);
+        const float dist =
+            static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
+        float v = a.max_obs_dist - dist;
+        v = v < 0.0f ? 0.0f : v;
+        total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
+      }
+      if (a.have_vel) {
+        // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
+        // evaluated redundantly by every lane (wave-uniform addresses)
+        const int nv = a.P - 1;
+        const float *vx = a.vvx + (size_t)n * nv;
+        const float *vy = a.vvy + (size_t)n * nv;
+        const float *om = a.vom + (size_t)n * nv;
+        const float div = static_cast<float>(3L * nv);
+        if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
+          float c = 0.0f;
+          for (int k = 1; k < nv; ++k) {
+            if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
+            if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
+            if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
+          }
+          total = accum(total, a.w_smooth, kc::div_rn(c, div));
+        }
+        if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
+          float c = 0.0f;
+          for (int k = 2; k < nv; ++k) {
+            if (a.acc0 > 0)
+              c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
+            if (a.acc1 > 0)
+              c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
+            if (a.acc2 > 0)
+              c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
+          }
+          total = accum(total, a.w_jerk, kc::div_rn(c, div));
+        }
+      }
+      // constant-velocity samples: both terms are exactly 0 and `total += w*0`
+      // leaves total unchanged, so nothing to do when !have_vel.
+      if (lane == 0) {
+        a.costs[n] = total;
+        if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
+          const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
+          if (k < s_key) s_key = k;
+        }
+      }
+    }
+    __syncthreads();  // LDS minima are reused by the next sample
+    KC_STAMP(3);
   }
-}
 
-__global__ __launch_bounds__(kPairBlock) void pair_cost_kernel(PairArgs a) {
-  const int na = *a.adm_count;
-  const long points = (long)na * a.P;
-  const long lanes = (long)gridDim.x * kPairBlock;
-  // widest group that still leaves every group at most ~2 points
-  if (points * 64 <= 2 * lanes) pair_body<64>(a, na);
-  else if (points * 8 <= 2 * lanes) pair_body<8>(a, na);
-  else pair_body<1>(a, na);
+  // ---- block epilogue: one atomic per block, last block publishes --------------
+  if (threadIdx.x == 0) {
+    const long long k = s_key;
+    if (k != KEY_NONE) atomicMin(&a.result[W_KEY], k);
+    // no cache-level fence: the only cross-block data are the two device-scope
+    // atomics (performed at the memory side); the wait orders them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ticket = atomicAdd(
+        reinterpret_cast<unsigned long long *>(&a.result[W_TICKET]), 1ull);
+    is_last = (ticket == working - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  KC_STAMP(4);
+  if (!is_last) return;
+  __shared__ long long s_fkey;
+  __shared__ int wsum[kCostWaves];
+  if (threadIdx.x == 0) s_fkey = atomicMin(&a.result[W_KEY], KEY_NONE);  // memory-side read
+  __syncthreads();
+  const long long fkey = s_fkey;
+  // the reference's index counts the admissible samples in front of the winner
+  int cnt = 0;
+  if (fkey != KEY_NONE) {
+    long long lim =
+        static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
+    if (lim > a.n) lim = a.n;
+    for (long long k = threadIdx.x; k < lim; k += kCostBlock) cnt += a.flags[k];
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if (lane == 0) wsum[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kCostWaves; ++w) s += wsum[w];
+    if (fkey == KEY_NONE) s = -1;
+    a.result[R_KEY] = fkey;
+    a.result[R_NADM] = na;
+    a.result[R_COMPACT] = s;
+    if (a.host_pub) {
+      // zero-copy hand-off: the host polls the sequence word instead of
+      // waiting on a D2H copy + stream sync
+      volatile long long *hp = a.host_pub;
+      hp[0] = fkey;
+      hp[1] = na;
+      hp[2] = s;
+      __threadfence_system();
+      hp[3] = a.seq;
+      __threadfence_system();
+    }
+    a.result[W_KEY] = KEY_NONE;
+    a.result[W_NADM] = 0;
+    a.result[W_TICKET] = 0;
+    a.result[W_LIST] = 0;  // admissible-list counter of the next cycle
+  }
+  KC_STAMP(5);
 }
 
 // ordered compaction of the admissible flags (one workgroup): adm_list[i] =
-// i-th admissible local sample id, adm_count = how many.  Runs after the
-// collision pass; a kernel boundary is the cheapest agent-scope hand-off.
-// Every thread owns a contiguous chunk (all its flags are requested up front:
-// one memory latency), a block-wide scan of the chunk counts gives the offsets.
+// i-th admissible local sample id, *adm_count = how many.  Used by the split
+// roll-out path and by kc_cost_evaluate (the fused kernel appends to the list
+// itself).  Every thread owns a contiguous chunk (all its flags are requested
+// up front: one memory latency), a block-wide scan gives the offsets.
 constexpr int kCompactMaxPer = 64;  // 1024 threads x 64 = 65536 samples
 
 __global__ __launch_bounds__(1024) void compact_kernel(
     const uint8_t *__restrict__ flags, int n, int *__restrict__ adm_list,
-    int *__restrict__ adm_count) {
+    long long *__restrict__ adm_count) {
   __shared__ int wave_tot[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = (n + 1023) / 1024;  // <= kCompactMaxPer (checked on the host)
@@ -658,7 +903,6 @@ __global__ __launch_bounds__(1024) void compact_kernel(
     if (i < n && flags[i] != 0) bits |= 1ull << k;
   }
   const int mine = __popcll(bits);
-  // inclusive scan of `mine` inside the wave, then across the 16 waves
   int incl = mine;
   for (int off = 1; off < 64; off <<= 1) {
     const int v = __shfl_up(incl, off, 64);
@@ -678,228 +922,6 @@ __global__ __launch_bounds__(1024) void compact_kernel(
     adm_list[dst++] = i0 + k;
   }
   if (threadIdx.x == 0) *adm_count = tot;
-}
-
-// ===========================================================================
-// K4: one wavefront per sample: goal cost, ordered path-cost sum, obstacle
-// cost, smoothness / jerk, the weighted total in the reference's accumulation
-// order (cost_evaluator.cpp:59-100: float total, each += a double multiply-add
-// rounded once), then the packed (cost, index) key: LDS across the block's
-// wavefronts, one atomic per workgroup, last block publishes.
-// ===========================================================================
-struct FinalArgs {
-  int n, first, P, S, O;
-  int have_vel;
-  const float *px, *py;
-  const uint8_t *flags;
-  const int *adm_list, *adm_count;
-  const float *sx, *sy, *sz, *acc_seg;
-  float seg_len, ref_len;
-  const float *mind;
-  const float *goal_cost, *end_err;
-  const double *omin;
-  const float *vvx, *vvy, *vom;  // [n][P-1] when have_vel
-  float max_obs_dist;
-  float acc0, acc1, acc2;
-  double w_path, w_goal, w_obs, w_smooth, w_jerk;
-  float *costs;
-  long long *result;  // R_* published record + W_* working area (see enum)
-  long long *host_pub;  // pinned host mirror {key, n_adm, compact, seq} or null
-  long long seq;        // cycle sequence number the host waits for
-};
-
-constexpr int kFinalBlock = 256;           // 4 wavefronts
-constexpr int kFinalSamples = kFinalBlock / 64;  // one wavefront per sample
-
-// device result record (long long slots)
-enum { R_KEY = 0, R_NADM = 1, R_COMPACT = 2, R_SPARE = 3,   // published
-       W_KEY = 4, W_NADM = 5, W_TICKET = 6, W_SPARE = 7,    // working area
-       R_SCRATCH = 8, R_SLOTS = 10 };
-
-__device__ __forceinline__ float dist_sq3(float ax, float ay, float az,
-                                          float bx, float by, float bz) {
-  const float dx = ax - bx, dy = ay - by, dz = az - bz;
-  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-  return xx + (yy + zz);
-}
-__device__ __forceinline__ float accum(float total, double w, float c) {
-  return static_cast<float>(static_cast<double>(total) +
-                            w * static_cast<double>(c));
-}
-__device__ __forceinline__ float sq_over(float total, float d, float lim) {
-  // smoothness_cost += std::pow(delta, 2) / accLimits_[i]  (double, then float)
-  const double dd = static_cast<double>(d);
-  return static_cast<float>(static_cast<double>(total) +
-                            (dd * dd) / static_cast<double>(lim));
-}
-__device__ __forceinline__ float lane_value(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// One wavefront per sample.  The per-point values of K2/K3 arrive with one
-// coalesced load per 64 points; the path-cost sum must keep the reference's
-// order (float, i = 0..P-1), so it walks the lanes with v_readlane; the
-// obstacle minimum is order-free and uses shuffles.  All lanes then hold the
-// same (wave-uniform) total.  Keys are reduced across the block's wavefronts
-// through LDS and published with one atomic per block; the block that arrives
-// last turns the winner's raw index into the reference's compacted index
-// (admissible samples in front of it) and re-arms the working area.
-__global__ __launch_bounds__(kFinalBlock) void finalize_kernel(FinalArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long key = KEY_NONE;  // best of this wavefront's samples
-  int adm = 0;
-  // few, fat workgroups: the per-block atomics below all hit the same words;
-  // only admissible samples are visited (compacted list)
-  const int na = *a.adm_count;
-  for (int i = blockIdx.x * kFinalSamples + wave; i < na;
-       i += gridDim.x * kFinalSamples) {
-  const int n = a.adm_list[i];
-  {
-    adm += 1;
-    float total = 0.0f;
-    if (a.ref_len > 0.0f) {
-      if (a.w_goal > 0.0) {
-        // goalCostFunc, cost_evaluator.cpp:150-177: evaluated by the END-point
-        // lane of the pair kernel
-        const float c = a.goal_cost[n];
-        total = accum(total, a.w_goal, c);
-      }
-      if (a.w_path > 0.0) {
-        // pathCostFunc, cost_evaluator.cpp:111-141
-        const float *m = a.mind + (size_t)n * a.P;
-        float sum = 0.0f;
-        for (int base = 0; base < a.P; base += 64) {
-          const int cnt = min(64, a.P - base);
-          const float v = (lane < cnt) ? m[base + lane] : 0.0f;
-          for (int i = 0; i < cnt; ++i) sum += lane_value(v, i);
-        }
-        const float end_err = a.end_err[n];
-        const float c = kc::div_rn(
-            kc::div_rn(sum, static_cast<float>(a.P)) + end_err, 2.0f);
-        total = accum(total, a.w_path, c);
-      }
-    }
-    if (a.O > 0 && a.w_obs > 0.0) {
-      // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
-      const double *m = a.omin + (size_t)n * a.P;
-      double best = DBL_MAX;
-      for (int i = lane; i < a.P; i += 64) best = m[i] < best ? m[i] : best;
-      for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(best, off, 64);
-        best = o < best ? o : best;
-      }
-      const float min_d2 = static_cast<float>(best);
-      const float dist =
-          static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
-      float v = a.max_obs_dist - dist;
-      v = v < 0.0f ? 0.0f : v;
-      total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
-    }
-    if (a.have_vel) {
-      // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
-      // evaluated redundantly by every lane (wave-uniform addresses)
-      const int nv = a.P - 1;
-      const float *vx = a.vvx + (size_t)n * nv;
-      const float *vy = a.vvy + (size_t)n * nv;
-      const float *om = a.vom + (size_t)n * nv;
-      const float div = static_cast<float>(3L * nv);
-      if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
-        float c = 0.0f;
-        for (int i = 1; i < nv; ++i) {
-          if (a.acc0 > 0) c = sq_over(c, vx[i] - vx[i - 1], a.acc0);
-          if (a.acc1 > 0) c = sq_over(c, vy[i] - vy[i - 1], a.acc1);
-          if (a.acc2 > 0) c = sq_over(c, om[i] - om[i - 1], a.acc2);
-        }
-        total = accum(total, a.w_smooth, kc::div_rn(c, div));
-      }
-      if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
-        float c = 0.0f;
-        for (int i = 2; i < nv; ++i) {
-          if (a.acc0 > 0)
-            c = sq_over(c, vx[i] - 2 * vx[i - 1] + vx[i - 2], a.acc0);
-          if (a.acc1 > 0)
-            c = sq_over(c, vy[i] - 2 * vy[i - 1] + vy[i - 2], a.acc1);
-          if (a.acc2 > 0)
-            c = sq_over(c, om[i] - 2 * om[i - 1] + om[i - 2], a.acc2);
-        }
-        total = accum(total, a.w_jerk, kc::div_rn(c, div));
-      }
-    }
-    // constant-velocity samples: both terms are exactly 0 and `total += w*0`
-    // leaves total unchanged, so nothing to do when !have_vel.
-    if (lane == 0) a.costs[n] = total;
-    if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
-      const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
-      key = k < key ? k : key;
-    }
-  }
-  }  // sample loop
-
-  __shared__ long long wkey[kFinalSamples];
-  __shared__ int wadm[kFinalSamples];
-  __shared__ int is_last;
-  if (lane == 0) {
-    wkey[wave] = key;
-    wadm[wave] = adm;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long k = wkey[0];
-    int c = wadm[0];
-    for (int w = 1; w < kFinalSamples; ++w) {
-      k = wkey[w] < k ? wkey[w] : k;
-      c += wadm[w];
-    }
-    if (k != KEY_NONE) atomicMin(&a.result[W_KEY], k);
-    if (c) atomicAdd(reinterpret_cast<unsigned long long *>(&a.result[W_NADM]),
-                     static_cast<unsigned long long>(c));
-    __threadfence();
-    const unsigned long long ticket = atomicAdd(
-        reinterpret_cast<unsigned long long *>(&a.result[W_TICKET]), 1ull);
-    is_last = (ticket == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  // ---- last block: publish + compacted index + re-arm -----------------------
-  __threadfence();
-  if (threadIdx.x == 0) {
-    // atomics are performed at the memory side: these reads see every block
-    const long long fkey = atomicMin(&a.result[W_KEY], KEY_NONE);
-    const long long fadm = static_cast<long long>(atomicAdd(
-        reinterpret_cast<unsigned long long *>(&a.result[W_NADM]), 0ull));
-    int s = -1;
-    if (fkey != KEY_NONE) {
-      // position of the winner in the ordered admissible list = the
-      // reference's index into its admissible-only container
-      const int local = static_cast<int>(
-          static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) -
-          a.first);
-      int lo = 0, hi = na;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a.adm_list[mid] < local) lo = mid + 1;
-        else hi = mid;
-      }
-      s = lo;
-    }
-    a.result[R_KEY] = fkey;
-    a.result[R_NADM] = fadm;
-    a.result[R_COMPACT] = s;
-    if (a.host_pub) {
-      // zero-copy hand-off: the host polls the sequence word instead of
-      // waiting on a D2H copy + stream sync
-      volatile long long *hp = a.host_pub;
-      hp[0] = fkey;
-      hp[1] = fadm;
-      hp[2] = s;
-      __threadfence_system();
-      hp[3] = a.seq;
-      __threadfence_system();
-    }
-    a.result[W_KEY] = KEY_NONE;
-    a.result[W_NADM] = 0;
-    a.result[W_TICKET] = 0;
-  }
 }
 
 // admissible samples in front of a raw index (multi-GPU: rebuilds the
@@ -931,7 +953,7 @@ __global__ void init_result_kernel(long long *result) {
   result[W_KEY] = KEY_NONE;
   result[W_NADM] = 0;
   result[W_TICKET] = 0;
-  result[W_SPARE] = 0;
+  result[W_LIST] = 0;
   result[R_SCRATCH] = 0;
 }
 
@@ -966,7 +988,8 @@ struct kc_dwa {
   int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
   bool have_gbits = false;
   size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
-  int fused_samples = 32, fused_block = 512;
+  bool cost_lds_ok = false;             // sample_cost_kernel<true> may take kCostLdsBudget
+  int fused_samples = 32, fused_block = 1024;
   bool have_sensor = false;
 
   // samples
@@ -986,23 +1009,22 @@ struct kc_dwa {
   DevBuf<uint32_t> d_bits;
   PinBuf<double> h_ddz;
   DevBuf<double> d_ddz;
-  DevBuf<float> d_px, d_py, d_mind, d_costs, d_goal_d2, d_goal_cost, d_end_err;
-  DevBuf<int> d_goal_arg;
-  DevBuf<int> d_adm;  // [0] count, [1..] ordered admissible sample ids
+  DevBuf<float> d_px, d_py, d_costs;
+  DevBuf<int> d_adm;  // admissible local sample ids (count lives in d_result[W_LIST])
   DevBuf<double2> d_pos;
-  DevBuf<double> d_omin;
   DevBuf<uint8_t> d_flags;
   DevBuf<float> d_vvx, d_vvy, d_vom;  // kc_cost_evaluate velocities
   bool have_vel = false;
+  bool need_compact = false;  // flags exist but the admissible list does not
+  bool list_dirty = false;    // a fused roll-out appended, no cost kernel re-armed
+  DevBuf<unsigned long long> d_dbg;  // KC_DEBUG_STAMPS diagnostic only
+  bool debug_stamps = false;
 
   // tracked segment + obstacles
   size_t S = 0, O = 0;
   float seg_len = 0.f, ref_len = 0.f, max_obs_dist = 0.f;
   PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
   DevBuf<float> d_seg;
-  PinBuf<double4> h_runs;  // bounding spheres of runs of kSegRun segment points
-  DevBuf<double4> d_runs;
-  size_t nruns = 0;
   PinBuf<float> h_obs;  // ox | oy (sensor order, as setPointScan stores them)
   // obstacle buckets for the exact nearest-obstacle search (K3)
   BucketDev bucket{};
@@ -1010,6 +1032,8 @@ struct kc_dwa {
   DevBuf<int> d_cells;
   PinBuf<float> h_bobs;  // bx | by in cell order
   DevBuf<float> d_bobs;
+  PinBuf<uint8_t> h_skip;  // Chebyshev distance to the nearest non-empty cell
+  DevBuf<uint8_t> d_skip;
   size_t n_bucketed = 0;
 
   DevBuf<long long> d_result;  // key, n_adm, compact index, scratch
@@ -1125,14 +1149,25 @@ int upload_obstacles(kc_dwa *c, size_t n) {
     KC_HIP(hipMemcpyAsync(c->d_cells.p, c->h_cells.p, 2 * sizeof(int),
                           hipMemcpyHostToDevice, c->stream));
     KC_TRY(c->d_bobs.reserve(2));
+    KC_TRY(c->h_skip.reserve(4));
+    KC_TRY(c->d_skip.reserve(4));
+    std::memset(c->h_skip.p, 255, 4);
+    KC_HIP(hipMemcpyAsync(c->d_skip.p, c->h_skip.p, 4, hipMemcpyHostToDevice, c->stream));
+    b.skip = c->d_skip.p;
     b.cell_start = c->d_cells.p;
     b.bx = c->d_bobs.p;
     b.by = c->d_bobs.p + 1;
     return KC_OK;
   }
-  constexpr int kMaxSide = 128;
+  // about one obstacle per cell, at most 64 x 64 cells so that the cell and
+  // skip tables sit in LDS (sample_cost_kernel); a finer grid in global memory
+  // for very long lists
+  const int kMaxSide =
+      nf <= 65536 ? std::min(64, std::max(8, static_cast<int>(std::ceil(std::sqrt(
+                                                 static_cast<double>(nf))))))
+                  : 256;
   const double ext = std::max(hix - lox, hiy - loy);
-  b.g = std::max(0.25, ext / (kMaxSide - 1));
+  b.g = std::max(0.125, ext / (kMaxSide - 1));
   b.inv_g = 1.0 / b.g;
   b.gx0 = lox;
   b.gy0 = loy;
@@ -1163,6 +1198,42 @@ int upload_obstacles(kc_dwa *c, size_t n) {
     bx[dst] = ox[i];
     by[dst] = oy[i];
   }
+  // Chebyshev distance transform of the non-empty cells (two chamfer passes
+  // with the 8-neighbourhood are exact for the Chebyshev metric)
+  KC_TRY(c->h_skip.reserve(ncell + 4));
+  KC_TRY(c->d_skip.reserve(ncell + 4));
+  {
+    uint8_t *sk = c->h_skip.p;
+    const int W = b.W, H = b.H;
+    for (size_t k = 0; k < ncell; ++k) sk[k] = (cs[k + 1] > cs[k]) ? 0 : 255;
+    auto at = [&](int x, int y) -> int { return sk[static_cast<size_t>(y) * W + x]; };
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x) {
+        int v = at(x, y);
+        if (x > 0) v = std::min(v, at(x - 1, y) + 1);
+        if (y > 0) {
+          v = std::min(v, at(x, y - 1) + 1);
+          if (x > 0) v = std::min(v, at(x - 1, y - 1) + 1);
+          if (x + 1 < W) v = std::min(v, at(x + 1, y - 1) + 1);
+        }
+        sk[static_cast<size_t>(y) * W + x] = static_cast<uint8_t>(std::min(v, 255));
+      }
+    for (int y = H - 1; y >= 0; --y)
+      for (int x = W - 1; x >= 0; --x) {
+        int v = at(x, y);
+        if (x + 1 < W) v = std::min(v, at(x + 1, y) + 1);
+        if (y + 1 < H) {
+          v = std::min(v, at(x, y + 1) + 1);
+          if (x + 1 < W) v = std::min(v, at(x + 1, y + 1) + 1);
+          if (x > 0) v = std::min(v, at(x - 1, y + 1) + 1);
+        }
+        sk[static_cast<size_t>(y) * W + x] = static_cast<uint8_t>(std::min(v, 255));
+      }
+  }
+  for (size_t k = ncell; k < ncell + 4; ++k) c->h_skip.p[k] = 255;  // word padding
+  KC_HIP(hipMemcpyAsync(c->d_skip.p, c->h_skip.p, ncell + 4, hipMemcpyHostToDevice,
+                        c->stream));
+  b.skip = c->d_skip.p;
   KC_HIP(hipMemcpyAsync(c->d_cells.p, cs, (ncell + 1) * sizeof(int),
                         hipMemcpyHostToDevice, c->stream));
   KC_HIP(hipMemcpyAsync(c->d_bobs.p, c->h_bobs.p, 2 * nf * sizeof(float),
@@ -1170,6 +1241,7 @@ int upload_obstacles(kc_dwa *c, size_t n) {
   b.cell_start = c->d_cells.p;
   b.bx = c->d_bobs.p;
   b.by = c->d_bobs.p + nf;
+  b.nobs = static_cast<int>(nf);
   c->n_bucketed = nf;
   return KC_OK;
 }
@@ -1336,100 +1408,87 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
   const float *seg = c->d_seg.p;
   const size_t S = c->S;
-  KC_TRY(c->timing.start("compact_kernel", s));
-  hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, c->d_flags.p,
-                     static_cast<int>(n), c->d_adm.p + 1, c->d_adm.p);
-  KC_TRY(c->timing.stop(s));
-  if (use_path || use_goal || use_obs) {
-    PairArgs pa{};
-    pa.px = c->d_px.p;
-    pa.py = c->d_py.p;
-    pa.adm_list = c->d_adm.p + 1;
-    pa.adm_count = c->d_adm.p;
-    pa.n = static_cast<int>(n);
-    pa.P = static_cast<int>(P);
-    pa.use_seg = (use_path || use_goal) ? 1 : 0;
-    pa.use_obs = use_obs ? 1 : 0;
-    if (pa.use_seg) {
-      KC_TRY(c->d_mind.reserve(n * P));
-      KC_TRY(c->d_goal_d2.reserve(n));
-      KC_TRY(c->d_goal_arg.reserve(n));
-      KC_TRY(c->d_goal_cost.reserve(n));
-      KC_TRY(c->d_end_err.reserve(n));
-      pa.sz_raw = seg + 2 * S;
-      pa.acc_seg = seg + 4 * S;
-      pa.seg_len = c->seg_len;
-      pa.ref_len = c->ref_len;
-      pa.goal_cost = c->d_goal_cost.p;
-      pa.end_err = c->d_end_err.p;
-      pa.sx = seg;
-      pa.sy = seg + S;
-      pa.szz = seg + 3 * S;
-      pa.S = static_cast<int>(S);
-      pa.nruns = static_cast<int>(c->nruns);
-      pa.runs = c->d_runs.p;
-      pa.mind = c->d_mind.p;
-      pa.goal_d2 = c->d_goal_d2.p;
-      pa.goal_arg = c->d_goal_arg.p;
-    }
-    if (use_obs) {
-      KC_TRY(c->d_omin.reserve(n * P));
-      pa.b = c->bucket;
-      pa.omin = c->d_omin.p;
-    }
-    KC_TRY(c->timing.start("pair_cost_kernel", s));
-    // fixed-size grid: the kernel sizes its lane groups from the device-side
-    // admissible count
-    const unsigned pair_blocks =
-        std::min(2048u, std::max(64u, blocks_for(n * P * 64, kPairBlock)));
-    hipLaunchKernelGGL(pair_cost_kernel, dim3(pair_blocks), dim3(kPairBlock), 0,
-                       s, pa);
+  if (c->need_compact) {  // split roll-out path / external samples
+    KC_TRY(c->timing.start("compact_kernel", s));
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, c->d_flags.p,
+                       static_cast<int>(n), c->d_adm.p, c->d_result.p + W_LIST);
     KC_TRY(c->timing.stop(s));
   }
-  FinalArgs fa{};
-  fa.n = static_cast<int>(n);
-  fa.first = static_cast<int>(first);
-  fa.P = static_cast<int>(P);
-  fa.S = static_cast<int>(S);
-  fa.O = static_cast<int>(c->O);
-  fa.have_vel = c->have_vel ? 1 : 0;
-  fa.px = c->d_px.p;
-  fa.py = c->d_py.p;
-  fa.flags = c->d_flags.p;
-  fa.adm_list = c->d_adm.p + 1;
-  fa.adm_count = c->d_adm.p;
-  fa.sx = seg;
-  fa.sy = seg + S;
-  fa.sz = seg + 2 * S;
-  fa.acc_seg = seg + 4 * S;
-  fa.seg_len = c->seg_len;
-  fa.ref_len = c->ref_len;
-  fa.mind = c->d_mind.p;
-  fa.goal_cost = c->d_goal_cost.p;
-  fa.end_err = c->d_end_err.p;
-  fa.omin = c->d_omin.p;
-  fa.vvx = c->d_vvx.p;
-  fa.vvy = c->d_vvy.p;
-  fa.vom = c->d_vom.p;
-  fa.max_obs_dist = c->max_obs_dist;
-  fa.acc0 = c->prm.acc_limits[0];
-  fa.acc1 = c->prm.acc_limits[1];
-  fa.acc2 = c->prm.acc_limits[2];
-  fa.w_path = c->w.reference_path_distance_weight;
-  fa.w_goal = c->w.goal_distance_weight;
-  fa.w_obs = c->w.obstacles_distance_weight;
-  fa.w_smooth = c->w.smoothness_weight;
-  fa.w_jerk = c->w.jerk_weight;
-  fa.costs = c->d_costs.p;
-  fa.result = c->d_result.p;
-  fa.host_pub = c->h_pub.p;
-  fa.seq = ++c->seq;
+  CostArgs ca{};
+  ca.n = static_cast<int>(n);
+  ca.first = static_cast<int>(first);
+  ca.P = static_cast<int>(P);
+  ca.S = static_cast<int>(S);
+  ca.O = static_cast<int>(c->O);
+  ca.use_seg = (use_path || use_goal) ? 1 : 0;
+  ca.use_obs = use_obs ? 1 : 0;
+  ca.have_vel = c->have_vel ? 1 : 0;
+  ca.px = c->d_px.p;
+  ca.py = c->d_py.p;
+  ca.flags = c->d_flags.p;
+  ca.adm_list = c->d_adm.p;
+  ca.adm_count = c->d_result.p + W_LIST;
+  ca.sx = seg;
+  ca.sy = seg + S;
+  ca.sz = seg + 2 * S;
+  ca.szz = seg + 3 * S;
+  ca.acc_seg = seg + 4 * S;
+  ca.seg_len = c->seg_len;
+  ca.ref_len = c->ref_len;
+  ca.b = c->bucket;
+  ca.vvx = c->d_vvx.p;
+  ca.vvy = c->d_vvy.p;
+  ca.vom = c->d_vom.p;
+  ca.max_obs_dist = c->max_obs_dist;
+  ca.acc0 = c->prm.acc_limits[0];
+  ca.acc1 = c->prm.acc_limits[1];
+  ca.acc2 = c->prm.acc_limits[2];
+  ca.w_path = c->w.reference_path_distance_weight;
+  ca.w_goal = c->w.goal_distance_weight;
+  ca.w_obs = c->w.obstacles_distance_weight;
+  ca.w_smooth = c->w.smoothness_weight;
+  ca.w_jerk = c->w.jerk_weight;
+  ca.costs = c->d_costs.p;
+  ca.result = c->d_result.p;
+  ca.host_pub = c->h_pub.p;
+  ca.seq = ++c->seq;
   c->pub_pending = true;
-  KC_TRY(c->timing.start("finalize_kernel", s));
-  hipLaunchKernelGGL(finalize_kernel,
-                     dim3(std::min(blocks_for(n, kFinalSamples), 64u)),
-                     dim3(kFinalBlock), 0, s, fa);
+  if (c->debug_stamps) {
+    KC_TRY(c->d_dbg.reserve(512 * 16));
+    KC_HIP(hipMemsetAsync(c->d_dbg.p, 0, 512 * 16 * 8, s));
+    ca.dbg = c->d_dbg.p;
+  }
+  // one workgroup per admissible sample (grid-stride over the device-side
+  // list); the search structures go to LDS when they fit
+  const unsigned cost_blocks = static_cast<unsigned>(std::min<size_t>(n, 512));
+  size_t lds = P * 3 * sizeof(float);
+  size_t lds_tab = 0, lds_obs = 0;
+  if (ca.use_seg) lds_tab += 5 * S * sizeof(float);
+  if (ca.use_obs) {
+    const size_t ncell = static_cast<size_t>(ca.b.W) * ca.b.H;
+    lds_tab += (ncell + 1) * sizeof(int) + ((ncell + 3) & ~size_t(3));
+    lds_obs = 2 * static_cast<size_t>(ca.b.nobs) * sizeof(float);
+  }
+  const bool tab_lds = c->cost_lds_ok && lds + lds_tab + 64 <= kCostLdsBudget;
+  const bool obs_lds = tab_lds && ca.use_obs && lds + lds_tab + lds_obs + 64 <= kCostLdsBudget;
+  if (c->debug_stamps && c->seq <= 2)
+    std::fprintf(stderr, "[kc] cost kernel: base=%zu tables=%zu obstacles=%zu nobs=%d grid=%dx%d S=%zu tab_lds=%d obs_lds=%d\n",
+                 lds, lds_tab, lds_obs, ca.b.nobs, ca.b.W, ca.b.H, S, int(tab_lds), int(obs_lds));
+  KC_TRY(c->timing.start("sample_cost_kernel", s));
+  if (obs_lds)
+    hipLaunchKernelGGL((sample_cost_kernel<true, true>), dim3(cost_blocks), dim3(kCostBlock),
+                       lds + lds_tab + lds_obs, s, ca);
+  else if (tab_lds)
+    hipLaunchKernelGGL((sample_cost_kernel<true, false>), dim3(cost_blocks), dim3(kCostBlock),
+                       lds + lds_tab, s, ca);
+  else
+    hipLaunchKernelGGL((sample_cost_kernel<false, false>), dim3(cost_blocks), dim3(kCostBlock),
+                       lds, s, ca);
   KC_TRY(c->timing.stop(s));
+  // the kernel re-armed the list counter: a second evaluate of the same
+  // roll-out has to rebuild the list from the flags
+  c->list_dirty = false;
+  c->need_compact = true;
   KC_HIP(hipGetLastError());
   return KC_OK;
 }
@@ -1568,6 +1627,14 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<32, 1024>));
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<64, 1024>));
     if (ok) c->lds_limit = 150 * 1024;
+    c->cost_lds_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kCostLdsBudget)) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kCostLdsBudget)) == hipSuccess;
+    if (!c->cost_lds_ok) (void)hipGetLastError();
   }
   if (const char *e = std::getenv("KC_FUSED_CFG")) {  // tuning hook: "samples,threads"
     int sa = 0, th = 0;
@@ -1576,8 +1643,12 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       c->fused_block = th;
     }
   }
+  if (const char *e = std::getenv("KC_DEBUG_STAMPS")) c->debug_stamps = e[0] == '1';
   if (const char *e = std::getenv("KC_FORCE_SPLIT"))
-    if (e[0] == '1') c->lds_limit = 0;  // test hook: exercise the split path
+    if (e[0] == '1') {  // test hook: exercise the split / in-place paths
+      c->lds_limit = 0;
+      c->cost_lds_ok = false;
+    }
   hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, c->stream,
                      c->d_result.p);
   if (hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -1592,6 +1663,41 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
 void kc_dwa_destroy(kc_dwa *c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->prm.device);
+  if (c->debug_stamps && c->d_dbg.p) {  // diagnostic dump of the last cycle
+    std::vector<unsigned long long> h(512 * 16);
+    e = hipDeviceSynchronize();
+    e = hipMemcpy(h.data(), c->d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < 512; ++b) if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
+    double mx[16] = {0}, sm[16] = {0};
+    int nb = 0;
+    for (int b = 0; b < 512; ++b) {
+      if (!h[b * 16] || !h[b * 16 + 4]) continue;
+      ++nb;
+      for (int k = 0; k < 16; ++k) {
+        if (!h[b * 16 + k]) continue;
+        const double us = (h[b * 16 + k] - t0) / 100.0;
+        mx[k] = std::max(mx[k], us);
+        sm[k] += us;
+      }
+    }
+    std::fprintf(stderr, "[kc stamps] %d working blocks; us since first block start (avg / max):\n", nb);
+    const char *nm[16] = {"start", "count loaded", "points done", "sample done", "ticket", "published", "lds filled", "first point", "p0 seg done", "p0 seg loop", "p0 seg reduce", "-", "-", "", "", ""};
+    {
+      double mhz = 0; int cnt = 0;
+      for (int b = 0; b < 512; ++b) {
+        if (!h[b * 16] || !h[b * 16 + 2] || !h[b * 16 + 14]) continue;
+        mhz += double(h[b * 16 + 14] - h[b * 16 + 13]) / (double(h[b * 16 + 2] - h[b * 16]) / 100.0);
+        ++cnt;
+      }
+      std::fprintf(stderr, "  s_memtime ticks per us (start -> points done): %.1f\n", cnt ? mhz / cnt : 0.0);
+    }
+    const int order[13] = {0, 1, 6, 9, 10, 8, 11, 12, 7, 2, 3, 4, 5};
+    for (int q = 0; q < 13; ++q) {
+      const int k = order[q];
+      std::fprintf(stderr, "  %-14s %7.2f / %7.2f\n", nm[k], nb ? sm[k] / nb : 0.0, mx[k]);
+    }
+  }
   if (c->own_stream) {
     e = hipStreamSynchronize(c->own_stream);
     e = hipStreamDestroy(c->own_stream);
@@ -1609,28 +1715,23 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_ddz.release();
   c->d_px.release();
   c->d_py.release();
-  c->d_mind.release();
   c->d_costs.release();
-  c->d_omin.release();
   c->d_flags.release();
+  c->d_dbg.release();
   c->d_vvx.release();
   c->d_vvy.release();
   c->d_vom.release();
   c->h_seg.release();
   c->d_seg.release();
-  c->h_runs.release();
-  c->d_runs.release();
   c->h_obs.release();
   c->h_cells.release();
   c->d_cells.release();
   c->h_bobs.release();
   c->d_bobs.release();
-  c->d_goal_d2.release();
-  c->d_goal_cost.release();
+  c->h_skip.release();
+  c->d_skip.release();
   c->h_gbits.release();
   c->d_gbits.release();
-  c->d_end_err.release();
-  c->d_goal_arg.release();
   c->d_adm.release();
   c->d_pos.release();
   c->d_result.release();
@@ -1817,32 +1918,6 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   c->seg_len = len;
   KC_HIP(hipMemcpyAsync(c->d_seg.p, h, 5 * S * sizeof(float),
                         hipMemcpyHostToDevice, c->stream));
-  // bounding sphere of every run of kSegRun consecutive points (K2 pruning):
-  // centre = mid-point of the run's bounding box, radius inflated by 1e-6
-  c->nruns = (S + kSegRun - 1) / kSegRun;
-  KC_TRY(c->h_runs.reserve(c->nruns));
-  KC_TRY(c->d_runs.reserve(c->nruns));
-  for (size_t r = 0; r < c->nruns; ++r) {
-    const size_t j0 = r * kSegRun, j1 = std::min(j0 + kSegRun, S);
-    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (size_t j = j0; j < j1; ++j)
-      for (int k = 0; k < 3; ++k) {
-        const double v = h[k * S + j];
-        lo[k] = std::min(lo[k], v);
-        hi[k] = std::max(hi[k], v);
-      }
-    const double cx = 0.5 * (lo[0] + hi[0]), cy = 0.5 * (lo[1] + hi[1]),
-                 cz = 0.5 * (lo[2] + hi[2]);
-    double rad = 0.0;
-    for (size_t j = j0; j < j1; ++j) {
-      const double dx = h[j] - cx, dy = h[S + j] - cy, dz = h[2 * S + j] - cz;
-      rad = std::max(rad, std::sqrt(dx * dx + dy * dy + dz * dz));
-    }
-    if (!std::isfinite(rad)) rad = 1e300;  // never skipped
-    c->h_runs.p[r] = make_double4(cx, cy, cz, rad * (1.0 + 1e-6) + 1e-9);
-  }
-  KC_HIP(hipMemcpyAsync(c->d_runs.p, c->h_runs.p, c->nruns * sizeof(double4),
-                        hipMemcpyHostToDevice, c->stream));
   return KC_OK;
 }
 
@@ -1908,6 +1983,8 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   a.px = c->d_px.p;
   a.py = c->d_py.p;
   a.flags = c->d_flags.p;
+  a.adm_list = c->d_adm.p;
+  a.adm_count = c->d_result.p + W_LIST;
   const bool may_collide = c->have_sensor && !c->vox_kx.empty();
   KC_TRY(window_geometry(c, start->x, start->y, cycle_reach(c), a.c));
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
@@ -1916,7 +1993,11 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   const size_t bits_bytes = a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 : 0;
   const bool fused = c->prm.shape != KC_SPHERE && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
+  c->need_compact = !fused;
   if (fused) {
+    if (c->list_dirty)  // previous roll-out was never evaluated: re-arm the list
+      KC_HIP(hipMemsetAsync(c->d_result.p + W_LIST, 0, sizeof(long long), s));
+    c->list_dirty = true;
     a.c.lds = 1;
     KC_TRY(c->timing.start("rollout_collide_kernel", s));
     const dim3 grid(blocks_for(n, fs)), block(fb);
@@ -2135,6 +2216,7 @@ int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
   c->P = P;
   c->n_roll = n;
   c->external = true;
+  c->need_compact = true;
   c->have_vel = vel;
   c->rolled = true;
   c->evaluated = false;
