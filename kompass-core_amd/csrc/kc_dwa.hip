@@ -988,6 +988,7 @@ struct kc_dwa {
   int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
   bool have_gbits = false;
   size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
+  bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
   bool cost_lds_ok = false;             // sample_cost_kernel<true> may take kCostLdsBudget
   int fused_samples = 32, fused_block = 1024;
   bool have_sensor = false;
@@ -1041,6 +1042,8 @@ struct kc_dwa {
   PinBuf<long long> h_pub;     // {key, n_adm, compact, seq} written by the GPU
   long long seq = 0;           // last cycle sequence handed to finalize
   bool pub_pending = false;
+  bool drained = false;  // the host saw the last cost kernel's record: every earlier
+                         // command of the stream has finished with the staging buffers
   PinBuf<float> h_row;         // winner row staging
   kc_result last{};
   bool have_last = false;
@@ -1507,6 +1510,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
         c->h_result.p[1] = hp[1];
         c->h_result.p[2] = hp[2];
         got = true;
+        c->drained = true;
         break;
       }
       if ((spins & 1023) == 1023 &&
@@ -1642,6 +1646,16 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       c->fused_samples = sa;
       c->fused_block = th;
     }
+  }
+  {
+    int large_bar = 0;
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->device) != hipSuccess) {
+      (void)hipGetLastError();
+      large_bar = 0;
+    }
+    c->trig_direct = large_bar != 0;
+    if (const char *e = std::getenv("KC_TRIG_COPY"))
+      if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
   }
   if (const char *e = std::getenv("KC_DEBUG_STAMPS")) c->debug_stamps = e[0] == '1';
   if (const char *e = std::getenv("KC_FORCE_SPLIT"))
@@ -1928,7 +1942,12 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
             c->prm.max_points);
   KC_TRY(use_device(c));
   hipStream_t s = c->stream;
-  KC_HIP(hipStreamSynchronize(s));  // pinned staging of the last cycle is free
+  // The staging buffers of the last cycle must be free.  When the host has
+  // already seen the record the last cost kernel publishes at its very end,
+  // everything in front of it has completed and the (slow) stream wait is
+  // skipped; commands queued since then only read buffers this call leaves alone.
+  if (!c->drained || c->timing.enabled) KC_HIP(hipStreamSynchronize(s));
+  c->drained = false;
   c->timing.begin_cycle();
   c->P = P;
   c->rolled = false;
@@ -1948,25 +1967,42 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   KC_TRY(c->d_trig.reserve(A * P));
   const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
   {
+    // Where the table is written: straight into device memory when the host
+    // can address it (large BAR: write-combined stores, no copy command and no
+    // copy engine latency on the critical path), else into pinned memory
+    // followed by an H2D copy.
     const double yaw0 = start->yaw;
     const double *om_v = c->lat.omega_values.data();
-    double2 *tab = c->h_trig.p;
+    double2 *tab = c->trig_direct ? c->d_trig.p : c->h_trig.p;
     WorkerPool::instance().parallel_for(A, 2, [=](size_t r0, size_t r1) {
-      for (size_t r = r0; r < r1; ++r) {
-        double yaw = yaw0;
-        const double om = om_v[r];
+      // a worker's rows are computed into a small local tile and written out
+      // as one contiguous run per step (the table is step-major: the kernels
+      // read consecutive omega rows with consecutive lanes)
+      constexpr size_t kTileRows = 16;
+      double2 tile[kTileRows];
+      double yaw[kTileRows];
+      for (size_t rb = r0; rb < r1; rb += kTileRows) {
+        const size_t nr = std::min(kTileRows, r1 - rb);
+        for (size_t i = 0; i < nr; ++i) yaw[i] = yaw0;
         for (size_t k = 0; k < P; ++k) {
-          double sn, cs;
-          ::sincos(yaw, &sn, &cs);  // bit-identical to sin()/cos() (tested)
-          tab[k * A + r] = make_double2(cs, sn);
-          yaw += om * dt;
+          for (size_t i = 0; i < nr; ++i) {
+            double sn, cs;
+            ::sincos(yaw[i], &sn, &cs);  // bit-identical to sin()/cos() (tested)
+            tile[i] = make_double2(cs, sn);
+            yaw[i] += om_v[rb + i] * dt;
+          }
+          std::memcpy(tab + k * A + rb, tile, nr * sizeof(double2));
         }
       }
+#if defined(__x86_64__)
+      __builtin_ia32_sfence();  // write-combined stores leave the core before "done"
+#endif
     });
   }
   c->timing.mark("host:trig_table");
-  KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
-                        hipMemcpyHostToDevice, s));
+  if (!c->trig_direct)
+    KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
+                          hipMemcpyHostToDevice, s));
   RollArgs a{};
   KC_TRY(ensure_cycle_buffers(c, n, P));
   a.n = static_cast<int>(n);
