@@ -54,12 +54,21 @@ struct RollArgs {
   double x0, y0, dt;
   const double *vx, *vy;
   const int32_t *row;
+  const int32_t *perm;  // fused kernel: local sample ids ordered by omega row, so that the
+                        // samples of a workgroup share as few trig rows as possible
   const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
   float *px, *py;       // [n][P] sample-major
   double2 *pos;         // [P][n] step-major double poses (collision pass input)
   uint8_t *flags;       // [n] admissible
   int *adm_list;        // admissible local sample ids, appended (any order)
   long long *adm_count; // device counter (re-armed by the cost kernel)
+  // early launch (fused kernel only): the kernel is queued BEFORE the host has
+  // produced the trig table, so launch + dispatch latency overlap the libm
+  // work; the host then writes the table and this sequence word through the
+  // BAR and the workgroups wait for it.  Null: the table is already there.
+  const long long *trig_flag;
+  long long trig_seq;
+  long long *dev_err;   // set when the wait gives up (host never delivered)
   CollDev c;
 };
 
@@ -267,6 +276,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   uint32_t *lbits = reinterpret_cast<uint32_t *>(
       smem + (size_t)kFusedSamples * PP * sizeof(double2));
   __shared__ int lhit[kFusedSamples];
+  __shared__ int lperm[kFusedSamples];  // local sample id of slot s
+  __shared__ int lrow[kFusedSamples];   // its trig row
 
   const int tid = threadIdx.x;
   const int base = blockIdx.x * kFusedSamples;
@@ -274,7 +285,12 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   const int steps = a.P - 1;
 
   // ---- A: window bits + trig rows -----------------------------------------
-  if (tid < kFusedSamples) lhit[tid] = 0;
+  if (tid < kFusedSamples) {
+    lhit[tid] = 0;
+    const int ls = tid < rows ? a.perm[base + tid] : 0;
+    lperm[tid] = ls;
+    lrow[tid] = tid < rows ? a.row[a.first + ls] : 0;
+  }
   if (a.c.enabled) {
     // window origin is word aligned with the sensor bitmap: whole-word copies
     const int nwords = a.c.H * a.c.wpr;
@@ -288,10 +304,45 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       lbits[i] = v;
     }
   }
-  {
+  if (a.trig_flag) {
+    // wait for the host's table (system-scope loads: the word and the table
+    // arrive over PCIe, behind this GPU's caches).  Bounded: ~50 ms.
+    __shared__ int s_late;
+    if (tid == 0) {
+      int late = 0;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(a.trig_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) !=
+             a.trig_seq) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {
+          late = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      s_late = late;
+    }
+    __syncthreads();
+    if (s_late) {  // give the cycle up: nothing admissible, error word set
+      if (tid < rows) a.flags[lperm[tid]] = 0;
+      if (tid == 0) *a.dev_err = 1;
+      return;
+    }
     const int s = tid & (kFusedSamples - 1);
     if (s < rows) {
-      const int r = a.row[a.first + base + s];
+      const int r = lrow[s];
+      const double *tg = reinterpret_cast<const double *>(a.trig);
+      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
+        const size_t e = ((size_t)k * a.A + r) * 2;
+        const double cs = __hip_atomic_load(tg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const double sn = __hip_atomic_load(tg + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        lpos[s * PP + k] = make_double2(cs, sn);
+      }
+    }
+  } else {
+    __syncthreads();  // lrow
+    const int s = tid & (kFusedSamples - 1);
+    if (s < rows) {
+      const int r = lrow[s];
       for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples)
         lpos[s * PP + k] = a.trig[(size_t)k * a.A + r];
     }
@@ -299,8 +350,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __syncthreads();
   // ---- B: serial recurrences (wavefront 0) ----------------------------------
   if (tid < rows) {
-    const double vx = a.vx[a.first + base + tid];
-    const double vy = a.vy[a.first + base + tid];
+    const double vx = a.vx[a.first + lperm[tid]];
+    const double vy = a.vy[a.first + lperm[tid]];
     double x = a.x0, y = a.y0;
     double2 *mine = lpos + tid * PP;
     double2 cs = mine[0];
@@ -317,8 +368,6 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   // ---- C: float rows out + one pose per lane against the window bits ---------
   {
     const int total = rows * a.P;
-    float *gx = a.px + (size_t)base * a.P;
-    float *gy = a.py + (size_t)base * a.P;
     int s = 0, k = tid;
     while (k >= a.P) {
       k -= a.P;
@@ -328,12 +377,21 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       double2 p;
       if (k == 0) p = make_double2(a.x0, a.y0);
       else p = lpos[s * PP + k - 1];
-      gx[i] = static_cast<float>(p.x);
-      gy[i] = static_cast<float>(p.y);
+      const size_t o = (size_t)lperm[s] * a.P + k;  // sample-major rows
+      a.px[o] = static_cast<float>(p.x);
+      a.py[o] = static_cast<float>(p.y);
       if (a.c.enabled && k > 0) {
         bool hit;
         if (a.c.shape == KC_BOX) {
-          const double2 t = a.trig[(size_t)k * a.A + a.row[a.first + base + s]];  // yaw_k
+          const size_t e = (size_t)k * a.A + lrow[s];  // yaw_k
+          double2 t;
+          if (a.trig_flag) {
+            const double *tg = reinterpret_cast<const double *>(a.trig);
+            t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          } else {
+            t = a.trig[e];
+          }
           hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y);
         } else {
           hit = hit_round(a.c, lbits, p.x, p.y);
@@ -350,7 +408,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __syncthreads();
   if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
     const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
-    if (tid < rows) a.flags[base + tid] = ok ? 1 : 0;
+    if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
     const unsigned long long bal = __ballot(ok);
     const int cnt = __popcll(bal);
     int start = 0;
@@ -359,7 +417,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
           reinterpret_cast<unsigned long long *>(a.adm_count),
           static_cast<unsigned long long>(cnt)));
     start = __shfl(start, 0, 64);
-    if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = base + tid;
+    if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = lperm[tid];
   }
 }
 
@@ -469,7 +527,8 @@ struct BucketDev {
 // device result record (long long slots)
 enum { R_KEY = 0, R_NADM = 1, R_COMPACT = 2, R_SPARE = 3,   // published
        W_KEY = 4, W_NADM = 5, W_TICKET = 6, W_LIST = 7,     // working area
-       R_SCRATCH = 8, R_SLOTS = 10 };
+       R_SCRATCH = 8, R_TRIGSEQ = 9,  // host-written (BAR): sequence of the trig table in d_trig
+       R_SLOTS = 10 };
 
 struct CostArgs {
   int n, first, P, S, O;
@@ -861,15 +920,17 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
     int s = 0;
     for (int w = 0; w < kCostWaves; ++w) s += wsum[w];
     if (fkey == KEY_NONE) s = -1;
+    // W_NADM doubles as the device error word (roll-out kernel gave up waiting)
+    const long long na_pub = a.result[W_NADM] ? -1 : na;
     a.result[R_KEY] = fkey;
-    a.result[R_NADM] = na;
+    a.result[R_NADM] = na_pub;
     a.result[R_COMPACT] = s;
     if (a.host_pub) {
       // zero-copy hand-off: the host polls the sequence word instead of
       // waiting on a D2H copy + stream sync
       volatile long long *hp = a.host_pub;
       hp[0] = fkey;
-      hp[1] = na;
+      hp[1] = na_pub;
       hp[2] = s;
       __threadfence_system();
       hp[3] = a.seq;
@@ -955,6 +1016,7 @@ __global__ void init_result_kernel(long long *result) {
   result[W_TICKET] = 0;
   result[W_LIST] = 0;
   result[R_SCRATCH] = 0;
+  result[R_TRIGSEQ] = 0;
 }
 
 __global__ void fill_u8_kernel(uint8_t *p, int n, uint8_t v) {
@@ -988,6 +1050,11 @@ struct kc_dwa {
   int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
   bool have_gbits = false;
   size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
+  DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
+  std::vector<int32_t> h_perm;
+  bool perm_valid = false;
+  bool early_launch = true;             // fused kernel queued before the trig table exists
+  long long trig_seq = 0;
   bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
   bool cost_lds_ok = false;             // sample_cost_kernel<true> may take kCostLdsBudget
   int fused_samples = 32, fused_block = 1024;
@@ -1259,6 +1326,7 @@ int upload_samples(kc_dwa *c) {
     c->vmax_lin = std::max(c->vmax_lin, std::hypot(c->lat.vx[i], c->lat.vy[i]));
   c->shard_first = 0;
   c->shard_count = n;
+  c->perm_valid = false;
   if (n == 0) return KC_OK;
   KC_TRY(c->d_vx.reserve(n));
   KC_TRY(c->d_vy.reserve(n));
@@ -1271,6 +1339,24 @@ int upload_samples(kc_dwa *c) {
   KC_HIP(hipMemcpyAsync(c->d_row.p, c->lat.row.data(), n * sizeof(int32_t),
                         hipMemcpyHostToDevice, c->stream));
   KC_HIP(hipStreamSynchronize(c->stream));
+  return KC_OK;
+}
+
+// shard-local sample ids ordered by trig row (stable): consecutive samples of a
+// fused workgroup then share one or two rows of the table
+int build_perm(kc_dwa *c) {
+  const size_t n = c->shard_count, first = c->shard_first;
+  c->perm_valid = true;
+  if (n == 0) return KC_OK;
+  c->h_perm.resize(n);
+  for (size_t i = 0; i < n; ++i) c->h_perm[i] = static_cast<int32_t>(i);
+  const int32_t *row = c->lat.row.data() + first;
+  std::stable_sort(c->h_perm.begin(), c->h_perm.end(),
+                   [row](int32_t x, int32_t y) { return row[x] < row[y]; });
+  KC_TRY(c->d_perm.reserve(n));
+  KC_HIP(hipMemcpyAsync(c->d_perm.p, c->h_perm.data(), n * sizeof(int32_t),
+                        hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));  // h_perm is pageable
   return KC_OK;
 }
 
@@ -1527,6 +1613,8 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
   c->timing.mark("host:wait_result");
   kc_result r{};
   const long long key = c->h_result.p[0];
+  if (c->h_result.p[1] < 0)
+    KC_FAIL(KC_ERR_HIP, "roll-out kernel gave up waiting for the host's trig table");
   r.n_admissible = c->h_result.p[1];
   r.n_samples = static_cast<int64_t>(n);
   if (key == KEY_NONE) {
@@ -1656,6 +1744,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     c->trig_direct = large_bar != 0;
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
+    if (const char *e = std::getenv("KC_EARLY_LAUNCH"))
+      c->early_launch = e[0] != '0';            // tuning/test hook
   }
   if (const char *e = std::getenv("KC_DEBUG_STAMPS")) c->debug_stamps = e[0] == '1';
   if (const char *e = std::getenv("KC_FORCE_SPLIT"))
@@ -1732,6 +1822,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_costs.release();
   c->d_flags.release();
   c->d_dbg.release();
+  c->d_perm.release();
   c->d_vvx.release();
   c->d_vvy.release();
   c->d_vom.release();
@@ -1835,6 +1926,7 @@ int kc_dwa_set_shard(kc_dwa *c, size_t first, size_t count) {
             first + count, c->lat.size());
   c->shard_first = first;
   c->shard_count = count;
+  c->perm_valid = false;
   return KC_OK;
 }
 
@@ -1966,43 +2058,37 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   KC_TRY(c->h_trig.reserve(A * P));
   KC_TRY(c->d_trig.reserve(A * P));
   const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
-  {
-    // Where the table is written: straight into device memory when the host
-    // can address it (large BAR: write-combined stores, no copy command and no
-    // copy engine latency on the critical path), else into pinned memory
-    // followed by an H2D copy.
-    const double yaw0 = start->yaw;
-    const double *om_v = c->lat.omega_values.data();
-    double2 *tab = c->trig_direct ? c->d_trig.p : c->h_trig.p;
-    WorkerPool::instance().parallel_for(A, 2, [=](size_t r0, size_t r1) {
-      // a worker's rows are computed into a small local tile and written out
-      // as one contiguous run per step (the table is step-major: the kernels
-      // read consecutive omega rows with consecutive lanes)
-      constexpr size_t kTileRows = 16;
-      double2 tile[kTileRows];
-      double yaw[kTileRows];
-      for (size_t rb = r0; rb < r1; rb += kTileRows) {
-        const size_t nr = std::min(kTileRows, r1 - rb);
-        for (size_t i = 0; i < nr; ++i) yaw[i] = yaw0;
-        for (size_t k = 0; k < P; ++k) {
-          for (size_t i = 0; i < nr; ++i) {
-            double sn, cs;
-            ::sincos(yaw[i], &sn, &cs);  // bit-identical to sin()/cos() (tested)
-            tile[i] = make_double2(cs, sn);
-            yaw[i] += om_v[rb + i] * dt;
-          }
-          std::memcpy(tab + k * A + rb, tile, nr * sizeof(double2));
+  // Where the table is written: straight into device memory when the host
+  // can address it (large BAR: write-combined stores, no copy command and no
+  // copy engine latency on the critical path), else into pinned memory
+  // followed by an H2D copy.
+  const double yaw0 = start->yaw;
+  const double *om_v = c->lat.omega_values.data();
+  double2 *tab = c->trig_direct ? c->d_trig.p : c->h_trig.p;
+  auto trig_rows = [=](size_t r0, size_t r1) {
+    // a worker's rows are computed into a small local tile and written out
+    // as one contiguous run per step (the table is step-major: the kernels
+    // read consecutive omega rows with consecutive lanes)
+    constexpr size_t kTileRows = 16;
+    double2 tile[kTileRows];
+    double yaw[kTileRows];
+    for (size_t rb = r0; rb < r1; rb += kTileRows) {
+      const size_t nr = std::min(kTileRows, r1 - rb);
+      for (size_t i = 0; i < nr; ++i) yaw[i] = yaw0;
+      for (size_t k = 0; k < P; ++k) {
+        for (size_t i = 0; i < nr; ++i) {
+          double sn, cs;
+          ::sincos(yaw[i], &sn, &cs);  // bit-identical to sin()/cos() (tested)
+          tile[i] = make_double2(cs, sn);
+          yaw[i] += om_v[rb + i] * dt;
         }
+        std::memcpy(tab + k * A + rb, tile, nr * sizeof(double2));
       }
+    }
 #if defined(__x86_64__)
-      __builtin_ia32_sfence();  // write-combined stores leave the core before "done"
+    __builtin_ia32_sfence();  // write-combined stores leave the core before "done"
 #endif
-    });
-  }
-  c->timing.mark("host:trig_table");
-  if (!c->trig_direct)
-    KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
-                          hipMemcpyHostToDevice, s));
+  };
   RollArgs a{};
   KC_TRY(ensure_cycle_buffers(c, n, P));
   a.n = static_cast<int>(n);
@@ -2030,11 +2116,36 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   const bool fused = c->prm.shape != KC_SPHERE && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
   c->need_compact = !fused;
+  // early launch: queue the fused kernel first and let launch + dispatch
+  // latency run under the host's libm work (needs the BAR path for the table
+  // and its sequence word; not while kernels are being timed, the wait would
+  // be charged to the kernel)
+  const bool early = fused && c->trig_direct && c->early_launch && !c->timing.enabled;
+  struct PoolJoin {  // an error return below must not leave the job running
+    ~PoolJoin() { WorkerPool::instance().wait(); }
+  } pool_join;
+  if (early) {
+    // the workers produce the table while this thread queues the kernel
+    WorkerPool::instance().begin(A, 2, trig_rows);
+  } else {
+    WorkerPool::instance().parallel_for(A, 2, trig_rows);
+    c->timing.mark("host:trig_table");
+    if (!c->trig_direct)
+      KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
+                            hipMemcpyHostToDevice, s));
+  }
   if (fused) {
+    if (!c->perm_valid) KC_TRY(build_perm(c));
+    a.perm = c->d_perm.p;
     if (c->list_dirty)  // previous roll-out was never evaluated: re-arm the list
       KC_HIP(hipMemsetAsync(c->d_result.p + W_LIST, 0, sizeof(long long), s));
     c->list_dirty = true;
     a.c.lds = 1;
+    if (early) {
+      a.trig_flag = c->d_result.p + R_TRIGSEQ;
+      a.trig_seq = ++c->trig_seq;
+      a.dev_err = c->d_result.p + W_NADM;
+    }
     KC_TRY(c->timing.start("rollout_collide_kernel", s));
     const dim3 grid(blocks_for(n, fs)), block(fb);
     const size_t smem = pos_bytes + bits_bytes;
@@ -2045,6 +2156,15 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
     else hipLaunchKernelGGL((rollout_collide_kernel<32, 512>), grid, block, smem, s, a);
     KC_TRY(c->timing.stop(s));
     c->timing.mark("host:launch_rollout");
+    if (early) {
+      WorkerPool::instance().wait();
+      // the table is out of the cores (sfence in every worker); now the word
+      // the workgroups are waiting for
+      *reinterpret_cast<volatile long long *>(c->d_result.p + R_TRIGSEQ) = a.trig_seq;
+#if defined(__x86_64__)
+      __builtin_ia32_sfence();
+#endif
+    }
   } else {
     // split path (sphere, very long horizons, windows beyond LDS): roll-out
     // first, window bits built on the host while it runs, then the pose-

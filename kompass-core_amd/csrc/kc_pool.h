@@ -30,6 +30,42 @@ class WorkerPool {
 
   // fn(begin, end) over [0, n) split into one contiguous chunk per thread; the
   // caller takes the first chunk.  Serial when n is small or no workers exist.
+  // Asynchronous form: the workers take the whole range while the caller does
+  // something else (e.g. a kernel launch); wait() returns when they are done.
+  // Without workers the range is processed on the spot.  fn is copied.
+  template <typename F>
+  void begin(size_t n, size_t min_chunk, F fn) {
+    const size_t parts =
+        std::min<size_t>(threads_.size(), min_chunk ? std::max<size_t>(n / min_chunk, 1) : n);
+    if (threads_.empty() || n == 0) {
+      if (n) fn(size_t(0), n);
+      async_gen_ = 0;
+      return;
+    }
+    async_lock_ = std::unique_lock<std::mutex>(run_mu_);  // one job at a time
+    job_fn_ = [fn, n, parts](size_t part) {
+      // worker w carries part w + 1: shift down, the caller takes none
+      const size_t q = part - 1;
+      const size_t b = n * q / parts, e = n * (q + 1) / parts;
+      if (b < e) fn(b, e);
+    };
+    job_parts_ = parts + 1;
+    const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      gen_.store(g, std::memory_order_release);
+    }
+    if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+    async_gen_ = g;
+  }
+  void wait() {
+    if (!async_gen_) return;
+    for (size_t w = 0; w < threads_.size(); ++w)
+      while (slots_[w].done.load(std::memory_order_acquire) != async_gen_) cpu_relax();
+    async_gen_ = 0;
+    async_lock_.unlock();
+  }
+
   template <typename F>
   void parallel_for(size_t n, size_t min_chunk, F &&fn) {
     const size_t parts =
@@ -118,6 +154,8 @@ class WorkerPool {
   std::vector<std::thread> threads_;
   std::unique_ptr<Slot[]> slots_;
   std::mutex mu_, run_mu_;
+  std::unique_lock<std::mutex> async_lock_;
+  uint64_t async_gen_ = 0;
   std::condition_variable cv_;
   alignas(64) std::atomic<uint64_t> gen_{0};
   alignas(64) std::atomic<int> sleepers_{0};
