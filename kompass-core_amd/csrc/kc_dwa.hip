@@ -43,6 +43,14 @@ struct CollDev {
   // update); the fused kernel copies its window out of it, word aligned
   const uint32_t *gbits;      // [gH][gwpr]
   int gkx0, gky0, gH, gwpr;   // origin (keys), rows, words per row
+  // the same bitmap dilated twice (built by dilate_kernel once per sensor
+  // update): `ginner` marks the cells from which an occupied cell is SURELY
+  // within the robot's inscribed radius, `gouter` the cells from which one is
+  // POSSIBLY within its circumscribed radius.  A pose in a cell outside
+  // gouter cannot collide, one inside ginner does; only the thin shell in
+  // between needs the exact test.
+  const uint32_t *ginner, *gouter;
+  int dil;                    // masks present
 };
 
 struct RollArgs {
@@ -69,8 +77,15 @@ struct RollArgs {
   const long long *trig_flag;
   long long trig_seq;
   long long *dev_err;   // set when the wait gives up (host never delivered)
+  unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
   CollDev c;
 };
+
+#define KC_RSTAMP(slot)                                                    \
+  do {                                                                     \
+    if (a.dbg && threadIdx.x == 0)                                         \
+      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 
 // ===========================================================================
 // collision: analytic shape-vs-occupied-voxel test (restated A4 contract)
@@ -259,6 +274,52 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Dilated occupancy masks (once per sensor update).  For a pose in cell c and
+// an occupied cell at integer offset (i, j) the clamped distance d used by the
+// exact tests obeys  res*hypot((|i|-1)+, (|j|-1)+) <= d <= res*hypot(i, j),
+// so with rho = radius / res (in cells, 1e-6 of slack for the rounding of the
+// pose's own cell index):
+//   inner: hypot(i, j) <= rho_in - 1e-6            -> collision certain
+//   outer: hypot((|i|-1)+, (|j|-1)+) <= rho_out + 1e-6 -> collision possible
+// Both sets are runs per row offset j (half widths win[|j|], wout[|j|]; -1 =
+// empty).  One thread per output word; a row is dilated horizontally from the
+// three words around the output word (half widths <= 31).
+// ---------------------------------------------------------------------------
+constexpr int kMaxDil = 32;
+struct DilArgs {
+  const uint32_t *g;
+  uint32_t *inner, *outer;
+  int H, wpr, R;
+  signed char win[kMaxDil + 1], wout[kMaxDil + 1];
+};
+__device__ __forceinline__ uint32_t hdilate(uint32_t left, uint32_t mid, uint32_t right, int w) {
+  uint32_t acc = mid;
+  for (int s = 1; s <= w; ++s)
+    acc |= (mid << s) | (left >> (32 - s)) | (mid >> s) | (right << (32 - s));
+  return acc;
+}
+__global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.H * a.wpr) return;
+  const int y = t / a.wpr, w = t - y * a.wpr;
+  uint32_t in_acc = 0u, out_acc = 0u;
+  for (int j = -a.R; j <= a.R; ++j) {
+    const int yy = y + j;
+    if (yy < 0 || yy >= a.H) continue;
+    const uint32_t *row = a.g + (size_t)yy * a.wpr;
+    const uint32_t mid = row[w];
+    const uint32_t left = w > 0 ? row[w - 1] : 0u;
+    const uint32_t right = w + 1 < a.wpr ? row[w + 1] : 0u;
+    if ((mid | left | right) == 0u) continue;
+    const int aj = j < 0 ? -j : j;
+    if (a.win[aj] >= 0) in_acc |= hdilate(left, mid, right, a.win[aj]);
+    if (a.wout[aj] >= 0) out_acc |= hdilate(left, mid, right, a.wout[aj]);
+  }
+  a.inner[t] = in_acc;
+  a.outer[t] = out_acc;
+}
+
 // ===========================================================================
 // K1 (fused): roll-out + collision gate of 32 samples per workgroup, no global
 // round trip in between.  512 lanes: (A) copy the occupancy bits of the
@@ -275,6 +336,11 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   double2 *lpos = reinterpret_cast<double2 *>(smem);
   uint32_t *lbits = reinterpret_cast<uint32_t *>(
       smem + (size_t)kFusedSamples * PP * sizeof(double2));
+  const int nwin = a.c.enabled ? a.c.H * a.c.wpr : 0;
+  uint32_t *linner = lbits + nwin;                 // a.c.dil only
+  uint32_t *louter = linner + (a.c.dil ? nwin : 0);
+  int *lcand = reinterpret_cast<int *>(louter + (a.c.dil ? nwin : 0));  // [samples * P]
+  __shared__ int ncand;
   __shared__ int lhit[kFusedSamples];
   __shared__ int lperm[kFusedSamples];  // local sample id of slot s
   __shared__ int lrow[kFusedSamples];   // its trig row
@@ -284,6 +350,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   const int rows = min(kFusedSamples, a.n - base);
   const int steps = a.P - 1;
 
+  KC_RSTAMP(0);
   // ---- A: window bits + trig rows -----------------------------------------
   if (tid < kFusedSamples) {
     lhit[tid] = 0;
@@ -298,12 +365,24 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     for (int i = tid; i < nwords; i += kFusedBlock) {
       const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
       const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
-      uint32_t v = 0u;
-      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr)
-        v = a.c.gbits[(size_t)gy * a.c.gwpr + gw];
+      uint32_t v = 0u, vi = 0u, vo = 0u;
+      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
+        const size_t g = (size_t)gy * a.c.gwpr + gw;
+        v = a.c.gbits[g];
+        if (a.c.dil) {
+          vi = a.c.ginner[g];
+          vo = a.c.gouter[g];
+        }
+      }
       lbits[i] = v;
+      if (a.c.dil) {
+        linner[i] = vi;
+        louter[i] = vo;
+      }
     }
   }
+  if (tid == 0) ncand = 0;
+  KC_RSTAMP(1);
   if (a.trig_flag) {
     // wait for the host's table (system-scope loads: the word and the table
     // arrive over PCIe, behind this GPU's caches).  Bounded: ~50 ms.
@@ -322,6 +401,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       s_late = late;
     }
     __syncthreads();
+    KC_RSTAMP(2);
     if (s_late) {  // give the cycle up: nothing admissible, error word set
       if (tid < rows) a.flags[lperm[tid]] = 0;
       if (tid == 0) *a.dev_err = 1;
@@ -348,6 +428,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   }
   __syncthreads();
+  KC_RSTAMP(3);
   // ---- B: serial recurrences (wavefront 0) ----------------------------------
   if (tid < rows) {
     const double vx = a.vx[a.first + lperm[tid]];
@@ -365,7 +446,9 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   }
   __syncthreads();
-  // ---- C: float rows out + one pose per lane against the window bits ---------
+  KC_RSTAMP(4);
+  // ---- C: float rows out; poses classified with the dilated masks, the
+  // undecided ones queued and tested exactly by densely packed lanes ----------
   {
     const int total = rows * a.P;
     int s = 0, k = tid;
@@ -381,22 +464,25 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       a.px[o] = static_cast<float>(p.x);
       a.py[o] = static_cast<float>(p.y);
       if (a.c.enabled && k > 0) {
-        bool hit;
-        if (a.c.shape == KC_BOX) {
-          const size_t e = (size_t)k * a.A + lrow[s];  // yaw_k
-          double2 t;
-          if (a.trig_flag) {
-            const double *tg = reinterpret_cast<const double *>(a.trig);
-            t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          } else {
-            t = a.trig[e];
+        bool exact = true;
+        if (a.c.dil) {
+          const double dx = p.x - a.c.tx, dy = p.y - a.c.ty;
+          const double xf = a.c.r00 * dx + a.c.r10 * dy;
+          const double yf = a.c.r01 * dx + a.c.r11 * dy;
+          const int cx = static_cast<int>(floor(xf * a.c.inv)) - a.c.kx0;
+          const int cy = static_cast<int>(floor(yf * a.c.inv)) - a.c.ky0;
+          if (cx >= 0 && cx < a.c.W && cy >= 0 && cy < a.c.H) {
+            const int w = cy * a.c.wpr + (cx >> 5);
+            const uint32_t bit = 1u << (cx & 31);
+            if (linner[w] & bit) {
+              lhit[s] = 1;  // every writer stores the same value
+              exact = false;
+            } else if (!(louter[w] & bit)) {
+              exact = false;
+            }
           }
-          hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y);
-        } else {
-          hit = hit_round(a.c, lbits, p.x, p.y);
         }
-        if (hit) lhit[s] = 1;  // every writer stores the same value
+        if (exact) lcand[atomicAdd(&ncand, 1)] = (s << 16) | k;
       }
       k += kFusedBlock;
       while (k >= a.P) {
@@ -406,6 +492,32 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   }
   __syncthreads();
+  {
+    const int nc = ncand;
+    for (int i = tid; i < nc; i += kFusedBlock) {
+      const int s = lcand[i] >> 16, k = lcand[i] & 0xFFFF;
+      if (lhit[s]) continue;  // already decided (stale reads only cost work)
+      const double2 p = lpos[s * PP + k - 1];
+      bool hit;
+      if (a.c.shape == KC_BOX) {
+        const size_t e = (size_t)k * a.A + lrow[s];  // yaw_k
+        double2 t;
+        if (a.trig_flag) {
+          const double *tg = reinterpret_cast<const double *>(a.trig);
+          t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+          t = a.trig[e];
+        }
+        hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y);
+      } else {
+        hit = hit_round(a.c, lbits, p.x, p.y);
+      }
+      if (hit) lhit[s] = 1;
+    }
+  }
+  __syncthreads();
+  KC_RSTAMP(5);
   if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
     const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
     if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
@@ -419,6 +531,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     start = __shfl(start, 0, 64);
     if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = lperm[tid];
   }
+  KC_RSTAMP(6);
 }
 
 // ===========================================================================
@@ -1050,6 +1163,9 @@ struct kc_dwa {
   int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
   bool have_gbits = false;
   size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
+  DevBuf<uint32_t> d_ginner, d_gouter;  // dilated sensor bitmaps
+  bool have_dil = false;
+  DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
   DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
   std::vector<int32_t> h_perm;
   bool perm_valid = false;
@@ -1168,6 +1284,25 @@ int upload_voxels(kc_dwa *c) {
     loy = std::min(loy, c->vox_ky[i]);
     hiy = std::max(hiy, c->vox_ky[i]);
   }
+  // dilation radii in cells (see dilate_kernel); the bitmap is padded so that
+  // the dilated masks fit
+  const double rho_in = (c->prm.shape == KC_BOX
+                             ? std::min(static_cast<double>(c->prm.dims[0]),
+                                        static_cast<double>(c->prm.dims[1])) / 2.0
+                             : c->radius) / c->res;
+  const double rho_out = (c->prm.shape == KC_BOX
+                              ? std::sqrt(std::pow(static_cast<double>(c->prm.dims[0]) / 2.0, 2) +
+                                          std::pow(static_cast<double>(c->prm.dims[1]) / 2.0, 2))
+                              : c->radius) / c->res;
+  const int R = static_cast<int>(std::floor(rho_out + 1e-6)) + 1;
+  c->have_dil = c->prm.shape != KC_SPHERE && std::isfinite(rho_out) && R <= 30 && rho_in >= 0.0;
+  if (c->have_dil) {
+    const int pad = R + 1;
+    lox -= pad;
+    loy -= pad;
+    hix += pad;
+    hiy += pad;
+  }
   const long W = static_cast<long>(hix) - lox + 1, H = static_cast<long>(hiy) - loy + 1;
   if (W > 8192 || H > 8192) return KC_OK;  // too sparse/far: split path only
   c->gkx0 = lox;
@@ -1184,6 +1319,41 @@ int upload_voxels(kc_dwa *c) {
   }
   KC_HIP(hipMemcpyAsync(c->d_gbits.p, c->h_gbits.p, nwords * sizeof(uint32_t),
                         hipMemcpyHostToDevice, c->stream));
+  if (c->have_dil) {
+    KC_TRY(c->d_ginner.reserve(nwords));
+    KC_TRY(c->d_gouter.reserve(nwords));
+    DilArgs da{};
+    da.g = c->d_gbits.p;
+    da.inner = c->d_ginner.p;
+    da.outer = c->d_gouter.p;
+    da.H = c->gH;
+    da.wpr = c->gwpr;
+    da.R = R;
+    for (int j = 0; j <= kMaxDil; ++j) {
+      da.win[j] = da.wout[j] = -1;
+      if (j > R) continue;
+      // inner: largest i with hypot(i, j) <= rho_in - 1e-6
+      const double ri = rho_in - 1e-6;
+      if (ri >= 0.0 && static_cast<double>(j) <= ri) {
+        int i = static_cast<int>(std::floor(std::sqrt(ri * ri - static_cast<double>(j) * j)));
+        while (i >= 0 && std::hypot(static_cast<double>(i), static_cast<double>(j)) > ri) --i;
+        da.win[j] = static_cast<signed char>(std::min(i, 31));
+      }
+      // outer: largest i with hypot((i-1)+, (j-1)+) <= rho_out + 1e-6
+      const double ro = rho_out + 1e-6;
+      const double jj = std::max(j - 1, 0);
+      if (jj <= ro) {
+        int i = static_cast<int>(std::floor(std::sqrt(ro * ro - jj * jj))) + 2;
+        while (i > 0 && std::hypot(static_cast<double>(std::max(i - 1, 0)), jj) > ro) --i;
+        da.wout[j] = static_cast<signed char>(std::min(i, 31));
+      }
+    }
+    const unsigned nb = static_cast<unsigned>((nwords + 255) / 256);
+    KC_TRY(c->timing.start("dilate_kernel", c->stream));
+    hipLaunchKernelGGL(dilate_kernel, dim3(nb), dim3(256), 0, c->stream, da);
+    KC_TRY(c->timing.stop(c->stream));
+    KC_HIP(hipGetLastError());
+  }
   c->have_gbits = true;
   return KC_OK;
 }
@@ -1411,6 +1581,9 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
     cd.W += static_cast<int>(rel - aligned);
     cd.kx0 = static_cast<int>(c->gkx0 + aligned);
     cd.gbits = c->d_gbits.p;
+    cd.ginner = c->d_ginner.p;
+    cd.gouter = c->d_gouter.p;
+    cd.dil = c->have_dil ? 1 : 0;
     cd.gkx0 = c->gkx0;
     cd.gky0 = c->gky0;
     cd.gH = c->gH;
@@ -1767,6 +1940,24 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
 void kc_dwa_destroy(kc_dwa *c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->prm.device);
+  if (c->debug_stamps && c->d_dbg2.p) {
+    std::vector<unsigned long long> h(512 * 16);
+    e = hipDeviceSynchronize();
+    e = hipMemcpy(h.data(), c->d_dbg2.p, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < 512; ++b) if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
+    const char *nm[7] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "end"};
+    std::fprintf(stderr, "[kc stamps] roll-out kernel, us since first block start (avg / max):\n");
+    for (int k = 0; k < 7; ++k) {
+      double sm = 0, mx = 0; int nb = 0;
+      for (int b = 0; b < 512; ++b) {
+        if (!h[b * 16] || !h[b * 16 + k]) continue;
+        const double us = (h[b * 16 + k] - t0) / 100.0;
+        sm += us; mx = std::max(mx, us); ++nb;
+      }
+      std::fprintf(stderr, "  %-18s %7.2f / %7.2f  (%d blocks)\n", nm[k], nb ? sm / nb : 0.0, mx, nb);
+    }
+  }
   if (c->debug_stamps && c->d_dbg.p) {  // diagnostic dump of the last cycle
     std::vector<unsigned long long> h(512 * 16);
     e = hipDeviceSynchronize();
@@ -1822,6 +2013,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_costs.release();
   c->d_flags.release();
   c->d_dbg.release();
+  c->d_dbg2.release();
   c->d_perm.release();
   c->d_vvx.release();
   c->d_vvy.release();
@@ -1837,6 +2029,8 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_skip.release();
   c->h_gbits.release();
   c->d_gbits.release();
+  c->d_ginner.release();
+  c->d_gouter.release();
   c->d_adm.release();
   c->d_pos.release();
   c->d_result.release();
@@ -2112,7 +2306,9 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
   const int fs = c->fused_samples, fb = c->fused_block;
   const size_t pos_bytes = static_cast<size_t>(fs) * (P | 1) * sizeof(double2);
-  const size_t bits_bytes = a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 : 0;
+  const size_t bits_bytes =
+      (a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 * (a.c.dil ? 3 : 1) : 0) +
+      static_cast<size_t>(fs) * P * sizeof(int);  // + queue of undecided poses
   const bool fused = c->prm.shape != KC_SPHERE && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
   c->need_compact = !fused;
@@ -2137,6 +2333,11 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   if (fused) {
     if (!c->perm_valid) KC_TRY(build_perm(c));
     a.perm = c->d_perm.p;
+    if (c->debug_stamps) {
+      KC_TRY(c->d_dbg2.reserve(512 * 16));
+      KC_HIP(hipMemsetAsync(c->d_dbg2.p, 0, 512 * 16 * 8, s));
+      a.dbg = c->d_dbg2.p;
+    }
     if (c->list_dirty)  // previous roll-out was never evaluated: re-arm the list
       KC_HIP(hipMemsetAsync(c->d_result.p + W_LIST, 0, sizeof(long long), s));
     c->list_dirty = true;
