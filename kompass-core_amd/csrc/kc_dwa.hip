@@ -619,7 +619,6 @@ __global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
 // record to the host through pinned memory and re-arms the working area.
 // ===========================================================================
 constexpr int kCostBlock = 512;  // 8 wavefronts, two workgroups per CU
-constexpr int kCostWaves = kCostBlock / 64;
 // LDS the search structures of one workgroup may take (two workgroups share
 // the 160 KB of a CU)
 constexpr size_t kCostLdsBudget = 78 * 1024;
@@ -659,8 +658,7 @@ struct CostArgs {
   double w_path, w_goal, w_obs, w_smooth, w_jerk;
   float *costs;
   long long *result;    // R_* published record + W_* working area
-  long long *host_pub;  // pinned host mirror {key, n_adm, compact, seq} or null
-  long long seq;        // cycle sequence number the host waits for
+  long long *block_keys;  // [gridDim.x] best key of every workgroup (publish_kernel reduces)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS): per-block phase clocks
 };
 
@@ -746,7 +744,6 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
   __shared__ float s_goal, s_end;
   __shared__ long long s_key;
   __shared__ unsigned long long s_obest;  // sample-wide min squared obstacle distance (double bits)
-  __shared__ int is_last;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
   KC_STAMP(0);
@@ -755,7 +752,10 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
   KC_STAMP(1);
   // blocks beyond the admissible count have nothing to do and take no ticket
   const unsigned working = static_cast<unsigned>(min(static_cast<int>(gridDim.x), max(na, 1)));
-  if (blockIdx.x >= working) return;
+  if (blockIdx.x >= working) {
+    if (threadIdx.x == 0) a.block_keys[blockIdx.x] = KEY_NONE;
+    return;
+  }
   if (threadIdx.x == 0) s_key = KEY_NONE;
 
   const BucketDev &b = a.b;
@@ -999,23 +999,50 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
     KC_STAMP(3);
   }
 
-  // ---- block epilogue: one atomic per block, last block publishes --------------
-  if (threadIdx.x == 0) {
-    const long long k = s_key;
-    if (k != KEY_NONE) atomicMin(&a.result[W_KEY], k);
-    // no cache-level fence: the only cross-block data are the two device-scope
-    // atomics (performed at the memory side); the wait orders them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long ticket = atomicAdd(
-        reinterpret_cast<unsigned long long *>(&a.result[W_TICKET]), 1ull);
-    is_last = (ticket == working - 1) ? 1 : 0;
-  }
-  __syncthreads();
+  // ---- block epilogue: the block's best key, for publish_kernel ----------------
+  if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
   KC_STAMP(4);
-  if (!is_last) return;
+}
+
+// One workgroup, queued behind sample_cost_kernel: minimum of the per-block
+// keys, the reference's compacted index of the winner (admissible samples in
+// front of it), the record for the host (pinned memory, polled: no D2H copy, no
+// stream wait) and the re-arming of the working slots.  A kernel boundary
+// instead of a device-wide "last block" ticket: hundreds of same-address
+// atomics cost more than the dispatch of this kernel.
+struct PubArgs {
+  const long long *block_keys;
+  int nblocks;
+  const uint8_t *flags;
+  int n, first;
+  long long *result;
+  long long *host_pub;
+  long long seq;
+};
+constexpr int kPubBlock = 512;
+__global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
+  __shared__ long long wkey[kPubBlock / 64];
+  __shared__ int wsum[kPubBlock / 64];
   __shared__ long long s_fkey;
-  __shared__ int wsum[kCostWaves];
-  if (threadIdx.x == 0) s_fkey = atomicMin(&a.result[W_KEY], KEY_NONE);  // memory-side read
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long k = KEY_NONE;
+  for (int b = threadIdx.x; b < a.nblocks; b += kPubBlock) {
+    const long long v = a.block_keys[b];
+    k = v < k ? v : k;
+  }
+  const long long na = a.result[W_LIST];
+  const long long err = a.result[W_NADM];  // device error word (roll-out gave up waiting)
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(k, off, 64);
+    k = o < k ? o : k;
+  }
+  if (lane == 0) wkey[wave] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long m = wkey[0];
+    for (int w = 1; w < kPubBlock / 64; ++w) m = wkey[w] < m ? wkey[w] : m;
+    s_fkey = m;
+  }
   __syncthreads();
   const long long fkey = s_fkey;
   // the reference's index counts the admissible samples in front of the winner
@@ -1024,37 +1051,33 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
     long long lim =
         static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
     if (lim > a.n) lim = a.n;
-    for (long long k = threadIdx.x; k < lim; k += kCostBlock) cnt += a.flags[k];
+    for (long long i = threadIdx.x; i < lim; i += kPubBlock) cnt += a.flags[i];
   }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
   if (lane == 0) wsum[wave] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) {
     int s = 0;
-    for (int w = 0; w < kCostWaves; ++w) s += wsum[w];
+    for (int w = 0; w < kPubBlock / 64; ++w) s += wsum[w];
     if (fkey == KEY_NONE) s = -1;
-    // W_NADM doubles as the device error word (roll-out kernel gave up waiting)
-    const long long na_pub = a.result[W_NADM] ? -1 : na;
-    a.result[R_KEY] = fkey;
-    a.result[R_NADM] = na_pub;
-    a.result[R_COMPACT] = s;
+    const long long na_pub = err ? -1 : na;
     if (a.host_pub) {
-      // zero-copy hand-off: the host polls the sequence word instead of
-      // waiting on a D2H copy + stream sync
+      // zero-copy hand-off: the host polls the sequence word
       volatile long long *hp = a.host_pub;
       hp[0] = fkey;
       hp[1] = na_pub;
       hp[2] = s;
       __threadfence_system();
       hp[3] = a.seq;
-      __threadfence_system();
     }
+    a.result[R_KEY] = fkey;
+    a.result[R_NADM] = na_pub;
+    a.result[R_COMPACT] = s;
     a.result[W_KEY] = KEY_NONE;
     a.result[W_NADM] = 0;
     a.result[W_TICKET] = 0;
     a.result[W_LIST] = 0;  // admissible-list counter of the next cycle
   }
-  KC_STAMP(5);
 }
 
 // ordered compaction of the admissible flags (one workgroup): adm_list[i] =
@@ -1163,6 +1186,7 @@ struct kc_dwa {
   int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
   bool have_gbits = false;
   size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
+  DevBuf<long long> d_block_keys;       // per-workgroup best keys of the cost kernel
   DevBuf<uint32_t> d_ginner, d_gouter;  // dilated sensor bitmaps
   bool have_dil = false;
   DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
@@ -1712,9 +1736,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.w_jerk = c->w.jerk_weight;
   ca.costs = c->d_costs.p;
   ca.result = c->d_result.p;
-  ca.host_pub = c->h_pub.p;
-  ca.seq = ++c->seq;
-  c->pub_pending = true;
+  KC_TRY(c->d_block_keys.reserve(512));
+  ca.block_keys = c->d_block_keys.p;
   if (c->debug_stamps) {
     KC_TRY(c->d_dbg.reserve(512 * 16));
     KC_HIP(hipMemsetAsync(c->d_dbg.p, 0, 512 * 16 * 8, s));
@@ -1747,6 +1770,21 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     hipLaunchKernelGGL((sample_cost_kernel<false, false>), dim3(cost_blocks), dim3(kCostBlock),
                        lds, s, ca);
   KC_TRY(c->timing.stop(s));
+  {
+    PubArgs pa{};
+    pa.block_keys = c->d_block_keys.p;
+    pa.nblocks = static_cast<int>(cost_blocks);
+    pa.flags = c->d_flags.p;
+    pa.n = static_cast<int>(n);
+    pa.first = static_cast<int>(first);
+    pa.result = c->d_result.p;
+    pa.host_pub = c->h_pub.p;
+    pa.seq = ++c->seq;
+    c->pub_pending = true;
+    KC_TRY(c->timing.start("publish_kernel", s));
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kPubBlock), 0, s, pa);
+    KC_TRY(c->timing.stop(s));
+  }
   // the kernel re-armed the list counter: a second evaluate of the same
   // roll-out has to rebuild the list from the flags
   c->list_dirty = false;
@@ -2028,6 +2066,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_skip.release();
   c->d_skip.release();
   c->h_gbits.release();
+  c->d_block_keys.release();
   c->d_gbits.release();
   c->d_ginner.release();
   c->d_gouter.release();
