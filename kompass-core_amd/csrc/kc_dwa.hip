@@ -1062,13 +1062,15 @@ __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
     if (fkey == KEY_NONE) s = -1;
     const long long na_pub = err ? -1 : na;
     if (a.host_pub) {
-      // zero-copy hand-off: the host polls the sequence word
+      // zero-copy hand-off: the host polls the record.  No fence between the
+      // words: the fourth is a checksum over the other three (it includes the
+      // sequence number), so a half-arrived record is never accepted.
+      const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
       volatile long long *hp = a.host_pub;
       hp[0] = fkey;
-      hp[1] = na_pub;
-      hp[2] = s;
-      __threadfence_system();
-      hp[3] = a.seq;
+      hp[1] = w1;
+      hp[2] = a.seq;
+      hp[3] = fkey ^ w1 ^ a.seq ^ 0x5bd1e9955bd1e995ll;
     }
     a.result[R_KEY] = fkey;
     a.result[R_NADM] = na_pub;
@@ -1801,11 +1803,11 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
     volatile long long *hp = c->h_pub.p;
     const auto t0 = std::chrono::steady_clock::now();
     for (long spins = 0;; ++spins) {
-      if (hp[3] == c->seq) {
-        std::atomic_thread_fence(std::memory_order_acquire);
-        c->h_result.p[0] = hp[0];
-        c->h_result.p[1] = hp[1];
-        c->h_result.p[2] = hp[2];
+      const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
+      if (w2 == c->seq && w3 == (w0 ^ w1 ^ w2 ^ 0x5bd1e9955bd1e995ll)) {
+        c->h_result.p[0] = w0;
+        c->h_result.p[1] = w1 >> 32;  // n_admissible (-1: device error)
+        c->h_result.p[2] = static_cast<long long>(static_cast<int32_t>(w1 & 0xFFFFFFFFll));
         got = true;
         c->drained = true;
         break;
