@@ -64,6 +64,8 @@ struct RollArgs {
   const int32_t *row;
   const int32_t *perm;  // fused kernel: local sample ids ordered by omega row, so that the
                         // samples of a workgroup share as few trig rows as possible
+  const double *pvx, *pvy;  // velocities and trig rows in that order (one load, no
+  const int32_t *prow;      // dependent second one)
   const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
   float *px, *py;       // [n][P] sample-major
   double2 *pos;         // [P][n] step-major double poses (collision pass input)
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ int lhit[kFusedSamples];
   __shared__ int lperm[kFusedSamples];  // local sample id of slot s
   __shared__ int lrow[kFusedSamples];   // its trig row
+  __shared__ double lvx[kFusedSamples], lvy[kFusedSamples];
 
   const int tid = threadIdx.x;
   const int base = blockIdx.x * kFusedSamples;
@@ -354,9 +357,11 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   // ---- A: window bits + trig rows -----------------------------------------
   if (tid < kFusedSamples) {
     lhit[tid] = 0;
-    const int ls = tid < rows ? a.perm[base + tid] : 0;
-    lperm[tid] = ls;
-    lrow[tid] = tid < rows ? a.row[a.first + ls] : 0;
+    const bool in = tid < rows;
+    lperm[tid] = in ? a.perm[base + tid] : 0;
+    lrow[tid] = in ? a.prow[base + tid] : 0;
+    lvx[tid] = in ? a.pvx[base + tid] : 0.0;
+    lvy[tid] = in ? a.pvy[base + tid] : 0.0;
   }
   if (a.c.enabled) {
     // window origin is word aligned with the sensor bitmap: whole-word copies
@@ -429,20 +434,46 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   }
   __syncthreads();
   KC_RSTAMP(3);
-  // ---- B: serial recurrences (wavefront 0) ----------------------------------
+  // ---- B: recurrences.  Path::State::update (datatypes/path.h:24-30) is
+  //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt;
+  // the increments do not depend on the running sums, so every lane forms some
+  // of them first (in place over the trig entries), and only the additions -
+  // whose order fixes the rounding - run as a serial chain per sample.
+  for (int i = tid; i < rows * steps; i += kFusedBlock) {
+    const int s = i / steps, k = i - s * steps;
+    const double vx = lvx[s], vy = lvy[s];
+    const double2 cs = lpos[s * PP + k];
+    const double tx = vx * cs.x - vy * cs.y;
+    const double ty = vx * cs.y + vy * cs.x;
+    lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
+  }
+  __syncthreads();
+  KC_RSTAMP(7);
   if (tid < rows) {
-    const double vx = a.vx[a.first + lperm[tid]];
-    const double vy = a.vy[a.first + lperm[tid]];
+    // sixteen increments per register chunk: one LDS latency per chunk instead
+    // of one per step
+    constexpr int kChunk = 16;
     double x = a.x0, y = a.y0;
     double2 *mine = lpos + tid * PP;
-    double2 cs = mine[0];
-    for (int k = 0; k < steps; ++k) {
-      const double2 nxt = mine[min(k + 1, steps - 1)];  // ahead of the chain
-      // Path::State::update, datatypes/path.h:24-30
-      x += (vx * cs.x - vy * cs.y) * a.dt;
-      y += (vx * cs.y + vy * cs.x) * a.dt;
-      mine[k] = make_double2(x, y);  // pose k+1
-      cs = nxt;
+    int k = 0;
+    for (; k + kChunk <= steps; k += kChunk) {
+      double2 v[kChunk];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) v[j] = mine[k + j];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        x += v[j].x;
+        y += v[j].y;
+        v[j] = make_double2(x, y);  // pose k + j + 1
+      }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) mine[k + j] = v[j];
+    }
+    for (; k < steps; ++k) {
+      const double2 inc = mine[k];
+      x += inc.x;
+      y += inc.y;
+      mine[k] = make_double2(x, y);
     }
   }
   __syncthreads();
@@ -1192,6 +1223,8 @@ struct kc_dwa {
   DevBuf<uint32_t> d_ginner, d_gouter;  // dilated sensor bitmaps
   bool have_dil = false;
   DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
+  DevBuf<double> d_pvx, d_pvy;          // sample velocities / trig rows in d_perm order
+  DevBuf<int32_t> d_prow;
   DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
   std::vector<int32_t> h_perm;
   bool perm_valid = false;
@@ -1550,9 +1583,23 @@ int build_perm(kc_dwa *c) {
   std::stable_sort(c->h_perm.begin(), c->h_perm.end(),
                    [row](int32_t x, int32_t y) { return row[x] < row[y]; });
   KC_TRY(c->d_perm.reserve(n));
+  KC_TRY(c->d_pvx.reserve(n));
+  KC_TRY(c->d_pvy.reserve(n));
+  KC_TRY(c->d_prow.reserve(n));
+  std::vector<double> pvx(n), pvy(n);
+  std::vector<int32_t> prow(n);
+  for (size_t i = 0; i < n; ++i) {
+    const size_t g = first + static_cast<size_t>(c->h_perm[i]);
+    pvx[i] = c->lat.vx[g];
+    pvy[i] = c->lat.vy[g];
+    prow[i] = c->lat.row[g];
+  }
   KC_HIP(hipMemcpyAsync(c->d_perm.p, c->h_perm.data(), n * sizeof(int32_t),
                         hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipStreamSynchronize(c->stream));  // h_perm is pageable
+  KC_HIP(hipMemcpyAsync(c->d_pvx.p, pvx.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipMemcpyAsync(c->d_pvy.p, pvy.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipMemcpyAsync(c->d_prow.p, prow.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
   return KC_OK;
 }
 
@@ -1986,9 +2033,9 @@ void kc_dwa_destroy(kc_dwa *c) {
     e = hipMemcpy(h.data(), c->d_dbg2.p, h.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 512; ++b) if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
-    const char *nm[7] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "end"};
+    const char *nm[8] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "end", "increments done"};
     std::fprintf(stderr, "[kc stamps] roll-out kernel, us since first block start (avg / max):\n");
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
       double sm = 0, mx = 0; int nb = 0;
       for (int b = 0; b < 512; ++b) {
         if (!h[b * 16] || !h[b * 16 + k]) continue;
@@ -2055,6 +2102,9 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_dbg.release();
   c->d_dbg2.release();
   c->d_perm.release();
+  c->d_pvx.release();
+  c->d_pvy.release();
+  c->d_prow.release();
   c->d_vvx.release();
   c->d_vvy.release();
   c->d_vom.release();
@@ -2206,7 +2256,9 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
                       float max_range) {
   if (!c || !st || (n && !xyz)) KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
+  const auto dbg_t0 = std::chrono::steady_clock::now();
   KC_HIP(hipStreamSynchronize(c->stream));
+  const auto dbg_t1 = std::chrono::steady_clock::now();
   // updateSensorData<std::vector<Path::Point>>(cloud, global_frame = true)
   c->frame = hm::Rigid3f::identity();
   c->vox_kx.clear();
@@ -2225,8 +2277,17 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   }
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;
+  const auto dbg_t2 = std::chrono::steady_clock::now();
   KC_TRY(upload_voxels(c));
-  return upload_obstacles(c, n);
+  const auto dbg_t3 = std::chrono::steady_clock::now();
+  const int rc = upload_obstacles(c, n);
+  const auto dbg_t4 = std::chrono::steady_clock::now();
+  if (c->debug_stamps) {
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    std::fprintf(stderr, "[kc] set_points: sync %.1f | voxelise+transform %.1f | upload_voxels %.1f | upload_obstacles %.1f us\n",
+                 us(dbg_t0, dbg_t1), us(dbg_t1, dbg_t2), us(dbg_t2, dbg_t3), us(dbg_t3, dbg_t4));
+  }
+  return rc;
 }
 
 int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
@@ -2374,6 +2435,9 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   if (fused) {
     if (!c->perm_valid) KC_TRY(build_perm(c));
     a.perm = c->d_perm.p;
+    a.pvx = c->d_pvx.p;
+    a.pvy = c->d_pvy.p;
+    a.prow = c->d_prow.p;
     if (c->debug_stamps) {
       KC_TRY(c->d_dbg2.reserve(512 * 16));
       KC_HIP(hipMemsetAsync(c->d_dbg2.p, 0, 512 * 16 * 8, s));
