@@ -618,41 +618,50 @@ __global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
 }
 
 // ===========================================================================
-// K2: cost of every admissible sample + argmin, one workgroup per sample,
-// one WAVEFRONT per trajectory point, 64 lanes per search.
+// K2: cost of every admissible sample + per-workgroup argmin.  One WAVEFRONT
+// per sample (sixteen samples in flight per workgroup), one lane per
+// trajectory point; the search tables sit in LDS, filled once per workgroup.
 //
 // Tracked segment (pathCostFunc inner loops, cost_evaluator.cpp:120-130, and
 // goalCostFunc's closest-point search, :157-166): d2 = dx*dx + (dy*dy + dz*dz)
-// in float over all S segment points, 64 at a time, then a wave reduction with
-// the lowest index winning ties (the reference's strict `<` in index order);
-// min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt, so one
-// sqrt per point; the END point's search also yields the goal cost
-// ((a-b)^2 == (b-a)^2 bit for bit).
+// in float, the lowest index winning ties (the reference's strict `<` in index
+// order); min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt,
+// so one sqrt per point; the END point's search also yields the goal cost
+// ((a-b)^2 == (b-a)^2 bit for bit).  Instead of all S points a lane evaluates
+// (1) the first point of every chunk of the segment, (2) a bounding-sphere
+// test per chunk against that upper bound (|q - p_j| >= |q - c| - r; spheres
+// from the host, 1e-4 relative slack, non-finite chunks always qualify), and
+// (3) every remaining point of the chunks that may hold something closer - the
+// same minimum and the same lowest index as the full scan.
 //
 // Obstacles (TrajectoryPath::minDist2D, trajectory.h:218-235): float
 // difference, squares and sum in double, rounded to float once; the rounding
 // is monotonic, so the minimum is taken in double and rounded later.  Instead
 // of the reference's brute force over all O obstacles the points are bucketed
-// on a uniform grid (host, once per sensor update) and searched outwards in
-// growing square blocks of cells, one cell row per lane.  A block of
-// half-width m cells contains every obstacle closer than m*g to the query, so
-// once the best squared distance is below (m*g)^2 (1e-6 relative guard, four
-// orders above the float rounding of the differences) nothing outside can beat
-// it; distances >= max_obstacles_dist all give cost 0, so the search also
-// stops once m*g covers that range.
+// on a uniform grid (host, once per sensor update) with a Chebyshev distance
+// table to the nearest non-empty cell.  A lane searches square rings of cells
+// outwards from the first ring that can hold a point.  A block of half-width m
+// contains every obstacle closer than m*g, so once the best squared distance
+// is below (m*g)^2 (1e-6 relative guard, four orders above the float rounding
+// of the differences) nothing outside can beat it.  Only the minimum over the
+// whole trajectory is used (obstaclesDistCostFunc, cost_evaluator.cpp:179-184),
+// so the lanes of a sample share their best distance: a lane whose unvisited
+// cells are all farther than what another lane already found stops, and so
+// does one that has covered max_obstacles_dist (those distances cost 0).
 //
-// The per-point minima stay in LDS; wavefront 0 then forms the weighted total
-// in the reference's accumulation order (cost_evaluator.cpp:59-100: float
-// total, each += a double multiply-add rounded once; the path-cost sum walks
-// the points in order with v_readlane), packs the (cost, index) key, and the
-// block publishes its best key with one atomic.  The block that arrives last
-// turns the winner's raw index into the reference's compacted index, hands the
-// record to the host through pinned memory and re-arms the working area.
+// The weighted total follows the reference's accumulation order
+// (cost_evaluator.cpp:59-100: float total, each += a double multiply-add
+// rounded once; the path-cost sum walks the points in order with
+// v_readlane).  Every workgroup leaves its best (cost, index) key for
+// publish_kernel.
 // ===========================================================================
-constexpr int kCostBlock = 512;  // 8 wavefronts, two workgroups per CU
-// LDS the search structures of one workgroup may take (two workgroups share
-// the 160 KB of a CU)
-constexpr size_t kCostLdsBudget = 78 * 1024;
+constexpr int kCostBlock = 1024;  // 16 wavefronts = 16 samples in flight, one workgroup per CU
+constexpr int kCostWaves = kCostBlock / 64;
+constexpr int kCostGrid = 256;    // one workgroup per CU
+// LDS the search tables of a workgroup may take
+constexpr size_t kCostLdsBudget = 150 * 1024;
+constexpr int kSegChunkMin = 16;
+constexpr long long kBlockKernelMaxAdm = 1024;  // longest list the workgroup-per-sample kernel gets  // segment points per bounding sphere (at most 64 chunks)
 
 struct BucketDev {
   int W, H;            // cells
@@ -680,7 +689,9 @@ struct CostArgs {
   const uint8_t *flags;
   const int *adm_list;            // admissible local sample ids (any order)
   const long long *adm_count;     // device-side count (result[W_LIST])
-  const float *sx, *sy, *sz, *szz, *acc_seg;
+  const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the
+                                               // chunk spheres [4][nch]: cx, cy, cz, r
+  int seg_chunk, nch;             // points per chunk, chunk count (<= 64)
   float seg_len, ref_len;
   BucketDev b;
   const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
@@ -762,12 +773,19 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// kLds: the tracked segment, the bucket cell table and the skip table are
-// copied into LDS once per workgroup; kObsLds: the obstacle coordinates too.
-// The searches are chains of dependent loads, so where the tables sit decides
-// the latency of every step.
+// ---------------------------------------------------------------------------
+// K2b: the same costs for SHORT admissible lists (a cluttered scene leaves a few
+// hundred samples): one workgroup per sample, eight lanes per trajectory point,
+// so that a sample's searches are spread over eight wavefronts instead of being
+// one long chain in a single one.  Brute-force segment scan (eight lanes per
+// point), block search around the query cell, same arithmetic and the same
+// results as sample_cost_kernel; the host picks the kernel from the admissible
+// count of the previous cycle.
+// ---------------------------------------------------------------------------
+constexpr int kBlkCostBlock = 512;  // 8 wavefronts, two workgroups per CU
+constexpr size_t kBlkLdsBudget = 78 * 1024;
 template <bool kLds, bool kObsLds>
-__global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) {
+__global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(CostArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   float *s_mind = reinterpret_cast<float *>(smem);               // [P]
   float *s_px = s_mind + a.P;                                    // [P]
@@ -777,10 +795,7 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
   __shared__ unsigned long long s_obest;  // sample-wide min squared obstacle distance (double bits)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
-  KC_STAMP(0);
-  KC_STAMP_CLK(13);
-  const int na = static_cast<int>(*a.adm_count);
-  KC_STAMP(1);
+    const int na = static_cast<int>(*a.adm_count);
   // blocks beyond the admissible count have nothing to do and take no ticket
   const unsigned working = static_cast<unsigned>(min(static_cast<int>(gridDim.x), max(na, 1)));
   if (blockIdx.x >= working) {
@@ -812,18 +827,18 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
     if (a.use_seg) {
       // the five rows are contiguous in global memory too (d_seg)
 #pragma unroll 4
-      for (int j = threadIdx.x; j < 5 * a.S; j += kCostBlock) l_seg[j] = a.sx[j];
+      for (int j = threadIdx.x; j < 5 * a.S; j += kBlkCostBlock) l_seg[j] = a.sx[j];
     }
     if (a.use_obs) {
 #pragma unroll 4
-      for (int j = threadIdx.x; j <= ncell; j += kCostBlock) l_cells[j] = b.cell_start[j];
+      for (int j = threadIdx.x; j <= ncell; j += kBlkCostBlock) l_cells[j] = b.cell_start[j];
       // the skip table is padded to a multiple of 4 bytes on the host
       const uint32_t *gs = reinterpret_cast<const uint32_t *>(b.skip);
       uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
-      for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kCostBlock) ls[j] = gs[j];
+      for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kBlkCostBlock) ls[j] = gs[j];
       if (kObsLds) {
 #pragma unroll 4
-        for (int j = threadIdx.x; j < b.nobs; j += kCostBlock) {
+        for (int j = threadIdx.x; j < b.nobs; j += kBlkCostBlock) {
           l_obs[j] = b.bx[j];
           l_obs[b.nobs + j] = b.by[j];
         }
@@ -839,17 +854,16 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
       s_px[threadIdx.x] = a.px[(size_t)n * a.P + threadIdx.x];
       s_py[threadIdx.x] = a.py[(size_t)n * a.P + threadIdx.x];
     }
-    for (int k = kCostBlock + threadIdx.x; k < a.P; k += kCostBlock) {
+    for (int k = kBlkCostBlock + threadIdx.x; k < a.P; k += kBlkCostBlock) {
       s_px[k] = a.px[(size_t)n * a.P + k];
       s_py[k] = a.py[(size_t)n * a.P + k];
     }
     __syncthreads();  // also covers the structure copy above
-    KC_STAMP(6);
     // ---- eight lanes per trajectory point (64 points per pass) ----------------
     // Idle groups (beyond P) work on a clamped point and write nothing, so
     // the cross-lane steps always see active lanes.
     const int sub = threadIdx.x & 7;
-    for (int p0 = 0; p0 < a.P; p0 += kCostBlock / 8) {
+    for (int p0 = 0; p0 < a.P; p0 += kBlkCostBlock / 8) {
       const int pp = p0 + (threadIdx.x >> 3);
       const bool live = pp < a.P;
       const int p = live ? pp : a.P - 1;
@@ -869,7 +883,6 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
             arg = j;
           }
         }
-        if (p0 == 0) KC_STAMP(9);
         // non-negative floats order like their bit patterns; ties go to the
         // lowest segment index (the reference's strict `<` in index order)
         const uint32_t mine = __float_as_uint(best);
@@ -877,7 +890,6 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
         arg = static_cast<int>(
             group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
         best = __uint_as_float(mbits);
-        if (p0 == 0) KC_STAMP(10);
         if (sub == 0 && live) {
           s_mind[p] = kc::sqrt_rn(best);
           if (p == a.P - 1) {
@@ -892,7 +904,6 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
           }
         }
       }
-      if (p0 == 0) KC_STAMP(8);
       if (a.use_obs) {
         // query cell (clamped: a query outside the grid searches from the
         // border and the guarantee radius shrinks by its distance to the grid)
@@ -953,11 +964,8 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
           m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
         }
       }
-      if (p0 == 0) KC_STAMP(7);
     }
     __syncthreads();
-    KC_STAMP(2);
-    KC_STAMP_CLK(14);
     // ---- wavefront 0: weighted total of this sample ---------------------------
     if (wave == 0) {
       float total = 0.0f;
@@ -1027,10 +1035,318 @@ __global__ __launch_bounds__(kCostBlock, 4) void sample_cost_kernel(CostArgs a) 
       }
     }
     __syncthreads();  // LDS minima are reused by the next sample
-    KC_STAMP(3);
   }
 
   // ---- block epilogue: the block's best key, for publish_kernel ----------------
+  if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
+}
+
+
+// kLds: the tracked segment (+ chunk spheres), the bucket cell table and the
+// skip table are copied into LDS once per workgroup; kObsLds: the obstacle
+// coordinates too.  Otherwise they are read in place.
+template <bool kLds, bool kObsLds>
+__global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ long long s_key;
+  __shared__ unsigned long long s_obest[kCostWaves];  // per sample: min squared obstacle distance (double bits)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
+  KC_STAMP(0);
+  const int na = static_cast<int>(*a.adm_count);
+  KC_STAMP(1);
+  const BucketDev &b = a.b;
+  const int ncell = b.W * b.H;
+  const int seg_words = a.use_seg ? 5 * a.S + 4 * a.nch : 0;
+  // LDS layout: segment rows + chunk spheres | cell table | skip table (padded
+  // to words) | obstacle coordinates.  The pointers are chosen at compile time
+  // so that the LDS variants issue ds_read, not flat loads.
+  float *const l_seg = reinterpret_cast<float *>(smem);
+  int *const l_cells = reinterpret_cast<int *>(l_seg + seg_words);
+  uint8_t *const l_skip = reinterpret_cast<uint8_t *>(l_cells + (a.use_obs ? ncell + 1 : 0));
+  float *const l_obs = reinterpret_cast<float *>(l_skip + (a.use_obs ? ((ncell + 3) & ~3) : 0));
+  const int *const cells = kLds ? l_cells : b.cell_start;
+  const uint8_t *const skip = kLds ? l_skip : b.skip;
+  const float *const obx = kObsLds ? l_obs : b.bx;
+  const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
+  const float *const sg = kLds ? l_seg : a.sx;
+  const float *const sx = sg, *const sy = sg + a.S, *const sz = sg + 2 * a.S,
+              *const szz = sg + 3 * a.S, *const sacc = sg + 4 * a.S;
+  const float *const ccx = sg + 5 * a.S, *const ccy = ccx + a.nch, *const ccz = ccy + a.nch,
+              *const ccr = ccz + a.nch;
+  if (threadIdx.x == 0) s_key = KEY_NONE;
+  if (na > 0 && kLds) {
+#pragma unroll 8
+    for (int j = threadIdx.x; j < seg_words; j += kCostBlock) l_seg[j] = a.sx[j];
+    if (a.use_obs) {
+#pragma unroll 8
+      for (int j = threadIdx.x; j <= ncell; j += kCostBlock) l_cells[j] = b.cell_start[j];
+      // the skip table is padded to a multiple of 4 bytes on the host
+      const uint32_t *gs = reinterpret_cast<const uint32_t *>(b.skip);
+      uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
+      for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kCostBlock) ls[j] = gs[j];
+      if (kObsLds) {
+#pragma unroll 8
+        for (int j = threadIdx.x; j < 2 * b.nobs; j += kCostBlock) l_obs[j] = b.bx[j];  // bx | by contiguous
+      }
+    }
+  }
+  __syncthreads();
+  KC_STAMP(6);
+
+  long long wkey = KEY_NONE;
+  // sample i of the list goes to wavefront (i / grid) of workgroup (i % grid):
+  // a short list spreads over all CUs, one wavefront each
+  for (int i = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); i < na;
+       i += kCostWaves * static_cast<int>(gridDim.x)) {
+    const int n = a.adm_list[i];
+    if (lane == 0) s_obest[wave] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
+    float sum = 0.0f;            // ordered path-cost sum, carried over the point tiles
+    float goal = 0.0f, endc = 0.0f;
+    for (int p0 = 0; p0 < a.P; p0 += 64) {
+      const int pp = p0 + lane;
+      const bool live = pp < a.P;
+      const int p = live ? pp : a.P - 1;  // idle lanes shadow the last point, write nothing
+      const float x = a.px[(size_t)n * a.P + p], y = a.py[(size_t)n * a.P + p];
+      float mind = 0.0f, goal_l = 0.0f, end_l = 0.0f;
+      const bool st = a.dbg && i == static_cast<int>(blockIdx.x) && p0 == 0;  // first sample of wavefront 0
+      if (st) KC_STAMP(7);
+      if (a.use_seg) {
+        float best = FLT_MAX;
+        int arg = 0;
+        // (1) the first point of every chunk: ascending index, strict `<`
+#pragma unroll 8
+        for (int c = 0; c < a.nch; ++c) {
+          const int j = c * a.seg_chunk;
+          const float dx = sx[j] - x;
+          const float dy = sy[j] - y;
+          const float xx = dx * dx;
+          const float yy = dy * dy;
+          const float dd = xx + (yy + szz[j]);  // Eigen order a + (b + c)
+          if (dd < best) {
+            best = dd;
+            arg = j;
+          }
+        }
+        if (st) KC_STAMP(8);
+        // (2) chunks that may hold something at least as close: |q - c| - r <= thr,
+        // tested on the squares (no square root per chunk); 1e-4 relative slack
+        // on the bound, 1e-5 on the compared square
+        const float thr = __builtin_sqrtf(best) * 1.0001f;
+        unsigned long long cand = 0ull;
+#pragma unroll 8
+        for (int c = 0; c < a.nch; ++c) {
+          const float dx = ccx[c] - x, dy = ccy[c] - y, dz = ccz[c];
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          const float lim = thr + ccr[c];
+          // qualifies unless provably farther (NaN compares false: qualifies)
+          if (!(d2 > lim * lim * 1.00001f)) cand |= 1ull << c;
+        }
+        if (st) KC_STAMP(9);
+        // (3) the remaining points of those chunks
+        while (cand) {
+          const int c = __ffsll(static_cast<long long>(cand)) - 1;
+          cand &= cand - 1ull;
+          const int j0 = c * a.seg_chunk;
+          const int j1 = min(j0 + a.seg_chunk, a.S);
+          // five points per batch: their LDS reads are in flight together
+          for (int jb = j0 + 1; jb < j1; jb += 5) {
+            float vx[5], vy[5], vz[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+              const int j = min(jb + u, j1 - 1);
+              vx[u] = sx[j];
+              vy[u] = sy[j];
+              vz[u] = szz[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+              const int j = jb + u;
+              const float dx = vx[u] - x;
+              const float dy = vy[u] - y;
+              const float xx = dx * dx;
+              const float yy = dy * dy;
+              const float dd = xx + (yy + vz[u]);
+              if (j < j1 && (dd < best || (dd == best && j < arg))) {
+                best = dd;
+                arg = j;
+              }
+            }
+          }
+        }
+        if (st) KC_STAMP(10);
+        mind = kc::sqrt_rn(best);
+        if (pp == a.P - 1) {
+          // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
+          const float arc = kc::div_rn(a.ref_len - sacc[arg], a.ref_len);
+          goal_l = arc + kc::div_rn(mind, a.ref_len);
+          // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
+          const int e = a.S - 1;
+          const float dx = x - sx[e], dy = y - sy[e], dz = 0.0f - sz[e];
+          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+          end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
+        }
+      }
+      if (st) KC_STAMP(11);
+      if (a.use_obs) {
+        // query cell (clamped: a query outside the grid searches from the
+        // border and the guarantee radius shrinks by its distance to the grid)
+        const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+        const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+        int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+        double off = 0.0;
+        if (fx < 0.0) off = fmax(off, -fx);
+        if (fy < 0.0) off = fmax(off, -fy);
+        if (fx > b.W) off = fmax(off, fx - b.W);
+        if (fy > b.H) off = fmax(off, fy - b.H);
+        cx = min(max(cx, 0), b.W - 1);
+        cy = min(max(cy, 0), b.H - 1);
+        const int mmax = max(b.W, b.H);
+        const int sk = static_cast<int>(skip[cy * b.W + cx]);
+        // cells closer (Chebyshev) than sk are empty: the first ring is sk, and
+        // nothing is closer than (sk - 1 - off) cells
+        int pm = sk - 1;           // half-width of the block known to be empty / visited
+        int m = max(1, sk);
+        double best = DBL_MAX;
+        bool active = live && !(isnan(fx) || isnan(fy));
+        if ((static_cast<double>(pm) - off) * b.g >= b.cap) active = false;  // all of it costs 0
+        while (__ballot(active)) {
+          if (active) {
+            const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+            const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+            for (int row = y0; row <= y1; ++row) {
+              // rows inside the visited block only add the two side runs
+              const bool inner = pm >= 0 && row >= cy - pm && row <= cy + pm;
+              int beg = cells[row * b.W + x0];
+              int end = inner ? cells[row * b.W + max(cx - pm, x0)]
+                              : cells[row * b.W + x1 + 1];
+              for (int pass = 0; pass < 2; ++pass) {
+                for (int jb = beg; jb < end; jb += 4) {
+                  float ox[4], oy[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    const int j = min(jb + u, end - 1);  // repeats of the last one change nothing
+                    ox[u] = obx[j];
+                    oy[u] = oby[j];
+                  }
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) {
+                    const double dx = static_cast<double>(ox[u] - x);
+                    const double dy = static_cast<double>(oy[u] - y);
+                    const double dd = dx * dx + dy * dy;
+                    best = dd < best ? dd : best;
+                  }
+                }
+                if (!inner) break;
+                beg = cells[row * b.W + min(cx + pm, x1) + 1];
+                end = cells[row * b.W + x1 + 1];
+              }
+            }
+            atomicMin(&s_obest[wave], static_cast<unsigned long long>(__double_as_longlong(best)));
+          }
+          // (all lanes: the LDS queue of a wavefront is in order, the read sees every lane's minimum)
+          const double shared = __longlong_as_double(static_cast<long long>(
+              *const_cast<volatile unsigned long long *>(&s_obest[wave])));
+          if (active) {
+            // every obstacle closer than `reach` (true distance) was visited
+            const double reach = (static_cast<double>(m) - off) * b.g;
+            bool done = m >= mmax;  // whole grid visited
+            if (reach > 0.0) {
+              const double r2 = reach * reach * (1.0 - 1e-6);
+              if (shared < r2) done = true;
+              if (reach >= b.cap) done = true;
+            }
+            if (done) {
+              active = false;
+            } else {
+              // next half-width: enough cells to cover sqrt(shared) (+ guard),
+              // or the cap radius when nothing has been found yet (any
+              // over-estimate only visits more cells: float sqrt is enough)
+              const double need =
+                  shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
+                                   : b.cap;
+              const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
+              pm = m;
+              m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
+            }
+          }
+        }
+      }
+      if (st) KC_STAMP(12);
+      // ordered path-cost sum of this tile (pathCostFunc, cost_evaluator.cpp:111-141)
+      if (a.use_seg) {
+        const int cnt = min(64, a.P - p0);
+        for (int k = 0; k < cnt; ++k) sum += lane_value(mind, k);
+        if (p0 + 64 >= a.P) {
+          goal = lane_value(goal_l, a.P - 1 - p0);
+          endc = lane_value(end_l, a.P - 1 - p0);
+        }
+      }
+    }
+    // ---- weighted total (uniform over the wavefront) ---------------------------
+    float total = 0.0f;
+    if (a.ref_len > 0.0f) {
+      if (a.w_goal > 0.0) total = accum(total, a.w_goal, goal);
+      if (a.w_path > 0.0) {
+        const float c = kc::div_rn(
+            kc::div_rn(sum, static_cast<float>(a.P)) + endc, 2.0f);
+        total = accum(total, a.w_path, c);
+      }
+    }
+    if (a.O > 0 && a.w_obs > 0.0) {
+      // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
+      const double best = __longlong_as_double(static_cast<long long>(
+          *const_cast<volatile unsigned long long *>(&s_obest[wave])));
+      const float min_d2 = static_cast<float>(best);
+      const float dist =
+          static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
+      float v = a.max_obs_dist - dist;
+      v = v < 0.0f ? 0.0f : v;
+      total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
+    }
+    if (a.have_vel) {
+      // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
+      // evaluated redundantly by every lane (wave-uniform addresses)
+      const int nv = a.P - 1;
+      const float *vx = a.vvx + (size_t)n * nv;
+      const float *vy = a.vvy + (size_t)n * nv;
+      const float *om = a.vom + (size_t)n * nv;
+      const float div = static_cast<float>(3L * nv);
+      if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
+        float c = 0.0f;
+        for (int k = 1; k < nv; ++k) {
+          if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
+          if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
+          if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
+        }
+        total = accum(total, a.w_smooth, kc::div_rn(c, div));
+      }
+      if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
+        float c = 0.0f;
+        for (int k = 2; k < nv; ++k) {
+          if (a.acc0 > 0)
+            c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
+          if (a.acc1 > 0)
+            c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
+          if (a.acc2 > 0)
+            c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
+        }
+        total = accum(total, a.w_jerk, kc::div_rn(c, div));
+      }
+    }
+    // constant-velocity samples: both terms are exactly 0 and `total += w*0`
+    // leaves total unchanged, so nothing to do when !have_vel.
+    if (lane == 0) a.costs[n] = total;
+    if (a.dbg && i == static_cast<int>(blockIdx.x)) KC_STAMP(3);
+    if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
+      const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
+      wkey = k < wkey ? k : wkey;
+    }
+  }
+  KC_STAMP(2);
+  // ---- the workgroup's best key, for publish_kernel ----------------------------
+  if (lane == 0 && wkey != KEY_NONE) atomicMin(&s_key, wkey);
+  __syncthreads();
   if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
   KC_STAMP(4);
 }
@@ -1230,6 +1546,9 @@ struct kc_dwa {
   bool perm_valid = false;
   bool early_launch = true;             // fused kernel queued before the trig table exists
   long long trig_seq = 0;
+  int seg_chunk = kSegChunkMin, seg_nch = 0;  // chunking of the tracked segment (cost kernel)
+  long long last_nadm = -1;             // admissible count of the previous cycle (kernel choice)
+  int cost_kernel_force = 0;            // 1: workgroup-per-sample, 2: wavefront-per-sample (KC_COST_KERNEL)
   bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
   bool cost_lds_ok = false;             // sample_cost_kernel<true> may take kCostLdsBudget
   int fused_samples = 32, fused_block = 1024;
@@ -1768,6 +2087,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.sz = seg + 2 * S;
   ca.szz = seg + 3 * S;
   ca.acc_seg = seg + 4 * S;
+  ca.seg_chunk = c->seg_chunk;
+  ca.nch = c->seg_nch;
   ca.seg_len = c->seg_len;
   ca.ref_len = c->ref_len;
   ca.b = c->bucket;
@@ -1792,32 +2113,54 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     KC_HIP(hipMemsetAsync(c->d_dbg.p, 0, 512 * 16 * 8, s));
     ca.dbg = c->d_dbg.p;
   }
-  // one workgroup per admissible sample (grid-stride over the device-side
-  // list); the search structures go to LDS when they fit
-  const unsigned cost_blocks = static_cast<unsigned>(std::min<size_t>(n, 512));
-  size_t lds = P * 3 * sizeof(float);
+  // Short admissible lists (the count of the previous cycle is the predictor)
+  // go to the workgroup-per-sample kernel, long ones to the wavefront-per-
+  // sample kernel; both are correct for any list.
+  bool use_block = c->last_nadm >= 0 && c->last_nadm <= kBlockKernelMaxAdm;
+  if (c->cost_kernel_force == 1) use_block = true;
+  if (c->cost_kernel_force == 2) use_block = false;
+  unsigned cost_blocks;
   size_t lds_tab = 0, lds_obs = 0;
-  if (ca.use_seg) lds_tab += 5 * S * sizeof(float);
   if (ca.use_obs) {
     const size_t ncell = static_cast<size_t>(ca.b.W) * ca.b.H;
     lds_tab += (ncell + 1) * sizeof(int) + ((ncell + 3) & ~size_t(3));
     lds_obs = 2 * static_cast<size_t>(ca.b.nobs) * sizeof(float);
   }
-  const bool tab_lds = c->cost_lds_ok && lds + lds_tab + 64 <= kCostLdsBudget;
-  const bool obs_lds = tab_lds && ca.use_obs && lds + lds_tab + lds_obs + 64 <= kCostLdsBudget;
-  if (c->debug_stamps && c->seq <= 2)
-    std::fprintf(stderr, "[kc] cost kernel: base=%zu tables=%zu obstacles=%zu nobs=%d grid=%dx%d S=%zu tab_lds=%d obs_lds=%d\n",
-                 lds, lds_tab, lds_obs, ca.b.nobs, ca.b.W, ca.b.H, S, int(tab_lds), int(obs_lds));
   KC_TRY(c->timing.start("sample_cost_kernel", s));
-  if (obs_lds)
-    hipLaunchKernelGGL((sample_cost_kernel<true, true>), dim3(cost_blocks), dim3(kCostBlock),
-                       lds + lds_tab + lds_obs, s, ca);
-  else if (tab_lds)
-    hipLaunchKernelGGL((sample_cost_kernel<true, false>), dim3(cost_blocks), dim3(kCostBlock),
-                       lds + lds_tab, s, ca);
-  else
-    hipLaunchKernelGGL((sample_cost_kernel<false, false>), dim3(cost_blocks), dim3(kCostBlock),
-                       lds, s, ca);
+  if (use_block) {
+    cost_blocks = static_cast<unsigned>(std::min<size_t>(n, 512));
+    size_t lds = (P * 3 * sizeof(float) + 15) & ~size_t(15);
+    if (ca.use_seg) lds_tab += 5 * S * sizeof(float);
+    const bool tab_lds = c->cost_lds_ok && lds + lds_tab + 64 <= kBlkLdsBudget;
+    const bool obs_lds = tab_lds && ca.use_obs && lds + lds_tab + lds_obs + 64 <= kBlkLdsBudget;
+    if (obs_lds)
+      hipLaunchKernelGGL((sample_cost_block_kernel<true, true>), dim3(cost_blocks),
+                         dim3(kBlkCostBlock), lds + lds_tab + lds_obs, s, ca);
+    else if (tab_lds)
+      hipLaunchKernelGGL((sample_cost_block_kernel<true, false>), dim3(cost_blocks),
+                         dim3(kBlkCostBlock), lds + lds_tab, s, ca);
+    else
+      hipLaunchKernelGGL((sample_cost_block_kernel<false, false>), dim3(cost_blocks),
+                         dim3(kBlkCostBlock), lds, s, ca);
+  } else {
+    // one workgroup per CU, sixteen samples (wavefronts) in flight in each
+    cost_blocks = static_cast<unsigned>(std::min<size_t>(n, kCostGrid));
+    if (ca.use_seg) lds_tab += (5 * S + 4 * static_cast<size_t>(ca.nch)) * sizeof(float);
+    const bool tab_lds = c->cost_lds_ok && lds_tab + 64 <= kCostLdsBudget;
+    const bool obs_lds = tab_lds && ca.use_obs && lds_tab + lds_obs + 64 <= kCostLdsBudget;
+    if (c->debug_stamps && c->seq <= 2)
+      std::fprintf(stderr, "[kc] cost kernel: tables=%zu obstacles=%zu nobs=%d grid=%dx%d S=%zu chunk=%d tab_lds=%d obs_lds=%d\n",
+                   lds_tab, lds_obs, ca.b.nobs, ca.b.W, ca.b.H, S, ca.seg_chunk, int(tab_lds), int(obs_lds));
+    if (obs_lds)
+      hipLaunchKernelGGL((sample_cost_kernel<true, true>), dim3(cost_blocks), dim3(kCostBlock),
+                         lds_tab + lds_obs, s, ca);
+    else if (tab_lds)
+      hipLaunchKernelGGL((sample_cost_kernel<true, false>), dim3(cost_blocks), dim3(kCostBlock),
+                         lds_tab, s, ca);
+    else
+      hipLaunchKernelGGL((sample_cost_kernel<false, false>), dim3(cost_blocks), dim3(kCostBlock),
+                         0, s, ca);
+  }
   KC_TRY(c->timing.stop(s));
   {
     PubArgs pa{};
@@ -1876,6 +2219,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
   if (c->h_result.p[1] < 0)
     KC_FAIL(KC_ERR_HIP, "roll-out kernel gave up waiting for the host's trig table");
   r.n_admissible = c->h_result.p[1];
+  c->last_nadm = r.n_admissible;
   r.n_samples = static_cast<int64_t>(n);
   if (key == KEY_NONE) {
     r.found = 0;
@@ -1958,8 +2302,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
   if ((rc = c->d_result.reserve(R_SLOTS)) ||
       (rc = c->h_result.reserve(R_SLOTS)) ||
       (rc = ensure_cycle_buffers(c, p->max_samples, p->max_points)) ||
-      (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
-      (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16))) ||
+      (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 4 * 64)) ||
+      (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 4 * 64)) ||
       (rc = c->h_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->d_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->h_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
@@ -1985,7 +2329,13 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
                             static_cast<int>(kCostLdsBudget)) == hipSuccess &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(kCostLdsBudget)) == hipSuccess;
+                            static_cast<int>(kCostLdsBudget)) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_block_kernel<true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kBlkLdsBudget)) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_block_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kBlkLdsBudget)) == hipSuccess;
     if (!c->cost_lds_ok) (void)hipGetLastError();
   }
   if (const char *e = std::getenv("KC_FUSED_CFG")) {  // tuning hook: "samples,threads"
@@ -2004,6 +2354,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     c->trig_direct = large_bar != 0;
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
+    if (const char *e = std::getenv("KC_COST_KERNEL"))  // tuning/test hook: "block" | "wave"
+      c->cost_kernel_force = e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0;
     if (const char *e = std::getenv("KC_EARLY_LAUNCH"))
       c->early_launch = e[0] != '0';            // tuning/test hook
   }
@@ -2064,7 +2416,7 @@ void kc_dwa_destroy(kc_dwa *c) {
       }
     }
     std::fprintf(stderr, "[kc stamps] %d working blocks; us since first block start (avg / max):\n", nb);
-    const char *nm[16] = {"start", "count loaded", "points done", "sample done", "ticket", "published", "lds filled", "first point", "p0 seg done", "p0 seg loop", "p0 seg reduce", "-", "-", "", "", ""};
+    const char *nm[16] = {"start", "count loaded", "all samples done", "first sample done", "key written", "-", "lds filled", "s0 points loaded", "s0 seg pass 1", "s0 seg pass 2", "s0 seg pass 3", "s0 seg done", "s0 obstacles done", "", "", ""};
     {
       double mhz = 0; int cnt = 0;
       for (int b = 0; b < 512; ++b) {
@@ -2074,7 +2426,7 @@ void kc_dwa_destroy(kc_dwa *c) {
       }
       std::fprintf(stderr, "  s_memtime ticks per us (start -> points done): %.1f\n", cnt ? mhz / cnt : 0.0);
     }
-    const int order[13] = {0, 1, 6, 9, 10, 8, 11, 12, 7, 2, 3, 4, 5};
+    const int order[13] = {0, 1, 6, 7, 8, 9, 10, 11, 12, 3, 2, 4, 5};
     for (int q = 0; q < 13; ++q) {
       const int k = order[q];
       std::fprintf(stderr, "  %-14s %7.2f / %7.2f\n", nm[k], nb ? sm[k] / nb : 0.0, mx[k]);
@@ -2299,8 +2651,13 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   c->S = S;
   c->ref_len = ref_len;
   if (S == 0) return KC_OK;
-  KC_TRY(c->h_seg.reserve(5 * S));
-  KC_TRY(c->d_seg.reserve(5 * S));
+  // rows [5][S], then bounding spheres of the chunks [4][nch] (cost kernel, step 2)
+  const size_t chunk = std::max<size_t>(kSegChunkMin, (S + 63) / 64);
+  const size_t nch = (S + chunk - 1) / chunk;
+  c->seg_chunk = static_cast<int>(chunk);
+  c->seg_nch = static_cast<int>(nch);
+  KC_TRY(c->h_seg.reserve(5 * S + 4 * nch));
+  KC_TRY(c->d_seg.reserve(5 * S + 4 * nch));
   float *h = c->h_seg.p;
   for (size_t j = 0; j < S; ++j) {
     const float zz = z ? z[j] : 0.0f;
@@ -2310,6 +2667,45 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     h[3 * S + j] = zz * zz;  // (seg.z - 0)^2 of Path::distance
     h[4 * S + j] = acc[j];
   }
+  {
+    float *ccx = h + 5 * S, *ccy = ccx + nch, *ccz = ccy + nch, *ccr = ccz + nch;
+    for (size_t k = 0; k < nch; ++k) {
+      const size_t j0 = k * chunk, j1 = std::min(j0 + chunk, S);
+      double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+      bool finite = true;
+      for (size_t j = j0; j < j1; ++j) {
+        const double p[3] = {h[j], h[S + j], h[2 * S + j]};
+        for (int q = 0; q < 3; ++q) {
+          finite = finite && std::isfinite(p[q]);
+          lo[q] = std::min(lo[q], p[q]);
+          hi[q] = std::max(hi[q], p[q]);
+        }
+      }
+      if (!finite) {  // never skipped
+        ccx[k] = ccy[k] = ccz[k] = 0.0f;
+        ccr[k] = std::numeric_limits<float>::infinity();
+        continue;
+      }
+      // centre stored as float; the radius is taken around the STORED centre
+      // and rounded up with slack for the float evaluation on the device
+      const float fc[3] = {static_cast<float>(0.5 * (lo[0] + hi[0])),
+                           static_cast<float>(0.5 * (lo[1] + hi[1])),
+                           static_cast<float>(0.5 * (lo[2] + hi[2]))};
+      double r = 0.0;
+      for (size_t j = j0; j < j1; ++j) {
+        const double dx = h[j] - static_cast<double>(fc[0]);
+        const double dy = h[S + j] - static_cast<double>(fc[1]);
+        const double dz = h[2 * S + j] - static_cast<double>(fc[2]);
+        r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
+      }
+      const double mag = std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]) + r;
+      ccx[k] = fc[0];
+      ccy[k] = fc[1];
+      ccz[k] = fc[2];
+      ccr[k] = std::nextafter(static_cast<float>(r * (1.0 + 1e-6) + 1e-6 * mag + 1e-30),
+                              std::numeric_limits<float>::infinity());
+    }
+  }
   // View::totalSegmentLength, path.h:85-91
   float len = 0.0f;
   for (size_t j = 0; j + 1 < S; ++j) {
@@ -2318,7 +2714,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     len += std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
   }
   c->seg_len = len;
-  KC_HIP(hipMemcpyAsync(c->d_seg.p, h, 5 * S * sizeof(float),
+  KC_HIP(hipMemcpyAsync(c->d_seg.p, h, (5 * S + 4 * nch) * sizeof(float),
                         hipMemcpyHostToDevice, c->stream));
   return KC_OK;
 }
