@@ -31,6 +31,22 @@ for p in (ROOT, ROOT / "kompass-core_amd"):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass
+    (profiles/*_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE runs of this same
+    command, gfx950 correction applied); None when there is none."""
+    import glob
+    import json as _json
+
+    files = sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_hbm.json")))
+    if not files:
+        return None, None
+    rec = _json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    if not rec:
+        return None, os.path.basename(files[-1])
+    return rec.get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1])
+
+
 def algorithmic_bytes(N, P, map_side, S, O):
     """16 B per trajectory-step (8 B x,y written by the
     roll-out + 8 B read back by the cost pass) + 20 B per sample (12 B velocity
@@ -147,6 +163,7 @@ def controller_bench(args, rank, world, local_rank):
         dom_ms = float(np.mean(kernel_ms[dom]))
         bytes_launch = algorithmic_bytes(count, P, base["map_side"], S, O)
         achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom)
         out = {
             "metric": "trajectory-steps/s", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -165,12 +182,15 @@ def controller_bench(args, rank, world, local_rank):
             "host_phases_ms": {k: float(np.mean(v)) for k, v in host_ms.items()},
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": dom_ms,
-                "note": "VALU/latency-bound path: ~8 MB per cycle (SURVEY 8d); PMC HBM bytes in profiles/",
+                "note": "latency/VALU-bound path: the whole cycle moves ~7 MB (SURVEY 8d); "
+                        "`achieved` prices the cycle's algorithmic bytes against the slowest kernel",
             },
             "winner": {"found": found, "cost": cost, "raw_index": raw},
         }
+        if world == 1:
+            out["extras"] = extras(ctx, inp, P, pose)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(inp, vx, vy, om, pose(args.steps - 1), found, cost, raw, args)
     if use_dist:
@@ -179,6 +199,36 @@ def controller_bench(args, rank, world, local_rank):
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return out
+
+
+def extras(ctx, inp, P, pose):
+    """Not part of `value`: what the per-cycle input updates cost, and the same
+    cycle when every sample is admissible (robot in open space)."""
+    def med(fn, n):
+        ts = []
+        for i in range(n):
+            t0 = time.perf_counter()
+            fn(i)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts) * 1e3)
+
+    pts = np.asarray(inp["points"], dtype=np.float32).reshape(-1, 3)
+    out = {
+        "set_points_ms": med(lambda i: ctx.set_points(inp["state"], inp["points"], inp["max_range"]), 20),
+        "set_tracked_segment_ms": med(lambda i: ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"],
+                                                                         inp["ref_len"]), 20),
+    }
+    far = pts[np.hypot(pts[:, 0], pts[:, 1]) > 10.0]
+    ctx.set_points(inp["state"], far, inp["max_range"])
+    for i in range(20):
+        r = ctx.cycle(pose(i), P)
+    out["open_space"] = {"ms_per_step": med(lambda i: ctx.cycle(pose(i), P), 200),
+                         "n_admissible": int(r.n_admissible), "obstacles": int(len(far)),
+                         "what": "same lattice, obstacles nearer than 10 m removed: every sample admissible"}
+    ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+    r = ctx.cycle(pose(0), P)
+    out["n_admissible"] = int(r.n_admissible)
     return out
 
 

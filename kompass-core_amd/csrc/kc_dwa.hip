@@ -2126,7 +2126,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     lds_tab += (ncell + 1) * sizeof(int) + ((ncell + 3) & ~size_t(3));
     lds_obs = 2 * static_cast<size_t>(ca.b.nobs) * sizeof(float);
   }
-  KC_TRY(c->timing.start("sample_cost_kernel", s));
+  KC_TRY(c->timing.start(use_block ? "sample_cost_block_kernel" : "sample_cost_kernel", s));
   if (use_block) {
     cost_blocks = static_cast<unsigned>(std::min<size_t>(n, 512));
     size_t lds = (P * 3 * sizeof(float) + 15) & ~size_t(15);
