@@ -60,7 +60,9 @@ def controller_bench(args, rank, world, local_rank):
     import sharding
     import synthetic as syn
 
-    use_dist = world > 1
+    # KC_BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL all-reduce on the
+    # device-resident key) with a single rank, e.g. on a one-GPU box
+    use_dist = world > 1 or os.environ.get("KC_BENCH_FORCE_DIST") == "1"
     torch = None
     if use_dist:
         import torch
@@ -342,9 +344,19 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    out = mapper_bench(args) if args.mapper else controller_bench(args, rank, world, local_rank)
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version
+    # banner on stdout when the first communicator comes up) are pointed at stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        out = mapper_bench(args) if args.mapper else controller_bench(args, rank, world, local_rank)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     if rank == 0 and out is not None:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

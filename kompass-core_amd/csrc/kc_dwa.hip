@@ -2116,6 +2116,13 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   // Short admissible lists (the count of the previous cycle is the predictor)
   // go to the workgroup-per-sample kernel, long ones to the wavefront-per-
   // sample kernel; both are correct for any list.
+  if (c->h_pub.p && c->seq > 0) {
+    // callers that never fetch (multi-GPU: the key is all-reduced on the
+    // device) still leave the previous cycle's record in the pinned mirror
+    volatile long long *hp = c->h_pub.p;
+    const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
+    if (w2 == c->seq && w3 == (w0 ^ w1 ^ w2 ^ 0x5bd1e9955bd1e995ll)) c->last_nadm = w1 >> 32;
+  }
   bool use_block = c->last_nadm >= 0 && c->last_nadm <= kBlockKernelMaxAdm;
   if (c->cost_kernel_force == 1) use_block = true;
   if (c->cost_kernel_force == 2) use_block = false;
