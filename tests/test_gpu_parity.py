@@ -281,38 +281,69 @@ def test_full_size_cfg2_properties():
     np.testing.assert_array_equal(o["costs"].view(np.uint32), costs[:64].view(np.uint32))
 
 
-def test_split_path_equals_fused_path(tmp_path):
-    """The split pipeline (roll-out kernel + host-built window bits + pose-parallel
-    collision kernel: spheres, long horizons, windows beyond LDS) must agree with
-    the fused LDS kernel bit for bit.  KC_FORCE_SPLIT=1 selects it in a child
-    process (the switch is read at context creation)."""
+_PATH_SCENARIOS = [
+    # (config, lattice scale, robot shape, dims, variant)
+    ("cfg1", 1.0, syn.CYLINDER, [0.1, 0.4], None),
+    ("cfg2", 0.25, syn.BOX, [0.3, 0.2, 0.4], None),
+    ("cfg3", 0.04, syn.CYLINDER, [0.2, 0.4], None),       # P = 100: two point tiles per wavefront
+    ("cfg2", 0.25, syn.CYLINDER, [0.1, 0.4], "open"),     # every sample admissible
+    ("cfg2", 0.1, syn.CYLINDER, [0.1, 0.4], "longseg"),   # 1600-point segment: chunks of 25
+]
+
+
+def _path_scenario(name, scale, shape, dims, variant, seed=4):
+    inp = syn.make_controller_inputs(name, seed=seed, scale=scale)
+    inp["robot"] = dict(shape=shape, dims=dims)
+    if variant == "open":
+        pts = np.asarray(inp["points"], dtype=np.float32).reshape(-1, 3)
+        inp["points"] = pts[np.hypot(pts[:, 0], pts[:, 1]) > 4.0]
+    if variant == "longseg":
+        seg, acc = syn.straight_segment(1600, 0.005)
+        inp["seg_xyz"], inp["acc_at_seg"] = seg, acc
+    return inp
+
+
+@pytest.mark.parametrize("env", [
+    {"KC_FORCE_SPLIT": "1"},      # roll-out + host window bits + pose-parallel collision + compaction
+    {"KC_COST_KERNEL": "wave"},   # wavefront-per-sample cost kernel for every list
+    {"KC_COST_KERNEL": "block"},  # workgroup-per-sample cost kernel for every list
+    {"KC_TRIG_COPY": "1"},        # trig table through pinned memory + H2D copy, launch after it
+    {"KC_EARLY_LAUNCH": "0"},     # BAR table, but classic order
+], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_alternate_paths_equal_default_path(tmp_path, env):
+    """Every alternative device path (selected by a switch read at context
+    creation, hence a child process) must agree bit for bit with the default
+    path and with the oracle: paths, admissible set, per-sample costs, winner."""
     import os
     import subprocess
     import sys
 
-    out = tmp_path / "split.npz"
+    out = tmp_path / "alt.npz"
+    root = Path(__file__).resolve().parent.parent
     code = f"""
-import sys; sys.path[:0] = [{str(Path(__file__).resolve().parent.parent)!r}, {str(Path(__file__).resolve().parent.parent / 'kompass-core_amd')!r}, {str(Path(__file__).resolve().parent)!r}]
-import numpy as np, kompass_hip as kh, synthetic as syn
+import sys; sys.path[:0] = [{str(root)!r}, {str(root / 'kompass-core_amd')!r}, {str(root / 'tests')!r}]
+import numpy as np, kompass_hip as kh
 from helpers import hip_cycle
+from test_gpu_parity import _PATH_SCENARIOS, _path_scenario
 res = {{}}
-for name, scale, shape, dims in [("cfg1", 1.0, syn.CYLINDER, [0.1, 0.4]), ("cfg2", 0.25, syn.BOX, [0.3, 0.2, 0.4])]:
-    inp = syn.make_controller_inputs(name, seed=4, scale=scale)
-    inp["robot"] = dict(shape=shape, dims=dims)
-    h = hip_cycle(kh, inp)
-    res[name + "_px"] = h["px"]; res[name + "_raw"] = h["raw"]; res[name + "_costs"] = h["costs"]
-    res[name + "_idx"] = np.int64(h["res"]["index"])
+for k, sc in enumerate(_PATH_SCENARIOS):
+    h = hip_cycle(kh, _path_scenario(*sc))
+    h2 = hip_cycle(kh, _path_scenario(*sc))  # second context: same answer again
+    assert np.array_equal(h["costs"].view(np.uint32), h2["costs"].view(np.uint32))
+    res[f"{{k}}_px"] = h["px"]; res[f"{{k}}_raw"] = h["raw"]; res[f"{{k}}_costs"] = h["costs"]
+    res[f"{{k}}_idx"] = np.int64(h["res"]["index"])
 np.savez({str(out)!r}, **res)
 """
-    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, KC_FORCE_SPLIT="1"), timeout=240)
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, **env), timeout=300)
     got = np.load(out)
-    for name, scale, shape, dims in [("cfg1", 1.0, syn.CYLINDER, [0.1, 0.4]), ("cfg2", 0.25, syn.BOX, [0.3, 0.2, 0.4])]:
-        inp = syn.make_controller_inputs(name, seed=4, scale=scale)
-        inp["robot"] = dict(shape=shape, dims=dims)
+    for k, sc in enumerate(_PATH_SCENARIOS):
+        inp = _path_scenario(*sc)
         h = hip_cycle(kh, inp)
         o = oracle_cycle(inp)
         assert_cycle_equal(o, h)
-        np.testing.assert_array_equal(got[name + "_raw"], h["raw"])
-        np.testing.assert_array_equal(got[name + "_px"].view(np.uint32), h["px"].view(np.uint32))
-        np.testing.assert_array_equal(got[name + "_costs"].view(np.uint32), h["costs"].view(np.uint32))
-        assert int(got[name + "_idx"]) == h["res"]["index"]
+        if sc[4] == "open":
+            assert len(h["raw"]) == len(inp["vx"])  # nothing dropped
+        np.testing.assert_array_equal(got[f"{k}_raw"], h["raw"])
+        np.testing.assert_array_equal(got[f"{k}_px"].view(np.uint32), h["px"].view(np.uint32))
+        np.testing.assert_array_equal(got[f"{k}_costs"].view(np.uint32), h["costs"].view(np.uint32))
+        assert int(got[f"{k}_idx"]) == h["res"]["index"]
