@@ -1543,7 +1543,12 @@ struct kc_dwa {
   DevBuf<int32_t> d_prow;
   DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
   std::vector<int32_t> h_perm;
+  double inv_res = 0.0;      // 1.0 / res (octomap resolution_factor)
   bool perm_valid = false;
+  bool bar_dirty = false;    // BAR stores not yet fenced
+  bool update_busy = false;  // an update call queued device work since the last idle point
+  std::vector<int> cell_id, cell_cursor;  // bucketing scratch (reused)
+  std::vector<uint8_t> skip_pad;
   bool early_launch = true;             // fused kernel queued before the trig table exists
   long long trig_seq = 0;
   int seg_chunk = kSegChunkMin, seg_nch = 0;  // chunking of the tracked segment (cost kernel)
@@ -1622,8 +1627,43 @@ inline unsigned blocks_for(size_t n, unsigned per) {
 }
 
 // accept one octree-frame point into the voxel column list
-void add_voxel(kc_dwa *c, float px, float py, float pz) {
-  const double inv = 1.0 / c->res;
+// host -> device for the per-update tables: plain stores through the BAR when
+// the host can address device memory (the stream must not hold readers of
+// `dst`, see quiesce_for_update), else a copy command
+int upload_table(kc_dwa *c, void *dst, const void *src, size_t bytes) {
+  if (bytes == 0) return KC_OK;
+  if (c->trig_direct) {
+    std::memcpy(dst, src, bytes);
+    c->bar_dirty = true;
+    return KC_OK;
+  }
+  KC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return KC_OK;
+}
+// write-combined stores out of the core before anything is launched behind them
+inline void bar_flush(kc_dwa *c) {
+  if (c->bar_dirty) {
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();
+#endif
+    c->bar_dirty = false;
+  }
+}
+// Before the host overwrites per-update tables: nothing queued may still read
+// them.  A cycle whose record the host has seen proves that everything queued
+// before it has finished; work queued since then (dilate_kernel, copies) is
+// tracked by `update_busy`.
+int quiesce_for_update(kc_dwa *c) {
+  if (!c->drained || c->update_busy) {
+    KC_HIP(hipStreamSynchronize(c->stream));
+    c->update_busy = false;
+    c->drained = true;
+  }
+  return KC_OK;
+}
+
+inline void add_voxel(kc_dwa *c, float px, float py, float pz) {
+  const double inv = c->inv_res;
   const double fx = std::floor(inv * static_cast<double>(px));
   const double fy = std::floor(inv * static_cast<double>(py));
   const double fz = std::floor(inv * static_cast<double>(pz));
@@ -1695,9 +1735,10 @@ int upload_voxels(kc_dwa *c) {
     const int cx = c->vox_kx[i] - lox, cy = c->vox_ky[i] - loy;
     c->h_gbits.p[static_cast<size_t>(cy) * c->gwpr + (cx >> 5)] |= 1u << (cx & 31);
   }
-  KC_HIP(hipMemcpyAsync(c->d_gbits.p, c->h_gbits.p, nwords * sizeof(uint32_t),
-                        hipMemcpyHostToDevice, c->stream));
+  KC_TRY(upload_table(c, c->d_gbits.p, c->h_gbits.p, nwords * sizeof(uint32_t)));
+  if (!c->trig_direct) c->update_busy = true;
   if (c->have_dil) {
+    bar_flush(c);  // the kernel below reads the bitmap
     KC_TRY(c->d_ginner.reserve(nwords));
     KC_TRY(c->d_gouter.reserve(nwords));
     DilArgs da{};
@@ -1731,6 +1772,7 @@ int upload_voxels(kc_dwa *c) {
     hipLaunchKernelGGL(dilate_kernel, dim3(nb), dim3(256), 0, c->stream, da);
     KC_TRY(c->timing.stop(c->stream));
     KC_HIP(hipGetLastError());
+    c->update_busy = true;
   }
   c->have_gbits = true;
   return KC_OK;
@@ -1789,8 +1831,9 @@ int upload_obstacles(kc_dwa *c, size_t n) {
   b.inv_g = 1.0 / b.g;
   b.gx0 = lox;
   b.gy0 = loy;
-  b.W = std::min(kMaxSide, static_cast<int>(std::floor((hix - lox) * b.inv_g)) + 1);
-  b.H = std::min(kMaxSide, static_cast<int>(std::floor((hiy - loy) * b.inv_g)) + 1);
+  // (the quotients are >= 0 and far below 2^31: truncation is floor)
+  b.W = std::min(kMaxSide, static_cast<int>((hix - lox) * b.inv_g) + 1);
+  b.H = std::min(kMaxSide, static_cast<int>((hiy - loy) * b.inv_g) + 1);
   const size_t ncell = static_cast<size_t>(b.W) * b.H;
   KC_TRY(c->h_cells.reserve(ncell + 1));
   KC_TRY(c->d_cells.reserve(ncell + 1));
@@ -1798,64 +1841,70 @@ int upload_obstacles(kc_dwa *c, size_t n) {
   KC_TRY(c->d_bobs.reserve(2 * nf));
   int *cs = c->h_cells.p;
   std::fill(cs, cs + ncell + 1, 0);
-  auto cell_of = [&](size_t i) {
-    int cx = static_cast<int>(std::floor((static_cast<double>(ox[i]) - b.gx0) * b.inv_g));
-    int cy = static_cast<int>(std::floor((static_cast<double>(oy[i]) - b.gy0) * b.inv_g));
+  // one pass for the cell of every point (-1: not finite), one for the scatter
+  c->cell_id.resize(n);
+  int *cid = c->cell_id.data();
+  for (size_t i = 0; i < n; ++i) {
+    if (!std::isfinite(ox[i]) || !std::isfinite(oy[i])) {
+      cid[i] = -1;
+      continue;
+    }
+    int cx = static_cast<int>((static_cast<double>(ox[i]) - b.gx0) * b.inv_g);
+    int cy = static_cast<int>((static_cast<double>(oy[i]) - b.gy0) * b.inv_g);
     cx = std::min(std::max(cx, 0), b.W - 1);
     cy = std::min(std::max(cy, 0), b.H - 1);
-    return static_cast<size_t>(cy) * b.W + cx;
-  };
-  for (size_t i = 0; i < n; ++i)
-    if (std::isfinite(ox[i]) && std::isfinite(oy[i])) cs[cell_of(i) + 1]++;
+    const int id = cy * b.W + cx;
+    cid[i] = id;
+    cs[id + 1]++;
+  }
   for (size_t k = 0; k < ncell; ++k) cs[k + 1] += cs[k];
-  std::vector<int> cursor(cs, cs + ncell);
+  c->cell_cursor.assign(cs, cs + ncell);
+  int *cursor = c->cell_cursor.data();
   float *bx = c->h_bobs.p, *by = c->h_bobs.p + nf;
   for (size_t i = 0; i < n; ++i) {
-    if (!std::isfinite(ox[i]) || !std::isfinite(oy[i])) continue;
-    const int dst = cursor[cell_of(i)]++;
+    if (cid[i] < 0) continue;
+    const int dst = cursor[cid[i]]++;
     bx[dst] = ox[i];
     by[dst] = oy[i];
   }
   // Chebyshev distance transform of the non-empty cells (two chamfer passes
-  // with the 8-neighbourhood are exact for the Chebyshev metric)
+  // with the 8-neighbourhood are exact for the Chebyshev metric); a border of
+  // 255 around the table keeps the inner loops free of range tests
   KC_TRY(c->h_skip.reserve(ncell + 4));
   KC_TRY(c->d_skip.reserve(ncell + 4));
   {
-    uint8_t *sk = c->h_skip.p;
-    const int W = b.W, H = b.H;
-    for (size_t k = 0; k < ncell; ++k) sk[k] = (cs[k + 1] > cs[k]) ? 0 : 255;
-    auto at = [&](int x, int y) -> int { return sk[static_cast<size_t>(y) * W + x]; };
+    const int W = b.W, H = b.H, Wp = W + 2;
+    c->skip_pad.assign(static_cast<size_t>(Wp) * (H + 2), 255);
+    uint8_t *pad = c->skip_pad.data();
     for (int y = 0; y < H; ++y)
       for (int x = 0; x < W; ++x) {
-        int v = at(x, y);
-        if (x > 0) v = std::min(v, at(x - 1, y) + 1);
-        if (y > 0) {
-          v = std::min(v, at(x, y - 1) + 1);
-          if (x > 0) v = std::min(v, at(x - 1, y - 1) + 1);
-          if (x + 1 < W) v = std::min(v, at(x + 1, y - 1) + 1);
-        }
-        sk[static_cast<size_t>(y) * W + x] = static_cast<uint8_t>(std::min(v, 255));
+        const size_t k = static_cast<size_t>(y) * W + x;
+        if (cs[k + 1] > cs[k]) pad[(y + 1) * Wp + x + 1] = 0;
       }
-    for (int y = H - 1; y >= 0; --y)
-      for (int x = W - 1; x >= 0; --x) {
-        int v = at(x, y);
-        if (x + 1 < W) v = std::min(v, at(x + 1, y) + 1);
-        if (y + 1 < H) {
-          v = std::min(v, at(x, y + 1) + 1);
-          if (x + 1 < W) v = std::min(v, at(x + 1, y + 1) + 1);
-          if (x > 0) v = std::min(v, at(x - 1, y + 1) + 1);
-        }
-        sk[static_cast<size_t>(y) * W + x] = static_cast<uint8_t>(std::min(v, 255));
+    for (int y = 1; y <= H; ++y) {
+      uint8_t *r = pad + y * Wp, *u = r - Wp;
+      for (int x = 1; x <= W; ++x) {
+        const int m = std::min(std::min<int>(r[x - 1], u[x]), std::min<int>(u[x - 1], u[x + 1]));
+        if (m + 1 < r[x]) r[x] = static_cast<uint8_t>(m + 1);
       }
+    }
+    for (int y = H; y >= 1; --y) {
+      uint8_t *r = pad + y * Wp, *l = r + Wp;
+      for (int x = W; x >= 1; --x) {
+        const int m = std::min(std::min<int>(r[x + 1], l[x]), std::min<int>(l[x + 1], l[x - 1]));
+        if (m + 1 < r[x]) r[x] = static_cast<uint8_t>(m + 1);
+      }
+    }
+    uint8_t *sk = c->h_skip.p;
+    for (int y = 0; y < H; ++y) std::memcpy(sk + static_cast<size_t>(y) * W, pad + (y + 1) * Wp + 1, W);
   }
   for (size_t k = ncell; k < ncell + 4; ++k) c->h_skip.p[k] = 255;  // word padding
-  KC_HIP(hipMemcpyAsync(c->d_skip.p, c->h_skip.p, ncell + 4, hipMemcpyHostToDevice,
-                        c->stream));
+  KC_TRY(upload_table(c, c->d_skip.p, c->h_skip.p, ncell + 4));
+  KC_TRY(upload_table(c, c->d_cells.p, cs, (ncell + 1) * sizeof(int)));
+  KC_TRY(upload_table(c, c->d_bobs.p, c->h_bobs.p, 2 * nf * sizeof(float)));
+  if (!c->trig_direct) c->update_busy = true;
+  bar_flush(c);
   b.skip = c->d_skip.p;
-  KC_HIP(hipMemcpyAsync(c->d_cells.p, cs, (ncell + 1) * sizeof(int),
-                        hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipMemcpyAsync(c->d_bobs.p, c->h_bobs.p, 2 * nf * sizeof(float),
-                        hipMemcpyHostToDevice, c->stream));
   b.cell_start = c->d_cells.p;
   b.bx = c->d_bobs.p;
   b.by = c->d_bobs.p + nf;
@@ -2285,6 +2334,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     c->height = 2 * c->prm.dims[0];
   }
   c->res = p->octree_res;
+  c->inv_res = 1.0 / c->res;
   hm::Quat q{p->sensor_rot_xyzw[3], p->sensor_rot_xyzw[0],
              p->sensor_rot_xyzw[1], p->sensor_rot_xyzw[2]};
   c->sensor_tf_body = hm::Rigid3f::from_quat(q, p->sensor_pos);
@@ -2579,7 +2629,7 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   if (!c || !st || (n && (!ranges || !angles)))
     KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
-  KC_HIP(hipStreamSynchronize(c->stream));  // staging buffers are reused
+  KC_TRY(quiesce_for_update(c));  // staging buffers and device tables are reused
   // CollisionChecker::updateState + updateSensorData<LaserScan>
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->frame = body * c->sensor_tf_body;
@@ -2616,7 +2666,7 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   if (!c || !st || (n && !xyz)) KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
   const auto dbg_t0 = std::chrono::steady_clock::now();
-  KC_HIP(hipStreamSynchronize(c->stream));
+  KC_TRY(quiesce_for_update(c));
   const auto dbg_t1 = std::chrono::steady_clock::now();
   // updateSensorData<std::vector<Path::Point>>(cloud, global_frame = true)
   c->frame = hm::Rigid3f::identity();
@@ -2626,6 +2676,8 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   const hm::Rigid3f T = c->sensor_tf_body * body;
   KC_TRY(c->h_obs.reserve(2 * std::max<size_t>(n, 1)));
+  c->vox_kx.reserve(n);
+  c->vox_ky.reserve(n);
   for (size_t i = 0; i < n; ++i) {
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     add_voxel(c, x, y, z);
@@ -2654,7 +2706,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
                                float ref_len) {
   if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
-  KC_HIP(hipStreamSynchronize(c->stream));
+  KC_TRY(quiesce_for_update(c));
   c->S = S;
   c->ref_len = ref_len;
   if (S == 0) return KC_OK;
@@ -2721,8 +2773,9 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     len += std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
   }
   c->seg_len = len;
-  KC_HIP(hipMemcpyAsync(c->d_seg.p, h, (5 * S + 4 * nch) * sizeof(float),
-                        hipMemcpyHostToDevice, c->stream));
+  KC_TRY(upload_table(c, c->d_seg.p, h, (5 * S + 4 * nch) * sizeof(float)));
+  if (!c->trig_direct) c->update_busy = true;
+  bar_flush(c);
   return KC_OK;
 }
 
