@@ -326,6 +326,62 @@ def mapper_bench(args):
     }
 
 
+def pointcloud_bench(args):
+    """SURVEY 8f rank 1 (not the default bench line; `--pointcloud`): 1M-point
+    PointCloud2 buffer resident on the device -> 2048-bin laserscan."""
+    import torch
+
+    import kompass_hip as kh
+    from oracle import ko
+
+    n, bins, step = 1_000_000, 2048, 16
+    rng = np.random.default_rng(0)
+    xyz = np.zeros((n, 4), np.float32)
+    xyz[:, 0] = rng.uniform(-30, 30, n)
+    xyz[:, 1] = rng.uniform(-30, 30, n)
+    xyz[:, 2] = rng.uniform(0.0, 1.0, n)
+    host = xyz.reshape(-1).view(np.int8)
+    dev = torch.from_numpy(host.copy()).cuda()
+    torch.cuda.synchronize()
+    ctx = kh.CloudContext(max_bytes=host.size, max_bins=bins)
+    call = lambda: ctx.to_laserscan(None, step, n * step, 1, n, 0, 4, 8, 25.0, 0.0, 1.0, num_bins=bins,
+                                    device_ptr=dev.data_ptr(), nbytes=host.size)
+    for _ in range(args.warmup):
+        got = call()
+    ctx.timing_enable(True)
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        got = call()
+        kms += [ms for name, ms in ctx.timings() if name == "cloud_bins_kernel"]
+    el = time.perf_counter() - t0
+    ctx.timing_enable(False)
+    t1 = time.perf_counter()
+    got_h = ctx.to_laserscan(host, step, n * step, 1, n, 0, 4, 8, 25.0, 0.0, 1.0, num_bins=bins)
+    el_host = time.perf_counter() - t1
+    t2 = time.perf_counter()
+    want = ko.pointcloud_to_laserscan(host, step, n * step, 1, n, 0, 4, 8, 25.0, 0.0, 1.0, num_bins=bins)
+    t_cpu = time.perf_counter() - t2
+    k_ms = float(np.mean(kms))
+    bytes_launch = 12 * n + 8 * bins  # x, y, z of every point read once + one double per bin
+    return {
+        "metric": "points/s", "value": n * args.steps / el, "unit": "points/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 in / f64 ranges", "data": "synthetic",
+        "config": {"workload": f"point cloud -> laserscan: {n} points (16-byte records, device resident), {bins} bins"},
+        "kernels_ms": {"cloud_bins_kernel": k_ms},
+        "roofline": {"bound": "hbm", "kernel": "cloud_bins_kernel", "achieved": bytes_launch / (k_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": k_ms},
+        "pcie_inclusive_ms": 1e3 * el_host,
+        "rebinned_on_host": ctx.last_rebinned(),
+        "cpu_baseline": {"value": n / t_cpu, "unit": "points/s", "cores": 1, "kind": "port",
+                         "sample": f"one {n}-point cloud, {t_cpu * 1e3:.1f} ms"},
+        "matches_cpu": bool(np.array_equal(got.view(np.uint64), want.view(np.uint64))
+                            and np.array_equal(got_h.view(np.uint64), want.view(np.uint64))),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,6 +389,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
     ap.add_argument("--mapper", action="store_true", help="bench the LocalMapper (cfg4) instead")
+    ap.add_argument("--pointcloud", action="store_true", help="SURVEY 8f rank 1 instead of the controller")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -350,7 +407,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        out = mapper_bench(args) if args.mapper else controller_bench(args, rank, world, local_rank)
+        out = (mapper_bench(args) if args.mapper else pointcloud_bench(args) if args.pointcloud
+               else controller_bench(args, rank, world, local_rank))
     finally:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

@@ -260,6 +260,39 @@ int kc_mapper_timing_enable(kc_mapper *ctx, int enable);
 int kc_mapper_timing_get(kc_mapper *ctx, const char **names, float *ms,
                          size_t cap, size_t *count_out);
 
+/* ------------------------------------------------------------------------ */
+/* Raw point cloud -> laserscan                           */
+/* ------------------------------------------------------------------------ */
+typedef struct kc_cloud kc_cloud;
+
+/* scratch for clouds of up to max_bytes bytes / max_bins angular bins (both
+ * grow on demand) */
+int kc_cloud_create(size_t max_bytes, size_t max_bins, int device, kc_cloud **out);
+void kc_cloud_destroy(kc_cloud *ctx);
+/* pointCloudToLaserScanFromRaw (utils/pointcloud.h:116-177: angle_step > 0,
+ * bins = ceil(2 pi / angle_step), angles_out[i] = i * angle_step; and
+ * :205-259: angle_step <= 0, num_bins bins, angles_out may be NULL).  data is
+ * a PointCloud2-style byte buffer (float32 x, y, z at the given byte offsets of
+ * every point_step-byte record; rows row_step bytes apart); data_on_device != 0
+ * means `data` is a device address on ctx's device.  ranges_out[bin] = the
+ * smallest planar distance of the points of that bin that pass the origin and z
+ * filters, max_range where there is none: the same doubles as the reference's
+ * CPU loop (bins from the host libm's atan2f: the device bins every point, the
+ * few within 1e-6 rad of a bin edge are re-binned on the host).  Points with a
+ * non-finite x or y are skipped (the reference indexes out of bounds). */
+int kc_cloud_to_laserscan(kc_cloud *ctx, const int8_t *data, size_t nbytes,
+                          int data_on_device, int point_step, int row_step,
+                          int height, int width, int x_offset, int y_offset,
+                          int z_offset, double max_range, double min_z,
+                          double max_z, double angle_step, int num_bins,
+                          double *ranges_out, double *angles_out, size_t cap,
+                          size_t *bins_out);
+/* points the last call sent back to the host for exact binning */
+int kc_cloud_last_rebinned(kc_cloud *ctx, size_t *count_out);
+int kc_cloud_timing_enable(kc_cloud *ctx, int enable);
+int kc_cloud_timing_get(kc_cloud *ctx, const char **names, float *ms, size_t cap,
+                        size_t *count_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 #include "controllers/dwa.h"
 #include "mapping/local_mapper_gpu.h"
 #include "utils/logger.h"
+#include "utils/pointcloud.h"
 
 namespace py = pybind11;
 using namespace Kompass;
@@ -338,6 +339,13 @@ PYBIND11_MODULE(kompass_cpp, m) {
       .def("scan_to_grid", [gridView](py::object self, const std::vector<double> &angles, const std::vector<double> &ranges) {
              return gridView(self.cast<Mapping::LocalMapper &>().scanToGrid(angles, ranges), self);
            }, "Convert laser scan data to occupancy grid", py::arg("angles"), py::arg("ranges"))
+      .def("scan_to_grid", [gridView](py::object self, const std::vector<int8_t> &data, int point_step, int row_step,
+                                      int height, int width, float x_offset, float y_offset, float z_offset) {
+             return gridView(self.cast<Mapping::LocalMapper &>().scanToGrid(data, point_step, row_step, height, width,
+                                                                           x_offset, y_offset, z_offset), self);
+           }, "Convert a raw point cloud to occupancy grid", py::arg("data"), py::arg("point_step"),
+           py::arg("row_step"), py::arg("height"), py::arg("width"), py::arg("x_offset"), py::arg("y_offset"),
+           py::arg("z_offset"))
       // the reference binds scan_to_grid_baysian to scanToGrid as well
       // (bindings_mapping.cpp:59-75)
       .def("scan_to_grid_baysian", [gridView](py::object self, const std::vector<double> &angles, const std::vector<double> &ranges) {
@@ -351,6 +359,35 @@ PYBIND11_MODULE(kompass_cpp, m) {
            }), py::arg("grid_height"), py::arg("grid_width"), py::arg("resolution"), py::arg("laserscan_position"),
            py::arg("laserscan_orientation"), py::arg("is_pointcloud"), py::arg("scan_size"), py::arg("angle_step"),
            py::arg("max_height"), py::arg("min_height"), py::arg("range_max"), py::arg("max_points_per_line") = 32);
+
+  // ----------------------------------------------------------------- utils
+  // (bindings_utils.cpp:75-118; the CriticalZoneChecker and the PCD reader of
+  // that submodule are outside this build's scope)
+  auto ut = m.def_submodule("utils", "KOMPASS CPP utilities");
+  ut.def("pointcloud_to_laserscan_from_raw",
+         [](const std::vector<int8_t> &data, int point_step, int row_step, int height, int width, int x_offset,
+            int y_offset, int z_offset, double max_range, double min_z, double max_z, double angle_step) {
+           std::vector<double> ranges_out, angles_out;
+           pointCloudToLaserScanFromRaw(data, point_step, row_step, height, width, x_offset, y_offset, z_offset,
+                                        max_range, min_z, max_z, angle_step, ranges_out, angles_out);
+           return std::make_tuple(ranges_out, angles_out);
+         },
+         py::arg("data"), py::arg("point_step"), py::arg("row_step"), py::arg("height"), py::arg("width"),
+         py::arg("x_offset"), py::arg("y_offset"), py::arg("z_offset"), py::arg("max_range"), py::arg("min_z"),
+         py::arg("max_z"), py::arg("angle_step"),
+         "Converts raw PointCloud2 to ranges and angles using a specific angular step.");
+  ut.def("pointcloud_to_laserscan_from_raw",
+         [](const std::vector<int8_t> &data, int point_step, int row_step, int height, int width, int x_offset,
+            int y_offset, int z_offset, double max_range, double min_z, double max_z, int num_bins) {
+           std::vector<double> ranges_out;
+           pointCloudToLaserScanFromRaw(data, point_step, row_step, height, width, x_offset, y_offset, z_offset,
+                                        max_range, min_z, max_z, num_bins, ranges_out);
+           return ranges_out;
+         },
+         py::arg("data"), py::arg("point_step"), py::arg("row_step"), py::arg("height"), py::arg("width"),
+         py::arg("x_offset"), py::arg("y_offset"), py::arg("z_offset"), py::arg("max_range"), py::arg("min_z"),
+         py::arg("max_z"), py::arg("num_bins"),
+         "Converts raw PointCloud2 to ranges only, using a fixed number of bins.");
 
   // ---------------------------------------------------------- module level
   py::enum_<LogLevel>(m, "LogLevel")

@@ -1,8 +1,8 @@
 // laserscan -> occupancy LocalMapper of the kompass_cpp surface (reference:
 // mapping/local_mapper.{h,cpp}).  scanToGrid runs on the device with the CPU
-// mapper's semantics (same cells, bit for bit); the Bayesian update and the
-// raw point-cloud overloads are outside this build's scope (M3,
-// M5) and throw.
+// mapper's semantics (same cells, bit for bit), the raw point-cloud overload
+// bins the cloud on the device first (M5); the Bayesian update is outside this
+// build's scope (M3) and throws.
 #pragma once
 
 #include <cstdint>
@@ -52,6 +52,9 @@ class LocalMapper {
   const int m_maxPointsPerLine;
   const Eigen::Vector3f m_laserscanPosition;
   const int m_scanSize;
+  const float m_maxHeight, m_minHeight;
+  // pointcloud mode (local_mapper.h:38-56): angles i * 2 pi / scanSize
+  std::vector<double> initializedAngles, initializedRanges;
   Eigen::MatrixXi gridData;
   hip::MapperHandle ctx_;
 };

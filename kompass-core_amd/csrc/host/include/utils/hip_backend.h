@@ -29,6 +29,10 @@ struct DwaDeleter {
 struct MapperDeleter {
   void operator()(kc_mapper *p) const { kc_mapper_destroy(p); }
 };
+struct CloudDeleter {
+  void operator()(kc_cloud *p) const { kc_cloud_destroy(p); }
+};
+using CloudHandle = std::unique_ptr<kc_cloud, CloudDeleter>;
 using DwaHandle = std::shared_ptr<kc_dwa>;
 using MapperHandle = std::unique_ptr<kc_mapper, MapperDeleter>;
 
@@ -36,6 +40,12 @@ inline DwaHandle makeDwa(const kc_dwa_params &p) {
   kc_dwa *raw = nullptr;
   check(kc_dwa_create(&p, &raw));
   return DwaHandle(raw, DwaDeleter());
+}
+
+inline CloudHandle makeCloud(size_t max_bytes, size_t max_bins) {
+  kc_cloud *raw = nullptr;
+  check(kc_cloud_create(max_bytes, max_bins, 0, &raw));
+  return CloudHandle(raw);
 }
 
 }  // namespace hip

@@ -1,6 +1,10 @@
 // LocalMapper host side (reference: src/mapping/local_mapper.cpp).
 #include "mapping/local_mapper.h"
 
+#include <cmath>
+
+#include "utils/pointcloud.h"
+
 #include <stdexcept>
 
 namespace Kompass {
@@ -17,12 +21,22 @@ hip::MapperHandle makeMapper(int H, int W, float res, const Eigen::Vector3f &pos
 }  // namespace
 
 LocalMapper::LocalMapper(const int H, const int W, const float res, const Eigen::Vector3f &pos,
-                         const float orient, const bool, const int scanSize, const float,
-                         const float, const float, const float rangeMax, const int maxPointsPerLine,
-                         const int)
+                         const float orient, const bool isPointCloud, const int scanSize, const float,
+                         const float maxHeight, const float minHeight, const float rangeMax,
+                         const int maxPointsPerLine, const int)
     : m_gridHeight(H), m_gridWidth(W), m_resolution(res), m_laserscanOrientation(orient),
       m_rangeMax(rangeMax), m_maxPointsPerLine(maxPointsPerLine), m_laserscanPosition(pos),
-      m_scanSize(scanSize), gridData(H, W), ctx_(makeMapper(H, W, res, pos, orient, scanSize)) {}
+      m_scanSize(scanSize), m_maxHeight(maxHeight), m_minHeight(minHeight), gridData(H, W),
+      ctx_(makeMapper(H, W, res, pos, orient, scanSize)) {
+  if (isPointCloud) {
+    // local_mapper.h:38-56: the angle step is derived from the scan size so
+    // that binning and ray casting see the same grid
+    const double derived_step = (2.0 * M_PI) / static_cast<double>(scanSize);
+    initializedAngles.resize(std::max(scanSize, 0));
+    initializedRanges.resize(std::max(scanSize, 0));
+    for (int i = 0; i < scanSize; ++i) initializedAngles[i] = i * derived_step;
+  }
+}
 
 LocalMapper::LocalMapper(const int H, const int W, const float res, const Eigen::Vector3f &pos,
                          const float orient, const bool isPointCloud, const int scanSize,
@@ -39,11 +53,16 @@ Eigen::MatrixXi &LocalMapper::scanToGrid(const std::vector<double> &angles,
   return gridData;
 }
 
-Eigen::MatrixXi &LocalMapper::scanToGrid(const std::vector<int8_t> &, int, int, int, int, float,
-                                         float, float) {
-  throw std::runtime_error(
-      "LocalMapper::scanToGrid(raw point cloud): the pointcloud -> laserscan step is outside "
-      "this build's scope (SURVEY.md 8f rank 1)");
+// local_mapper.cpp:243-251
+Eigen::MatrixXi &LocalMapper::scanToGrid(const std::vector<int8_t> &data, int point_step,
+                                         int row_step, int height, int width, float x_offset,
+                                         float y_offset, float z_offset) {
+  if (initializedAngles.empty())
+    throw std::runtime_error("LocalMapper::scanToGrid(raw point cloud): not constructed with is_pointcloud");
+  pointCloudToLaserScanFromRaw(data, point_step, row_step, height, width, static_cast<int>(x_offset),
+                               static_cast<int>(y_offset), static_cast<int>(z_offset), m_rangeMax,
+                               m_minHeight, m_maxHeight, m_scanSize, initializedRanges);
+  return scanToGrid(initializedAngles, initializedRanges);
 }
 std::tuple<Eigen::MatrixXi &, Eigen::MatrixXf &>
 LocalMapper::scanToGridBaysian(const std::vector<double> &, const std::vector<double> &) {

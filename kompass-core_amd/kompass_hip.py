@@ -120,6 +120,14 @@ SIGNATURES = {
     "kc_mapper_sync": (C.c_int, [_vp]),
     "kc_mapper_timing_enable": (C.c_int, [_vp, C.c_int]),
     "kc_mapper_timing_get": (C.c_int, [_vp, C.POINTER(C.c_char_p), _fp, _sz, C.POINTER(_sz)]),
+    "kc_cloud_create": (C.c_int, [_sz, _sz, C.c_int, C.POINTER(_vp)]),
+    "kc_cloud_destroy": (None, [_vp]),
+    "kc_cloud_to_laserscan": (C.c_int, [_vp, C.c_void_p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_double, C.c_int, _dp, _dp, _sz, C.POINTER(_sz)]),
+    "kc_cloud_last_rebinned": (C.c_int, [_vp, C.POINTER(_sz)]),
+    "kc_cloud_timing_enable": (C.c_int, [_vp, C.c_int]),
+    "kc_cloud_timing_get": (C.c_int, [_vp, C.POINTER(C.c_char_p), _fp, _sz, C.POINTER(_sz)]),
 }
 
 _lib = None
@@ -399,4 +407,62 @@ class MapperContext:
         ms = (C.c_float * 16)()
         n = _sz(0)
         _check(lib().kc_mapper_timing_get(self.h, names, ms, 16, C.byref(n)))
+        return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+class CloudContext:
+    """Owner of one kc_cloud context (raw point cloud -> laserscan)."""
+
+    def __init__(self, max_bytes=1 << 20, max_bins=4096, device=0):
+        self.h = _vp()
+        _check(lib().kc_cloud_create(int(max_bytes), int(max_bins), int(device), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().kc_cloud_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def to_laserscan(self, data, point_step, row_step, height, width, x_offset, y_offset, z_offset,
+                     max_range, min_z, max_z, angle_step=None, num_bins=None, device_ptr=None, nbytes=None):
+        """pointCloudToLaserScanFromRaw: (ranges, angles) with angle_step,
+        ranges with num_bins.  `data`: bytes / int8 array on the host, or pass
+        device_ptr + nbytes for a buffer that already lives on the device."""
+        by_step = angle_step is not None
+        nb = int(np.ceil(2.0 * np.pi / angle_step)) if by_step else int(num_bins)
+        cap = max(nb, 1)
+        ranges = np.zeros(cap, np.float64)
+        angles = np.zeros(cap, np.float64)
+        n = _sz(0)
+        if device_ptr is not None:
+            ptr, size, on_dev = int(device_ptr), int(nbytes), 1
+        else:
+            buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.int8)
+                                       if not isinstance(data, np.ndarray) else data.view(np.int8).reshape(-1))
+            ptr, size, on_dev = buf.ctypes.data, buf.size, 0
+        _check(lib().kc_cloud_to_laserscan(self.h, ptr, size, on_dev, int(point_step), int(row_step), int(height),
+                                           int(width), int(x_offset), int(y_offset), int(z_offset),
+                                           float(max_range), float(min_z), float(max_z),
+                                           float(angle_step) if by_step else 0.0, nb, _pd(ranges), _pd(angles),
+                                           cap, C.byref(n)))
+        return (ranges[:n.value], angles[:n.value]) if by_step else ranges[:n.value]
+
+    def last_rebinned(self) -> int:
+        n = _sz(0)
+        _check(lib().kc_cloud_last_rebinned(self.h, C.byref(n)))
+        return n.value
+
+    def timing_enable(self, on=True):
+        _check(lib().kc_cloud_timing_enable(self.h, int(bool(on))))
+
+    def timings(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = _sz(0)
+        _check(lib().kc_cloud_timing_get(self.h, names, ms, 16, C.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]

@@ -160,6 +160,9 @@ def lib():
         "ko_dwa_path": (vp, [vp]),
         "ko_dwa_max_segment_size": (sz, [vp]),
         "ko_dwa_closest_index": (sz, [vp]),
+        "ko_pointcloud_to_laserscan": (C.c_long, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                 C.c_double, C.c_int, _dp, _dp, C.c_size_t]),
         "ko_mapper_scan_to_grid": (C.c_int, [C.c_int, C.c_int, C.c_float, _fp, C.c_float, _dp, _dp,
                                              sz, _ip]),
         "ko_baseline_cycle": (C.c_long, [vp, C.POINTER(CostCtx), C.POINTER(State), C.c_double, sz,
@@ -502,6 +505,26 @@ def scan_to_grid(H, W, res, position, orientation, angles, ranges):
     lib().ko_mapper_scan_to_grid(H, W, float(np.float32(res)), _pf(p), float(np.float32(orientation)),
                                  _pd(a), _pd(r), len(a), _pi(g))
     return g.reshape(W, H).T.copy()  # column-major (i + j*H) -> [i, j]
+
+
+def pointcloud_to_laserscan(data, point_step, row_step, height, width, x_offset, y_offset, z_offset,
+                            max_range, min_z, max_z, angle_step=None, num_bins=None):
+    """pointCloudToLaserScanFromRaw: (ranges, angles) for the angle_step
+    overload, ranges for the num_bins overload."""
+    buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.int8) if not isinstance(data, np.ndarray)
+                               else data.view(np.int8).reshape(-1))
+    by_step = angle_step is not None
+    nb = int(np.ceil(2.0 * np.pi / angle_step)) if by_step else int(num_bins)
+    cap = max(nb, 1)
+    ranges = np.zeros(cap, np.float64)
+    angles = np.zeros(cap, np.float64)
+    n = lib().ko_pointcloud_to_laserscan(buf.ctypes.data, buf.size, point_step, row_step, height, width,
+                                         x_offset, y_offset, z_offset, float(max_range), float(min_z),
+                                         float(max_z), float(angle_step) if by_step else 0.0, nb,
+                                         _pd(ranges), _pd(angles), cap)
+    if n < 0:
+        raise ValueError("invalid point cloud arguments")
+    return (ranges[:n], angles[:n]) if by_step else ranges[:n]
 
 
 def baseline_cycle(coll, ci: CostInputs, start, dt, P, vx, vy, omega, threads=1):

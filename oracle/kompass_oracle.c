@@ -1664,3 +1664,52 @@ long ko_baseline_cycle(ko_coll *coll, const ko_cost_ctx *cx,
   if (n_adm_out) *n_adm_out = na;
   return bi;
 }
+
+
+/* ===========================================================================
+ * M5: pointCloudToLaserScanFromRaw, utils/pointcloud.h:116-177 and :205-259
+ * =========================================================================== */
+long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_step,
+                                int row_step, int height, int width, int x_offset,
+                                int y_offset, int z_offset, double max_range,
+                                double min_z, double max_z, double angle_step,
+                                int num_bins, double *ranges_out,
+                                double *angles_out, size_t cap) {
+  (void)width; /* pointcloud.h:137-138: the loops use row_step / point_step only */
+  const double two_pi = 2.0 * M_PI;
+  const int by_step = angle_step > 0.0;
+  if (point_step <= 0 || row_step < 0 || height < 0 || x_offset < 0 ||
+      y_offset < 0 || z_offset < 0 || !ranges_out)
+    return -1;
+  if (by_step) num_bins = (int)ceil(two_pi / angle_step); /* :124 */
+  if (num_bins <= 0 || (size_t)num_bins > cap) return -1;
+  for (int i = 0; i < num_bins; ++i) { /* :127-132 / :214 */
+    if (by_step && angles_out) angles_out[i] = i * angle_step;
+    ranges_out[i] = max_range;
+  }
+  int max_off = x_offset > y_offset ? x_offset : y_offset;
+  if (z_offset > max_off) max_off = z_offset;
+  for (int row = 0; row < height; ++row) {
+    for (int col = 0; col < row_step; col += point_step) {
+      const size_t point_start = (size_t)row * (size_t)row_step + (size_t)col;
+      if (point_start + (size_t)max_off + sizeof(float) > nbytes) continue; /* :139-146 */
+      float x, y, z;
+      memcpy(&x, data + point_start + x_offset, sizeof(float));
+      memcpy(&y, data + point_start + y_offset, sizeof(float));
+      memcpy(&z, data + point_start + z_offset, sizeof(float));
+      const float xx = x * x, yy = y * y;
+      const float range_sq = xx + yy; /* :153 */
+      if ((double)range_sq < 1e-6) continue;
+      if ((double)z < min_z || (max_z >= 0.0 && (double)z > max_z)) continue; /* :159 */
+      if (!isfinite(x) || !isfinite(y)) continue; /* reference: int(NaN) index, UB */
+      double angle = (double)atan2f(y, x); /* std::atan2(float, float) */
+      if (angle < 0.0) angle += two_pi;
+      int bin = by_step ? (int)(angle / angle_step)            /* :168 */
+                        : (int)((angle / two_pi) * num_bins);  /* :250 */
+      if (bin > num_bins - 1) bin = num_bins - 1;
+      const double distance = (double)sqrtf(range_sq); /* std::sqrt(float) */
+      if (distance < ranges_out[bin]) ranges_out[bin] = distance;
+    }
+  }
+  return num_bins;
+}

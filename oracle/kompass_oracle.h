@@ -246,6 +246,23 @@ int ko_mapper_scan_to_grid(int grid_height, int grid_width, float resolution,
                            float laserscan_orientation, const double *angles,
                            const double *ranges, size_t n, int32_t *grid_out);
 
+/* ---- M5: raw point cloud -> laserscan (CPU semantics) ----------------------- */
+/* utils/pointcloud.h:116-177 (angle_step overload: angle_step > 0, *num_bins is
+ * an output = ceil(2 pi / angle_step), angles_out[i] = i * angle_step) and
+ * :205-259 (num_bins overload: angle_step <= 0, *num_bins is the input,
+ * angles_out may be NULL).  Points are float32 triples at byte offsets inside
+ * `point_step`-byte records; the column loop runs over row_step in steps of
+ * point_step (`width` is not used by the reference either).  Returns the number
+ * of bins, or -1 when cap is too small / arguments are invalid.  Non-finite x
+ * or y make the reference index out of bounds (int(NaN)); here they are
+ * skipped. */
+long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_step,
+                                int row_step, int height, int width, int x_offset,
+                                int y_offset, int z_offset, double max_range,
+                                double min_z, double max_z, double angle_step,
+                                int num_bins, double *ranges_out,
+                                double *angles_out, size_t cap);
+
 /* bounded multi-thread CPU baseline helper: roll-out + costs with `threads`
  * workers over contiguous sample blocks (mirrors the reference ThreadPool
  * scheme, trajectory_sampler.cpp:192-205) -- used only by bench.py. */
