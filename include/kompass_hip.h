@@ -293,6 +293,38 @@ int kc_cloud_timing_enable(kc_cloud *ctx, int enable);
 int kc_cloud_timing_get(kc_cloud *ctx, const char **names, float *ms, size_t cap,
                         size_t *count_out);
 
+/* ------------------------------------------------------------------------ */
+/* CriticalZoneChecker                                    */
+/* ------------------------------------------------------------------------ */
+typedef struct kc_zone kc_zone;
+
+/* CriticalZoneChecker ctor + preset (utils/critical_zone_check.cpp:13-83;
+ * critical_zone_check_gpu.h ctor for the device variant).  shape / dims as in
+ * kc_dwa_params; sensor_rot_xyzw is the Eigen::Vector4f of the reference
+ * ((x, y, z, w), not normalised by the reference either); critical_angle in
+ * degrees; angles = the scan angles the index sets are preset for.
+ * KC_ERR_INVALID when slowdown_distance <= critical_distance (:52-56). */
+int kc_zone_create(int shape, const float *dims, int ndims,
+                   const float sensor_pos[3], const float sensor_rot_xyzw[4],
+                   float critical_angle, float critical_distance,
+                   float slowdown_distance, const double *angles, size_t n,
+                   float min_height, float max_height, float range_max,
+                   int device, kc_zone **out);
+void kc_zone_destroy(kc_zone *ctx);
+/* check(ranges, forward) (:85-117): 0.0 stop, (0, 1) slow-down factor, 1.0 clear;
+ * ranges has one entry per preset angle */
+int kc_zone_check(kc_zone *ctx, const double *ranges, size_t n, int forward,
+                  float *factor_out);
+/* check(raw cloud, forward) (:119-131): cloud -> ranges over the preset number
+ * of bins (kc_cloud_to_laserscan semantics) -> check */
+int kc_zone_check_cloud(kc_zone *ctx, const int8_t *data, size_t nbytes,
+                        int point_step, int row_step, int height, int width,
+                        int x_offset, int y_offset, int z_offset, int forward,
+                        float *factor_out);
+/* the preset index sets (tests / debugging) */
+int kc_zone_indices(kc_zone *ctx, int forward, int64_t *out, size_t cap,
+                    size_t *count_out);
+
 #ifdef __cplusplus
 }
 #endif

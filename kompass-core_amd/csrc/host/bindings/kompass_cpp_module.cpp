@@ -11,6 +11,7 @@
 #include "controllers/dwa.h"
 #include "mapping/local_mapper_gpu.h"
 #include "utils/logger.h"
+#include "utils/critical_zone_check.h"
 #include "utils/pointcloud.h"
 
 namespace py = pybind11;
@@ -361,9 +362,54 @@ PYBIND11_MODULE(kompass_cpp, m) {
            py::arg("max_height"), py::arg("min_height"), py::arg("range_max"), py::arg("max_points_per_line") = 32);
 
   // ----------------------------------------------------------------- utils
-  // (bindings_utils.cpp:75-118; the CriticalZoneChecker and the PCD reader of
-  // that submodule are outside this build's scope)
+  // (bindings_utils.cpp:47-118, bindings_gpu.cpp:40-68; the PCD reader of that
+  // submodule is outside this build's scope)
   auto ut = m.def_submodule("utils", "KOMPASS CPP utilities");
+  {
+    auto czInit = [](auto *tag, CriticalZoneChecker::InputType it, CollisionChecker::ShapeType shape,
+                     const std::vector<float> &dims, const py::object &spos, const py::object &srot, float ca,
+                     float cd, float sd, const std::vector<double> &angles, float minh, float maxh, float rmax) {
+      using T = std::remove_pointer_t<decltype(tag)>;
+      return std::make_unique<T>(it, shape, dims, vec3(spos), vec4(srot), ca, cd, sd, angles, minh, maxh, rmax);
+    };
+    py::class_<CriticalZoneChecker> cz(ut, "CriticalZoneChecker");
+    py::enum_<CriticalZoneChecker::InputType>(cz, "InputType")
+        .value("LASERSCAN", CriticalZoneChecker::InputType::LASERSCAN)
+        .value("POINTCLOUD", CriticalZoneChecker::InputType::POINTCLOUD);
+    py::enum_<PointFieldType>(ut, "PointFieldType")
+        .value("INT8", PointFieldType::INT8).value("UINT8", PointFieldType::UINT8)
+        .value("INT16", PointFieldType::INT16).value("UINT16", PointFieldType::UINT16)
+        .value("INT32", PointFieldType::INT32).value("UINT32", PointFieldType::UINT32)
+        .value("FLOAT32", PointFieldType::FLOAT32).value("FLOAT64", PointFieldType::FLOAT64);
+    cz.def(py::init([czInit](CriticalZoneChecker::InputType it, CollisionChecker::ShapeType shape,
+                             const std::vector<float> &dims, const py::object &spos, const py::object &srot,
+                             float ca, float cd, float sd, const std::vector<double> &angles, float minh,
+                             float maxh, float rmax) {
+             return czInit(static_cast<CriticalZoneChecker *>(nullptr), it, shape, dims, spos, srot, ca, cd, sd,
+                           angles, minh, maxh, rmax);
+           }), py::arg("input_type"), py::arg("robot_shape"), py::arg("robot_dimensions"),
+           py::arg("sensor_position_body"), py::arg("sensor_rotation_body"), py::arg("critical_angle"),
+           py::arg("critical_distance"), py::arg("slowdown_distance"), py::arg("scan_angles"),
+           py::arg("min_height"), py::arg("max_height"), py::arg("range_max"))
+        .def("check", py::overload_cast<const std::vector<double> &, bool>(&CriticalZoneChecker::check),
+             py::arg("ranges"), py::arg("forward"))
+        .def("check", py::overload_cast<const std::vector<int8_t> &, int, int, int, int, int, int, int, bool>(
+                          &CriticalZoneChecker::check),
+             py::arg("data"), py::arg("point_step"), py::arg("row_step"), py::arg("height"), py::arg("width"),
+             py::arg("x_offset"), py::arg("y_offset"), py::arg("z_offset"), py::arg("forward"));
+    py::class_<CriticalZoneCheckerGPU, CriticalZoneChecker>(ut, "CriticalZoneCheckerGPU")
+        .def(py::init([](CriticalZoneChecker::InputType it, CollisionChecker::ShapeType shape,
+                         const std::vector<float> &dims, const py::object &spos, const py::object &srot, float ca,
+                         float cd, float sd, const std::vector<double> &angles, float minh, float maxh, float rmax,
+                         PointFieldType ft) {
+               return std::make_unique<CriticalZoneCheckerGPU>(it, shape, dims, vec3(spos), vec4(srot), ca, cd, sd,
+                                                               angles, minh, maxh, rmax, ft);
+             }), py::arg("input_type"), py::arg("robot_shape"), py::arg("robot_dimensions"),
+             py::arg("sensor_position_body"), py::arg("sensor_rotation_body"), py::arg("critical_angle"),
+             py::arg("critical_distance"), py::arg("slowdown_distance"), py::arg("scan_angles"),
+             py::arg("min_height"), py::arg("max_height"), py::arg("range_max"),
+             py::arg("cloud_field_type") = PointFieldType::FLOAT32);
+  }
   ut.def("pointcloud_to_laserscan_from_raw",
          [](const std::vector<int8_t> &data, int point_step, int row_step, int height, int width, int x_offset,
             int y_offset, int z_offset, double max_range, double min_z, double max_z, double angle_step) {

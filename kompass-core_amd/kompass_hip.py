@@ -120,6 +120,13 @@ SIGNATURES = {
     "kc_mapper_sync": (C.c_int, [_vp]),
     "kc_mapper_timing_enable": (C.c_int, [_vp, C.c_int]),
     "kc_mapper_timing_get": (C.c_int, [_vp, C.POINTER(C.c_char_p), _fp, _sz, C.POINTER(_sz)]),
+    "kc_zone_create": (C.c_int, [C.c_int, _fp, C.c_int, _fp, _fp, C.c_float, C.c_float, C.c_float, _dp, _sz,
+                                 C.c_float, C.c_float, C.c_float, C.c_int, C.POINTER(_vp)]),
+    "kc_zone_destroy": (None, [_vp]),
+    "kc_zone_check": (C.c_int, [_vp, _dp, _sz, C.c_int, C.POINTER(C.c_float)]),
+    "kc_zone_check_cloud": (C.c_int, [_vp, C.c_void_p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "kc_zone_indices": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64), _sz, C.POINTER(_sz)]),
     "kc_cloud_create": (C.c_int, [_sz, _sz, C.c_int, C.POINTER(_vp)]),
     "kc_cloud_destroy": (None, [_vp]),
     "kc_cloud_to_laserscan": (C.c_int, [_vp, C.c_void_p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -466,3 +473,50 @@ class CloudContext:
         n = _sz(0)
         _check(lib().kc_cloud_timing_get(self.h, names, ms, 16, C.byref(n)))
         return [(names[i].decode(), float(ms[i])) for i in range(n.value)]
+
+
+class ZoneContext:
+    """Owner of one kc_zone context (CriticalZoneChecker)."""
+
+    def __init__(self, shape, dims, sensor_pos, sensor_rot_xyzw, critical_angle, critical_distance,
+                 slowdown_distance, angles, min_height, max_height, range_max, device=0):
+        d, sp, sr = _f32(dims), _f32(sensor_pos), _f32(sensor_rot_xyzw)
+        a = _f64(angles)
+        self.n = len(a)
+        self.h = _vp()
+        _check(lib().kc_zone_create(int(shape), _pf(d), len(d), _pf(sp), _pf(sr), float(np.float32(critical_angle)),
+                                    float(np.float32(critical_distance)), float(np.float32(slowdown_distance)),
+                                    _pd(a), len(a), float(np.float32(min_height)), float(np.float32(max_height)),
+                                    float(np.float32(range_max)), int(device), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().kc_zone_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, ranges, forward) -> float:
+        r = _f64(ranges)
+        f = C.c_float(0)
+        _check(lib().kc_zone_check(self.h, _pd(r), len(r), int(bool(forward)), C.byref(f)))
+        return float(f.value)
+
+    def check_cloud(self, data, point_step, row_step, height, width, x_offset, y_offset, z_offset, forward) -> float:
+        buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.int8) if not isinstance(data, np.ndarray)
+                                   else data.view(np.int8).reshape(-1))
+        f = C.c_float(0)
+        _check(lib().kc_zone_check_cloud(self.h, buf.ctypes.data, buf.size, int(point_step), int(row_step),
+                                         int(height), int(width), int(x_offset), int(y_offset), int(z_offset),
+                                         int(bool(forward)), C.byref(f)))
+        return float(f.value)
+
+    def indices(self, forward):
+        out = (C.c_int64 * max(self.n, 1))()
+        n = _sz(0)
+        _check(lib().kc_zone_indices(self.h, int(bool(forward)), out, self.n, C.byref(n)))
+        return np.array(out[:n.value], dtype=np.int64)

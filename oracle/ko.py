@@ -160,6 +160,13 @@ def lib():
         "ko_dwa_path": (vp, [vp]),
         "ko_dwa_max_segment_size": (sz, [vp]),
         "ko_dwa_closest_index": (sz, [vp]),
+        "ko_czc_create": (C.c_void_p, [C.c_int, _fp, _fp, _fp, C.c_float, C.c_float, C.c_float, _dp, C.c_size_t,
+                                       C.c_float, C.c_float, C.c_float]),
+        "ko_czc_destroy": (None, [C.c_void_p]),
+        "ko_czc_check": (C.c_float, [C.c_void_p, _dp, C.c_int]),
+        "ko_czc_check_cloud": (C.c_float, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int]),
+        "ko_czc_indices": (C.c_size_t, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.c_size_t]),
         "ko_pointcloud_to_laserscan": (C.c_long, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                  C.c_double, C.c_int, _dp, _dp, C.c_size_t]),
@@ -525,6 +532,42 @@ def pointcloud_to_laserscan(data, point_step, row_step, height, width, x_offset,
     if n < 0:
         raise ValueError("invalid point cloud arguments")
     return (ranges[:n], angles[:n]) if by_step else ranges[:n]
+
+
+class CriticalZone:
+    """CriticalZoneChecker (utils/critical_zone_check.cpp), CPU semantics."""
+
+    def __init__(self, shape, dims, sensor_pos, sensor_rot_xyzw, critical_angle, critical_distance,
+                 slowdown_distance, angles, min_height, max_height, range_max):
+        d, sp, sr = _f32(dims), _f32(sensor_pos), _f32(sensor_rot_xyzw)
+        self.angles = _f64(angles)
+        self.h = lib().ko_czc_create(int(shape), _pf(d), _pf(sp), _pf(sr), float(np.float32(critical_angle)),
+                                     float(np.float32(critical_distance)), float(np.float32(slowdown_distance)),
+                                     _pd(self.angles), len(self.angles), float(np.float32(min_height)),
+                                     float(np.float32(max_height)), float(np.float32(range_max)))
+        if not self.h:
+            raise ValueError("SlowDown distance must be greater than the Critical distance / invalid shape")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ko_czc_destroy(self.h)
+            self.h = None
+
+    def check(self, ranges, forward):
+        r = _f64(ranges)
+        assert len(r) >= len(self.angles)
+        return float(lib().ko_czc_check(self.h, _pd(r), int(bool(forward))))
+
+    def check_cloud(self, data, point_step, row_step, height, width, x_offset, y_offset, z_offset, forward):
+        buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.int8) if not isinstance(data, np.ndarray)
+                                   else data.view(np.int8).reshape(-1))
+        return float(lib().ko_czc_check_cloud(self.h, buf.ctypes.data, buf.size, point_step, row_step, height, width,
+                                              x_offset, y_offset, z_offset, int(bool(forward))))
+
+    def indices(self, forward):
+        out = (C.c_size_t * max(len(self.angles), 1))()
+        n = lib().ko_czc_indices(self.h, int(bool(forward)), out, len(self.angles))
+        return np.array(out[:n], dtype=np.int64)
 
 
 def baseline_cycle(coll, ci: CostInputs, start, dt, P, vx, vy, omega, threads=1):

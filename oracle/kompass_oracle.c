@@ -1713,3 +1713,120 @@ long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_ste
   }
   return num_bins;
 }
+
+
+/* ===========================================================================
+ * CriticalZoneChecker, utils/critical_zone_check.cpp
+ * =========================================================================== */
+struct ko_czc {
+  double robot_radius;     /* robotRadius_ (double member) */
+  float min_height, max_height, range_max;
+  float critical_angle;    /* half cone, normalised, stored as float */
+  float critical_distance, slowdown_distance;
+  size_t n;
+  float *sin_a, *cos_a;
+  size_t *fwd, *bwd;
+  size_t n_fwd, n_bwd;
+  iso3f tf;                /* sensor_tf_body_ */
+};
+
+ko_czc *ko_czc_create(int shape, const float *dims, const float sensor_pos[3],
+                      const float sensor_rot_xyzw[4], float critical_angle_deg,
+                      float critical_distance, float slowdown_distance,
+                      const double *angles, size_t n, float min_height,
+                      float max_height, float range_max) {
+  if (!(slowdown_distance > critical_distance)) return NULL; /* :52-56 */
+  ko_czc *z = (ko_czc *)calloc(1, sizeof(*z));
+  if (!z) return NULL;
+  z->min_height = min_height;
+  z->max_height = max_height;
+  z->range_max = range_max;
+  if (shape == 0) { /* :26-28 */
+    z->robot_radius = dims[0];
+  } else if (shape == 1) { /* :29-33: std::sqrt(pow(float,2) + pow(float,2)) / 2 in double */
+    z->robot_radius = sqrt(pow((double)dims[0], 2) + pow((double)dims[1], 2)) / 2;
+  } else if (shape == 2) {
+    z->robot_radius = dims[0];
+  } else {
+    free(z);
+    return NULL;
+  }
+  /* Eigen::Quaternionf(Vector4f) takes the coefficients in (x, y, z, w) order */
+  quatf q = {sensor_rot_xyzw[3], sensor_rot_xyzw[0], sensor_rot_xyzw[1], sensor_rot_xyzw[2]};
+  z->tf = iso_from_quat(q, sensor_pos);
+  /* :46-48: float angle_rad = critical_angle * M_PI / 180.0 (double product, float store) */
+  const float angle_rad = (float)((double)critical_angle_deg * M_PI / 180.0);
+  z->critical_angle = (float)normalize_mpi_pi((double)(angle_rad / 2));
+  z->critical_distance = critical_distance;
+  z->slowdown_distance = slowdown_distance;
+  z->n = n;
+  z->sin_a = (float *)malloc(sizeof(float) * (n ? n : 1));
+  z->cos_a = (float *)malloc(sizeof(float) * (n ? n : 1));
+  z->fwd = (size_t *)malloc(sizeof(size_t) * (n ? n : 1));
+  z->bwd = (size_t *)malloc(sizeof(size_t) * (n ? n : 1));
+  for (size_t i = 0; i < n; ++i) { /* preset, :60-83 */
+    z->cos_a[i] = (float)cos(angles[i]);
+    z->sin_a[i] = (float)sin(angles[i]);
+    float p[3];
+    iso_apply(&z->tf, z->cos_a[i], z->sin_a[i], 0.0f, p);
+    const float abs_theta = fabsf(atan2f(p[1], p[0]));
+    if (abs_theta <= z->critical_angle) z->fwd[z->n_fwd++] = i;
+    /* float >= double(M_PI - float) */
+    if ((double)abs_theta >= M_PI - (double)z->critical_angle) z->bwd[z->n_bwd++] = i;
+  }
+  return z;
+}
+
+void ko_czc_destroy(ko_czc *z) {
+  if (!z) return;
+  free(z->sin_a);
+  free(z->cos_a);
+  free(z->fwd);
+  free(z->bwd);
+  free(z);
+}
+
+size_t ko_czc_indices(const ko_czc *z, int forward, size_t *out, size_t cap) {
+  const size_t n = forward ? z->n_fwd : z->n_bwd;
+  const size_t *src = forward ? z->fwd : z->bwd;
+  for (size_t i = 0; i < n && i < cap; ++i) out[i] = src[i];
+  return n;
+}
+
+float ko_czc_check(const ko_czc *z, const double *ranges, int forward) { /* :85-117 */
+  const size_t *idx = forward ? z->fwd : z->bwd;
+  const size_t n = forward ? z->n_fwd : z->n_bwd;
+  float slowdown_factor = 1.0f;
+  for (size_t k = 0; k < n; ++k) {
+    const size_t i = idx[k];
+    const float x = (float)(ranges[i] * (double)z->cos_a[i]);
+    const float y = (float)(ranges[i] * (double)z->sin_a[i]);
+    float p[3];
+    iso_apply(&z->tf, x, y, 0.0f, p);
+    /* std::sqrt(std::pow(float, 2) + std::pow(float, 2)): double, stored as float */
+    const float converted_range = (float)sqrt(pow((double)p[1], 2) + pow((double)p[0], 2));
+    const float distance = (float)((double)converted_range - z->robot_radius);
+    if (distance <= z->critical_distance) return 0.0f;
+    if (distance <= z->slowdown_distance) {
+      const float f = (distance - z->critical_distance) /
+                      (z->slowdown_distance - z->critical_distance);
+      if (f < slowdown_factor) slowdown_factor = f; /* std::min(a, b): b < a ? b : a */
+    }
+  }
+  return slowdown_factor;
+}
+
+float ko_czc_check_cloud(const ko_czc *z, const int8_t *data, size_t nbytes,
+                         int point_step, int row_step, int height, int width,
+                         int x_offset, int y_offset, int z_offset, int forward) { /* :119-131 */
+  if (z->n == 0) return 1.0f;
+  double *ranges = (double *)malloc(sizeof(double) * z->n);
+  const long nb = ko_pointcloud_to_laserscan(data, nbytes, point_step, row_step, height, width,
+                                             x_offset, y_offset, z_offset, (double)z->range_max,
+                                             (double)z->min_height, (double)z->max_height, 0.0,
+                                             (int)z->n, ranges, NULL, z->n);
+  float r = 1.0f;
+  if (nb == (long)z->n) r = ko_czc_check(z, ranges, forward);
+  free(ranges);
+  return r;
+}

@@ -263,6 +263,26 @@ long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_ste
                                 int num_bins, double *ranges_out,
                                 double *angles_out, size_t cap);
 
+/* ---- CriticalZoneChecker (CPU semantics), SURVEY 8f rank 2 ------------------- */
+/* utils/critical_zone_check.{h,cpp}: ctor :13-58 (shape -> radius, sensor
+ * transform from the (x, y, z, w) rotation 4-vector, half cone angle), preset
+ * :60-83 (forward / backward index sets), check(ranges) :85-117, check(cloud)
+ * :119-131 (num_bins overload of pointCloudToLaserScanFromRaw with range_max /
+ * min / max height, then check(ranges)).  shape: 0 cylinder, 1 box, 2 sphere. */
+typedef struct ko_czc ko_czc;
+ko_czc *ko_czc_create(int shape, const float *dims, const float sensor_pos[3],
+                      const float sensor_rot_xyzw[4], float critical_angle_deg,
+                      float critical_distance, float slowdown_distance,
+                      const double *angles, size_t n, float min_height,
+                      float max_height, float range_max);
+void ko_czc_destroy(ko_czc *z);
+float ko_czc_check(const ko_czc *z, const double *ranges, int forward);
+float ko_czc_check_cloud(const ko_czc *z, const int8_t *data, size_t nbytes,
+                         int point_step, int row_step, int height, int width,
+                         int x_offset, int y_offset, int z_offset, int forward);
+/* introspection for the tests: index sets and trig tables */
+size_t ko_czc_indices(const ko_czc *z, int forward, size_t *out, size_t cap);
+
 /* bounded multi-thread CPU baseline helper: roll-out + costs with `threads`
  * workers over contiguous sample blocks (mirrors the reference ThreadPool
  * scheme, trajectory_sampler.cpp:192-205) -- used only by bench.py. */
