@@ -83,11 +83,18 @@ struct RollArgs {
   CollDev c;
 };
 
+// Phase clocks for kernel tuning: compiled in only with -DKC_PHASE_STAMPS (the
+// product build carries none of it); KC_DEBUG_STAMPS=1 then dumps them when the
+// context is destroyed.
+#ifdef KC_PHASE_STAMPS
 #define KC_RSTAMP(slot)                                                    \
   do {                                                                     \
     if (a.dbg && threadIdx.x == 0)                                         \
       a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+#else
+#define KC_RSTAMP(slot) do { } while (0)
+#endif
 
 // ===========================================================================
 // collision: analytic shape-vs-occupied-voxel test (restated A4 contract)
@@ -704,16 +711,15 @@ struct CostArgs {
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS): per-block phase clocks
 };
 
-#define KC_STAMP_CLK(slot)                                                 \
-  do {                                                                     \
-    if (a.dbg && threadIdx.x == 0)                                         \
-      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
+#ifdef KC_PHASE_STAMPS
 #define KC_STAMP(slot)                                                     \
   do {                                                                     \
     if (a.dbg && threadIdx.x == 0)                                         \
       a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+#else
+#define KC_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ float accum(float total, double w, float c) {
   return static_cast<float>(static_cast<double>(total) +
@@ -1109,7 +1115,11 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
       const int p = live ? pp : a.P - 1;  // idle lanes shadow the last point, write nothing
       const float x = a.px[(size_t)n * a.P + p], y = a.py[(size_t)n * a.P + p];
       float mind = 0.0f, goal_l = 0.0f, end_l = 0.0f;
+#ifdef KC_PHASE_STAMPS
       const bool st = a.dbg && i == static_cast<int>(blockIdx.x) && p0 == 0;  // first sample of wavefront 0
+#else
+      constexpr bool st = false;
+#endif
       if (st) KC_STAMP(7);
       if (a.use_seg) {
         float best = FLT_MAX;
@@ -1337,7 +1347,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
     // constant-velocity samples: both terms are exactly 0 and `total += w*0`
     // leaves total unchanged, so nothing to do when !have_vel.
     if (lane == 0) a.costs[n] = total;
-    if (a.dbg && i == static_cast<int>(blockIdx.x)) KC_STAMP(3);
+    if (i == static_cast<int>(blockIdx.x)) KC_STAMP(3);
     if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
       const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
       wkey = k < wkey ? k : wkey;
@@ -2157,11 +2167,13 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.result = c->d_result.p;
   KC_TRY(c->d_block_keys.reserve(512));
   ca.block_keys = c->d_block_keys.p;
+#ifdef KC_PHASE_STAMPS
   if (c->debug_stamps) {
     KC_TRY(c->d_dbg.reserve(512 * 16));
     KC_HIP(hipMemsetAsync(c->d_dbg.p, 0, 512 * 16 * 8, s));
     ca.dbg = c->d_dbg.p;
   }
+#endif
   // Short admissible lists (the count of the previous cycle is the predictor)
   // go to the workgroup-per-sample kernel, long ones to the wavefront-per-
   // sample kernel; both are correct for any list.
@@ -2894,11 +2906,13 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
     a.pvx = c->d_pvx.p;
     a.pvy = c->d_pvy.p;
     a.prow = c->d_prow.p;
+#ifdef KC_PHASE_STAMPS
     if (c->debug_stamps) {
       KC_TRY(c->d_dbg2.reserve(512 * 16));
       KC_HIP(hipMemsetAsync(c->d_dbg2.p, 0, 512 * 16 * 8, s));
       a.dbg = c->d_dbg2.p;
     }
+#endif
     if (c->list_dirty)  // previous roll-out was never evaluated: re-arm the list
       KC_HIP(hipMemsetAsync(c->d_result.p + W_LIST, 0, sizeof(long long), s));
     c->list_dirty = true;
