@@ -9,7 +9,10 @@
 // OCCUPIED on the end cells.  Stream order between the passes gives exactly
 // the max.  One wavefront per beam; the Bresenham error term has a closed form
 // per step, so the 64 lanes each rasterise a contiguous chunk of the line.
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "kc_internal.h"
@@ -24,22 +27,19 @@ struct MapGeom {
   float pos0, pos1;
 };
 
-// end cell of every beam: LocalMapper::updateGrid_ (local_mapper.cpp:127-134)
+// end cell of a beam: LocalMapper::updateGrid_ (local_mapper.cpp:127-134)
 // + localToGrid (local_mapper.h:210-222).  cos/sin come from the host libm
 // table (the reference calls ::cos(double) on the float sum orient + angle).
-__global__ void beam_endpoints_kernel(MapGeom g, const float *__restrict__ ranges,
-                                      const double2 *__restrict__ trig, int n,
-                                      int2 *__restrict__ to) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
-  const double r = static_cast<double>(ranges[b]);
-  const double2 cs = trig[b];
+// Both passes recompute it (a handful of operations) instead of a third kernel
+// and an array in between.
+__device__ __forceinline__ int2 beam_endpoint(const MapGeom &g, float range, double2 cs) {
+  const double r = static_cast<double>(range);
   const float x = static_cast<float>(static_cast<double>(g.pos0) + r * cs.x);
   const float y = static_cast<float>(static_cast<double>(g.pos1) + r * cs.y);
   int2 t;
   t.x = g.c0 + static_cast<int>(kc::div_rn(x, g.res));  // trunc toward zero
   t.y = g.c1 + static_cast<int>(kc::div_rn(y, g.res));
-  to[b] = t;
+  return t;
 }
 
 __device__ __forceinline__ void stamp_empty(int *grid, const MapGeom &g, int i,
@@ -54,11 +54,12 @@ __device__ __forceinline__ void stamp_empty(int *grid, const MapGeom &g, int i,
 constexpr int kBeamsPerBlock = 4;
 
 __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_kernel(
-    MapGeom g, const int2 *__restrict__ to, int n, int *__restrict__ grid) {
+    MapGeom g, const float *__restrict__ ranges, const double2 *__restrict__ trig, int n,
+    int *__restrict__ grid) {
   const int beam = blockIdx.x * kBeamsPerBlock + (threadIdx.x >> 6);
   if (beam >= n) return;
   const int lane = threadIdx.x & 63;
-  const int2 t = to[beam];
+  const int2 t = beam_endpoint(g, ranges[beam], trig[beam]);
   int dx = t.x - g.s0, dy = t.y - g.s1;
   const int xstep = dx >= 0 ? 1 : -1, ystep = dy >= 0 ? 1 : -1;
   dx = abs(dx);
@@ -115,13 +116,26 @@ __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_kernel(
 
 // pass 3: the end cell of every beam (fillGridAroundPoint with padding 0,
 // local_mapper.cpp:148-151)
-__global__ void endpoints_kernel(MapGeom g, const int2 *__restrict__ to, int n,
-                                 int *__restrict__ grid) {
+// The last workgroup to finish tells the host (sequence number into pinned
+// memory, polled by kc_mapper_sync instead of a stream wait); every workgroup
+// releases its stores (device scope) before it takes its ticket.
+__global__ void endpoints_kernel(MapGeom g, const float *__restrict__ ranges,
+                                 const double2 *__restrict__ trig, int n, int *__restrict__ grid,
+                                 unsigned int *ticket, long long *host_seq, long long seq) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n) return;
-  const int2 t = to[b];
-  if (t.x >= 0 && t.x < g.H && t.y >= 0 && t.y < g.W)
-    grid[(size_t)t.x + (size_t)t.y * (size_t)g.H] = KC_OCCUPIED;
+  if (b < n) {
+    const int2 t = beam_endpoint(g, ranges[b], trig[b]);
+    if (t.x >= 0 && t.x < g.H && t.y >= 0 && t.y < g.W)
+      grid[(size_t)t.x + (size_t)t.y * (size_t)g.H] = KC_OCCUPIED;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      *ticket = 0u;
+      *reinterpret_cast<volatile long long *>(host_seq) = seq;
+    }
+  }
 }
 
 }  // namespace kc
@@ -138,7 +152,10 @@ struct kc_mapper {
   DevBuf<int> d_grid;
   DevBuf<float> d_ranges;
   DevBuf<double2> d_trig;
-  DevBuf<int2> d_to;
+  DevBuf<unsigned int> d_ticket;
+  PinBuf<long long> h_seq;   // written by the last endpoints workgroup
+  long long seq = 0;         // scans launched
+  bool direct = false;       // host stores reach device memory (large BAR)
   PinBuf<float> h_ranges;
   PinBuf<double2> h_trig;
   PinBuf<int> h_grid;
@@ -150,20 +167,38 @@ struct kc_mapper {
 
 namespace {
 
+// true when the last scan launched is known to have finished (its sequence
+// number arrived), after polling for at most `us` microseconds
+bool scan_done(kc_mapper *m, int us) {
+  if (m->seq == 0) return true;
+  volatile long long *p = m->h_seq.p;
+  if (*p == m->seq) return true;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 0;; ++spins) {
+    if (*p == m->seq) return true;
+    if ((spins & 255) == 255 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(us))
+      return false;
+  }
+}
+
 int run_scan(kc_mapper *m, const double *angles, const double *ranges,
              size_t n) {
   KC_HIP(hipSetDevice(m->device));
   hipStream_t s = m->stream;
-  KC_HIP(hipStreamSynchronize(s));  // staging buffers free again
+  // the staging / device range buffers are free once the previous scan is done
+  if (m->timing.enabled || !scan_done(m, 0)) KC_HIP(hipStreamSynchronize(s));
   m->timing.begin_cycle();
   const size_t cells = static_cast<size_t>(m->g.H) * m->g.W;
   KC_TRY(m->timing.start("grid_clear", s));
   KC_HIP(hipMemsetAsync(m->d_grid.p, 0xFF, cells * sizeof(int), s));  // -1
   KC_TRY(m->timing.stop(s));
-  if (n == 0) return KC_OK;
+  if (n == 0) {
+    m->seq = 0;  // nothing will signal: kc_mapper_sync waits on the stream
+    return KC_OK;
+  }
   KC_TRY(m->d_ranges.reserve(n));
   KC_TRY(m->d_trig.reserve(n));
-  KC_TRY(m->d_to.reserve(n));
   KC_TRY(m->h_ranges.reserve(n));
   KC_TRY(m->h_trig.reserve(n));
   const bool same = m->trig_valid && m->last_angles.size() == n &&
@@ -181,24 +216,31 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
     KC_HIP(hipMemcpyAsync(m->d_trig.p, m->h_trig.p, n * sizeof(double2),
                           hipMemcpyHostToDevice, s));
   }
-  for (size_t i = 0; i < n; ++i)
-    m->h_ranges.p[i] = static_cast<float>(ranges[i]);
-  KC_HIP(hipMemcpyAsync(m->d_ranges.p, m->h_ranges.p, n * sizeof(float),
-                        hipMemcpyHostToDevice, s));
+  if (m->direct) {
+    // ranges straight into device memory (write-combined stores over the BAR)
+    float *dst = m->d_ranges.p;
+    for (size_t i = 0; i < n; ++i) dst[i] = static_cast<float>(ranges[i]);
+#if defined(__x86_64__)
+    __builtin_ia32_sfence();
+#endif
+  } else {
+    for (size_t i = 0; i < n; ++i)
+      m->h_ranges.p[i] = static_cast<float>(ranges[i]);
+    KC_HIP(hipMemcpyAsync(m->d_ranges.p, m->h_ranges.p, n * sizeof(float),
+                          hipMemcpyHostToDevice, s));
+  }
   const int ni = static_cast<int>(n);
-  KC_TRY(m->timing.start("beam_endpoints_kernel", s));
-  hipLaunchKernelGGL(beam_endpoints_kernel, dim3((ni + 255) / 256), dim3(256),
-                     0, s, m->g, m->d_ranges.p, m->d_trig.p, ni, m->d_to.p);
-  KC_TRY(m->timing.stop(s));
   KC_TRY(m->timing.start("rays_kernel", s));
   hipLaunchKernelGGL(rays_kernel,
                      dim3((ni + kBeamsPerBlock - 1) / kBeamsPerBlock),
-                     dim3(64 * kBeamsPerBlock), 0, s, m->g, m->d_to.p, ni,
+                     dim3(64 * kBeamsPerBlock), 0, s, m->g, m->d_ranges.p, m->d_trig.p, ni,
                      m->d_grid.p);
   KC_TRY(m->timing.stop(s));
+  ++m->seq;
   KC_TRY(m->timing.start("endpoints_kernel", s));
   hipLaunchKernelGGL(endpoints_kernel, dim3((ni + 255) / 256), dim3(256), 0, s,
-                     m->g, m->d_to.p, ni, m->d_grid.p);
+                     m->g, m->d_ranges.p, m->d_trig.p, ni, m->d_grid.p, m->d_ticket.p,
+                     m->h_seq.p, m->seq);
   KC_TRY(m->timing.stop(s));
   KC_HIP(hipGetLastError());
   return KC_OK;
@@ -248,8 +290,22 @@ int kc_mapper_create(int H, int W, float res, const float pos[3], float orient,
   const size_t cells = static_cast<size_t>(H) * W;
   int rc;
   if ((rc = m->d_grid.reserve(cells)) || (rc = m->h_grid.reserve(cells)) ||
-      (rc = m->d_ranges.reserve(std::max<size_t>(max_scan, 16))))
+      (rc = m->d_ranges.reserve(std::max<size_t>(max_scan, 16))) ||
+      (rc = m->d_ticket.reserve(1)) || (rc = m->h_seq.reserve(1)))
     return fail(rc);
+  m->h_seq.p[0] = 0;
+  if (hipMemset(m->d_ticket.p, 0, sizeof(unsigned int)) != hipSuccess) {
+    set_error("ticket initialisation failed");
+    return fail(KC_ERR_HIP);
+  }
+  int large_bar = 0;
+  if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) != hipSuccess) {
+    (void)hipGetLastError();
+    large_bar = 0;
+  }
+  m->direct = large_bar != 0;
+  if (const char *e = std::getenv("KC_TRIG_COPY"))
+    if (e[0] == '1') m->direct = false;  // test hook: staged copies
   *out = m;
   return KC_OK;
 }
@@ -266,7 +322,8 @@ void kc_mapper_destroy(kc_mapper *m) {
   m->d_grid.release();
   m->d_ranges.release();
   m->d_trig.release();
-  m->d_to.release();
+  m->d_ticket.release();
+  m->h_seq.release();
   m->h_ranges.release();
   m->h_trig.release();
   m->h_grid.release();
@@ -309,6 +366,9 @@ int kc_mapper_grid_device(kc_mapper *m, void **dev) {
 int kc_mapper_sync(kc_mapper *m) {
   if (!m) KC_FAIL(KC_ERR_INVALID, "null context");
   KC_HIP(hipSetDevice(m->device));
+  // the last endpoints workgroup reports the scan into pinned memory: poll it
+  // (a stream wait costs ~10 us), fall back to the stream after 2 ms
+  if (m->seq != 0 && scan_done(m, 2000)) return KC_OK;
   KC_HIP(hipStreamSynchronize(m->stream));
   return KC_OK;
 }
