@@ -1,0 +1,178 @@
+// Device-side argument blocks of the roll-out / collision kernels and the
+// exact shape-vs-voxel tests (restated A4 contract).  Part of kc_dwa.hip.
+#pragma once
+
+namespace kc {
+
+// ===========================================================================
+// device-side parameter blocks (passed by value)
+// ===========================================================================
+struct CollDev {
+  int shape;        // KC_CYLINDER / KC_BOX / KC_SPHERE
+  int enabled;      // 0 => no occupied cell inside the reachable window
+  int lds;          // stage the occupancy bits in LDS
+  int kx0, ky0;     // window origin (voxel keys, octree frame)
+  int W, H, wpr;    // window size in cells, 32-bit words per row
+  double r00, r01, r10, r11;  // octree-frame rotation (float values widened)
+  double tx, ty;              // octree-frame origin in the world
+  double res, inv;            // voxel edge, 1/res (octomap resolution_factor)
+  double radius, rr;          // cylinder / sphere radius, radius^2
+  double a, b;                // box half extents
+  const uint32_t *bits;       // [H][wpr] occupancy bits (global)
+  const double *ddz;          // sphere only: per-cell z gap [H][W]
+  // occupancy bits of ALL accepted voxel columns (built once per sensor
+  // update); the fused kernel copies its window out of it, word aligned
+  const uint32_t *gbits;      // [gH][gwpr]
+  int gkx0, gky0, gH, gwpr;   // origin (keys), rows, words per row
+  // the same bitmap dilated twice (built by dilate_kernel once per sensor
+  // update): `ginner` marks the cells from which an occupied cell is SURELY
+  // within the robot's inscribed radius, `gouter` the cells from which one is
+  // POSSIBLY within its circumscribed radius.  A pose in a cell outside
+  // gouter cannot collide, one inside ginner does; only the thin shell in
+  // between needs the exact test.
+  const uint32_t *ginner, *gouter;
+  int dil;                    // masks present
+};
+
+struct RollArgs {
+  int n;            // samples in this launch (shard)
+  int first;        // offset of the shard in the sample arrays
+  int P;            // points per trajectory
+  int A;            // trig-table row count
+  int stage;        // LDS transposition of the outputs
+  double x0, y0, dt;
+  const double *vx, *vy;
+  const int32_t *row;
+  const int32_t *perm;  // fused kernel: local sample ids ordered by omega row, so that the
+                        // samples of a workgroup share as few trig rows as possible
+  const double *pvx, *pvy;  // velocities and trig rows in that order (one load, no
+  const int32_t *prow;      // dependent second one)
+  const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
+  float *px, *py;       // [n][P] sample-major
+  double2 *pos;         // [P][n] step-major double poses (collision pass input)
+  uint8_t *flags;       // [n] admissible
+  int *adm_list;        // admissible local sample ids, appended (any order)
+  long long *adm_count; // device counter (re-armed by the cost kernel)
+  // early launch (fused kernel only): the kernel is queued BEFORE the host has
+  // produced the trig table, so launch + dispatch latency overlap the libm
+  // work; the host then writes the table and this sequence word through the
+  // BAR and the workgroups wait for it.  Null: the table is already there.
+  const long long *trig_flag;
+  long long trig_seq;
+  long long *dev_err;   // set when the wait gives up (host never delivered)
+  unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
+  CollDev c;
+};
+
+// Phase clocks for kernel tuning: compiled in only with -DKC_PHASE_STAMPS (the
+// product build carries none of it); KC_DEBUG_STAMPS=1 then dumps them when the
+// context is destroyed.
+#ifdef KC_PHASE_STAMPS
+#define KC_RSTAMP(slot)                                                    \
+  do {                                                                     \
+    if (a.dbg && threadIdx.x == 0)                                         \
+      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define KC_RSTAMP(slot) do { } while (0)
+#endif
+
+// ===========================================================================
+// collision: analytic shape-vs-occupied-voxel test (restated A4 contract)
+// ===========================================================================
+template <typename BitsPtr>
+__device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
+                                          double x, double y) {
+  const double dx = x - c.tx, dy = y - c.ty;
+  const double xf = c.r00 * dx + c.r10 * dy;
+  const double yf = c.r01 * dx + c.r11 * dy;
+  const double r = c.radius;
+  int cx0 = static_cast<int>(floor((xf - r) * c.inv)) - 1 - c.kx0;
+  int cx1 = static_cast<int>(floor((xf + r) * c.inv)) + 1 - c.kx0;
+  int cy0 = static_cast<int>(floor((yf - r) * c.inv)) - 1 - c.ky0;
+  int cy1 = static_cast<int>(floor((yf + r) * c.inv)) + 1 - c.ky0;
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, c.W - 1);
+  cy1 = min(cy1, c.H - 1);
+  for (int cy = cy0; cy <= cy1; ++cy) {
+    const int ky = c.ky0 + cy;
+    const double ylo = static_cast<double>(ky) * c.res;
+    const double yhi = static_cast<double>(ky + 1) * c.res;
+    double gy = 0.0;
+    if (ylo - yf > gy) gy = ylo - yf;
+    if (yf - yhi > gy) gy = yf - yhi;
+    for (int wbase = cx0 & ~31; wbase <= cx1; wbase += 32) {
+      uint32_t m = bits[cy * c.wpr + (wbase >> 5)];
+      if (wbase < cx0) m &= 0xFFFFFFFFu << (cx0 - wbase);
+      if (cx1 - wbase < 31) m &= 0xFFFFFFFFu >> (31 - (cx1 - wbase));
+      while (m) {
+        const int b = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1;
+        const int cx = wbase + b;
+        const int kx = c.kx0 + cx;
+        const double xlo = static_cast<double>(kx) * c.res;
+        const double xhi = static_cast<double>(kx + 1) * c.res;
+        double gx = 0.0;
+        if (xlo - xf > gx) gx = xlo - xf;
+        if (xf - xhi > gx) gx = xf - xhi;
+        double zz = 0.0;
+        if (c.shape == KC_SPHERE) {
+          const double g = c.ddz[cy * c.W + cx];
+          zz = g * g;
+        }
+        const double d2 = gx * gx + gy * gy + zz;
+        if (d2 <= c.rr) return true;
+      }
+    }
+  }
+  return false;
+}
+
+template <typename BitsPtr>
+__device__ __forceinline__ bool hit_box(const CollDev &c, BitsPtr bits,
+                                        double x, double y, double cw,
+                                        double sw) {
+  const double dx = x - c.tx, dy = y - c.ty;
+  const double xf = c.r00 * dx + c.r10 * dy;
+  const double yf = c.r01 * dx + c.r11 * dy;
+  const double ux = c.r00 * cw + c.r10 * sw;
+  const double uy = c.r01 * cw + c.r11 * sw;
+  const double vx = -uy, vy = ux;
+  const double ex = c.a * fabs(ux) + c.b * fabs(vx);
+  const double ey = c.a * fabs(uy) + c.b * fabs(vy);
+  int cx0 = static_cast<int>(floor((xf - ex) * c.inv)) - 1 - c.kx0;
+  int cx1 = static_cast<int>(floor((xf + ex) * c.inv)) + 1 - c.kx0;
+  int cy0 = static_cast<int>(floor((yf - ey) * c.inv)) - 1 - c.ky0;
+  int cy1 = static_cast<int>(floor((yf + ey) * c.inv)) + 1 - c.ky0;
+  cx0 = max(cx0, 0);
+  cy0 = max(cy0, 0);
+  cx1 = min(cx1, c.W - 1);
+  cy1 = min(cy1, c.H - 1);
+  const double h = c.res / 2.0;
+  const double hu = h * (fabs(ux) + fabs(uy));
+  const double hv = h * (fabs(vx) + fabs(vy));
+  for (int cy = cy0; cy <= cy1; ++cy) {
+    const int ky = c.ky0 + cy;
+    const double qy = (static_cast<double>(ky) + 0.5) * c.res - yf;
+    for (int wbase = cx0 & ~31; wbase <= cx1; wbase += 32) {
+      uint32_t m = bits[cy * c.wpr + (wbase >> 5)];
+      if (wbase < cx0) m &= 0xFFFFFFFFu << (cx0 - wbase);
+      if (cx1 - wbase < 31) m &= 0xFFFFFFFFu >> (31 - (cx1 - wbase));
+      while (m) {
+        const int b = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1;
+        const int kx = c.kx0 + wbase + b;
+        const double qx = (static_cast<double>(kx) + 0.5) * c.res - xf;
+        if (fabs(qx) > h + ex) continue;
+        if (fabs(qy) > h + ey) continue;
+        if (fabs(qx * ux + qy * uy) > c.a + hu) continue;
+        if (fabs(qx * vx + qy * vy) > c.b + hv) continue;
+        return true;
+      }
+    }
+  }
+  return false;
+}
+
+}  // namespace kc

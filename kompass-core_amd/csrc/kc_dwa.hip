@@ -21,1505 +21,9 @@
 #include "kc_internal.h"
 #include "kc_pool.h"
 
-namespace kc {
-
-// ===========================================================================
-// device-side parameter blocks (passed by value)
-// ===========================================================================
-struct CollDev {
-  int shape;        // KC_CYLINDER / KC_BOX / KC_SPHERE
-  int enabled;      // 0 => no occupied cell inside the reachable window
-  int lds;          // stage the occupancy bits in LDS
-  int kx0, ky0;     // window origin (voxel keys, octree frame)
-  int W, H, wpr;    // window size in cells, 32-bit words per row
-  double r00, r01, r10, r11;  // octree-frame rotation (float values widened)
-  double tx, ty;              // octree-frame origin in the world
-  double res, inv;            // voxel edge, 1/res (octomap resolution_factor)
-  double radius, rr;          // cylinder / sphere radius, radius^2
-  double a, b;                // box half extents
-  const uint32_t *bits;       // [H][wpr] occupancy bits (global)
-  const double *ddz;          // sphere only: per-cell z gap [H][W]
-  // occupancy bits of ALL accepted voxel columns (built once per sensor
-  // update); the fused kernel copies its window out of it, word aligned
-  const uint32_t *gbits;      // [gH][gwpr]
-  int gkx0, gky0, gH, gwpr;   // origin (keys), rows, words per row
-  // the same bitmap dilated twice (built by dilate_kernel once per sensor
-  // update): `ginner` marks the cells from which an occupied cell is SURELY
-  // within the robot's inscribed radius, `gouter` the cells from which one is
-  // POSSIBLY within its circumscribed radius.  A pose in a cell outside
-  // gouter cannot collide, one inside ginner does; only the thin shell in
-  // between needs the exact test.
-  const uint32_t *ginner, *gouter;
-  int dil;                    // masks present
-};
-
-struct RollArgs {
-  int n;            // samples in this launch (shard)
-  int first;        // offset of the shard in the sample arrays
-  int P;            // points per trajectory
-  int A;            // trig-table row count
-  int stage;        // LDS transposition of the outputs
-  double x0, y0, dt;
-  const double *vx, *vy;
-  const int32_t *row;
-  const int32_t *perm;  // fused kernel: local sample ids ordered by omega row, so that the
-                        // samples of a workgroup share as few trig rows as possible
-  const double *pvx, *pvy;  // velocities and trig rows in that order (one load, no
-  const int32_t *prow;      // dependent second one)
-  const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
-  float *px, *py;       // [n][P] sample-major
-  double2 *pos;         // [P][n] step-major double poses (collision pass input)
-  uint8_t *flags;       // [n] admissible
-  int *adm_list;        // admissible local sample ids, appended (any order)
-  long long *adm_count; // device counter (re-armed by the cost kernel)
-  // early launch (fused kernel only): the kernel is queued BEFORE the host has
-  // produced the trig table, so launch + dispatch latency overlap the libm
-  // work; the host then writes the table and this sequence word through the
-  // BAR and the workgroups wait for it.  Null: the table is already there.
-  const long long *trig_flag;
-  long long trig_seq;
-  long long *dev_err;   // set when the wait gives up (host never delivered)
-  unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
-  CollDev c;
-};
-
-// Phase clocks for kernel tuning: compiled in only with -DKC_PHASE_STAMPS (the
-// product build carries none of it); KC_DEBUG_STAMPS=1 then dumps them when the
-// context is destroyed.
-#ifdef KC_PHASE_STAMPS
-#define KC_RSTAMP(slot)                                                    \
-  do {                                                                     \
-    if (a.dbg && threadIdx.x == 0)                                         \
-      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define KC_RSTAMP(slot) do { } while (0)
-#endif
-
-// ===========================================================================
-// collision: analytic shape-vs-occupied-voxel test (restated A4 contract)
-// ===========================================================================
-template <typename BitsPtr>
-__device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
-                                          double x, double y) {
-  const double dx = x - c.tx, dy = y - c.ty;
-  const double xf = c.r00 * dx + c.r10 * dy;
-  const double yf = c.r01 * dx + c.r11 * dy;
-  const double r = c.radius;
-  int cx0 = static_cast<int>(floor((xf - r) * c.inv)) - 1 - c.kx0;
-  int cx1 = static_cast<int>(floor((xf + r) * c.inv)) + 1 - c.kx0;
-  int cy0 = static_cast<int>(floor((yf - r) * c.inv)) - 1 - c.ky0;
-  int cy1 = static_cast<int>(floor((yf + r) * c.inv)) + 1 - c.ky0;
-  cx0 = max(cx0, 0);
-  cy0 = max(cy0, 0);
-  cx1 = min(cx1, c.W - 1);
-  cy1 = min(cy1, c.H - 1);
-  for (int cy = cy0; cy <= cy1; ++cy) {
-    const int ky = c.ky0 + cy;
-    const double ylo = static_cast<double>(ky) * c.res;
-    const double yhi = static_cast<double>(ky + 1) * c.res;
-    double gy = 0.0;
-    if (ylo - yf > gy) gy = ylo - yf;
-    if (yf - yhi > gy) gy = yf - yhi;
-    for (int wbase = cx0 & ~31; wbase <= cx1; wbase += 32) {
-      uint32_t m = bits[cy * c.wpr + (wbase >> 5)];
-      if (wbase < cx0) m &= 0xFFFFFFFFu << (cx0 - wbase);
-      if (cx1 - wbase < 31) m &= 0xFFFFFFFFu >> (31 - (cx1 - wbase));
-      while (m) {
-        const int b = __ffs(static_cast<int>(m)) - 1;
-        m &= m - 1;
-        const int cx = wbase + b;
-        const int kx = c.kx0 + cx;
-        const double xlo = static_cast<double>(kx) * c.res;
-        const double xhi = static_cast<double>(kx + 1) * c.res;
-        double gx = 0.0;
-        if (xlo - xf > gx) gx = xlo - xf;
-        if (xf - xhi > gx) gx = xf - xhi;
-        double zz = 0.0;
-        if (c.shape == KC_SPHERE) {
-          const double g = c.ddz[cy * c.W + cx];
-          zz = g * g;
-        }
-        const double d2 = gx * gx + gy * gy + zz;
-        if (d2 <= c.rr) return true;
-      }
-    }
-  }
-  return false;
-}
-
-template <typename BitsPtr>
-__device__ __forceinline__ bool hit_box(const CollDev &c, BitsPtr bits,
-                                        double x, double y, double cw,
-                                        double sw) {
-  const double dx = x - c.tx, dy = y - c.ty;
-  const double xf = c.r00 * dx + c.r10 * dy;
-  const double yf = c.r01 * dx + c.r11 * dy;
-  const double ux = c.r00 * cw + c.r10 * sw;
-  const double uy = c.r01 * cw + c.r11 * sw;
-  const double vx = -uy, vy = ux;
-  const double ex = c.a * fabs(ux) + c.b * fabs(vx);
-  const double ey = c.a * fabs(uy) + c.b * fabs(vy);
-  int cx0 = static_cast<int>(floor((xf - ex) * c.inv)) - 1 - c.kx0;
-  int cx1 = static_cast<int>(floor((xf + ex) * c.inv)) + 1 - c.kx0;
-  int cy0 = static_cast<int>(floor((yf - ey) * c.inv)) - 1 - c.ky0;
-  int cy1 = static_cast<int>(floor((yf + ey) * c.inv)) + 1 - c.ky0;
-  cx0 = max(cx0, 0);
-  cy0 = max(cy0, 0);
-  cx1 = min(cx1, c.W - 1);
-  cy1 = min(cy1, c.H - 1);
-  const double h = c.res / 2.0;
-  const double hu = h * (fabs(ux) + fabs(uy));
-  const double hv = h * (fabs(vx) + fabs(vy));
-  for (int cy = cy0; cy <= cy1; ++cy) {
-    const int ky = c.ky0 + cy;
-    const double qy = (static_cast<double>(ky) + 0.5) * c.res - yf;
-    for (int wbase = cx0 & ~31; wbase <= cx1; wbase += 32) {
-      uint32_t m = bits[cy * c.wpr + (wbase >> 5)];
-      if (wbase < cx0) m &= 0xFFFFFFFFu << (cx0 - wbase);
-      if (cx1 - wbase < 31) m &= 0xFFFFFFFFu >> (31 - (cx1 - wbase));
-      while (m) {
-        const int b = __ffs(static_cast<int>(m)) - 1;
-        m &= m - 1;
-        const int kx = c.kx0 + wbase + b;
-        const double qx = (static_cast<double>(kx) + 0.5) * c.res - xf;
-        if (fabs(qx) > h + ex) continue;
-        if (fabs(qy) > h + ey) continue;
-        if (fabs(qx * ux + qy * uy) > c.a + hu) continue;
-        if (fabs(qx * vx + qy * vy) > c.b + hv) continue;
-        return true;
-      }
-    }
-  }
-  return false;
-}
-
-// ===========================================================================
-// K1a: roll-out.  One lane per sample: the recurrence x_{k+1} = x_k + (...) is
-// serial in k and keeps the reference's addition order (path.h:24-30).  The
-// float path leaves through an LDS tile so the sample-major rows are written as
-// whole contiguous lines; the double poses go out step-major (coalesced) for
-// the collision pass.
-// ===========================================================================
-constexpr int kRollBlock = 64;
-
-__global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int P1 = a.P | 1;  // odd row pitch: conflict-free column writes
-  float *tx = reinterpret_cast<float *>(smem);
-  float *ty = tx + (size_t)kRollBlock * P1;
-
-  const int tid = threadIdx.x;
-  const int base = blockIdx.x * kRollBlock;
-  const int n = base + tid;
-
-  if (n < a.n) {
-    const double vx = a.vx[a.first + n];
-    const double vy = a.vy[a.first + n];
-    const int r = a.row[a.first + n];
-    double x = a.x0, y = a.y0;
-    const float fx0 = static_cast<float>(x), fy0 = static_cast<float>(y);
-    if (a.stage) {
-      tx[tid * P1] = fx0;
-      ty[tid * P1] = fy0;
-    } else {
-      a.px[(size_t)n * a.P] = fx0;
-      a.py[(size_t)n * a.P] = fy0;
-    }
-    const bool want_pos = a.c.enabled != 0;
-    // all trig rows of (up to) 64 steps are requested at once and held in
-    // registers, so the serial recurrence pays the memory latency once
-    constexpr int CH = 64;
-    double2 tr[CH];
-    const int steps = a.P - 1;
-    for (int k0 = 0; k0 < steps; k0 += CH) {
-#pragma unroll
-      for (int j = 0; j < CH; ++j)
-        tr[j] = a.trig[(size_t)min(k0 + j, steps - 1) * a.A + r];
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const int k = k0 + j;
-        if (k < steps) {
-          const double2 cs = tr[j];
-          // Path::State::update, datatypes/path.h:24-30
-          x += (vx * cs.x - vy * cs.y) * a.dt;
-          y += (vx * cs.y + vy * cs.x) * a.dt;
-          if (want_pos) a.pos[(size_t)(k + 1) * a.n + n] = make_double2(x, y);
-          const float fx = static_cast<float>(x), fy = static_cast<float>(y);
-          if (a.stage) {
-            tx[tid * P1 + k + 1] = fx;
-            ty[tid * P1 + k + 1] = fy;
-          } else {
-            a.px[(size_t)n * a.P + k + 1] = fx;
-            a.py[(size_t)n * a.P + k + 1] = fy;
-          }
-        }
-      }
-    }
-    a.flags[n] = 1;
-  }
-
-  if (a.stage) {
-    __syncthreads();
-    // the block's 64 rows are one contiguous [64*P] range of each plane
-    const int rows = min(kRollBlock, a.n - base);
-    const int total = rows * a.P;
-    float *gx = a.px + (size_t)base * a.P;
-    float *gy = a.py + (size_t)base * a.P;
-    int s = 0, k = tid;
-    while (k >= a.P) {
-      k -= a.P;
-      ++s;
-    }
-    for (int i = tid; i < total; i += kRollBlock) {
-      gx[i] = tx[s * P1 + k];
-      gy[i] = ty[s * P1 + k];
-      k += kRollBlock;
-      while (k >= a.P) {
-        k -= a.P;
-        ++s;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Dilated occupancy masks (once per sensor update).  For a pose in cell c and
-// an occupied cell at integer offset (i, j) the clamped distance d used by the
-// exact tests obeys  res*hypot((|i|-1)+, (|j|-1)+) <= d <= res*hypot(i, j),
-// so with rho = radius / res (in cells, 1e-6 of slack for the rounding of the
-// pose's own cell index):
-//   inner: hypot(i, j) <= rho_in - 1e-6            -> collision certain
-//   outer: hypot((|i|-1)+, (|j|-1)+) <= rho_out + 1e-6 -> collision possible
-// Both sets are runs per row offset j (half widths win[|j|], wout[|j|]; -1 =
-// empty).  One thread per output word; a row is dilated horizontally from the
-// three words around the output word (half widths <= 31).
-// ---------------------------------------------------------------------------
-constexpr int kMaxDil = 32;
-struct DilArgs {
-  const uint32_t *g;
-  uint32_t *inner, *outer;
-  int H, wpr, R;
-  signed char win[kMaxDil + 1], wout[kMaxDil + 1];
-};
-__device__ __forceinline__ uint32_t hdilate(uint32_t left, uint32_t mid, uint32_t right, int w) {
-  uint32_t acc = mid;
-  for (int s = 1; s <= w; ++s)
-    acc |= (mid << s) | (left >> (32 - s)) | (mid >> s) | (right << (32 - s));
-  return acc;
-}
-__global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.H * a.wpr) return;
-  const int y = t / a.wpr, w = t - y * a.wpr;
-  uint32_t in_acc = 0u, out_acc = 0u;
-  for (int j = -a.R; j <= a.R; ++j) {
-    const int yy = y + j;
-    if (yy < 0 || yy >= a.H) continue;
-    const uint32_t *row = a.g + (size_t)yy * a.wpr;
-    const uint32_t mid = row[w];
-    const uint32_t left = w > 0 ? row[w - 1] : 0u;
-    const uint32_t right = w + 1 < a.wpr ? row[w + 1] : 0u;
-    if ((mid | left | right) == 0u) continue;
-    const int aj = j < 0 ? -j : j;
-    if (a.win[aj] >= 0) in_acc |= hdilate(left, mid, right, a.win[aj]);
-    if (a.wout[aj] >= 0) out_acc |= hdilate(left, mid, right, a.wout[aj]);
-  }
-  a.inner[t] = in_acc;
-  a.outer[t] = out_acc;
-}
-
-// ===========================================================================
-// K1 (fused): roll-out + collision gate of 32 samples per workgroup, no global
-// round trip in between.  512 lanes: (A) copy the occupancy bits of the
-// reachable window into LDS (word aligned with the sensor bitmap) and fetch the trig
-// rows into LDS (every load in flight at once), (B) wavefront 0 runs the 64
-// serial recurrences LDS -> LDS (pose k+1 replaces trig row k in place),
-// (C) all lanes convert the poses to the float sample-major rows (coalesced)
-// and test one pose each against the LDS bits; a hit marks the sample.
-// ===========================================================================
-template <int kFusedSamples, int kFusedBlock>
-__global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int PP = a.P | 1;  // pitch of a sample's row in 16-byte slots
-  double2 *lpos = reinterpret_cast<double2 *>(smem);
-  uint32_t *lbits = reinterpret_cast<uint32_t *>(
-      smem + (size_t)kFusedSamples * PP * sizeof(double2));
-  const int nwin = a.c.enabled ? a.c.H * a.c.wpr : 0;
-  uint32_t *linner = lbits + nwin;                 // a.c.dil only
-  uint32_t *louter = linner + (a.c.dil ? nwin : 0);
-  int *lcand = reinterpret_cast<int *>(louter + (a.c.dil ? nwin : 0));  // [samples * P]
-  __shared__ int ncand;
-  __shared__ int lhit[kFusedSamples];
-  __shared__ int lperm[kFusedSamples];  // local sample id of slot s
-  __shared__ int lrow[kFusedSamples];   // its trig row
-  __shared__ double lvx[kFusedSamples], lvy[kFusedSamples];
-
-  const int tid = threadIdx.x;
-  const int base = blockIdx.x * kFusedSamples;
-  const int rows = min(kFusedSamples, a.n - base);
-  const int steps = a.P - 1;
-
-  KC_RSTAMP(0);
-  // ---- A: window bits + trig rows -----------------------------------------
-  if (tid < kFusedSamples) {
-    lhit[tid] = 0;
-    const bool in = tid < rows;
-    lperm[tid] = in ? a.perm[base + tid] : 0;
-    lrow[tid] = in ? a.prow[base + tid] : 0;
-    lvx[tid] = in ? a.pvx[base + tid] : 0.0;
-    lvy[tid] = in ? a.pvy[base + tid] : 0.0;
-  }
-  if (a.c.enabled) {
-    // window origin is word aligned with the sensor bitmap: whole-word copies
-    const int nwords = a.c.H * a.c.wpr;
-    const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;  // exact: difference is a multiple of 32
-    for (int i = tid; i < nwords; i += kFusedBlock) {
-      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
-      const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
-      uint32_t v = 0u, vi = 0u, vo = 0u;
-      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
-        const size_t g = (size_t)gy * a.c.gwpr + gw;
-        v = a.c.gbits[g];
-        if (a.c.dil) {
-          vi = a.c.ginner[g];
-          vo = a.c.gouter[g];
-        }
-      }
-      lbits[i] = v;
-      if (a.c.dil) {
-        linner[i] = vi;
-        louter[i] = vo;
-      }
-    }
-  }
-  if (tid == 0) ncand = 0;
-  KC_RSTAMP(1);
-  if (a.trig_flag) {
-    // wait for the host's table (system-scope loads: the word and the table
-    // arrive over PCIe, behind this GPU's caches).  Bounded: ~50 ms.
-    __shared__ int s_late;
-    if (tid == 0) {
-      int late = 0;
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(a.trig_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) !=
-             a.trig_seq) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {
-          late = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
-      s_late = late;
-    }
-    __syncthreads();
-    KC_RSTAMP(2);
-    if (s_late) {  // give the cycle up: nothing admissible, error word set
-      if (tid < rows) a.flags[lperm[tid]] = 0;
-      if (tid == 0) *a.dev_err = 1;
-      return;
-    }
-    const int s = tid & (kFusedSamples - 1);
-    if (s < rows) {
-      const int r = lrow[s];
-      const double *tg = reinterpret_cast<const double *>(a.trig);
-      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
-        const size_t e = ((size_t)k * a.A + r) * 2;
-        const double cs = __hip_atomic_load(tg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const double sn = __hip_atomic_load(tg + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        lpos[s * PP + k] = make_double2(cs, sn);
-      }
-    }
-  } else {
-    __syncthreads();  // lrow
-    const int s = tid & (kFusedSamples - 1);
-    if (s < rows) {
-      const int r = lrow[s];
-      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples)
-        lpos[s * PP + k] = a.trig[(size_t)k * a.A + r];
-    }
-  }
-  __syncthreads();
-  KC_RSTAMP(3);
-  // ---- B: recurrences.  Path::State::update (datatypes/path.h:24-30) is
-  //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt;
-  // the increments do not depend on the running sums, so every lane forms some
-  // of them first (in place over the trig entries), and only the additions -
-  // whose order fixes the rounding - run as a serial chain per sample.
-  for (int i = tid; i < rows * steps; i += kFusedBlock) {
-    const int s = i / steps, k = i - s * steps;
-    const double vx = lvx[s], vy = lvy[s];
-    const double2 cs = lpos[s * PP + k];
-    const double tx = vx * cs.x - vy * cs.y;
-    const double ty = vx * cs.y + vy * cs.x;
-    lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
-  }
-  __syncthreads();
-  KC_RSTAMP(7);
-  if (tid < rows) {
-    // sixteen increments per register chunk: one LDS latency per chunk instead
-    // of one per step
-    constexpr int kChunk = 16;
-    double x = a.x0, y = a.y0;
-    double2 *mine = lpos + tid * PP;
-    int k = 0;
-    for (; k + kChunk <= steps; k += kChunk) {
-      double2 v[kChunk];
-#pragma unroll
-      for (int j = 0; j < kChunk; ++j) v[j] = mine[k + j];
-#pragma unroll
-      for (int j = 0; j < kChunk; ++j) {
-        x += v[j].x;
-        y += v[j].y;
-        v[j] = make_double2(x, y);  // pose k + j + 1
-      }
-#pragma unroll
-      for (int j = 0; j < kChunk; ++j) mine[k + j] = v[j];
-    }
-    for (; k < steps; ++k) {
-      const double2 inc = mine[k];
-      x += inc.x;
-      y += inc.y;
-      mine[k] = make_double2(x, y);
-    }
-  }
-  __syncthreads();
-  KC_RSTAMP(4);
-  // ---- C: float rows out; poses classified with the dilated masks, the
-  // undecided ones queued and tested exactly by densely packed lanes ----------
-  {
-    const int total = rows * a.P;
-    int s = 0, k = tid;
-    while (k >= a.P) {
-      k -= a.P;
-      ++s;
-    }
-    for (int i = tid; i < total; i += kFusedBlock) {
-      double2 p;
-      if (k == 0) p = make_double2(a.x0, a.y0);
-      else p = lpos[s * PP + k - 1];
-      const size_t o = (size_t)lperm[s] * a.P + k;  // sample-major rows
-      a.px[o] = static_cast<float>(p.x);
-      a.py[o] = static_cast<float>(p.y);
-      if (a.c.enabled && k > 0) {
-        bool exact = true;
-        if (a.c.dil) {
-          const double dx = p.x - a.c.tx, dy = p.y - a.c.ty;
-          const double xf = a.c.r00 * dx + a.c.r10 * dy;
-          const double yf = a.c.r01 * dx + a.c.r11 * dy;
-          const int cx = static_cast<int>(floor(xf * a.c.inv)) - a.c.kx0;
-          const int cy = static_cast<int>(floor(yf * a.c.inv)) - a.c.ky0;
-          if (cx >= 0 && cx < a.c.W && cy >= 0 && cy < a.c.H) {
-            const int w = cy * a.c.wpr + (cx >> 5);
-            const uint32_t bit = 1u << (cx & 31);
-            if (linner[w] & bit) {
-              lhit[s] = 1;  // every writer stores the same value
-              exact = false;
-            } else if (!(louter[w] & bit)) {
-              exact = false;
-            }
-          }
-        }
-        if (exact) lcand[atomicAdd(&ncand, 1)] = (s << 16) | k;
-      }
-      k += kFusedBlock;
-      while (k >= a.P) {
-        k -= a.P;
-        ++s;
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const int nc = ncand;
-    for (int i = tid; i < nc; i += kFusedBlock) {
-      const int s = lcand[i] >> 16, k = lcand[i] & 0xFFFF;
-      if (lhit[s]) continue;  // already decided (stale reads only cost work)
-      const double2 p = lpos[s * PP + k - 1];
-      bool hit;
-      if (a.c.shape == KC_BOX) {
-        const size_t e = (size_t)k * a.A + lrow[s];  // yaw_k
-        double2 t;
-        if (a.trig_flag) {
-          const double *tg = reinterpret_cast<const double *>(a.trig);
-          t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else {
-          t = a.trig[e];
-        }
-        hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y);
-      } else {
-        hit = hit_round(a.c, lbits, p.x, p.y);
-      }
-      if (hit) lhit[s] = 1;
-    }
-  }
-  __syncthreads();
-  KC_RSTAMP(5);
-  if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
-    const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
-    if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
-    const unsigned long long bal = __ballot(ok);
-    const int cnt = __popcll(bal);
-    int start = 0;
-    if (tid == 0 && cnt)
-      start = static_cast<int>(atomicAdd(
-          reinterpret_cast<unsigned long long *>(a.adm_count),
-          static_cast<unsigned long long>(cnt)));
-    start = __shfl(start, 0, 64);
-    if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = lperm[tid];
-  }
-  KC_RSTAMP(6);
-}
-
-// ===========================================================================
-// K1b: collision gate.  A sample is dropped as soon as ANY of its poses
-// collides (trajectory_sampler.cpp:147-152 with drop_samples_ == true), so the
-// (step, sample) pairs are independent: one lane per pose, occupancy bits of
-// the reachable window staged in LDS, a hit clears the sample's flag (every
-// writer stores the same 0).
-// ===========================================================================
-constexpr int kCollBlock = 256;
-
-__global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);
-  if (a.c.lds) {
-    const int nwords = a.c.H * a.c.wpr;
-    for (int i = threadIdx.x; i < nwords; i += kCollBlock) lbits[i] = a.c.bits[i];
-    __syncthreads();
-  }
-  const long t = (long)blockIdx.x * kCollBlock + threadIdx.x;
-  if (t >= (long)a.n * (a.P - 1)) return;
-  const int k = static_cast<int>(t / a.n) + 1;  // pose index 1..P-1
-  const int n = static_cast<int>(t - (long)(k - 1) * a.n);
-  const double2 p = a.pos[(size_t)k * a.n + n];
-  bool hit;
-  if (a.c.shape == KC_BOX) {
-    const double2 cs = a.trig[(size_t)k * a.A + a.row[a.first + n]];  // yaw_k
-    hit = a.c.lds ? hit_box(a.c, lbits, p.x, p.y, cs.x, cs.y)
-                  : hit_box(a.c, a.c.bits, p.x, p.y, cs.x, cs.y);
-  } else {
-    hit = a.c.lds ? hit_round(a.c, lbits, p.x, p.y)
-                  : hit_round(a.c, a.c.bits, p.x, p.y);
-  }
-  if (hit) a.flags[n] = 0;
-}
-
-// batch pose check (CollisionChecker::checkCollisions for arbitrary poses):
-// occupancy bits read from global memory, cos/sin(yaw) from the host table
-__global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
-                                  const double2 *__restrict__ cs, int n,
-                                  uint8_t *__restrict__ hit) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double2 p = pos[i];
-  bool h;
-  if (c.shape == KC_BOX) {
-    const double2 t = cs[i];
-    h = hit_box(c, c.bits, p.x, p.y, t.x, t.y);
-  } else {
-    h = hit_round(c, c.bits, p.x, p.y);
-  }
-  hit[i] = h ? 1 : 0;
-}
-
-// ===========================================================================
-// K2: cost of every admissible sample + per-workgroup argmin.  One WAVEFRONT
-// per sample (sixteen samples in flight per workgroup), one lane per
-// trajectory point; the search tables sit in LDS, filled once per workgroup.
-//
-// Tracked segment (pathCostFunc inner loops, cost_evaluator.cpp:120-130, and
-// goalCostFunc's closest-point search, :157-166): d2 = dx*dx + (dy*dy + dz*dz)
-// in float, the lowest index winning ties (the reference's strict `<` in index
-// order); min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt,
-// so one sqrt per point; the END point's search also yields the goal cost
-// ((a-b)^2 == (b-a)^2 bit for bit).  Instead of all S points a lane evaluates
-// (1) the first point of every chunk of the segment, (2) a bounding-sphere
-// test per chunk against that upper bound (|q - p_j| >= |q - c| - r; spheres
-// from the host, 1e-4 relative slack, non-finite chunks always qualify), and
-// (3) every remaining point of the chunks that may hold something closer - the
-// same minimum and the same lowest index as the full scan.
-//
-// Obstacles (TrajectoryPath::minDist2D, trajectory.h:218-235): float
-// difference, squares and sum in double, rounded to float once; the rounding
-// is monotonic, so the minimum is taken in double and rounded later.  Instead
-// of the reference's brute force over all O obstacles the points are bucketed
-// on a uniform grid (host, once per sensor update) with a Chebyshev distance
-// table to the nearest non-empty cell.  A lane searches square rings of cells
-// outwards from the first ring that can hold a point.  A block of half-width m
-// contains every obstacle closer than m*g, so once the best squared distance
-// is below (m*g)^2 (1e-6 relative guard, four orders above the float rounding
-// of the differences) nothing outside can beat it.  Only the minimum over the
-// whole trajectory is used (obstaclesDistCostFunc, cost_evaluator.cpp:179-184),
-// so the lanes of a sample share their best distance: a lane whose unvisited
-// cells are all farther than what another lane already found stops, and so
-// does one that has covered max_obstacles_dist (those distances cost 0).
-//
-// The weighted total follows the reference's accumulation order
-// (cost_evaluator.cpp:59-100: float total, each += a double multiply-add
-// rounded once; the path-cost sum walks the points in order with
-// v_readlane).  Every workgroup leaves its best (cost, index) key for
-// publish_kernel.
-// ===========================================================================
-constexpr int kCostBlock = 1024;  // 16 wavefronts = 16 samples in flight, one workgroup per CU
-constexpr int kCostWaves = kCostBlock / 64;
-constexpr int kCostGrid = 256;    // one workgroup per CU
-// LDS the search tables of a workgroup may take
-constexpr size_t kCostLdsBudget = 150 * 1024;
-constexpr int kSegChunkMin = 16;
-constexpr long long kBlockKernelMaxAdm = 1024;  // longest list the workgroup-per-sample kernel gets  // segment points per bounding sphere (at most 64 chunks)
-
-struct BucketDev {
-  int W, H;            // cells
-  double gx0, gy0;     // origin
-  double g, inv_g;     // cell edge
-  double cap;          // max_obstacles_dist * 1.001 (search never needs more)
-  const int *cell_start;   // [W*H + 1]
-  const float *bx, *by;    // obstacle coordinates in cell order
-  const uint8_t *skip;     // [W*H] Chebyshev distance (cells, saturated at 255)
-                           // to the nearest non-empty cell: the first block
-                           // searched is the smallest that can contain a point
-  int nobs;                // finite obstacles in bx/by
-};
-
-// device result record (long long slots)
-enum { R_KEY = 0, R_NADM = 1, R_COMPACT = 2, R_SPARE = 3,   // published
-       W_KEY = 4, W_NADM = 5, W_TICKET = 6, W_LIST = 7,     // working area
-       R_SCRATCH = 8, R_TRIGSEQ = 9,  // host-written (BAR): sequence of the trig table in d_trig
-       R_SLOTS = 10 };
-
-struct CostArgs {
-  int n, first, P, S, O;
-  int use_seg, use_obs, have_vel;
-  const float *px, *py;
-  const uint8_t *flags;
-  const int *adm_list;            // admissible local sample ids (any order)
-  const long long *adm_count;     // device-side count (result[W_LIST])
-  const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the
-                                               // chunk spheres [4][nch]: cx, cy, cz, r
-  int seg_chunk, nch;             // points per chunk, chunk count (<= 64)
-  float seg_len, ref_len;
-  BucketDev b;
-  const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
-  float max_obs_dist;
-  float acc0, acc1, acc2;
-  double w_path, w_goal, w_obs, w_smooth, w_jerk;
-  float *costs;
-  long long *result;    // R_* published record + W_* working area
-  long long *block_keys;  // [gridDim.x] best key of every workgroup (publish_kernel reduces)
-  unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS): per-block phase clocks
-};
-
-#ifdef KC_PHASE_STAMPS
-#define KC_STAMP(slot)                                                     \
-  do {                                                                     \
-    if (a.dbg && threadIdx.x == 0)                                         \
-      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-#else
-#define KC_STAMP(slot) do { } while (0)
-#endif
-
-__device__ __forceinline__ float accum(float total, double w, float c) {
-  return static_cast<float>(static_cast<double>(total) +
-                            w * static_cast<double>(c));
-}
-__device__ __forceinline__ float sq_over(float total, float d, float lim) {
-  // smoothness_cost += std::pow(delta, 2) / accLimits_[i]  (double, then float)
-  const double dd = static_cast<double>(d);
-  return static_cast<float>(static_cast<double>(total) +
-                            (dd * dd) / static_cast<double>(lim));
-}
-// Wave-wide unsigned minimum on the DPP path (four cross-lane ALU steps inside
-// each row of 16, then four scalar row reads) instead of six ds_bpermute round
-// trips: the searches are latency chains, and a bpermute costs about as much
-// as an LDS access.  All 64 lanes must be active; the result is wave-uniform.
-template <int kCtrl>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
-  return static_cast<uint32_t>(
-      __builtin_amdgcn_update_dpp(0, static_cast<int>(v), kCtrl, 0xf, 0xf, false));
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
-  v = min(v, dpp_u32<0x140>(v));  // row_mirror
-  const uint32_t r0 = __builtin_amdgcn_readlane(static_cast<int>(v), 0);
-  const uint32_t r1 = __builtin_amdgcn_readlane(static_cast<int>(v), 16);
-  const uint32_t r2 = __builtin_amdgcn_readlane(static_cast<int>(v), 32);
-  const uint32_t r3 = __builtin_amdgcn_readlane(static_cast<int>(v), 48);
-  return min(min(r0, r1), min(r2, r3));
-}
-// the same inside each aligned group of eight lanes (three DPP steps; every
-// lane of the group ends up with the group's minimum)
-__device__ __forceinline__ uint32_t group8_min_u32(uint32_t v) {
-  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
-  return v;
-}
-__device__ __forceinline__ double group8_min_nonneg(double v) {
-  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
-  const uint32_t hi = static_cast<uint32_t>(u >> 32), lo = static_cast<uint32_t>(u);
-  const uint32_t mh = group8_min_u32(hi);
-  const uint32_t ml = group8_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
-  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(mh) << 32) | ml));
-}
-// minimum of non-negative, non-NaN doubles (their bit patterns order like the
-// values): high words first, then the low words of the lanes that tie
-__device__ __forceinline__ double wave_min_nonneg(double v) {
-  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
-  const uint32_t hi = static_cast<uint32_t>(u >> 32), lo = static_cast<uint32_t>(u);
-  const uint32_t mh = wave_min_u32(hi);
-  const uint32_t ml = wave_min_u32(hi == mh ? lo : 0xFFFFFFFFu);
-  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(mh) << 32) | ml));
-}
-__device__ __forceinline__ float lane_value(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-// ---------------------------------------------------------------------------
-// K2b: the same costs for SHORT admissible lists (a cluttered scene leaves a few
-// hundred samples): one workgroup per sample, eight lanes per trajectory point,
-// so that a sample's searches are spread over eight wavefronts instead of being
-// one long chain in a single one.  Brute-force segment scan (eight lanes per
-// point), block search around the query cell, same arithmetic and the same
-// results as sample_cost_kernel; the host picks the kernel from the admissible
-// count of the previous cycle.
-// ---------------------------------------------------------------------------
-constexpr int kBlkCostBlock = 512;  // 8 wavefronts, two workgroups per CU
-constexpr size_t kBlkLdsBudget = 78 * 1024;
-template <bool kLds, bool kObsLds>
-__global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(CostArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  float *s_mind = reinterpret_cast<float *>(smem);               // [P]
-  float *s_px = s_mind + a.P;                                    // [P]
-  float *s_py = s_px + a.P;                                      // [P]
-  __shared__ float s_goal, s_end;
-  __shared__ long long s_key;
-  __shared__ unsigned long long s_obest;  // sample-wide min squared obstacle distance (double bits)
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
-    const int na = static_cast<int>(*a.adm_count);
-  // blocks beyond the admissible count have nothing to do and take no ticket
-  const unsigned working = static_cast<unsigned>(min(static_cast<int>(gridDim.x), max(na, 1)));
-  if (blockIdx.x >= working) {
-    if (threadIdx.x == 0) a.block_keys[blockIdx.x] = KEY_NONE;
-    return;
-  }
-  if (threadIdx.x == 0) s_key = KEY_NONE;
-
-  const BucketDev &b = a.b;
-  // LDS layout after the per-sample arrays: five segment rows, the cell table,
-  // the skip table (padded to words), the obstacle coordinates.  The pointers
-  // are chosen at compile time so that the LDS variants issue ds_read, not
-  // flat loads.
-  const int ncell = b.W * b.H;
-  float *const l_seg = s_py + a.P;
-  int *const l_cells = reinterpret_cast<int *>(l_seg + (a.use_seg ? 5 * a.S : 0));
-  uint8_t *const l_skip = reinterpret_cast<uint8_t *>(l_cells + (a.use_obs ? ncell + 1 : 0));
-  float *const l_obs = reinterpret_cast<float *>(l_skip + (a.use_obs ? ((ncell + 3) & ~3) : 0));
-  const int *const cells = kLds ? l_cells : b.cell_start;
-  const uint8_t *const skip = kLds ? l_skip : b.skip;
-  const float *const obx = kObsLds ? l_obs : b.bx;
-  const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
-  const float *const sx = kLds ? l_seg : a.sx;
-  const float *const sy = kLds ? l_seg + a.S : a.sy;
-  const float *const sz = kLds ? l_seg + 2 * a.S : a.sz;
-  const float *const szz = kLds ? l_seg + 3 * a.S : a.szz;
-  const float *const sacc = kLds ? l_seg + 4 * a.S : a.acc_seg;
-  if (kLds) {
-    if (a.use_seg) {
-      // the five rows are contiguous in global memory too (d_seg)
-#pragma unroll 4
-      for (int j = threadIdx.x; j < 5 * a.S; j += kBlkCostBlock) l_seg[j] = a.sx[j];
-    }
-    if (a.use_obs) {
-#pragma unroll 4
-      for (int j = threadIdx.x; j <= ncell; j += kBlkCostBlock) l_cells[j] = b.cell_start[j];
-      // the skip table is padded to a multiple of 4 bytes on the host
-      const uint32_t *gs = reinterpret_cast<const uint32_t *>(b.skip);
-      uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
-      for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kBlkCostBlock) ls[j] = gs[j];
-      if (kObsLds) {
-#pragma unroll 4
-        for (int j = threadIdx.x; j < b.nobs; j += kBlkCostBlock) {
-          l_obs[j] = b.bx[j];
-          l_obs[b.nobs + j] = b.by[j];
-        }
-      }
-    }
-  }
-
-  for (int i = blockIdx.x; i < na; i += gridDim.x) {
-    const int n = a.adm_list[i];
-    if (threadIdx.x == 0)
-      s_obest = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
-    if (threadIdx.x < a.P) {
-      s_px[threadIdx.x] = a.px[(size_t)n * a.P + threadIdx.x];
-      s_py[threadIdx.x] = a.py[(size_t)n * a.P + threadIdx.x];
-    }
-    for (int k = kBlkCostBlock + threadIdx.x; k < a.P; k += kBlkCostBlock) {
-      s_px[k] = a.px[(size_t)n * a.P + k];
-      s_py[k] = a.py[(size_t)n * a.P + k];
-    }
-    __syncthreads();  // also covers the structure copy above
-    // ---- eight lanes per trajectory point (64 points per pass) ----------------
-    // Idle groups (beyond P) work on a clamped point and write nothing, so
-    // the cross-lane steps always see active lanes.
-    const int sub = threadIdx.x & 7;
-    for (int p0 = 0; p0 < a.P; p0 += kBlkCostBlock / 8) {
-      const int pp = p0 + (threadIdx.x >> 3);
-      const bool live = pp < a.P;
-      const int p = live ? pp : a.P - 1;
-      const float x = s_px[p], y = s_py[p];
-      if (a.use_seg) {
-        float best = FLT_MAX;
-        int arg = 0;
-#pragma unroll 4
-        for (int j = sub; j < a.S; j += 8) {  // j ascending per lane
-          const float dx = sx[j] - x;
-          const float dy = sy[j] - y;
-          const float xx = dx * dx;
-          const float yy = dy * dy;
-          const float d = xx + (yy + szz[j]);  // Eigen order a + (b + c)
-          if (d < best) {
-            best = d;
-            arg = j;
-          }
-        }
-        // non-negative floats order like their bit patterns; ties go to the
-        // lowest segment index (the reference's strict `<` in index order)
-        const uint32_t mine = __float_as_uint(best);
-        const uint32_t mbits = group8_min_u32(mine);
-        arg = static_cast<int>(
-            group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
-        best = __uint_as_float(mbits);
-        if (sub == 0 && live) {
-          s_mind[p] = kc::sqrt_rn(best);
-          if (p == a.P - 1) {
-            // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
-            const float arc = kc::div_rn(a.ref_len - sacc[arg], a.ref_len);
-            s_goal = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
-            // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
-            const int e = a.S - 1;
-            const float dx = x - sx[e], dy = y - sy[e], dz = 0.0f - sz[e];
-            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-            s_end = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
-          }
-        }
-      }
-      if (a.use_obs) {
-        // query cell (clamped: a query outside the grid searches from the
-        // border and the guarantee radius shrinks by its distance to the grid)
-        const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-        const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-        int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-        double off = 0.0;
-        if (fx < 0.0) off = fmax(off, -fx);
-        if (fy < 0.0) off = fmax(off, -fy);
-        if (fx > b.W) off = fmax(off, fx - b.W);
-        if (fy > b.H) off = fmax(off, fy - b.H);
-        cx = min(max(cx, 0), b.W - 1);
-        cy = min(max(cy, 0), b.H - 1);
-        double best = DBL_MAX;
-        const int mmax = max(b.W, b.H);
-        // first block: just large enough to contain the nearest non-empty cell;
-        // following blocks: just large enough to prove the best distance found
-        int m = max(1, static_cast<int>(skip[cy * b.W + cx]));
-        for (;;) {  // uniform within the group of eight, divergent between groups
-          const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-          const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-          // a row of the block is a contiguous run of the cell-ordered obstacle
-          // list: four rows per pass, two lanes per row
-          for (int row = y0 + (sub >> 1); row <= y1; row += 4) {
-            const int beg = cells[row * b.W + x0];
-            const int end = cells[row * b.W + x1 + 1];
-            for (int j = beg + (sub & 1); j < end; j += 2) {
-              const double dx = static_cast<double>(obx[j] - x);
-              const double dy = static_cast<double>(oby[j] - y);
-              const double dd = dx * dx + dy * dy;
-              best = dd < best ? dd : best;
-            }
-          }
-          best = group8_min_nonneg(best);
-          // Only the minimum over the whole sample is used (trajectory.h:218-235
-          // inside obstaclesDistCostFunc), so the points of a sample share
-          // their best distance: a point stops as soon as everything it has
-          // not visited yet is farther than what some point already found.
-          if (sub == 0 && live)
-            atomicMin(&s_obest, static_cast<unsigned long long>(__double_as_longlong(best)));
-          const double shared = __longlong_as_double(static_cast<long long>(
-              *const_cast<volatile unsigned long long *>(&s_obest)));
-          // every obstacle closer than `reach` (true distance) was visited
-          const double reach = (static_cast<double>(m) - off) * b.g;
-          if (reach > 0.0) {
-            const double r2 = reach * reach * (1.0 - 1e-6);
-            if (shared < r2) break;
-            if (reach >= b.cap) break;
-          }
-          if (m >= mmax) break;  // whole grid visited
-          // next half-width: enough cells to cover sqrt(shared) (+ guard), or
-          // the cap radius when nothing has been found yet (any over-estimate
-          // only visits more cells: float sqrt is enough)
-          const double need =
-              shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
-                               : b.cap;
-          const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
-          m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-        }
-      }
-    }
-    __syncthreads();
-    // ---- wavefront 0: weighted total of this sample ---------------------------
-    if (wave == 0) {
-      float total = 0.0f;
-      if (a.ref_len > 0.0f) {
-        if (a.w_goal > 0.0) total = accum(total, a.w_goal, s_goal);
-        if (a.w_path > 0.0) {
-          // pathCostFunc, cost_evaluator.cpp:111-141: ordered float sum
-          float sum = 0.0f;
-          for (int base = 0; base < a.P; base += 64) {
-            const int cnt = min(64, a.P - base);
-            const float v = (lane < cnt) ? s_mind[base + lane] : 0.0f;
-            for (int k = 0; k < cnt; ++k) sum += lane_value(v, k);
-          }
-          const float c = kc::div_rn(
-              kc::div_rn(sum, static_cast<float>(a.P)) + s_end, 2.0f);
-          total = accum(total, a.w_path, c);
-        }
-      }
-      if (a.O > 0 && a.w_obs > 0.0) {
-        // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
-        const double best = __longlong_as_double(static_cast<long long>(s_obest));
-        const float min_d2 = static_cast<float>(best);
-        const float dist =
-            static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
-        float v = a.max_obs_dist - dist;
-        v = v < 0.0f ? 0.0f : v;
-        total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
-      }
-      if (a.have_vel) {
-        // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
-        // evaluated redundantly by every lane (wave-uniform addresses)
-        const int nv = a.P - 1;
-        const float *vx = a.vvx + (size_t)n * nv;
-        const float *vy = a.vvy + (size_t)n * nv;
-        const float *om = a.vom + (size_t)n * nv;
-        const float div = static_cast<float>(3L * nv);
-        if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
-          float c = 0.0f;
-          for (int k = 1; k < nv; ++k) {
-            if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
-            if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
-            if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
-          }
-          total = accum(total, a.w_smooth, kc::div_rn(c, div));
-        }
-        if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
-          float c = 0.0f;
-          for (int k = 2; k < nv; ++k) {
-            if (a.acc0 > 0)
-              c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
-            if (a.acc1 > 0)
-              c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
-            if (a.acc2 > 0)
-              c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
-          }
-          total = accum(total, a.w_jerk, kc::div_rn(c, div));
-        }
-      }
-      // constant-velocity samples: both terms are exactly 0 and `total += w*0`
-      // leaves total unchanged, so nothing to do when !have_vel.
-      if (lane == 0) {
-        a.costs[n] = total;
-        if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
-          const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
-          if (k < s_key) s_key = k;
-        }
-      }
-    }
-    __syncthreads();  // LDS minima are reused by the next sample
-  }
-
-  // ---- block epilogue: the block's best key, for publish_kernel ----------------
-  if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
-}
-
-
-// kLds: the tracked segment (+ chunk spheres), the bucket cell table and the
-// skip table are copied into LDS once per workgroup; kObsLds: the obstacle
-// coordinates too.  Otherwise they are read in place.
-template <bool kLds, bool kObsLds>
-__global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ long long s_key;
-  __shared__ unsigned long long s_obest[kCostWaves];  // per sample: min squared obstacle distance (double bits)
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
-  KC_STAMP(0);
-  const int na = static_cast<int>(*a.adm_count);
-  KC_STAMP(1);
-  const BucketDev &b = a.b;
-  const int ncell = b.W * b.H;
-  const int seg_words = a.use_seg ? 5 * a.S + 4 * a.nch : 0;
-  // LDS layout: segment rows + chunk spheres | cell table | skip table (padded
-  // to words) | obstacle coordinates.  The pointers are chosen at compile time
-  // so that the LDS variants issue ds_read, not flat loads.
-  float *const l_seg = reinterpret_cast<float *>(smem);
-  int *const l_cells = reinterpret_cast<int *>(l_seg + seg_words);
-  uint8_t *const l_skip = reinterpret_cast<uint8_t *>(l_cells + (a.use_obs ? ncell + 1 : 0));
-  float *const l_obs = reinterpret_cast<float *>(l_skip + (a.use_obs ? ((ncell + 3) & ~3) : 0));
-  const int *const cells = kLds ? l_cells : b.cell_start;
-  const uint8_t *const skip = kLds ? l_skip : b.skip;
-  const float *const obx = kObsLds ? l_obs : b.bx;
-  const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
-  const float *const sg = kLds ? l_seg : a.sx;
-  const float *const sx = sg, *const sy = sg + a.S, *const sz = sg + 2 * a.S,
-              *const szz = sg + 3 * a.S, *const sacc = sg + 4 * a.S;
-  const float *const ccx = sg + 5 * a.S, *const ccy = ccx + a.nch, *const ccz = ccy + a.nch,
-              *const ccr = ccz + a.nch;
-  if (threadIdx.x == 0) s_key = KEY_NONE;
-  if (na > 0 && kLds) {
-#pragma unroll 8
-    for (int j = threadIdx.x; j < seg_words; j += kCostBlock) l_seg[j] = a.sx[j];
-    if (a.use_obs) {
-#pragma unroll 8
-      for (int j = threadIdx.x; j <= ncell; j += kCostBlock) l_cells[j] = b.cell_start[j];
-      // the skip table is padded to a multiple of 4 bytes on the host
-      const uint32_t *gs = reinterpret_cast<const uint32_t *>(b.skip);
-      uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
-      for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kCostBlock) ls[j] = gs[j];
-      if (kObsLds) {
-#pragma unroll 8
-        for (int j = threadIdx.x; j < 2 * b.nobs; j += kCostBlock) l_obs[j] = b.bx[j];  // bx | by contiguous
-      }
-    }
-  }
-  __syncthreads();
-  KC_STAMP(6);
-
-  long long wkey = KEY_NONE;
-  // sample i of the list goes to wavefront (i / grid) of workgroup (i % grid):
-  // a short list spreads over all CUs, one wavefront each
-  for (int i = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); i < na;
-       i += kCostWaves * static_cast<int>(gridDim.x)) {
-    const int n = a.adm_list[i];
-    if (lane == 0) s_obest[wave] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
-    float sum = 0.0f;            // ordered path-cost sum, carried over the point tiles
-    float goal = 0.0f, endc = 0.0f;
-    for (int p0 = 0; p0 < a.P; p0 += 64) {
-      const int pp = p0 + lane;
-      const bool live = pp < a.P;
-      const int p = live ? pp : a.P - 1;  // idle lanes shadow the last point, write nothing
-      const float x = a.px[(size_t)n * a.P + p], y = a.py[(size_t)n * a.P + p];
-      float mind = 0.0f, goal_l = 0.0f, end_l = 0.0f;
-#ifdef KC_PHASE_STAMPS
-      const bool st = a.dbg && i == static_cast<int>(blockIdx.x) && p0 == 0;  // first sample of wavefront 0
-#else
-      constexpr bool st = false;
-#endif
-      if (st) KC_STAMP(7);
-      if (a.use_seg) {
-        float best = FLT_MAX;
-        int arg = 0;
-        // (1) the first point of every chunk: ascending index, strict `<`
-#pragma unroll 8
-        for (int c = 0; c < a.nch; ++c) {
-          const int j = c * a.seg_chunk;
-          const float dx = sx[j] - x;
-          const float dy = sy[j] - y;
-          const float xx = dx * dx;
-          const float yy = dy * dy;
-          const float dd = xx + (yy + szz[j]);  // Eigen order a + (b + c)
-          if (dd < best) {
-            best = dd;
-            arg = j;
-          }
-        }
-        if (st) KC_STAMP(8);
-        // (2) chunks that may hold something at least as close: |q - c| - r <= thr,
-        // tested on the squares (no square root per chunk); 1e-4 relative slack
-        // on the bound, 1e-5 on the compared square
-        const float thr = __builtin_sqrtf(best) * 1.0001f;
-        unsigned long long cand = 0ull;
-#pragma unroll 8
-        for (int c = 0; c < a.nch; ++c) {
-          const float dx = ccx[c] - x, dy = ccy[c] - y, dz = ccz[c];
-          const float d2 = dx * dx + dy * dy + dz * dz;
-          const float lim = thr + ccr[c];
-          // qualifies unless provably farther (NaN compares false: qualifies)
-          if (!(d2 > lim * lim * 1.00001f)) cand |= 1ull << c;
-        }
-        if (st) KC_STAMP(9);
-        // (3) the remaining points of those chunks
-        while (cand) {
-          const int c = __ffsll(static_cast<long long>(cand)) - 1;
-          cand &= cand - 1ull;
-          const int j0 = c * a.seg_chunk;
-          const int j1 = min(j0 + a.seg_chunk, a.S);
-          // five points per batch: their LDS reads are in flight together
-          for (int jb = j0 + 1; jb < j1; jb += 5) {
-            float vx[5], vy[5], vz[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-              const int j = min(jb + u, j1 - 1);
-              vx[u] = sx[j];
-              vy[u] = sy[j];
-              vz[u] = szz[j];
-            }
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-              const int j = jb + u;
-              const float dx = vx[u] - x;
-              const float dy = vy[u] - y;
-              const float xx = dx * dx;
-              const float yy = dy * dy;
-              const float dd = xx + (yy + vz[u]);
-              if (j < j1 && (dd < best || (dd == best && j < arg))) {
-                best = dd;
-                arg = j;
-              }
-            }
-          }
-        }
-        if (st) KC_STAMP(10);
-        mind = kc::sqrt_rn(best);
-        if (pp == a.P - 1) {
-          // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
-          const float arc = kc::div_rn(a.ref_len - sacc[arg], a.ref_len);
-          goal_l = arc + kc::div_rn(mind, a.ref_len);
-          // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
-          const int e = a.S - 1;
-          const float dx = x - sx[e], dy = y - sy[e], dz = 0.0f - sz[e];
-          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-          end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
-        }
-      }
-      if (st) KC_STAMP(11);
-      if (a.use_obs) {
-        // query cell (clamped: a query outside the grid searches from the
-        // border and the guarantee radius shrinks by its distance to the grid)
-        const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-        const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-        int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-        double off = 0.0;
-        if (fx < 0.0) off = fmax(off, -fx);
-        if (fy < 0.0) off = fmax(off, -fy);
-        if (fx > b.W) off = fmax(off, fx - b.W);
-        if (fy > b.H) off = fmax(off, fy - b.H);
-        cx = min(max(cx, 0), b.W - 1);
-        cy = min(max(cy, 0), b.H - 1);
-        const int mmax = max(b.W, b.H);
-        const int sk = static_cast<int>(skip[cy * b.W + cx]);
-        // cells closer (Chebyshev) than sk are empty: the first ring is sk, and
-        // nothing is closer than (sk - 1 - off) cells
-        int pm = sk - 1;           // half-width of the block known to be empty / visited
-        int m = max(1, sk);
-        double best = DBL_MAX;
-        bool active = live && !(isnan(fx) || isnan(fy));
-        if ((static_cast<double>(pm) - off) * b.g >= b.cap) active = false;  // all of it costs 0
-        while (__ballot(active)) {
-          if (active) {
-            const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-            const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-            for (int row = y0; row <= y1; ++row) {
-              // rows inside the visited block only add the two side runs
-              const bool inner = pm >= 0 && row >= cy - pm && row <= cy + pm;
-              int beg = cells[row * b.W + x0];
-              int end = inner ? cells[row * b.W + max(cx - pm, x0)]
-                              : cells[row * b.W + x1 + 1];
-              for (int pass = 0; pass < 2; ++pass) {
-                for (int jb = beg; jb < end; jb += 4) {
-                  float ox[4], oy[4];
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) {
-                    const int j = min(jb + u, end - 1);  // repeats of the last one change nothing
-                    ox[u] = obx[j];
-                    oy[u] = oby[j];
-                  }
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) {
-                    const double dx = static_cast<double>(ox[u] - x);
-                    const double dy = static_cast<double>(oy[u] - y);
-                    const double dd = dx * dx + dy * dy;
-                    best = dd < best ? dd : best;
-                  }
-                }
-                if (!inner) break;
-                beg = cells[row * b.W + min(cx + pm, x1) + 1];
-                end = cells[row * b.W + x1 + 1];
-              }
-            }
-            atomicMin(&s_obest[wave], static_cast<unsigned long long>(__double_as_longlong(best)));
-          }
-          // (all lanes: the LDS queue of a wavefront is in order, the read sees every lane's minimum)
-          const double shared = __longlong_as_double(static_cast<long long>(
-              *const_cast<volatile unsigned long long *>(&s_obest[wave])));
-          if (active) {
-            // every obstacle closer than `reach` (true distance) was visited
-            const double reach = (static_cast<double>(m) - off) * b.g;
-            bool done = m >= mmax;  // whole grid visited
-            if (reach > 0.0) {
-              const double r2 = reach * reach * (1.0 - 1e-6);
-              if (shared < r2) done = true;
-              if (reach >= b.cap) done = true;
-            }
-            if (done) {
-              active = false;
-            } else {
-              // next half-width: enough cells to cover sqrt(shared) (+ guard),
-              // or the cap radius when nothing has been found yet (any
-              // over-estimate only visits more cells: float sqrt is enough)
-              const double need =
-                  shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
-                                   : b.cap;
-              const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
-              pm = m;
-              m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-            }
-          }
-        }
-      }
-      if (st) KC_STAMP(12);
-      // ordered path-cost sum of this tile (pathCostFunc, cost_evaluator.cpp:111-141)
-      if (a.use_seg) {
-        const int cnt = min(64, a.P - p0);
-        for (int k = 0; k < cnt; ++k) sum += lane_value(mind, k);
-        if (p0 + 64 >= a.P) {
-          goal = lane_value(goal_l, a.P - 1 - p0);
-          endc = lane_value(end_l, a.P - 1 - p0);
-        }
-      }
-    }
-    // ---- weighted total (uniform over the wavefront) ---------------------------
-    float total = 0.0f;
-    if (a.ref_len > 0.0f) {
-      if (a.w_goal > 0.0) total = accum(total, a.w_goal, goal);
-      if (a.w_path > 0.0) {
-        const float c = kc::div_rn(
-            kc::div_rn(sum, static_cast<float>(a.P)) + endc, 2.0f);
-        total = accum(total, a.w_path, c);
-      }
-    }
-    if (a.O > 0 && a.w_obs > 0.0) {
-      // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
-      const double best = __longlong_as_double(static_cast<long long>(
-          *const_cast<volatile unsigned long long *>(&s_obest[wave])));
-      const float min_d2 = static_cast<float>(best);
-      const float dist =
-          static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
-      float v = a.max_obs_dist - dist;
-      v = v < 0.0f ? 0.0f : v;
-      total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
-    }
-    if (a.have_vel) {
-      // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
-      // evaluated redundantly by every lane (wave-uniform addresses)
-      const int nv = a.P - 1;
-      const float *vx = a.vvx + (size_t)n * nv;
-      const float *vy = a.vvy + (size_t)n * nv;
-      const float *om = a.vom + (size_t)n * nv;
-      const float div = static_cast<float>(3L * nv);
-      if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
-        float c = 0.0f;
-        for (int k = 1; k < nv; ++k) {
-          if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
-          if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
-          if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
-        }
-        total = accum(total, a.w_smooth, kc::div_rn(c, div));
-      }
-      if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
-        float c = 0.0f;
-        for (int k = 2; k < nv; ++k) {
-          if (a.acc0 > 0)
-            c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
-          if (a.acc1 > 0)
-            c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
-          if (a.acc2 > 0)
-            c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
-        }
-        total = accum(total, a.w_jerk, kc::div_rn(c, div));
-      }
-    }
-    // constant-velocity samples: both terms are exactly 0 and `total += w*0`
-    // leaves total unchanged, so nothing to do when !have_vel.
-    if (lane == 0) a.costs[n] = total;
-    if (i == static_cast<int>(blockIdx.x)) KC_STAMP(3);
-    if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
-      const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
-      wkey = k < wkey ? k : wkey;
-    }
-  }
-  KC_STAMP(2);
-  // ---- the workgroup's best key, for publish_kernel ----------------------------
-  if (lane == 0 && wkey != KEY_NONE) atomicMin(&s_key, wkey);
-  __syncthreads();
-  if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
-  KC_STAMP(4);
-}
-
-// One workgroup, queued behind sample_cost_kernel: minimum of the per-block
-// keys, the reference's compacted index of the winner (admissible samples in
-// front of it), the record for the host (pinned memory, polled: no D2H copy, no
-// stream wait) and the re-arming of the working slots.  A kernel boundary
-// instead of a device-wide "last block" ticket: hundreds of same-address
-// atomics cost more than the dispatch of this kernel.
-struct PubArgs {
-  const long long *block_keys;
-  int nblocks;
-  const uint8_t *flags;
-  int n, first;
-  long long *result;
-  long long *host_pub;
-  long long seq;
-};
-constexpr int kPubBlock = 512;
-__global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
-  __shared__ long long wkey[kPubBlock / 64];
-  __shared__ int wsum[kPubBlock / 64];
-  __shared__ long long s_fkey;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long k = KEY_NONE;
-  for (int b = threadIdx.x; b < a.nblocks; b += kPubBlock) {
-    const long long v = a.block_keys[b];
-    k = v < k ? v : k;
-  }
-  const long long na = a.result[W_LIST];
-  const long long err = a.result[W_NADM];  // device error word (roll-out gave up waiting)
-  for (int off = 32; off > 0; off >>= 1) {
-    const long long o = __shfl_xor(k, off, 64);
-    k = o < k ? o : k;
-  }
-  if (lane == 0) wkey[wave] = k;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long m = wkey[0];
-    for (int w = 1; w < kPubBlock / 64; ++w) m = wkey[w] < m ? wkey[w] : m;
-    s_fkey = m;
-  }
-  __syncthreads();
-  const long long fkey = s_fkey;
-  // the reference's index counts the admissible samples in front of the winner
-  int cnt = 0;
-  if (fkey != KEY_NONE) {
-    long long lim =
-        static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
-    if (lim > a.n) lim = a.n;
-    for (long long i = threadIdx.x; i < lim; i += kPubBlock) cnt += a.flags[i];
-  }
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-  if (lane == 0) wsum[wave] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < kPubBlock / 64; ++w) s += wsum[w];
-    if (fkey == KEY_NONE) s = -1;
-    const long long na_pub = err ? -1 : na;
-    if (a.host_pub) {
-      // zero-copy hand-off: the host polls the record.  No fence between the
-      // words: the fourth is a checksum over the other three (it includes the
-      // sequence number), so a half-arrived record is never accepted.
-      const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
-      volatile long long *hp = a.host_pub;
-      hp[0] = fkey;
-      hp[1] = w1;
-      hp[2] = a.seq;
-      hp[3] = fkey ^ w1 ^ a.seq ^ 0x5bd1e9955bd1e995ll;
-    }
-    a.result[R_KEY] = fkey;
-    a.result[R_NADM] = na_pub;
-    a.result[R_COMPACT] = s;
-    a.result[W_KEY] = KEY_NONE;
-    a.result[W_NADM] = 0;
-    a.result[W_TICKET] = 0;
-    a.result[W_LIST] = 0;  // admissible-list counter of the next cycle
-  }
-}
-
-// ordered compaction of the admissible flags (one workgroup): adm_list[i] =
-// i-th admissible local sample id, *adm_count = how many.  Used by the split
-// roll-out path and by kc_cost_evaluate (the fused kernel appends to the list
-// itself).  Every thread owns a contiguous chunk (all its flags are requested
-// up front: one memory latency), a block-wide scan gives the offsets.
-constexpr int kCompactMaxPer = 64;  // 1024 threads x 64 = 65536 samples
-
-__global__ __launch_bounds__(1024) void compact_kernel(
-    const uint8_t *__restrict__ flags, int n, int *__restrict__ adm_list,
-    long long *__restrict__ adm_count) {
-  __shared__ int wave_tot[16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = (n + 1023) / 1024;  // <= kCompactMaxPer (checked on the host)
-  const int i0 = threadIdx.x * per;
-  unsigned long long bits = 0;  // per <= 64 flags of this thread
-  for (int k = 0; k < per; ++k) {
-    const int i = i0 + k;
-    if (i < n && flags[i] != 0) bits |= 1ull << k;
-  }
-  const int mine = __popcll(bits);
-  int incl = mine;
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += v;
-  }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  int woff = 0, tot = 0;
-  for (int w = 0; w < 16; ++w) {
-    if (w < wave) woff += wave_tot[w];
-    tot += wave_tot[w];
-  }
-  int dst = woff + incl - mine;
-  while (bits) {
-    const int k = __ffsll(static_cast<long long>(bits)) - 1;
-    bits &= bits - 1;
-    adm_list[dst++] = i0 + k;
-  }
-  if (threadIdx.x == 0) *adm_count = tot;
-}
-
-// admissible samples in front of a raw index (multi-GPU: rebuilds the
-// reference's compacted index across shards).  One workgroup.
-__global__ __launch_bounds__(1024) void count_before_kernel(
-    const uint8_t *__restrict__ flags, int n, int first, long long target_raw,
-    long long *result, int slot) {
-  long long lim = target_raw - first;  // local bound
-  if (lim > n) lim = n;
-  int c = 0;
-  for (long long i = threadIdx.x; i < lim; i += 1024) c += flags[i];
-  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-  __shared__ int wsum[16];
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < 16; ++w) s += wsum[w];
-    result[slot] = s;
-  }
-}
-
-// arms the result record (context creation, and the empty-batch case)
-__global__ void init_result_kernel(long long *result) {
-  result[R_KEY] = KEY_NONE;
-  result[R_NADM] = 0;
-  result[R_COMPACT] = -1;
-  result[R_SPARE] = 0;
-  result[W_KEY] = KEY_NONE;
-  result[W_NADM] = 0;
-  result[W_TICKET] = 0;
-  result[W_LIST] = 0;
-  result[R_SCRATCH] = 0;
-  result[R_TRIGSEQ] = 0;
-}
-
-__global__ void fill_u8_kernel(uint8_t *p, int n, uint8_t v) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
-}  // namespace kc
+#include "kc_collision_dev.h"
+#include "kc_rollout_kernels.h"
+#include "kc_cost_kernels.h"
 
 // ===========================================================================
 // host context

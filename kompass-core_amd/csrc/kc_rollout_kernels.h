@@ -1,0 +1,437 @@
+// Roll-out and collision kernels (A2-A4): split path, sensor-bitmap dilation,
+// fused roll-out + pose gate, pose-parallel collision pass.  Part of kc_dwa.hip.
+#pragma once
+
+namespace kc {
+
+// ===========================================================================
+// K1a: roll-out.  One lane per sample: the recurrence x_{k+1} = x_k + (...) is
+// serial in k and keeps the reference's addition order (path.h:24-30).  The
+// float path leaves through an LDS tile so the sample-major rows are written as
+// whole contiguous lines; the double poses go out step-major (coalesced) for
+// the collision pass.
+// ===========================================================================
+constexpr int kRollBlock = 64;
+
+__global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int P1 = a.P | 1;  // odd row pitch: conflict-free column writes
+  float *tx = reinterpret_cast<float *>(smem);
+  float *ty = tx + (size_t)kRollBlock * P1;
+
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kRollBlock;
+  const int n = base + tid;
+
+  if (n < a.n) {
+    const double vx = a.vx[a.first + n];
+    const double vy = a.vy[a.first + n];
+    const int r = a.row[a.first + n];
+    double x = a.x0, y = a.y0;
+    const float fx0 = static_cast<float>(x), fy0 = static_cast<float>(y);
+    if (a.stage) {
+      tx[tid * P1] = fx0;
+      ty[tid * P1] = fy0;
+    } else {
+      a.px[(size_t)n * a.P] = fx0;
+      a.py[(size_t)n * a.P] = fy0;
+    }
+    const bool want_pos = a.c.enabled != 0;
+    // all trig rows of (up to) 64 steps are requested at once and held in
+    // registers, so the serial recurrence pays the memory latency once
+    constexpr int CH = 64;
+    double2 tr[CH];
+    const int steps = a.P - 1;
+    for (int k0 = 0; k0 < steps; k0 += CH) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        tr[j] = a.trig[(size_t)min(k0 + j, steps - 1) * a.A + r];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int k = k0 + j;
+        if (k < steps) {
+          const double2 cs = tr[j];
+          // Path::State::update, datatypes/path.h:24-30
+          x += (vx * cs.x - vy * cs.y) * a.dt;
+          y += (vx * cs.y + vy * cs.x) * a.dt;
+          if (want_pos) a.pos[(size_t)(k + 1) * a.n + n] = make_double2(x, y);
+          const float fx = static_cast<float>(x), fy = static_cast<float>(y);
+          if (a.stage) {
+            tx[tid * P1 + k + 1] = fx;
+            ty[tid * P1 + k + 1] = fy;
+          } else {
+            a.px[(size_t)n * a.P + k + 1] = fx;
+            a.py[(size_t)n * a.P + k + 1] = fy;
+          }
+        }
+      }
+    }
+    a.flags[n] = 1;
+  }
+
+  if (a.stage) {
+    __syncthreads();
+    // the block's 64 rows are one contiguous [64*P] range of each plane
+    const int rows = min(kRollBlock, a.n - base);
+    const int total = rows * a.P;
+    float *gx = a.px + (size_t)base * a.P;
+    float *gy = a.py + (size_t)base * a.P;
+    int s = 0, k = tid;
+    while (k >= a.P) {
+      k -= a.P;
+      ++s;
+    }
+    for (int i = tid; i < total; i += kRollBlock) {
+      gx[i] = tx[s * P1 + k];
+      gy[i] = ty[s * P1 + k];
+      k += kRollBlock;
+      while (k >= a.P) {
+        k -= a.P;
+        ++s;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Dilated occupancy masks (once per sensor update).  For a pose in cell c and
+// an occupied cell at integer offset (i, j) the clamped distance d used by the
+// exact tests obeys  res*hypot((|i|-1)+, (|j|-1)+) <= d <= res*hypot(i, j),
+// so with rho = radius / res (in cells, 1e-6 of slack for the rounding of the
+// pose's own cell index):
+//   inner: hypot(i, j) <= rho_in - 1e-6            -> collision certain
+//   outer: hypot((|i|-1)+, (|j|-1)+) <= rho_out + 1e-6 -> collision possible
+// Both sets are runs per row offset j (half widths win[|j|], wout[|j|]; -1 =
+// empty).  One thread per output word; a row is dilated horizontally from the
+// three words around the output word (half widths <= 31).
+// ---------------------------------------------------------------------------
+constexpr int kMaxDil = 32;
+struct DilArgs {
+  const uint32_t *g;
+  uint32_t *inner, *outer;
+  int H, wpr, R;
+  signed char win[kMaxDil + 1], wout[kMaxDil + 1];
+};
+__device__ __forceinline__ uint32_t hdilate(uint32_t left, uint32_t mid, uint32_t right, int w) {
+  uint32_t acc = mid;
+  for (int s = 1; s <= w; ++s)
+    acc |= (mid << s) | (left >> (32 - s)) | (mid >> s) | (right << (32 - s));
+  return acc;
+}
+__global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.H * a.wpr) return;
+  const int y = t / a.wpr, w = t - y * a.wpr;
+  uint32_t in_acc = 0u, out_acc = 0u;
+  for (int j = -a.R; j <= a.R; ++j) {
+    const int yy = y + j;
+    if (yy < 0 || yy >= a.H) continue;
+    const uint32_t *row = a.g + (size_t)yy * a.wpr;
+    const uint32_t mid = row[w];
+    const uint32_t left = w > 0 ? row[w - 1] : 0u;
+    const uint32_t right = w + 1 < a.wpr ? row[w + 1] : 0u;
+    if ((mid | left | right) == 0u) continue;
+    const int aj = j < 0 ? -j : j;
+    if (a.win[aj] >= 0) in_acc |= hdilate(left, mid, right, a.win[aj]);
+    if (a.wout[aj] >= 0) out_acc |= hdilate(left, mid, right, a.wout[aj]);
+  }
+  a.inner[t] = in_acc;
+  a.outer[t] = out_acc;
+}
+
+// ===========================================================================
+// K1 (fused): roll-out + collision gate of 32 samples per workgroup, no global
+// round trip in between.  512 lanes: (A) copy the occupancy bits of the
+// reachable window into LDS (word aligned with the sensor bitmap) and fetch the trig
+// rows into LDS (every load in flight at once), (B) wavefront 0 runs the 64
+// serial recurrences LDS -> LDS (pose k+1 replaces trig row k in place),
+// (C) all lanes convert the poses to the float sample-major rows (coalesced)
+// and test one pose each against the LDS bits; a hit marks the sample.
+// ===========================================================================
+template <int kFusedSamples, int kFusedBlock>
+__global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int PP = a.P | 1;  // pitch of a sample's row in 16-byte slots
+  double2 *lpos = reinterpret_cast<double2 *>(smem);
+  uint32_t *lbits = reinterpret_cast<uint32_t *>(
+      smem + (size_t)kFusedSamples * PP * sizeof(double2));
+  const int nwin = a.c.enabled ? a.c.H * a.c.wpr : 0;
+  uint32_t *linner = lbits + nwin;                 // a.c.dil only
+  uint32_t *louter = linner + (a.c.dil ? nwin : 0);
+  int *lcand = reinterpret_cast<int *>(louter + (a.c.dil ? nwin : 0));  // [samples * P]
+  __shared__ int ncand;
+  __shared__ int lhit[kFusedSamples];
+  __shared__ int lperm[kFusedSamples];  // local sample id of slot s
+  __shared__ int lrow[kFusedSamples];   // its trig row
+  __shared__ double lvx[kFusedSamples], lvy[kFusedSamples];
+
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * kFusedSamples;
+  const int rows = min(kFusedSamples, a.n - base);
+  const int steps = a.P - 1;
+
+  KC_RSTAMP(0);
+  // ---- A: window bits + trig rows -----------------------------------------
+  if (tid < kFusedSamples) {
+    lhit[tid] = 0;
+    const bool in = tid < rows;
+    lperm[tid] = in ? a.perm[base + tid] : 0;
+    lrow[tid] = in ? a.prow[base + tid] : 0;
+    lvx[tid] = in ? a.pvx[base + tid] : 0.0;
+    lvy[tid] = in ? a.pvy[base + tid] : 0.0;
+  }
+  if (a.c.enabled) {
+    // window origin is word aligned with the sensor bitmap: whole-word copies
+    const int nwords = a.c.H * a.c.wpr;
+    const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;  // exact: difference is a multiple of 32
+    for (int i = tid; i < nwords; i += kFusedBlock) {
+      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
+      const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
+      uint32_t v = 0u, vi = 0u, vo = 0u;
+      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
+        const size_t g = (size_t)gy * a.c.gwpr + gw;
+        v = a.c.gbits[g];
+        if (a.c.dil) {
+          vi = a.c.ginner[g];
+          vo = a.c.gouter[g];
+        }
+      }
+      lbits[i] = v;
+      if (a.c.dil) {
+        linner[i] = vi;
+        louter[i] = vo;
+      }
+    }
+  }
+  if (tid == 0) ncand = 0;
+  KC_RSTAMP(1);
+  if (a.trig_flag) {
+    // wait for the host's table (system-scope loads: the word and the table
+    // arrive over PCIe, behind this GPU's caches).  Bounded: ~50 ms.
+    __shared__ int s_late;
+    if (tid == 0) {
+      int late = 0;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(a.trig_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) !=
+             a.trig_seq) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {
+          late = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      s_late = late;
+    }
+    __syncthreads();
+    KC_RSTAMP(2);
+    if (s_late) {  // give the cycle up: nothing admissible, error word set
+      if (tid < rows) a.flags[lperm[tid]] = 0;
+      if (tid == 0) *a.dev_err = 1;
+      return;
+    }
+    const int s = tid & (kFusedSamples - 1);
+    if (s < rows) {
+      const int r = lrow[s];
+      const double *tg = reinterpret_cast<const double *>(a.trig);
+      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
+        const size_t e = ((size_t)k * a.A + r) * 2;
+        const double cs = __hip_atomic_load(tg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const double sn = __hip_atomic_load(tg + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        lpos[s * PP + k] = make_double2(cs, sn);
+      }
+    }
+  } else {
+    __syncthreads();  // lrow
+    const int s = tid & (kFusedSamples - 1);
+    if (s < rows) {
+      const int r = lrow[s];
+      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples)
+        lpos[s * PP + k] = a.trig[(size_t)k * a.A + r];
+    }
+  }
+  __syncthreads();
+  KC_RSTAMP(3);
+  // ---- B: recurrences.  Path::State::update (datatypes/path.h:24-30) is
+  //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt;
+  // the increments do not depend on the running sums, so every lane forms some
+  // of them first (in place over the trig entries), and only the additions -
+  // whose order fixes the rounding - run as a serial chain per sample.
+  for (int i = tid; i < rows * steps; i += kFusedBlock) {
+    const int s = i / steps, k = i - s * steps;
+    const double vx = lvx[s], vy = lvy[s];
+    const double2 cs = lpos[s * PP + k];
+    const double tx = vx * cs.x - vy * cs.y;
+    const double ty = vx * cs.y + vy * cs.x;
+    lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
+  }
+  __syncthreads();
+  KC_RSTAMP(7);
+  if (tid < rows) {
+    // sixteen increments per register chunk: one LDS latency per chunk instead
+    // of one per step
+    constexpr int kChunk = 16;
+    double x = a.x0, y = a.y0;
+    double2 *mine = lpos + tid * PP;
+    int k = 0;
+    for (; k + kChunk <= steps; k += kChunk) {
+      double2 v[kChunk];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) v[j] = mine[k + j];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        x += v[j].x;
+        y += v[j].y;
+        v[j] = make_double2(x, y);  // pose k + j + 1
+      }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) mine[k + j] = v[j];
+    }
+    for (; k < steps; ++k) {
+      const double2 inc = mine[k];
+      x += inc.x;
+      y += inc.y;
+      mine[k] = make_double2(x, y);
+    }
+  }
+  __syncthreads();
+  KC_RSTAMP(4);
+  // ---- C: float rows out; poses classified with the dilated masks, the
+  // undecided ones queued and tested exactly by densely packed lanes ----------
+  {
+    const int total = rows * a.P;
+    int s = 0, k = tid;
+    while (k >= a.P) {
+      k -= a.P;
+      ++s;
+    }
+    for (int i = tid; i < total; i += kFusedBlock) {
+      double2 p;
+      if (k == 0) p = make_double2(a.x0, a.y0);
+      else p = lpos[s * PP + k - 1];
+      const size_t o = (size_t)lperm[s] * a.P + k;  // sample-major rows
+      a.px[o] = static_cast<float>(p.x);
+      a.py[o] = static_cast<float>(p.y);
+      if (a.c.enabled && k > 0) {
+        bool exact = true;
+        if (a.c.dil) {
+          const double dx = p.x - a.c.tx, dy = p.y - a.c.ty;
+          const double xf = a.c.r00 * dx + a.c.r10 * dy;
+          const double yf = a.c.r01 * dx + a.c.r11 * dy;
+          const int cx = static_cast<int>(floor(xf * a.c.inv)) - a.c.kx0;
+          const int cy = static_cast<int>(floor(yf * a.c.inv)) - a.c.ky0;
+          if (cx >= 0 && cx < a.c.W && cy >= 0 && cy < a.c.H) {
+            const int w = cy * a.c.wpr + (cx >> 5);
+            const uint32_t bit = 1u << (cx & 31);
+            if (linner[w] & bit) {
+              lhit[s] = 1;  // every writer stores the same value
+              exact = false;
+            } else if (!(louter[w] & bit)) {
+              exact = false;
+            }
+          }
+        }
+        if (exact) lcand[atomicAdd(&ncand, 1)] = (s << 16) | k;
+      }
+      k += kFusedBlock;
+      while (k >= a.P) {
+        k -= a.P;
+        ++s;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const int nc = ncand;
+    for (int i = tid; i < nc; i += kFusedBlock) {
+      const int s = lcand[i] >> 16, k = lcand[i] & 0xFFFF;
+      if (lhit[s]) continue;  // already decided (stale reads only cost work)
+      const double2 p = lpos[s * PP + k - 1];
+      bool hit;
+      if (a.c.shape == KC_BOX) {
+        const size_t e = (size_t)k * a.A + lrow[s];  // yaw_k
+        double2 t;
+        if (a.trig_flag) {
+          const double *tg = reinterpret_cast<const double *>(a.trig);
+          t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+          t = a.trig[e];
+        }
+        hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y);
+      } else {
+        hit = hit_round(a.c, lbits, p.x, p.y);
+      }
+      if (hit) lhit[s] = 1;
+    }
+  }
+  __syncthreads();
+  KC_RSTAMP(5);
+  if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
+    const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
+    if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
+    const unsigned long long bal = __ballot(ok);
+    const int cnt = __popcll(bal);
+    int start = 0;
+    if (tid == 0 && cnt)
+      start = static_cast<int>(atomicAdd(
+          reinterpret_cast<unsigned long long *>(a.adm_count),
+          static_cast<unsigned long long>(cnt)));
+    start = __shfl(start, 0, 64);
+    if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = lperm[tid];
+  }
+  KC_RSTAMP(6);
+}
+
+// ===========================================================================
+// K1b: collision gate.  A sample is dropped as soon as ANY of its poses
+// collides (trajectory_sampler.cpp:147-152 with drop_samples_ == true), so the
+// (step, sample) pairs are independent: one lane per pose, occupancy bits of
+// the reachable window staged in LDS, a hit clears the sample's flag (every
+// writer stores the same 0).
+// ===========================================================================
+constexpr int kCollBlock = 256;
+
+__global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);
+  if (a.c.lds) {
+    const int nwords = a.c.H * a.c.wpr;
+    for (int i = threadIdx.x; i < nwords; i += kCollBlock) lbits[i] = a.c.bits[i];
+    __syncthreads();
+  }
+  const long t = (long)blockIdx.x * kCollBlock + threadIdx.x;
+  if (t >= (long)a.n * (a.P - 1)) return;
+  const int k = static_cast<int>(t / a.n) + 1;  // pose index 1..P-1
+  const int n = static_cast<int>(t - (long)(k - 1) * a.n);
+  const double2 p = a.pos[(size_t)k * a.n + n];
+  bool hit;
+  if (a.c.shape == KC_BOX) {
+    const double2 cs = a.trig[(size_t)k * a.A + a.row[a.first + n]];  // yaw_k
+    hit = a.c.lds ? hit_box(a.c, lbits, p.x, p.y, cs.x, cs.y)
+                  : hit_box(a.c, a.c.bits, p.x, p.y, cs.x, cs.y);
+  } else {
+    hit = a.c.lds ? hit_round(a.c, lbits, p.x, p.y)
+                  : hit_round(a.c, a.c.bits, p.x, p.y);
+  }
+  if (hit) a.flags[n] = 0;
+}
+
+// batch pose check (CollisionChecker::checkCollisions for arbitrary poses):
+// occupancy bits read from global memory, cos/sin(yaw) from the host table
+__global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
+                                  const double2 *__restrict__ cs, int n,
+                                  uint8_t *__restrict__ hit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double2 p = pos[i];
+  bool h;
+  if (c.shape == KC_BOX) {
+    const double2 t = cs[i];
+    h = hit_box(c, c.bits, p.x, p.y, t.x, t.y);
+  } else {
+    h = hit_round(c, c.bits, p.x, p.y);
+  }
+  hit[i] = h ? 1 : 0;
+}
+
+}  // namespace kc
