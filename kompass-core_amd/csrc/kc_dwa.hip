@@ -869,6 +869,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     return fail(KC_ERR_HIP);
   }
   c->stream = c->own_stream;
+  (void)WorkerPool::instance();  // start the host workers now, not inside the first cycle
   int rc;
   if ((rc = c->h_pub.reserve(8))) return fail(rc);
   for (int i = 0; i < 8; ++i) c->h_pub.p[i] = 0;
