@@ -109,8 +109,10 @@ def controller_bench(args, rank, world, local_rank):
             return ctx.cycle(pose(i), P)  # roll-out + evaluate + fetch in one ABI call
         ctx.rollout(pose(i), P)
         ctx.evaluate()
-        sharding.allreduce_best(key_t)
-        return int(key_t.item())  # D2H + sync, like fetch_result
+        sharding.allreduce_best(key_t)      # ONE 8-byte all-reduce(min) on the device record
+        ctx.publish_result()                # reduced record -> pinned memory
+        r = ctx.fetch_result()              # polled, no D2H copy / stream wait
+        return sharding.key_pack(float(r.cost), int(r.raw_index)) if r.found else sharding.KEY_NONE
 
     def barrier():
         if use_dist:

@@ -215,6 +215,12 @@ int kc_cost_evaluate(kc_dwa *ctx, const float *paths_x, const float *paths_y,
  * kc_dwa_result_device() returns the device address of that int64[2] record so
  * the caller can all-reduce(min) / all-gather it on the same stream. */
 int kc_dwa_result_device(kc_dwa *ctx, void **dev_int64x2);
+/* after the caller has reduced that record in place (all-reduce on the
+ * context's stream): queue a one-wavefront kernel that hands the record to the
+ * host through pinned memory, so that kc_dwa_fetch_result returns the REDUCED
+ * key without a D2H copy or a stream wait (index / n_admissible of the result
+ * are the local shard's and only meaningful on the owning rank) */
+int kc_dwa_publish_result(kc_dwa *ctx);
 /* number of admissible samples with raw index < raw_index on this shard (used
  * to rebuild the reference's compacted index across shards) */
 int kc_dwa_count_admissible_before(kc_dwa *ctx, int64_t global_raw_index,

@@ -819,6 +819,18 @@ __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
   }
 }
 
+// the (externally reduced) device record again into the pinned mirror
+__global__ void republish_kernel(const long long *result, long long *host_pub, long long seq) {
+  const long long key = result[R_KEY];
+  const long long w1 = (result[R_NADM] << 32) |
+                       static_cast<long long>(static_cast<uint32_t>(result[R_COMPACT]));
+  volatile long long *hp = host_pub;
+  hp[0] = key;
+  hp[1] = w1;
+  hp[2] = seq;
+  hp[3] = key ^ w1 ^ seq ^ 0x5bd1e9955bd1e995ll;
+}
+
 // ordered compaction of the admissible flags (one workgroup): adm_list[i] =
 // i-th admissible local sample id, *adm_count = how many.  Used by the split
 // roll-out path and by kc_cost_evaluate (the fused kernel appends to the list

@@ -1687,6 +1687,17 @@ int kc_dwa_result_device(kc_dwa *c, void **dev) {
   return KC_OK;
 }
 
+int kc_dwa_publish_result(kc_dwa *c) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!c->evaluated) KC_FAIL(KC_ERR_STATE, "nothing evaluated yet");
+  KC_TRY(use_device(c));
+  hipLaunchKernelGGL(republish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_result.p,
+                     c->h_pub.p, ++c->seq);
+  KC_HIP(hipGetLastError());
+  c->pub_pending = true;
+  return KC_OK;
+}
+
 int kc_dwa_count_admissible_before(kc_dwa *c, int64_t raw, int64_t *count) {
   if (!c || !count) KC_FAIL(KC_ERR_INVALID, "null argument");
   if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");

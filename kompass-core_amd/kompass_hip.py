@@ -105,6 +105,7 @@ SIGNATURES = {
     "kc_dwa_get_samples": (C.c_int, [_vp, _fp, _fp, _ip, _fp, _sz, C.POINTER(_sz)]),
     "kc_cost_evaluate": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _sz, _sz, _fp, C.POINTER(Result)]),
     "kc_dwa_result_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "kc_dwa_publish_result": (C.c_int, [_vp]),
     "kc_dwa_count_admissible_before": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64)]),
     "kc_key_cost": (C.c_float, [C.c_int64]),
     "kc_key_index": (C.c_int64, [C.c_int64]),
@@ -339,6 +340,11 @@ class DwaContext:
         _check(lib().kc_cost_evaluate(self.h, _pf(px), _pf(py), _pf(v[0]), _pf(v[1]), _pf(v[2]), N, P,
                                       _pf(costs), C.byref(r)))
         return r, costs[:N]
+
+    def publish_result(self):
+        """After an in-place reduction of the device record: hand it to the host
+        through pinned memory (fetch_result then returns the reduced key)."""
+        _check(lib().kc_dwa_publish_result(self.h))
 
     def result_device_ptr(self) -> int:
         p = _vp()

@@ -347,3 +347,39 @@ np.savez({str(out)!r}, **res)
         np.testing.assert_array_equal(got[f"{k}_px"].view(np.uint32), h["px"].view(np.uint32))
         np.testing.assert_array_equal(got[f"{k}_costs"].view(np.uint32), h["costs"].view(np.uint32))
         assert int(got[f"{k}_idx"]) == h["res"]["index"]
+
+
+def test_publish_result_hands_over_the_device_record():
+    """Multi-GPU hand-off: rollout + evaluate, (all-reduce by the caller on the
+    device record), kc_dwa_publish_result, kc_dwa_fetch_result -- without an
+    exchange the record is this context's own result; after the caller lowers
+    the key in place, the lowered key comes back."""
+    import ctypes as C
+
+    inp = syn.make_controller_inputs("cfg1", seed=2)
+    ref = hip_cycle(kh, inp)
+    ctx = hip_context(kh, inp)
+    st = inp["state"]
+    ctx.set_weights(kh.make_weights(*inp["weights"]))
+    ctx.set_points(st, inp["points"], inp["max_range"])
+    ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+    ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
+    for _ in range(3):
+        ctx.rollout(st, inp["P"])
+        ctx.evaluate()
+        ctx.publish_result()
+        r = ctx.fetch_result()
+        assert r.found and r.raw_index == ref["res"]["raw_index"]
+        assert np.float32(r.cost) == np.float32(ref["res"]["cost"])
+        assert r.n_admissible == ref["res"]["n_admissible"] and r.index == ref["res"]["index"]
+    # stand-in for the all-reduce: another rank's better key written into the record
+    hip = C.CDLL("libamdhip64.so")
+    better = np.array([kh.lib().kc_key_pack(C.c_float(0.125), C.c_int64(123456))], np.int64)
+    ctx.rollout(st, inp["P"])
+    ctx.evaluate()
+    ctx.fetch_result()  # the stream is idle now
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(C.c_void_p(ctx.result_device_ptr()), better.ctypes.data_as(C.c_void_p), 8, 1) == 0
+    ctx.publish_result()
+    r = ctx.fetch_result()
+    assert r.found and r.raw_index == 123456 and np.float32(r.cost) == np.float32(0.125)
