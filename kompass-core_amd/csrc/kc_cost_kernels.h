@@ -15,11 +15,17 @@ namespace kc {
 // order); min_j sqrt(d2_j) == sqrt(min_j d2_j) for the correctly rounded sqrt,
 // so one sqrt per point; the END point's search also yields the goal cost
 // ((a-b)^2 == (b-a)^2 bit for bit).  Instead of all S points a lane evaluates
-// (1) the first point of every chunk of the segment, (2) a bounding-sphere
-// test per chunk against that upper bound (|q - p_j| >= |q - c| - r; spheres
-// from the host, 1e-4 relative slack, non-finite chunks always qualify), and
-// (3) every remaining point of the chunks that may hold something closer - the
-// same minimum and the same lowest index as the full scan.
+// (1) the first point of every super-chunk (8 chunks of 16 points), (2) a
+// bounding-sphere test per super-chunk against that upper bound
+// (|q - p_j| >= |q - c| - r), (3) the first points of the chunks of the
+// surviving super-chunks, (4) a capsule test per such chunk
+// (|q - p_j| >= dist(q, chord AB) - max_j dist(p_j, AB): on a smooth path the
+// band of chunks that can hold the minimum is one or two wide, where a sphere
+// leaves sqrt(2 d r) of path), and (5) every remaining point of the chunks
+// that may hold something at least as close -- the same minimum and the same
+// lowest index as the full scan.  Bounds come from the host (computed around
+// the stored float values, rounded up, 1e-4 relative slack in the tests;
+// non-finite chunks always qualify).
 //
 // Obstacles (TrajectoryPath::minDist2D, trajectory.h:218-235): float
 // difference, squares and sum in double, rounded to float once; the rounding
@@ -76,9 +82,10 @@ struct CostArgs {
   const uint8_t *flags;
   const int *adm_list;            // admissible local sample ids (any order)
   const long long *adm_count;     // device-side count (result[W_LIST])
-  const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the
-                                               // chunk spheres [4][nch]: cx, cy, cz, r
-  int seg_chunk, nch;             // points per chunk, chunk count (<= 64)
+  const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the chunk capsules
+                                               // [8][nch]: ax ay az abx aby abz 1/|ab|^2 eps, then
+                                               // the super-chunk spheres [4][nsup]: cx cy cz r
+  int seg_chunk, nch, nsup;       // points per chunk, chunk count (<= 64), super-chunks of 8 chunks
   float seg_len, ref_len;
   BucketDev b;
   const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
   KC_STAMP(1);
   const BucketDev &b = a.b;
   const int ncell = b.W * b.H;
-  const int seg_words = a.use_seg ? 5 * a.S + 4 * a.nch : 0;
+  const int seg_words = a.use_seg ? 5 * a.S + 8 * a.nch + 4 * a.nsup : 0;
   // LDS layout: segment rows + chunk spheres | cell table | skip table (padded
   // to words) | obstacle coordinates.  The pointers are chosen at compile time
   // so that the LDS variants issue ds_read, not flat loads.
@@ -458,8 +465,8 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
   const float *const sg = kLds ? l_seg : a.sx;
   const float *const sx = sg, *const sy = sg + a.S, *const sz = sg + 2 * a.S,
               *const szz = sg + 3 * a.S, *const sacc = sg + 4 * a.S;
-  const float *const ccx = sg + 5 * a.S, *const ccy = ccx + a.nch, *const ccz = ccy + a.nch,
-              *const ccr = ccz + a.nch;
+  const float *const cap = sg + 5 * a.S;             // [8][nch]
+  const float *const sup = cap + 8 * a.nch;          // [4][nsup]
   if (threadIdx.x == 0) s_key = KEY_NONE;
   if (na > 0 && kLds) {
 #pragma unroll 8
@@ -504,10 +511,10 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
       if (a.use_seg) {
         float best = FLT_MAX;
         int arg = 0;
-        // (1) the first point of every chunk: ascending index, strict `<`
-#pragma unroll 8
-        for (int c = 0; c < a.nch; ++c) {
-          const int j = c * a.seg_chunk;
+        const int sup_pts = 8 * a.seg_chunk;
+        // (1) the first point of every super-chunk: ascending index, strict `<`
+        for (int s = 0; s < a.nsup; ++s) {
+          const int j = s * sup_pts;
           const float dx = sx[j] - x;
           const float dy = sy[j] - y;
           const float xx = dx * dx;
@@ -518,22 +525,59 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
             arg = j;
           }
         }
-        if (st) KC_STAMP(8);
-        // (2) chunks that may hold something at least as close: |q - c| - r <= thr,
-        // tested on the squares (no square root per chunk); 1e-4 relative slack
-        // on the bound, 1e-5 on the compared square
-        const float thr = __builtin_sqrtf(best) * 1.0001f;
-        unsigned long long cand = 0ull;
-#pragma unroll 8
-        for (int c = 0; c < a.nch; ++c) {
-          const float dx = ccx[c] - x, dy = ccy[c] - y, dz = ccz[c];
+        // (2) super-chunks that may hold something at least as close:
+        // |q - c| - r <= thr on the squares; 1e-4 relative slack on the bound,
+        // 1e-5 on the compared square (NaN compares false: qualifies)
+        float thr = __builtin_sqrtf(best) * 1.0001f;
+        unsigned smask = 0u;
+        for (int s = 0; s < a.nsup; ++s) {
+          const float dx = sup[s] - x, dy = sup[a.nsup + s] - y, dz = sup[2 * a.nsup + s];
           const float d2 = dx * dx + dy * dy + dz * dz;
-          const float lim = thr + ccr[c];
-          // qualifies unless provably farther (NaN compares false: qualifies)
-          if (!(d2 > lim * lim * 1.00001f)) cand |= 1ull << c;
+          const float lim = thr + sup[3 * a.nsup + s];
+          if (!(d2 > lim * lim * 1.00001f)) smask |= 1u << s;
+        }
+        if (st) KC_STAMP(8);
+        // (3) the first points of their other chunks
+        for (unsigned m = smask; m;) {
+          const int s = __ffs(static_cast<int>(m)) - 1;
+          m &= m - 1u;
+#pragma unroll
+          for (int u = 1; u < 8; ++u) {
+            const int c = s * 8 + u;
+            const int j = min(c, a.nch - 1) * a.seg_chunk;  // a repeat of the last chunk changes nothing
+            const float dx = sx[j] - x;
+            const float dy = sy[j] - y;
+            const float xx = dx * dx;
+            const float yy = dy * dy;
+            const float dd = xx + (yy + szz[j]);
+            if (dd < best || (dd == best && j < arg)) {
+              best = dd;
+              arg = j;
+            }
+          }
+        }
+        // (4) capsule test of their chunks: distance to the chord minus the
+        // largest deviation of the chunk's points from it
+        thr = __builtin_sqrtf(best) * 1.0001f;
+        unsigned long long cand = 0ull;
+        for (unsigned m = smask; m;) {
+          const int s = __ffs(static_cast<int>(m)) - 1;
+          m &= m - 1u;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int c = min(s * 8 + u, a.nch - 1);
+            const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
+            const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
+            float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+            if (!(d2 > lim * lim * 1.0001f)) cand |= 1ull << c;
+          }
         }
         if (st) KC_STAMP(9);
-        // (3) the remaining points of those chunks
+        // (5) the remaining points of those chunks
         while (cand) {
           const int c = __ffsll(static_cast<long long>(cand)) - 1;
           cand &= cand - 1ull;

@@ -65,7 +65,7 @@ struct kc_dwa {
   std::vector<uint8_t> skip_pad;
   bool early_launch = true;             // fused kernel queued before the trig table exists
   long long trig_seq = 0;
-  int seg_chunk = kSegChunkMin, seg_nch = 0;  // chunking of the tracked segment (cost kernel)
+  int seg_chunk = kSegChunkMin, seg_nch = 0, seg_nsup = 0;  // chunking of the tracked segment (cost kernel)
   long long last_nadm = -1;             // admissible count of the previous cycle (kernel choice)
   int cost_kernel_force = 0;            // 1: workgroup-per-sample, 2: wavefront-per-sample (KC_COST_KERNEL)
   bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
@@ -652,6 +652,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.acc_seg = seg + 4 * S;
   ca.seg_chunk = c->seg_chunk;
   ca.nch = c->seg_nch;
+  ca.nsup = c->seg_nsup;
   ca.seg_len = c->seg_len;
   ca.ref_len = c->ref_len;
   ca.b = c->bucket;
@@ -717,7 +718,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   } else {
     // one workgroup per CU, sixteen samples (wavefronts) in flight in each
     cost_blocks = static_cast<unsigned>(std::min<size_t>(n, kCostGrid));
-    if (ca.use_seg) lds_tab += (5 * S + 4 * static_cast<size_t>(ca.nch)) * sizeof(float);
+    if (ca.use_seg)
+      lds_tab += (5 * S + 8 * static_cast<size_t>(ca.nch) + 4 * static_cast<size_t>(ca.nsup)) * sizeof(float);
     const bool tab_lds = c->cost_lds_ok && lds_tab + 64 <= kCostLdsBudget;
     const bool obs_lds = tab_lds && ca.use_obs && lds_tab + lds_obs + 64 <= kCostLdsBudget;
     if (c->debug_stamps && c->seq <= 2)
@@ -876,8 +878,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
   if ((rc = c->d_result.reserve(R_SLOTS)) ||
       (rc = c->h_result.reserve(R_SLOTS)) ||
       (rc = ensure_cycle_buffers(c, p->max_samples, p->max_points)) ||
-      (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 4 * 64)) ||
-      (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 4 * 64)) ||
+      (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 8 * 64 + 4 * 8)) ||
+      (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 8 * 64 + 4 * 8)) ||
       (rc = c->h_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->d_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->h_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
@@ -1227,13 +1229,17 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   c->S = S;
   c->ref_len = ref_len;
   if (S == 0) return KC_OK;
-  // rows [5][S], then bounding spheres of the chunks [4][nch] (cost kernel, step 2)
+  // rows [5][S], then capsules of the chunks [8][nch] and bounding spheres of
+  // the super-chunks (8 chunks) [4][nsup] (sample_cost_kernel, steps 2 and 4)
   const size_t chunk = std::max<size_t>(kSegChunkMin, (S + 63) / 64);
   const size_t nch = (S + chunk - 1) / chunk;
+  const size_t nsup = (nch + 7) / 8;
   c->seg_chunk = static_cast<int>(chunk);
   c->seg_nch = static_cast<int>(nch);
-  KC_TRY(c->h_seg.reserve(5 * S + 4 * nch));
-  KC_TRY(c->d_seg.reserve(5 * S + 4 * nch));
+  c->seg_nsup = static_cast<int>(nsup);
+  const size_t seg_words = 5 * S + 8 * nch + 4 * nsup;
+  KC_TRY(c->h_seg.reserve(seg_words));
+  KC_TRY(c->d_seg.reserve(seg_words));
   float *h = c->h_seg.p;
   for (size_t j = 0; j < S; ++j) {
     const float zz = z ? z[j] : 0.0f;
@@ -1243,23 +1249,70 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     h[3 * S + j] = zz * zz;  // (seg.z - 0)^2 of Path::distance
     h[4 * S + j] = acc[j];
   }
+  const float kInf = std::numeric_limits<float>::infinity();
+  auto up = [](double v) {  // to float, rounded up
+    return std::nextafter(static_cast<float>(v), std::numeric_limits<float>::infinity());
+  };
+  auto pt = [&](size_t j, double p[3]) {
+    p[0] = h[j];
+    p[1] = h[S + j];
+    p[2] = h[2 * S + j];
+  };
   {
-    float *ccx = h + 5 * S, *ccy = ccx + nch, *ccz = ccy + nch, *ccr = ccz + nch;
+    float *cap = h + 5 * S;
     for (size_t k = 0; k < nch; ++k) {
       const size_t j0 = k * chunk, j1 = std::min(j0 + chunk, S);
+      bool finite = true;
+      for (size_t j = j0; j < j1; ++j)
+        finite = finite && std::isfinite(h[j]) && std::isfinite(h[S + j]) && std::isfinite(h[2 * S + j]);
+      double A[3], B[3];
+      pt(j0, A);
+      pt(j1 - 1, B);
+      // the chord as the kernel sees it: float A, float AB, float 1/|AB|^2
+      const float ab[3] = {static_cast<float>(B[0] - A[0]), static_cast<float>(B[1] - A[1]),
+                           static_cast<float>(B[2] - A[2])};
+      const double l2 = static_cast<double>(ab[0]) * ab[0] + static_cast<double>(ab[1]) * ab[1] +
+                        static_cast<double>(ab[2]) * ab[2];
+      const float inv = (finite && l2 > 0.0 && std::isfinite(1.0 / l2)) ? static_cast<float>(1.0 / l2) : 0.0f;
+      double eps = 0.0, mag = 0.0;
+      for (size_t j = j0; j < j1 && finite; ++j) {
+        double P[3];
+        pt(j, P);
+        const double q[3] = {P[0] - A[0], P[1] - A[1], P[2] - A[2]};
+        double t = (q[0] * ab[0] + q[1] * ab[1] + q[2] * ab[2]) * static_cast<double>(inv);
+        t = std::min(std::max(t, 0.0), 1.0);
+        const double e[3] = {q[0] - t * ab[0], q[1] - t * ab[1], q[2] - t * ab[2]};
+        eps = std::max(eps, std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
+        mag = std::max(mag, std::fabs(P[0]) + std::fabs(P[1]) + std::fabs(P[2]));
+      }
+      cap[k] = static_cast<float>(A[0]);
+      cap[nch + k] = static_cast<float>(A[1]);
+      cap[2 * nch + k] = static_cast<float>(A[2]);
+      cap[3 * nch + k] = finite ? ab[0] : 0.0f;
+      cap[4 * nch + k] = finite ? ab[1] : 0.0f;
+      cap[5 * nch + k] = finite ? ab[2] : 0.0f;
+      cap[6 * nch + k] = inv;
+      // deviation of the points from the chord, plus slack for the float chord
+      // parameter and coordinate rounding
+      cap[7 * nch + k] = finite ? up(eps * (1.0 + 1e-6) + 2e-6 * std::sqrt(l2) + 1e-6 * mag + 1e-30) : kInf;
+    }
+    float *sup = cap + 8 * nch;
+    for (size_t s = 0; s < nsup; ++s) {
+      const size_t j0 = s * 8 * chunk, j1 = std::min(j0 + 8 * chunk, S);
       double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
       bool finite = true;
       for (size_t j = j0; j < j1; ++j) {
-        const double p[3] = {h[j], h[S + j], h[2 * S + j]};
+        double P[3];
+        pt(j, P);
         for (int q = 0; q < 3; ++q) {
-          finite = finite && std::isfinite(p[q]);
-          lo[q] = std::min(lo[q], p[q]);
-          hi[q] = std::max(hi[q], p[q]);
+          finite = finite && std::isfinite(P[q]);
+          lo[q] = std::min(lo[q], P[q]);
+          hi[q] = std::max(hi[q], P[q]);
         }
       }
       if (!finite) {  // never skipped
-        ccx[k] = ccy[k] = ccz[k] = 0.0f;
-        ccr[k] = std::numeric_limits<float>::infinity();
+        sup[s] = sup[nsup + s] = sup[2 * nsup + s] = 0.0f;
+        sup[3 * nsup + s] = kInf;
         continue;
       }
       // centre stored as float; the radius is taken around the STORED centre
@@ -1269,17 +1322,16 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
                            static_cast<float>(0.5 * (lo[2] + hi[2]))};
       double r = 0.0;
       for (size_t j = j0; j < j1; ++j) {
-        const double dx = h[j] - static_cast<double>(fc[0]);
-        const double dy = h[S + j] - static_cast<double>(fc[1]);
-        const double dz = h[2 * S + j] - static_cast<double>(fc[2]);
+        double P[3];
+        pt(j, P);
+        const double dx = P[0] - fc[0], dy = P[1] - fc[1], dz = P[2] - fc[2];
         r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
       }
       const double mag = std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]) + r;
-      ccx[k] = fc[0];
-      ccy[k] = fc[1];
-      ccz[k] = fc[2];
-      ccr[k] = std::nextafter(static_cast<float>(r * (1.0 + 1e-6) + 1e-6 * mag + 1e-30),
-                              std::numeric_limits<float>::infinity());
+      sup[s] = fc[0];
+      sup[nsup + s] = fc[1];
+      sup[2 * nsup + s] = fc[2];
+      sup[3 * nsup + s] = up(r * (1.0 + 1e-6) + 1e-6 * mag + 1e-30);
     }
   }
   // View::totalSegmentLength, path.h:85-91
@@ -1290,7 +1342,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     len += std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
   }
   c->seg_len = len;
-  KC_TRY(upload_table(c, c->d_seg.p, h, (5 * S + 4 * nch) * sizeof(float)));
+  KC_TRY(upload_table(c, c->d_seg.p, h, seg_words * sizeof(float)));
   if (!c->trig_direct) c->update_busy = true;
   bar_flush(c);
   return KC_OK;
