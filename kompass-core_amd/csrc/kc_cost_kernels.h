@@ -85,7 +85,7 @@ struct CostArgs {
   const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the chunk capsules
                                                // [8][nch]: ax ay az abx aby abz 1/|ab|^2 eps, then
                                                // the super-chunk spheres [4][nsup]: cx cy cz r
-  int seg_chunk, nch, nsup;       // points per chunk, chunk count (<= 64), super-chunks of 8 chunks
+  int seg_chunk, nch;             // points per chunk, chunk count (<= 64)
   float seg_len, ref_len;
   BucketDev b;
   const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
@@ -96,6 +96,9 @@ struct CostArgs {
   long long *result;    // R_* published record + W_* working area
   long long *block_keys;  // [gridDim.x] best key of every workgroup (publish_kernel reduces)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS): per-block phase clocks
+  int nsup;                 // super-chunks of 8 chunks (kept at the end: the workgroup-per-sample
+                            // kernel lost 5 us when this field sat next to nch -- its scalar
+                            // argument loads are sensitive to the layout above)
 };
 
 #ifdef KC_PHASE_STAMPS
