@@ -54,7 +54,8 @@ constexpr int kCostGrid = 256;    // one workgroup per CU
 // LDS the search tables of a workgroup may take
 constexpr size_t kCostLdsBudget = 150 * 1024;
 constexpr int kSegChunkMin = 16;
-constexpr long long kBlockKernelMaxAdm = 1024;  // longest list the workgroup-per-sample kernel gets  // segment points per bounding sphere (at most 64 chunks)
+constexpr long long kBlockKernelMaxAdm = 512;   // longest list the workgroup-per-sample kernel gets (one
+                                                // resident round of workgroups; measured crossover ~650)  // segment points per bounding sphere (at most 64 chunks)
 
 struct BucketDev {
   int W, H;            // cells
