@@ -98,7 +98,13 @@ def controller_bench(args, rank, world, local_rank):
 
     key_t = None
     if use_dist:
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        # kernels, the RCCL all-reduce and the hand-off kernel share ONE explicit
+        # stream (torch's default stream has handle 0, which the ABI reads as
+        # "use the context's own stream": the collective would then not be
+        # ordered behind the kernels)
+        stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(stream)
+        ctx.set_stream(stream.cuda_stream)
         key_t = sharding.as_torch_int64(ctx.result_device_ptr(), 4, torch.device("cuda", local_rank))[:1]
 
     def pose(i):  # a new pose every cycle: nothing can be reused between steps

@@ -120,8 +120,10 @@ typedef struct kc_dwa kc_dwa;
 int kc_dwa_create(const kc_dwa_params *params, kc_dwa **out);
 void kc_dwa_destroy(kc_dwa *ctx);
 
-/* adopt an external hipStream_t (e.g. torch's current stream) for all work of
- * this context; NULL restores the context's own stream */
+/* adopt an external hipStream_t for all work of this context; NULL restores the
+ * context's own (non-blocking) stream.  NB: the handle of the legacy default
+ * stream IS NULL -- to share a stream with a framework create an explicit one
+ * there (torch.cuda.Stream()) and pass its handle. */
 int kc_dwa_set_stream(kc_dwa *ctx, void *hip_stream);
 /* CollisionChecker::resetOctreeResolution, collision_check.cpp:70-75 */
 int kc_dwa_set_resolution(kc_dwa *ctx, double octree_res);
