@@ -229,6 +229,13 @@ def extras(ctx, inp, P, pose):
         "set_tracked_segment_ms": med(lambda i: ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"],
                                                                          inp["ref_len"]), 20),
     }
+    def fresh_inputs_cycle(i):
+        ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+        ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+        ctx.cycle(pose(i), P)
+
+    # a controller step with new sensor data and a new tracked segment every time
+    out["update_and_cycle_ms"] = med(fresh_inputs_cycle, 100)
     far = pts[np.hypot(pts[:, 0], pts[:, 1]) > 10.0]
     ctx.set_points(inp["state"], far, inp["max_range"])
     for i in range(20):

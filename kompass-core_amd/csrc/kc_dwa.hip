@@ -24,6 +24,7 @@
 #include "kc_collision_dev.h"
 #include "kc_rollout_kernels.h"
 #include "kc_cost_kernels.h"
+#include "kc_sensor_kernels.h"
 
 // ===========================================================================
 // host context
@@ -41,7 +42,15 @@ struct kc_dwa {
   hm::Rigid3f sensor_tf_body;
   hm::Rigid3f frame;          // sensor_tf_world_ captured at set_scan/points
   double radius = 0, height = 0, res = 0.1;
-  std::vector<int32_t> vox_kx, vox_ky;  // z-accepted occupied columns
+  std::vector<int32_t> vox_kx, vox_ky;  // z-accepted occupied columns (host lists; built lazily
+                                        // when the sensor update ran on the device)
+  bool host_lists_valid = true;
+  hm::Rigid3f obs_tf{};                 // sensor_tf_body * body of the last point update
+  std::vector<float> raw_xyz;           // input of the last device-side sensor update
+  DevBuf<float> d_raw;
+  DevBuf<float4> d_sensor_tmp;
+  bool device_sensor = true;            // KC_SENSOR_HOST=1 turns the device-side update off
+  bool sensor_lds_ok = false;
   std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
   // occupancy bits of all accepted voxel columns over their bounding box
   PinBuf<uint32_t> h_gbits;
@@ -167,8 +176,10 @@ inline void bar_flush(kc_dwa *c) {
 // them.  A cycle whose record the host has seen proves that everything queued
 // before it has finished; work queued since then (dilate_kernel, copies) is
 // tracked by `update_busy`.
-int quiesce_for_update(kc_dwa *c) {
-  if (!c->drained || c->update_busy) {
+int quiesce_for_update(kc_dwa *c, bool sensor_tables = true) {
+  // (the tracked-segment table is only read by cost kernels, i.e. by cycles:
+  // work queued by a sensor update since the last cycle does not touch it)
+  if (!c->drained || (sensor_tables && c->update_busy)) {
     KC_HIP(hipStreamSynchronize(c->stream));
     c->update_busy = false;
     c->drained = true;
@@ -202,6 +213,94 @@ inline void add_voxel(kc_dwa *c, float px, float py, float pz) {
   c->vox_ky.push_back(static_cast<int32_t>(fy));
 }
 
+// dilation radii in cells (see dilate_kernel)
+struct DilGeom {
+  double rho_in, rho_out;
+  int R;
+};
+DilGeom dil_geom(const kc_dwa *c) {
+  DilGeom g;
+  g.rho_in = (c->prm.shape == KC_BOX ? std::min(static_cast<double>(c->prm.dims[0]),
+                                                static_cast<double>(c->prm.dims[1])) / 2.0
+                                     : c->radius) / c->res;
+  g.rho_out = (c->prm.shape == KC_BOX
+                   ? std::sqrt(std::pow(static_cast<double>(c->prm.dims[0]) / 2.0, 2) +
+                               std::pow(static_cast<double>(c->prm.dims[1]) / 2.0, 2))
+                   : c->radius) / c->res;
+  g.R = static_cast<int>(std::floor(g.rho_out + 1e-6)) + 1;
+  return g;
+}
+
+// extent of the sensor bitmap from the key bounding box (padded so that the
+// dilated masks fit); *fits = false when it is too sparse / far for the fused
+// path.  Reserves the three device bitmaps.
+int bitmap_extent(kc_dwa *c, int lox, int loy, int hix, int hiy, bool *fits) {
+  const DilGeom dg = dil_geom(c);
+  c->have_dil = c->prm.shape != KC_SPHERE && std::isfinite(dg.rho_out) && dg.R <= 30 &&
+                dg.rho_in >= 0.0;
+  if (c->have_dil) {
+    const int pad = dg.R + 1;
+    lox -= pad;
+    loy -= pad;
+    hix += pad;
+    hiy += pad;
+  }
+  const long W = static_cast<long>(hix) - lox + 1, H = static_cast<long>(hiy) - loy + 1;
+  *fits = !(W > 8192 || H > 8192);
+  if (!*fits) return KC_OK;
+  c->gkx0 = lox;
+  c->gky0 = loy;
+  c->gH = static_cast<int>(H);
+  c->gwpr = static_cast<int>((W + 31) / 32);
+  const size_t nwords = static_cast<size_t>(c->gH) * c->gwpr;
+  KC_TRY(c->d_gbits.reserve(nwords));
+  if (c->have_dil) {
+    KC_TRY(c->d_ginner.reserve(nwords));
+    KC_TRY(c->d_gouter.reserve(nwords));
+  }
+  return KC_OK;
+}
+
+// the two dilated masks from the bitmap in d_gbits
+int launch_dilate(kc_dwa *c) {
+  if (!c->have_dil) return KC_OK;
+  const DilGeom dg = dil_geom(c);
+  const size_t nwords = static_cast<size_t>(c->gH) * c->gwpr;
+  DilArgs da{};
+  da.g = c->d_gbits.p;
+  da.inner = c->d_ginner.p;
+  da.outer = c->d_gouter.p;
+  da.H = c->gH;
+  da.wpr = c->gwpr;
+  da.R = dg.R;
+  for (int j = 0; j <= kMaxDil; ++j) {
+    da.win[j] = da.wout[j] = -1;
+    if (j > dg.R) continue;
+    // inner: largest i with hypot(i, j) <= rho_in - 1e-6
+    const double ri = dg.rho_in - 1e-6;
+    if (ri >= 0.0 && static_cast<double>(j) <= ri) {
+      int i = static_cast<int>(std::floor(std::sqrt(ri * ri - static_cast<double>(j) * j)));
+      while (i >= 0 && std::hypot(static_cast<double>(i), static_cast<double>(j)) > ri) --i;
+      da.win[j] = static_cast<signed char>(std::min(i, 31));
+    }
+    // outer: largest i with hypot((i-1)+, (j-1)+) <= rho_out + 1e-6
+    const double ro = dg.rho_out + 1e-6;
+    const double jj = std::max(j - 1, 0);
+    if (jj <= ro) {
+      int i = static_cast<int>(std::floor(std::sqrt(ro * ro - jj * jj))) + 2;
+      while (i > 0 && std::hypot(static_cast<double>(std::max(i - 1, 0)), jj) > ro) --i;
+      da.wout[j] = static_cast<signed char>(std::min(i, 31));
+    }
+  }
+  const unsigned nb = static_cast<unsigned>((nwords + 255) / 256);
+  KC_TRY(c->timing.start("dilate_kernel", c->stream));
+  hipLaunchKernelGGL(dilate_kernel, dim3(nb), dim3(256), 0, c->stream, da);
+  KC_TRY(c->timing.stop(c->stream));
+  KC_HIP(hipGetLastError());
+  c->update_busy = true;
+  return KC_OK;
+}
+
 // occupancy bits of the accepted voxel columns over their bounding box ->
 // device, once per sensor update (the fused roll-out kernel copies its
 // reachable window out of it)
@@ -216,78 +315,20 @@ int upload_voxels(kc_dwa *c) {
     loy = std::min(loy, c->vox_ky[i]);
     hiy = std::max(hiy, c->vox_ky[i]);
   }
-  // dilation radii in cells (see dilate_kernel); the bitmap is padded so that
-  // the dilated masks fit
-  const double rho_in = (c->prm.shape == KC_BOX
-                             ? std::min(static_cast<double>(c->prm.dims[0]),
-                                        static_cast<double>(c->prm.dims[1])) / 2.0
-                             : c->radius) / c->res;
-  const double rho_out = (c->prm.shape == KC_BOX
-                              ? std::sqrt(std::pow(static_cast<double>(c->prm.dims[0]) / 2.0, 2) +
-                                          std::pow(static_cast<double>(c->prm.dims[1]) / 2.0, 2))
-                              : c->radius) / c->res;
-  const int R = static_cast<int>(std::floor(rho_out + 1e-6)) + 1;
-  c->have_dil = c->prm.shape != KC_SPHERE && std::isfinite(rho_out) && R <= 30 && rho_in >= 0.0;
-  if (c->have_dil) {
-    const int pad = R + 1;
-    lox -= pad;
-    loy -= pad;
-    hix += pad;
-    hiy += pad;
-  }
-  const long W = static_cast<long>(hix) - lox + 1, H = static_cast<long>(hiy) - loy + 1;
-  if (W > 8192 || H > 8192) return KC_OK;  // too sparse/far: split path only
-  c->gkx0 = lox;
-  c->gky0 = loy;
-  c->gH = static_cast<int>(H);
-  c->gwpr = static_cast<int>((W + 31) / 32);
+  bool fits = false;
+  KC_TRY(bitmap_extent(c, lox, loy, hix, hiy, &fits));
+  if (!fits) return KC_OK;  // too sparse/far: split path only
   const size_t nwords = static_cast<size_t>(c->gH) * c->gwpr;
   KC_TRY(c->h_gbits.reserve(nwords));
-  KC_TRY(c->d_gbits.reserve(nwords));
   std::memset(c->h_gbits.p, 0, nwords * sizeof(uint32_t));
   for (size_t i = 0; i < nv; ++i) {
-    const int cx = c->vox_kx[i] - lox, cy = c->vox_ky[i] - loy;
+    const int cx = c->vox_kx[i] - c->gkx0, cy = c->vox_ky[i] - c->gky0;
     c->h_gbits.p[static_cast<size_t>(cy) * c->gwpr + (cx >> 5)] |= 1u << (cx & 31);
   }
   KC_TRY(upload_table(c, c->d_gbits.p, c->h_gbits.p, nwords * sizeof(uint32_t)));
   if (!c->trig_direct) c->update_busy = true;
-  if (c->have_dil) {
-    bar_flush(c);  // the kernel below reads the bitmap
-    KC_TRY(c->d_ginner.reserve(nwords));
-    KC_TRY(c->d_gouter.reserve(nwords));
-    DilArgs da{};
-    da.g = c->d_gbits.p;
-    da.inner = c->d_ginner.p;
-    da.outer = c->d_gouter.p;
-    da.H = c->gH;
-    da.wpr = c->gwpr;
-    da.R = R;
-    for (int j = 0; j <= kMaxDil; ++j) {
-      da.win[j] = da.wout[j] = -1;
-      if (j > R) continue;
-      // inner: largest i with hypot(i, j) <= rho_in - 1e-6
-      const double ri = rho_in - 1e-6;
-      if (ri >= 0.0 && static_cast<double>(j) <= ri) {
-        int i = static_cast<int>(std::floor(std::sqrt(ri * ri - static_cast<double>(j) * j)));
-        while (i >= 0 && std::hypot(static_cast<double>(i), static_cast<double>(j)) > ri) --i;
-        da.win[j] = static_cast<signed char>(std::min(i, 31));
-      }
-      // outer: largest i with hypot((i-1)+, (j-1)+) <= rho_out + 1e-6
-      const double ro = rho_out + 1e-6;
-      const double jj = std::max(j - 1, 0);
-      if (jj <= ro) {
-        int i = static_cast<int>(std::floor(std::sqrt(ro * ro - jj * jj))) + 2;
-        while (i > 0 && std::hypot(static_cast<double>(std::max(i - 1, 0)), jj) > ro) --i;
-        da.wout[j] = static_cast<signed char>(std::min(i, 31));
-      }
-    }
-    const unsigned nb = static_cast<unsigned>((nwords + 255) / 256);
-    KC_TRY(c->timing.start("dilate_kernel", c->stream));
-    hipLaunchKernelGGL(dilate_kernel, dim3(nb), dim3(256), 0, c->stream, da);
-    KC_TRY(c->timing.stop(c->stream));
-    KC_HIP(hipGetLastError());
-    c->update_busy = true;
-  }
+  bar_flush(c);  // the kernel below reads the bitmap
+  KC_TRY(launch_dilate(c));
   c->have_gbits = true;
   return KC_OK;
 }
@@ -453,6 +494,159 @@ int upload_samples(kc_dwa *c) {
   return KC_OK;
 }
 
+// host lists of a global-frame point update (add_voxel per point, obstacle
+// coordinates through obs_tf): the sensor path of the host, and the lazy
+// fallback of the device path for code that walks the lists (split roll-out,
+// pose batches)
+void build_host_lists(kc_dwa *c, const float *xyz, size_t n) {
+  c->vox_kx.clear();
+  c->vox_ky.clear();
+  c->vox_ddz.clear();
+  c->vox_kx.reserve(n);
+  c->vox_ky.reserve(n);
+  if (c->h_obs.reserve(2 * std::max<size_t>(n, 1)) != KC_OK) return;
+  for (size_t i = 0; i < n; ++i) {
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    add_voxel(c, x, y, z);
+    float o[3];
+    c->obs_tf.apply(x, y, z, o);
+    c->h_obs.p[i] = o[0];
+    c->h_obs.p[n + i] = o[1];
+  }
+  c->host_lists_valid = true;
+}
+inline void ensure_host_lists(kc_dwa *c) {
+  if (!c->host_lists_valid) build_host_lists(c, c->raw_xyz.data(), c->raw_xyz.size() / 3);
+}
+// is there any occupied voxel column?  (after a device-side update the count is
+// not known on the host: any point may be one)
+inline bool any_voxel(const kc_dwa *c) {
+  return c->host_lists_valid ? !c->vox_kx.empty() : c->O > 0;
+}
+
+// Sensor update on the device (kc_sensor_kernels.h): the host only bounds the
+// cloud (one min/max pass), derives the bitmap extent and the bucket grid from
+// the bounds, stores the raw points through the BAR and queues two kernels.
+// *done = false: conditions not met, the caller takes the host path.
+int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
+  *done = false;
+  if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
+      n == 0 || n > 16384)
+    return KC_OK;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  size_t nfin = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+    if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) continue;
+    lo[0] = std::min(lo[0], x);
+    hi[0] = std::max(hi[0], x);
+    lo[1] = std::min(lo[1], y);
+    hi[1] = std::max(hi[1], y);
+    lo[2] = std::min(lo[2], z);
+    hi[2] = std::max(hi[2], z);
+    ++nfin;
+  }
+  if (nfin == 0) return KC_OK;
+  // bitmap: keys of the bounds (points beyond the 16-level octree are dropped
+  // by add_voxel anyway)
+  auto key = [&](float v) {
+    const double f = std::floor(c->inv_res * static_cast<double>(v));
+    return static_cast<int>(std::min(std::max(f, -32768.0), 32767.0));
+  };
+  bool fits = false;
+  KC_TRY(bitmap_extent(c, key(lo[0]), key(lo[1]), key(hi[0]), key(hi[1]), &fits));
+  const size_t nwords = fits ? static_cast<size_t>(c->gH) * c->gwpr : 0;
+  if (!fits || nwords * sizeof(uint32_t) > 64 * 1024) {
+    c->have_gbits = false;
+    return KC_OK;
+  }
+  // bucket grid: covers the image of the bounding box (an affine map takes the
+  // box into the hull of its eight transformed corners)
+  double blo[2] = {DBL_MAX, DBL_MAX}, bhi[2] = {-DBL_MAX, -DBL_MAX};
+  for (int k = 0; k < 8; ++k) {
+    float o[3];
+    c->obs_tf.apply((k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2], o);
+    if (!std::isfinite(o[0]) || !std::isfinite(o[1])) return KC_OK;
+    blo[0] = std::min(blo[0], static_cast<double>(o[0]));
+    bhi[0] = std::max(bhi[0], static_cast<double>(o[0]));
+    blo[1] = std::min(blo[1], static_cast<double>(o[1]));
+    bhi[1] = std::max(bhi[1], static_cast<double>(o[1]));
+  }
+  const double ext0 = std::max(bhi[0] - blo[0], bhi[1] - blo[1]);
+  const double margin = 1e-4 * ext0 + 1e-4;  // float rounding of the transformed points
+  blo[0] -= margin;
+  blo[1] -= margin;
+  bhi[0] += margin;
+  bhi[1] += margin;
+  BucketDev &b = c->bucket;
+  std::memset(&b, 0, sizeof(b));
+  b.cap = static_cast<double>(c->max_obs_dist) * 1.001;
+  const int side = std::min(64, std::max(8, static_cast<int>(std::ceil(std::sqrt(
+                                                static_cast<double>(n))))));
+  const double ext = std::max(bhi[0] - blo[0], bhi[1] - blo[1]);
+  b.g = std::max(0.125, ext / (side - 1));
+  b.inv_g = 1.0 / b.g;
+  b.gx0 = blo[0];
+  b.gy0 = blo[1];
+  b.W = std::min(side, static_cast<int>((bhi[0] - blo[0]) * b.inv_g) + 1);
+  b.H = std::min(side, static_cast<int>((bhi[1] - blo[1]) * b.inv_g) + 1);
+  const size_t ncell = static_cast<size_t>(b.W) * b.H;
+  KC_TRY(c->d_cells.reserve(ncell + 1));
+  KC_TRY(c->d_skip.reserve(ncell + 4));
+  KC_TRY(c->d_bobs.reserve(2 * n));
+  KC_TRY(c->d_raw.reserve(3 * n));
+  KC_TRY(c->d_sensor_tmp.reserve(n));
+  // the raw points: host copy for the lazy lists, device copy through the BAR
+  c->raw_xyz.assign(xyz, xyz + 3 * n);
+  c->host_lists_valid = false;
+  std::memcpy(c->d_raw.p, xyz, 3 * n * sizeof(float));
+  c->bar_dirty = true;
+  bar_flush(c);
+  SensorArgs a{};
+  a.xyz = c->d_raw.p;
+  a.n = static_cast<int>(n);
+  a.inv_res = c->inv_res;
+  a.res = c->res;
+  a.zc = -static_cast<double>(c->frame.t[2]);
+  a.half_height = c->height / 2.0;
+  a.gkx0 = c->gkx0;
+  a.gky0 = c->gky0;
+  a.gH = c->gH;
+  a.gwpr = c->gwpr;
+  a.gbits = c->d_gbits.p;
+  for (int r = 0; r < 3; ++r) {
+    for (int q = 0; q < 3; ++q) a.R[r][q] = c->obs_tf.R[r][q];
+    a.t[r] = c->obs_tf.t[r];
+  }
+  a.gx0 = b.gx0;
+  a.gy0 = b.gy0;
+  a.inv_g = b.inv_g;
+  a.W = b.W;
+  a.H = b.H;
+  a.cell_start = c->d_cells.p;
+  a.skip = c->d_skip.p;
+  a.bx = c->d_bobs.p;
+  a.by = c->d_bobs.p + n;
+  a.tmp = c->d_sensor_tmp.p;
+  const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
+  KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
+  hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
+  KC_TRY(c->timing.stop(c->stream));
+  KC_HIP(hipGetLastError());
+  c->update_busy = true;
+  KC_TRY(launch_dilate(c));
+  c->have_gbits = true;
+  b.skip = c->d_skip.p;
+  b.cell_start = c->d_cells.p;
+  b.bx = c->d_bobs.p;
+  b.by = c->d_bobs.p + n;
+  b.nobs = static_cast<int>(n);  // upper bound: the tail of each half is never indexed
+  c->O = n;
+  c->n_bucketed = n;
+  *done = true;
+  return KC_OK;
+}
+
 // shard-local sample ids ordered by trig row (stable): consecutive samples of a
 // fused workgroup then share one or two rows of the table
 int build_perm(kc_dwa *c) {
@@ -513,7 +707,7 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
   cd.rr = c->radius * c->radius;
   cd.a = static_cast<double>(c->prm.dims[0]) / 2.0;
   cd.b = static_cast<double>(c->prm.dims[1]) / 2.0;
-  if (!c->have_sensor || c->vox_kx.empty()) return KC_OK;  // enabled = 0
+  if (!c->have_sensor || !any_voxel(c)) return KC_OK;  // enabled = 0
   const double bound = (c->prm.shape == KC_BOX)
                            ? std::sqrt(cd.a * cd.a + cd.b * cd.b)
                            : c->radius;
@@ -553,6 +747,7 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
 // memory: the path for windows that do not fit LDS, spheres and pose batches
 int window_bits_host(kc_dwa *c, CollDev &cd) {
   if (!cd.enabled) return KC_OK;
+  ensure_host_lists(c);
   cd.enabled = 0;
   const size_t nwords = static_cast<size_t>(cd.H) * cd.wpr;
   KC_TRY(c->h_bits.reserve(nwords));
@@ -774,6 +969,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
         c->h_result.p[2] = static_cast<long long>(static_cast<int32_t>(w1 & 0xFFFFFFFFll));
         got = true;
         c->drained = true;
+        c->update_busy = false;  // queued in front of the cycle whose record just arrived
         break;
       }
       if ((spins & 1023) == 1023 &&
@@ -930,6 +1126,12 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     c->trig_direct = large_bar != 0;
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
+    if (const char *e = std::getenv("KC_SENSOR_HOST"))
+      if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
+    c->sensor_lds_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_build_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+    if (!c->sensor_lds_ok) (void)hipGetLastError();
     if (const char *e = std::getenv("KC_COST_KERNEL"))  // tuning/test hook: "block" | "wave"
       c->cost_kernel_force = e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0;
     if (const char *e = std::getenv("KC_EARLY_LAUNCH"))
@@ -1029,6 +1231,8 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_flags.release();
   c->d_dbg.release();
   c->d_dbg2.release();
+  c->d_raw.release();
+  c->d_sensor_tmp.release();
   c->d_perm.release();
   c->d_pvx.release();
   c->d_pvy.release();
@@ -1149,6 +1353,7 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
     KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
   KC_TRY(quiesce_for_update(c));  // staging buffers and device tables are reused
+  c->host_lists_valid = true;
   // CollisionChecker::updateState + updateSensorData<LaserScan>
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->frame = body * c->sensor_tf_body;
@@ -1189,24 +1394,21 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   const auto dbg_t1 = std::chrono::steady_clock::now();
   // updateSensorData<std::vector<Path::Point>>(cloud, global_frame = true)
   c->frame = hm::Rigid3f::identity();
-  c->vox_kx.clear();
-  c->vox_ky.clear();
-  c->vox_ddz.clear();
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
-  const hm::Rigid3f T = c->sensor_tf_body * body;
-  KC_TRY(c->h_obs.reserve(2 * std::max<size_t>(n, 1)));
-  c->vox_kx.reserve(n);
-  c->vox_ky.reserve(n);
-  for (size_t i = 0; i < n; ++i) {
-    const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    add_voxel(c, x, y, z);
-    float o[3];
-    T.apply(x, y, z, o);
-    c->h_obs.p[i] = o[0];
-    c->h_obs.p[n + i] = o[1];
-  }
+  c->obs_tf = c->sensor_tf_body * body;
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;
+  c->host_lists_valid = true;
+  bool done = false;
+  KC_TRY(sensor_update_device(c, xyz, n, &done));
+  if (done) {
+    if (c->debug_stamps)
+      std::fprintf(stderr, "[kc] set_points (device build): sync %.1f | host part %.1f us\n",
+                   std::chrono::duration<double, std::micro>(dbg_t1 - dbg_t0).count(),
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t1).count());
+    return KC_OK;
+  }
+  build_host_lists(c, xyz, n);
   const auto dbg_t2 = std::chrono::steady_clock::now();
   KC_TRY(upload_voxels(c));
   const auto dbg_t3 = std::chrono::steady_clock::now();
@@ -1225,7 +1427,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
                                float ref_len) {
   if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
-  KC_TRY(quiesce_for_update(c));
+  KC_TRY(quiesce_for_update(c, /*sensor_tables=*/false));
   c->S = S;
   c->ref_len = ref_len;
   if (S == 0) return KC_OK;
@@ -1428,7 +1630,7 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   a.flags = c->d_flags.p;
   a.adm_list = c->d_adm.p;
   a.adm_count = c->d_result.p + W_LIST;
-  const bool may_collide = c->have_sensor && !c->vox_kx.empty();
+  const bool may_collide = c->have_sensor && any_voxel(c);
   KC_TRY(window_geometry(c, start->x, start->y, cycle_reach(c), a.c));
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
   const int fs = c->fused_samples, fb = c->fused_block;

@@ -309,6 +309,7 @@ def _path_scenario(name, scale, shape, dims, variant, seed=4):
     {"KC_COST_KERNEL": "block"},  # workgroup-per-sample cost kernel for every list
     {"KC_TRIG_COPY": "1"},        # trig table through pinned memory + H2D copy, launch after it
     {"KC_EARLY_LAUNCH": "0"},     # BAR table, but classic order
+    {"KC_SENSOR_HOST": "1"},      # sensor update (voxel bitmap, buckets) built on the host
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_paths_equal_default_path(tmp_path, env):
     """Every alternative device path (selected by a switch read at context
