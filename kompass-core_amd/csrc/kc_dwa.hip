@@ -47,6 +47,10 @@ struct kc_dwa {
   bool host_lists_valid = true;
   hm::Rigid3f obs_tf{};                 // sensor_tf_body * body of the last point update
   std::vector<float> raw_xyz;           // input of the last device-side sensor update
+  bool raw_is_scan = false;             // ... laserscan points: obstacles are taken at z = 0
+  std::vector<double> scan_angles;      // angles of the last laserscan + their cos/sin (a lidar's
+  std::vector<double2> scan_cs;         // angle table does not change between scans)
+  std::vector<float> scan_xyz;          // sensor-frame points of the last laserscan
   DevBuf<float> d_raw;
   DevBuf<float4> d_sensor_tmp;
   bool device_sensor = true;            // KC_SENSOR_HOST=1 turns the device-side update off
@@ -509,7 +513,7 @@ void build_host_lists(kc_dwa *c, const float *xyz, size_t n) {
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     add_voxel(c, x, y, z);
     float o[3];
-    c->obs_tf.apply(x, y, z, o);
+    c->obs_tf.apply(x, y, c->raw_is_scan ? 0.0f : z, o);
     c->h_obs.p[i] = o[0];
     c->h_obs.p[n + i] = o[1];
   }
@@ -565,7 +569,8 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   double blo[2] = {DBL_MAX, DBL_MAX}, bhi[2] = {-DBL_MAX, -DBL_MAX};
   for (int k = 0; k < 8; ++k) {
     float o[3];
-    c->obs_tf.apply((k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2], o);
+    const float zc = c->raw_is_scan ? 0.0f : ((k & 4) ? hi[2] : lo[2]);
+    c->obs_tf.apply((k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], zc, o);
     if (!std::isfinite(o[0]) || !std::isfinite(o[1])) return KC_OK;
     blo[0] = std::min(blo[0], static_cast<double>(o[0]));
     bhi[0] = std::max(bhi[0], static_cast<double>(o[0]));
@@ -628,6 +633,7 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   a.bx = c->d_bobs.p;
   a.by = c->d_bobs.p + n;
   a.tmp = c->d_sensor_tmp.p;
+  a.obs_z_zero = c->raw_is_scan ? 1 : 0;
   const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
   KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
   hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
@@ -1360,27 +1366,35 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   if (!c->frame.planar())
     KC_FAIL(KC_ERR_UNSUPPORTED,
             "sensor rotation must be about the z axis (planar octree frame)");
-  c->vox_kx.clear();
-  c->vox_ky.clear();
-  c->vox_ddz.clear();
   const float hz = static_cast<float>(
       -static_cast<double>(c->sensor_tf_body.t[2]) / 2.0);
   // CostEvaluator::setPointScan(LaserScan): sensor_tf_body * body_tf_world
-  const hm::Rigid3f T = c->sensor_tf_body * body;
-  KC_TRY(c->h_obs.reserve(2 * std::max<size_t>(n, 1)));
+  c->obs_tf = c->sensor_tf_body * body;
+  c->raw_is_scan = true;
+  // cos/sin of the beam angles (host libm, like the reference), kept while the
+  // angle table stays the same
+  if (c->scan_angles.size() != n ||
+      (n && std::memcmp(c->scan_angles.data(), angles, n * sizeof(double)) != 0)) {
+    c->scan_angles.assign(angles, angles + n);
+    c->scan_cs.resize(n);
+    for (size_t i = 0; i < n; ++i) c->scan_cs[i] = make_double2(std::cos(angles[i]), std::sin(angles[i]));
+  }
+  // sensor-frame points: voxels at z = hz (collision_check.h:110-115; a
+  // non-finite range gives non-finite coordinates, which add_voxel drops),
+  // obstacles from the same x, y at z = 0 (cost path: no filter)
+  c->scan_xyz.resize(3 * n);
   for (size_t i = 0; i < n; ++i) {
-    const double r = ranges[i], a = angles[i];
-    const double ca = std::cos(a), sa = std::sin(a);
-    const double px = r * ca, py = r * sa;
-    if (std::isfinite(r))  // collision_check.h:110-115 (cost path: no filter)
-      add_voxel(c, static_cast<float>(px), static_cast<float>(py), hz);
-    float o[3];
-    T.apply(static_cast<float>(px), static_cast<float>(py), 0.0f, o);
-    c->h_obs.p[i] = o[0];
-    c->h_obs.p[n + i] = o[1];
+    const double r = ranges[i];
+    c->scan_xyz[3 * i] = static_cast<float>(r * c->scan_cs[i].x);
+    c->scan_xyz[3 * i + 1] = static_cast<float>(r * c->scan_cs[i].y);
+    c->scan_xyz[3 * i + 2] = hz;
   }
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;  // cost_evaluator.h:179
+  bool done = false;
+  KC_TRY(sensor_update_device(c, c->scan_xyz.data(), n, &done));
+  if (done) return KC_OK;
+  build_host_lists(c, c->scan_xyz.data(), n);
   KC_TRY(upload_voxels(c));
   return upload_obstacles(c, n);
 }
@@ -1396,6 +1410,7 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   c->frame = hm::Rigid3f::identity();
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->obs_tf = c->sensor_tf_body * body;
+  c->raw_is_scan = false;
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;
   c->host_lists_valid = true;

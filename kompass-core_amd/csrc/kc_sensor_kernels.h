@@ -26,6 +26,7 @@ struct SensorArgs {
   uint8_t *skip;             // [W*H] (+ padding written by the host)
   float *bx, *by;            // cell-ordered coordinates
   float4 *tmp;               // [n] (ox, oy, cell id, rank inside the cell) between the two passes
+  int obs_z_zero;            // laserscan: the obstacle of a point is taken at z = 0
 };
 
 constexpr int kSensorBlock = 1024;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
     float ox, oy;
     int id;
     float4 rec = make_float4(0.f, 0.f, __int_as_float(-1), 0.f);
-    if (sensor_obstacle(a, x, y, z, ox, oy, id))
+    if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id))
       rec = make_float4(ox, oy, __int_as_float(id), __int_as_float(atomicAdd(&lstart[id + 1], 1)));
     a.tmp[i] = rec;
   }
