@@ -54,6 +54,8 @@ constexpr int kCostGrid = 256;    // one workgroup per CU
 // LDS the search tables of a workgroup may take
 constexpr size_t kCostLdsBudget = 150 * 1024;
 constexpr int kSegChunkMin = 16;
+constexpr int kCoopMinSkip = 3;   // empty cells around every point from which the obstacle search
+                                  // of a sample is done point by point by the whole wavefront
 constexpr long long kBlockKernelMaxAdm = 512;   // longest list the workgroup-per-sample kernel gets (one
                                                 // resident round of workgroups; measured crossover ~650)  // segment points per bounding sphere (at most 64 chunks)
 
@@ -648,6 +650,9 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
         double best = DBL_MAX;
         bool active = live && !(isnan(fx) || isnan(fy));
         if ((static_cast<double>(pm) - off) * b.g >= b.cap) active = false;  // all of it costs 0
+        // lanes with an empty neighbourhood wait for the cooperative pass below
+        bool far = active && sk >= kCoopMinSkip && sk < 255;
+        if (far) active = false;
         while (__ballot(active)) {
           if (active) {
             const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
@@ -707,6 +712,94 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
               pm = m;
               m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
             }
+          }
+        }
+        // Far obstacles (points with an empty neighbourhood of kCoopMinSkip
+        // cells): a private ring walk per lane is long and mostly wasted,
+        // because only the trajectory minimum counts and the distance to the
+        // obstacle set is 1-Lipschitz along the trajectory.  After the near
+        // points have left their distances in the shared bound, the wavefront
+        // evaluates the far points one at a time TOGETHER (ring rows over the
+        // lanes), always the one with the smallest lower bound, and every exact
+        // distance raises the lower bounds of the others by the triangle
+        // inequality; points whose bound exceeds the best distance found are
+        // never evaluated.  The values that survive are exact, so the minimum
+        // is the one of the full scan.
+        if (__ballot(far)) {
+          // lower bound of this lane's distance (cells nearer than sk are empty)
+          double lbk = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
+          for (int guard = 0; guard < 64; ++guard) {
+            const double ub2 = __longlong_as_double(static_cast<long long>(
+                *const_cast<volatile unsigned long long *>(&s_obest[wave])));
+            // lanes that can still lower the minimum
+            const bool cont = far && lbk * lbk < ub2 * (1.0 - 1e-6) && lbk < b.cap;
+            const unsigned long long cm = __ballot(cont);
+            if (cm == 0ull) break;
+            // the one with the smallest lower bound (float key, ties by lane)
+            const uint32_t key = cont ? __float_as_uint(static_cast<float>(lbk)) : 0xFFFFFFFFu;
+            const uint32_t kmin = wave_min_u32(key);
+            const int q = __ffsll(static_cast<long long>(__ballot(cont && key == kmin))) - 1;
+            const float xq = lane_value(x, q), yq = lane_value(y, q);
+            const int cxq = __builtin_amdgcn_readlane(cx, q), cyq = __builtin_amdgcn_readlane(cy, q);
+            const int skq = __builtin_amdgcn_readlane(sk, q);
+            const double offq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(off), q),
+                                                 __builtin_amdgcn_readlane(__double2loint(off), q));
+            // exact search for (xq, yq): ring rows over the lanes
+            int pmq = skq - 1, mq = max(1, skq);
+            double found = DBL_MAX;   // wave-uniform after every stage
+            double proven = 0.0;      // everything closer than this was visited
+            for (;;) {
+              const int y0 = max(cyq - mq, 0), y1 = min(cyq + mq, b.H - 1);
+              const int x0 = max(cxq - mq, 0), x1 = min(cxq + mq, b.W - 1);
+              double part = DBL_MAX;
+              for (int row = y0 + lane; row <= y1; row += 64) {
+                const bool inner = pmq >= 0 && row >= cyq - pmq && row <= cyq + pmq;
+                int beg = cells[row * b.W + x0];
+                int end = inner ? cells[row * b.W + max(cxq - pmq, x0)] : cells[row * b.W + x1 + 1];
+                for (int pass = 0; pass < 2; ++pass) {
+                  for (int j = beg; j < end; ++j) {
+                    const double dx = static_cast<double>(obx[j] - xq);
+                    const double dy = static_cast<double>(oby[j] - yq);
+                    const double dd = dx * dx + dy * dy;
+                    part = dd < part ? dd : part;
+                  }
+                  if (!inner) break;
+                  beg = cells[row * b.W + min(cxq + pmq, x1) + 1];
+                  end = cells[row * b.W + x1 + 1];
+                }
+              }
+              const double stage = wave_min_nonneg(part);
+              found = stage < found ? stage : found;
+              const double sh = found < ub2 ? found : ub2;
+              const double reach = (static_cast<double>(mq) - offq) * b.g;
+              bool done = mq >= mmax;
+              if (reach > 0.0) {
+                proven = reach;
+                if (sh < reach * reach * (1.0 - 1e-6)) done = true;
+                if (reach >= b.cap) done = true;
+              }
+              if (done) break;
+              const double need = sh < DBL_MAX
+                                      ? static_cast<double>(__builtin_sqrtf(static_cast<float>(sh)) * 1.0001f)
+                                      : b.cap;
+              const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + offq) + 1.0;
+              pmq = mq;
+              mq = max(mq + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
+            }
+            if (lane == 0)
+              atomicMin(&s_obest[wave], static_cast<unsigned long long>(__double_as_longlong(found)));
+            // what is now known about the distance of point q: it is `found` when
+            // that lies inside the proven radius, at least the proven radius
+            // otherwise (the whole grid visited: nothing else exists)
+            double dq = kc::dsqrt_rn(found);
+            if (!(found < proven * proven) && mq < mmax) dq = proven;
+            if (lane == q) far = false;
+            // triangle inequality: d(p) >= d(q) - |p - q| (slack for the rounding)
+            const double ddx = static_cast<double>(x) - static_cast<double>(xq);
+            const double ddy = static_cast<double>(y) - static_cast<double>(yq);
+            const double sep = kc::dsqrt_rn(ddx * ddx + ddy * ddy);
+            const double lb = dq * (1.0 - 1e-6) - sep * (1.0 + 1e-6) - 1e-9;
+            lbk = lb > lbk ? lb : lbk;
           }
         }
       }
