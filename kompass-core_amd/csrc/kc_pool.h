@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <memory>
@@ -35,21 +36,26 @@ class WorkerPool {
   // Without workers the range is processed on the spot.  fn is copied.
   template <typename F>
   void begin(size_t n, size_t min_chunk, F fn) {
-    const size_t parts =
-        std::min<size_t>(threads_.size(), min_chunk ? std::max<size_t>(n / min_chunk, 1) : n);
+    // with a small pool the caller takes a share too (run inside wait(), after
+    // whatever it does in between); with a large one its share would only delay
+    // the result
+    const size_t self = threads_.size() <= 3 ? 1 : 0;
+    const size_t parts = std::min<size_t>(threads_.size() + self,
+                                          min_chunk ? std::max<size_t>(n / min_chunk, 1) : n);
     if (threads_.empty() || n == 0) {
       if (n) fn(size_t(0), n);
       async_gen_ = 0;
       return;
     }
     async_lock_ = std::unique_lock<std::mutex>(run_mu_);  // one job at a time
-    job_fn_ = [fn, n, parts](size_t part) {
-      // worker w carries part w + 1: shift down, the caller takes none
-      const size_t q = part - 1;
+    job_fn_ = [fn, n, parts, self](size_t part) {
+      // worker w carries part w + 1; without a caller share the parts shift down
+      const size_t q = part - (self ? 0 : 1);
       const size_t b = n * q / parts, e = n * (q + 1) / parts;
       if (b < e) fn(b, e);
     };
-    job_parts_ = parts + 1;
+    job_parts_ = parts + (self ? 0 : 1);
+    async_self_ = self != 0;
     const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -60,6 +66,7 @@ class WorkerPool {
   }
   void wait() {
     if (!async_gen_) return;
+    if (async_self_) job_fn_(0);
     for (size_t w = 0; w < threads_.size(); ++w)
       while (slots_[w].done.load(std::memory_order_acquire) != async_gen_) cpu_relax();
     async_gen_ = 0;
@@ -97,9 +104,48 @@ class WorkerPool {
     std::atomic<uint64_t> done{0};
   };
 
-  WorkerPool() {
+  // CPUs this process may actually use: hardware threads, capped by the cgroup
+  // CPU quota, shared between the ranks of a node (one process per GPU)
+  static unsigned usable_cpus() {
     unsigned hw = std::thread::hardware_concurrency();
-    int n = hw >= 64 ? 11 : hw >= 32 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;
+    if (hw == 0) hw = 1;
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+      char q[32] = {0};
+      long period = 0;
+      if (std::fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && q[0] != 'm') {
+        const long quota = std::atol(q);
+        if (quota > 0) hw = std::min<unsigned>(hw, static_cast<unsigned>(std::max<long>(1, quota / period)));
+      }
+      std::fclose(f);
+    }
+    else {  // cgroup v1
+      long quota = -1, period = 0;
+      if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(fq, "%ld", &quota) != 1) quota = -1;
+        std::fclose(fq);
+      }
+      if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(fp, "%ld", &period) != 1) period = 0;
+        std::fclose(fp);
+      }
+      if (quota > 0 && period > 0)
+        hw = std::min<unsigned>(hw, static_cast<unsigned>(std::max<long>(1, quota / period)));
+    }
+    unsigned ranks = 1;
+    for (const char *name : {"LOCAL_WORLD_SIZE", "WORLD_SIZE"})
+      if (const char *e = std::getenv(name)) {
+        const int r = std::atoi(e);
+        if (r > 1) {
+          ranks = static_cast<unsigned>(r);
+          break;
+        }
+      }
+    return std::max(1u, hw / ranks);
+  }
+
+  WorkerPool() {
+    const unsigned hw = usable_cpus();
+    int n = hw >= 16 ? 11 : hw >= 12 ? 7 : hw >= 6 ? 3 : hw >= 3 ? 1 : 0;
     if (const char *e = std::getenv("KC_HOST_THREADS")) {
       const int want = std::atoi(e);
       if (want >= 1 && want <= 64) n = want - 1;
@@ -156,6 +202,7 @@ class WorkerPool {
   std::mutex mu_, run_mu_;
   std::unique_lock<std::mutex> async_lock_;
   uint64_t async_gen_ = 0;
+  bool async_self_ = false;
   std::condition_variable cv_;
   alignas(64) std::atomic<uint64_t> gen_{0};
   alignas(64) std::atomic<int> sleepers_{0};
