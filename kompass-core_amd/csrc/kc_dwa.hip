@@ -76,6 +76,7 @@ struct kc_dwa {
   bool update_busy = false;  // an update call queued device work since the last idle point
   std::vector<int> cell_id, cell_cursor;  // bucketing scratch (reused)
   std::vector<uint8_t> skip_pad;
+  int test_late_flag_ms = 0;            // KC_TEST_LATE_FLAG_MS: delay the trig sequence word once
   bool early_launch = true;             // fused kernel queued before the trig table exists
   long long trig_seq = 0;
   int seg_chunk = kSegChunkMin, seg_nch = 0, seg_nsup = 0;  // chunking of the tracked segment (cost kernel)
@@ -1140,6 +1141,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (!c->sensor_lds_ok) (void)hipGetLastError();
     if (const char *e = std::getenv("KC_COST_KERNEL"))  // tuning/test hook: "block" | "wave"
       c->cost_kernel_force = e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0;
+    if (const char *e = std::getenv("KC_TEST_LATE_FLAG_MS")) c->test_late_flag_ms = std::atoi(e);
     if (const char *e = std::getenv("KC_EARLY_LAUNCH"))
       c->early_launch = e[0] != '0';            // tuning/test hook
   }
@@ -1708,6 +1710,10 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
     c->timing.mark("host:launch_rollout");
     if (early) {
       WorkerPool::instance().wait();
+      if (c->test_late_flag_ms > 0) {  // test hook: a host that does not deliver in time
+        std::this_thread::sleep_for(std::chrono::milliseconds(c->test_late_flag_ms));
+        c->test_late_flag_ms = 0;      // once
+      }
       // the table is out of the cores (sfence in every worker); now the word
       // the workgroups are waiting for
       *reinterpret_cast<volatile long long *>(c->d_result.p + R_TRIGSEQ) = a.trig_seq;
