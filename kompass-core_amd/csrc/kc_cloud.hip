@@ -16,6 +16,8 @@
 // is a 64-bit atomic min on the bits of the non-negative double.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -148,23 +150,51 @@ __global__ __launch_bounds__(kCloudBlock) void cloud_bins_kernel(CloudArgs a) {
 }
 
 // column minima of the per-workgroup rows
-__global__ __launch_bounds__(256) void cloud_merge_kernel(const unsigned long long *partial, int rows,
-                                                          int num_bins, unsigned long long *bins) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= num_bins) return;
-  unsigned long long m = partial[b];
-  for (int r = 1; r < rows; ++r) {
-    const unsigned long long v = partial[static_cast<size_t>(r) * num_bins + b];
-    m = v < m ? v : m;
+// ... and hands the result to the host: bins, edge-list count and (last
+// workgroup) the sequence number go straight into pinned host memory, which
+// the host polls instead of copying and waiting on the stream
+__global__ __launch_bounds__(1024) void cloud_merge_kernel(const unsigned long long *partial, int rows,
+                                                           int num_bins, unsigned long long *bins,
+                                                           const unsigned int *count_now,
+                                                           unsigned int *next_count, unsigned int *ticket,
+                                                           unsigned long long *host_out, long long seq) {
+  // 64 bins per workgroup, 16 lanes per bin over the rows (eight loads in
+  // flight per lane), LDS minimum over the 16
+  __shared__ unsigned long long part[16][64];
+  const int bl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + bl;
+  unsigned long long m = ~0ull;
+  if (b < num_bins) {
+#pragma unroll 8
+    for (int r = rg; r < rows; r += 16) {
+      const unsigned long long v = partial[static_cast<size_t>(r) * num_bins + b];
+      m = v < m ? v : m;
+    }
   }
-  bins[b] = m;
+  part[rg][bl] = m;
+  __syncthreads();
+  if (rg == 0 && b < num_bins) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = part[k][bl] < m ? part[k][bl] : m;
+    bins[b] = m;
+    host_out[2 + b] = m;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    *ticket = 0u;
+    host_out[1] = *count_now;
+    *next_count = 0u;  // the edge-list counter of the NEXT call (the two alternate)
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned long long *>(host_out) = static_cast<unsigned long long>(seq);
+  }
 }
 
 __global__ void cloud_arm_kernel(unsigned long long *bins, int n, double max_range,
-                                 unsigned int *list_count) {
+                                 unsigned int *counts) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (bins && i < n) bins[i] = static_cast<unsigned long long>(__double_as_longlong(max_range));
-  if (i == 0) *list_count = 0u;
+  if (i == 0) counts[0] = counts[1] = 0u;  // both edge-list counters
 }
 
 }  // namespace kc
@@ -178,7 +208,10 @@ struct kc_cloud {
   DevBuf<uint8_t> d_data;
   DevBuf<unsigned long long> d_bins;
   DevBuf<unsigned long long> d_partial;
-  DevBuf<unsigned int> d_count;
+  DevBuf<unsigned int> d_count;   // [2]: edge-list counters, alternating between calls; [2]: ticket
+  unsigned calls = 0;
+  PinBuf<unsigned long long> h_out;  // [0] sequence, [1] edge count, [2..] bins (written by the merge kernel)
+  long long seq = 0;
   DevBuf<float2> d_list;         // (x, y) of the edge points
   PinBuf<unsigned long long> h_bins;
   PinBuf<unsigned int> h_count;
@@ -211,8 +244,14 @@ int kc_cloud_create(size_t max_bytes, size_t max_bins, int device, kc_cloud **ou
   if ((rc = c->d_data.reserve(std::max<size_t>(max_bytes, 64))) ||
       (rc = c->d_bins.reserve(std::max<size_t>(max_bins, 16))) ||
       (rc = c->h_bins.reserve(std::max<size_t>(max_bins, 16))) ||
-      (rc = c->d_count.reserve(1)) || (rc = c->h_count.reserve(1)))
+      (rc = c->d_count.reserve(3)) || (rc = c->h_count.reserve(1)) ||
+      (rc = c->h_out.reserve(std::max<size_t>(max_bins, 16) + 2)))
     return fail(rc);
+  c->h_out.p[0] = 0;
+  if (hipMemset(c->d_count.p, 0, 3 * sizeof(unsigned int)) != hipSuccess) {
+    set_error("counter initialisation failed");
+    return fail(KC_ERR_HIP);
+  }
   c->lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(cloud_bins_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kCloudMaxLdsBins * 8) == hipSuccess;
@@ -237,6 +276,7 @@ void kc_cloud_destroy(kc_cloud *c) {
   c->d_count.release();
   c->h_bins.release();
   c->h_count.release();
+  c->h_out.release();
   c->h_list.release();
   delete c;
 }
@@ -310,10 +350,17 @@ int kc_cloud_to_laserscan(kc_cloud *c, const int8_t *data, size_t nbytes,
   a.n_packed = std::min<long long>(n_rec, static_cast<long long>(nbytes / 16));
   a.bins = c->d_bins.p;
   a.partial = c->d_partial.p;
-  a.list_count = c->d_count.p;
-  a.list = c->d_list.p;
-  hipLaunchKernelGGL(cloud_arm_kernel, dim3((num_bins + 255) / 256), dim3(256), 0, s,
-                     in_lds ? nullptr : c->d_bins.p, num_bins, max_range, c->d_count.p);
+  unsigned int *const count_now = c->d_count.p + (c->calls & 1u);
+  unsigned int *const count_next = c->d_count.p + ((c->calls + 1u) & 1u);
+  ++c->calls;
+  a.list_count = count_now;
+  // the edge list goes straight to pinned host memory (a few hundred 8-byte
+  // PCIe writes) when the polled hand-off is used
+  if (in_lds) KC_TRY(c->h_list.reserve(static_cast<size_t>(n_rec)));
+  a.list = in_lds ? c->h_list.p : c->d_list.p;
+  if (!in_lds)  // global-atomic path: the bins start at max_range (and both counters at 0)
+    hipLaunchKernelGGL(cloud_arm_kernel, dim3((num_bins + 255) / 256), dim3(256), 0, s,
+                       c->d_bins.p, num_bins, max_range, c->d_count.p);
   KC_TRY(c->timing.start("cloud_bins_kernel", s));
   if (in_lds)
     hipLaunchKernelGGL(cloud_bins_kernel<true>, dim3(grid), dim3(kCloudBlock),
@@ -321,25 +368,45 @@ int kc_cloud_to_laserscan(kc_cloud *c, const int8_t *data, size_t nbytes,
   else
     hipLaunchKernelGGL(cloud_bins_kernel<false>, dim3(grid), dim3(kCloudBlock), 0, s, a);
   KC_TRY(c->timing.stop(s));
+  size_t nl = 0;
   if (in_lds) {
+    KC_TRY(c->h_out.reserve(static_cast<size_t>(num_bins) + 2));
+    const long long seq = ++c->seq;
     KC_TRY(c->timing.start("cloud_merge_kernel", s));
-    hipLaunchKernelGGL(cloud_merge_kernel, dim3((num_bins + 255) / 256), dim3(256), 0, s,
-                       c->d_partial.p, static_cast<int>(grid), num_bins, c->d_bins.p);
+    hipLaunchKernelGGL(cloud_merge_kernel, dim3((num_bins + 63) / 64), dim3(1024), 0, s,
+                       c->d_partial.p, static_cast<int>(grid), num_bins, c->d_bins.p, count_now,
+                       count_next, c->d_count.p + 2, c->h_out.p, seq);
     KC_TRY(c->timing.stop(s));
+    KC_HIP(hipGetLastError());
+    // poll the sequence word (bounded: then wait on the stream)
+    volatile unsigned long long *hp = c->h_out.p;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0; hp[0] != static_cast<unsigned long long>(seq); ++spins) {
+      if ((spins & 1023) == 1023 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+        KC_HIP(hipStreamSynchronize(s));
+        break;
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < num_bins; ++i) std::memcpy(&ranges_out[i], &c->h_out.p[2 + i], sizeof(double));
+    nl = static_cast<size_t>(c->h_out.p[1]);
+  } else {
+    KC_HIP(hipGetLastError());
+    KC_HIP(hipMemcpyAsync(c->h_bins.p, c->d_bins.p, num_bins * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, s));
+    KC_HIP(hipMemcpyAsync(c->h_count.p, count_now, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    KC_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < num_bins; ++i) std::memcpy(&ranges_out[i], &c->h_bins.p[i], sizeof(double));
+    nl = c->h_count.p[0];
+    if (nl) {
+      KC_TRY(c->h_list.reserve(nl));
+      KC_HIP(hipMemcpyAsync(c->h_list.p, c->d_list.p, nl * sizeof(float2), hipMemcpyDeviceToHost, s));
+      KC_HIP(hipStreamSynchronize(s));
+    }
   }
-  KC_HIP(hipGetLastError());
-  KC_HIP(hipMemcpyAsync(c->h_bins.p, c->d_bins.p, num_bins * sizeof(unsigned long long),
-                        hipMemcpyDeviceToHost, s));
-  KC_HIP(hipMemcpyAsync(c->h_count.p, c->d_count.p, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-  KC_HIP(hipStreamSynchronize(s));
-  for (int i = 0; i < num_bins; ++i) std::memcpy(&ranges_out[i], &c->h_bins.p[i], sizeof(double));
-  const size_t nl = c->h_count.p[0];
   c->last_rebinned = nl;
-  if (nl == 0) return KC_OK;
   // the edge cases: the reference expression on the host (pointcloud.h:148-175)
-  KC_TRY(c->h_list.reserve(nl));
-  KC_HIP(hipMemcpyAsync(c->h_list.p, c->d_list.p, nl * sizeof(float2), hipMemcpyDeviceToHost, s));
-  KC_HIP(hipStreamSynchronize(s));
   for (size_t k = 0; k < nl; ++k) {
     const float x = c->h_list.p[k].x, y = c->h_list.p[k].y;
     const float xx = x * x, yy = y * y;
