@@ -347,6 +347,92 @@ def mapper_bench(args):
     }
 
 
+def bayes_mapper_bench(args):
+    """SURVEY 8f rank 3 (not the default bench line; `--mapper --bayes`): one
+    step of the Bayesian mapping loop at cfg4 size -- warp the previous
+    probability grid to the new pose, scan with the Bayesian update, feed the
+    probabilities back -- everything resident on the device.  The reference's
+    own CPU mapper benchmark times scanToGridBaysian
+    (benchmark_runner.cpp:207-213)."""
+    import kompass_hip as kh
+    import synthetic as syn
+    from oracle import ko
+
+    H = W = 1000
+    n = 4096
+    params = dict(p_prior=0.6, p_occupied=0.9, p_empty=0.1, range_sure=0.1, range_max=20.0, wall_size=0.2)
+    ang, rng = syn.dense_scan(n, 4.0)
+    m = kh.MapperContext(H, W, 0.05, (0, 0, 0), 0.0, n)
+    m.enable_bayes(**params)
+    scans = [rng * (1.0 + 0.01 * ((i % 5) - 2)) for i in range(8)]
+    pose = lambda i: ((0.01 * (i % 7), -0.005 * (i % 5)), 0.002 * (i % 11))
+
+    def step(i):
+        m.get_previous_grid_in_current_pose(*pose(i))
+        m.scan_to_grid_baysian_device(ang, scans[i % 8])
+        m.set_previous_prob(None)
+        m.sync()
+
+    for i in range(args.warmup):
+        step(i)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    m.set_stream(None)  # drains the stream: the last feedback copy is inside the timed region
+    el = time.perf_counter() - t0
+    m.timing_enable(True)
+    kms = {}
+    for i in range(args.steps):
+        m.get_previous_grid_in_current_pose(*pose(i))
+        for k, v in m.timings():
+            kms.setdefault(k, []).append(v)
+        m.scan_to_grid_baysian_device(ang, scans[i % 8])
+        m.sync()
+        for k, v in m.timings():
+            kms.setdefault(k, []).append(v)
+    m.timing_enable(False)
+    # parity + CPU baseline on the same three steps from a fresh state
+    m2 = kh.MapperContext(H, W, 0.05, (0, 0, 0), 0.0, n)
+    m2.enable_bayes(**params)
+    o = ko.BayesMapper(H, W, 0.05, (0, 0, 0), 0.0, **params)
+    t2 = time.perf_counter()
+    for i in range(3):
+        o.get_previous_grid_in_current_pose(*pose(i))
+        want_g, want_p = o.scan_to_grid_baysian(ang, scans[i % 8])
+        o.set_previous(want_p)
+    t_cpu = (time.perf_counter() - t2) / 3
+    for i in range(3):
+        m2.get_previous_grid_in_current_pose(*pose(i))
+        got_g, got_p = m2.scan_to_grid_baysian(ang, scans[i % 8])
+        m2.set_previous_prob(None)
+    same = bool(np.array_equal(got_g, want_g) and
+                np.array_equal(np.ascontiguousarray(got_p).view(np.uint32),
+                               np.ascontiguousarray(want_p).view(np.uint32)))
+    ray_cells = int((want_g >= 0).sum())
+    cells = H * W
+    # per step: warp 2x4 B/cell, clear 4, tags read+reset, previous read, prob write (4 each where
+    # touched), feedback copy 2x4, plus the ray read-modify-writes of the plain scan
+    bytes_step = cells * (8 + 4 + 4 + 4 + 8) + 12 * n + ray_cells * (12 + 8 + 4)
+    dom = max(kms, key=lambda k: np.mean(kms[k]))
+    dom_ms = float(np.mean(kms[dom]))
+    dom_bytes = {"warp_kernel": 8 * cells, "grid_clear": 4 * cells, "rays_kernel": 20 * ray_cells + 12 * n,
+                 "bayes_cells_kernel": 8 * cells + 12 * ray_cells, "endpoints_kernel": 16 * n}.get(dom, bytes_step)
+    return {
+        "metric": "mapping steps/s", "value": args.steps / el, "unit": "steps/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 probabilities (f64 odds) / int32 grid",
+        "data": "synthetic",
+        "config": {"workload": "cfg4 grid, Bayesian loop: warp previous grid + 4096-beam Bayesian scan + "
+                               "feedback, 1000x1000@0.05, grids resident on device"},
+        "kernels_ms": {k: float(np.mean(v)) for k, v in kms.items()},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None},
+        "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "steps/s", "cores": 1, "kind": "port",
+                         "sample": "3 steps", "grids_match": same},
+    }
+
+
 def pointcloud_bench(args):
     """SURVEY 8f rank 1 (not the default bench line; `--pointcloud`): 1M-point
     PointCloud2 buffer resident on the device -> 2048-bin laserscan."""
@@ -413,6 +499,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
     ap.add_argument("--mapper", action="store_true", help="bench the LocalMapper (cfg4) instead")
+    ap.add_argument("--bayes", action="store_true", help="with --mapper: the Bayesian mapping loop (8f rank 3)")
     ap.add_argument("--pointcloud", action="store_true", help="SURVEY 8f rank 1 instead of the controller")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -431,7 +518,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        out = (mapper_bench(args) if args.mapper else pointcloud_bench(args) if args.pointcloud
+        out = (bayes_mapper_bench(args) if args.mapper and args.bayes else
+               mapper_bench(args) if args.mapper else pointcloud_bench(args) if args.pointcloud
                else controller_bench(args, rank, world, local_rank))
     finally:
         sys.stdout.flush()

@@ -263,6 +263,36 @@ int kc_mapper_scan_to_grid(kc_mapper *ctx, const double *angles,
 int kc_mapper_scan_to_grid_device(kc_mapper *ctx, const double *angles,
                                   const double *ranges, size_t n);
 int kc_mapper_grid_device(kc_mapper *ctx, void **dev_grid_int32);
+
+/* LocalMapper's second ctor (local_mapper.h:58-103): the inverse sensor model of
+ * the Bayesian update.  kc_mapper_enable_bayes allocates the probability grids
+ * (float, column-major like the occupancy grid) and fills the previous grid
+ * with p_prior (local_mapper.h:81-83). */
+typedef struct kc_bayes_params {
+  float p_prior, p_occupied, p_empty, range_sure, range_max, wall_size;
+} kc_bayes_params;
+int kc_mapper_enable_bayes(kc_mapper *ctx, const kc_bayes_params *params);
+/* LocalMapper::scanToGridBaysian (local_mapper.cpp:161-202,222-241) in the
+ * reference's single-thread order: the probability of a cell is
+ * updateGridCellProbability (:106-125) of the LAST beam that crosses it and of
+ * the previous grid; untouched cells hold p_prior.  The occupancy grid is the
+ * one scanToGrid gives.  Parity is against this build's restatement only (the
+ * reference tests print these grids without asserting on them). */
+int kc_mapper_scan_to_grid_bayes(kc_mapper *ctx, const double *angles, const double *ranges,
+                                 size_t n, int32_t *grid_out, float *prob_out);
+int kc_mapper_scan_to_grid_bayes_device(kc_mapper *ctx, const double *angles,
+                                        const double *ranges, size_t n);
+/* device addresses of gridDataProb and (optional) previousGridDataProb */
+int kc_mapper_prob_device(kc_mapper *ctx, void **dev_prob_f32, void **dev_prev_f32);
+/* LocalMapper::getPreviousGridInCurrentPose (local_mapper.cpp:17-78): bilinear
+ * warp of the previous probability grid, in place (stream-ordered) */
+int kc_mapper_warp_previous(kc_mapper *ctx, const float current_position_in_previous_pose[2],
+                            double current_orientation_in_previous_pose);
+int kc_mapper_get_previous_prob(kc_mapper *ctx, float *prob_out);
+/* not in the reference, whose previous grid is only ever warped: upload a
+ * previous grid (in != NULL) or feed the last scan's probabilities back on the
+ * device (in == NULL) */
+int kc_mapper_set_previous_prob(kc_mapper *ctx, const float *in);
 int kc_mapper_sync(kc_mapper *ctx);
 int kc_mapper_timing_enable(kc_mapper *ctx, int enable);
 int kc_mapper_timing_get(kc_mapper *ctx, const char **names, float *ms,

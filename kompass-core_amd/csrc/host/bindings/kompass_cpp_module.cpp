@@ -3,6 +3,7 @@
 // reference module that kompass_core.control.dwa / mapping.local_mapper and
 // the named tests use, with the same submodule layout, class names, argument
 // names and defaults (reference: src/kompass_cpp/bindings/*.cpp).
+#include <cstring>
 #include <pybind11/functional.h>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
@@ -320,6 +321,12 @@ PYBIND11_MODULE(kompass_cpp, m) {
                             {(py::ssize_t)sizeof(int), (py::ssize_t)(sizeof(int) * g.rows())}, g.data(), owner);
   };
 
+  auto probView = [](Eigen::MatrixXf &g, py::handle owner) {
+    return py::array_t<float>({(py::ssize_t)g.rows(), (py::ssize_t)g.cols()},
+                              {(py::ssize_t)sizeof(float), (py::ssize_t)(sizeof(float) * g.rows())}, g.data(),
+                              owner);
+  };
+
   py::class_<Mapping::LocalMapper>(mp, "LocalMapper")
       .def(py::init([](int H, int W, float res, const py::object &pos, float orient, bool pc, int scan, float step,
                        float maxh, float minh, float rmax, int mppl, int threads) {
@@ -347,11 +354,49 @@ PYBIND11_MODULE(kompass_cpp, m) {
            }, "Convert a raw point cloud to occupancy grid", py::arg("data"), py::arg("point_step"),
            py::arg("row_step"), py::arg("height"), py::arg("width"), py::arg("x_offset"), py::arg("y_offset"),
            py::arg("z_offset"))
-      // the reference binds scan_to_grid_baysian to scanToGrid as well
-      // (bindings_mapping.cpp:59-75)
-      .def("scan_to_grid_baysian", [gridView](py::object self, const std::vector<double> &angles, const std::vector<double> &ranges) {
-             return gridView(self.cast<Mapping::LocalMapper &>().scanToGrid(angles, ranges), self);
-           }, py::arg("angles"), py::arg("ranges"));
+      // The reference binds scan_to_grid_baysian to scanToGrid
+      // (bindings_mapping.cpp:59-75) while its own Python caller unpacks two
+      // grids (mapping/local_mapper.py:289-306): bound here to the real
+      // scanToGridBaysian, which is what that caller needs.
+      .def("scan_to_grid_baysian", [gridView, probView](py::object self, const std::vector<double> &angles,
+                                                        const std::vector<double> &ranges) {
+             auto r = self.cast<Mapping::LocalMapper &>().scanToGridBaysian(angles, ranges);
+             return py::make_tuple(gridView(std::get<0>(r), self), probView(std::get<1>(r), self));
+           }, "Convert laser scan data to occupancy grid, with baysian update", py::arg("angles"), py::arg("ranges"))
+      .def("scan_to_grid_baysian", [gridView, probView](py::object self, const std::vector<int8_t> &data,
+                                                        int point_step, int row_step, int height, int width,
+                                                        float x_offset, float y_offset, float z_offset) {
+             auto r = self.cast<Mapping::LocalMapper &>().scanToGridBaysian(data, point_step, row_step, height,
+                                                                            width, x_offset, y_offset, z_offset);
+             return py::make_tuple(gridView(std::get<0>(r), self), probView(std::get<1>(r), self));
+           }, "Convert a raw point cloud to occupancy grid, with baysian update", py::arg("data"),
+           py::arg("point_step"), py::arg("row_step"), py::arg("height"), py::arg("width"), py::arg("x_offset"),
+           py::arg("y_offset"), py::arg("z_offset"))
+      // returns the warped grid (the reference returns None and its Python
+      // caller stores the result; `unknown_value`, which that caller passes, is
+      // accepted and unused: the fill value is the mapper's p_prior,
+      // local_mapper.cpp:41)
+      .def("get_previous_grid_in_current_pose", [probView](py::object self, const py::object &pos, double orient,
+                                                           const py::object &) {
+             auto &m = self.cast<Mapping::LocalMapper &>();
+             auto v = py::cast<std::vector<float>>(pos);
+             if (v.size() < 2) throw std::invalid_argument("current_position_in_previous_pose needs x and y");
+             m.getPreviousGridInCurrentPose(Eigen::Vector2f(v[0], v[1]), orient);
+             return probView(m.previousGridProb(), self);
+           }, py::arg("current_position_in_previous_pose"), py::arg("current_orientation_in_previous_pose"),
+           py::arg("unknown_value") = py::none())
+      .def("set_previous_grid", [](Mapping::LocalMapper &m, const py::object &prob) {
+             if (prob.is_none()) {
+               m.setPreviousGridProb(nullptr);
+               return;
+             }
+             auto a = py::array_t<float, py::array::f_style | py::array::forcecast>::ensure(prob);
+             if (!a || a.ndim() != 2) throw std::invalid_argument("previous grid must be a 2-D array");
+             Eigen::MatrixXf g(static_cast<int>(a.shape(0)), static_cast<int>(a.shape(1)));
+             std::memcpy(g.data(), a.data(), sizeof(float) * static_cast<size_t>(a.size()));
+             m.setPreviousGridProb(&g);
+           }, "Replace the previous probability grid (None: feed the last scan's probabilities back)",
+           py::arg("previous_grid") = py::none());
 
   py::class_<Mapping::LocalMapperGPU, Mapping::LocalMapper>(mp, "LocalMapperGPU")
       .def(py::init([](int H, int W, float res, const py::object &pos, float orient, bool pc, int scan, float step,

@@ -1,8 +1,9 @@
 // laserscan -> occupancy LocalMapper of the kompass_cpp surface (reference:
 // mapping/local_mapper.{h,cpp}).  scanToGrid runs on the device with the CPU
 // mapper's semantics (same cells, bit for bit), the raw point-cloud overload
-// bins the cloud on the device first (M5); the Bayesian update is outside this
-// build's scope (M3) and throws.
+// bins the cloud on the device first (M5); scanToGridBaysian and
+// getPreviousGridInCurrentPose (M3) run on the device as well, in the
+// reference's single-thread beam order.
 #pragma once
 
 #include <cstdint>
@@ -43,8 +44,16 @@ class LocalMapper {
   std::tuple<Eigen::MatrixXi &, Eigen::MatrixXf &>
   scanToGridBaysian(const std::vector<double> &angles,
                     const std::vector<double> &ranges);
+  std::tuple<Eigen::MatrixXi &, Eigen::MatrixXf &>
+  scanToGridBaysian(const std::vector<int8_t> &data, int point_step, int row_step, int height,
+                    int width, float x_offset, float y_offset, float z_offset);
   void getPreviousGridInCurrentPose(const Eigen::Vector2f &currentPositionInPreviousPose,
                                     double currentOrientationInPreviousPose);
+  // not in the reference, whose previousGridDataProb is only ever warped
+  // (local_mapper.cpp:77): read it back / replace it (nullptr = feed the last
+  // scan's probabilities back, a device copy)
+  Eigen::MatrixXf &previousGridProb();
+  void setPreviousGridProb(const Eigen::MatrixXf *prob);
 
  protected:
   const int m_gridHeight, m_gridWidth;
@@ -53,10 +62,16 @@ class LocalMapper {
   const Eigen::Vector3f m_laserscanPosition;
   const int m_scanSize;
   const float m_maxHeight, m_minHeight;
+  float m_angleStep = 0.0f;
+  // inverse sensor model, defaults of the first ctor (local_mapper.h:22-24)
+  float m_pPrior = 0.5f, m_pEmpty = 0.4f, m_pOccupied = 0.6f, m_rangeSure = 1.0f, m_wallSize = 0.2f;
   // pointcloud mode (local_mapper.h:38-56): angles i * 2 pi / scanSize
   std::vector<double> initializedAngles, initializedRanges;
   Eigen::MatrixXi gridData;
+  Eigen::MatrixXf gridDataProb, previousGridDataProb;
   hip::MapperHandle ctx_;
+  bool bayesEnabled_ = false;
+  void enableBayes();
 };
 
 }  // namespace Mapping

@@ -114,6 +114,75 @@ __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_kernel(
   }
 }
 
+// ---- M3: which beam decides a cell -------------------------------------------
+// The sequential reference overwrites gridDataProb(pt) beam after beam
+// (local_mapper.cpp:199), so the probability of a cell is the one computed with
+// the range of the LAST beam whose super-cover line crosses it: tag = beam + 1,
+// kept as a maximum.  Global atomics run at the memory side, one request per
+// 64-byte line a wave instruction touches, and that request rate is what bounds
+// this pass: the tags live in 4x4-cell blocks (one line each) and the 64 lanes
+// of a wave take 64 CONSECUTIVE steps of the line, so a wave instruction
+// touches ~20 lines instead of 64.
+__device__ __forceinline__ size_t tag_index(int i, int j, int hb) {
+  return ((static_cast<size_t>(j >> 2) * hb + (i >> 2)) << 4) | ((j & 3) << 2) | (i & 3);
+}
+
+__device__ __forceinline__ void stamp_tag(int *grid, unsigned int *last, unsigned int tag, int hb,
+                                          const MapGeom &g, int i, int j) {
+  if (i >= 0 && i < g.H && j >= 0 && j < g.W) {
+    grid[(size_t)i + (size_t)j * (size_t)g.H] = KC_EMPTY;
+    atomicMax(&last[tag_index(i, j, hb)], tag);
+  }
+}
+
+// same line as rays_kernel, one step per lane per pass: the state before step i
+// has the closed form used there for the first step of a chunk
+__global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_bayes_kernel(
+    MapGeom g, const float *__restrict__ ranges, const double2 *__restrict__ trig, int n,
+    int *__restrict__ grid, unsigned int *__restrict__ last, int hb) {
+  const int beam = blockIdx.x * kBeamsPerBlock + (threadIdx.x >> 6);
+  if (beam >= n) return;
+  const unsigned int tag = static_cast<unsigned int>(beam) + 1u;
+  const int lane = threadIdx.x & 63;
+  const int2 t = beam_endpoint(g, ranges[beam], trig[beam]);
+  int dx = t.x - g.s0, dy = t.y - g.s1;
+  const int xstep = dx >= 0 ? 1 : -1, ystep = dy >= 0 ? 1 : -1;
+  dx = abs(dx);
+  dy = abs(dy);
+  if (lane == 0) stamp_tag(grid, last, tag, hb, g, g.s0, g.s1);  // first emitted point
+  const bool xmajor = 2 * dx >= 2 * dy;
+  const int nsteps = xmajor ? dx : dy;
+  const long long dmaj = xmajor ? dx : dy, dmin = xmajor ? dy : dx;
+  const long long ddmaj = 2 * dmaj, ddmin = 2 * dmin;
+  const int astep = xmajor ? xstep : ystep, bstep = xmajor ? ystep : xstep;
+  const int a0 = xmajor ? g.s0 : g.s1, b0 = xmajor ? g.s1 : g.s0;
+  for (int i = lane + 1; i <= nsteps; i += 64) {
+    const long long eprev = dmaj + (long long)(i - 1) * ddmin;
+    const long long k = static_cast<long long>(
+        floor(static_cast<double>(eprev - 1) / static_cast<double>(ddmaj)));
+    const long long errorprev = eprev - k * ddmaj;
+    long long error = errorprev + ddmin;
+    const int a = a0 + astep * i;
+    int bq = b0 + bstep * (int)k;
+    if (error > ddmaj) {
+      bq += bstep;
+      error -= ddmaj;
+      const bool lo = error + errorprev < ddmaj, hi = error + errorprev > ddmaj;
+      // x-major: lo -> (x, y - ystep), hi -> (x - xstep, y); y-major mirrored
+      if (!hi) {  // lo or both
+        if (xmajor) stamp_tag(grid, last, tag, hb, g, a, bq - bstep);
+        else stamp_tag(grid, last, tag, hb, g, bq - bstep, a);
+      }
+      if (!lo) {  // hi or both
+        if (xmajor) stamp_tag(grid, last, tag, hb, g, a - astep, bq);
+        else stamp_tag(grid, last, tag, hb, g, bq, a - astep);
+      }
+    }
+    if (xmajor) stamp_tag(grid, last, tag, hb, g, a, bq);
+    else stamp_tag(grid, last, tag, hb, g, bq, a);
+  }
+}
+
 // pass 3: the end cell of every beam (fillGridAroundPoint with padding 0,
 // local_mapper.cpp:148-151)
 // The last workgroup to finish tells the host (sequence number into pinned
@@ -128,6 +197,7 @@ __global__ void endpoints_kernel(MapGeom g, const float *__restrict__ ranges,
     if (t.x >= 0 && t.x < g.H && t.y >= 0 && t.y < g.W)
       grid[(size_t)t.x + (size_t)t.y * (size_t)g.H] = KC_OCCUPIED;
   }
+  if (host_seq == nullptr) return;  // Bayesian scan: the cell pass reports
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -136,6 +206,99 @@ __global__ void endpoints_kernel(MapGeom g, const float *__restrict__ ranges,
       *reinterpret_cast<volatile long long *>(host_seq) = seq;
     }
   }
+}
+
+// ---- M3: Bayesian cell update + previous-grid warp ---------------------------
+struct BayesParams {
+  float p_prior, p_occupied, p_empty, range_sure, range_max, wall_size;
+};
+
+// LocalMapper::updateGridCellProbability (local_mapper.cpp:106-125), expression
+// by expression: the literal 1.0 makes the sensor odds and the product around
+// them double; the result narrows to float.
+__device__ __forceinline__ float bayes_cell(const BayesParams &bp, float res, float distance,
+                                            float current_range, float previous_prob) {
+  distance = distance * res;
+  current_range = current_range - bp.wall_size;
+  const float pF = (distance < current_range) ? bp.p_empty : bp.p_occupied;
+  const float delta = (distance < bp.range_sure) ? 0.0f : 1.0f;
+  const float p_sensor =
+      pF + (delta * kc::div_rn(distance - bp.range_sure, bp.range_max) * (bp.p_prior - pF));
+  const float prev_odds = kc::div_rn(previous_prob, 1 - previous_prob);
+  const double sensor_odds =
+      static_cast<double>(p_sensor) / (1.0 - static_cast<double>(p_sensor));
+  const float prior_odds = kc::div_rn(1 - bp.p_prior, bp.p_prior);
+  const double p_curr =
+      1 - (1 / (1 + ((static_cast<double>(prev_odds) * sensor_odds) *
+                     static_cast<double>(prior_odds))));
+  return static_cast<float>(p_curr);
+}
+
+// one thread per cell: the beam that decided the cell (tag) gives the range,
+// the cell's own position gives the distance -- (pt - m_startPoint).norm() on
+// Vector2i is Eigen's integer norm: the double sqrt truncated back to int
+// (local_mapper.cpp:180).  Cells no beam crossed keep the prior
+// (gridDataProb.fill, :227).  The tag grid is cleared for the next scan on the
+// way.  A workgroup covers 64 x 4 cells: each wave reads four whole tag lines
+// and four 64-byte runs of the column-major probability grids.
+__global__ __launch_bounds__(256) void bayes_cells_kernel(
+    MapGeom g, BayesParams bp, const float *__restrict__ ranges, unsigned int *__restrict__ last,
+    int hb, const float *__restrict__ prev, float *__restrict__ prob) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + wave * 16 + (lane & 15);
+  const int j = blockIdx.y * 4 + (lane >> 4);
+  if (i >= g.H || j >= g.W) return;
+  const size_t k = static_cast<size_t>(i) + static_cast<size_t>(j) * static_cast<size_t>(g.H);
+  const size_t tk = tag_index(i, j, hb);
+  const unsigned int tag = last[tk];
+  float v = bp.p_prior;
+  if (tag != 0u) {
+    const int di = i - g.s0, dj = j - g.s1;
+    const float distance =
+        static_cast<float>(static_cast<int>(kc::dsqrt_rn(static_cast<double>(di * di + dj * dj))));
+    v = bayes_cell(bp, g.res, distance, ranges[tag - 1u], prev[k]);
+    last[tk] = 0u;
+  }
+  prob[k] = v;
+}
+
+// one thread after the last pass of a Bayesian scan: the kernel boundary in
+// front of it has made the scan visible, it reports the sequence number
+__global__ void scan_done_kernel(long long *host_seq, long long seq) {
+  *reinterpret_cast<volatile long long *>(host_seq) = seq;
+}
+
+// LocalMapper::getPreviousGridInCurrentPose (local_mapper.cpp:17-78): the
+// reference inverts the same Matrix3f for every cell; the host does it once
+// (Eigen's closed 3x3 form) and hands over the two rows that matter.  The lazy
+// 3-term products reduce as a0 + (a1 + a2).  Cell (row y, col x) at y + x*H.
+struct WarpArgs {
+  float r0[3], r1[3];
+  int H, W;
+  float prior;
+};
+
+__global__ __launch_bounds__(256) void warp_kernel(WarpArgs a, const float *__restrict__ prev,
+                                                   float *__restrict__ out, unsigned int cells) {
+  const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= cells) return;
+  const int y = static_cast<int>(k % static_cast<unsigned int>(a.H));
+  const int x = static_cast<int>(k / static_cast<unsigned int>(a.H));
+  const float fx = static_cast<float>(x), fy = static_cast<float>(y);
+  const double srcX = static_cast<double>(a.r0[0] * fx + (a.r0[1] * fy + a.r0[2] * 1.0f));
+  const double srcY = static_cast<double>(a.r1[0] * fx + (a.r1[1] * fy + a.r1[2] * 1.0f));
+  float value = a.prior;
+  if (srcX >= 0 && srcX < a.W - 1 && srcY >= 0 && srcY < a.H - 1) {
+    const int x0 = static_cast<int>(floor(srcX)), y0 = static_cast<int>(floor(srcY));
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float w0 = static_cast<float>(srcX - x0), w1 = 1.0f - w0;
+    const float h0 = static_cast<float>(srcY - y0), h1 = 1.0f - h0;
+    const size_t H = static_cast<size_t>(a.H);
+    const float p00 = prev[y0 + x0 * H], p01 = prev[y0 + x1 * H];
+    const float p10 = prev[y1 + x0 * H], p11 = prev[y1 + x1 * H];
+    value = h1 * (w1 * p00 + w0 * p01) + h0 * (w1 * p10 + w0 * p11);
+  }
+  out[k] = value;
 }
 
 }  // namespace kc
@@ -159,6 +322,12 @@ struct kc_mapper {
   PinBuf<float> h_ranges;
   PinBuf<double2> h_trig;
   PinBuf<int> h_grid;
+  // M3 (kc_mapper_enable_bayes): probability grids + the deciding-beam tags
+  bool bayes = false;
+  BayesParams bp{};
+  DevBuf<float> d_prob, d_prev, d_prev_tmp;
+  DevBuf<unsigned int> d_last;
+  PinBuf<float> h_prob;
   // the angle table of a lidar does not change between scans: the trig table
   // is rebuilt only when the angles differ from the previous call
   std::vector<double> last_angles;
@@ -166,6 +335,12 @@ struct kc_mapper {
 };
 
 namespace {
+
+int float_bits(float f) {
+  int v;
+  std::memcpy(&v, &f, sizeof(v));
+  return v;
+}
 
 // true when the last scan launched is known to have finished (its sequence
 // number arrived), after polling for at most `us` microseconds
@@ -183,7 +358,7 @@ bool scan_done(kc_mapper *m, int us) {
 }
 
 int run_scan(kc_mapper *m, const double *angles, const double *ranges,
-             size_t n) {
+             size_t n, bool bayes = false) {
   KC_HIP(hipSetDevice(m->device));
   hipStream_t s = m->stream;
   // the staging / device range buffers are free once the previous scan is done
@@ -195,6 +370,9 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   KC_TRY(m->timing.stop(s));
   if (n == 0) {
     m->seq = 0;  // nothing will signal: kc_mapper_sync waits on the stream
+    if (bayes)   // gridDataProb.fill(m_pPrior), local_mapper.cpp:227
+      KC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m->d_prob.p),
+                               float_bits(m->bp.p_prior), cells, s));
     return KC_OK;
   }
   KC_TRY(m->d_ranges.reserve(n));
@@ -231,17 +409,29 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   }
   const int ni = static_cast<int>(n);
   KC_TRY(m->timing.start("rays_kernel", s));
-  hipLaunchKernelGGL(rays_kernel,
-                     dim3((ni + kBeamsPerBlock - 1) / kBeamsPerBlock),
-                     dim3(64 * kBeamsPerBlock), 0, s, m->g, m->d_ranges.p, m->d_trig.p, ni,
-                     m->d_grid.p);
+  const dim3 rgrid((ni + kBeamsPerBlock - 1) / kBeamsPerBlock), rblock(64 * kBeamsPerBlock);
+  const int hb = (m->g.H + 3) / 4;
+  if (bayes)
+    hipLaunchKernelGGL(rays_bayes_kernel, rgrid, rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p,
+                       ni, m->d_grid.p, m->d_last.p, hb);
+  else
+    hipLaunchKernelGGL(rays_kernel, rgrid, rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p, ni,
+                       m->d_grid.p);
   KC_TRY(m->timing.stop(s));
   ++m->seq;
   KC_TRY(m->timing.start("endpoints_kernel", s));
   hipLaunchKernelGGL(endpoints_kernel, dim3((ni + 255) / 256), dim3(256), 0, s,
                      m->g, m->d_ranges.p, m->d_trig.p, ni, m->d_grid.p, m->d_ticket.p,
-                     m->h_seq.p, m->seq);
+                     bayes ? static_cast<long long *>(nullptr) : m->h_seq.p, m->seq);
   KC_TRY(m->timing.stop(s));
+  if (bayes) {
+    KC_TRY(m->timing.start("bayes_cells_kernel", s));
+    hipLaunchKernelGGL(bayes_cells_kernel, dim3((m->g.H + 63) / 64, (m->g.W + 3) / 4), dim3(256),
+                       0, s, m->g, m->bp, m->d_ranges.p, m->d_last.p, hb, m->d_prev.p,
+                       m->d_prob.p);
+    KC_TRY(m->timing.stop(s));
+    hipLaunchKernelGGL(scan_done_kernel, dim3(1), dim3(1), 0, s, m->h_seq.p, m->seq);
+  }
   KC_HIP(hipGetLastError());
   return KC_OK;
 }
@@ -320,6 +510,11 @@ void kc_mapper_destroy(kc_mapper *m) {
   (void)e;
   m->timing.release();
   m->d_grid.release();
+  m->d_prob.release();
+  m->d_prev.release();
+  m->d_prev_tmp.release();
+  m->d_last.release();
+  m->h_prob.release();
   m->d_ranges.release();
   m->d_trig.release();
   m->d_ticket.release();
@@ -354,6 +549,140 @@ int kc_mapper_scan_to_grid(kc_mapper *m, const double *angles,
                         hipMemcpyDeviceToHost, m->stream));
   KC_HIP(hipStreamSynchronize(m->stream));
   std::memcpy(grid_out, m->h_grid.p, cells * sizeof(int));
+  return KC_OK;
+}
+
+// ---- M3 ------------------------------------------------------------------------
+int kc_mapper_enable_bayes(kc_mapper *m, const kc_bayes_params *p) {
+  if (!m || !p) KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_HIP(hipSetDevice(m->device));
+  KC_HIP(hipStreamSynchronize(m->stream));
+  const size_t cells = static_cast<size_t>(m->g.H) * m->g.W;
+  KC_TRY(m->d_prob.reserve(cells));
+  KC_TRY(m->d_prev.reserve(cells));
+  KC_TRY(m->d_prev_tmp.reserve(cells));
+  // tags in 4x4-cell blocks, one 64-byte line each
+  const size_t tag_words = static_cast<size_t>((m->g.H + 3) / 4) * ((m->g.W + 3) / 4) * 16;
+  KC_TRY(m->d_last.reserve(tag_words));
+  KC_TRY(m->h_prob.reserve(cells));
+  m->bp = BayesParams{p->p_prior, p->p_occupied, p->p_empty, p->range_sure, p->range_max,
+                      p->wall_size};
+  // previousGridDataProb.fill(m_pPrior), local_mapper.h:81-83
+  KC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m->d_prev.p),
+                           float_bits(p->p_prior), cells, m->stream));
+  KC_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m->d_prob.p),
+                           float_bits(p->p_prior), cells, m->stream));
+  KC_HIP(hipMemsetAsync(m->d_last.p, 0, tag_words * sizeof(unsigned int), m->stream));
+  KC_HIP(hipStreamSynchronize(m->stream));
+  m->bayes = true;
+  return KC_OK;
+}
+
+int kc_mapper_scan_to_grid_bayes_device(kc_mapper *m, const double *angles, const double *ranges,
+                                        size_t n) {
+  if (!m || (n && (!angles || !ranges))) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!m->bayes) KC_FAIL(KC_ERR_INVALID, "kc_mapper_enable_bayes has not been called");
+  return run_scan(m, angles, ranges, n, true);
+}
+
+int kc_mapper_scan_to_grid_bayes(kc_mapper *m, const double *angles, const double *ranges,
+                                 size_t n, int32_t *grid_out, float *prob_out) {
+  if (!grid_out || !prob_out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_TRY(kc_mapper_scan_to_grid_bayes_device(m, angles, ranges, n));
+  const size_t cells = static_cast<size_t>(m->g.H) * m->g.W;
+  KC_HIP(hipMemcpyAsync(m->h_grid.p, m->d_grid.p, cells * sizeof(int), hipMemcpyDeviceToHost,
+                        m->stream));
+  KC_HIP(hipMemcpyAsync(m->h_prob.p, m->d_prob.p, cells * sizeof(float), hipMemcpyDeviceToHost,
+                        m->stream));
+  KC_HIP(hipStreamSynchronize(m->stream));
+  std::memcpy(grid_out, m->h_grid.p, cells * sizeof(int));
+  std::memcpy(prob_out, m->h_prob.p, cells * sizeof(float));
+  return KC_OK;
+}
+
+int kc_mapper_prob_device(kc_mapper *m, void **dev_prob, void **dev_prev) {
+  if (!m || !dev_prob) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!m->bayes) KC_FAIL(KC_ERR_INVALID, "kc_mapper_enable_bayes has not been called");
+  *dev_prob = m->d_prob.p;
+  if (dev_prev) *dev_prev = m->d_prev.p;
+  return KC_OK;
+}
+
+int kc_mapper_warp_previous(kc_mapper *m, const float pos[2], double orient) {
+  if (!m || !pos) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!m->bayes) KC_FAIL(KC_ERR_INVALID, "kc_mapper_enable_bayes has not been called");
+  KC_HIP(hipSetDevice(m->device));
+  const MapGeom &g = m->g;
+  // localToGrid of the new centre, then the Matrix3f of local_mapper.cpp:27-37
+  const int cc0 = g.c0 + static_cast<int>(pos[0] / g.res);
+  const int cc1 = g.c1 + static_cast<int>(pos[1] / g.res);
+  const double ang = -1 * orient;
+  const double c = std::cos(ang), sn = std::sin(ang);
+  float t[3][3];
+  t[0][0] = static_cast<float>(c);
+  t[0][1] = static_cast<float>(-sn);
+  t[0][2] = static_cast<float>(0.5 * g.H - cc1 + (cc0 * sn - cc1 * c));
+  t[1][0] = static_cast<float>(sn);
+  t[1][1] = static_cast<float>(c);
+  t[1][2] = static_cast<float>(0.5 * g.W - cc0 - (cc0 * c + cc1 * sn));
+  t[2][0] = 0.0f;
+  t[2][1] = 0.0f;
+  t[2][2] = 1.0f;
+  // Eigen's 3x3 inverse: cofactors, det over column 0 as a0 + (a1 + a2)
+  auto cof = [&](int i, int j) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return t[i1][j1] * t[i2][j2] - t[i1][j2] * t[i2][j1];
+  };
+  const float k0 = cof(0, 0), k1 = cof(1, 0), k2 = cof(2, 0);
+  const float det = k0 * t[0][0] + (k1 * t[1][0] + k2 * t[2][0]);
+  const float invdet = 1.0f / det;
+  WarpArgs a{};
+  a.r0[0] = k0 * invdet;
+  a.r0[1] = k1 * invdet;
+  a.r0[2] = k2 * invdet;
+  for (int q = 0; q < 3; ++q) a.r1[q] = cof(q, 1) * invdet;
+  a.H = g.H;
+  a.W = g.W;
+  a.prior = m->bp.p_prior;
+  const unsigned int cells = static_cast<unsigned int>(static_cast<size_t>(g.H) * g.W);
+  m->timing.begin_cycle();
+  KC_TRY(m->timing.start("warp_kernel", m->stream));
+  hipLaunchKernelGGL(warp_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, m->stream, a,
+                     m->d_prev.p, m->d_prev_tmp.p, cells);
+  KC_TRY(m->timing.stop(m->stream));
+  KC_HIP(hipGetLastError());
+  std::swap(m->d_prev, m->d_prev_tmp);  // stream order covers the next reader
+  return KC_OK;
+}
+
+int kc_mapper_get_previous_prob(kc_mapper *m, float *out) {
+  if (!m || !out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!m->bayes) KC_FAIL(KC_ERR_INVALID, "kc_mapper_enable_bayes has not been called");
+  KC_HIP(hipSetDevice(m->device));
+  const size_t cells = static_cast<size_t>(m->g.H) * m->g.W;
+  KC_HIP(hipMemcpyAsync(m->h_prob.p, m->d_prev.p, cells * sizeof(float), hipMemcpyDeviceToHost,
+                        m->stream));
+  KC_HIP(hipStreamSynchronize(m->stream));
+  std::memcpy(out, m->h_prob.p, cells * sizeof(float));
+  return KC_OK;
+}
+
+int kc_mapper_set_previous_prob(kc_mapper *m, const float *in) {
+  if (!m) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!m->bayes) KC_FAIL(KC_ERR_INVALID, "kc_mapper_enable_bayes has not been called");
+  KC_HIP(hipSetDevice(m->device));
+  const size_t cells = static_cast<size_t>(m->g.H) * m->g.W;
+  if (in) {
+    KC_HIP(hipStreamSynchronize(m->stream));  // h_prob may still be in flight
+    std::memcpy(m->h_prob.p, in, cells * sizeof(float));
+    KC_HIP(hipMemcpyAsync(m->d_prev.p, m->h_prob.p, cells * sizeof(float), hipMemcpyHostToDevice,
+                          m->stream));
+    KC_HIP(hipStreamSynchronize(m->stream));
+  } else {
+    // feed the last probability grid back as the next scan's prior
+    KC_HIP(hipMemcpyAsync(m->d_prev.p, m->d_prob.p, cells * sizeof(float),
+                          hipMemcpyDeviceToDevice, m->stream));
+  }
   return KC_OK;
 }
 

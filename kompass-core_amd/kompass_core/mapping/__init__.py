@@ -1,1 +1,1 @@
-from .local_mapper import LocalMapper, MapConfig  # noqa: F401
+from .local_mapper import LocalMapper, MapConfig, ScanModelConfig  # noqa: F401

@@ -118,6 +118,13 @@ SIGNATURES = {
     "kc_mapper_scan_to_grid": (C.c_int, [_vp, _dp, _dp, _sz, _ip]),
     "kc_mapper_scan_to_grid_device": (C.c_int, [_vp, _dp, _dp, _sz]),
     "kc_mapper_grid_device": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "kc_mapper_enable_bayes": (C.c_int, [_vp, C.c_void_p]),
+    "kc_mapper_scan_to_grid_bayes": (C.c_int, [_vp, _dp, _dp, _sz, _ip, _fp]),
+    "kc_mapper_scan_to_grid_bayes_device": (C.c_int, [_vp, _dp, _dp, _sz]),
+    "kc_mapper_prob_device": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "kc_mapper_warp_previous": (C.c_int, [_vp, _fp, C.c_double]),
+    "kc_mapper_get_previous_prob": (C.c_int, [_vp, _fp]),
+    "kc_mapper_set_previous_prob": (C.c_int, [_vp, _fp]),
     "kc_mapper_sync": (C.c_int, [_vp]),
     "kc_mapper_timing_enable": (C.c_int, [_vp, C.c_int]),
     "kc_mapper_timing_get": (C.c_int, [_vp, C.POINTER(C.c_char_p), _fp, _sz, C.POINTER(_sz)]),
@@ -403,6 +410,50 @@ class MapperContext:
     def scan_to_grid_device(self, angles, ranges):
         a, r = _f64(angles), _f64(ranges)
         _check(lib().kc_mapper_scan_to_grid_device(self.h, _pd(a), _pd(r), len(a)))
+
+    # ---- M3: Bayesian update (LocalMapper's second ctor) ----------------------
+    def enable_bayes(self, p_prior=0.5, p_occupied=0.6, p_empty=0.4, range_sure=1.0, range_max=20.0,
+                     wall_size=0.2):
+        params = (C.c_float * 6)(*[float(np.float32(v)) for v in
+                                   (p_prior, p_occupied, p_empty, range_sure, range_max, wall_size)])
+        _check(lib().kc_mapper_enable_bayes(self.h, C.cast(params, C.c_void_p)))
+
+    def scan_to_grid_baysian(self, angles, ranges):
+        """-> (int32 [H, W] occupancy, float32 [H, W] probabilities)."""
+        a, r = _f64(angles), _f64(ranges)
+        g = np.empty(self.H * self.W, np.int32)
+        pr = np.empty(self.H * self.W, np.float32)
+        _check(lib().kc_mapper_scan_to_grid_bayes(self.h, _pd(a), _pd(r), len(a), g.ctypes.data_as(_ip),
+                                                  _pf(pr)))
+        return g.reshape(self.W, self.H).T, pr.reshape(self.W, self.H).T
+
+    def scan_to_grid_baysian_device(self, angles, ranges):
+        a, r = _f64(angles), _f64(ranges)
+        _check(lib().kc_mapper_scan_to_grid_bayes_device(self.h, _pd(a), _pd(r), len(a)))
+
+    def prob_device_ptrs(self):
+        p, q = _vp(), _vp()
+        _check(lib().kc_mapper_prob_device(self.h, C.byref(p), C.byref(q)))
+        return p.value, q.value
+
+    def get_previous_grid_in_current_pose(self, position, orientation):
+        pos = _f32(np.asarray(position, np.float32)[:2])
+        _check(lib().kc_mapper_warp_previous(self.h, _pf(pos), float(orientation)))
+
+    def previous_prob(self):
+        pr = np.empty(self.H * self.W, np.float32)
+        _check(lib().kc_mapper_get_previous_prob(self.h, _pf(pr)))
+        return pr.reshape(self.W, self.H).T
+
+    def set_previous_prob(self, prob=None):
+        """prob [H, W] -> previous grid; None feeds the last scan's probabilities back (device copy)."""
+        if prob is None:
+            _check(lib().kc_mapper_set_previous_prob(self.h, None))
+            return
+        flat = np.ascontiguousarray(np.asarray(prob, np.float32).T).reshape(-1)
+        if flat.size != self.H * self.W:
+            raise ValueError("previous grid must be [grid_height, grid_width]")
+        _check(lib().kc_mapper_set_previous_prob(self.h, _pf(flat)))
 
     def sync(self):
         _check(lib().kc_mapper_sync(self.h))

@@ -172,6 +172,14 @@ def lib():
                                                  C.c_double, C.c_int, _dp, _dp, C.c_size_t]),
         "ko_mapper_scan_to_grid": (C.c_int, [C.c_int, C.c_int, C.c_float, _fp, C.c_float, _dp, _dp,
                                              sz, _ip]),
+        "ko_bmap_create": (C.c_void_p, [C.c_int, C.c_int, C.c_float, _fp, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_float, C.c_float, C.c_float]),
+        "ko_bmap_destroy": (None, [C.c_void_p]),
+        "ko_bmap_scan": (C.c_int, [C.c_void_p, _dp, _dp, sz, _ip, _fp]),
+        "ko_bmap_warp": (C.c_int, [C.c_void_p, _fp, C.c_double]),
+        "ko_bmap_warp_matrix": (None, [C.c_void_p, _fp, C.c_double, _fp]),
+        "ko_bmap_previous": (_fp, [C.c_void_p]),
+        "ko_bmap_set_previous": (None, [C.c_void_p, _fp]),
         "ko_baseline_cycle": (C.c_long, [vp, C.POINTER(CostCtx), C.POINTER(State), C.c_double, sz,
                                          _dp, _dp, _dp, sz, C.c_int, _fp, C.POINTER(C.c_long)]),
     }
@@ -512,6 +520,57 @@ def scan_to_grid(H, W, res, position, orientation, angles, ranges):
     lib().ko_mapper_scan_to_grid(H, W, float(np.float32(res)), _pf(p), float(np.float32(orientation)),
                                  _pd(a), _pd(r), len(a), _pi(g))
     return g.reshape(W, H).T.copy()  # column-major (i + j*H) -> [i, j]
+
+
+class BayesMapper:
+    """LocalMapper built with the Bayesian ctor (local_mapper.h:58-103):
+    scanToGridBaysian + getPreviousGridInCurrentPose.  Grids come back as
+    [H, W] arrays (Eigen's column-major storage restored)."""
+
+    def __init__(self, H, W, res, position, orientation, p_prior=0.5, p_occupied=0.6, p_empty=0.4,
+                 range_sure=1.0, range_max=20.0, wall_size=0.2):
+        self.H, self.W = int(H), int(W)
+        p = _f32(position)
+        f = lambda v: float(np.float32(v))
+        self.h = lib().ko_bmap_create(self.H, self.W, f(res), _pf(p), f(orientation), f(p_prior), f(p_occupied),
+                                      f(p_empty), f(range_sure), f(range_max), f(wall_size))
+        if not self.h:
+            raise ValueError("invalid mapper arguments")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ko_bmap_destroy(self.h)
+            self.h = None
+
+    def _unpack(self, flat):
+        return flat.reshape(self.W, self.H).T.copy()
+
+    def scan_to_grid_baysian(self, angles, ranges):
+        a, r = _f64(angles), _f64(ranges)
+        g = np.zeros(self.H * self.W, np.int32)
+        pr = np.zeros(self.H * self.W, np.float32)
+        lib().ko_bmap_scan(self.h, _pd(a), _pd(r), len(a), _pi(g), _pf(pr))
+        return self._unpack(g), self._unpack(pr)
+
+    def get_previous_grid_in_current_pose(self, position, orientation):
+        p = _f32(np.asarray(position, np.float32)[:2])
+        if lib().ko_bmap_warp(self.h, _pf(p), float(orientation)) != 0:
+            raise MemoryError
+        return self.previous()
+
+    def warp_matrix(self, position, orientation):
+        p = _f32(np.asarray(position, np.float32)[:2])
+        inv = np.zeros(9, np.float32)
+        lib().ko_bmap_warp_matrix(self.h, _pf(p), float(orientation), _pf(inv))
+        return inv.reshape(3, 3)
+
+    def previous(self):
+        return self._unpack(_arr(lib().ko_bmap_previous(self.h), self.H * self.W))
+
+    def set_previous(self, prob):
+        flat = np.ascontiguousarray(np.asarray(prob, np.float32).T).reshape(-1)  # [i, j] -> i + j*H
+        assert flat.size == self.H * self.W
+        lib().ko_bmap_set_previous(self.h, _pf(flat))
 
 
 def pointcloud_to_laserscan(data, point_step, row_step, height, width, x_offset, y_offset, z_offset,

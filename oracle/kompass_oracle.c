@@ -1581,6 +1581,225 @@ int ko_mapper_scan_to_grid(int H, int W, float res, const float pos[3],
 }
 
 /* ======================================================================== */
+/* M3: Bayesian update + previous-grid warp (parity unpinned: the reference    */
+/* tests only print these grids, mapper_test.cpp:136-220)                      */
+/* ======================================================================== */
+struct ko_bmap {
+  int H, W;
+  int c0, c1, s0, s1;
+  float res, pos0, pos1, orient;
+  float p_prior, p_occupied, p_empty, range_sure, range_max, wall_size;
+  float *prev; /* previousGridDataProb, column-major [H x W] */
+};
+
+ko_bmap *ko_bmap_create(int H, int W, float res, const float pos[3], float orient,
+                        float p_prior, float p_occupied, float p_empty,
+                        float range_sure, float range_max, float wall_size) {
+  if (H <= 0 || W <= 0 || !(res > 0.0f) || !pos) return NULL;
+  ko_bmap *b = (ko_bmap *)calloc(1, sizeof(*b));
+  if (!b) return NULL;
+  b->H = H;
+  b->W = W;
+  b->res = res;
+  b->pos0 = pos[0];
+  b->pos1 = pos[1];
+  b->orient = orient;
+  b->c0 = (int)round((double)(H / 2)) - 1; /* local_mapper.h:72-73 */
+  b->c1 = (int)round((double)(W / 2)) - 1;
+  b->s0 = b->c0 + (int)(pos[0] / res);
+  b->s1 = b->c1 + (int)(pos[1] / res);
+  b->p_prior = p_prior;
+  b->p_occupied = p_occupied;
+  b->p_empty = p_empty;
+  b->range_sure = range_sure;
+  b->range_max = range_max;
+  b->wall_size = wall_size;
+  b->prev = (float *)malloc(sizeof(float) * (size_t)H * (size_t)W);
+  if (!b->prev) {
+    free(b);
+    return NULL;
+  }
+  /* local_mapper.h:81-83 */
+  for (size_t k = 0; k < (size_t)H * (size_t)W; ++k) b->prev[k] = p_prior;
+  return b;
+}
+
+void ko_bmap_destroy(ko_bmap *b) {
+  if (!b) return;
+  free(b->prev);
+  free(b);
+}
+
+const float *ko_bmap_previous(const ko_bmap *b) { return b->prev; }
+
+void ko_bmap_set_previous(ko_bmap *b, const float *prob) {
+  memcpy(b->prev, prob, sizeof(float) * (size_t)b->H * (size_t)b->W);
+}
+
+/* LocalMapper::updateGridCellProbability, local_mapper.cpp:106-125.  The
+ * literal 1.0 makes the sensor odds, and everything multiplied with them, a
+ * double expression; the result narrows to float on return. */
+static float bayes_cell(const ko_bmap *b, float distance, float current_range,
+                        float previous_prob) {
+  distance = distance * b->res;
+  current_range = current_range - b->wall_size;
+  const float pF = (distance < current_range) ? b->p_empty : b->p_occupied;
+  const float delta = (distance < b->range_sure) ? 0.0f : 1.0f;
+  const float p_sensor =
+      pF + (delta * ((distance - b->range_sure) / b->range_max) * (b->p_prior - pF));
+  const float prev_odds = previous_prob / (1 - previous_prob);
+  const double sensor_odds = (double)p_sensor / (1.0 - (double)p_sensor);
+  const float prior_odds = (1 - b->p_prior) / b->p_prior;
+  const double p_curr =
+      1 - (1 / (1 + (((double)prev_odds * sensor_odds) * (double)prior_odds)));
+  return (float)p_curr;
+}
+
+typedef struct {
+  grid_sink g;
+  const ko_bmap *b;
+  float *prob;
+  float range;
+} bayes_sink;
+
+/* the per-point body of updateGridBaysian_, local_mapper.cpp:177-201 */
+static inline void bayes_emit(bayes_sink *s, int i, int j) {
+  const ko_bmap *b = s->b;
+  if (i >= 0 && i < b->H && j >= 0 && j < b->W) {
+    /* (pt - m_startPoint).norm() on Vector2i: Eigen's integer norm, the double
+     * sqrt truncated back to int */
+    const int di = i - b->s0, dj = j - b->s1;
+    const float distance = (float)(int)sqrt((double)(di * di + dj * dj));
+    const size_t k = (size_t)i + (size_t)j * (size_t)b->H;
+    s->prob[k] = bayes_cell(b, distance, s->range, b->prev[k]);
+    grid_emit(&s->g, i, j);
+  }
+}
+
+/* bresenhamEnhanced (line_drawing.h:55-124) feeding bayes_emit */
+static void bresenham_bayes(int x0, int y0, int x1, int y1, bayes_sink *s) {
+  int x = x0, y = y0;
+  int dx = x1 - x0, dy = y1 - y0;
+  bayes_emit(s, x, y);
+  const int xstep = (dx >= 0) ? 1 : -1, ystep = (dy >= 0) ? 1 : -1;
+  dx = abs(dx);
+  dy = abs(dy);
+  const int ddy = 2 * dy, ddx = 2 * dx;
+  const int xmajor = ddx >= ddy;
+  const int n = xmajor ? dx : dy, ddmaj = xmajor ? ddx : ddy, ddmin = xmajor ? ddy : ddx;
+  int errorprev = n, error = n;
+  for (int i = 0; i < n; i++) {
+    if (xmajor) x += xstep; else y += ystep;
+    error += ddmin;
+    if (error > ddmaj) {
+      if (xmajor) y += ystep; else x += xstep;
+      error -= ddmaj;
+      /* x-major emits (x, y-ystep) below the line and (x-xstep, y) above; the
+       * y-major branch mirrors that */
+      const int lo = xmajor ? (error + errorprev < ddmaj) : (error + errorprev > ddmaj);
+      const int hi = xmajor ? (error + errorprev > ddmaj) : (error + errorprev < ddmaj);
+      if (lo) {
+        bayes_emit(s, x, y - ystep);
+      } else if (hi) {
+        bayes_emit(s, x - xstep, y);
+      } else {
+        bayes_emit(s, x - xstep, y);
+        bayes_emit(s, x, y - ystep);
+      }
+    }
+    bayes_emit(s, x, y);
+    errorprev = error;
+  }
+}
+
+/* LocalMapper::scanToGridBaysian, local_mapper.cpp:222-241 (single thread:
+ * the last beam that crosses a cell decides its probability) */
+int ko_bmap_scan(ko_bmap *b, const double *angles, const double *ranges, size_t n,
+                 int32_t *grid, float *prob) {
+  const size_t cells = (size_t)b->H * (size_t)b->W;
+  for (size_t k = 0; k < cells; ++k) grid[k] = KO_UNEXPLORED;
+  for (size_t k = 0; k < cells; ++k) prob[k] = b->p_prior;
+  bayes_sink s = {{grid, b->H, b->W, 0, 0}, b, prob, 0.0f};
+  for (size_t q = 0; q < n; ++q) {
+    const float angle = (float)angles[q], range = (float)ranges[q];
+    const float x =
+        (float)((double)b->pos0 + ((double)range * cos((double)(b->orient + angle))));
+    const float y =
+        (float)((double)b->pos1 + ((double)range * sin((double)(b->orient + angle))));
+    s.g.to0 = b->c0 + (int)(x / b->res);
+    s.g.to1 = b->c1 + (int)(y / b->res);
+    s.range = range;
+    bresenham_bayes(b->s0, b->s1, s.g.to0, s.g.to1, &s);
+  }
+  return 0;
+}
+
+/* LocalMapper::getPreviousGridInCurrentPose, local_mapper.cpp:17-78.  The
+ * reference inverts the same Matrix3f for every cell; the inverse is Eigen's
+ * closed 3x3 form (cofactors, determinant over column 0 as a0 + (a1 + a2)) and
+ * the product rows are lazy 3-term reductions a0 + (a1 + a2). */
+static inline float cof3(const float m[3][3], int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+}
+
+void ko_bmap_warp_matrix(const ko_bmap *b, const float pos[2], double orient, float inv[3][3]) {
+  const int cc0 = b->c0 + (int)(pos[0] / b->res); /* localToGrid */
+  const int cc1 = b->c1 + (int)(pos[1] / b->res);
+  const double ang = -1 * orient;
+  const double c = cos(ang), s = sin(ang);
+  float m[3][3];
+  m[0][0] = (float)c;
+  m[0][1] = (float)(-s);
+  m[0][2] = (float)(0.5 * b->H - cc1 + (cc0 * s - cc1 * c));
+  m[1][0] = (float)s;
+  m[1][1] = (float)c;
+  m[1][2] = (float)(0.5 * b->W - cc0 - (cc0 * c + cc1 * s));
+  m[2][0] = 0.0f;
+  m[2][1] = 0.0f;
+  m[2][2] = 1.0f;
+  const float k0 = cof3(m, 0, 0), k1 = cof3(m, 1, 0), k2 = cof3(m, 2, 0);
+  const float det = k0 * m[0][0] + (k1 * m[1][0] + k2 * m[2][0]);
+  const float invdet = 1.0f / det;
+  inv[0][0] = k0 * invdet;
+  inv[0][1] = k1 * invdet;
+  inv[0][2] = k2 * invdet;
+  for (int r = 1; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) inv[r][q] = cof3(m, q, r) * invdet;
+}
+
+int ko_bmap_warp(ko_bmap *b, const float pos[2], double orient) {
+  float inv[3][3];
+  ko_bmap_warp_matrix(b, pos, orient, inv);
+  const size_t cells = (size_t)b->H * (size_t)b->W;
+  float *out = (float *)malloc(sizeof(float) * cells);
+  if (!out) return -1;
+  for (size_t k = 0; k < cells; ++k) out[k] = b->p_prior;
+  const int rows = b->H, cols = b->W;
+  for (int y = 0; y < b->H; ++y) {
+    for (int x = 0; x < b->W; ++x) {
+      const float fx = (float)x, fy = (float)y;
+      const double srcX = (double)(inv[0][0] * fx + (inv[0][1] * fy + inv[0][2] * 1.0f));
+      const double srcY = (double)(inv[1][0] * fx + (inv[1][1] * fy + inv[1][2] * 1.0f));
+      if (srcX >= 0 && srcX < cols - 1 && srcY >= 0 && srcY < rows - 1) {
+        const int x0 = (int)floor(srcX), y0 = (int)floor(srcY);
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const float w0 = (float)(srcX - x0), w1 = 1.0f - w0;
+        const float h0 = (float)(srcY - y0), h1 = 1.0f - h0;
+#define KO_P(r, c) b->prev[(size_t)(r) + (size_t)(c) * (size_t)rows]
+        const float value = h1 * (w1 * KO_P(y0, x0) + w0 * KO_P(y0, x1)) +
+                            h0 * (w1 * KO_P(y1, x0) + w0 * KO_P(y1, x1));
+#undef KO_P
+        out[(size_t)y + (size_t)x * (size_t)rows] = value;
+      }
+    }
+  }
+  free(b->prev);
+  b->prev = out;
+  return 0;
+}
+
+/* ======================================================================== */
 /* bounded multi-thread baseline (bench.py cpu_baseline only)                */
 /* ======================================================================== */
 typedef struct {

@@ -246,6 +246,29 @@ int ko_mapper_scan_to_grid(int grid_height, int grid_width, float resolution,
                            float laserscan_orientation, const double *angles,
                            const double *ranges, size_t n, int32_t *grid_out);
 
+/* ---- M3: Bayesian update + previous-grid warp (CPU semantics) ------------- */
+/* local_mapper.h:58-103 (ctor), local_mapper.cpp:17-78 (warp), :106-125 (cell
+ * probability), :161-202,222-241 (scan).  PARITY UNPINNED: the reference's
+ * tests only print these grids (mapper_test.cpp:136-220); the restatement
+ * follows the source expression by expression, including Eigen's integer
+ * Vector2i::norm() (double sqrt truncated to int) and its closed-form 3x3
+ * inverse.  Grids are column-major float/int32 [H x W]. */
+typedef struct ko_bmap ko_bmap;
+ko_bmap *ko_bmap_create(int grid_height, int grid_width, float resolution,
+                        const float laserscan_position[3], float laserscan_orientation,
+                        float p_prior, float p_occupied, float p_empty, float range_sure,
+                        float range_max, float wall_size);
+void ko_bmap_destroy(ko_bmap *b);
+int ko_bmap_scan(ko_bmap *b, const double *angles, const double *ranges, size_t n,
+                 int32_t *grid_out, float *prob_out);
+int ko_bmap_warp(ko_bmap *b, const float current_position_in_previous_pose[2],
+                 double current_orientation_in_previous_pose);
+void ko_bmap_warp_matrix(const ko_bmap *b, const float pos[2], double orient, float inv[3][3]);
+const float *ko_bmap_previous(const ko_bmap *b);
+/* not in the reference (previousGridDataProb is only ever warped): lets a test
+ * start from a non-constant previous grid */
+void ko_bmap_set_previous(ko_bmap *b, const float *prob);
+
 /* ---- M5: raw point cloud -> laserscan (CPU semantics) ----------------------- */
 /* utils/pointcloud.h:116-177 (angle_step overload: angle_step > 0, *num_bins is
  * an output = ceil(2 pi / angle_step), angles_out[i] = i * angle_step) and

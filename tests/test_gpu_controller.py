@@ -211,6 +211,55 @@ def test_local_mapper_frontend():
     assert (m2.occupancy == 100).mean() < 0.01
 
 
+def test_local_mapper_frontend_baysian():
+    """MapConfig(baysian_update=True): the module-level scan_to_grid_baysian /
+    get_previous_grid_in_current_pose (bound to the real C++ methods here, see
+    the binding's comment) against the oracle over a three-pose drive."""
+    from kompass_core.mapping import ScanModelConfig
+    from kompass_core.models import RobotState
+    d = json.loads((GOLD / "laserscan_data.json").read_text())
+    ang = d["angle_min"] + np.arange(len(d["ranges"])) * d["angle_increment"]
+    rng0 = np.clip(np.nan_to_num(np.array(d["ranges"], float), posinf=d["range_max"]), 0, 20.0)
+    sm = ScanModelConfig()
+    assert abs(sm.p_empty - 0.1) < 1e-12
+    m = LocalMapper(MapConfig(width=8.0, height=6.0, resolution=0.05, baysian_update=True), sm)
+    o = ko.BayesMapper(120, 160, 0.05, (0, 0, 0), 0.0, p_prior=sm.p_prior, p_occupied=sm.p_occupied,
+                       p_empty=sm.p_empty, range_sure=sm.range_sure, range_max=sm.range_max, wall_size=sm.wall_size)
+    poses = [(0.0, 0.0, 0.0), (0.10, 0.02, 0.05), (0.22, 0.01, 0.12)]
+    for k, (x, y, yaw) in enumerate(poses):
+        scan = LaserScanData(angle_min=d["angle_min"], angle_max=d["angle_max"], angle_increment=d["angle_increment"],
+                             range_max=d["range_max"], ranges=rng0 * (1.0 + 0.02 * k), angles=ang)
+        if k:
+            px, py, pyaw = poses[k - 1]
+            c, s = np.cos(pyaw), np.sin(pyaw)
+            rel = (c * (x - px) + s * (y - py), -s * (x - px) + c * (y - py))
+            want_prev = o.get_previous_grid_in_current_pose(rel, yaw - pyaw)
+        m.update_from_scan(RobotState(x=x, y=y, yaw=yaw), scan)
+        want_g, want_p = o.scan_to_grid_baysian(ang, np.clip(scan.ranges, 0, 20.0))
+        np.testing.assert_array_equal(m.occupancy, want_g)
+        np.testing.assert_array_equal(m.scan_occupancy_prob.view(np.uint32), want_p.view(np.uint32))
+        if k:
+            np.testing.assert_array_equal(np.ascontiguousarray(m.previous_grid_prob_transformed).view(np.uint32),
+                                          want_prev.view(np.uint32))
+        layer = m.probabilistic_occupancy
+        assert set(np.unique(layer)) <= {-1, 0, 100}
+        assert ((layer == -1) == (want_p == np.float32(sm.p_prior))).all()
+    # kompass_cpp level: feeding the probabilities back (extension, see local_mapper.h)
+    import kompass_cpp
+    cm = kompass_cpp.mapping.LocalMapper(grid_height=120, grid_width=160, resolution=0.05,
+                                         laserscan_position=[0.0, 0.0, 0.0], laserscan_orientation=0.0,
+                                         is_pointcloud=False, scan_size=len(ang), p_prior=0.6, p_occupied=0.9,
+                                         p_empty=0.1, range_sure=0.1, range_max=20.0, wall_size=0.1, angle_step=0.01,
+                                         max_height=10.0, min_height=-10.0, max_points_per_line=600)
+    o2 = ko.BayesMapper(120, 160, 0.05, (0, 0, 0), 0.0, 0.6, 0.9, 0.1, 0.1, 20.0, 0.1)
+    for k in range(2):
+        g, p = cm.scan_to_grid_baysian(angles=list(ang), ranges=list(rng0))
+        wg, wp = o2.scan_to_grid_baysian(ang, rng0)
+        np.testing.assert_array_equal(np.asarray(p).copy().view(np.uint32), wp.view(np.uint32))
+        cm.set_previous_grid(None)
+        o2.set_previous(wp)
+
+
 def test_collision_checker_batch_poses():
     """kc_dwa_check_poses == oracle check_at for all shapes (checkStatesFeasibility path)."""
     rng = np.random.default_rng(9)
