@@ -243,10 +243,48 @@ def extras(ctx, inp, P, pose):
     out["open_space"] = {"ms_per_step": med(lambda i: ctx.cycle(pose(i), P), 200),
                          "n_admissible": int(r.n_admissible), "obstacles": int(len(far)),
                          "what": "same lattice, obstacles nearer than 10 m removed: every sample admissible"}
+    out["mapper_handoff"] = handoff_extra(ctx, inp, P, pose, med)
     ctx.set_points(inp["state"], inp["points"], inp["max_range"])
     r = ctx.cycle(pose(0), P)
     out["n_admissible"] = int(r.n_admissible)
     return out
+
+
+def handoff_extra(ctx, inp, P, pose, med):
+    """scan -> grid -> controller, once with the grid staying
+    on the device (OCCUPIED cells extracted there) and once the reference's way
+    (grid to the host, point list extracted there, list back to the device)."""
+    import kompass_hip as kh
+    import synthetic as syn
+
+    side, res, beams = 500, 0.05, 4096
+    ang, rng = syn.dense_scan(beams, 0.9)
+    m = kh.MapperContext(side, side, res, (0, 0, 0), 0.0, beams)
+    c0 = side // 2 - 1
+    seg = lambda: ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+
+    def on_device(i):
+        m.scan_to_grid_device(ang, rng)
+        ctx.set_grid_from_mapper(inp["state"], m, inp["max_range"])
+        seg()
+        return ctx.cycle(pose(i), P)
+
+    def through_host(i):
+        g = m.scan_to_grid(ang, rng)
+        ii, jj = np.nonzero(g == 100)
+        pts = np.zeros((len(ii), 3), np.float32)
+        pts[:, 0] = (ii - c0).astype(np.float32) * np.float32(res)
+        pts[:, 1] = (jj - c0).astype(np.float32) * np.float32(res)
+        ctx.set_points(inp["state"], pts, inp["max_range"])
+        seg()
+        return ctx.cycle(pose(i), P)
+
+    ra, rb = on_device(0), through_host(0)
+    same = bool(ra.found == rb.found and ra.raw_index == rb.raw_index and
+                np.float32(ra.cost) == np.float32(rb.cost) and ra.n_admissible == rb.n_admissible)
+    return {"on_device_ms": med(on_device, 100), "through_host_ms": med(through_host, 30),
+            "same_result": same, "n_admissible": int(ra.n_admissible),
+            "what": f"{beams}-beam scan -> {side}x{side} grid -> sensor update -> segment -> cycle"}
 
 
 def cpu_baseline(inp, vx, vy, om, state, found, cost, raw, args):

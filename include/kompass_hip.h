@@ -158,6 +158,23 @@ int kc_dwa_set_scan(kc_dwa *ctx, const kc_state *state, const double *ranges,
 int kc_dwa_set_points(kc_dwa *ctx, const kc_state *state, const float *xyz,
                       size_t n, float max_sensor_range);
 
+/* SURVEY 8f rank 4 -- occupancy grid -> obstacle set without the host round
+ * trip (the reference goes grid -> host -> point list -> DWA, control/dwa.py:
+ * 298-299 with local_map).  dev_grid: int32, column-major [H x W] (the
+ * LocalMapper layout, kc_mapper_grid_device); every OCCUPIED (100) cell (i,j)
+ * becomes the point ((i - c0) res, (j - c1) res, 0), c0/c1 = the mapper's
+ * central cell (local_mapper.h:26-27), i.e. the inverse of localToGrid
+ * (:210-222).  State afterwards == kc_dwa_set_points with that list.  The grid
+ * must be complete in stream order of the controller's stream, or finished. */
+int kc_dwa_set_grid_device(kc_dwa *ctx, const kc_state *state, const int32_t *dev_grid,
+                           int grid_height, int grid_width, float resolution, int central_i,
+                           int central_j, float max_sensor_range);
+/* same, from a mapper context of this library: geometry and stream ordering
+ * (event wait, no host synchronisation) are taken from it */
+struct kc_mapper;
+int kc_dwa_set_grid_from_mapper(kc_dwa *ctx, const kc_state *state, struct kc_mapper *mapper,
+                                float max_sensor_range);
+
 /* the (reference_path, tracked_segment) arguments of getMinTrajectoryCost
  * (cost_evaluator.h:139-142): segment points (Path::View X/Y/Z, path.h:39-76),
  * acc_at_seg[j] = reference_path->getDistanceAtIndex(seg_start + j)

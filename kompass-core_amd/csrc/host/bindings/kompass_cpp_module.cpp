@@ -288,6 +288,10 @@ PYBIND11_MODULE(kompass_cpp, m) {
            py::arg("cost_weights"), py::arg("max_num_threads") = 1)
       .def("compute_velocity_commands", [](DWA &d, const Control::Velocity2D &v, const Control::LaserScan &s) {
              return d.computeVelocityCommandsSet<Control::LaserScan>(v, s); })
+      // sensor data = the last grid of a LocalMapper, consumed where it lies on
+      // the device (not in the reference: SURVEY 8f rank 4)
+      .def("compute_velocity_commands", [](DWA &d, const Control::Velocity2D &v, const Mapping::LocalMapper &m) {
+             return d.computeVelocityCommandsSet<Mapping::LocalMapper>(v, m); })
       .def("compute_velocity_commands", [](DWA &d, const Control::Velocity2D &v, const py::object &cloud) {
              return d.computeVelocityCommandsSet<std::vector<Path::Point>>(v, points(cloud)); })
       .def("add_custom_cost", &DWA::addCustomCost)
@@ -347,6 +351,9 @@ PYBIND11_MODULE(kompass_cpp, m) {
       .def("scan_to_grid", [gridView](py::object self, const std::vector<double> &angles, const std::vector<double> &ranges) {
              return gridView(self.cast<Mapping::LocalMapper &>().scanToGrid(angles, ranges), self);
            }, "Convert laser scan data to occupancy grid", py::arg("angles"), py::arg("ranges"))
+      .def("scan_to_grid_on_device", &Mapping::LocalMapper::scanToGridOnDevice,
+           "Scan into the device-resident grid only (for DWA.compute_velocity_commands(vel, mapper))",
+           py::arg("angles"), py::arg("ranges"))
       .def("scan_to_grid", [gridView](py::object self, const std::vector<int8_t> &data, int point_step, int row_step,
                                       int height, int width, float x_offset, float y_offset, float z_offset) {
              return gridView(self.cast<Mapping::LocalMapper &>().scanToGrid(data, point_step, row_step, height, width,

@@ -53,6 +53,12 @@ class LocalMapper {
   // (local_mapper.cpp:77): read it back / replace it (nullptr = feed the last
   // scan's probabilities back, a device copy)
   Eigen::MatrixXf &previousGridProb();
+  // the device context: lets the controller consume the last grid where it
+  // lies (DWA::computeVelocityCommand(vel, mapper))
+  kc_mapper *hipContext() const { return ctx_.get(); }
+  // scan -> grid without the copy to the host (the grid of scanToGrid is NOT
+  // refreshed by this call)
+  void scanToGridOnDevice(const std::vector<double> &angles, const std::vector<double> &ranges);
   void setPreviousGridProb(const Eigen::MatrixXf *prob);
 
  protected:

@@ -72,6 +72,10 @@ class TrajectorySampler {
                        const Path::State &current_pose,
                        const std::vector<Path::Point> &cloud);
 
+  std::unique_ptr<TrajectorySamples2D>
+  generateTrajectories(const Velocity2D &current_vel, const Path::State &current_pose,
+                       const Mapping::LocalMapper &mapper);
+
   void resetOctreeResolution(const double resolution);
   float getRobotRadius() const;
   Trajectory2D generateSingleSampleFromVel(const Velocity2D &vel,
@@ -97,6 +101,8 @@ class TrajectorySampler {
   size_t rolloutOnDevice(const Velocity2D &current_vel, const Path::State &pose,
                          const std::vector<Path::Point> &cloud,
                          float max_sensor_range);
+  size_t rolloutOnDevice(const Velocity2D &current_vel, const Path::State &pose,
+                         const Mapping::LocalMapper &mapper, float max_sensor_range);
   const hip::DwaHandle &context() const { return ctx_; }
   ControlType controlType() const { return ctrType; }
   const ControlLimitsParams &limits() const { return ctrlimits; }

@@ -72,6 +72,12 @@ Eigen::MatrixXi &LocalMapper::scanToGrid(const std::vector<double> &angles,
   return gridData;
 }
 
+void LocalMapper::scanToGridOnDevice(const std::vector<double> &angles,
+                                     const std::vector<double> &ranges) {
+  const size_t n = std::min(angles.size(), ranges.size());
+  hip::check(kc_mapper_scan_to_grid_device(ctx_.get(), angles.data(), ranges.data(), n));
+}
+
 // local_mapper.cpp:243-251
 Eigen::MatrixXi &LocalMapper::scanToGrid(const std::vector<int8_t> &data, int point_step,
                                          int row_step, int height, int width, float x_offset,

@@ -100,6 +100,10 @@ void CollisionChecker::updateSensorData(const std::vector<Path::Point> &cloud,
   }
   hip::check(kc_dwa_set_points(ctx_.get(), &st, xyz.data(), cloud.size(), maxSensorRange));
 }
+void CollisionChecker::updateSensorData(const Mapping::LocalMapper &mapper, const bool) {
+  const kc_state st = toKc(state_);
+  hip::check(kc_dwa_set_grid_from_mapper(ctx_.get(), &st, mapper.hipContext(), maxSensorRange));
+}
 std::vector<bool> CollisionChecker::checkCollisions(const std::vector<Path::State> &states) {
   const size_t n = states.size();
   std::vector<double> x(n), y(n), yaw(n);
@@ -243,6 +247,14 @@ size_t TrajectorySampler::rolloutOnDevice(const Velocity2D &vel, const Path::Sta
   return launch(vel, pose);
 }
 
+size_t TrajectorySampler::rolloutOnDevice(const Velocity2D &vel, const Path::State &pose,
+                                          const Mapping::LocalMapper &mapper, float max_range) {
+  collChecker->maxSensorRange = max_range;
+  collChecker->updateState(pose);
+  collChecker->updateSensorData(mapper);
+  return launch(vel, pose);
+}
+
 std::unique_ptr<TrajectorySamples2D> TrajectorySampler::collect() {
   const size_t P = numPointsPerTrajectory;
   auto out = std::make_unique<TrajectorySamples2D>(numTrajectories, P);
@@ -277,6 +289,13 @@ std::unique_ptr<TrajectorySamples2D>
 TrajectorySampler::generateTrajectories(const Velocity2D &vel, const Path::State &pose,
                                         const std::vector<Path::Point> &cloud) {
   rolloutOnDevice(vel, pose, cloud, collChecker->maxSensorRange);
+  return collect();
+}
+
+std::unique_ptr<TrajectorySamples2D>
+TrajectorySampler::generateTrajectories(const Velocity2D &vel, const Path::State &pose,
+                                        const Mapping::LocalMapper &mapper) {
+  rolloutOnDevice(vel, pose, mapper, collChecker->maxSensorRange);
   return collect();
 }
 

@@ -52,6 +52,14 @@ struct kc_dwa {
   std::vector<double2> scan_cs;         // angle table does not change between scans)
   std::vector<float> scan_xyz;          // sensor-frame points of the last laserscan
   DevBuf<float> d_raw;
+  // grid hand-off (kc_dwa_set_grid_device): the point list is produced on the
+  // device; the host copy is fetched only if something walks the lists
+  bool raw_on_device = false;
+  size_t raw_n = 0;
+  DevBuf<unsigned int> d_gridcnt;
+  PinBuf<long long> h_gridrec;  // {seq, count, imin, imax, jmin, jmax}
+  long long grid_seq = 0;
+  hipEvent_t grid_ready = nullptr;  // mapper stream -> this stream
   DevBuf<float4> d_sensor_tmp;
   bool device_sensor = true;            // KC_SENSOR_HOST=1 turns the device-side update off
   bool sensor_lds_ok = false;
@@ -521,7 +529,19 @@ void build_host_lists(kc_dwa *c, const float *xyz, size_t n) {
   c->host_lists_valid = true;
 }
 inline void ensure_host_lists(kc_dwa *c) {
-  if (!c->host_lists_valid) build_host_lists(c, c->raw_xyz.data(), c->raw_xyz.size() / 3);
+  if (c->host_lists_valid) return;
+  if (c->raw_on_device) {
+    // the list of a grid hand-off never left the device: fetch it now
+    c->raw_xyz.resize(3 * c->raw_n);
+    if (hipMemcpyAsync(c->raw_xyz.data(), c->d_raw.p, 3 * c->raw_n * sizeof(float),
+                       hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      c->raw_xyz.clear();
+    }
+    c->raw_on_device = false;
+  }
+  build_host_lists(c, c->raw_xyz.data(), c->raw_xyz.size() / 3);
 }
 // is there any occupied voxel column?  (after a device-side update the count is
 // not known on the host: any point may be one)
@@ -533,8 +553,12 @@ inline bool any_voxel(const kc_dwa *c) {
 // cloud (one min/max pass), derives the bitmap extent and the bucket grid from
 // the bounds, stores the raw points through the BAR and queues two kernels.
 // *done = false: conditions not met, the caller takes the host path.
+int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
+                                 const float hi[3], bool *done);
+
 int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   *done = false;
+  c->raw_on_device = false;
   if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
       n == 0 || n > 16384)
     return KC_OK;
@@ -552,6 +576,17 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
     ++nfin;
   }
   if (nfin == 0) return KC_OK;
+  return sensor_update_device_bounded(c, xyz, n, lo, hi, done);
+}
+
+// the part behind the bounds; xyz == nullptr: the points are in d_raw already
+// (grid hand-off)
+int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
+                                 const float hi[3], bool *done) {
+  *done = false;
+  if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
+      n == 0 || n > 16384)
+    return KC_OK;
   // bitmap: keys of the bounds (points beyond the 16-level octree are dropped
   // by add_voxel anyway)
   auto key = [&](float v) {
@@ -603,11 +638,17 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   KC_TRY(c->d_raw.reserve(3 * n));
   KC_TRY(c->d_sensor_tmp.reserve(n));
   // the raw points: host copy for the lazy lists, device copy through the BAR
-  c->raw_xyz.assign(xyz, xyz + 3 * n);
   c->host_lists_valid = false;
-  std::memcpy(c->d_raw.p, xyz, 3 * n * sizeof(float));
-  c->bar_dirty = true;
-  bar_flush(c);
+  if (xyz) {
+    c->raw_xyz.assign(xyz, xyz + 3 * n);
+    std::memcpy(c->d_raw.p, xyz, 3 * n * sizeof(float));
+    c->bar_dirty = true;
+    bar_flush(c);
+  } else {
+    c->raw_xyz.clear();
+    c->raw_on_device = true;
+    c->raw_n = n;
+  }
   SensorArgs a{};
   a.xyz = c->d_raw.p;
   a.n = static_cast<int>(n);
@@ -1240,6 +1281,12 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_dbg.release();
   c->d_dbg2.release();
   c->d_raw.release();
+  c->d_gridcnt.release();
+  c->h_gridrec.release();
+  if (c->grid_ready) {
+    hipError_t ge = hipEventDestroy(c->grid_ready);
+    (void)ge;
+  }
   c->d_sensor_tmp.release();
   c->d_perm.release();
   c->d_pvx.release();
@@ -1437,6 +1484,103 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
                  us(dbg_t0, dbg_t1), us(dbg_t1, dbg_t2), us(dbg_t2, dbg_t3), us(dbg_t3, dbg_t4));
   }
   return rc;
+}
+
+// the mapper's grid feeds the controller without leaving the
+// device.  Same state as kc_dwa_set_points with the list of the OCCUPIED cells.
+int kc_dwa_set_grid_device(kc_dwa *c, const kc_state *st, const int32_t *dev_grid, int H, int W,
+                           float res, int c0, int c1, float max_range) {
+  if (!c || !st || !dev_grid) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (H <= 0 || W <= 0 || !(res > 0.0f) || static_cast<size_t>(H) * W > 0x3FFFFFFFul)
+    KC_FAIL(KC_ERR_INVALID, "grid dimensions and resolution must be positive");
+  KC_TRY(use_device(c));
+  KC_TRY(quiesce_for_update(c));
+  c->frame = hm::Rigid3f::identity();
+  const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
+  c->obs_tf = c->sensor_tf_body * body;
+  c->raw_is_scan = false;
+  c->raw_on_device = false;
+  c->have_sensor = true;
+  c->max_obs_dist = max_range / 3.0f;
+  c->host_lists_valid = true;
+  const size_t cells = static_cast<size_t>(H) * W;
+  KC_TRY(c->d_raw.reserve(3 * cells));
+  KC_TRY(c->h_gridrec.reserve(8));
+  if (!c->d_gridcnt.p) {
+    KC_TRY(c->d_gridcnt.reserve(8));
+    const int init[5] = {0, INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+    KC_HIP(hipMemcpyAsync(c->d_gridcnt.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipStreamSynchronize(c->stream));
+    c->h_gridrec.p[0] = 0;
+  }
+  GridPtsArgs ga{};
+  ga.grid = dev_grid;
+  ga.H = H;
+  ga.W = W;
+  ga.c0 = c0;
+  ga.c1 = c1;
+  ga.res = res;
+  ga.xyz = c->d_raw.p;
+  ga.cnt = c->d_gridcnt.p;
+  const long long seq = ++c->grid_seq;
+  KC_TRY(c->timing.start("grid_points_kernel", c->stream));
+  hipLaunchKernelGGL(grid_points_kernel, dim3(blocks_for(cells, 256)), dim3(256), 0, c->stream, ga);
+  KC_TRY(c->timing.stop(c->stream));
+  hipLaunchKernelGGL(grid_points_publish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_gridcnt.p,
+                     c->h_gridrec.p, seq);
+  KC_HIP(hipGetLastError());
+  c->update_busy = true;
+  {
+    volatile long long *p = c->h_gridrec.p;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0; *p != seq; ++spins) {
+      if ((spins & 255) == 255 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+        KC_HIP(hipStreamSynchronize(c->stream));
+        break;
+      }
+    }
+    if (*p != seq) KC_FAIL(KC_ERR_HIP, "the grid hand-off kernels did not report");
+  }
+  const size_t n = static_cast<size_t>(c->h_gridrec.p[1]);
+  if (n == 0) {
+    build_host_lists(c, nullptr, 0);
+    KC_TRY(upload_voxels(c));
+    return upload_obstacles(c, 0);
+  }
+  const float lo[3] = {static_cast<float>(static_cast<int>(c->h_gridrec.p[2]) - c0) * res,
+                       static_cast<float>(static_cast<int>(c->h_gridrec.p[4]) - c1) * res, 0.0f};
+  const float hi[3] = {static_cast<float>(static_cast<int>(c->h_gridrec.p[3]) - c0) * res,
+                       static_cast<float>(static_cast<int>(c->h_gridrec.p[5]) - c1) * res, 0.0f};
+  bool done = false;
+  KC_TRY(sensor_update_device_bounded(c, nullptr, n, lo, hi, &done));
+  if (done) return KC_OK;
+  // large maps / spheres: the host path, on the (small) list instead of the grid
+  c->raw_xyz.resize(3 * n);
+  KC_HIP(hipMemcpyAsync(c->raw_xyz.data(), c->d_raw.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost,
+                        c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  c->update_busy = false;
+  c->raw_on_device = false;
+  build_host_lists(c, c->raw_xyz.data(), n);
+  KC_TRY(upload_voxels(c));
+  return upload_obstacles(c, n);
+}
+
+int kc_dwa_set_grid_from_mapper(kc_dwa *c, const kc_state *st, kc_mapper *m, float max_range) {
+  if (!c || !st || !m) KC_FAIL(KC_ERR_INVALID, "null argument");
+  kc::MapperView v{};
+  KC_TRY(kc::mapper_view(m, &v));
+  if (v.device != c->prm.device)
+    KC_FAIL(KC_ERR_INVALID, "mapper on device %d, controller on device %d", v.device, c->prm.device);
+  KC_TRY(use_device(c));
+  if (v.stream != c->stream) {
+    // the controller's stream waits for the scan; the host does not
+    if (!c->grid_ready) KC_HIP(hipEventCreateWithFlags(&c->grid_ready, hipEventDisableTiming));
+    KC_HIP(hipEventRecord(c->grid_ready, v.stream));
+    KC_HIP(hipStreamWaitEvent(c->stream, c->grid_ready, 0));
+  }
+  return kc_dwa_set_grid_device(c, st, v.grid, v.H, v.W, v.res, v.c0, v.c1, max_range);
 }
 
 int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,

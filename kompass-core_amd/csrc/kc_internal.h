@@ -213,4 +213,14 @@ __host__ __device__ inline int64_t key_pack(float cost, uint32_t index) {
   return static_cast<int64_t>((hi << 32) | static_cast<uint64_t>(index));
 }
 
+// internal view of a mapper context for the grid hand-off (kc_dwa.hip)
+struct MapperView {
+  const int *grid;
+  int H, W, c0, c1;
+  float res;
+  hipStream_t stream;
+  int device;
+};
+int mapper_view(kc_mapper *m, MapperView *out);
+
 }  // namespace kc

@@ -438,6 +438,14 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
 
 }  // namespace
 
+namespace kc {
+int mapper_view(kc_mapper *m, MapperView *out) {
+  if (!m || !out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  *out = MapperView{m->d_grid.p, m->g.H, m->g.W, m->g.c0, m->g.c1, m->g.res, m->stream, m->device};
+  return KC_OK;
+}
+}  // namespace kc
+
 extern "C" {
 
 int kc_mapper_create(int H, int W, float res, const float pos[3], float orient,

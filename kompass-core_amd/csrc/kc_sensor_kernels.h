@@ -167,4 +167,62 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
   for (int i = tid; i < nw; i += kSensorBlock) a.gbits[i] = lbits[i];
 }
 
+// ---- occupancy grid -> point list on the device ------------
+// One thread per cell of a column-major int32 grid (LocalMapper layout, cell
+// (i,j) at i + j*H): OCCUPIED cells become points ((i - c0) res, (j - c1) res, 0)
+// -- the inverse of LocalMapper::localToGrid (local_mapper.h:210-222) -- in a
+// list whose order is arbitrary (every consumer takes sets or minima).  One
+// counter add per wavefront that holds a hit; the index bounds of the hits
+// let the host size the voxel bitmap and the bucket grid without seeing a point.
+struct GridPtsArgs {
+  const int *grid;
+  int H, W, c0, c1;
+  float res;
+  float *xyz;           // [H*W][3] capacity
+  unsigned int *cnt;    // count, then (as int) imin, imax, jmin, jmax
+};
+
+__global__ __launch_bounds__(256) void grid_points_kernel(GridPtsArgs a) {
+  const unsigned int k = blockIdx.x * 256u + threadIdx.x;
+  const unsigned int cells = static_cast<unsigned int>(a.H) * static_cast<unsigned int>(a.W);
+  const bool hit = k < cells && a.grid[k] == KC_OCCUPIED;
+  const unsigned long long m = __ballot(hit);
+  if (m == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  unsigned int base = 0;
+  if (lane == __ffsll(static_cast<long long>(m)) - 1) base = atomicAdd(&a.cnt[0], __popcll(m));
+  base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1, 64);
+  if (hit) {
+    const int i = static_cast<int>(k % static_cast<unsigned int>(a.H));
+    const int j = static_cast<int>(k / static_cast<unsigned int>(a.H));
+    const unsigned int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+    a.xyz[3 * static_cast<size_t>(slot)] = static_cast<float>(i - a.c0) * a.res;
+    a.xyz[3 * static_cast<size_t>(slot) + 1] = static_cast<float>(j - a.c1) * a.res;
+    a.xyz[3 * static_cast<size_t>(slot) + 2] = 0.0f;
+    int *b = reinterpret_cast<int *>(a.cnt);
+    atomicMin(&b[1], i);
+    atomicMax(&b[2], i);
+    atomicMin(&b[3], j);
+    atomicMax(&b[4], j);
+  }
+}
+
+// one thread behind it (the kernel boundary has made the counters visible):
+// count + bounds into pinned host memory, counters re-armed
+__global__ void grid_points_publish_kernel(unsigned int *cnt, long long *host, long long seq) {
+  int *b = reinterpret_cast<int *>(cnt);
+  host[1] = cnt[0];
+  host[2] = b[1];
+  host[3] = b[2];
+  host[4] = b[3];
+  host[5] = b[4];
+  cnt[0] = 0u;
+  b[1] = INT_MAX;
+  b[2] = INT_MIN;
+  b[3] = INT_MAX;
+  b[4] = INT_MIN;
+  __threadfence_system();
+  *reinterpret_cast<volatile long long *>(host) = seq;
+}
+
 }  // namespace kc

@@ -89,7 +89,11 @@ class DWA(FollowerTemplate):
             self._result.is_found = False
             return False
         vel = kompass_cpp.types.Velocity2D(vx=current_state.vx, vy=current_state.vy, omega=current_state.omega)
-        if local_map is not None:
+        if isinstance(local_map, kompass_cpp.mapping.LocalMapper):
+            # not in the reference: the mapper's last grid is consumed where it
+            # lies on the device (OCCUPIED cells -> point list)
+            sensor = local_map
+        elif local_map is not None:
             sensor = np.asarray(local_map, dtype=np.float32)
         elif laser_scan is not None:
             if len(laser_scan.angles) != len(laser_scan.ranges):
@@ -103,7 +107,7 @@ class DWA(FollowerTemplate):
             logging.error("Cannot compute control without sensor data. Provide 'laser_scan' or 'point_cloud' input")
             return False
         try:
-            if debug:
+            if debug and not isinstance(sensor, kompass_cpp.mapping.LocalMapper):
                 self._planner.debug_velocity_search(vel, sensor, self._config.drop_samples)
             self._result = self._planner.compute_velocity_commands(vel, sensor)
         except Exception as e:  # reference: log and report "no control"

@@ -94,6 +94,9 @@ SIGNATURES = {
     "kc_dwa_set_shard": (C.c_int, [_vp, _sz, _sz]),
     "kc_dwa_set_scan": (C.c_int, [_vp, C.POINTER(State), _dp, _dp, _sz, C.c_float]),
     "kc_dwa_set_points": (C.c_int, [_vp, C.POINTER(State), _fp, _sz, C.c_float]),
+    "kc_dwa_set_grid_device": (C.c_int, [_vp, C.POINTER(State), _vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                         C.c_float]),
+    "kc_dwa_set_grid_from_mapper": (C.c_int, [_vp, C.POINTER(State), _vp, C.c_float]),
     "kc_dwa_set_tracked_segment": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _sz, C.c_float]),
     "kc_dwa_rollout": (C.c_int, [_vp, C.POINTER(State), _sz]),
     "kc_dwa_check_poses": (C.c_int, [_vp, _dp, _dp, _dp, _sz, C.POINTER(C.c_uint8)]),
@@ -280,6 +283,21 @@ class DwaContext:
         p = _f32(xyz).reshape(-1, 3)
         st = State(*state)
         _check(lib().kc_dwa_set_points(self.h, C.byref(st), _pf(p), len(p), float(max_sensor_range)))
+
+    def set_grid_device(self, state, dev_grid_ptr, grid_height, grid_width, resolution, central=None,
+                        max_sensor_range=10.0):
+        """OCCUPIED cells of a device-resident LocalMapper grid -> sensor data (8f rank 4)."""
+        st = State(*state)
+        if central is None:  # local_mapper.h:26-27
+            central = (int(round(grid_height // 2)) - 1, int(round(grid_width // 2)) - 1)
+        _check(lib().kc_dwa_set_grid_device(self.h, C.byref(st), _vp(dev_grid_ptr), int(grid_height),
+                                            int(grid_width), float(np.float32(resolution)), int(central[0]),
+                                            int(central[1]), float(max_sensor_range)))
+
+    def set_grid_from_mapper(self, state, mapper, max_sensor_range=10.0):
+        """Same, from a MapperContext: the scan may still be in flight (stream-ordered)."""
+        st = State(*state)
+        _check(lib().kc_dwa_set_grid_from_mapper(self.h, C.byref(st), mapper.h, float(max_sensor_range)))
 
     def set_tracked_segment(self, seg_xyz, acc_at_seg, ref_path_length):
         seg = _f32(seg_xyz).reshape(-1, 3)

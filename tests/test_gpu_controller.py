@@ -260,6 +260,69 @@ def test_local_mapper_frontend_baysian():
         o2.set_previous(wp)
 
 
+def test_dwa_consumes_the_mapper_grid_on_the_device():
+    """Closed loop with `local_map=<kompass_cpp LocalMapper>`: every cycle the
+    scan goes into the device grid (no host copy) and the controller takes its
+    OCCUPIED cells from there; the oracle gets the list a host would extract
+    from the same grid.  Robot-centred grid, so the world-fixed wall is
+    re-scanned from every pose."""
+    import kompass_cpp
+    cfg = DWAConfig(max_linear_samples=11, max_angular_samples=11, octree_resolution=0.1,
+                    costs_weights=TrajectoryCostsWeights(reference_path_distance_weight=1.0, goal_distance_weight=3.0,
+                                                         obstacles_distance_weight=1.0, smoothness_weight=0.0,
+                                                         jerk_weight=0.0),
+                    prediction_horizon=20, control_horizon=2, control_time_step=0.1)
+    robot, gpu, cpu = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.CYLINDER, [0.1, 0.4],
+                                LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0),
+                                AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0), cfg)
+    H = W = 160
+    res = 0.1
+    ang = np.linspace(-np.pi, np.pi, 720, endpoint=False)
+    mapper = kompass_cpp.mapping.LocalMapper(grid_height=H, grid_width=W, resolution=res,
+                                             laserscan_position=[0.0, 0.0, 0.0], laserscan_orientation=0.0,
+                                             is_pointcloud=False, scan_size=len(ang), angle_step=0.01, max_height=10.0,
+                                             min_height=-10.0, range_max=20.0, max_points_per_line=400)
+    c0, c1 = H // 2 - 1, W // 2 - 1
+    pts = [(x, 0.0) for x in np.arange(0.0, 6.01, 0.5)]
+    gpu.set_path(_P(pts))
+    cpu.set_path(np.array([[x, y, 0.0] for x, y in pts], np.float32))
+    robot.state.x, robot.state.y, robot.state.yaw = 0.0, 0.1, 0.0
+    cycles, blocked = 0, 0
+    for _ in range(60):
+        s = robot.state
+        # a round post of radius 0.25 m at (2.5, 0.45) in the world, seen from the robot
+        dx, dy = 2.5 - s.x, 0.45 - s.y
+        dist, bearing = math.hypot(dx, dy), math.atan2(dy, dx) - s.yaw
+        half = math.asin(min(1.0, 0.25 / max(dist, 0.26)))
+        rel = (ang - bearing + np.pi) % (2 * np.pi) - np.pi
+        rng = np.where(np.abs(rel) < half, max(dist - 0.25, 0.05), 7.5)
+        mapper.scan_to_grid_on_device(angles=list(ang), ranges=list(rng))
+        ok = gpu.loop_step(current_state=s, local_map=mapper)
+        cpu.set_state(s.x, s.y, s.yaw, s.speed)
+        if cpu.is_goal_reached():
+            assert not ok
+            break
+        grid = ko.scan_to_grid(H, W, res, (0, 0, 0), 0.0, ang, rng)
+        jj, ii = np.nonzero(grid.T == 100)
+        cloud = np.zeros((len(ii), 3), np.float32)
+        cloud[:, 0] = (ii - c0).astype(np.float32) * np.float32(res)
+        cloud[:, 1] = (jj - c1).astype(np.float32) * np.float32(res)
+        vel = tuple(float(np.float32(v)) for v in (s.vx, s.vy, s.omega))
+        o = cpu.compute(vel, points=cloud)
+        assert ok and gpu.has_result() == bool(o["found"]), f"cycle {cycles}"
+        if not o["found"]:
+            break
+        blocked += int(o["n_admissible"] < o["n_generated"])
+        assert np.float32(gpu.result_cost) == np.float32(o["cost"]), f"cycle {cycles}"
+        np.testing.assert_array_equal(np.asarray(gpu.optimal_path().x), o["path_x"])
+        np.testing.assert_array_equal(np.asarray(gpu.optimal_path().y), o["path_y"])
+        cycles += 1
+        for vx, vy, om in zip(gpu.linear_x_control, gpu.linear_y_control, gpu.angular_control):
+            robot.set_control(velocity_x=vx, velocity_y=vy, omega=om)
+            robot.get_state(dt=0.1)
+    assert cycles > 10 and blocked > 0, "the post must have cost the controller some samples"
+
+
 def test_collision_checker_batch_poses():
     """kc_dwa_check_poses == oracle check_at for all shapes (checkStatesFeasibility path)."""
     rng = np.random.default_rng(9)
