@@ -10,6 +10,7 @@
 // the max.  One wavefront per beam; the Bresenham error term has a closed form
 // per step, so the 64 lanes each rasterise a contiguous chunk of the line.
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -55,7 +56,7 @@ constexpr int kBeamsPerBlock = 4;
 
 __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_kernel(
     MapGeom g, const float *__restrict__ ranges, const double2 *__restrict__ trig, int n,
-    int *__restrict__ grid) {
+    int *__restrict__ grid, int step_limit) {
   const int beam = blockIdx.x * kBeamsPerBlock + (threadIdx.x >> 6);
   if (beam >= n) return;
   const int lane = threadIdx.x & 63;
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_kernel(
   dy = abs(dy);
   if (lane == 0) stamp_empty(grid, g, g.s0, g.s1);  // first emitted point
   const bool xmajor = 2 * dx >= 2 * dy;
-  const int nsteps = xmajor ? dx : dy;
+  // tiled scan: only the first step_limit steps (the tiles own the rest)
+  const int nsteps = min(xmajor ? dx : dy, step_limit);
   if (nsteps == 0) return;
   const long long dmaj = xmajor ? dx : dy, dmin = xmajor ? dy : dx;
   const long long ddmaj = 2 * dmaj, ddmin = 2 * dmin;
@@ -139,7 +141,8 @@ __device__ __forceinline__ void stamp_tag(int *grid, unsigned int *last, unsigne
 // has the closed form used there for the first step of a chunk
 __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_bayes_kernel(
     MapGeom g, const float *__restrict__ ranges, const double2 *__restrict__ trig, int n,
-    int *__restrict__ grid, unsigned int *__restrict__ last, int hb) {
+    int *__restrict__ grid, unsigned int *__restrict__ last, int hb, int step_first,
+    int step_limit) {
   const int beam = blockIdx.x * kBeamsPerBlock + (threadIdx.x >> 6);
   if (beam >= n) return;
   const unsigned int tag = static_cast<unsigned int>(beam) + 1u;
@@ -149,14 +152,15 @@ __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_bayes_kernel(
   const int xstep = dx >= 0 ? 1 : -1, ystep = dy >= 0 ? 1 : -1;
   dx = abs(dx);
   dy = abs(dy);
-  if (lane == 0) stamp_tag(grid, last, tag, hb, g, g.s0, g.s1);  // first emitted point
+  if (lane == 0 && step_first <= 1) stamp_tag(grid, last, tag, hb, g, g.s0, g.s1);  // first emitted point
   const bool xmajor = 2 * dx >= 2 * dy;
   const int nsteps = xmajor ? dx : dy;
   const long long dmaj = xmajor ? dx : dy, dmin = xmajor ? dy : dx;
   const long long ddmaj = 2 * dmaj, ddmin = 2 * dmin;
   const int astep = xmajor ? xstep : ystep, bstep = xmajor ? ystep : xstep;
   const int a0 = xmajor ? g.s0 : g.s1, b0 = xmajor ? g.s1 : g.s0;
-  for (int i = lane + 1; i <= nsteps; i += 64) {
+  const int nwalk = min(nsteps, step_limit);
+  for (int i = lane + step_first; i <= nwalk; i += 64) {
     const long long eprev = dmaj + (long long)(i - 1) * ddmin;
     const long long k = static_cast<long long>(
         floor(static_cast<double>(eprev - 1) / static_cast<double>(ddmaj)));
@@ -180,6 +184,232 @@ __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_bayes_kernel(
     }
     if (xmajor) stamp_tag(grid, last, tag, hb, g, a, bq);
     else stamp_tag(grid, last, tag, hb, g, bq, a);
+  }
+}
+
+// ---- tiled scan -----------------------------------------------------------------
+// Cell ownership instead of beam ownership: a workgroup owns a 64 x 16 tile of
+// the grid in LDS, finds the beams whose line crosses it (separating-axis band
+// test, then the exact step range along the major axis and the minor range of
+// those steps) and walks only the steps inside.  Every cell is written once,
+// coalesced, UNEXPLORED included -- no clear pass, no global atomics, and steps
+// outside the grid are never walked.  Around the sensor every beam crosses the
+// same few tiles, so the first kNearSteps steps of each beam stay with the
+// beam-parallel kernels (rays_kernel / rays_bayes_kernel with a step limit),
+// which run behind this one and only ever raise a cell.
+constexpr int kTileI = 64, kTileJ = 16, kNearSteps = 64;
+constexpr int kTileThreads = 256;
+constexpr int kChunkSteps = 16;  // steps one lane walks: the closed-form start costs a division
+constexpr int kMaxChunks = (kTileI + 2 + kChunkSteps - 1) / kChunkSteps + 1;
+constexpr int kRoundBeams = 2 * kTileThreads;  // beams tested between two barriers
+
+__global__ void beam_ends_kernel(MapGeom g, const float *__restrict__ ranges,
+                                 const double2 *__restrict__ trig, int n, int2 *__restrict__ ends) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n) ends[b] = beam_endpoint(g, ranges[b], trig[b]);
+}
+
+struct TileTask {
+  int beam, ifirst, ilast;
+};
+
+struct TileLds {
+  unsigned int cell[kTileI * kTileJ];
+  TileTask task[kRoundBeams * kMaxChunks];
+  int ntask;
+};
+
+// line of one beam in major/minor form
+struct BeamLine {
+  int a0, b0, astep, bstep, nsteps;
+  long long dmaj, ddmaj, ddmin;
+  bool xmajor;
+};
+
+__device__ __forceinline__ BeamLine beam_line(const MapGeom &g, int2 t) {
+  BeamLine l;
+  const int dx = t.x - g.s0, dy = t.y - g.s1;
+  const int adx = abs(dx), ady = abs(dy);
+  l.xmajor = adx >= ady;  // 2 dx >= 2 dy
+  l.nsteps = l.xmajor ? adx : ady;
+  l.astep = l.xmajor ? (dx >= 0 ? 1 : -1) : (dy >= 0 ? 1 : -1);
+  l.bstep = l.xmajor ? (dy >= 0 ? 1 : -1) : (dx >= 0 ? 1 : -1);
+  l.a0 = l.xmajor ? g.s0 : g.s1;
+  l.b0 = l.xmajor ? g.s1 : g.s0;
+  l.dmaj = l.nsteps;
+  l.ddmaj = 2 * l.dmaj;
+  l.ddmin = 2 * static_cast<long long>(l.xmajor ? ady : adx);
+  return l;
+}
+
+// minor increments made by the steps 1..i (k_i of rays_kernel)
+__device__ __forceinline__ long long minor_after(const BeamLine &l, int i) {
+  return static_cast<long long>(floor(
+      static_cast<double>(l.dmaj + static_cast<long long>(i) * l.ddmin - 1) / static_cast<double>(l.ddmaj)));
+}
+
+// Stamps of the beams [b_begin, b_end), steps [step_min, step_max], that fall
+// into the tile [I0..I1] x [J0..J1], into L.cell (tag = beam + 1, maximum; any
+// non-zero value without kBayes).  Rounds of kTileThreads beams: every thread
+// tests one beam and queues the crossing part of its line in chunks of
+// kChunkSteps steps, then the threads share the chunks.
+template <bool kBayes>
+__device__ void tile_accumulate(const MapGeom &g, const int2 *__restrict__ ends, int b_begin,
+                                int b_end, int step_min, int step_max, int I0, int I1, int J0,
+                                int J1, TileLds &L) {
+  // tile centre relative to the start cell, half extents + 3 cells: a stamped
+  // cell lies within two cells of the ideal line
+  const double ci = 0.5 * (I0 + I1) - g.s0, cj = 0.5 * (J0 + J1) - g.s1;
+  const double hi = 0.5 * (I1 - I0) + 3.0, hj = 0.5 * (J1 - J0) + 3.0;
+  // the workgroups of a launch start at different rounds: all of them reading the
+  // same two kilobytes of end cells at the same time is an L2 hot spot
+  const int nrounds = (b_end - b_begin + kRoundBeams - 1) / kRoundBeams;
+  const int rot = static_cast<int>(blockIdx.x + blockIdx.y * gridDim.x);
+  for (int r = 0; r < nrounds; ++r) {
+    const int base = b_begin + ((r + rot) % nrounds) * kRoundBeams;
+    if (threadIdx.x == 0) L.ntask = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kRoundBeams / kTileThreads; ++u) {
+      const int b = base + u * kTileThreads + static_cast<int>(threadIdx.x);
+      if (b >= b_end) continue;
+      const int2 t = ends[b];
+      const int dx = t.x - g.s0, dy = t.y - g.s1;
+      const double cross = static_cast<double>(dx) * cj - static_cast<double>(dy) * ci;
+      if (fabs(cross) <= fabs(static_cast<double>(dy)) * hi + fabs(static_cast<double>(dx)) * hj) {
+        const BeamLine l = beam_line(g, t);
+        const int A0 = l.xmajor ? I0 : J0, A1 = l.xmajor ? I1 : J1;
+        const int B0 = l.xmajor ? J0 : I0, B1 = l.xmajor ? J1 : I1;
+        // a stamp of step i sits at major coordinate a_i or a_i - astep
+        int ilo = l.astep > 0 ? A0 - l.a0 : l.a0 - A1;
+        int ihi = l.astep > 0 ? A1 + 1 - l.a0 : l.a0 - A0 + 1;
+        ilo = max(ilo, max(step_min, 1));
+        ihi = min(ihi, min(step_max, l.nsteps));
+        if (ilo <= ihi) {
+          // the minor coordinate only moves one way: the stamps of steps
+          // ilo..ihi lie between the minor cell before step ilo and the one
+          // after step ihi
+          const int m0 = l.b0 + l.bstep * static_cast<int>(minor_after(l, ilo - 1));
+          const int m1 = l.b0 + l.bstep * static_cast<int>(minor_after(l, ihi));
+          if (max(m0, m1) >= B0 && min(m0, m1) <= B1) {
+            const int nch = (ihi - ilo) / kChunkSteps + 1;
+            const int slot = atomicAdd(&L.ntask, nch);
+            for (int c = 0; c < nch; ++c)
+              L.task[slot + c] = TileTask{b, ilo + c * kChunkSteps, min(ilo + (c + 1) * kChunkSteps - 1, ihi)};
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int nt = L.ntask;
+    for (int q = threadIdx.x; q < nt; q += kTileThreads) {
+      const TileTask task = L.task[q];
+      const BeamLine l = beam_line(g, ends[task.beam]);
+      const unsigned int tag = kBayes ? static_cast<unsigned int>(task.beam) + 1u : 1u;
+      // tile-local (major, minor) coordinates and LDS strides
+      const int A0 = l.xmajor ? I0 : J0, B0 = l.xmajor ? J0 : I0;
+      const unsigned int EA = static_cast<unsigned int>((l.xmajor ? I1 : J1) - A0 + 1);
+      const unsigned int EB = static_cast<unsigned int>((l.xmajor ? J1 : I1) - B0 + 1);
+      const int SA = l.xmajor ? 1 : kTileI, SB = l.xmajor ? kTileI : 1;
+      auto stamp = [&](int am, int bm) {
+        if (static_cast<unsigned int>(am) < EA && static_cast<unsigned int>(bm) < EB) {
+          const int idx = am * SA + bm * SB;
+          if (kBayes) atomicMax(&L.cell[idx], tag);
+          else L.cell[idx] = 1u;
+        }
+      };
+      const long long k = minor_after(l, task.ifirst - 1);
+      const long long e0 = l.dmaj + static_cast<long long>(task.ifirst - 1) * l.ddmin - k * l.ddmaj;
+      int a = l.a0 + l.astep * (task.ifirst - 1) - A0;
+      int bq = l.b0 + l.bstep * static_cast<int>(k) - B0;
+      if (l.nsteps < (1 << 28)) {
+        // the error term stays in [1, ddmaj] and the sums below 2 ddmaj: 32 bits
+        const int ddmaj = static_cast<int>(l.ddmaj), ddmin = static_cast<int>(l.ddmin);
+        int error = static_cast<int>(e0);
+        for (int i = task.ifirst; i <= task.ilast; ++i) {
+          const int errorprev = error;
+          a += l.astep;
+          error += ddmin;
+          if (error > ddmaj) {
+            bq += l.bstep;
+            error -= ddmaj;
+            const int sum = error + errorprev;
+            if (sum <= ddmaj) stamp(a, bq - l.bstep);  // below the line, or both
+            if (sum >= ddmaj) stamp(a - l.astep, bq);  // above the line, or both
+          }
+          stamp(a, bq);
+        }
+      } else {
+        long long error = e0;
+        for (int i = task.ifirst; i <= task.ilast; ++i) {
+          const long long errorprev = error;
+          a += l.astep;
+          error += l.ddmin;
+          if (error > l.ddmaj) {
+            bq += l.bstep;
+            error -= l.ddmaj;
+            const long long sum = error + errorprev;
+            if (sum <= l.ddmaj) stamp(a, bq - l.bstep);
+            if (sum >= l.ddmaj) stamp(a - l.astep, bq);
+          }
+          stamp(a, bq);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// far field: one workgroup per tile, all beams, steps beyond kNearSteps; writes
+// every cell of the tile (UNEXPLORED / EMPTY, and the tag grid with kBayes)
+template <bool kBayes>
+__global__ __launch_bounds__(kTileThreads) void scan_tiles_kernel(
+    MapGeom g, const int2 *__restrict__ ends, int n, int *__restrict__ grid,
+    unsigned int *__restrict__ last, int hb) {
+  __shared__ TileLds L;
+  const int I0 = blockIdx.x * kTileI, J0 = blockIdx.y * kTileJ;
+  const int I1 = min(I0 + kTileI, g.H) - 1, J1 = min(J0 + kTileJ, g.W) - 1;
+  for (int t = threadIdx.x; t < kTileI * kTileJ; t += kTileThreads) L.cell[t] = 0u;
+  tile_accumulate<kBayes>(g, ends, 0, n, kNearSteps + 1, INT_MAX, I0, I1, J0, J1, L);
+  for (int t = threadIdx.x; t < kTileI * kTileJ; t += kTileThreads) {
+    const int i = I0 + (t & (kTileI - 1)), j = J0 + t / kTileI;
+    if (i <= I1 && j <= J1) {
+      const unsigned int v = L.cell[t];
+      grid[static_cast<size_t>(i) + static_cast<size_t>(j) * static_cast<size_t>(g.H)] =
+          v ? KC_EMPTY : KC_UNEXPLORED;
+      if (kBayes) last[tag_index(i, j, hb)] = v;
+    }
+  }
+}
+
+// near field with tags (Bayesian scan): the tiles around the sensor, each
+// shared by `gridDim.z` workgroups that take one slice of the beams each --
+// contiguous slices, so that a slice of an ordered scan is a sector and touches
+// few cells -- and raise what the far-field kernel wrote: EMPTY by plain
+// stores, tags by one atomic per touched cell and slice.
+__global__ __launch_bounds__(kTileThreads) void near_tiles_kernel(
+    MapGeom g, const int2 *__restrict__ ends, int n, int *__restrict__ grid,
+    unsigned int *__restrict__ last, int hb, int ti0, int tj0) {
+  __shared__ TileLds L;
+  const int I0 = (ti0 + static_cast<int>(blockIdx.x)) * kTileI;
+  const int J0 = (tj0 + static_cast<int>(blockIdx.y)) * kTileJ;
+  const int I1 = min(I0 + kTileI, g.H) - 1, J1 = min(J0 + kTileJ, g.W) - 1;
+  const int per = (n + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z);
+  const int b_begin = static_cast<int>(blockIdx.z) * per, b_end = min(b_begin + per, n);
+  if (b_begin >= b_end) return;
+  for (int t = threadIdx.x; t < kTileI * kTileJ; t += kTileThreads) L.cell[t] = 0u;
+  tile_accumulate<true>(g, ends, b_begin, b_end, 1, kNearSteps, I0, I1, J0, J1, L);
+  // the first emitted point of every beam is the start cell
+  if (threadIdx.x == 0 && g.s0 >= I0 && g.s0 <= I1 && g.s1 >= J0 && g.s1 <= J1)
+    atomicMax(&L.cell[(g.s0 - I0) + (g.s1 - J0) * kTileI], static_cast<unsigned int>(b_end));
+  __syncthreads();
+  for (int t = threadIdx.x; t < kTileI * kTileJ; t += kTileThreads) {
+    const unsigned int v = L.cell[t];
+    if (v != 0u) {
+      const int i = I0 + (t & (kTileI - 1)), j = J0 + t / kTileI;
+      grid[static_cast<size_t>(i) + static_cast<size_t>(j) * static_cast<size_t>(g.H)] = KC_EMPTY;
+      atomicMax(&last[tag_index(i, j, hb)], v);
+    }
   }
 }
 
@@ -316,6 +546,14 @@ struct kc_mapper {
   DevBuf<float> d_ranges;
   DevBuf<double2> d_trig;
   DevBuf<unsigned int> d_ticket;
+  DevBuf<int2> d_ends;       // tiled scan: end cell of every beam
+  // KC_MAPPER_TILES: 1 = Bayesian scans tiled (default: the tag maximum needs no
+  // global atomic beyond the tiles around the sensor), 3 = Bayesian scans with
+  // only the near field tiled and the far field beam-parallel (faster for short
+  // ranges, slower for long ones), 2 = plain scans tiled too (slower than the
+  // three beam-parallel passes: test hook), 0 = never
+  int tile_mode = 1;
+  bool tiles = false;        // ... for the scan being queued
   PinBuf<long long> h_seq;   // written by the last endpoints workgroup
   long long seq = 0;         // scans launched
   bool direct = false;       // host stores reach device memory (large BAR)
@@ -365,9 +603,12 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   if (m->timing.enabled || !scan_done(m, 0)) KC_HIP(hipStreamSynchronize(s));
   m->timing.begin_cycle();
   const size_t cells = static_cast<size_t>(m->g.H) * m->g.W;
-  KC_TRY(m->timing.start("grid_clear", s));
-  KC_HIP(hipMemsetAsync(m->d_grid.p, 0xFF, cells * sizeof(int), s));  // -1
-  KC_TRY(m->timing.stop(s));
+  m->tiles = m->tile_mode == 2 || (m->tile_mode == 1 && bayes);
+  if (!m->tiles || n == 0) {  // the tiled scan writes every cell itself
+    KC_TRY(m->timing.start("grid_clear", s));
+    KC_HIP(hipMemsetAsync(m->d_grid.p, 0xFF, cells * sizeof(int), s));  // -1
+    KC_TRY(m->timing.stop(s));
+  }
   if (n == 0) {
     m->seq = 0;  // nothing will signal: kc_mapper_sync waits on the stream
     if (bayes)   // gridDataProb.fill(m_pPrior), local_mapper.cpp:227
@@ -408,15 +649,54 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
                           hipMemcpyHostToDevice, s));
   }
   const int ni = static_cast<int>(n);
-  KC_TRY(m->timing.start("rays_kernel", s));
   const dim3 rgrid((ni + kBeamsPerBlock - 1) / kBeamsPerBlock), rblock(64 * kBeamsPerBlock);
   const int hb = (m->g.H + 3) / 4;
-  if (bayes)
+  int step_limit = INT_MAX;
+  if (m->tiles) {
+    KC_TRY(m->d_ends.reserve(n));
+    KC_TRY(m->timing.start("beam_ends_kernel", s));
+    hipLaunchKernelGGL(beam_ends_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, m->g,
+                       m->d_ranges.p, m->d_trig.p, ni, m->d_ends.p);
+    KC_TRY(m->timing.stop(s));
+    const dim3 tgrid((m->g.H + kTileI - 1) / kTileI, (m->g.W + kTileJ - 1) / kTileJ);
+    KC_TRY(m->timing.start("scan_tiles_kernel", s));
+    if (bayes)
+      hipLaunchKernelGGL(scan_tiles_kernel<true>, tgrid, dim3(256), 0, s, m->g, m->d_ends.p, ni,
+                         m->d_grid.p, m->d_last.p, hb);
+    else
+      hipLaunchKernelGGL(scan_tiles_kernel<false>, tgrid, dim3(256), 0, s, m->g, m->d_ends.p, ni,
+                         m->d_grid.p, static_cast<unsigned int *>(nullptr), hb);
+    KC_TRY(m->timing.stop(s));
+    step_limit = kNearSteps;
+  }
+  const bool hybrid = bayes && m->tile_mode == 3;
+  if (hybrid) {
+    // far field: beam-parallel, a global atomic per stamp (few beams share a far cell)
+    KC_TRY(m->d_ends.reserve(n));
+    hipLaunchKernelGGL(beam_ends_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, m->g,
+                       m->d_ranges.p, m->d_trig.p, ni, m->d_ends.p);
+    KC_TRY(m->timing.start("rays_kernel", s));
     hipLaunchKernelGGL(rays_bayes_kernel, rgrid, rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p,
-                       ni, m->d_grid.p, m->d_last.p, hb);
+                       ni, m->d_grid.p, m->d_last.p, hb, kNearSteps + 1, INT_MAX);
+    KC_TRY(m->timing.stop(s));
+  }
+  KC_TRY(m->timing.start(bayes && (m->tiles || hybrid) ? "near_tiles_kernel" : "rays_kernel", s));
+  if (bayes && (m->tiles || hybrid)) {
+    // tiles that hold cells within kNearSteps + 1 (Chebyshev) of the start cell
+    const int ia = std::max(m->g.s0 - kNearSteps - 1, 0), ib = std::min(m->g.s0 + kNearSteps + 1, m->g.H - 1);
+    const int ja = std::max(m->g.s1 - kNearSteps - 1, 0), jb = std::min(m->g.s1 + kNearSteps + 1, m->g.W - 1);
+    if (ia <= ib && ja <= jb) {
+      const int ti0 = ia / kTileI, tj0 = ja / kTileJ;
+      const dim3 ngrid(ib / kTileI - ti0 + 1, jb / kTileJ - tj0 + 1, std::min(32, std::max(1, ni / 64)));
+      hipLaunchKernelGGL(near_tiles_kernel, ngrid, dim3(kTileThreads), 0, s, m->g, m->d_ends.p, ni,
+                         m->d_grid.p, m->d_last.p, hb, ti0, tj0);
+    }
+  } else if (bayes)
+    hipLaunchKernelGGL(rays_bayes_kernel, rgrid, rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p,
+                       ni, m->d_grid.p, m->d_last.p, hb, 1, step_limit);
   else
     hipLaunchKernelGGL(rays_kernel, rgrid, rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p, ni,
-                       m->d_grid.p);
+                       m->d_grid.p, step_limit);
   KC_TRY(m->timing.stop(s));
   ++m->seq;
   KC_TRY(m->timing.start("endpoints_kernel", s));
@@ -504,6 +784,8 @@ int kc_mapper_create(int H, int W, float res, const float pos[3], float orient,
   m->direct = large_bar != 0;
   if (const char *e = std::getenv("KC_TRIG_COPY"))
     if (e[0] == '1') m->direct = false;  // test hook: staged copies
+  if (const char *e = std::getenv("KC_MAPPER_TILES"))
+    if (e[0] >= '0' && e[0] <= '3') m->tile_mode = e[0] - '0';
   *out = m;
   return KC_OK;
 }
@@ -526,6 +808,7 @@ void kc_mapper_destroy(kc_mapper *m) {
   m->d_ranges.release();
   m->d_trig.release();
   m->d_ticket.release();
+  m->d_ends.release();
   m->h_seq.release();
   m->h_ranges.release();
   m->h_trig.release();

@@ -110,6 +110,8 @@ def test_oracle_warp_keeps_a_constant_grid_and_fills_with_the_prior():
 # HIP path vs oracle (GPU)
 # ---------------------------------------------------------------------------
 _CASES = [
+    (640, 160, 0.05, (-14.0, 3.0, 0), 1.0, 1500, 2.5, BENCH),
+    (333, 517, 0.02, (1.0, -2.0, 0), 2.2, 2048, 1.0, DEFAULT),
     (400, 400, 0.05, (0, 0, 0), 0.0, 3600, 1.0, BENCH),
     (200, 300, 0.1, (0.35, -0.2, 0.1), 0.6, 777, 1.0, DEFAULT),
     (101, 77, 0.07, (-0.5, 0.4, 0), -2.0, 360, 0.5, BENCH),
@@ -122,9 +124,11 @@ def _bits(a):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tiles", ["3", "1", "0"])  # hybrid (default) / all tiles / all beam-parallel
 @pytest.mark.parametrize("H,W,res,pos,orient,n,scale,params", _CASES)
-def test_bayes_scan_parity(H, W, res, pos, orient, n, scale, params):
+def test_bayes_scan_parity(H, W, res, pos, orient, n, scale, params, tiles, monkeypatch):
     import kompass_hip as kh
+    monkeypatch.setenv("KC_MAPPER_TILES", tiles)
     ang, rng = _scan(n, scale)
     o = ko.BayesMapper(H, W, res, pos, orient, **params)
     m = kh.MapperContext(H, W, res, pos, orient, n)

@@ -210,8 +210,13 @@ def test_cost_evaluate_random_with_velocities():
     (200, 300, 0.1, (0.35, -0.2, 0.1), 0.6, 777, 1.0),
     (101, 77, 0.07, (-0.5, 0.4, 0), -2.0, 360, 0.5),
     (1000, 1000, 0.05, (0, 0, 0), 0.0, 4096, 4.0),
+    (40, 50, 0.1, (0.3, 0.2, 0), 0.3, 64, 0.3),              # smaller than one tile row
+    (640, 160, 0.05, (-14.0, 3.0, 0), 1.0, 1500, 2.5),       # sensor near a corner, tile-aligned grid
+    (333, 517, 0.02, (1.0, -2.0, 0), 2.2, 2048, 1.0),        # long lines, ragged tiles
 ])
-def test_mapper_parity(H, W, res, pos, orient, n, scale):
+@pytest.mark.parametrize("tiles", ["2", "1"])
+def test_mapper_parity(H, W, res, pos, orient, n, scale, tiles, monkeypatch):
+    monkeypatch.setenv("KC_MAPPER_TILES", tiles)   # 2: tiled scan, 1: three beam-parallel passes (default for plain scans)
     ang, rng = syn.dense_scan(n, scale)
     r = np.random.default_rng(5)
     rng = rng * (0.6 + 0.8 * r.random(n))
@@ -239,6 +244,25 @@ def test_mapper_fixture_scan():
     m = kh.MapperContext(200, 200, 0.1, (0, 0, 0), 0.0, len(rng))
     np.testing.assert_array_equal(m.scan_to_grid(ang, rng), want)
     assert (want == 100).sum() > 0
+
+
+def test_mapper_random_scenes():
+    """Random geometry, sensor pose and ranges (some zero, some far beyond the grid), one beam to thousands."""
+    r = np.random.default_rng(77)
+    for case in range(24):
+        H, W = int(r.integers(3, 700)), int(r.integers(3, 700))
+        res = float(r.choice([0.02, 0.05, 0.1, 0.25]))
+        ext = min(H, W) * res
+        pos = (float(r.uniform(-0.6, 0.6) * ext), float(r.uniform(-0.6, 0.6) * ext), 0.0)   # may lie outside the grid
+        orient = float(r.uniform(-3.2, 3.2))
+        n = int(r.choice([1, 2, 17, 360, 1000, 3000]))
+        ang = np.sort(r.uniform(-np.pi, np.pi, n)) if case % 3 else r.uniform(-7, 7, n)     # unsorted angles too
+        rng = r.uniform(0, 1.2 * ext, n) * r.choice([1.0, 1.0, 1.0, 0.0, 12.0], n)
+        want = ko.scan_to_grid(H, W, res, pos, orient, ang, rng)
+        m = kh.MapperContext(H, W, res, pos, orient, n)
+        got = m.scan_to_grid(ang, rng)
+        assert np.array_equal(got, want), (case, H, W, res, pos, orient, n, int((got != want).sum()))
+        m.close()
 
 
 def test_mapper_empty_scan():
