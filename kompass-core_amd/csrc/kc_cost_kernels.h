@@ -102,6 +102,11 @@ struct CostArgs {
   int nsup;                 // super-chunks of 8 chunks (kept at the end: the workgroup-per-sample
                             // kernel lost 5 us when this field sat next to nch -- its scalar
                             // argument loads are sensitive to the layout above)
+  const float *dc;          // [dc_H][dc_W] distance from a cell centre to the nearest obstacle (+inf
+                            // beyond cap + a cell), a grid of its own from the bucket origin; or
+                            // null (cell_dist_kernel, kc_sensor_kernels.h)
+  double dc_inv_g, dc_h;    // 1 / cell edge, half a cell diagonal
+  int dc_W, dc_H;
 };
 
 #ifdef KC_PHASE_STAMPS
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ long long s_key;
   __shared__ unsigned long long s_obest[kCostWaves];  // per sample: min squared obstacle distance (double bits)
+  __shared__ int s_next;  // next sample slot of this workgroup (the wavefronts pull: samples differ in cost)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
   KC_STAMP(0);
@@ -473,7 +479,10 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
               *const szz = sg + 3 * a.S, *const sacc = sg + 4 * a.S;
   const float *const cap = sg + 5 * a.S;             // [8][nch]
   const float *const sup = cap + 8 * a.nch;          // [4][nsup]
-  if (threadIdx.x == 0) s_key = KEY_NONE;
+  if (threadIdx.x == 0) {
+    s_key = KEY_NONE;
+    s_next = 0;
+  }
   if (na > 0 && kLds) {
 #pragma unroll 8
     for (int j = threadIdx.x; j < seg_words; j += kCostBlock) l_seg[j] = a.sx[j];
@@ -494,14 +503,19 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
   KC_STAMP(6);
 
   long long wkey = KEY_NONE;
-  // sample i of the list goes to wavefront (i / grid) of workgroup (i % grid):
-  // a short list spreads over all CUs, one wavefront each
-  for (int i = wave * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x); i < na;
-       i += kCostWaves * static_cast<int>(gridDim.x)) {
+  // sample i of the list belongs to workgroup (i % grid): a short list spreads
+  // over all CUs; inside the workgroup the wavefronts pull the next one
+  for (;;) {
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&s_next, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    const int i = slot * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
+    if (i >= na) break;
     const int n = a.adm_list[i];
     if (lane == 0) s_obest[wave] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
     float sum = 0.0f;            // ordered path-cost sum, carried over the point tiles
     float goal = 0.0f, endc = 0.0f;
+    double ubound2 = DBL_MAX;    // square of an upper bound of the sample's obstacle distance (not attained)
     for (int p0 = 0; p0 < a.P; p0 += 64) {
       const int pp = p0 + lane;
       const bool live = pp < a.P;
@@ -653,6 +667,22 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
         // lanes with an empty neighbourhood wait for the cooperative pass below
         bool far = active && sk >= kCoopMinSkip && sk < 255;
         if (far) active = false;
+        // bracket of this point's distance from the centre table (off == 0: the
+        // point lies in its cell): within half a cell diagonal of the centre's
+        double lb0 = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
+        double ubp = DBL_MAX;
+        if (far && a.dc != nullptr && off == 0.0) {
+          const int ix = min(max(static_cast<int>((static_cast<double>(x) - b.gx0) * a.dc_inv_g), 0), a.dc_W - 1);
+          const int iy = min(max(static_cast<int>((static_cast<double>(y) - b.gy0) * a.dc_inv_g), 0), a.dc_H - 1);
+          const float dcv = a.dc[iy * a.dc_W + ix];
+          if (dcv > 3.0e38f) {
+            far = false;  // farther than the cap: costs nothing
+          } else {
+            const double hh = a.dc_h + 1e-4 + static_cast<double>(dcv) * 1e-6;
+            lb0 = fmax(lb0, static_cast<double>(dcv) - hh);
+            ubp = static_cast<double>(dcv) + hh;
+          }
+        }
         while (__ballot(active)) {
           if (active) {
             const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
@@ -726,11 +756,18 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
         // never evaluated.  The values that survive are exact, so the minimum
         // is the one of the full scan.
         if (__ballot(far)) {
-          // lower bound of this lane's distance (cells nearer than sk are empty)
-          double lbk = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
+          // lower bound of this lane's distance (cells nearer than sk are empty;
+          // the centre table when there is one)
+          double lbk = lb0;
+          {
+            // the smallest upper bound bounds the trajectory minimum: points whose
+            // lower bound lies above it are never evaluated
+            const double u = wave_min_nonneg(far ? ubp : DBL_MAX);
+            if (u < 1.0e150) ubound2 = fmin(ubound2, u * u);
+          }
           for (int guard = 0; guard < 64; ++guard) {
-            const double ub2 = __longlong_as_double(static_cast<long long>(
-                *const_cast<volatile unsigned long long *>(&s_obest[wave])));
+            const double ub2 = fmin(ubound2, __longlong_as_double(static_cast<long long>(
+                *const_cast<volatile unsigned long long *>(&s_obest[wave]))));
             // lanes that can still lower the minimum
             const bool cont = far && lbk * lbk < ub2 * (1.0 - 1e-6) && lbk < b.cap;
             const unsigned long long cm = __ballot(cont);
@@ -744,8 +781,14 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
             const int skq = __builtin_amdgcn_readlane(sk, q);
             const double offq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(off), q),
                                                  __builtin_amdgcn_readlane(__double2loint(off), q));
-            // exact search for (xq, yq): ring rows over the lanes
+            // exact search for (xq, yq): ring rows over the lanes; with a bound on
+            // the answer the first block is already the one that proves it
             int pmq = skq - 1, mq = max(1, skq);
+            if (ub2 < 1.0e300) {
+              const double need0 = static_cast<double>(__builtin_sqrtf(static_cast<float>(ub2)) * 1.0001f);
+              const double mm0 = ceil(fmin(need0, b.cap * 1.001) * b.inv_g + offq) + 1.0;
+              mq = max(mq, static_cast<int>(fmin(mm0, static_cast<double>(mmax))));
+            }
             double found = DBL_MAX;   // wave-uniform after every stage
             double proven = 0.0;      // everything closer than this was visited
             for (;;) {

@@ -138,6 +138,12 @@ struct kc_dwa {
   PinBuf<uint8_t> h_skip;  // Chebyshev distance to the nearest non-empty cell
   DevBuf<uint8_t> d_skip;
   size_t n_bucketed = 0;
+  DevBuf<float> d_dc;    // cell centre -> nearest obstacle (device sensor build only)
+  bool have_dc = false;  // ... valid for the current buckets
+  bool no_dc = false;    // KC_COST_DC=0: test hook, the searches without the centre table
+  int dc_side = 64;      // KC_COST_DC=<cells along the longer side of the table>
+  double dc_inv_g = 0, dc_h = 0;
+  int dc_W = 0, dc_H = 0;
 
   DevBuf<long long> d_result;  // key, n_adm, compact index, scratch
   PinBuf<long long> h_result;
@@ -352,6 +358,7 @@ int upload_voxels(kc_dwa *c) {
 int upload_obstacles(kc_dwa *c, size_t n) {
   c->O = n;
   c->n_bucketed = 0;
+  c->have_dc = false;  // the centre table belongs to the device-side build
   if (n == 0) return KC_OK;
   const float *ox = c->h_obs.p, *oy = c->h_obs.p + n;
   double lox = DBL_MAX, loy = DBL_MAX, hix = -DBL_MAX, hiy = -DBL_MAX;
@@ -682,6 +689,39 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   KC_TRY(c->timing.stop(c->stream));
   KC_HIP(hipGetLastError());
   c->update_busy = true;
+  c->have_dc = false;
+  if (!c->no_dc) {
+    // centre-distance table for the far searches of the cost kernels: a grid of
+    // its own (dc_side cells along the longer side) over the bucket extent
+    CellDistArgs da{};
+    const double ex = b.W * b.g, ey = b.H * b.g;
+    da.gx0 = b.gx0;
+    da.gy0 = b.gy0;
+    da.gd = std::max(ex, ey) / c->dc_side;
+    da.Wd = std::min(c->dc_side + 1, static_cast<int>(std::ceil(ex / da.gd * (1.0 + 1e-9))) + 1);
+    da.Hd = std::min(c->dc_side + 1, static_cast<int>(std::ceil(ey / da.gd * (1.0 + 1e-9))) + 1);
+    const size_t nd = static_cast<size_t>(da.Wd) * da.Hd;
+    KC_TRY(c->d_dc.reserve(nd));
+    da.dc = c->d_dc.p;
+    da.g = b.g;
+    da.inv_g = b.inv_g;
+    da.cap = b.cap;
+    da.W = b.W;
+    da.H = b.H;
+    da.cell_start = c->d_cells.p;
+    da.skip = c->d_skip.p;
+    da.bx = c->d_bobs.p;
+    da.by = c->d_bobs.p + n;
+    KC_TRY(c->timing.start("cell_dist_kernel", c->stream));
+    hipLaunchKernelGGL(cell_dist_kernel, dim3(blocks_for(nd, 4)), dim3(256), 0, c->stream, da);
+    KC_TRY(c->timing.stop(c->stream));
+    KC_HIP(hipGetLastError());
+    c->dc_inv_g = 1.0 / da.gd;
+    c->dc_h = da.gd * 0.70710678118654757;
+    c->dc_W = da.Wd;
+    c->dc_H = da.Hd;
+    c->have_dc = true;
+  }
   KC_TRY(launch_dilate(c));
   c->have_gbits = true;
   b.skip = c->d_skip.p;
@@ -896,6 +936,11 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.seg_chunk = c->seg_chunk;
   ca.nch = c->seg_nch;
   ca.nsup = c->seg_nsup;
+  ca.dc = c->have_dc ? c->d_dc.p : nullptr;
+  ca.dc_inv_g = c->dc_inv_g;
+  ca.dc_h = c->dc_h;
+  ca.dc_W = c->dc_W;
+  ca.dc_H = c->dc_H;
   ca.seg_len = c->seg_len;
   ca.ref_len = c->ref_len;
   ca.b = c->bucket;
@@ -1176,6 +1221,11 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
+    if (const char *e = std::getenv("KC_COST_DC"))
+    {
+      if (e[0] == '0' && e[1] == 0) c->no_dc = true;    // test hook: searches without the centre table
+      else if (std::atoi(e) >= 8 && std::atoi(e) <= 512) c->dc_side = std::atoi(e);
+    }
     c->sensor_lds_ok =
         hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_build_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
@@ -1281,6 +1331,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_dbg.release();
   c->d_dbg2.release();
   c->d_raw.release();
+  c->d_dc.release();
   c->d_gridcnt.release();
   c->h_gridrec.release();
   if (c->grid_ready) {

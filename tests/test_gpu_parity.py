@@ -312,6 +312,8 @@ _PATH_SCENARIOS = [
     ("cfg3", 0.04, syn.CYLINDER, [0.2, 0.4], None),       # P = 100: two point tiles per wavefront
     ("cfg2", 0.25, syn.CYLINDER, [0.1, 0.4], "open"),     # every sample admissible
     ("cfg2", 0.1, syn.CYLINDER, [0.1, 0.4], "longseg"),   # 1600-point segment: chunks of 25
+    ("cfg2", 0.25, syn.CYLINDER, [0.1, 0.4], "ring"),     # obstacles on a closed curve 3-7 m away: far searches
+    ("cfg3", 0.04, syn.CYLINDER, [0.1, 0.4], "ring"),     # ... with two point tiles per wavefront
 ]
 
 
@@ -321,6 +323,12 @@ def _path_scenario(name, scale, shape, dims, variant, seed=4):
     if variant == "open":
         pts = np.asarray(inp["points"], dtype=np.float32).reshape(-1, 3)
         inp["points"] = pts[np.hypot(pts[:, 0], pts[:, 1]) > 4.0]
+    if variant == "ring":
+        ang, rng = syn.dense_scan(1500, 1.0)
+        ring = np.zeros((len(ang), 3), np.float32)
+        ring[:, 0] = (rng * np.cos(ang)).astype(np.float32)
+        ring[:, 1] = (rng * np.sin(ang)).astype(np.float32)
+        inp["points"] = ring
     if variant == "longseg":
         seg, acc = syn.straight_segment(1600, 0.005)
         inp["seg_xyz"], inp["acc_at_seg"] = seg, acc
@@ -334,6 +342,8 @@ def _path_scenario(name, scale, shape, dims, variant, seed=4):
     {"KC_TRIG_COPY": "1"},        # trig table through pinned memory + H2D copy, launch after it
     {"KC_EARLY_LAUNCH": "0"},     # BAR table, but classic order
     {"KC_SENSOR_HOST": "1"},      # sensor update (voxel bitmap, buckets) built on the host
+    {"KC_COST_DC": "0"},          # far-obstacle searches without the cell-centre distance table
+    {"KC_COST_KERNEL": "wave", "KC_COST_DC": "0"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternate_paths_equal_default_path(tmp_path, env):
     """Every alternative device path (selected by a switch read at context

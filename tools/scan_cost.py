@@ -22,5 +22,26 @@ for n in (360, 720, 4096):
         t0 = time.perf_counter(); ctx.set_scan(inp["state"], r, ang, 10.0); t1 = time.perf_counter()
         res = ctx.cycle((0.0, 0.0, 0.001, 0.0), P); t2 = time.perf_counter()
         ts.append(t1 - t0); tc.append(t2 - t1)
+    ctx.timing_enable(True)
+    acc = {}
+    for i in range(20):
+        ctx.cycle((0.0, 0.0, 0.001, 0.0), P)
+        for k, v in ctx.timings():
+            acc.setdefault(k, []).append(v)
+    ctx.timing_enable(False)
+    print("   kernels (us, HIP events):", {k: round(float(np.mean(v)) * 1e3, 1) for k, v in acc.items()})
+    # the same cycle without the obstacle term / without the segment terms
+    for label, w in (("no obstacle cost", (1.0, 1.0, 0.0, 0.0, 0.0)), ("obstacle cost only", (0.0, 0.0, 1.0, 0.0, 0.0))):
+        ctx.set_weights(kh.make_weights(*w))
+        ctx.timing_enable(True)
+        acc = {}
+        for i in range(20):
+            ctx.cycle((0.0, 0.0, 0.001, 0.0), P)
+            for k, v in ctx.timings():
+                if "cost" in k:
+                    acc.setdefault(k, []).append(v)
+        ctx.timing_enable(False)
+        print("   ", label, {k: round(float(np.mean(v)) * 1e3, 1) for k, v in acc.items()})
+    ctx.set_weights(kh.make_weights(*inp["weights"]))
     print(f"set_scan({n:4d} beams) {np.median(ts[20:])*1e6:6.1f} us | following cycle {np.median(tc[20:])*1e6:6.1f} us | admissible {res.n_admissible}")
     ctx.close()
