@@ -102,11 +102,17 @@ struct CostArgs {
   int nsup;                 // super-chunks of 8 chunks (kept at the end: the workgroup-per-sample
                             // kernel lost 5 us when this field sat next to nch -- its scalar
                             // argument loads are sensitive to the layout above)
-  const float *dc;          // [dc_H][dc_W] distance from a cell centre to the nearest obstacle (+inf
+};
+
+// second argument of the long-list kernel only (the layout of CostArgs is left
+// alone: the workgroup-per-sample kernel is sensitive to it)
+struct DcArgs {
+  const float *dc;          // [H][W] distance from a cell centre to the nearest obstacle (+inf
                             // beyond cap + a cell), a grid of its own from the bucket origin; or
                             // null (cell_dist_kernel, kc_sensor_kernels.h)
-  double dc_inv_g, dc_h;    // 1 / cell edge, half a cell diagonal
-  int dc_W, dc_H;
+  double inv_g, h;          // 1 / cell edge, half a cell diagonal
+  int W, H;
+  const int *enable;        // device flag of the sensor build: table filled in or not
 };
 
 #ifdef KC_PHASE_STAMPS
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
 // skip table are copied into LDS once per workgroup; kObsLds: the obstacle
 // coordinates too.  Otherwise they are read in place.
 template <bool kLds, bool kObsLds>
-__global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
+__global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcArgs t) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ long long s_key;
   __shared__ unsigned long long s_obest[kCostWaves];  // per sample: min squared obstacle distance (double bits)
@@ -479,6 +485,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
               *const szz = sg + 3 * a.S, *const sacc = sg + 4 * a.S;
   const float *const cap = sg + 5 * a.S;             // [8][nch]
   const float *const sup = cap + 8 * a.nch;          // [4][nsup]
+  const bool use_dc = t.dc != nullptr && *t.enable != 0;
   if (threadIdx.x == 0) {
     s_key = KEY_NONE;
     s_next = 0;
@@ -671,14 +678,14 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a) {
         // point lies in its cell): within half a cell diagonal of the centre's
         double lb0 = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
         double ubp = DBL_MAX;
-        if (far && a.dc != nullptr && off == 0.0) {
-          const int ix = min(max(static_cast<int>((static_cast<double>(x) - b.gx0) * a.dc_inv_g), 0), a.dc_W - 1);
-          const int iy = min(max(static_cast<int>((static_cast<double>(y) - b.gy0) * a.dc_inv_g), 0), a.dc_H - 1);
-          const float dcv = a.dc[iy * a.dc_W + ix];
+        if (far && use_dc && off == 0.0) {
+          const int ix = min(max(static_cast<int>((static_cast<double>(x) - b.gx0) * t.inv_g), 0), t.W - 1);
+          const int iy = min(max(static_cast<int>((static_cast<double>(y) - b.gy0) * t.inv_g), 0), t.H - 1);
+          const float dcv = t.dc[iy * t.W + ix];
           if (dcv > 3.0e38f) {
             far = false;  // farther than the cap: costs nothing
           } else {
-            const double hh = a.dc_h + 1e-4 + static_cast<double>(dcv) * 1e-6;
+            const double hh = t.h + 1e-4 + static_cast<double>(dcv) * 1e-6;
             lb0 = fmax(lb0, static_cast<double>(dcv) - hh);
             ubp = static_cast<double>(dcv) + hh;
           }

@@ -139,6 +139,7 @@ struct kc_dwa {
   DevBuf<uint8_t> d_skip;
   size_t n_bucketed = 0;
   DevBuf<float> d_dc;    // cell centre -> nearest obstacle (device sensor build only)
+  DevBuf<int> d_dc_enable;  // ... filled in or not (decided by sensor_build_kernel)
   bool have_dc = false;  // ... valid for the current buckets
   bool no_dc = false;    // KC_COST_DC=0: test hook, the searches without the centre table
   int dc_side = 64;      // KC_COST_DC=<cells along the longer side of the table>
@@ -683,6 +684,8 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   a.by = c->d_bobs.p + n;
   a.tmp = c->d_sensor_tmp.p;
   a.obs_z_zero = c->raw_is_scan ? 1 : 0;
+  KC_TRY(c->d_dc_enable.reserve(1));
+  a.dc_enable = c->d_dc_enable.p;
   const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
   KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
   hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
@@ -712,6 +715,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     da.skip = c->d_skip.p;
     da.bx = c->d_bobs.p;
     da.by = c->d_bobs.p + n;
+    da.enable = c->d_dc_enable.p;
     KC_TRY(c->timing.start("cell_dist_kernel", c->stream));
     hipLaunchKernelGGL(cell_dist_kernel, dim3(blocks_for(nd, 4)), dim3(256), 0, c->stream, da);
     KC_TRY(c->timing.stop(c->stream));
@@ -936,11 +940,13 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.seg_chunk = c->seg_chunk;
   ca.nch = c->seg_nch;
   ca.nsup = c->seg_nsup;
-  ca.dc = c->have_dc ? c->d_dc.p : nullptr;
-  ca.dc_inv_g = c->dc_inv_g;
-  ca.dc_h = c->dc_h;
-  ca.dc_W = c->dc_W;
-  ca.dc_H = c->dc_H;
+  DcArgs dt{};
+  dt.dc = c->have_dc ? c->d_dc.p : nullptr;
+  dt.inv_g = c->dc_inv_g;
+  dt.h = c->dc_h;
+  dt.W = c->dc_W;
+  dt.H = c->dc_H;
+  dt.enable = c->d_dc_enable.p;
   ca.seg_len = c->seg_len;
   ca.ref_len = c->ref_len;
   ca.b = c->bucket;
@@ -1015,13 +1021,13 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
                    lds_tab, lds_obs, ca.b.nobs, ca.b.W, ca.b.H, S, ca.seg_chunk, int(tab_lds), int(obs_lds));
     if (obs_lds)
       hipLaunchKernelGGL((sample_cost_kernel<true, true>), dim3(cost_blocks), dim3(kCostBlock),
-                         lds_tab + lds_obs, s, ca);
+                         lds_tab + lds_obs, s, ca, dt);
     else if (tab_lds)
       hipLaunchKernelGGL((sample_cost_kernel<true, false>), dim3(cost_blocks), dim3(kCostBlock),
-                         lds_tab, s, ca);
+                         lds_tab, s, ca, dt);
     else
       hipLaunchKernelGGL((sample_cost_kernel<false, false>), dim3(cost_blocks), dim3(kCostBlock),
-                         0, s, ca);
+                         0, s, ca, dt);
   }
   KC_TRY(c->timing.stop(s));
   {
@@ -1332,6 +1338,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_dbg2.release();
   c->d_raw.release();
   c->d_dc.release();
+  c->d_dc_enable.release();
   c->d_gridcnt.release();
   c->h_gridrec.release();
   if (c->grid_ready) {
@@ -1558,8 +1565,12 @@ int kc_dwa_set_grid_device(kc_dwa *c, const kc_state *st, const int32_t *dev_gri
   KC_TRY(c->d_raw.reserve(3 * cells));
   KC_TRY(c->h_gridrec.reserve(8));
   if (!c->d_gridcnt.p) {
-    KC_TRY(c->d_gridcnt.reserve(8));
-    const int init[5] = {0, INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+    KC_TRY(c->d_gridcnt.reserve(5 * kGridCntStride));
+    int init[5 * kGridCntStride] = {0};
+    init[1 * kGridCntStride] = INT_MAX;
+    init[2 * kGridCntStride] = INT_MIN;
+    init[3 * kGridCntStride] = INT_MAX;
+    init[4 * kGridCntStride] = INT_MIN;
     KC_HIP(hipMemcpyAsync(c->d_gridcnt.p, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
     KC_HIP(hipStreamSynchronize(c->stream));
     c->h_gridrec.p[0] = 0;

@@ -27,6 +27,9 @@ struct SensorArgs {
   float *bx, *by;            // cell-ordered coordinates
   float4 *tmp;               // [n] (ox, oy, cell id, rank inside the cell) between the two passes
   int obs_z_zero;            // laserscan: the obstacle of a point is taken at z = 0
+  int *dc_enable;            // out: 1 when fewer than a third of the bucket cells hold a point (the
+                             // centre-distance table pays only where trajectory points have empty
+                             // neighbourhoods), else 0: cell_dist_kernel and the cost kernels skip it
 };
 
 constexpr int kSensorBlock = 1024;
@@ -53,9 +56,11 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(
       smem + ((static_cast<size_t>(nw) * 4 + static_cast<size_t>(ncell + 1) * 4 + 7) & ~size_t(7)));  // [H]
   __shared__ int wave_tot[kSensorBlock / 64];
+  __shared__ int s_nonempty;
   const int tid = threadIdx.x;
   for (int i = tid; i < nw; i += kSensorBlock) lbits[i] = 0u;
   for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = 0;
+  if (tid == 0) s_nonempty = 0;
   __syncthreads();
   // ---- 1: voxel bits + bucket counts ----------------------------------------
   for (int i = tid; i < a.n; i += kSensorBlock) {
@@ -129,10 +134,14 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
     for (int y = wave; y < a.H; y += kSensorBlock / 64) {
       const bool ne = lane < a.W && lstart[y * a.W + lane + 1] > lstart[y * a.W + lane];
       const unsigned long long m = __ballot(ne);
-      if (lane == 0) lmask[y] = m;
+      if (lane == 0) {
+        lmask[y] = m;
+        atomicAdd(&s_nonempty, __popcll(m));
+      }
     }
   }
   __syncthreads();
+  if (tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
   for (int k = tid; k < ncell; k += kSensorBlock) {
     const int y = k / a.W, x = k - y * a.W;
     unsigned long long acc = lmask[y];
@@ -186,9 +195,11 @@ struct CellDistArgs {
   const int *cell_start;
   const uint8_t *skip;
   const float *bx, *by;
+  const int *enable;       // written by sensor_build_kernel
 };
 
 __global__ __launch_bounds__(256) void cell_dist_kernel(CellDistArgs a) {
+  if (*a.enable == 0) return;  // dense obstacle field: the table would not be used
   const int lane = threadIdx.x & 63;
   const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (k >= a.Wd * a.Hd) return;
@@ -261,31 +272,62 @@ struct GridPtsArgs {
   int H, W, c0, c1;
   float res;
   float *xyz;           // [H*W][3] capacity
-  unsigned int *cnt;    // count, then (as int) imin, imax, jmin, jmax
+  unsigned int *cnt;    // count, then (as int) imin, imax, jmin, jmax -- one 64-byte line each
+                        // (word k at cnt[16 k]): atomics on one line serialise
 };
+constexpr int kGridCntStride = 16;
 
 __global__ __launch_bounds__(256) void grid_points_kernel(GridPtsArgs a) {
+  // hits are counted and bounded per workgroup in LDS first: one slot range and
+  // four bound updates per workgroup that holds a hit (same-address global
+  // atomics serialise at ~90 per microsecond)
+  __shared__ unsigned int s_hits, s_base;
+  __shared__ int s_lo_i, s_hi_i, s_lo_j, s_hi_j;
+  if (threadIdx.x == 0) {
+    s_hits = 0u;
+    s_lo_i = INT_MAX;
+    s_hi_i = INT_MIN;
+    s_lo_j = INT_MAX;
+    s_hi_j = INT_MIN;
+  }
+  __syncthreads();
   const unsigned int k = blockIdx.x * 256u + threadIdx.x;
   const unsigned int cells = static_cast<unsigned int>(a.H) * static_cast<unsigned int>(a.W);
   const bool hit = k < cells && a.grid[k] == KC_OCCUPIED;
   const unsigned long long m = __ballot(hit);
-  if (m == 0ull) return;
   const int lane = threadIdx.x & 63;
-  unsigned int base = 0;
-  if (lane == __ffsll(static_cast<long long>(m)) - 1) base = atomicAdd(&a.cnt[0], __popcll(m));
-  base = __shfl(base, __ffsll(static_cast<long long>(m)) - 1, 64);
-  if (hit) {
-    const int i = static_cast<int>(k % static_cast<unsigned int>(a.H));
-    const int j = static_cast<int>(k / static_cast<unsigned int>(a.H));
-    const unsigned int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-    a.xyz[3 * static_cast<size_t>(slot)] = static_cast<float>(i - a.c0) * a.res;
-    a.xyz[3 * static_cast<size_t>(slot) + 1] = static_cast<float>(j - a.c1) * a.res;
-    a.xyz[3 * static_cast<size_t>(slot) + 2] = 0.0f;
+  const int i = static_cast<int>(k % static_cast<unsigned int>(a.H));
+  const int j = static_cast<int>(k / static_cast<unsigned int>(a.H));
+  unsigned int rank = 0;
+  if (m != 0ull) {
+    const int leader = __ffsll(static_cast<long long>(m)) - 1;
+    unsigned int wbase = 0;
+    if (lane == leader) wbase = atomicAdd(&s_hits, static_cast<unsigned int>(__popcll(m)));
+    wbase = __shfl(wbase, leader, 64);
+    rank = wbase + __popcll(m & ((1ull << lane) - 1ull));
+    if (hit) {
+      atomicMin(&s_lo_i, i);
+      atomicMax(&s_hi_i, i);
+      atomicMin(&s_lo_j, j);
+      atomicMax(&s_hi_j, j);
+    }
+  }
+  __syncthreads();
+  if (s_hits == 0u) return;
+  if (threadIdx.x == 0) {
+    s_base = atomicAdd(&a.cnt[0], s_hits);
     int *b = reinterpret_cast<int *>(a.cnt);
-    atomicMin(&b[1], i);
-    atomicMax(&b[2], i);
-    atomicMin(&b[3], j);
-    atomicMax(&b[4], j);
+    atomicMin(&b[1 * kGridCntStride], s_lo_i);
+    atomicMax(&b[2 * kGridCntStride], s_hi_i);
+    atomicMin(&b[3 * kGridCntStride], s_lo_j);
+    atomicMax(&b[4 * kGridCntStride], s_hi_j);
+  }
+  __syncthreads();
+  if (hit) {
+    const size_t slot = static_cast<size_t>(s_base) + rank;
+    a.xyz[3 * slot] = static_cast<float>(i - a.c0) * a.res;
+    a.xyz[3 * slot + 1] = static_cast<float>(j - a.c1) * a.res;
+    a.xyz[3 * slot + 2] = 0.0f;
   }
 }
 
@@ -294,15 +336,15 @@ __global__ __launch_bounds__(256) void grid_points_kernel(GridPtsArgs a) {
 __global__ void grid_points_publish_kernel(unsigned int *cnt, long long *host, long long seq) {
   int *b = reinterpret_cast<int *>(cnt);
   host[1] = cnt[0];
-  host[2] = b[1];
-  host[3] = b[2];
-  host[4] = b[3];
-  host[5] = b[4];
+  host[2] = b[1 * kGridCntStride];
+  host[3] = b[2 * kGridCntStride];
+  host[4] = b[3 * kGridCntStride];
+  host[5] = b[4 * kGridCntStride];
   cnt[0] = 0u;
-  b[1] = INT_MAX;
-  b[2] = INT_MIN;
-  b[3] = INT_MAX;
-  b[4] = INT_MIN;
+  b[1 * kGridCntStride] = INT_MAX;
+  b[2 * kGridCntStride] = INT_MIN;
+  b[3 * kGridCntStride] = INT_MAX;
+  b[4 * kGridCntStride] = INT_MIN;
   __threadfence_system();
   *reinterpret_cast<volatile long long *>(host) = seq;
 }
