@@ -4,6 +4,8 @@ robot shapes, sensor mounts, poses, tracked segments with curvature and height,
 weights, horizons over one and two point tiles, point-list and laserscan
 updates, several cycles per context (so both cost kernels and the lazy host
 lists come into play)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -55,13 +57,18 @@ SCENES = [(kind, seg, shape) for kind in ("clutter", "ring", "far", "wall", "few
           for seg in ("straight", "arc", "wavy") for shape in (0, 1)]
 
 
+# KC_FUZZ_SEEDS="2000,3000,...": more seed bases for a longer campaign (same process)
+_SEEDS = [1000] + [int(s) for s in os.environ.get("KC_FUZZ_SEEDS", "").split(",") if s.strip()]
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 @pytest.mark.parametrize("case", range(len(SCENES)))
-def test_random_scene(case):
+def test_random_scene(case, seed):
     kind, segk, shape = SCENES[case]
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(seed + case)
     # every fifth scene has > 512 samples, so that long admissible lists (the
     # wavefront-per-sample cost kernel beyond the first cycle) occur as well
-    inp = syn.make_controller_inputs("cfg1", seed=case, scale=3.0 if case % 5 == 0 else rng.choice([0.6, 1.0, 1.6]))
+    inp = syn.make_controller_inputs("cfg1", seed=case + (seed - 1000), scale=3.0 if case % 5 == 0 else rng.choice([0.6, 1.0, 1.6]))
     inp["P"] = int(rng.choice([12, 33, 64, 65, 90]))
     inp["robot"] = (dict(shape=syn.CYLINDER, dims=[float(rng.uniform(0.08, 0.4)), 0.5]) if shape == 0
                     else dict(shape=syn.BOX, dims=[float(rng.uniform(0.2, 0.7)), float(rng.uniform(0.15, 0.5)), 0.5]))
