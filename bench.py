@@ -236,6 +236,19 @@ def extras(ctx, inp, P, pose):
 
     # a controller step with new sensor data and a new tracked segment every time
     out["update_and_cycle_ms"] = med(fresh_inputs_cycle, 100)
+    # the same with the reference path resident on the device: only the window moves
+    ctx.set_path(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+
+    def fresh_inputs_window_cycle(i):
+        ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+        ctx.set_tracked_window(0, len(inp["seg_xyz"]))
+        return ctx.cycle(pose(i), P)
+
+    ra = ctx.cycle(pose(0), P)
+    rb = fresh_inputs_window_cycle(0)
+    out["update_and_cycle_resident_path_ms"] = med(fresh_inputs_window_cycle, 100)
+    out["resident_path_same_result"] = bool(ra.raw_index == rb.raw_index and np.float32(ra.cost) == np.float32(rb.cost))
+    ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
     far = pts[np.hypot(pts[:, 0], pts[:, 1]) > 10.0]
     ctx.set_points(inp["state"], far, inp["max_range"])
     for i in range(20):

@@ -183,6 +183,18 @@ int kc_dwa_set_tracked_segment(kc_dwa *ctx, const float *x, const float *y,
                                const float *z, const float *acc_at_seg,
                                size_t seg_size, float ref_path_length);
 
+/* SURVEY 8f rank 4, second half -- the reference path resident on the device.
+ * kc_dwa_set_path: the whole (interpolated) path once per path: points, the
+ * accumulated length at every point (Path::getDistanceAtIndex, path.h:74-76)
+ * and the total length.  kc_dwa_set_tracked_window(start, size): the tracked
+ * segment = points [start, start + size) of that path; same state as
+ * kc_dwa_set_tracked_segment(x + start, y + start, z + start, acc + start,
+ * size, total_length), with the search tables built by a kernel, stream-ordered
+ * between two cycles (no host synchronisation). */
+int kc_dwa_set_path(kc_dwa *ctx, const float *x, const float *y, const float *z,
+                    const float *acc_length, size_t n, float total_length);
+int kc_dwa_set_tracked_window(kc_dwa *ctx, size_t start, size_t size);
+
 /* A2-A4: TrajectorySampler::generateTrajectories (trajectory_sampler.cpp:
  * 295-314 -> :118-179) for the context's samples, drop_samples = true.
  * num_points = numPointsPerTrajectory of this cycle (<= max_points). */

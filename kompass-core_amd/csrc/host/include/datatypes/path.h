@@ -97,6 +97,9 @@ struct Path {
   const float *yData() const { return Y_.data(); }
   const float *zData() const { return Z_.data(); }
   const float *curvatureData() const { return K_.data(); }
+  // changes whenever the points or the accumulated lengths may have changed: lets
+  // the cost evaluator keep the path resident on the device between cycles
+  unsigned long long serial() const { return serial_; }
 
  private:
   std::vector<float> X_, Y_, Z_, K_;
@@ -105,6 +108,8 @@ struct Path {
   float total_length_ = 0.0f;
   std::vector<float> acc_;
   bool interpolated_ = false;
+  unsigned long long serial_ = 0;
+  void touch();
   void checkSegment(size_t s) const;
 };
 

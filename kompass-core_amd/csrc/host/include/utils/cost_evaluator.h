@@ -100,6 +100,7 @@ class CostEvaluator {
                                          size_t P);
   std::unique_ptr<TrajectoryCostsWeights> costWeights;
   hip::DwaHandle ctx_;
+  unsigned long long residentSerial_ = 0;  // Path::serial() of the path resident on the device
 };
 
 }  // namespace Control

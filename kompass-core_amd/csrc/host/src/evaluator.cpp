@@ -102,6 +102,22 @@ void CostEvaluator::setPointScan(const std::vector<Path::Point> &cloud, const Pa
 
 void CostEvaluator::uploadSegment(const Path::Path *ref, const Path::Path::View &seg) {
   const size_t S = seg.getSize();
+  // a view into `ref` (what the controllers pass): the path stays resident on
+  // the device, only the window moves (kc_dwa_set_path once per path content)
+  const size_t start = seg.getStartIndex();
+  if (S > 0 && start + S <= ref->getSize() && seg.getXPointer() == ref->xData() + start &&
+      seg.getYPointer() == ref->yData() + start && seg.getZPointer() == ref->zData() + start) {
+    if (residentSerial_ != ref->serial()) {
+      const size_t N = ref->getSize();
+      std::vector<float> acc(N);
+      for (size_t j = 0; j < N; ++j) acc[j] = ref->getDistanceAtIndex(j);
+      hip::check(kc_dwa_set_path(ctx_.get(), ref->xData(), ref->yData(), ref->zData(), acc.data(), N,
+                                 ref->totalPathLength()));
+      residentSerial_ = ref->serial();
+    }
+    hip::check(kc_dwa_set_tracked_window(ctx_.get(), start, S));
+    return;
+  }
   std::vector<float> acc(S);
   for (size_t j = 0; j < S; ++j)  // Path::getDistanceAtIndex(closest_abs_idx)
     acc[j] = ref->getDistanceAtIndex(seg.getStartIndex() + j);

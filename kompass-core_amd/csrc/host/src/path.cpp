@@ -3,6 +3,7 @@
 // tracked segment handed to the device is bit-identical.
 #include "datatypes/path.h"
 
+#include <atomic>
 #include <algorithm>
 #include <stdexcept>
 #include <string>
@@ -64,6 +65,7 @@ Path::Path(const std::vector<Point> &points) {
     Z_[i] = points[i].z();
     K_[i] = 0.0f;
   }
+  touch();
 }
 
 Path::Path(const Eigen::VectorXf &x, const Eigen::VectorXf &y,
@@ -80,6 +82,12 @@ Path::Path(const Eigen::VectorXf &x, const Eigen::VectorXf &y,
     Y_[i] = y[(Eigen::Index)i];
     Z_[i] = z[(Eigen::Index)i];
   }
+  touch();
+}
+
+void Path::touch() {
+  static std::atomic<unsigned long long> next{1};
+  serial_ = next.fetch_add(1, std::memory_order_relaxed);
 }
 
 void Path::resize(size_t n) {
@@ -88,6 +96,7 @@ void Path::resize(size_t n) {
   Z_.resize(n);
   K_.resize(n);
   interpolated_ = false;
+  touch();
 }
 
 float Path::distanceSquared(const Point &a, const Point &b) {
@@ -153,6 +162,7 @@ void Path::pushPoint(const Point &p) {
   Y_[size_] = p.y();
   Z_[size_] = p.z();
   ++size_;
+  touch();
 }
 
 static float heading(const Point &a, const Point &b) {
@@ -219,6 +229,7 @@ void Path::interpolate(double max_dist, InterpolationType type) {
     ++k;
   }
   interpolated_ = true;
+  touch();
   size_ = k;
   // discrete curvature from successive chords
   if (size_ >= 2) {
@@ -255,6 +266,7 @@ void Path::segment(double seg_len, size_t max_pts) {
       first_len = at;
     }
   }
+  touch();
 }
 
 }  // namespace Path

@@ -25,6 +25,7 @@
 #include "kc_rollout_kernels.h"
 #include "kc_cost_kernels.h"
 #include "kc_sensor_kernels.h"
+#include "kc_segment_kernels.h"
 
 // ===========================================================================
 // host context
@@ -128,6 +129,18 @@ struct kc_dwa {
   float seg_len = 0.f, ref_len = 0.f, max_obs_dist = 0.f;
   PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
   DevBuf<float> d_seg;
+  // resident reference path (kc_dwa_set_path): rows x | y | z | acc on the
+  // device, edge lengths on the host (the window length is an ordered float sum)
+  DevBuf<float> d_path;
+  // the window kernel runs beside the roll-out on a stream of its own; the cost
+  // kernel waits for its event.  Only while no cost kernel can still read d_seg.
+  hipStream_t seg_stream = nullptr;
+  hipEvent_t seg_event = nullptr;
+  bool seg_pending = false;   // event recorded, the next cost kernel has to wait for it
+  bool cost_idle = true;      // no cost kernel queued since the host last saw a result / synchronised
+  std::vector<float> path_edge;
+  size_t path_n = 0;
+  float path_len = 0.f;
   PinBuf<float> h_obs;  // ox | oy (sensor order, as setPointScan stores them)
   // obstacle buckets for the exact nearest-obstacle search (K3)
   BucketDev bucket{};
@@ -203,6 +216,7 @@ int quiesce_for_update(kc_dwa *c, bool sensor_tables = true) {
     KC_HIP(hipStreamSynchronize(c->stream));
     c->update_busy = false;
     c->drained = true;
+    c->cost_idle = true;
   }
   return KC_OK;
 }
@@ -909,6 +923,11 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const bool use_goal = c->ref_len > 0.0f && c->w.goal_distance_weight > 0.0;
   if ((use_path || use_goal) && c->S == 0)
     KC_FAIL(KC_ERR_STATE, "tracked segment not set");
+  if (c->seg_pending) {  // tables written by segment_window_kernel on its own stream
+    KC_HIP(hipStreamWaitEvent(s, c->seg_event, 0));
+    c->seg_pending = false;
+  }
+  c->cost_idle = false;
   const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
   const float *seg = c->d_seg.p;
   const size_t S = c->S;
@@ -1068,6 +1087,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
         c->h_result.p[2] = static_cast<long long>(static_cast<int32_t>(w1 & 0xFFFFFFFFll));
         got = true;
         c->drained = true;
+        c->cost_idle = true;
         c->update_busy = false;  // queued in front of the cycle whose record just arrived
         break;
       }
@@ -1081,6 +1101,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
     KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
                           hipMemcpyDeviceToHost, c->stream));
     KC_HIP(hipStreamSynchronize(c->stream));
+    c->cost_idle = true;
   }
   c->timing.mark("host:wait_result");
   kc_result r{};
@@ -1262,6 +1283,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
 void kc_dwa_destroy(kc_dwa *c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->prm.device);
+  if (c->seg_stream) e = hipStreamSynchronize(c->seg_stream);  // before any buffer goes
   if (c->debug_stamps && c->d_dbg2.p) {
     std::vector<unsigned long long> h(512 * 16);
     e = hipDeviceSynchronize();
@@ -1355,6 +1377,13 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_vom.release();
   c->h_seg.release();
   c->d_seg.release();
+  c->d_path.release();
+  if (c->seg_stream) {
+    hipError_t se = hipStreamSynchronize(c->seg_stream);
+    se = hipStreamDestroy(c->seg_stream);
+    se = hipEventDestroy(c->seg_event);
+    (void)se;
+  }
   c->h_obs.release();
   c->h_cells.release();
   c->d_cells.release();
@@ -1651,6 +1680,10 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
   KC_TRY(quiesce_for_update(c, /*sensor_tables=*/false));
+  if (c->seg_pending) {  // a window kernel may still be writing the table
+    KC_HIP(hipEventSynchronize(c->seg_event));
+    c->seg_pending = false;
+  }
   c->S = S;
   c->ref_len = ref_len;
   if (S == 0) return KC_OK;
@@ -1770,6 +1803,109 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   KC_TRY(upload_table(c, c->d_seg.p, h, seg_words * sizeof(float)));
   if (!c->trig_direct) c->update_busy = true;
   bar_flush(c);
+  return KC_OK;
+}
+
+// SURVEY 8f rank 4, second half: the interpolated reference path stays on the
+// device; a cycle moves the tracked window and a kernel builds the tables.
+int kc_dwa_set_path(kc_dwa *c, const float *x, const float *y, const float *z, const float *acc,
+                    size_t n, float total_length) {
+  if (!c || (n && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_TRY(use_device(c));
+  // the old rows may still be read by a queued window kernel
+  KC_HIP(hipStreamSynchronize(c->stream));
+  if (c->seg_stream) KC_HIP(hipStreamSynchronize(c->seg_stream));
+  c->seg_pending = false;
+  c->update_busy = false;
+  c->drained = true;
+  c->cost_idle = true;
+  c->path_n = n;
+  c->path_len = total_length;
+  c->path_edge.assign(n > 1 ? n - 1 : 0, 0.0f);
+  if (n == 0) return KC_OK;
+  KC_TRY(c->d_path.reserve(4 * n));
+  std::vector<float> rows(4 * n);
+  for (size_t j = 0; j < n; ++j) {
+    rows[j] = x[j];
+    rows[n + j] = y[j];
+    rows[2 * n + j] = z ? z[j] : 0.0f;
+    rows[3 * n + j] = acc[j];
+  }
+  for (size_t j = 0; j + 1 < n; ++j) {  // the terms of View::totalSegmentLength, path.h:85-91
+    const float dx = rows[j] - rows[j + 1], dy = rows[n + j] - rows[n + j + 1],
+                dz = rows[2 * n + j] - rows[2 * n + j + 1];
+    c->path_edge[j] = std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
+  }
+  KC_HIP(hipMemcpyAsync(c->d_path.p, rows.data(), 4 * n * sizeof(float), hipMemcpyHostToDevice,
+                        c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));  // pageable source
+  return KC_OK;
+}
+
+int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (start > c->path_n || S > c->path_n - start)
+    KC_FAIL(KC_ERR_RANGE, "window [%zu, %zu) outside the resident path of %zu points", start,
+            start + S, c->path_n);
+  KC_TRY(use_device(c));
+  c->S = S;
+  c->ref_len = c->path_len;
+  if (S == 0) return KC_OK;
+  const size_t chunk = std::max<size_t>(kSegChunkMin, (S + 63) / 64);
+  const size_t nch = (S + chunk - 1) / chunk;
+  const size_t nsup = (nch + 7) / 8;
+  c->seg_chunk = static_cast<int>(chunk);
+  c->seg_nch = static_cast<int>(nch);
+  c->seg_nsup = static_cast<int>(nsup);
+  const size_t seg_words = 5 * S + 8 * nch + 4 * nsup;
+  if (seg_words > c->d_seg.cap) {  // growing frees the old table: nothing may still read or write it
+    KC_HIP(hipStreamSynchronize(c->stream));
+    if (c->seg_stream) KC_HIP(hipStreamSynchronize(c->seg_stream));
+    c->seg_pending = false;
+    c->update_busy = false;
+    c->drained = true;
+    c->cost_idle = true;
+    KC_TRY(c->d_seg.reserve(seg_words));
+    KC_TRY(c->h_seg.reserve(seg_words));
+  }
+  // View::totalSegmentLength: float sum in index order
+  float len = 0.0f;
+  for (size_t j = start; j + 1 < start + S; ++j) len += c->path_edge[j];
+  c->seg_len = len;
+  const size_t n = c->path_n;
+  SegWindowArgs a{};
+  a.px = c->d_path.p + start;
+  a.py = c->d_path.p + n + start;
+  a.pz = c->d_path.p + 2 * n + start;
+  a.pacc = c->d_path.p + 3 * n + start;
+  a.S = static_cast<int>(S);
+  a.chunk = static_cast<int>(chunk);
+  a.nch = static_cast<int>(nch);
+  a.nsup = static_cast<int>(nsup);
+  a.seg = c->d_seg.p;
+  // No cost kernel in flight (the host has seen the last result): nothing reads
+  // the table, so the kernel runs on a stream of its own, beside the sensor
+  // build and the roll-out, and the next cost kernel waits for its event.
+  // Otherwise in stream order: behind the queued cost kernel, in front of the next.
+  hipStream_t ws = c->stream;
+  if (c->cost_idle) {
+    if (!c->seg_stream) {
+      KC_HIP(hipStreamCreateWithFlags(&c->seg_stream, hipStreamNonBlocking));
+      KC_HIP(hipEventCreateWithFlags(&c->seg_event, hipEventDisableTiming));
+    }
+    ws = c->seg_stream;
+  } else if (c->seg_pending) {
+    KC_HIP(hipStreamWaitEvent(c->stream, c->seg_event, 0));  // keep the two writers in order
+    c->seg_pending = false;
+  }
+  KC_TRY(c->timing.start("segment_window_kernel", ws));
+  hipLaunchKernelGGL(segment_window_kernel, dim3(1), dim3(kSegWinBlock), 0, ws, a);
+  KC_TRY(c->timing.stop(ws));
+  KC_HIP(hipGetLastError());
+  if (ws != c->stream) {
+    KC_HIP(hipEventRecord(c->seg_event, ws));
+    c->seg_pending = true;
+  }
   return KC_OK;
 }
 

@@ -1,0 +1,140 @@
+// Tracked-segment tables on the device (second half): the
+// interpolated reference path stays resident (kc_dwa_set_path), a cycle only
+// moves the window (kc_dwa_set_tracked_window) and this kernel writes what
+// kc_dwa_set_tracked_segment builds on the host -- the rows [5][S], the chunk
+// capsules [8][nch] and the super-chunk spheres [4][nsup] -- with the same
+// double arithmetic and the same slack.  The bounds only prune the searches of
+// the cost kernels, so validity is what matters; they come out identical to the
+// host's (maxima and minima do not depend on the order).  Part of kc_dwa.hip.
+#pragma once
+
+namespace kc {
+
+struct SegWindowArgs {
+  const float *px, *py, *pz, *pacc;  // resident path rows, already offset to the window start
+  int S, chunk, nch, nsup;
+  float *seg;                        // out: d_seg
+};
+
+constexpr int kSegWinBlock = 1024;
+
+__device__ __forceinline__ float seg_round_up(double v) {  // nextafter((float)v, +inf), v >= 0
+  const float f = static_cast<float>(v);
+  if (!(f < __builtin_inff())) return f;
+  return __uint_as_float(__float_as_uint(f) + 1u);
+}
+
+__device__ __forceinline__ double wave_max_f64(double v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowArgs a) {
+  const int S = a.S, nch = a.nch, nsup = a.nsup;
+  float *h = a.seg;
+  for (int j = threadIdx.x; j < S; j += kSegWinBlock) {
+    const float zz = a.pz[j];
+    h[j] = a.px[j];
+    h[S + j] = a.py[j];
+    h[2 * S + j] = zz;
+    h[3 * S + j] = zz * zz;  // (seg.z - 0)^2 of Path::distance
+    h[4 * S + j] = a.pacc[j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int kWaves = kSegWinBlock / 64;
+  float *cap = h + 5 * S;
+  // capsules: one wavefront per chunk, lanes over its points
+  for (int k = wave; k < nch; k += kWaves) {
+    const int j0 = k * a.chunk, j1 = min(j0 + a.chunk, S);
+    bool fin = true;
+    for (int j = j0 + lane; j < j1; j += 64)
+      fin = fin && isfinite(a.px[j]) && isfinite(a.py[j]) && isfinite(a.pz[j]);
+    const bool finite = __ballot(!fin) == 0ull;
+    const double A[3] = {a.px[j0], a.py[j0], a.pz[j0]};
+    const double B[3] = {a.px[j1 - 1], a.py[j1 - 1], a.pz[j1 - 1]};
+    // the chord as the cost kernels see it: float A, float AB, float 1/|AB|^2
+    const float ab[3] = {static_cast<float>(B[0] - A[0]), static_cast<float>(B[1] - A[1]),
+                         static_cast<float>(B[2] - A[2])};
+    const double l2 = static_cast<double>(ab[0]) * ab[0] + static_cast<double>(ab[1]) * ab[1] +
+                      static_cast<double>(ab[2]) * ab[2];
+    const float inv = (finite && l2 > 0.0 && isfinite(1.0 / l2)) ? static_cast<float>(1.0 / l2) : 0.0f;
+    double eps = 0.0, mag = 0.0;
+    if (finite) {
+      for (int j = j0 + lane; j < j1; j += 64) {
+        const double P[3] = {a.px[j], a.py[j], a.pz[j]};
+        const double q[3] = {P[0] - A[0], P[1] - A[1], P[2] - A[2]};
+        double t = (q[0] * ab[0] + q[1] * ab[1] + q[2] * ab[2]) * static_cast<double>(inv);
+        t = fmin(fmax(t, 0.0), 1.0);
+        const double e[3] = {q[0] - t * ab[0], q[1] - t * ab[1], q[2] - t * ab[2]};
+        eps = fmax(eps, sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
+        mag = fmax(mag, fabs(P[0]) + fabs(P[1]) + fabs(P[2]));
+      }
+    }
+    eps = wave_max_f64(eps);
+    mag = wave_max_f64(mag);
+    if (lane == 0) {
+      cap[k] = static_cast<float>(A[0]);
+      cap[nch + k] = static_cast<float>(A[1]);
+      cap[2 * nch + k] = static_cast<float>(A[2]);
+      cap[3 * nch + k] = finite ? ab[0] : 0.0f;
+      cap[4 * nch + k] = finite ? ab[1] : 0.0f;
+      cap[5 * nch + k] = finite ? ab[2] : 0.0f;
+      cap[6 * nch + k] = inv;
+      cap[7 * nch + k] =
+          finite ? seg_round_up(eps * (1.0 + 1e-6) + 2e-6 * sqrt(l2) + 1e-6 * mag + 1e-30) : __builtin_inff();
+    }
+  }
+  // spheres: one wavefront per super-chunk of eight chunks
+  float *sup = cap + 8 * nch;
+  for (int s = wave; s < nsup; s += kWaves) {
+    const int j0 = s * 8 * a.chunk, j1 = min(j0 + 8 * a.chunk, S);
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    bool fin = true;
+    for (int j = j0 + lane; j < j1; j += 64) {
+      const double P[3] = {a.px[j], a.py[j], a.pz[j]};
+      for (int q = 0; q < 3; ++q) {
+        fin = fin && isfinite(P[q]);
+        lo[q] = fmin(lo[q], P[q]);
+        hi[q] = fmax(hi[q], P[q]);
+      }
+    }
+    const bool finite = __ballot(!fin) == 0ull;
+    if (!finite) {  // never skipped
+      if (lane == 0) {
+        sup[s] = sup[nsup + s] = sup[2 * nsup + s] = 0.0f;
+        sup[3 * nsup + s] = __builtin_inff();
+      }
+      continue;
+    }
+    float fc[3];
+    for (int q = 0; q < 3; ++q) fc[q] = static_cast<float>(0.5 * (wave_min_f64(lo[q]) + wave_max_f64(hi[q])));
+    // the radius is taken around the STORED centre and rounded up with slack
+    double r = 0.0;
+    for (int j = j0 + lane; j < j1; j += 64) {
+      const double dx = static_cast<double>(a.px[j]) - fc[0], dy = static_cast<double>(a.py[j]) - fc[1],
+                   dz = static_cast<double>(a.pz[j]) - fc[2];
+      r = fmax(r, sqrt(dx * dx + dy * dy + dz * dz));
+    }
+    r = wave_max_f64(r);
+    if (lane == 0) {
+      const double mag = fabs(static_cast<double>(fc[0])) + fabs(static_cast<double>(fc[1])) +
+                         fabs(static_cast<double>(fc[2])) + r;
+      sup[s] = fc[0];
+      sup[nsup + s] = fc[1];
+      sup[2 * nsup + s] = fc[2];
+      sup[3 * nsup + s] = seg_round_up(r * (1.0 + 1e-6) + 1e-6 * mag + 1e-30);
+    }
+  }
+}
+
+}  // namespace kc

@@ -94,6 +94,8 @@ SIGNATURES = {
     "kc_dwa_set_shard": (C.c_int, [_vp, _sz, _sz]),
     "kc_dwa_set_scan": (C.c_int, [_vp, C.POINTER(State), _dp, _dp, _sz, C.c_float]),
     "kc_dwa_set_points": (C.c_int, [_vp, C.POINTER(State), _fp, _sz, C.c_float]),
+    "kc_dwa_set_path": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _sz, C.c_float]),
+    "kc_dwa_set_tracked_window": (C.c_int, [_vp, _sz, _sz]),
     "kc_dwa_set_grid_device": (C.c_int, [_vp, C.POINTER(State), _vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                          C.c_float]),
     "kc_dwa_set_grid_from_mapper": (C.c_int, [_vp, C.POINTER(State), _vp, C.c_float]),
@@ -298,6 +300,19 @@ class DwaContext:
         """Same, from a MapperContext: the scan may still be in flight (stream-ordered)."""
         st = State(*state)
         _check(lib().kc_dwa_set_grid_from_mapper(self.h, C.byref(st), mapper.h, float(max_sensor_range)))
+
+    def set_path(self, path_xyz, acc_at_point, total_length):
+        """The whole interpolated reference path, resident on the device (once per path)."""
+        pts = _f32(path_xyz).reshape(-1, 3)
+        x, y, z = _f32(pts[:, 0]), _f32(pts[:, 1]), _f32(pts[:, 2])
+        acc = _f32(acc_at_point)
+        assert len(acc) == len(x)
+        _check(lib().kc_dwa_set_path(self.h, _pf(x), _pf(y), _pf(z), _pf(acc), len(x),
+                                     float(np.float32(total_length))))
+
+    def set_tracked_window(self, start, size):
+        """Tracked segment = points [start, start + size) of the resident path."""
+        _check(lib().kc_dwa_set_tracked_window(self.h, int(start), int(size)))
 
     def set_tracked_segment(self, seg_xyz, acc_at_seg, ref_path_length):
         seg = _f32(seg_xyz).reshape(-1, 3)

@@ -110,3 +110,42 @@ def test_random_scene(case, seed):
             h = hip_cycle(kh, inp, None, sensor_pos, sensor_rot, ctx=ctx)
         assert_cycle_equal(o, h)
     ctx.close()
+
+
+@pytest.mark.parametrize("segk", ["straight", "arc", "wavy"])
+def test_tracked_window_of_a_resident_path(segk):
+    """kc_dwa_set_path + kc_dwa_set_tracked_window (tables built on the device)
+    == the oracle on the same window, for windows of many sizes and positions,
+    growing and shrinking, on one context."""
+    rng = np.random.default_rng(99)
+    inp = syn.make_controller_inputs("cfg1", seed=7, scale=2.0)
+    inp["P"] = 40
+    inp["points"] = _obstacles(rng, "clutter")
+    path, acc = _segment(rng, segk, 3000)
+    total = float(acc[-1]) + 0.75
+    ctx = hip_context(kh, dict(inp, seg_xyz=path[:16]), max_points=inp["P"])   # small table first: it has to grow
+    ctx.set_weights(kh.make_weights(*inp["weights"]))
+    ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
+    ctx.set_path(path, acc, total)
+    windows = [(0, 40), (0, 201), (1234, 700), (1500, 1500), (2999, 1), (2990, 10), (100, 17), (0, 3000), (777, 64)]
+    for k, (start, size) in enumerate(windows):
+        inp["state"] = (float(path[start, 0]) + float(rng.uniform(-0.3, 0.3)),
+                        float(path[start, 1]) + float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-3.1, 3.1)), 0.3)
+        inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"] = path[start:start + size], acc[start:start + size], total
+        o = oracle_cycle(inp)
+        ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+        ctx.set_tracked_window(start, size)
+        res = ctx.cycle(inp["state"], inp["P"])
+        px, py, raw, costs = ctx.get_samples(with_costs=True)
+        h = dict(px=px.copy(), py=py.copy(), raw=raw.copy(), costs=costs.copy(), res=res.as_dict())
+        if res.found:
+            h["best"] = ctx.get_best()
+        assert_cycle_equal(o, h)
+        # and the host-built tables of the same window give the same costs
+        ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+        ctx.cycle(inp["state"], inp["P"])
+        _, _, _, costs2 = ctx.get_samples(with_costs=True)
+        np.testing.assert_array_equal(costs2.view(np.uint32), costs.view(np.uint32))
+    with pytest.raises((ValueError, IndexError, RuntimeError)):
+        ctx.set_tracked_window(2990, 20)
+    ctx.close()
