@@ -4,6 +4,7 @@
 // reference's host glue (adaptive horizon, tracked segment).
 #include "utils/cost_evaluator.h"
 
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -104,8 +105,16 @@ void CostEvaluator::uploadSegment(const Path::Path *ref, const Path::Path::View 
   const size_t S = seg.getSize();
   // a view into `ref` (what the controllers pass): the path stays resident on
   // the device, only the window moves (kc_dwa_set_path once per path content)
+  // Opt-in (KOMPASS_RESIDENT_PATH=1): it takes 10 us of segment handling off the
+  // host per cycle, but the table kernel then sits in the stream in front of the
+  // cost kernel (+7 us per cycle), while the host-built tables are ready before
+  // the roll-out has finished.
+  static const bool resident = [] {
+    const char *e = std::getenv("KOMPASS_RESIDENT_PATH");
+    return e && e[0] == '1';
+  }();
   const size_t start = seg.getStartIndex();
-  if (S > 0 && start + S <= ref->getSize() && seg.getXPointer() == ref->xData() + start &&
+  if (resident && S > 0 && start + S <= ref->getSize() && seg.getXPointer() == ref->xData() + start &&
       seg.getYPointer() == ref->yData() + start && seg.getZPointer() == ref->zData() + start) {
     if (residentSerial_ != ref->serial()) {
       const size_t N = ref->getSize();

@@ -132,12 +132,6 @@ struct kc_dwa {
   // resident reference path (kc_dwa_set_path): rows x | y | z | acc on the
   // device, edge lengths on the host (the window length is an ordered float sum)
   DevBuf<float> d_path;
-  // the window kernel runs beside the roll-out on a stream of its own; the cost
-  // kernel waits for its event.  Only while no cost kernel can still read d_seg.
-  hipStream_t seg_stream = nullptr;
-  hipEvent_t seg_event = nullptr;
-  bool seg_pending = false;   // event recorded, the next cost kernel has to wait for it
-  bool cost_idle = true;      // no cost kernel queued since the host last saw a result / synchronised
   std::vector<float> path_edge;
   size_t path_n = 0;
   float path_len = 0.f;
@@ -154,8 +148,10 @@ struct kc_dwa {
   DevBuf<float> d_dc;    // cell centre -> nearest obstacle (device sensor build only)
   DevBuf<int> d_dc_enable;  // ... filled in or not (decided by sensor_build_kernel)
   bool have_dc = false;  // ... valid for the current buckets
-  bool no_dc = false;    // KC_COST_DC=0: test hook, the searches without the centre table
-  int dc_side = 64;      // KC_COST_DC=<cells along the longer side of the table>
+  // Off by default: per sensor update the table costs about what it saves in the
+  // one cycle that follows; it pays when several cycles share a sensor update.
+  bool no_dc = true;     // KC_COST_DC=<cells along the longer side of the table> turns it on
+  int dc_side = 64;
   double dc_inv_g = 0, dc_h = 0;
   int dc_W = 0, dc_H = 0;
 
@@ -216,7 +212,6 @@ int quiesce_for_update(kc_dwa *c, bool sensor_tables = true) {
     KC_HIP(hipStreamSynchronize(c->stream));
     c->update_busy = false;
     c->drained = true;
-    c->cost_idle = true;
   }
   return KC_OK;
 }
@@ -923,11 +918,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const bool use_goal = c->ref_len > 0.0f && c->w.goal_distance_weight > 0.0;
   if ((use_path || use_goal) && c->S == 0)
     KC_FAIL(KC_ERR_STATE, "tracked segment not set");
-  if (c->seg_pending) {  // tables written by segment_window_kernel on its own stream
-    KC_HIP(hipStreamWaitEvent(s, c->seg_event, 0));
-    c->seg_pending = false;
-  }
-  c->cost_idle = false;
+
   const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
   const float *seg = c->d_seg.p;
   const size_t S = c->S;
@@ -1087,7 +1078,6 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
         c->h_result.p[2] = static_cast<long long>(static_cast<int32_t>(w1 & 0xFFFFFFFFll));
         got = true;
         c->drained = true;
-        c->cost_idle = true;
         c->update_busy = false;  // queued in front of the cycle whose record just arrived
         break;
       }
@@ -1101,7 +1091,6 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
     KC_HIP(hipMemcpyAsync(c->h_result.p, c->d_result.p, 4 * sizeof(long long),
                           hipMemcpyDeviceToHost, c->stream));
     KC_HIP(hipStreamSynchronize(c->stream));
-    c->cost_idle = true;
   }
   c->timing.mark("host:wait_result");
   kc_result r{};
@@ -1250,8 +1239,10 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
     if (const char *e = std::getenv("KC_COST_DC"))
     {
-      if (e[0] == '0' && e[1] == 0) c->no_dc = true;    // test hook: searches without the centre table
-      else if (std::atoi(e) >= 8 && std::atoi(e) <= 512) c->dc_side = std::atoi(e);
+      if (std::atoi(e) >= 8 && std::atoi(e) <= 512) {
+        c->dc_side = std::atoi(e);
+        c->no_dc = false;
+      }
     }
     c->sensor_lds_ok =
         hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_build_kernel),
@@ -1283,7 +1274,6 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
 void kc_dwa_destroy(kc_dwa *c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->prm.device);
-  if (c->seg_stream) e = hipStreamSynchronize(c->seg_stream);  // before any buffer goes
   if (c->debug_stamps && c->d_dbg2.p) {
     std::vector<unsigned long long> h(512 * 16);
     e = hipDeviceSynchronize();
@@ -1378,12 +1368,6 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_seg.release();
   c->d_seg.release();
   c->d_path.release();
-  if (c->seg_stream) {
-    hipError_t se = hipStreamSynchronize(c->seg_stream);
-    se = hipStreamDestroy(c->seg_stream);
-    se = hipEventDestroy(c->seg_event);
-    (void)se;
-  }
   c->h_obs.release();
   c->h_cells.release();
   c->d_cells.release();
@@ -1680,10 +1664,6 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
   KC_TRY(quiesce_for_update(c, /*sensor_tables=*/false));
-  if (c->seg_pending) {  // a window kernel may still be writing the table
-    KC_HIP(hipEventSynchronize(c->seg_event));
-    c->seg_pending = false;
-  }
   c->S = S;
   c->ref_len = ref_len;
   if (S == 0) return KC_OK;
@@ -1814,11 +1794,8 @@ int kc_dwa_set_path(kc_dwa *c, const float *x, const float *y, const float *z, c
   KC_TRY(use_device(c));
   // the old rows may still be read by a queued window kernel
   KC_HIP(hipStreamSynchronize(c->stream));
-  if (c->seg_stream) KC_HIP(hipStreamSynchronize(c->seg_stream));
-  c->seg_pending = false;
   c->update_busy = false;
   c->drained = true;
-  c->cost_idle = true;
   c->path_n = n;
   c->path_len = total_length;
   c->path_edge.assign(n > 1 ? n - 1 : 0, 0.0f);
@@ -1860,11 +1837,8 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   const size_t seg_words = 5 * S + 8 * nch + 4 * nsup;
   if (seg_words > c->d_seg.cap) {  // growing frees the old table: nothing may still read or write it
     KC_HIP(hipStreamSynchronize(c->stream));
-    if (c->seg_stream) KC_HIP(hipStreamSynchronize(c->seg_stream));
-    c->seg_pending = false;
     c->update_busy = false;
     c->drained = true;
-    c->cost_idle = true;
     KC_TRY(c->d_seg.reserve(seg_words));
     KC_TRY(c->h_seg.reserve(seg_words));
   }
@@ -1883,29 +1857,13 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   a.nch = static_cast<int>(nch);
   a.nsup = static_cast<int>(nsup);
   a.seg = c->d_seg.p;
-  // No cost kernel in flight (the host has seen the last result): nothing reads
-  // the table, so the kernel runs on a stream of its own, beside the sensor
-  // build and the roll-out, and the next cost kernel waits for its event.
-  // Otherwise in stream order: behind the queued cost kernel, in front of the next.
-  hipStream_t ws = c->stream;
-  if (c->cost_idle) {
-    if (!c->seg_stream) {
-      KC_HIP(hipStreamCreateWithFlags(&c->seg_stream, hipStreamNonBlocking));
-      KC_HIP(hipEventCreateWithFlags(&c->seg_event, hipEventDisableTiming));
-    }
-    ws = c->seg_stream;
-  } else if (c->seg_pending) {
-    KC_HIP(hipStreamWaitEvent(c->stream, c->seg_event, 0));  // keep the two writers in order
-    c->seg_pending = false;
-  }
-  KC_TRY(c->timing.start("segment_window_kernel", ws));
-  hipLaunchKernelGGL(segment_window_kernel, dim3(1), dim3(kSegWinBlock), 0, ws, a);
-  KC_TRY(c->timing.stop(ws));
+  // stream order: behind the cost kernel of the last cycle, in front of the
+  // next (a side stream + event was measured as well: the cross-stream wait costs
+  // as much as the kernel it hides)
+  KC_TRY(c->timing.start("segment_window_kernel", c->stream));
+  hipLaunchKernelGGL(segment_window_kernel, dim3(1), dim3(kSegWinBlock), 0, c->stream, a);
+  KC_TRY(c->timing.stop(c->stream));
   KC_HIP(hipGetLastError());
-  if (ws != c->stream) {
-    KC_HIP(hipEventRecord(c->seg_event, ws));
-    c->seg_pending = true;
-  }
   return KC_OK;
 }
 

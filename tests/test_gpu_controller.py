@@ -323,6 +323,23 @@ def test_dwa_consumes_the_mapper_grid_on_the_device():
     assert cycles > 10 and blocked > 0, "the post must have cost the controller some samples"
 
 
+def test_closed_loop_with_the_resident_path(tmp_path):
+    """KOMPASS_RESIDENT_PATH=1 (read once per process, hence a child): the
+    CostEvaluator keeps the reference path on the device and moves a window; the
+    closed-loop scenarios must agree with the oracle cycle by cycle as before."""
+    import os
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, "-m", "pytest", str(root / "tests" / "test_gpu_controller.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "test_dwa_cpp_scenarios or test_dwa_reference_python_scenario",
+                        "-p", "no:cacheprovider"],
+                       env=dict(os.environ, KOMPASS_RESIDENT_PATH="1"), cwd=str(root), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "7 passed" in r.stdout, r.stdout[-500:]
+
+
 def test_collision_checker_batch_poses():
     """kc_dwa_check_poses == oracle check_at for all shapes (checkStatesFeasibility path)."""
     rng = np.random.default_rng(9)
