@@ -149,3 +149,10 @@ def test_tracked_window_of_a_resident_path(segk):
     with pytest.raises((ValueError, IndexError, RuntimeError)):
         ctx.set_tracked_window(2990, 20)
     ctx.close()
+    # no resident path yet: any non-empty window is out of range; an empty path is accepted
+    ctx2 = hip_context(kh, inp, max_points=inp["P"])
+    with pytest.raises((ValueError, IndexError, RuntimeError)):
+        ctx2.set_tracked_window(0, 1)
+    ctx2.set_path(np.zeros((0, 3), np.float32), np.zeros(0, np.float32), 0.0)
+    ctx2.set_tracked_window(0, 0)
+    ctx2.close()
