@@ -545,20 +545,18 @@ void build_host_lists(kc_dwa *c, const float *xyz, size_t n) {
   }
   c->host_lists_valid = true;
 }
-inline void ensure_host_lists(kc_dwa *c) {
-  if (c->host_lists_valid) return;
+inline int ensure_host_lists(kc_dwa *c) {
+  if (c->host_lists_valid) return KC_OK;
   if (c->raw_on_device) {
     // the list of a grid hand-off never left the device: fetch it now
     c->raw_xyz.resize(3 * c->raw_n);
-    if (hipMemcpyAsync(c->raw_xyz.data(), c->d_raw.p, 3 * c->raw_n * sizeof(float),
-                       hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) {
-      (void)hipGetLastError();
-      c->raw_xyz.clear();
-    }
+    KC_HIP(hipMemcpyAsync(c->raw_xyz.data(), c->d_raw.p, 3 * c->raw_n * sizeof(float),
+                          hipMemcpyDeviceToHost, c->stream));
+    KC_HIP(hipStreamSynchronize(c->stream));
     c->raw_on_device = false;
   }
   build_host_lists(c, c->raw_xyz.data(), c->raw_xyz.size() / 3);
+  return KC_OK;
 }
 // is there any occupied voxel column?  (after a device-side update the count is
 // not known on the host: any point may be one)
@@ -848,7 +846,7 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
 // memory: the path for windows that do not fit LDS, spheres and pose batches
 int window_bits_host(kc_dwa *c, CollDev &cd) {
   if (!cd.enabled) return KC_OK;
-  ensure_host_lists(c);
+  KC_TRY(ensure_host_lists(c));
   cd.enabled = 0;
   const size_t nwords = static_cast<size_t>(cd.H) * cd.wpr;
   KC_TRY(c->h_bits.reserve(nwords));
