@@ -311,7 +311,9 @@ int kc_mapper_scan_to_grid_bayes(kc_mapper *ctx, const double *angles, const dou
                                  size_t n, int32_t *grid_out, float *prob_out);
 int kc_mapper_scan_to_grid_bayes_device(kc_mapper *ctx, const double *angles,
                                         const double *ranges, size_t n);
-/* device addresses of gridDataProb and (optional) previousGridDataProb */
+/* device addresses of gridDataProb and (optional) previousGridDataProb; the
+ * previous grid lives in two buffers that swap on every kc_mapper_warp_previous:
+ * ask again after a warp */
 int kc_mapper_prob_device(kc_mapper *ctx, void **dev_prob_f32, void **dev_prev_f32);
 /* LocalMapper::getPreviousGridInCurrentPose (local_mapper.cpp:17-78): bilinear
  * warp of the previous probability grid, in place (stream-ordered) */
