@@ -546,8 +546,10 @@ def pointcloud_bench(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: a timed region of ~0.1 s, so that one scheduling hiccup of the (shared, CPU-quota'd)
+    # host -- a few ms -- does not move the mean by tens of percent
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
     ap.add_argument("--mapper", action="store_true", help="bench the LocalMapper (cfg4) instead")
     ap.add_argument("--bayes", action="store_true", help="with --mapper: the Bayesian mapping loop (8f rank 3)")
