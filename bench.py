@@ -300,6 +300,22 @@ def handoff_extra(ctx, inp, P, pose, med):
             "what": f"{beams}-beam scan -> {side}x{side} grid -> sensor update -> segment -> cycle"}
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup quota
+    (the GPU boxes show 256 hardware threads and allow 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(inp, vx, vy, om, state, found, cost, raw, args):
     """The oracle (a port of the reference CPU path, `kind: port`) timed on this
     host's cores on a bounded sample of the same workload, 1 thread (the
@@ -316,7 +332,7 @@ def cpu_baseline(inp, vx, vy, om, state, found, cost, raw, args):
                        np.float32(inp["max_range"]) / np.float32(3.0), inp["acc_limits"],
                        ko.make_weights(*inp["weights"]))
     P = inp["P"]
-    ncores = os.cpu_count() or 1
+    ncores = usable_cpus()
     n = len(vx)
     # full-batch parity of the last GPU cycle, all cores
     t0 = time.perf_counter()
