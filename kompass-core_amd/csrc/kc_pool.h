@@ -172,13 +172,15 @@ class WorkerPool {
     // thread got to run must still be seen (and acknowledged)
     uint64_t seen = 0;
     for (;;) {
-      // spin for up to ~2 ms of wall time, then sleep on the condition variable
+      // spin for up to ~0.5 ms of wall time (a controller at a steady rate of a
+      // few kHz finds the workers hot), then sleep on the condition variable: an
+      // idle or slow caller must not burn the CPU quota of its container
       int spins = 0;
       auto t_spin = std::chrono::steady_clock::now();
       while (gen_.load(std::memory_order_acquire) == seen) {
         cpu_relax();
         if ((++spins & 255) == 0 &&
-            std::chrono::steady_clock::now() - t_spin > std::chrono::milliseconds(2)) {
+            std::chrono::steady_clock::now() - t_spin > std::chrono::microseconds(500)) {
           std::unique_lock<std::mutex> lk(mu_);
           sleepers_.fetch_add(1, std::memory_order_acq_rel);
           cv_.wait(lk, [&] {
