@@ -21,7 +21,13 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
+# numpy's BLAS starts one thread per hardware thread it sees (256 on the GPU box, whose
+# container may use 16): that burst alone gets the process CPU-throttled for a period or two.
+# Nothing here needs a threaded BLAS.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+
+import numpy as np  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 for p in (ROOT, ROOT / "kompass-core_amd"):
