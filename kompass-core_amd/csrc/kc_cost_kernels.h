@@ -480,19 +480,32 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   const uint8_t *const skip = kLds ? l_skip : b.skip;
   const float *const obx = kObsLds ? l_obs : b.bx;
   const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
-  const float *const sg = kLds ? l_seg : a.sx;
-  const float *const sx = sg, *const sy = sg + a.S, *const sz = sg + 2 * a.S,
-              *const szz = sg + 3 * a.S, *const sacc = sg + 4 * a.S;
-  const float *const cap = sg + 5 * a.S;             // [8][nch]
-  const float *const sup = cap + 8 * a.nch;          // [4][nsup]
+  // In LDS the segment points are records (x, y, z^2, accumulated length): one
+  // 16-byte read per point instead of three reads from three rows; the
+  // capsules and spheres follow (the space of the fifth row stays unused)
+  const float4 *const l_pts = reinterpret_cast<const float4 *>(l_seg);
+  const float *const cap = kLds ? l_seg + 4 * a.S : a.sx + 5 * a.S;  // [8][nch]
+  const float *const sup = cap + 8 * a.nch;                          // [4][nsup]
+  auto seg_pt = [&](int j) -> float4 {  // (x, y, z^2, -) of segment point j
+    if (kLds) return l_pts[j];
+    return make_float4(a.sx[j], a.sy[j], a.szz[j], 0.0f);
+  };
   const bool use_dc = t.dc != nullptr && *t.enable != 0;
+  const float sz_end = (a.use_seg && a.S > 0) ? a.sz[a.S - 1] : 0.0f;  // z of the last segment point (end term)
   if (threadIdx.x == 0) {
     s_key = KEY_NONE;
     s_next = 0;
   }
   if (na > 0 && kLds) {
-#pragma unroll 8
-    for (int j = threadIdx.x; j < seg_words; j += kCostBlock) l_seg[j] = a.sx[j];
+    if (a.use_seg) {
+      float4 *const wp = reinterpret_cast<float4 *>(l_seg);
+#pragma unroll 4
+      for (int j = threadIdx.x; j < a.S; j += kCostBlock)
+        wp[j] = make_float4(a.sx[j], a.sy[j], a.szz[j], a.acc_seg[j]);
+      float *const wc = l_seg + 4 * a.S;
+      const float *const gc = a.sx + 5 * a.S;
+      for (int j = threadIdx.x; j < 8 * a.nch + 4 * a.nsup; j += kCostBlock) wc[j] = gc[j];
+    }
     if (a.use_obs) {
 #pragma unroll 8
       for (int j = threadIdx.x; j <= ncell; j += kCostBlock) l_cells[j] = b.cell_start[j];
@@ -542,11 +555,12 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
         // (1) the first point of every super-chunk: ascending index, strict `<`
         for (int s = 0; s < a.nsup; ++s) {
           const int j = s * sup_pts;
-          const float dx = sx[j] - x;
-          const float dy = sy[j] - y;
+          const float4 q = seg_pt(j);
+          const float dx = q.x - x;
+          const float dy = q.y - y;
           const float xx = dx * dx;
           const float yy = dy * dy;
-          const float dd = xx + (yy + szz[j]);  // Eigen order a + (b + c)
+          const float dd = xx + (yy + q.z);  // Eigen order a + (b + c)
           if (dd < best) {
             best = dd;
             arg = j;
@@ -572,11 +586,12 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
           for (int u = 1; u < 8; ++u) {
             const int c = s * 8 + u;
             const int j = min(c, a.nch - 1) * a.seg_chunk;  // a repeat of the last chunk changes nothing
-            const float dx = sx[j] - x;
-            const float dy = sy[j] - y;
+            const float4 q = seg_pt(j);
+            const float dx = q.x - x;
+            const float dy = q.y - y;
             const float xx = dx * dx;
             const float yy = dy * dy;
-            const float dd = xx + (yy + szz[j]);
+            const float dd = xx + (yy + q.z);
             if (dd < best || (dd == best && j < arg)) {
               best = dd;
               arg = j;
@@ -616,9 +631,10 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
               const int j = min(jb + u, j1 - 1);
-              vx[u] = sx[j];
-              vy[u] = sy[j];
-              vz[u] = szz[j];
+              const float4 q = seg_pt(j);
+              vx[u] = q.x;
+              vy[u] = q.y;
+              vz[u] = q.z;
             }
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
@@ -639,11 +655,13 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
         mind = kc::sqrt_rn(best);
         if (pp == a.P - 1) {
           // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
-          const float arc = kc::div_rn(a.ref_len - sacc[arg], a.ref_len);
+          const float acc_arg = kLds ? l_pts[arg].w : a.acc_seg[arg];
+          const float arc = kc::div_rn(a.ref_len - acc_arg, a.ref_len);
           goal_l = arc + kc::div_rn(mind, a.ref_len);
           // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
           const int e = a.S - 1;
-          const float dx = x - sx[e], dy = y - sy[e], dz = 0.0f - sz[e];
+          const float4 qe = seg_pt(e);
+          const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
           const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
           end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
         }
