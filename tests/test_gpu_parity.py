@@ -384,6 +384,43 @@ np.savez({str(out)!r}, **res)
         assert int(got[f"{k}_idx"]) == h["res"]["index"]
 
 
+def test_contexts_side_by_side_and_from_two_threads():
+    """Two controller contexts, a mapper and a cloud context in one process:
+    interleaved from one thread, then driven from two threads at once (the
+    worker pool of the host trig table is shared and serialises its jobs).
+    Every cycle must equal the oracle's, whatever ran in between."""
+    import threading
+    inps = [_path_scenario(*_PATH_SCENARIOS[1]), _path_scenario(*_PATH_SCENARIOS[5])]
+    want = [oracle_cycle(i) for i in inps]
+    ctxs = [hip_context(kh, i) for i in inps]
+    m = kh.MapperContext(200, 200, 0.05, (0, 0, 0), 0.0, 512)
+    ang, rng = syn.dense_scan(512, 0.5)
+    grid_want = ko.scan_to_grid(200, 200, 0.05, (0, 0, 0), 0.0, ang, rng)
+    for rep in range(3):
+        for k in (0, 1, 1, 0):
+            m.scan_to_grid_device(ang, rng)
+            assert_cycle_equal(want[k], hip_cycle(kh, inps[k], ctx=ctxs[k]))
+        np.testing.assert_array_equal(m.scan_to_grid(ang, rng), grid_want)
+    errors = []
+
+    def drive(k):
+        try:
+            for rep in range(20):
+                assert_cycle_equal(want[k], hip_cycle(kh, inps[k], ctx=ctxs[k]))
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for c in ctxs:
+        c.close()
+    m.close()
+
+
 def test_publish_result_hands_over_the_device_record():
     """Multi-GPU hand-off: rollout + evaluate, (all-reduce by the caller on the
     device record), kc_dwa_publish_result, kc_dwa_fetch_result -- without an
