@@ -202,6 +202,7 @@ constexpr int kTileThreads = 256;
 constexpr int kChunkSteps = 16;  // steps one lane walks: the closed-form start costs a division
 constexpr int kMaxChunks = (kTileI + 2 + kChunkSteps - 1) / kChunkSteps + 1;
 constexpr int kRoundBeams = 2 * kTileThreads;  // beams tested between two barriers
+constexpr int kNearSlices = 64;                // beam slices that share a near-field tile
 
 __global__ void beam_ends_kernel(MapGeom g, const float *__restrict__ ranges,
                                  const double2 *__restrict__ trig, int n, int2 *__restrict__ ends) {
@@ -687,7 +688,7 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
     const int ja = std::max(m->g.s1 - kNearSteps - 1, 0), jb = std::min(m->g.s1 + kNearSteps + 1, m->g.W - 1);
     if (ia <= ib && ja <= jb) {
       const int ti0 = ia / kTileI, tj0 = ja / kTileJ;
-      const dim3 ngrid(ib / kTileI - ti0 + 1, jb / kTileJ - tj0 + 1, std::min(32, std::max(1, ni / 64)));
+      const dim3 ngrid(ib / kTileI - ti0 + 1, jb / kTileJ - tj0 + 1, std::min(kNearSlices, std::max(1, ni / 32)));
       hipLaunchKernelGGL(near_tiles_kernel, ngrid, dim3(kTileThreads), 0, s, m->g, m->d_ends.p, ni,
                          m->d_grid.p, m->d_last.p, hb, ti0, tj0);
     }
