@@ -204,10 +204,24 @@ constexpr int kMaxChunks = (kTileI + 2 + kChunkSteps - 1) / kChunkSteps + 1;
 constexpr int kRoundBeams = 2 * kTileThreads;  // beams tested between two barriers
 constexpr int kNearSlices = 64;                // beam slices that share a near-field tile
 
+// direction sector (of 64) of the cell offset (dx, dy) from the start cell: a
+// cheap first cut of the beam x tile tests -- a line can only reach a tile whose
+// angular span, seen from the start cell, holds the line's direction
+__device__ __forceinline__ int sector_of_angle(float a) {
+  const int s = static_cast<int>((a + 3.14159265358979f) * (64.0f / 6.28318530717959f));
+  return min(max(s, 0), 63);
+}
+
+// ends[b] = end cell of beam b; behind the n end cells, one byte per beam: its sector
 __global__ void beam_ends_kernel(MapGeom g, const float *__restrict__ ranges,
                                  const double2 *__restrict__ trig, int n, int2 *__restrict__ ends) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n) ends[b] = beam_endpoint(g, ranges[b], trig[b]);
+  if (b < n) {
+    const int2 t = beam_endpoint(g, ranges[b], trig[b]);
+    ends[b] = t;
+    reinterpret_cast<uint8_t *>(ends + n)[b] = static_cast<uint8_t>(
+        sector_of_angle(atan2f(static_cast<float>(t.y - g.s1), static_cast<float>(t.x - g.s0))));
+  }
 }
 
 struct TileTask {
@@ -255,13 +269,44 @@ __device__ __forceinline__ long long minor_after(const BeamLine &l, int i) {
 // tests one beam and queues the crossing part of its line in chunks of
 // kChunkSteps steps, then the threads share the chunks.
 template <bool kBayes>
-__device__ void tile_accumulate(const MapGeom &g, const int2 *__restrict__ ends, int b_begin,
-                                int b_end, int step_min, int step_max, int I0, int I1, int J0,
-                                int J1, TileLds &L) {
+__device__ void tile_accumulate(const MapGeom &g, const int2 *__restrict__ ends, int n_all,
+                                int b_begin, int b_end, int step_min, int step_max, int I0, int I1,
+                                int J0, int J1, TileLds &L) {
   // tile centre relative to the start cell, half extents + 3 cells: a stamped
   // cell lies within two cells of the ideal line
   const double ci = 0.5 * (I0 + I1) - g.s0, cj = 0.5 * (J0 + J1) - g.s1;
   const double hi = 0.5 * (I1 - I0) + 3.0, hj = 0.5 * (J1 - J0) + 3.0;
+  // sectors the tile (grown by the same three cells) spans as seen from the
+  // start cell, one more on either side; all of them when the start lies inside
+  unsigned long long smask = ~0ull;
+  if (fabs(ci) > hi || fabs(cj) > hj) {
+    const float ax[4] = {static_cast<float>(ci - hi), static_cast<float>(ci + hi), static_cast<float>(ci - hi),
+                         static_cast<float>(ci + hi)};
+    const float ay[4] = {static_cast<float>(cj - hj), static_cast<float>(cj - hj), static_cast<float>(cj + hj),
+                         static_cast<float>(cj + hj)};
+    const float a0 = atan2f(ay[0], ax[0]);
+    float lo = 0.0f, up = 0.0f;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      float dd = atan2f(ay[q], ax[q]) - a0;
+      if (dd > 3.14159265358979f) dd -= 6.28318530717959f;
+      if (dd <= -3.14159265358979f) dd += 6.28318530717959f;
+      lo = fminf(lo, dd);
+      up = fmaxf(up, dd);
+    }
+    auto wrap = [](float a) {
+      if (a > 3.14159265358979f) a -= 6.28318530717959f;
+      if (a < -3.14159265358979f) a += 6.28318530717959f;
+      return a;
+    };
+    const int s_lo = sector_of_angle(wrap(a0 + lo)), s_up = sector_of_angle(wrap(a0 + up));
+    const int cnt = ((s_up - s_lo) & 63) + 3;  // the span plus one sector on either side
+    smask = 0ull;
+    if (cnt >= 64) smask = ~0ull;
+    else
+      for (int q = 0; q < cnt; ++q) smask |= 1ull << ((s_lo - 1 + q) & 63);
+  }
+  const uint8_t *const sect = reinterpret_cast<const uint8_t *>(ends + n_all);
   // the workgroups of a launch start at different rounds: all of them reading the
   // same two kilobytes of end cells at the same time is an L2 hot spot
   const int nrounds = (b_end - b_begin + kRoundBeams - 1) / kRoundBeams;
@@ -274,6 +319,7 @@ __device__ void tile_accumulate(const MapGeom &g, const int2 *__restrict__ ends,
     for (int u = 0; u < kRoundBeams / kTileThreads; ++u) {
       const int b = base + u * kTileThreads + static_cast<int>(threadIdx.x);
       if (b >= b_end) continue;
+      if (!((smask >> sect[b]) & 1ull)) continue;
       const int2 t = ends[b];
       const int dx = t.x - g.s0, dy = t.y - g.s1;
       const double cross = static_cast<double>(dx) * cj - static_cast<double>(dy) * ci;
@@ -371,7 +417,7 @@ __global__ __launch_bounds__(kTileThreads) void scan_tiles_kernel(
   const int I0 = blockIdx.x * kTileI, J0 = blockIdx.y * kTileJ;
   const int I1 = min(I0 + kTileI, g.H) - 1, J1 = min(J0 + kTileJ, g.W) - 1;
   for (int t = threadIdx.x; t < kTileI * kTileJ; t += kTileThreads) L.cell[t] = 0u;
-  tile_accumulate<kBayes>(g, ends, 0, n, kNearSteps + 1, INT_MAX, I0, I1, J0, J1, L);
+  tile_accumulate<kBayes>(g, ends, n, 0, n, kNearSteps + 1, INT_MAX, I0, I1, J0, J1, L);
   for (int t = threadIdx.x; t < kTileI * kTileJ; t += kTileThreads) {
     const int i = I0 + (t & (kTileI - 1)), j = J0 + t / kTileI;
     if (i <= I1 && j <= J1) {
@@ -399,7 +445,7 @@ __global__ __launch_bounds__(kTileThreads) void near_tiles_kernel(
   const int b_begin = static_cast<int>(blockIdx.z) * per, b_end = min(b_begin + per, n);
   if (b_begin >= b_end) return;
   for (int t = threadIdx.x; t < kTileI * kTileJ; t += kTileThreads) L.cell[t] = 0u;
-  tile_accumulate<true>(g, ends, b_begin, b_end, 1, kNearSteps, I0, I1, J0, J1, L);
+  tile_accumulate<true>(g, ends, n, b_begin, b_end, 1, kNearSteps, I0, I1, J0, J1, L);
   // the first emitted point of every beam is the start cell
   if (threadIdx.x == 0 && g.s0 >= I0 && g.s0 <= I1 && g.s1 >= J0 && g.s1 <= J1)
     atomicMax(&L.cell[(g.s0 - I0) + (g.s1 - J0) * kTileI], static_cast<unsigned int>(b_end));
@@ -654,7 +700,7 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   const int hb = (m->g.H + 3) / 4;
   int step_limit = INT_MAX;
   if (m->tiles) {
-    KC_TRY(m->d_ends.reserve(n));
+    KC_TRY(m->d_ends.reserve(n + n / 8 + 2));  // end cells + one sector byte per beam
     KC_TRY(m->timing.start("beam_ends_kernel", s));
     hipLaunchKernelGGL(beam_ends_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, m->g,
                        m->d_ranges.p, m->d_trig.p, ni, m->d_ends.p);
@@ -673,7 +719,7 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   const bool hybrid = bayes && m->tile_mode == 3;
   if (hybrid) {
     // far field: beam-parallel, a global atomic per stamp (few beams share a far cell)
-    KC_TRY(m->d_ends.reserve(n));
+    KC_TRY(m->d_ends.reserve(n + n / 8 + 2));  // end cells + one sector byte per beam
     hipLaunchKernelGGL(beam_ends_kernel, dim3((ni + 255) / 256), dim3(256), 0, s, m->g,
                        m->d_ranges.p, m->d_trig.p, ni, m->d_ends.p);
     KC_TRY(m->timing.start("rays_kernel", s));

@@ -217,3 +217,32 @@ def test_mapping_loop_with_feedback():
         o.set_previous(want_p)
         m.set_previous_prob(None)
     np.testing.assert_array_equal(_bits(m.previous_prob()), _bits(o.previous()))
+
+
+@pytest.mark.gpu
+def test_bayes_random_scenes():
+    """Random grids, sensor poses (also outside the grid), beam sets (ordered and not) and ranges through
+    the tiled Bayesian scan, against the oracle."""
+    import kompass_hip as kh
+    r = np.random.default_rng(4242)
+    for case in range(30):
+        H, W = int(r.integers(3, 500)), int(r.integers(3, 500))
+        res = float(r.choice([0.02, 0.05, 0.1, 0.25]))
+        ext = min(H, W) * res
+        pos = (float(r.uniform(-0.6, 0.6) * ext), float(r.uniform(-0.6, 0.6) * ext), 0.0)
+        orient = float(r.uniform(-3.2, 3.2))
+        n = int(r.choice([1, 3, 64, 360, 1500, 4000]))
+        ang = np.sort(r.uniform(-np.pi, np.pi, n)) if case % 3 else r.uniform(-7, 7, n)
+        rng = r.uniform(0, 1.2 * ext, n) * r.choice([1.0, 1.0, 1.0, 0.0, 12.0], n)
+        params = BENCH if case % 2 else DEFAULT
+        o = ko.BayesMapper(H, W, res, pos, orient, **params)
+        m = kh.MapperContext(H, W, res, pos, orient, n)
+        m.enable_bayes(**params)
+        prev = r.uniform(0.02, 0.98, (H, W)).astype(np.float32)
+        o.set_previous(prev)
+        m.set_previous_prob(prev)
+        want_g, want_p = o.scan_to_grid_baysian(ang, rng)
+        got_g, got_p = m.scan_to_grid_baysian(ang, rng)
+        assert np.array_equal(got_g, want_g), (case, H, W, res, pos, orient, n, int((got_g != want_g).sum()))
+        assert np.array_equal(_bits(got_p), _bits(want_p)), (case, H, W, res, pos, orient, n)
+        m.close()

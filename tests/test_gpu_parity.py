@@ -246,10 +246,13 @@ def test_mapper_fixture_scan():
     assert (want == 100).sum() > 0
 
 
-def test_mapper_random_scenes():
-    """Random geometry, sensor pose and ranges (some zero, some far beyond the grid), one beam to thousands."""
-    r = np.random.default_rng(77)
-    for case in range(24):
+@pytest.mark.parametrize("tiles", ["1", "2"])
+def test_mapper_random_scenes(tiles, monkeypatch):
+    """Random geometry, sensor pose and ranges (some zero, some far beyond the grid), one beam to thousands;
+    beam-parallel passes (default for plain scans) and the tiled scan."""
+    monkeypatch.setenv("KC_MAPPER_TILES", tiles)
+    r = np.random.default_rng(77 + int(tiles))
+    for case in range(40):
         H, W = int(r.integers(3, 700)), int(r.integers(3, 700))
         res = float(r.choice([0.02, 0.05, 0.1, 0.25]))
         ext = min(H, W) * res
