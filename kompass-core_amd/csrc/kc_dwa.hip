@@ -61,7 +61,6 @@ struct kc_dwa {
   PinBuf<long long> h_gridrec;  // {seq, count, imin, imax, jmin, jmax}
   long long grid_seq = 0;
   hipEvent_t grid_ready = nullptr;  // mapper stream -> this stream
-  DevBuf<float4> d_sensor_tmp;
   bool device_sensor = true;            // KC_SENSOR_HOST=1 turns the device-side update off
   bool sensor_lds_ok = false;
   std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
@@ -651,7 +650,6 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   KC_TRY(c->d_skip.reserve(ncell + 4));
   KC_TRY(c->d_bobs.reserve(2 * n));
   KC_TRY(c->d_raw.reserve(3 * n));
-  KC_TRY(c->d_sensor_tmp.reserve(n));
   // the raw points: host copy for the lazy lists, device copy through the BAR
   c->host_lists_valid = false;
   if (xyz) {
@@ -689,7 +687,6 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   a.skip = c->d_skip.p;
   a.bx = c->d_bobs.p;
   a.by = c->d_bobs.p + n;
-  a.tmp = c->d_sensor_tmp.p;
   a.obs_z_zero = c->raw_is_scan ? 1 : 0;
   KC_TRY(c->d_dc_enable.reserve(1));
   a.dc_enable = c->d_dc_enable.p;
@@ -1355,7 +1352,6 @@ void kc_dwa_destroy(kc_dwa *c) {
     hipError_t ge = hipEventDestroy(c->grid_ready);
     (void)ge;
   }
-  c->d_sensor_tmp.release();
   c->d_perm.release();
   c->d_pvx.release();
   c->d_pvy.release();

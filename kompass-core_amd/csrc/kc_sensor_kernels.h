@@ -25,7 +25,6 @@ struct SensorArgs {
   int *cell_start;           // [W*H + 1]
   uint8_t *skip;             // [W*H] (+ padding written by the host)
   float *bx, *by;            // cell-ordered coordinates
-  float4 *tmp;               // [n] (ox, oy, cell id, rank inside the cell) between the two passes
   int obs_z_zero;            // laserscan: the obstacle of a point is taken at z = 0
   int *dc_enable;            // out: 1 when fewer than a third of the bucket cells hold a point (the
                              // centre-distance table pays only where trajectory points have empty
@@ -63,28 +62,54 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
   if (tid == 0) s_nonempty = 0;
   __syncthreads();
   // ---- 1: voxel bits + bucket counts ----------------------------------------
-  for (int i = tid; i < a.n; i += kSensorBlock) {
-    const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-    // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
-    const double fx = floor(a.inv_res * static_cast<double>(x));
-    const double fy = floor(a.inv_res * static_cast<double>(y));
-    const double fz = floor(a.inv_res * static_cast<double>(z));
-    if (fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0) {
-      const int kz = static_cast<int>(fz);
-      const double zlo = static_cast<double>(kz) * a.res;
-      const double zhi = static_cast<double>(kz + 1) * a.res;
-      if (zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height) {
-        const int cx = static_cast<int>(fx) - a.gkx0, cy = static_cast<int>(fy) - a.gky0;
-        if (cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr)
-          atomicOr(&lbits[cy * a.gwpr + (cx >> 5)], 1u << (cx & 31));
+  // A thread keeps the records of its points (<= 16: the host sends at most
+  // 16 k points here) in registers until the scatter of step 4 -- transformed
+  // coordinates and (cell id | rank in the cell << 12) -- and loads the raw
+  // points eight at a time, so that their latencies overlap.
+  constexpr int kPer = 16;
+  float rox[kPer], roy[kPer];
+  int rcell[kPer];
+#pragma unroll
+  for (int h = 0; h < kPer / 8; ++h) {
+    float qx[8], qy[8], qz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = tid + (h * 8 + u) * kSensorBlock;
+      const int j = i < a.n ? i : 0;  // idle slots shadow point 0, used for nothing
+      qx[u] = a.xyz[3 * j];
+      qy[u] = a.xyz[3 * j + 1];
+      qz[u] = a.xyz[3 * j + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = h * 8 + u;
+      const int i = tid + k * kSensorBlock;
+      rcell[k] = -1;
+      rox[k] = roy[k] = 0.0f;
+      if (i >= a.n) continue;
+      const float x = qx[u], y = qy[u], z = qz[u];
+      // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
+      const double fx = floor(a.inv_res * static_cast<double>(x));
+      const double fy = floor(a.inv_res * static_cast<double>(y));
+      const double fz = floor(a.inv_res * static_cast<double>(z));
+      if (fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0) {
+        const int kz = static_cast<int>(fz);
+        const double zlo = static_cast<double>(kz) * a.res;
+        const double zhi = static_cast<double>(kz + 1) * a.res;
+        if (zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height) {
+          const int cx = static_cast<int>(fx) - a.gkx0, cy = static_cast<int>(fy) - a.gky0;
+          if (cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr)
+            atomicOr(&lbits[cy * a.gwpr + (cx >> 5)], 1u << (cx & 31));
+        }
+      }
+      float ox, oy;
+      int id;
+      if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id)) {
+        rox[k] = ox;
+        roy[k] = oy;
+        rcell[k] = id | (atomicAdd(&lstart[id + 1], 1) << 12);  // id < 4096 cells, rank < 16384
       }
     }
-    float ox, oy;
-    int id;
-    float4 rec = make_float4(0.f, 0.f, __int_as_float(-1), 0.f);
-    if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id))
-      rec = make_float4(ox, oy, __int_as_float(id), __int_as_float(atomicAdd(&lstart[id + 1], 1)));
-    a.tmp[i] = rec;
   }
   __syncthreads();
   // ---- 2: cell starts.  The count of cell k sits in slot k + 1 (slot 0 is 0), so
@@ -163,13 +188,12 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
   }
   if (tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
   // ---- 4: scatter the coordinates into their cells (start + rank) --------------
-  for (int i = tid; i < a.n; i += kSensorBlock) {
-    const float4 rec = a.tmp[i];
-    const int id = __float_as_int(rec.z);
-    if (id >= 0) {
-      const int pos = lstart[id] + __float_as_int(rec.w);
-      a.bx[pos] = rec.x;
-      a.by[pos] = rec.y;
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    if (rcell[k] >= 0) {
+      const int pos = lstart[rcell[k] & 4095] + (rcell[k] >> 12);
+      a.bx[pos] = rox[k];
+      a.by[pos] = roy[k];
     }
   }
   // ---- 5: the bitmap --------------------------------------------------------------
