@@ -578,7 +578,59 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
     return KC_OK;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   size_t nfin = 0;
-  for (size_t i = 0; i < n; ++i) {
+  bool bounded = false;
+#if defined(__x86_64__)
+  // This pass sits on the critical path of a sensor update (nothing is launched
+  // before the bounds are known): four points per step with SSE min / max;
+  // any non-finite coordinate (v - v != 0) sends the whole list to the loop below.
+  {
+    typedef float v4 __attribute__((vector_size(16)));
+    typedef int v4i __attribute__((vector_size(16)));
+    const v4 big = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX}, zero = {0.f, 0.f, 0.f, 0.f};
+    v4 mn[3] = {big, big, big}, mx[3] = {-big, -big, -big};
+    v4i ok = {-1, -1, -1, -1};
+    const size_t total = 3 * n;
+    size_t i = 0;
+    for (; i + 12 <= total; i += 12) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        v4 v;
+        std::memcpy(&v, xyz + i + 4 * q, sizeof(v));
+        mn[q] = __builtin_ia32_minps(mn[q], v);
+        mx[q] = __builtin_ia32_maxps(mx[q], v);
+        const v4 dv = v - v;
+        ok &= (dv == zero);
+      }
+    }
+    if ((ok[0] & ok[1] & ok[2] & ok[3]) != 0) {
+      // lanes: v0 = x0 y0 z0 x1 | v1 = y1 z1 x2 y2 | v2 = z2 x3 y3 z3
+      static const int vec_of[3][4] = {{0, 0, 1, 2}, {0, 1, 1, 2}, {0, 1, 2, 2}};
+      static const int lane_of[3][4] = {{0, 3, 2, 1}, {1, 0, 3, 2}, {2, 1, 0, 3}};
+      for (int a = 0; a < 3; ++a)
+        for (int q = 0; q < 4; ++q) {
+          lo[a] = std::min(lo[a], mn[vec_of[a][q]][lane_of[a][q]]);
+          hi[a] = std::max(hi[a], mx[vec_of[a][q]][lane_of[a][q]]);
+        }
+      bool tail_ok = true;
+      for (; i < total; ++i) {  // fewer than four points
+        const float v = xyz[i];
+        tail_ok = tail_ok && std::isfinite(v);
+        lo[i % 3] = std::min(lo[i % 3], v);
+        hi[i % 3] = std::max(hi[i % 3], v);
+      }
+      if (tail_ok) {
+        bounded = true;
+        nfin = n;
+      } else {
+        for (int a = 0; a < 3; ++a) {
+          lo[a] = FLT_MAX;
+          hi[a] = -FLT_MAX;
+        }
+      }
+    }
+  }
+#endif
+  for (size_t i = 0; i < n && !bounded; ++i) {
     const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
     if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(z))) continue;
     lo[0] = std::min(lo[0], x);

@@ -387,6 +387,27 @@ np.savez({str(out)!r}, **res)
         assert int(got[f"{k}_idx"]) == h["res"]["index"]
 
 
+@pytest.mark.parametrize("where", ["body", "tail", "none"])
+def test_point_list_with_non_finite_entries(where):
+    """NaN / inf coordinates in a point list: dropped by the octree (add_voxel) and never the nearest
+    obstacle, on the device builder as in the oracle -- also when they sit in the last points of the
+    list (the vectorised bounds pass of the host treats the tail separately)."""
+    inp = syn.make_controller_inputs("cfg2", seed=6, scale=0.25)
+    pts = np.asarray(inp["points"], np.float32).reshape(-1, 3).copy()
+    pts = pts[: len(pts) - (len(pts) % 4) + 2]          # a tail of two points behind the groups of four
+    if where == "body":
+        pts[10, 0] = np.nan
+        pts[501, 1] = np.inf
+        pts[999, 2] = -np.inf
+    elif where == "tail":
+        pts[-1, 1] = np.nan
+    inp["points"] = pts
+    o = oracle_cycle(inp)
+    h = hip_cycle(kh, inp)
+    assert len(o["raw"]) > 0
+    assert_cycle_equal(o, h)
+
+
 def test_contexts_side_by_side_and_from_two_threads():
     """Two controller contexts, a mapper and a cloud context in one process:
     interleaved from one thread, then driven from two threads at once (the
