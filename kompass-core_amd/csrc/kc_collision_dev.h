@@ -62,6 +62,11 @@ struct RollArgs {
   long long *dev_err;   // set when the wait gives up (host never delivered)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
   CollDev c;
+  // c.dil == 2: the first cycle after a sensor update dilates its window itself
+  // (dilate_kernel then runs behind that cycle, for the following ones): run
+  // half-widths of the two discs per row offset, win[0..R] | wout[0..R], and R
+  const signed char *diltab;
+  int dilR;
 };
 
 // Phase clocks for kernel tuning: compiled in only with -DKC_PHASE_STAMPS (the

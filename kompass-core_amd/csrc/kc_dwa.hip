@@ -72,6 +72,11 @@ struct kc_dwa {
   size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
   DevBuf<long long> d_block_keys;       // per-workgroup best keys of the cost kernel
   DevBuf<uint32_t> d_ginner, d_gouter;  // dilated sensor bitmaps
+  DevBuf<signed char> d_diltab;         // disc run tables for the roll-out that dilates its own window
+  int dil_R = 0;
+  bool dil_lazy = false;                // the masks of the current bitmap are not built yet
+  int dil_uses = 0;                     // roll-outs that dilated their own window since the update
+  bool lazy_dilate = true;              // KC_LAZY_DILATE=0: dilate_kernel inside every sensor update
   bool have_dil = false;
   DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
   DevBuf<double> d_pvx, d_pvy;          // sample velocities / trig rows in d_perm order
@@ -289,8 +294,12 @@ int bitmap_extent(kc_dwa *c, int lox, int loy, int hix, int hiy, bool *fits) {
   return KC_OK;
 }
 
+// run half-widths of the two discs per row offset (see DilArgs)
+void dil_tables(const DilGeom &dg, signed char win[kMaxDil + 1], signed char wout[kMaxDil + 1]);
+
 // the two dilated masks from the bitmap in d_gbits
 int launch_dilate(kc_dwa *c) {
+  c->dil_lazy = false;
   if (!c->have_dil) return KC_OK;
   const DilGeom dg = dil_geom(c);
   const size_t nwords = static_cast<size_t>(c->gH) * c->gwpr;
@@ -301,25 +310,7 @@ int launch_dilate(kc_dwa *c) {
   da.H = c->gH;
   da.wpr = c->gwpr;
   da.R = dg.R;
-  for (int j = 0; j <= kMaxDil; ++j) {
-    da.win[j] = da.wout[j] = -1;
-    if (j > dg.R) continue;
-    // inner: largest i with hypot(i, j) <= rho_in - 1e-6
-    const double ri = dg.rho_in - 1e-6;
-    if (ri >= 0.0 && static_cast<double>(j) <= ri) {
-      int i = static_cast<int>(std::floor(std::sqrt(ri * ri - static_cast<double>(j) * j)));
-      while (i >= 0 && std::hypot(static_cast<double>(i), static_cast<double>(j)) > ri) --i;
-      da.win[j] = static_cast<signed char>(std::min(i, 31));
-    }
-    // outer: largest i with hypot((i-1)+, (j-1)+) <= rho_out + 1e-6
-    const double ro = dg.rho_out + 1e-6;
-    const double jj = std::max(j - 1, 0);
-    if (jj <= ro) {
-      int i = static_cast<int>(std::floor(std::sqrt(ro * ro - jj * jj))) + 2;
-      while (i > 0 && std::hypot(static_cast<double>(std::max(i - 1, 0)), jj) > ro) --i;
-      da.wout[j] = static_cast<signed char>(std::min(i, 31));
-    }
-  }
+  dil_tables(dg, da.win, da.wout);
   const unsigned nb = static_cast<unsigned>((nwords + 255) / 256);
   KC_TRY(c->timing.start("dilate_kernel", c->stream));
   hipLaunchKernelGGL(dilate_kernel, dim3(nb), dim3(256), 0, c->stream, da);
@@ -329,11 +320,53 @@ int launch_dilate(kc_dwa *c) {
   return KC_OK;
 }
 
+// A sensor update does not queue dilate_kernel itself: the first roll-out that
+// follows dilates its own window in LDS (RollArgs::diltab); the kernel runs
+// only if a second cycle comes on the same data.  This writes the table the
+// roll-out reads and marks the masks as not built yet.
+int defer_dilate(kc_dwa *c) {
+  if (!c->have_dil || !c->lazy_dilate || !c->trig_direct) return launch_dilate(c);
+  const DilGeom dg = dil_geom(c);
+  signed char tab[2 * (kMaxDil + 1)];
+  dil_tables(dg, tab, tab + kMaxDil + 1);
+  KC_TRY(c->d_diltab.reserve(sizeof(tab)));
+  std::memcpy(c->d_diltab.p, tab, sizeof(tab));  // over the BAR, like the other per-update tables
+  c->bar_dirty = true;
+  bar_flush(c);
+  c->dil_R = dg.R;
+  c->dil_lazy = true;
+  c->dil_uses = 0;
+  return KC_OK;
+}
+
+void dil_tables(const DilGeom &dg, signed char win[kMaxDil + 1], signed char wout[kMaxDil + 1]) {
+  for (int j = 0; j <= kMaxDil; ++j) {
+    win[j] = wout[j] = -1;
+    if (j > dg.R) continue;
+    // inner: largest i with hypot(i, j) <= rho_in - 1e-6
+    const double ri = dg.rho_in - 1e-6;
+    if (ri >= 0.0 && static_cast<double>(j) <= ri) {
+      int i = static_cast<int>(std::floor(std::sqrt(ri * ri - static_cast<double>(j) * j)));
+      while (i >= 0 && std::hypot(static_cast<double>(i), static_cast<double>(j)) > ri) --i;
+      win[j] = static_cast<signed char>(std::min(i, 31));
+    }
+    // outer: largest i with hypot((i-1)+, (j-1)+) <= rho_out + 1e-6
+    const double ro = dg.rho_out + 1e-6;
+    const double jj = std::max(j - 1, 0);
+    if (jj <= ro) {
+      int i = static_cast<int>(std::floor(std::sqrt(ro * ro - jj * jj))) + 2;
+      while (i > 0 && std::hypot(static_cast<double>(std::max(i - 1, 0)), jj) > ro) --i;
+      wout[j] = static_cast<signed char>(std::min(i, 31));
+    }
+  }
+}
+
 // occupancy bits of the accepted voxel columns over their bounding box ->
 // device, once per sensor update (the fused roll-out kernel copies its
 // reachable window out of it)
 int upload_voxels(kc_dwa *c) {
   c->have_gbits = false;
+  c->dil_lazy = false;
   const size_t nv = c->vox_kx.size();
   if (nv == 0) return KC_OK;
   int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN;
@@ -355,8 +388,8 @@ int upload_voxels(kc_dwa *c) {
   }
   KC_TRY(upload_table(c, c->d_gbits.p, c->h_gbits.p, nwords * sizeof(uint32_t)));
   if (!c->trig_direct) c->update_busy = true;
-  bar_flush(c);  // the kernel below reads the bitmap
-  KC_TRY(launch_dilate(c));
+  bar_flush(c);  // the kernels behind it read the bitmap
+  KC_TRY(defer_dilate(c));
   c->have_gbits = true;
   return KC_OK;
 }
@@ -664,6 +697,8 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   const size_t nwords = fits ? static_cast<size_t>(c->gH) * c->gwpr : 0;
   if (!fits || nwords * sizeof(uint32_t) > 64 * 1024) {
     c->have_gbits = false;
+    c->dil_lazy = false;
+  c->dil_lazy = false;
     return KC_OK;
   }
   // bucket grid: covers the image of the bounding box (an affine map takes the
@@ -782,7 +817,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     c->dc_H = da.Hd;
     c->have_dc = true;
   }
-  KC_TRY(launch_dilate(c));
+  KC_TRY(defer_dilate(c));
   c->have_gbits = true;
   b.skip = c->d_skip.p;
   b.cell_start = c->d_cells.p;
@@ -880,7 +915,7 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
     cd.gbits = c->d_gbits.p;
     cd.ginner = c->d_ginner.p;
     cd.gouter = c->d_gouter.p;
-    cd.dil = c->have_dil ? 1 : 0;
+    cd.dil = c->have_dil ? (c->dil_lazy ? 2 : 1) : 0;
     cd.gkx0 = c->gkx0;
     cd.gky0 = c->gky0;
     cd.gH = c->gH;
@@ -1284,6 +1319,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
+    if (const char *e = std::getenv("KC_LAZY_DILATE"))
+      if (e[0] == '0') c->lazy_dilate = false;          // test hook: dilate_kernel inside every sensor update
     if (const char *e = std::getenv("KC_COST_DC"))
     {
       if (std::atoi(e) >= 8 && std::atoi(e) <= 512) {
@@ -1425,6 +1462,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_block_keys.release();
   c->d_gbits.release();
   c->d_ginner.release();
+  c->d_diltab.release();
   c->d_gouter.release();
   c->d_adm.release();
   c->d_pos.release();
@@ -1766,9 +1804,10 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
         double t = (q[0] * ab[0] + q[1] * ab[1] + q[2] * ab[2]) * static_cast<double>(inv);
         t = std::min(std::max(t, 0.0), 1.0);
         const double e[3] = {q[0] - t * ab[0], q[1] - t * ab[1], q[2] - t * ab[2]};
-        eps = std::max(eps, std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
+        eps = std::max(eps, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);  // squared: one sqrt per chunk
         mag = std::max(mag, std::fabs(P[0]) + std::fabs(P[1]) + std::fabs(P[2]));
       }
+      eps = std::sqrt(eps);  // sqrt is monotonic and correctly rounded: max of the roots
       cap[k] = static_cast<float>(A[0]);
       cap[nch + k] = static_cast<float>(A[1]);
       cap[2 * nch + k] = static_cast<float>(A[2]);
@@ -1809,8 +1848,9 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
         double P[3];
         pt(j, P);
         const double dx = P[0] - fc[0], dy = P[1] - fc[1], dz = P[2] - fc[2];
-        r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
+        r = std::max(r, dx * dx + dy * dy + dz * dz);
       }
+      r = std::sqrt(r);
       const double mag = std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]) + r;
       sup[s] = fc[0];
       sup[nsup + s] = fc[1];
@@ -1998,9 +2038,27 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
   const int fs = c->fused_samples, fb = c->fused_block;
   const size_t pos_bytes = static_cast<size_t>(fs) * (P | 1) * sizeof(double2);
-  const size_t bits_bytes =
+  size_t bits_bytes =
       (a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 * (a.c.dil ? 3 : 1) : 0) +
       static_cast<size_t>(fs) * P * sizeof(int);  // + queue of undecided poses
+  if (a.c.enabled && a.c.dil == 2) {
+    // The first cycle on new sensor data dilates its own window from the raw
+    // bits + halo (a controller that gets new data every cycle never runs
+    // dilate_kernel at all); a second cycle on the same data builds the masks
+    // once, and so does a window that does not fit with its halo.
+    const size_t halo = static_cast<size_t>(a.c.H + 2 * c->dil_R) * (a.c.wpr + 2) * 4;
+    if (c->dil_uses++ == 0 && c->prm.shape != KC_SPHERE &&
+        pos_bytes + bits_bytes + halo + 512 <= c->lds_limit) {
+      bits_bytes += halo;
+      a.diltab = c->d_diltab.p;
+      a.dilR = c->dil_R;
+    } else {
+      KC_TRY(launch_dilate(c));
+      a.c.dil = 1;
+    }
+  } else if (c->dil_lazy && !a.c.enabled) {
+    // nothing within reach this cycle: the masks are still owed to the next one
+  }
   const bool fused = c->prm.shape != KC_SPHERE && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
   c->need_compact = !fused;

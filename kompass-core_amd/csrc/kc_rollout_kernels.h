@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   uint32_t *linner = lbits + nwin;                 // a.c.dil only
   uint32_t *louter = linner + (a.c.dil ? nwin : 0);
   int *lcand = reinterpret_cast<int *>(louter + (a.c.dil ? nwin : 0));  // [samples * P]
+  uint32_t *lhalo = reinterpret_cast<uint32_t *>(lcand + kFusedSamples * a.P);  // a.c.dil == 2 only
   __shared__ int ncand;
   __shared__ int lhit[kFusedSamples];
   __shared__ int lperm[kFusedSamples];  // local sample id of slot s
@@ -180,7 +181,45 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     lvx[tid] = in ? a.pvx[base + tid] : 0.0;
     lvy[tid] = in ? a.pvy[base + tid] : 0.0;
   }
-  if (a.c.enabled) {
+  if (a.c.enabled && a.c.dil == 2) {
+    // The dilated masks of this sensor update do not exist yet: the raw bits of
+    // the window plus a halo of R rows and one word either way go to LDS, and
+    // the window words are dilated from there exactly as dilate_kernel does
+    // (rows outside the bitmap are skipped, words outside it are empty).
+    const int R = a.dilR;
+    const int hw = a.c.wpr + 2, hh = a.c.H + 2 * R;
+    const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;
+    for (int i = tid; i < hw * hh; i += kFusedBlock) {
+      const int hy = i / hw, hx = i - hy * hw;
+      const int gy = a.c.ky0 + hy - R - a.c.gky0, gw = w0 + hx - 1;
+      uint32_t v = 0u;
+      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) v = a.c.gbits[(size_t)gy * a.c.gwpr + gw];
+      lhalo[i] = v;
+    }
+    __syncthreads();
+    const signed char *win = a.diltab, *wout = a.diltab + kMaxDil + 1;
+    const int nwords = a.c.H * a.c.wpr;
+    for (int i = tid; i < nwords; i += kFusedBlock) {
+      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
+      uint32_t in_acc = 0u, out_acc = 0u;
+      for (int j = -R; j <= R; ++j) {
+        const int gy = a.c.ky0 + cy + j - a.c.gky0;
+        if (gy < 0 || gy >= a.c.gH) continue;
+        const uint32_t *row = lhalo + (cy + j + R) * hw + w;  // [w] = left, [w + 1] = mid, [w + 2] = right
+        const uint32_t left = row[0], mid = row[1], right = row[2];
+        if ((mid | left | right) == 0u) continue;
+        const int aj = j < 0 ? -j : j;
+        if (win[aj] >= 0) in_acc |= hdilate(left, mid, right, win[aj]);
+        if (wout[aj] >= 0) out_acc |= hdilate(left, mid, right, wout[aj]);
+      }
+      // (words of the window outside the bitmap stay empty, as in the copy below)
+      const int gy0 = a.c.ky0 + cy - a.c.gky0, gw0 = w0 + w;
+      const bool inside = gy0 >= 0 && gy0 < a.c.gH && gw0 >= 0 && gw0 < a.c.gwpr;
+      lbits[i] = lhalo[(cy + R) * hw + w + 1];
+      linner[i] = inside ? in_acc : 0u;
+      louter[i] = inside ? out_acc : 0u;
+    }
+  } else if (a.c.enabled) {
     // window origin is word aligned with the sensor bitmap: whole-word copies
     const int nwords = a.c.H * a.c.wpr;
     const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;  // exact: difference is a multiple of 32

@@ -345,6 +345,7 @@ def _path_scenario(name, scale, shape, dims, variant, seed=4):
     {"KC_TRIG_COPY": "1"},        # trig table through pinned memory + H2D copy, launch after it
     {"KC_EARLY_LAUNCH": "0"},     # BAR table, but classic order
     {"KC_SENSOR_HOST": "1"},      # sensor update (voxel bitmap, buckets) built on the host
+    {"KC_LAZY_DILATE": "0"},      # dilate_kernel inside every sensor update (no self-dilating first cycle)
     {"KC_COST_DC": "64"},         # far-obstacle searches bracketed by the cell-centre distance table
     {"KC_COST_KERNEL": "wave", "KC_COST_DC": "128"},
 ], ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
