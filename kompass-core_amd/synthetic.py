@@ -116,7 +116,28 @@ CONFIGS = {
 }
 
 
-def make_controller_inputs(name: str, seed: int = 0, scale: float = 1.0):
+# Scenes (the costmap a config runs on).  "survey" is SURVEY.md 8(d)'s scene: Bernoulli(0.02) clutter
+# outside a 1 m free disc + solid border -- it leaves 5 % of cfg2's samples admissible and none of
+# cfg3's (10 s horizon), so the cost stage has little to do.  "mid" thins the clutter until roughly half
+# of the samples survive (cfg2 56 %, cfg3 40 %, cfg5 55 %); "open" keeps only what lies beyond 10 m
+# (border band), every sample admissible.
+SCENES = {
+    "survey": dict(p_occ=0.02, free_radius=1.0),
+    "mid": dict(p_occ=0.005, free_radius=1.0),
+    "open": dict(p_occ=0.02, free_radius=10.0),
+}
+MID_P_OCC = {"cfg3": 0.002}
+
+
+def scene_points(name: str, scene: str = "survey", seed: int = 0) -> np.ndarray:
+    c = CONFIGS[name]
+    sc = dict(SCENES[scene])
+    if scene == "mid":
+        sc["p_occ"] = MID_P_OCC.get(name, sc["p_occ"])
+    return costmap_points(c["map_side"], 0.05, seed, **sc)
+
+
+def make_controller_inputs(name: str, seed: int = 0, scale: float = 1.0, scene: str = "survey"):
     """Everything one controller cycle of a BASELINE config consumes.
     scale < 1 shrinks the sample lattice (parity tests at oracle-friendly size)."""
     c = CONFIGS[name]
@@ -128,9 +149,9 @@ def make_controller_inputs(name: str, seed: int = 0, scale: float = 1.0):
     else:
         vx, vy, om = lattice_nonholonomic(nvx, nom)
     seg, acc = (straight_segment if c["path"] == "straight" else arc_segment)(c["seg"])
-    pts = costmap_points(c["map_side"], 0.05, seed)
+    pts = scene_points(name, scene, seed)
     return dict(
-        name=name, ctr=c["ctr"], vx=vx, vy=vy, omega=om, P=c["P"], dt=0.1,
+        name=name, scene=scene, ctr=c["ctr"], vx=vx, vy=vy, omega=om, P=c["P"], dt=0.1,
         state=(0.0, 0.0, 0.0, 0.0), points=pts, octree_res=0.05,
         seg_xyz=seg, acc_at_seg=acc, ref_len=12.0 if c["path"] == "straight" else 47.12389,
         weights=c["weights"], max_range=10.0, robot=ROBOT_CYLINDER,

@@ -182,6 +182,9 @@ def lib():
         "ko_bmap_set_previous": (None, [C.c_void_p, _fp]),
         "ko_baseline_cycle": (C.c_long, [vp, C.POINTER(CostCtx), C.POINTER(State), C.c_double, sz,
                                          _dp, _dp, _dp, sz, C.c_int, _fp, C.POINTER(C.c_long)]),
+        "ko_full_cycle": (C.c_long, [vp, C.POINTER(CostCtx), C.POINTER(State), C.c_double, sz,
+                                     _dp, _dp, _dp, sz, C.c_int, _fp, _fp, C.POINTER(C.c_uint8), _fp]),
+        "ko_costs_mt": (None, [C.POINTER(CostCtx), _fp, _fp, _fp, _fp, _fp, sz, sz, C.c_int, _fp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -637,3 +640,64 @@ def baseline_cycle(coll, ci: CostInputs, start, dt, P, vx, vy, omega, threads=1)
     idx = lib().ko_baseline_cycle(coll.h if coll is not None else None, C.byref(ci.cx), C.byref(st), dt, P,
                                   _pd(vx), _pd(vy), _pd(omega), len(vx), threads, C.byref(mc), C.byref(na))
     return int(idx), float(mc.value), int(na.value)
+
+
+def host_threads() -> int:
+    """CPUs this process may really use (affinity mask capped by the cgroup quota)."""
+    import os
+
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def full_cycle(coll, ci: CostInputs | None, start, dt, P, vx, vy, omega, threads=None):
+    """Every sample rolled out and scored independently by `threads` workers
+    (the per-sample arithmetic of rollout() + min_trajectory_cost()), compacted
+    here in generation order.  -> dict(px, py, raw, costs, index, cost) like
+    tests/helpers.oracle_cycle."""
+    vx, vy, omega = _f64(vx), _f64(vy), _f64(omega)
+    n = len(vx)
+    px = np.zeros((max(n, 1), P), np.float32)
+    py = np.zeros((max(n, 1), P), np.float32)
+    adm = np.zeros(max(n, 1), np.uint8)
+    costs = np.zeros(max(n, 1), np.float32)
+    st = State(*start)
+    lib().ko_full_cycle(coll.h if coll is not None else None, C.byref(ci.cx) if ci is not None else None,
+                        C.byref(st), dt, P, _pd(vx), _pd(vy), _pd(omega), n, int(threads or host_threads()),
+                        _pf(px), _pf(py), adm.ctypes.data_as(C.POINTER(C.c_uint8)), _pf(costs))
+    raw = np.flatnonzero(adm[:n]).astype(np.int32)
+    c = costs[raw]
+    # cost_evaluator.cpp:101-104: strict `<` against FLT_MAX, lowest index wins ties
+    ok = np.flatnonzero(c < np.finfo(np.float32).max)
+    if len(ok):
+        idx = int(ok[np.argmin(c[ok])])
+        cost = float(c[idx])
+    else:
+        idx, cost = -1, 0.0
+    return dict(px=px[raw], py=py[raw], raw=raw, costs=c, index=idx, cost=cost)
+
+
+def costs_mt(ci: CostInputs, paths_x, paths_y, vel=None, threads=None):
+    """Per-sample total cost of caller-provided trajectories (threaded)
+    -> (argmin, min_cost, costs[N]) like min_trajectory_cost."""
+    px, py = _f32(paths_x), _f32(paths_y)
+    N, P = px.shape
+    costs = np.zeros(N, np.float32)
+    v = [_f32(a) for a in vel] if vel is not None else [None, None, None]
+    vp = [_pf(a) if a is not None else None for a in v]
+    lib().ko_costs_mt(C.byref(ci.cx), _pf(px), _pf(py), vp[0], vp[1], vp[2], N, P,
+                      int(threads or host_threads()), _pf(costs))
+    ok = np.flatnonzero(costs < np.finfo(np.float32).max)
+    if len(ok):
+        idx = int(ok[np.argmin(costs[ok])])
+        return idx, float(costs[idx]), costs
+    return -1, 0.0, costs

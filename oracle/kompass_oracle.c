@@ -1885,6 +1885,142 @@ long ko_baseline_cycle(ko_coll *coll, const ko_cost_ctx *cx,
 }
 
 
+/* ---- full-size parity helper (tests only): the same per-sample work as
+ * ko_rollout + ko_min_trajectory_cost (trajectory_sampler.cpp:118-179,
+ * cost_evaluator.cpp:49-109), every sample evaluated independently by
+ * `threads` workers that pull blocks of 16 samples from a shared counter.  All
+ * per-sample outputs are kept (raw numbering): px/py [n][P], adm [n] (1 =
+ * admissible), costs [n] (only where adm).  The caller compacts and takes the
+ * first strict minimum, exactly as the serial loop does. */
+typedef struct {
+  ko_coll *coll;
+  const ko_cost_ctx *cx;
+  const ko_state *start;
+  double dt;
+  size_t P, n;
+  const double *vx, *vy, *om;
+  float *px, *py, *costs;
+  uint8_t *adm;
+  size_t *next;
+  pthread_mutex_t *mu;
+  long n_adm;
+} fc_job;
+
+static void *fc_worker(void *arg) {
+  fc_job *j = (fc_job *)arg;
+  j->n_adm = 0;
+  for (;;) {
+    pthread_mutex_lock(j->mu);
+    const size_t k0 = *j->next;
+    *j->next = k0 + 16;
+    pthread_mutex_unlock(j->mu);
+    if (k0 >= j->n) break;
+    const size_t k1 = k0 + 16 < j->n ? k0 + 16 : j->n;
+    for (size_t k = k0; k < k1; ++k) {
+      float *px = j->px + k * j->P, *py = j->py + k * j->P;
+      const int ok = rollout_one(j->coll, j->start, j->dt, j->P, j->vx[k],
+                                 j->vy[k], j->om[k], px, py);
+      j->adm[k] = ok ? 1 : 0;
+      if (!ok) continue;
+      j->n_adm++;
+      if (j->cx && j->costs)
+        j->costs[k] = total_cost_one(j->cx, px, py, NULL, NULL, NULL, j->P);
+    }
+  }
+  return NULL;
+}
+
+long ko_full_cycle(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start,
+                   double dt, size_t P, const double *vx, const double *vy,
+                   const double *om, size_t n, int threads, float *px,
+                   float *py, uint8_t *adm, float *costs) {
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  fc_job jobs[64];
+  pthread_t tid[64];
+  size_t next = 0;
+  pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+  for (int t = 0; t < threads; ++t) {
+    fc_job *j = &jobs[t];
+    j->coll = coll;
+    j->cx = cx;
+    j->start = start;
+    j->dt = dt;
+    j->P = P;
+    j->n = n;
+    j->vx = vx;
+    j->vy = vy;
+    j->om = om;
+    j->px = px;
+    j->py = py;
+    j->costs = costs;
+    j->adm = adm;
+    j->next = &next;
+    j->mu = &mu;
+    j->n_adm = 0;
+    if (threads == 1)
+      fc_worker(j);
+    else
+      pthread_create(&tid[t], NULL, fc_worker, j);
+  }
+  long na = 0;
+  for (int t = 0; t < threads; ++t) {
+    if (threads > 1) pthread_join(tid[t], NULL);
+    na += jobs[t].n_adm;
+  }
+  return na;
+}
+
+/* the same for caller-provided trajectories (cost_evaluator.cpp:49-109 body
+ * per sample; velocities optional): costs [n] */
+typedef struct {
+  const ko_cost_ctx *cx;
+  const float *px, *py, *vx, *vy, *om;
+  size_t n, P, lo, hi;
+  float *costs;
+} ce_job;
+
+static void *ce_worker(void *arg) {
+  ce_job *j = (ce_job *)arg;
+  const size_t nv = j->P - 1;
+  for (size_t k = j->lo; k < j->hi; ++k)
+    j->costs[k] = total_cost_one(j->cx, j->px + k * j->P, j->py + k * j->P,
+                                 j->vx ? j->vx + k * nv : NULL,
+                                 j->vy ? j->vy + k * nv : NULL,
+                                 j->om ? j->om + k * nv : NULL, j->P);
+  return NULL;
+}
+
+void ko_costs_mt(const ko_cost_ctx *cx, const float *px, const float *py,
+                 const float *vx, const float *vy, const float *om, size_t n,
+                 size_t P, int threads, float *costs) {
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
+  ce_job jobs[64];
+  pthread_t tid[64];
+  for (int t = 0; t < threads; ++t) {
+    ce_job *j = &jobs[t];
+    j->cx = cx;
+    j->px = px;
+    j->py = py;
+    j->vx = vx;
+    j->vy = vy;
+    j->om = om;
+    j->n = n;
+    j->P = P;
+    j->lo = n * (size_t)t / (size_t)threads;
+    j->hi = n * (size_t)(t + 1) / (size_t)threads;
+    j->costs = costs;
+    if (threads == 1)
+      ce_worker(j);
+    else
+      pthread_create(&tid[t], NULL, ce_worker, j);
+  }
+  if (threads > 1)
+    for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+}
+
+
 /* ===========================================================================
  * M5: pointCloudToLaserScanFromRaw, utils/pointcloud.h:116-177 and :205-259
  * =========================================================================== */

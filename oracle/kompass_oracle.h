@@ -315,6 +315,18 @@ long ko_baseline_cycle(ko_coll *coll, const ko_cost_ctx *cx,
                        size_t n, int threads, float *min_cost_out,
                        long *n_admissible_out);
 
+/* full-size parity helpers (tests only): per-sample outputs in raw numbering,
+ * samples evaluated independently by `threads` workers; same per-sample
+ * arithmetic as ko_rollout + ko_min_trajectory_cost.  Returns the admissible
+ * count. */
+long ko_full_cycle(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start,
+                   double time_step, size_t P, const double *vx,
+                   const double *vy, const double *omega, size_t n, int threads,
+                   float *px, float *py, uint8_t *admissible, float *costs);
+void ko_costs_mt(const ko_cost_ctx *cx, const float *px, const float *py,
+                 const float *vx, const float *vy, const float *om, size_t n,
+                 size_t P, int threads, float *costs);
+
 #ifdef __cplusplus
 }
 #endif

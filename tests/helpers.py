@@ -32,6 +32,24 @@ def oracle_cycle(inp, scan=None, sensor_pos=(0, 0, 0), sensor_rot=(0, 0, 0, 1)):
     return dict(px=px, py=py, raw=raw, costs=costs, index=idx, cost=cost, ci=ci, coll=coll)
 
 
+def oracle_cycle_mt(inp, threads=None, sensor_pos=(0, 0, 0), sensor_rot=(0, 0, 0, 1)):
+    """oracle_cycle for BASELINE-size batches: every sample rolled out and
+    scored independently on all host cores (oracle/ko.full_cycle: the same
+    per-sample C functions, compacted in generation order, first strict minimum)."""
+    rb = inp["robot"]
+    coll = ko.Collision(rb["shape"], rb["dims"], sensor_pos, sensor_rot, inp["octree_res"])
+    st = inp["state"]
+    coll.update_state(st[0], st[1], st[2])
+    coll.update_points(inp["points"], True)
+    ox, oy = ko.obstacles_from_points(sensor_pos, sensor_rot, st, inp["points"])
+    ci = ko.CostInputs(inp["seg_xyz"], 0, inp["acc_at_seg"], inp["ref_len"],
+                       np.stack([ox, oy], axis=1), np.float32(inp["max_range"]) / np.float32(3.0),
+                       inp["acc_limits"], ko.make_weights(*inp["weights"]))
+    out = ko.full_cycle(coll, ci, st, inp["dt"], inp["P"], inp["vx"], inp["vy"], inp["omega"], threads)
+    out.update(ci=ci, coll=coll)
+    return out
+
+
 def hip_context(kh, inp, sensor_pos=(0, 0, 0), sensor_rot=(0, 0, 0, 1), max_samples=None, max_points=None):
     rb = inp["robot"]
     n = len(inp["vx"])
