@@ -130,6 +130,35 @@ int kc_dwa_set_resolution(kc_dwa *ctx, double octree_res);
 /* CostEvaluator::updateCostWeights, cost_evaluator.cpp:39-41 */
 int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
 
+/* Per-context switches of the device path (no counterpart in the reference, whose
+ * SYCL path has none; every setting gives bit-identical results -- tests/
+ * test_gpu_parity.py runs the cycle under each).  value: 0 / 1 unless stated.
+ *   "fused_cycle"    (1) kc_dwa_cycle runs the whole cycle as ONE launch when the
+ *                        cost tables fit in LDS beside the roll-out tile; 0: roll-out,
+ *                        cost and publish kernels
+ *   "write_paths"    (0) the single-launch cycle also stores every float row
+ *                        (otherwise rows are produced on demand by kc_dwa_get_samples)
+ *   "cost_kernel"    (0) stand-alone cost stage: 0 chosen from the admissible count
+ *                        of the previous cycle, 1 workgroup per sample, 2 wavefront per sample
+ *   "cost_dc_cells"  (0) n = 8..512: cell-centre distance table of n cells along the
+ *                        longer side for the far-obstacle searches (pays when several
+ *                        cycles share one sensor update); 0: off
+ *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
+ *   "early_launch"   (1) the roll-out kernel is queued before the host trig table exists
+ *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host
+ *   "trig_copy"      (0) trig table through pinned memory + H2D copy instead of BAR stores
+ *   "force_split"    (0) roll-out, collision and compaction as separate kernels
+ * kc_dwa_get_option also reads "last_cycle_single_launch" and "host_threads".
+ * Waits for the context's stream.  Process-wide defaults may be preset with the
+ * environment variables listed in DESIGN.md (test hooks). */
+int kc_dwa_set_option(kc_dwa *ctx, const char *name, double value);
+int kc_dwa_get_option(kc_dwa *ctx, const char *name, double *value);
+/* threads of the process-wide host pool that evaluates the libm trig table of a
+ * roll-out (path.h:24-30 calls cos/sin per step; here once per distinct omega and
+ * step): 1..64, the calling thread included.  Default: from the CPUs the process
+ * may use (cgroup quota / ranks on the node) or KC_HOST_THREADS. */
+int kc_set_host_threads(int n);
+
 /* A1 on the host: TrajectorySampler::UpdateReachableVelocityRange
  * (trajectory_sampler.cpp:328-372) + the lattice loops (:181-220 / :256-272,
  * maxNumThreads = 1 ordering) with the all-zero filter of :122-125.

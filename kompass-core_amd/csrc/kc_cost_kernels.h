@@ -194,6 +194,227 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
 // ---------------------------------------------------------------------------
 constexpr int kBlkCostBlock = 512;  // 8 wavefronts, two workgroups per CU
 constexpr size_t kBlkLdsBudget = 78 * 1024;
+
+// Where the float points of one sample come from: the sample-major rows in
+// global memory (split path, kc_cost_evaluate) or the double poses the fused
+// cycle kernel still holds in LDS (pose k at row[k - 1], the start pose in
+// front; the float is the one the roll-out would have stored).
+struct RowPts {
+  const float *rx, *ry;
+  __device__ __forceinline__ float x(int p) const { return rx[p]; }
+  __device__ __forceinline__ float y(int p) const { return ry[p]; }
+};
+struct PosePts {
+  const double2 *row;
+  double x0, y0;
+  __device__ __forceinline__ float x(int p) const {
+    return static_cast<float>(p == 0 ? x0 : row[p - 1].x);
+  }
+  __device__ __forceinline__ float y(int p) const {
+    return static_cast<float>(p == 0 ? y0 : row[p - 1].y);
+  }
+};
+// tracked segment as five rows (x | y | z | z^2 | acc) or as (x, y, z^2, acc) records
+struct SegRows {
+  const float *sx, *sy, *szz, *sacc;
+  __device__ __forceinline__ float4 pt(int j) const { return make_float4(sx[j], sy[j], szz[j], 0.0f); }
+  __device__ __forceinline__ float acc(int j) const { return sacc[j]; }
+};
+struct SegRecs {
+  const float4 *rec;
+  __device__ __forceinline__ float4 pt(int j) const { return rec[j]; }
+  __device__ __forceinline__ float acc(int j) const { return rec[j].w; }
+};
+
+// The searches of ONE sample by a team of kTeam lanes (a multiple of 64), eight
+// lanes per trajectory point: brute-force segment scan, block search around the
+// query cell.  Leaves s_mind[P], *s_goal, *s_end and the sample-wide minimum in
+// *s_obest (armed by the caller, behind a barrier).  tid = lane id inside the team.
+template <int kTeam, class Seg, class Pts>
+__device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg &seg, float sz_end,
+                                                   const int *cells, const uint8_t *skip,
+                                                   const float *obx, const float *oby, const Pts &pts,
+                                                   int tid, float *s_mind, float *s_goal, float *s_end,
+                                                   unsigned long long *s_obest) {
+  const BucketDev &b = a.b;
+  const int sub = tid & 7;
+  for (int p0 = 0; p0 < a.P; p0 += kTeam / 8) {
+    // Idle groups (beyond P) work on a clamped point and write nothing, so
+    // the cross-lane steps always see active lanes.
+    const int pp = p0 + (tid >> 3);
+    const bool live = pp < a.P;
+    const int p = live ? pp : a.P - 1;
+    const float x = pts.x(p), y = pts.y(p);
+    if (a.use_seg) {
+      float best = FLT_MAX;
+      int arg = 0;
+#pragma unroll 4
+      for (int j = sub; j < a.S; j += 8) {  // j ascending per lane
+        const float4 q = seg.pt(j);
+        const float dx = q.x - x;
+        const float dy = q.y - y;
+        const float xx = dx * dx;
+        const float yy = dy * dy;
+        const float d = xx + (yy + q.z);  // Eigen order a + (b + c)
+        if (d < best) {
+          best = d;
+          arg = j;
+        }
+      }
+      // non-negative floats order like their bit patterns; ties go to the
+      // lowest segment index (the reference's strict `<` in index order)
+      const uint32_t mine = __float_as_uint(best);
+      const uint32_t mbits = group8_min_u32(mine);
+      arg = static_cast<int>(
+          group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
+      best = __uint_as_float(mbits);
+      if (sub == 0 && live) {
+        s_mind[p] = kc::sqrt_rn(best);
+        if (p == a.P - 1) {
+          // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
+          const float arc = kc::div_rn(a.ref_len - seg.acc(arg), a.ref_len);
+          *s_goal = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
+          // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
+          const float4 qe = seg.pt(a.S - 1);
+          const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
+          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+          *s_end = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
+        }
+      }
+    }
+    if (a.use_obs) {
+      // query cell (clamped: a query outside the grid searches from the
+      // border and the guarantee radius shrinks by its distance to the grid)
+      const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+      const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+      int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+      double off = 0.0;
+      if (fx < 0.0) off = fmax(off, -fx);
+      if (fy < 0.0) off = fmax(off, -fy);
+      if (fx > b.W) off = fmax(off, fx - b.W);
+      if (fy > b.H) off = fmax(off, fy - b.H);
+      cx = min(max(cx, 0), b.W - 1);
+      cy = min(max(cy, 0), b.H - 1);
+      double best = DBL_MAX;
+      const int mmax = max(b.W, b.H);
+      // first block: just large enough to contain the nearest non-empty cell;
+      // following blocks: just large enough to prove the best distance found
+      int m = max(1, static_cast<int>(skip[cy * b.W + cx]));
+      for (;;) {  // uniform within the group of eight, divergent between groups
+        const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+        const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+        // a row of the block is a contiguous run of the cell-ordered obstacle
+        // list: four rows per pass, two lanes per row
+        for (int row = y0 + (sub >> 1); row <= y1; row += 4) {
+          const int beg = cells[row * b.W + x0];
+          const int end = cells[row * b.W + x1 + 1];
+          for (int j = beg + (sub & 1); j < end; j += 2) {
+            const double dx = static_cast<double>(obx[j] - x);
+            const double dy = static_cast<double>(oby[j] - y);
+            const double dd = dx * dx + dy * dy;
+            best = dd < best ? dd : best;
+          }
+        }
+        best = group8_min_nonneg(best);
+        // Only the minimum over the whole sample is used (trajectory.h:218-235
+        // inside obstaclesDistCostFunc), so the points of a sample share
+        // their best distance: a point stops as soon as everything it has
+        // not visited yet is farther than what some point already found.
+        if (sub == 0 && live)
+          atomicMin(s_obest, static_cast<unsigned long long>(__double_as_longlong(best)));
+        const double shared = __longlong_as_double(static_cast<long long>(
+            *const_cast<volatile unsigned long long *>(s_obest)));
+        // every obstacle closer than `reach` (true distance) was visited
+        const double reach = (static_cast<double>(m) - off) * b.g;
+        if (reach > 0.0) {
+          const double r2 = reach * reach * (1.0 - 1e-6);
+          if (shared < r2) break;
+          if (reach >= b.cap) break;
+        }
+        if (m >= mmax) break;  // whole grid visited
+        // next half-width: enough cells to cover sqrt(shared) (+ guard), or
+        // the cap radius when nothing has been found yet (any over-estimate
+        // only visits more cells: float sqrt is enough)
+        const double need =
+            shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
+                             : b.cap;
+        const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
+        m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
+      }
+    }
+  }
+}
+
+// smoothness + jerk of caller-provided velocity profiles (kc_cost_evaluate):
+// serial loops, evaluated redundantly by every lane (wave-uniform addresses)
+__device__ __forceinline__ float add_velocity_costs(const CostArgs &a, int n, float total) {
+  const int nv = a.P - 1;
+  const float *vx = a.vvx + (size_t)n * nv;
+  const float *vy = a.vvy + (size_t)n * nv;
+  const float *om = a.vom + (size_t)n * nv;
+  const float div = static_cast<float>(3L * nv);
+  if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
+    float c = 0.0f;
+    for (int k = 1; k < nv; ++k) {
+      if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
+      if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
+      if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
+    }
+    total = accum(total, a.w_smooth, kc::div_rn(c, div));
+  }
+  if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
+    float c = 0.0f;
+    for (int k = 2; k < nv; ++k) {
+      if (a.acc0 > 0)
+        c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
+      if (a.acc1 > 0)
+        c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
+      if (a.acc2 > 0)
+        c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
+    }
+    total = accum(total, a.w_jerk, kc::div_rn(c, div));
+  }
+  return total;
+}
+
+// obstaclesDistCostFunc, cost_evaluator.cpp:179-184, from the minimum squared distance (double)
+__device__ __forceinline__ float obstacle_cost_from(const CostArgs &a, double best) {
+  const float min_d2 = static_cast<float>(best);
+  const float dist = static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
+  float v = a.max_obs_dist - dist;
+  v = v < 0.0f ? 0.0f : v;
+  return kc::div_rn(v, a.max_obs_dist);
+}
+
+// weighted total of the sample a team has searched, by ONE wavefront (uniform result)
+__device__ __forceinline__ float team_sample_total(const CostArgs &a, int n, int lane,
+                                                   const float *s_mind, float s_goal, float s_end,
+                                                   unsigned long long s_obest) {
+  float total = 0.0f;
+  if (a.ref_len > 0.0f) {
+    if (a.w_goal > 0.0) total = accum(total, a.w_goal, s_goal);
+    if (a.w_path > 0.0) {
+      // pathCostFunc, cost_evaluator.cpp:111-141: ordered float sum
+      float sum = 0.0f;
+      for (int base = 0; base < a.P; base += 64) {
+        const int cnt = min(64, a.P - base);
+        const float v = (lane < cnt) ? s_mind[base + lane] : 0.0f;
+        for (int k = 0; k < cnt; ++k) sum += lane_value(v, k);
+      }
+      const float c = kc::div_rn(
+          kc::div_rn(sum, static_cast<float>(a.P)) + s_end, 2.0f);
+      total = accum(total, a.w_path, c);
+    }
+  }
+  if (a.O > 0 && a.w_obs > 0.0)
+    total = accum(total, a.w_obs,
+                  obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(s_obest))));
+  if (a.have_vel) total = add_velocity_costs(a, n, total);
+  // constant-velocity samples: both terms are exactly 0 and `total += w*0`
+  // leaves total unchanged, so nothing to do when !have_vel.
+  return total;
+}
+
 template <bool kLds, bool kObsLds>
 __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(CostArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -255,6 +476,8 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
       }
     }
   }
+  const SegRows seg{sx, sy, szz, sacc};
+  const RowPts pts{s_px, s_py};
 
   for (int i = blockIdx.x; i < na; i += gridDim.x) {
     const int n = a.adm_list[i];
@@ -269,173 +492,12 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
       s_py[k] = a.py[(size_t)n * a.P + k];
     }
     __syncthreads();  // also covers the structure copy above
-    // ---- eight lanes per trajectory point (64 points per pass) ----------------
-    // Idle groups (beyond P) work on a clamped point and write nothing, so
-    // the cross-lane steps always see active lanes.
-    const int sub = threadIdx.x & 7;
-    for (int p0 = 0; p0 < a.P; p0 += kBlkCostBlock / 8) {
-      const int pp = p0 + (threadIdx.x >> 3);
-      const bool live = pp < a.P;
-      const int p = live ? pp : a.P - 1;
-      const float x = s_px[p], y = s_py[p];
-      if (a.use_seg) {
-        float best = FLT_MAX;
-        int arg = 0;
-#pragma unroll 4
-        for (int j = sub; j < a.S; j += 8) {  // j ascending per lane
-          const float dx = sx[j] - x;
-          const float dy = sy[j] - y;
-          const float xx = dx * dx;
-          const float yy = dy * dy;
-          const float d = xx + (yy + szz[j]);  // Eigen order a + (b + c)
-          if (d < best) {
-            best = d;
-            arg = j;
-          }
-        }
-        // non-negative floats order like their bit patterns; ties go to the
-        // lowest segment index (the reference's strict `<` in index order)
-        const uint32_t mine = __float_as_uint(best);
-        const uint32_t mbits = group8_min_u32(mine);
-        arg = static_cast<int>(
-            group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
-        best = __uint_as_float(mbits);
-        if (sub == 0 && live) {
-          s_mind[p] = kc::sqrt_rn(best);
-          if (p == a.P - 1) {
-            // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
-            const float arc = kc::div_rn(a.ref_len - sacc[arg], a.ref_len);
-            s_goal = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
-            // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
-            const int e = a.S - 1;
-            const float dx = x - sx[e], dy = y - sy[e], dz = 0.0f - sz[e];
-            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-            s_end = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
-          }
-        }
-      }
-      if (a.use_obs) {
-        // query cell (clamped: a query outside the grid searches from the
-        // border and the guarantee radius shrinks by its distance to the grid)
-        const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-        const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-        int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-        double off = 0.0;
-        if (fx < 0.0) off = fmax(off, -fx);
-        if (fy < 0.0) off = fmax(off, -fy);
-        if (fx > b.W) off = fmax(off, fx - b.W);
-        if (fy > b.H) off = fmax(off, fy - b.H);
-        cx = min(max(cx, 0), b.W - 1);
-        cy = min(max(cy, 0), b.H - 1);
-        double best = DBL_MAX;
-        const int mmax = max(b.W, b.H);
-        // first block: just large enough to contain the nearest non-empty cell;
-        // following blocks: just large enough to prove the best distance found
-        int m = max(1, static_cast<int>(skip[cy * b.W + cx]));
-        for (;;) {  // uniform within the group of eight, divergent between groups
-          const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-          const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-          // a row of the block is a contiguous run of the cell-ordered obstacle
-          // list: four rows per pass, two lanes per row
-          for (int row = y0 + (sub >> 1); row <= y1; row += 4) {
-            const int beg = cells[row * b.W + x0];
-            const int end = cells[row * b.W + x1 + 1];
-            for (int j = beg + (sub & 1); j < end; j += 2) {
-              const double dx = static_cast<double>(obx[j] - x);
-              const double dy = static_cast<double>(oby[j] - y);
-              const double dd = dx * dx + dy * dy;
-              best = dd < best ? dd : best;
-            }
-          }
-          best = group8_min_nonneg(best);
-          // Only the minimum over the whole sample is used (trajectory.h:218-235
-          // inside obstaclesDistCostFunc), so the points of a sample share
-          // their best distance: a point stops as soon as everything it has
-          // not visited yet is farther than what some point already found.
-          if (sub == 0 && live)
-            atomicMin(&s_obest, static_cast<unsigned long long>(__double_as_longlong(best)));
-          const double shared = __longlong_as_double(static_cast<long long>(
-              *const_cast<volatile unsigned long long *>(&s_obest)));
-          // every obstacle closer than `reach` (true distance) was visited
-          const double reach = (static_cast<double>(m) - off) * b.g;
-          if (reach > 0.0) {
-            const double r2 = reach * reach * (1.0 - 1e-6);
-            if (shared < r2) break;
-            if (reach >= b.cap) break;
-          }
-          if (m >= mmax) break;  // whole grid visited
-          // next half-width: enough cells to cover sqrt(shared) (+ guard), or
-          // the cap radius when nothing has been found yet (any over-estimate
-          // only visits more cells: float sqrt is enough)
-          const double need =
-              shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
-                               : b.cap;
-          const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
-          m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-        }
-      }
-    }
+    team_sample_search<kBlkCostBlock>(a, seg, (a.use_seg && a.S > 0) ? sz[a.S - 1] : 0.0f, cells, skip,
+                                      obx, oby, pts, threadIdx.x, s_mind, &s_goal, &s_end, &s_obest);
     __syncthreads();
     // ---- wavefront 0: weighted total of this sample ---------------------------
     if (wave == 0) {
-      float total = 0.0f;
-      if (a.ref_len > 0.0f) {
-        if (a.w_goal > 0.0) total = accum(total, a.w_goal, s_goal);
-        if (a.w_path > 0.0) {
-          // pathCostFunc, cost_evaluator.cpp:111-141: ordered float sum
-          float sum = 0.0f;
-          for (int base = 0; base < a.P; base += 64) {
-            const int cnt = min(64, a.P - base);
-            const float v = (lane < cnt) ? s_mind[base + lane] : 0.0f;
-            for (int k = 0; k < cnt; ++k) sum += lane_value(v, k);
-          }
-          const float c = kc::div_rn(
-              kc::div_rn(sum, static_cast<float>(a.P)) + s_end, 2.0f);
-          total = accum(total, a.w_path, c);
-        }
-      }
-      if (a.O > 0 && a.w_obs > 0.0) {
-        // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
-        const double best = __longlong_as_double(static_cast<long long>(s_obest));
-        const float min_d2 = static_cast<float>(best);
-        const float dist =
-            static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
-        float v = a.max_obs_dist - dist;
-        v = v < 0.0f ? 0.0f : v;
-        total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
-      }
-      if (a.have_vel) {
-        // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
-        // evaluated redundantly by every lane (wave-uniform addresses)
-        const int nv = a.P - 1;
-        const float *vx = a.vvx + (size_t)n * nv;
-        const float *vy = a.vvy + (size_t)n * nv;
-        const float *om = a.vom + (size_t)n * nv;
-        const float div = static_cast<float>(3L * nv);
-        if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
-          float c = 0.0f;
-          for (int k = 1; k < nv; ++k) {
-            if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
-            if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
-            if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
-          }
-          total = accum(total, a.w_smooth, kc::div_rn(c, div));
-        }
-        if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
-          float c = 0.0f;
-          for (int k = 2; k < nv; ++k) {
-            if (a.acc0 > 0)
-              c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
-            if (a.acc1 > 0)
-              c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
-            if (a.acc2 > 0)
-              c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
-          }
-          total = accum(total, a.w_jerk, kc::div_rn(c, div));
-        }
-      }
-      // constant-velocity samples: both terms are exactly 0 and `total += w*0`
-      // leaves total unchanged, so nothing to do when !have_vel.
+      const float total = team_sample_total(a, n, lane, s_mind, s_goal, s_end, s_obest);
       if (lane == 0) {
         a.costs[n] = total;
         if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
@@ -451,6 +513,386 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
   if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
 }
 
+
+// The wavefront-per-sample evaluation of ONE sample (one lane per trajectory
+// point, tiles of 64 points): see the comment on top of this file.  `seg`
+// gives the (x, y, z^2) of a segment point and its accumulated length, `cap` /
+// `sup` the chunk capsules [8][nch] and super-chunk spheres [4][nsup], `pts`
+// the sample's float points; *obest is a 64-bit LDS word of this wavefront.
+// Returns the weighted total (wave-uniform).
+template <class Seg, class Pts>
+__device__ __forceinline__ float wave_sample_total(const CostArgs &a, const DcArgs &t, bool use_dc,
+                                                   const Seg &seg, const float *cap, const float *sup,
+                                                   float sz_end, const int *cells, const uint8_t *skip,
+                                                   const float *obx, const float *oby, const Pts &pts,
+                                                   int n, int lane, unsigned long long *obest,
+                                                   bool stamp) {
+  const BucketDev &b = a.b;
+if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
+  float sum = 0.0f;            // ordered path-cost sum, carried over the point tiles
+  float goal = 0.0f, endc = 0.0f;
+  double ubound2 = DBL_MAX;    // square of an upper bound of the sample's obstacle distance (not attained)
+  for (int p0 = 0; p0 < a.P; p0 += 64) {
+    const int pp = p0 + lane;
+    const bool live = pp < a.P;
+    const int p = live ? pp : a.P - 1;  // idle lanes shadow the last point, write nothing
+    const float x = pts.x(p), y = pts.y(p);
+    float mind = 0.0f, goal_l = 0.0f, end_l = 0.0f;
+    const bool st = stamp && p0 == 0;
+    if (st) KC_STAMP(7);
+    if (a.use_seg) {
+      float best = FLT_MAX;
+      int arg = 0;
+      const int sup_pts = 8 * a.seg_chunk;
+      // (1) the first point of every super-chunk: ascending index, strict `<`
+      for (int s = 0; s < a.nsup; ++s) {
+        const int j = s * sup_pts;
+        const float4 q = seg.pt(j);
+        const float dx = q.x - x;
+        const float dy = q.y - y;
+        const float xx = dx * dx;
+        const float yy = dy * dy;
+        const float dd = xx + (yy + q.z);  // Eigen order a + (b + c)
+        if (dd < best) {
+          best = dd;
+          arg = j;
+        }
+      }
+      // (2) super-chunks that may hold something at least as close:
+      // |q - c| - r <= thr on the squares; 1e-4 relative slack on the bound,
+      // 1e-5 on the compared square (NaN compares false: qualifies)
+      float thr = __builtin_sqrtf(best) * 1.0001f;
+      unsigned smask = 0u;
+      for (int s = 0; s < a.nsup; ++s) {
+        const float dx = sup[s] - x, dy = sup[a.nsup + s] - y, dz = sup[2 * a.nsup + s];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float lim = thr + sup[3 * a.nsup + s];
+        if (!(d2 > lim * lim * 1.00001f)) smask |= 1u << s;
+      }
+      if (st) KC_STAMP(8);
+      // (3) the first points of their other chunks
+      for (unsigned m = smask; m;) {
+        const int s = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1u;
+#pragma unroll
+        for (int u = 1; u < 8; ++u) {
+          const int c = s * 8 + u;
+          const int j = min(c, a.nch - 1) * a.seg_chunk;  // a repeat of the last chunk changes nothing
+          const float4 q = seg.pt(j);
+          const float dx = q.x - x;
+          const float dy = q.y - y;
+          const float xx = dx * dx;
+          const float yy = dy * dy;
+          const float dd = xx + (yy + q.z);
+          if (dd < best || (dd == best && j < arg)) {
+            best = dd;
+            arg = j;
+          }
+        }
+      }
+      // (4) capsule test of their chunks: distance to the chord minus the
+      // largest deviation of the chunk's points from it
+      thr = __builtin_sqrtf(best) * 1.0001f;
+      unsigned long long cand = 0ull;
+      for (unsigned m = smask; m;) {
+        const int s = __ffs(static_cast<int>(m)) - 1;
+        m &= m - 1u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int c = min(s * 8 + u, a.nch - 1);
+          const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
+          const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
+          float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
+          t = fminf(fmaxf(t, 0.0f), 1.0f);
+          const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
+          const float d2 = ex * ex + ey * ey + ez * ez;
+          const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+          if (!(d2 > lim * lim * 1.0001f)) cand |= 1ull << c;
+        }
+      }
+      if (st) KC_STAMP(9);
+      // (5) the remaining points of those chunks
+      while (cand) {
+        const int c = __ffsll(static_cast<long long>(cand)) - 1;
+        cand &= cand - 1ull;
+        const int j0 = c * a.seg_chunk;
+        const int j1 = min(j0 + a.seg_chunk, a.S);
+        // five points per batch: their LDS reads are in flight together
+        for (int jb = j0 + 1; jb < j1; jb += 5) {
+          float vx[5], vy[5], vz[5];
+#pragma unroll
+          for (int u = 0; u < 5; ++u) {
+            const int j = min(jb + u, j1 - 1);
+            const float4 q = seg.pt(j);
+            vx[u] = q.x;
+            vy[u] = q.y;
+            vz[u] = q.z;
+          }
+#pragma unroll
+          for (int u = 0; u < 5; ++u) {
+            const int j = jb + u;
+            const float dx = vx[u] - x;
+            const float dy = vy[u] - y;
+            const float xx = dx * dx;
+            const float yy = dy * dy;
+            const float dd = xx + (yy + vz[u]);
+            if (j < j1 && (dd < best || (dd == best && j < arg))) {
+              best = dd;
+              arg = j;
+            }
+          }
+        }
+      }
+      if (st) KC_STAMP(10);
+      mind = kc::sqrt_rn(best);
+      if (pp == a.P - 1) {
+        // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
+        const float acc_arg = seg.acc(arg);
+        const float arc = kc::div_rn(a.ref_len - acc_arg, a.ref_len);
+        goal_l = arc + kc::div_rn(mind, a.ref_len);
+        // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
+        const int e = a.S - 1;
+        const float4 qe = seg.pt(e);
+        const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
+        const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+        end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
+      }
+    }
+    if (st) KC_STAMP(11);
+    if (a.use_obs) {
+      // query cell (clamped: a query outside the grid searches from the
+      // border and the guarantee radius shrinks by its distance to the grid)
+      const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+      const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+      int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+      double off = 0.0;
+      if (fx < 0.0) off = fmax(off, -fx);
+      if (fy < 0.0) off = fmax(off, -fy);
+      if (fx > b.W) off = fmax(off, fx - b.W);
+      if (fy > b.H) off = fmax(off, fy - b.H);
+      cx = min(max(cx, 0), b.W - 1);
+      cy = min(max(cy, 0), b.H - 1);
+      const int mmax = max(b.W, b.H);
+      const int sk = static_cast<int>(skip[cy * b.W + cx]);
+      // cells closer (Chebyshev) than sk are empty: the first ring is sk, and
+      // nothing is closer than (sk - 1 - off) cells
+      int pm = sk - 1;           // half-width of the block known to be empty / visited
+      int m = max(1, sk);
+      double best = DBL_MAX;
+      bool active = live && !(isnan(fx) || isnan(fy));
+      if ((static_cast<double>(pm) - off) * b.g >= b.cap) active = false;  // all of it costs 0
+      // lanes with an empty neighbourhood wait for the cooperative pass below
+      bool far = active && sk >= kCoopMinSkip && sk < 255;
+      if (far) active = false;
+      // bracket of this point's distance from the centre table (off == 0: the
+      // point lies in its cell): within half a cell diagonal of the centre's
+      double lb0 = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
+      double ubp = DBL_MAX;
+      if (far && use_dc && off == 0.0) {
+        const int ix = min(max(static_cast<int>((static_cast<double>(x) - b.gx0) * t.inv_g), 0), t.W - 1);
+        const int iy = min(max(static_cast<int>((static_cast<double>(y) - b.gy0) * t.inv_g), 0), t.H - 1);
+        const float dcv = t.dc[iy * t.W + ix];
+        if (dcv > 3.0e38f) {
+          far = false;  // farther than the cap: costs nothing
+        } else {
+          const double hh = t.h + 1e-4 + static_cast<double>(dcv) * 1e-6;
+          lb0 = fmax(lb0, static_cast<double>(dcv) - hh);
+          ubp = static_cast<double>(dcv) + hh;
+        }
+      }
+      while (__ballot(active)) {
+        if (active) {
+          const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+          const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+          for (int row = y0; row <= y1; ++row) {
+            // rows inside the visited block only add the two side runs
+            const bool inner = pm >= 0 && row >= cy - pm && row <= cy + pm;
+            int beg = cells[row * b.W + x0];
+            int end = inner ? cells[row * b.W + max(cx - pm, x0)]
+                            : cells[row * b.W + x1 + 1];
+            for (int pass = 0; pass < 2; ++pass) {
+              for (int jb = beg; jb < end; jb += 4) {
+                float ox[4], oy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const int j = min(jb + u, end - 1);  // repeats of the last one change nothing
+                  ox[u] = obx[j];
+                  oy[u] = oby[j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const double dx = static_cast<double>(ox[u] - x);
+                  const double dy = static_cast<double>(oy[u] - y);
+                  const double dd = dx * dx + dy * dy;
+                  best = dd < best ? dd : best;
+                }
+              }
+              if (!inner) break;
+              beg = cells[row * b.W + min(cx + pm, x1) + 1];
+              end = cells[row * b.W + x1 + 1];
+            }
+          }
+          atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(best)));
+        }
+        // (all lanes: the LDS queue of a wavefront is in order, the read sees every lane's minimum)
+        const double shared = __longlong_as_double(static_cast<long long>(
+            *const_cast<volatile unsigned long long *>(obest)));
+        if (active) {
+          // every obstacle closer than `reach` (true distance) was visited
+          const double reach = (static_cast<double>(m) - off) * b.g;
+          bool done = m >= mmax;  // whole grid visited
+          if (reach > 0.0) {
+            const double r2 = reach * reach * (1.0 - 1e-6);
+            if (shared < r2) done = true;
+            if (reach >= b.cap) done = true;
+          }
+          if (done) {
+            active = false;
+          } else {
+            // next half-width: enough cells to cover sqrt(shared) (+ guard),
+            // or the cap radius when nothing has been found yet (any
+            // over-estimate only visits more cells: float sqrt is enough)
+            const double need =
+                shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
+                                 : b.cap;
+            const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
+            pm = m;
+            m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
+          }
+        }
+      }
+      // Far obstacles (points with an empty neighbourhood of kCoopMinSkip
+      // cells): a private ring walk per lane is long and mostly wasted,
+      // because only the trajectory minimum counts and the distance to the
+      // obstacle set is 1-Lipschitz along the trajectory.  After the near
+      // points have left their distances in the shared bound, the wavefront
+      // evaluates the far points one at a time TOGETHER (ring rows over the
+      // lanes), always the one with the smallest lower bound, and every exact
+      // distance raises the lower bounds of the others by the triangle
+      // inequality; points whose bound exceeds the best distance found are
+      // never evaluated.  The values that survive are exact, so the minimum
+      // is the one of the full scan.
+      if (__ballot(far)) {
+        // lower bound of this lane's distance (cells nearer than sk are empty;
+        // the centre table when there is one)
+        double lbk = lb0;
+        {
+          // the smallest upper bound bounds the trajectory minimum: points whose
+          // lower bound lies above it are never evaluated
+          const double u = wave_min_nonneg(far ? ubp : DBL_MAX);
+          if (u < 1.0e150) ubound2 = fmin(ubound2, u * u);
+        }
+        for (int guard = 0; guard < 64; ++guard) {
+          const double ub2 = fmin(ubound2, __longlong_as_double(static_cast<long long>(
+              *const_cast<volatile unsigned long long *>(obest))));
+          // lanes that can still lower the minimum
+          const bool cont = far && lbk * lbk < ub2 * (1.0 - 1e-6) && lbk < b.cap;
+          const unsigned long long cm = __ballot(cont);
+          if (cm == 0ull) break;
+          // the one with the smallest lower bound (float key, ties by lane)
+          const uint32_t key = cont ? __float_as_uint(static_cast<float>(lbk)) : 0xFFFFFFFFu;
+          const uint32_t kmin = wave_min_u32(key);
+          const int q = __ffsll(static_cast<long long>(__ballot(cont && key == kmin))) - 1;
+          const float xq = lane_value(x, q), yq = lane_value(y, q);
+          const int cxq = __builtin_amdgcn_readlane(cx, q), cyq = __builtin_amdgcn_readlane(cy, q);
+          const int skq = __builtin_amdgcn_readlane(sk, q);
+          const double offq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(off), q),
+                                               __builtin_amdgcn_readlane(__double2loint(off), q));
+          // exact search for (xq, yq): ring rows over the lanes; with a bound on
+          // the answer the first block is already the one that proves it
+          int pmq = skq - 1, mq = max(1, skq);
+          if (ub2 < 1.0e300) {
+            const double need0 = static_cast<double>(__builtin_sqrtf(static_cast<float>(ub2)) * 1.0001f);
+            const double mm0 = ceil(fmin(need0, b.cap * 1.001) * b.inv_g + offq) + 1.0;
+            mq = max(mq, static_cast<int>(fmin(mm0, static_cast<double>(mmax))));
+          }
+          double found = DBL_MAX;   // wave-uniform after every stage
+          double proven = 0.0;      // everything closer than this was visited
+          for (;;) {
+            const int y0 = max(cyq - mq, 0), y1 = min(cyq + mq, b.H - 1);
+            const int x0 = max(cxq - mq, 0), x1 = min(cxq + mq, b.W - 1);
+            double part = DBL_MAX;
+            for (int row = y0 + lane; row <= y1; row += 64) {
+              const bool inner = pmq >= 0 && row >= cyq - pmq && row <= cyq + pmq;
+              int beg = cells[row * b.W + x0];
+              int end = inner ? cells[row * b.W + max(cxq - pmq, x0)] : cells[row * b.W + x1 + 1];
+              for (int pass = 0; pass < 2; ++pass) {
+                for (int j = beg; j < end; ++j) {
+                  const double dx = static_cast<double>(obx[j] - xq);
+                  const double dy = static_cast<double>(oby[j] - yq);
+                  const double dd = dx * dx + dy * dy;
+                  part = dd < part ? dd : part;
+                }
+                if (!inner) break;
+                beg = cells[row * b.W + min(cxq + pmq, x1) + 1];
+                end = cells[row * b.W + x1 + 1];
+              }
+            }
+            const double stage = wave_min_nonneg(part);
+            found = stage < found ? stage : found;
+            const double sh = found < ub2 ? found : ub2;
+            const double reach = (static_cast<double>(mq) - offq) * b.g;
+            bool done = mq >= mmax;
+            if (reach > 0.0) {
+              proven = reach;
+              if (sh < reach * reach * (1.0 - 1e-6)) done = true;
+              if (reach >= b.cap) done = true;
+            }
+            if (done) break;
+            const double need = sh < DBL_MAX
+                                    ? static_cast<double>(__builtin_sqrtf(static_cast<float>(sh)) * 1.0001f)
+                                    : b.cap;
+            const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + offq) + 1.0;
+            pmq = mq;
+            mq = max(mq + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
+          }
+          if (lane == 0)
+            atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(found)));
+          // what is now known about the distance of point q: it is `found` when
+          // that lies inside the proven radius, at least the proven radius
+          // otherwise (the whole grid visited: nothing else exists)
+          double dq = kc::dsqrt_rn(found);
+          if (!(found < proven * proven) && mq < mmax) dq = proven;
+          if (lane == q) far = false;
+          // triangle inequality: d(p) >= d(q) - |p - q| (slack for the rounding)
+          const double ddx = static_cast<double>(x) - static_cast<double>(xq);
+          const double ddy = static_cast<double>(y) - static_cast<double>(yq);
+          const double sep = kc::dsqrt_rn(ddx * ddx + ddy * ddy);
+          const double lb = dq * (1.0 - 1e-6) - sep * (1.0 + 1e-6) - 1e-9;
+          lbk = lb > lbk ? lb : lbk;
+        }
+      }
+    }
+    if (st) KC_STAMP(12);
+    // ordered path-cost sum of this tile (pathCostFunc, cost_evaluator.cpp:111-141)
+    if (a.use_seg) {
+      const int cnt = min(64, a.P - p0);
+      for (int k = 0; k < cnt; ++k) sum += lane_value(mind, k);
+      if (p0 + 64 >= a.P) {
+        goal = lane_value(goal_l, a.P - 1 - p0);
+        endc = lane_value(end_l, a.P - 1 - p0);
+      }
+    }
+  }
+  // ---- weighted total (uniform over the wavefront) ---------------------------
+  float total = 0.0f;
+  if (a.ref_len > 0.0f) {
+    if (a.w_goal > 0.0) total = accum(total, a.w_goal, goal);
+    if (a.w_path > 0.0) {
+      const float c = kc::div_rn(
+          kc::div_rn(sum, static_cast<float>(a.P)) + endc, 2.0f);
+      total = accum(total, a.w_path, c);
+    }
+  }
+  if (a.O > 0 && a.w_obs > 0.0)
+    total = accum(total, a.w_obs,
+                  obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(
+                                            *const_cast<volatile unsigned long long *>(obest)))));
+  if (a.have_vel) total = add_velocity_costs(a, n, total);
+  // constant-velocity samples: both terms are exactly 0 and `total += w*0`
+  // leaves total unchanged, so nothing to do when !have_vel.
+  return total;
+}
 
 // kLds: the tracked segment (+ chunk spheres), the bucket cell table and the
 // skip table are copied into LDS once per workgroup; kObsLds: the obstacle
@@ -486,10 +928,6 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   const float4 *const l_pts = reinterpret_cast<const float4 *>(l_seg);
   const float *const cap = kLds ? l_seg + 4 * a.S : a.sx + 5 * a.S;  // [8][nch]
   const float *const sup = cap + 8 * a.nch;                          // [4][nsup]
-  auto seg_pt = [&](int j) -> float4 {  // (x, y, z^2, -) of segment point j
-    if (kLds) return l_pts[j];
-    return make_float4(a.sx[j], a.sy[j], a.szz[j], 0.0f);
-  };
   const bool use_dc = t.dc != nullptr && *t.enable != 0;
   const float sz_end = (a.use_seg && a.S > 0) ? a.sz[a.S - 1] : 0.0f;  // z of the last segment point (end term)
   if (threadIdx.x == 0) {
@@ -532,409 +970,19 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
     const int i = slot * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
     if (i >= na) break;
     const int n = a.adm_list[i];
-    if (lane == 0) s_obest[wave] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
-    float sum = 0.0f;            // ordered path-cost sum, carried over the point tiles
-    float goal = 0.0f, endc = 0.0f;
-    double ubound2 = DBL_MAX;    // square of an upper bound of the sample's obstacle distance (not attained)
-    for (int p0 = 0; p0 < a.P; p0 += 64) {
-      const int pp = p0 + lane;
-      const bool live = pp < a.P;
-      const int p = live ? pp : a.P - 1;  // idle lanes shadow the last point, write nothing
-      const float x = a.px[(size_t)n * a.P + p], y = a.py[(size_t)n * a.P + p];
-      float mind = 0.0f, goal_l = 0.0f, end_l = 0.0f;
+    const RowPts pts{a.px + (size_t)n * a.P, a.py + (size_t)n * a.P};
 #ifdef KC_PHASE_STAMPS
-      const bool st = a.dbg && i == static_cast<int>(blockIdx.x) && p0 == 0;  // first sample of wavefront 0
+    const bool stamp = a.dbg && i == static_cast<int>(blockIdx.x);  // first sample of wavefront 0
 #else
-      constexpr bool st = false;
+    constexpr bool stamp = false;
 #endif
-      if (st) KC_STAMP(7);
-      if (a.use_seg) {
-        float best = FLT_MAX;
-        int arg = 0;
-        const int sup_pts = 8 * a.seg_chunk;
-        // (1) the first point of every super-chunk: ascending index, strict `<`
-        for (int s = 0; s < a.nsup; ++s) {
-          const int j = s * sup_pts;
-          const float4 q = seg_pt(j);
-          const float dx = q.x - x;
-          const float dy = q.y - y;
-          const float xx = dx * dx;
-          const float yy = dy * dy;
-          const float dd = xx + (yy + q.z);  // Eigen order a + (b + c)
-          if (dd < best) {
-            best = dd;
-            arg = j;
-          }
-        }
-        // (2) super-chunks that may hold something at least as close:
-        // |q - c| - r <= thr on the squares; 1e-4 relative slack on the bound,
-        // 1e-5 on the compared square (NaN compares false: qualifies)
-        float thr = __builtin_sqrtf(best) * 1.0001f;
-        unsigned smask = 0u;
-        for (int s = 0; s < a.nsup; ++s) {
-          const float dx = sup[s] - x, dy = sup[a.nsup + s] - y, dz = sup[2 * a.nsup + s];
-          const float d2 = dx * dx + dy * dy + dz * dz;
-          const float lim = thr + sup[3 * a.nsup + s];
-          if (!(d2 > lim * lim * 1.00001f)) smask |= 1u << s;
-        }
-        if (st) KC_STAMP(8);
-        // (3) the first points of their other chunks
-        for (unsigned m = smask; m;) {
-          const int s = __ffs(static_cast<int>(m)) - 1;
-          m &= m - 1u;
-#pragma unroll
-          for (int u = 1; u < 8; ++u) {
-            const int c = s * 8 + u;
-            const int j = min(c, a.nch - 1) * a.seg_chunk;  // a repeat of the last chunk changes nothing
-            const float4 q = seg_pt(j);
-            const float dx = q.x - x;
-            const float dy = q.y - y;
-            const float xx = dx * dx;
-            const float yy = dy * dy;
-            const float dd = xx + (yy + q.z);
-            if (dd < best || (dd == best && j < arg)) {
-              best = dd;
-              arg = j;
-            }
-          }
-        }
-        // (4) capsule test of their chunks: distance to the chord minus the
-        // largest deviation of the chunk's points from it
-        thr = __builtin_sqrtf(best) * 1.0001f;
-        unsigned long long cand = 0ull;
-        for (unsigned m = smask; m;) {
-          const int s = __ffs(static_cast<int>(m)) - 1;
-          m &= m - 1u;
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int c = min(s * 8 + u, a.nch - 1);
-            const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
-            const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
-            float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
-            const float d2 = ex * ex + ey * ey + ez * ez;
-            const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
-            if (!(d2 > lim * lim * 1.0001f)) cand |= 1ull << c;
-          }
-        }
-        if (st) KC_STAMP(9);
-        // (5) the remaining points of those chunks
-        while (cand) {
-          const int c = __ffsll(static_cast<long long>(cand)) - 1;
-          cand &= cand - 1ull;
-          const int j0 = c * a.seg_chunk;
-          const int j1 = min(j0 + a.seg_chunk, a.S);
-          // five points per batch: their LDS reads are in flight together
-          for (int jb = j0 + 1; jb < j1; jb += 5) {
-            float vx[5], vy[5], vz[5];
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-              const int j = min(jb + u, j1 - 1);
-              const float4 q = seg_pt(j);
-              vx[u] = q.x;
-              vy[u] = q.y;
-              vz[u] = q.z;
-            }
-#pragma unroll
-            for (int u = 0; u < 5; ++u) {
-              const int j = jb + u;
-              const float dx = vx[u] - x;
-              const float dy = vy[u] - y;
-              const float xx = dx * dx;
-              const float yy = dy * dy;
-              const float dd = xx + (yy + vz[u]);
-              if (j < j1 && (dd < best || (dd == best && j < arg))) {
-                best = dd;
-                arg = j;
-              }
-            }
-          }
-        }
-        if (st) KC_STAMP(10);
-        mind = kc::sqrt_rn(best);
-        if (pp == a.P - 1) {
-          // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
-          const float acc_arg = kLds ? l_pts[arg].w : a.acc_seg[arg];
-          const float arc = kc::div_rn(a.ref_len - acc_arg, a.ref_len);
-          goal_l = arc + kc::div_rn(mind, a.ref_len);
-          // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
-          const int e = a.S - 1;
-          const float4 qe = seg_pt(e);
-          const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
-          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-          end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
-        }
-      }
-      if (st) KC_STAMP(11);
-      if (a.use_obs) {
-        // query cell (clamped: a query outside the grid searches from the
-        // border and the guarantee radius shrinks by its distance to the grid)
-        const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-        const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-        int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-        double off = 0.0;
-        if (fx < 0.0) off = fmax(off, -fx);
-        if (fy < 0.0) off = fmax(off, -fy);
-        if (fx > b.W) off = fmax(off, fx - b.W);
-        if (fy > b.H) off = fmax(off, fy - b.H);
-        cx = min(max(cx, 0), b.W - 1);
-        cy = min(max(cy, 0), b.H - 1);
-        const int mmax = max(b.W, b.H);
-        const int sk = static_cast<int>(skip[cy * b.W + cx]);
-        // cells closer (Chebyshev) than sk are empty: the first ring is sk, and
-        // nothing is closer than (sk - 1 - off) cells
-        int pm = sk - 1;           // half-width of the block known to be empty / visited
-        int m = max(1, sk);
-        double best = DBL_MAX;
-        bool active = live && !(isnan(fx) || isnan(fy));
-        if ((static_cast<double>(pm) - off) * b.g >= b.cap) active = false;  // all of it costs 0
-        // lanes with an empty neighbourhood wait for the cooperative pass below
-        bool far = active && sk >= kCoopMinSkip && sk < 255;
-        if (far) active = false;
-        // bracket of this point's distance from the centre table (off == 0: the
-        // point lies in its cell): within half a cell diagonal of the centre's
-        double lb0 = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
-        double ubp = DBL_MAX;
-        if (far && use_dc && off == 0.0) {
-          const int ix = min(max(static_cast<int>((static_cast<double>(x) - b.gx0) * t.inv_g), 0), t.W - 1);
-          const int iy = min(max(static_cast<int>((static_cast<double>(y) - b.gy0) * t.inv_g), 0), t.H - 1);
-          const float dcv = t.dc[iy * t.W + ix];
-          if (dcv > 3.0e38f) {
-            far = false;  // farther than the cap: costs nothing
-          } else {
-            const double hh = t.h + 1e-4 + static_cast<double>(dcv) * 1e-6;
-            lb0 = fmax(lb0, static_cast<double>(dcv) - hh);
-            ubp = static_cast<double>(dcv) + hh;
-          }
-        }
-        while (__ballot(active)) {
-          if (active) {
-            const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-            const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-            for (int row = y0; row <= y1; ++row) {
-              // rows inside the visited block only add the two side runs
-              const bool inner = pm >= 0 && row >= cy - pm && row <= cy + pm;
-              int beg = cells[row * b.W + x0];
-              int end = inner ? cells[row * b.W + max(cx - pm, x0)]
-                              : cells[row * b.W + x1 + 1];
-              for (int pass = 0; pass < 2; ++pass) {
-                for (int jb = beg; jb < end; jb += 4) {
-                  float ox[4], oy[4];
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) {
-                    const int j = min(jb + u, end - 1);  // repeats of the last one change nothing
-                    ox[u] = obx[j];
-                    oy[u] = oby[j];
-                  }
-#pragma unroll
-                  for (int u = 0; u < 4; ++u) {
-                    const double dx = static_cast<double>(ox[u] - x);
-                    const double dy = static_cast<double>(oy[u] - y);
-                    const double dd = dx * dx + dy * dy;
-                    best = dd < best ? dd : best;
-                  }
-                }
-                if (!inner) break;
-                beg = cells[row * b.W + min(cx + pm, x1) + 1];
-                end = cells[row * b.W + x1 + 1];
-              }
-            }
-            atomicMin(&s_obest[wave], static_cast<unsigned long long>(__double_as_longlong(best)));
-          }
-          // (all lanes: the LDS queue of a wavefront is in order, the read sees every lane's minimum)
-          const double shared = __longlong_as_double(static_cast<long long>(
-              *const_cast<volatile unsigned long long *>(&s_obest[wave])));
-          if (active) {
-            // every obstacle closer than `reach` (true distance) was visited
-            const double reach = (static_cast<double>(m) - off) * b.g;
-            bool done = m >= mmax;  // whole grid visited
-            if (reach > 0.0) {
-              const double r2 = reach * reach * (1.0 - 1e-6);
-              if (shared < r2) done = true;
-              if (reach >= b.cap) done = true;
-            }
-            if (done) {
-              active = false;
-            } else {
-              // next half-width: enough cells to cover sqrt(shared) (+ guard),
-              // or the cap radius when nothing has been found yet (any
-              // over-estimate only visits more cells: float sqrt is enough)
-              const double need =
-                  shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
-                                   : b.cap;
-              const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
-              pm = m;
-              m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-            }
-          }
-        }
-        // Far obstacles (points with an empty neighbourhood of kCoopMinSkip
-        // cells): a private ring walk per lane is long and mostly wasted,
-        // because only the trajectory minimum counts and the distance to the
-        // obstacle set is 1-Lipschitz along the trajectory.  After the near
-        // points have left their distances in the shared bound, the wavefront
-        // evaluates the far points one at a time TOGETHER (ring rows over the
-        // lanes), always the one with the smallest lower bound, and every exact
-        // distance raises the lower bounds of the others by the triangle
-        // inequality; points whose bound exceeds the best distance found are
-        // never evaluated.  The values that survive are exact, so the minimum
-        // is the one of the full scan.
-        if (__ballot(far)) {
-          // lower bound of this lane's distance (cells nearer than sk are empty;
-          // the centre table when there is one)
-          double lbk = lb0;
-          {
-            // the smallest upper bound bounds the trajectory minimum: points whose
-            // lower bound lies above it are never evaluated
-            const double u = wave_min_nonneg(far ? ubp : DBL_MAX);
-            if (u < 1.0e150) ubound2 = fmin(ubound2, u * u);
-          }
-          for (int guard = 0; guard < 64; ++guard) {
-            const double ub2 = fmin(ubound2, __longlong_as_double(static_cast<long long>(
-                *const_cast<volatile unsigned long long *>(&s_obest[wave]))));
-            // lanes that can still lower the minimum
-            const bool cont = far && lbk * lbk < ub2 * (1.0 - 1e-6) && lbk < b.cap;
-            const unsigned long long cm = __ballot(cont);
-            if (cm == 0ull) break;
-            // the one with the smallest lower bound (float key, ties by lane)
-            const uint32_t key = cont ? __float_as_uint(static_cast<float>(lbk)) : 0xFFFFFFFFu;
-            const uint32_t kmin = wave_min_u32(key);
-            const int q = __ffsll(static_cast<long long>(__ballot(cont && key == kmin))) - 1;
-            const float xq = lane_value(x, q), yq = lane_value(y, q);
-            const int cxq = __builtin_amdgcn_readlane(cx, q), cyq = __builtin_amdgcn_readlane(cy, q);
-            const int skq = __builtin_amdgcn_readlane(sk, q);
-            const double offq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(off), q),
-                                                 __builtin_amdgcn_readlane(__double2loint(off), q));
-            // exact search for (xq, yq): ring rows over the lanes; with a bound on
-            // the answer the first block is already the one that proves it
-            int pmq = skq - 1, mq = max(1, skq);
-            if (ub2 < 1.0e300) {
-              const double need0 = static_cast<double>(__builtin_sqrtf(static_cast<float>(ub2)) * 1.0001f);
-              const double mm0 = ceil(fmin(need0, b.cap * 1.001) * b.inv_g + offq) + 1.0;
-              mq = max(mq, static_cast<int>(fmin(mm0, static_cast<double>(mmax))));
-            }
-            double found = DBL_MAX;   // wave-uniform after every stage
-            double proven = 0.0;      // everything closer than this was visited
-            for (;;) {
-              const int y0 = max(cyq - mq, 0), y1 = min(cyq + mq, b.H - 1);
-              const int x0 = max(cxq - mq, 0), x1 = min(cxq + mq, b.W - 1);
-              double part = DBL_MAX;
-              for (int row = y0 + lane; row <= y1; row += 64) {
-                const bool inner = pmq >= 0 && row >= cyq - pmq && row <= cyq + pmq;
-                int beg = cells[row * b.W + x0];
-                int end = inner ? cells[row * b.W + max(cxq - pmq, x0)] : cells[row * b.W + x1 + 1];
-                for (int pass = 0; pass < 2; ++pass) {
-                  for (int j = beg; j < end; ++j) {
-                    const double dx = static_cast<double>(obx[j] - xq);
-                    const double dy = static_cast<double>(oby[j] - yq);
-                    const double dd = dx * dx + dy * dy;
-                    part = dd < part ? dd : part;
-                  }
-                  if (!inner) break;
-                  beg = cells[row * b.W + min(cxq + pmq, x1) + 1];
-                  end = cells[row * b.W + x1 + 1];
-                }
-              }
-              const double stage = wave_min_nonneg(part);
-              found = stage < found ? stage : found;
-              const double sh = found < ub2 ? found : ub2;
-              const double reach = (static_cast<double>(mq) - offq) * b.g;
-              bool done = mq >= mmax;
-              if (reach > 0.0) {
-                proven = reach;
-                if (sh < reach * reach * (1.0 - 1e-6)) done = true;
-                if (reach >= b.cap) done = true;
-              }
-              if (done) break;
-              const double need = sh < DBL_MAX
-                                      ? static_cast<double>(__builtin_sqrtf(static_cast<float>(sh)) * 1.0001f)
-                                      : b.cap;
-              const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + offq) + 1.0;
-              pmq = mq;
-              mq = max(mq + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-            }
-            if (lane == 0)
-              atomicMin(&s_obest[wave], static_cast<unsigned long long>(__double_as_longlong(found)));
-            // what is now known about the distance of point q: it is `found` when
-            // that lies inside the proven radius, at least the proven radius
-            // otherwise (the whole grid visited: nothing else exists)
-            double dq = kc::dsqrt_rn(found);
-            if (!(found < proven * proven) && mq < mmax) dq = proven;
-            if (lane == q) far = false;
-            // triangle inequality: d(p) >= d(q) - |p - q| (slack for the rounding)
-            const double ddx = static_cast<double>(x) - static_cast<double>(xq);
-            const double ddy = static_cast<double>(y) - static_cast<double>(yq);
-            const double sep = kc::dsqrt_rn(ddx * ddx + ddy * ddy);
-            const double lb = dq * (1.0 - 1e-6) - sep * (1.0 + 1e-6) - 1e-9;
-            lbk = lb > lbk ? lb : lbk;
-          }
-        }
-      }
-      if (st) KC_STAMP(12);
-      // ordered path-cost sum of this tile (pathCostFunc, cost_evaluator.cpp:111-141)
-      if (a.use_seg) {
-        const int cnt = min(64, a.P - p0);
-        for (int k = 0; k < cnt; ++k) sum += lane_value(mind, k);
-        if (p0 + 64 >= a.P) {
-          goal = lane_value(goal_l, a.P - 1 - p0);
-          endc = lane_value(end_l, a.P - 1 - p0);
-        }
-      }
-    }
-    // ---- weighted total (uniform over the wavefront) ---------------------------
-    float total = 0.0f;
-    if (a.ref_len > 0.0f) {
-      if (a.w_goal > 0.0) total = accum(total, a.w_goal, goal);
-      if (a.w_path > 0.0) {
-        const float c = kc::div_rn(
-            kc::div_rn(sum, static_cast<float>(a.P)) + endc, 2.0f);
-        total = accum(total, a.w_path, c);
-      }
-    }
-    if (a.O > 0 && a.w_obs > 0.0) {
-      // obstaclesDistCostFunc, cost_evaluator.cpp:179-184
-      const double best = __longlong_as_double(static_cast<long long>(
-          *const_cast<volatile unsigned long long *>(&s_obest[wave])));
-      const float min_d2 = static_cast<float>(best);
-      const float dist =
-          static_cast<float>(kc::dsqrt_rn(static_cast<double>(min_d2)));
-      float v = a.max_obs_dist - dist;
-      v = v < 0.0f ? 0.0f : v;
-      total = accum(total, a.w_obs, kc::div_rn(v, a.max_obs_dist));
-    }
-    if (a.have_vel) {
-      // caller-provided velocity profiles (kc_cost_evaluate): serial loops,
-      // evaluated redundantly by every lane (wave-uniform addresses)
-      const int nv = a.P - 1;
-      const float *vx = a.vvx + (size_t)n * nv;
-      const float *vy = a.vvy + (size_t)n * nv;
-      const float *om = a.vom + (size_t)n * nv;
-      const float div = static_cast<float>(3L * nv);
-      if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
-        float c = 0.0f;
-        for (int k = 1; k < nv; ++k) {
-          if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
-          if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
-          if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
-        }
-        total = accum(total, a.w_smooth, kc::div_rn(c, div));
-      }
-      if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
-        float c = 0.0f;
-        for (int k = 2; k < nv; ++k) {
-          if (a.acc0 > 0)
-            c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
-          if (a.acc1 > 0)
-            c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
-          if (a.acc2 > 0)
-            c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
-        }
-        total = accum(total, a.w_jerk, kc::div_rn(c, div));
-      }
-    }
-    // constant-velocity samples: both terms are exactly 0 and `total += w*0`
-    // leaves total unchanged, so nothing to do when !have_vel.
+    float total;
+    if (kLds)
+      total = wave_sample_total(a, t, use_dc, SegRecs{l_pts}, cap, sup, sz_end, cells, skip, obx, oby, pts,
+                                n, lane, &s_obest[wave], stamp);
+    else
+      total = wave_sample_total(a, t, use_dc, SegRows{a.sx, a.sy, a.szz, a.acc_seg}, cap, sup, sz_end,
+                                cells, skip, obx, oby, pts, n, lane, &s_obest[wave], stamp);
     if (lane == 0) a.costs[n] = total;
     if (i == static_cast<int>(blockIdx.x)) KC_STAMP(3);
     if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
@@ -1009,14 +1057,15 @@ __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
     const long long na_pub = err ? -1 : na;
     if (a.host_pub) {
       // zero-copy hand-off: the host polls the record.  No fence between the
-      // words: the fourth is a checksum over the other three (it includes the
-      // sequence number), so a half-arrived record is never accepted.
+      // words: the fourth is a mixing checksum over the others (record_check,
+      // kc_internal.h), so a half-arrived record is never accepted.
       const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
       volatile long long *hp = a.host_pub;
       hp[0] = fkey;
       hp[1] = w1;
       hp[2] = a.seq;
-      hp[3] = fkey ^ w1 ^ a.seq ^ 0x5bd1e9955bd1e995ll;
+      hp[4] = 0;  // no winner row in this record
+      hp[3] = record_check(fkey, w1, a.seq, 0);
     }
     a.result[R_KEY] = fkey;
     a.result[R_NADM] = na_pub;
@@ -1037,7 +1086,8 @@ __global__ void republish_kernel(const long long *result, long long *host_pub, l
   hp[0] = key;
   hp[1] = w1;
   hp[2] = seq;
-  hp[3] = key ^ w1 ^ seq ^ 0x5bd1e9955bd1e995ll;
+  hp[4] = 0;
+  hp[3] = record_check(key, w1, seq, 0);
 }
 
 // ordered compaction of the admissible flags (one workgroup): adm_list[i] =

@@ -1,0 +1,273 @@
+// Device functions of the single-launch controller cycle (the CycleTail form of
+// rollout_collide_kernel, kc_rollout_kernels.h): cost tables into LDS, cost of a
+// workgroup's survivors from the poses it still holds, arrival ticket + final
+// reduction by the workgroup that arrives last.  Part of kc_dwa.hip.
+//
+// Inter-workgroup visibility (MI355X: per-XCD L2s are not coherent with each
+// other): everything one workgroup hands to the last arriver -- its key, its
+// survivor mask, its best row -- is stored with agent-scope (sc1, write-through)
+// stores, every storing wave drains them (s_waitcnt vmcnt(0)) in front of the
+// workgroup barrier, ONE lane then takes the ticket with an agent-scope atomic
+// add, and the last arriver reads with agent-scope (sc1) loads behind its own
+// add and a workgroup barrier: the counter-ordered hand-off of
+// MI355X_MICROARCH.md ("Workgroup dispatch, XCD placement & inter-workgroup
+// visibility"), with no L2 write-back or invalidate on the critical path.
+#pragma once
+
+namespace kc {
+
+struct CycleTail;  // kc_rollout_kernels.h
+constexpr int kTeamMaxSurvivors = 8;  // up to here a workgroup costs its survivors two at a time,
+                                      // half its lanes each (eight per point); beyond, one per wavefront
+
+template <typename T>
+__device__ __forceinline__ void st_agent(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// LDS layout of the cost tables behind tab_off (the host sizes it the same way:
+// cycle_table_bytes in kc_dwa.hip)
+struct CycleTabs {
+  float4 *pts;      // [S] (x, y, z^2, accumulated length)
+  float *cap;       // [8][nch] capsules, then [4][nsup] spheres
+  int *cells;       // [ncell + 1]
+  uint8_t *skip;    // [ncell padded to 4]
+  float *mind;      // [2][P] team scratch
+};
+__device__ __forceinline__ CycleTabs cycle_tabs(const CostArgs &c, unsigned char *smem, unsigned tab_off) {
+  CycleTabs t;
+  const int ncell = c.b.W * c.b.H;
+  t.pts = reinterpret_cast<float4 *>(smem + tab_off);
+  t.cap = reinterpret_cast<float *>(t.pts + (c.use_seg ? c.S : 0));
+  t.cells = reinterpret_cast<int *>(t.cap + (c.use_seg ? 8 * c.nch + 4 * c.nsup : 0));
+  t.skip = reinterpret_cast<uint8_t *>(t.cells + (c.use_obs ? ncell + 1 : 0));
+  t.mind = reinterpret_cast<float *>(t.skip + (c.use_obs ? ((ncell + 3) & ~3) : 0));
+  return t;
+}
+
+template <class Tail>
+__device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned char *smem, int tid, int nthreads) {
+  const CostArgs &c = tail.c;
+  const CycleTabs t = cycle_tabs(c, smem, tail.tab_off);
+  if (c.use_seg) {
+#pragma unroll 2
+    for (int j = tid; j < c.S; j += nthreads) t.pts[j] = make_float4(c.sx[j], c.sy[j], c.szz[j], c.acc_seg[j]);
+    const float *gc = c.sx + 5 * c.S;
+    for (int j = tid; j < 8 * c.nch + 4 * c.nsup; j += nthreads) t.cap[j] = gc[j];
+  }
+  if (c.use_obs) {
+    const int ncell = c.b.W * c.b.H;
+#pragma unroll 4
+    for (int j = tid; j <= ncell; j += nthreads) t.cells[j] = c.b.cell_start[j];
+    // the skip table is padded to a multiple of 4 bytes on the host
+    const uint32_t *gs = reinterpret_cast<const uint32_t *>(c.b.skip);
+    uint32_t *ls = reinterpret_cast<uint32_t *>(t.skip);
+    for (int j = tid; j < (ncell + 3) / 4; j += nthreads) ls[j] = gs[j];
+  }
+}
+
+// Cost of the R survivors of this workgroup (slots lsurv[0..R), ascending).  Few
+// survivors: two at a time, half the workgroup each, eight lanes per point
+// (team_sample_search); many: one per wavefront, pulled from an LDS counter
+// (wave_sample_total).  Same arithmetic as the stand-alone cost kernels.  Returns
+// the workgroup's best key (uniform) and the slot of that sample.
+template <int kSamples, int kBlock, class Tail>
+__device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &tail, unsigned char *smem,
+                                                 const double2 *lpos, int PP, const int *lperm,
+                                                 const int *lsurv, int R, int tid, int *best_slot) {
+  const CostArgs &c = tail.c;
+  __shared__ long long s_key;
+  __shared__ unsigned long long s_ob[kBlock / 64];
+  __shared__ float s_goal[2], s_end[2];
+  __shared__ int s_next, s_bslot;
+  const CycleTabs t = cycle_tabs(c, smem, tail.tab_off);
+  const float sz_end = (c.use_seg && c.S > 0) ? c.sz[c.S - 1] : 0.0f;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid == 0) {
+    s_key = KEY_NONE;
+    s_next = 0;
+    s_bslot = -1;
+  }
+  const SegRecs seg{t.pts};
+  if (R <= kTeamMaxSurvivors) {
+    constexpr int kTeam = kBlock / 2;
+    const int h = tid / kTeam, tt = tid - h * kTeam;
+    for (int it = 0; 2 * it < R; ++it) {
+      const int q = 2 * it + h;
+      const bool active = q < R;
+      if (tt == 0) s_ob[h] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
+      __syncthreads();  // (first pass: also s_key)
+      const int s = active ? lsurv[q] : 0;
+      const PosePts pts{lpos + s * PP, a.x0, a.y0};
+      if (active)
+        team_sample_search<kTeam>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
+                                  t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h]);
+      __syncthreads();
+      if (active && tt < 64) {
+        const int n = lperm[s];
+        const float total = team_sample_total(c, n, lane, t.mind + h * c.P, s_goal[h], s_end[h], s_ob[h]);
+        if (lane == 0) {
+          c.costs[n] = total;
+          if (total < FLT_MAX)  // `total_cost < minCost`, minCost starts at FLT_MAX
+            atomicMin(&s_key, key_pack(total, static_cast<uint32_t>(c.first + n)));
+        }
+      }
+    }
+  } else {
+    __syncthreads();  // s_next, s_key
+    const bool use_dc = tail.t.dc != nullptr && *tail.t.enable != 0;
+    const float *cap = t.cap, *sup = t.cap + 8 * c.nch;
+    long long wkey = KEY_NONE;
+    for (;;) {
+      int q = 0;
+      if (lane == 0) q = atomicAdd(&s_next, 1);
+      q = __builtin_amdgcn_readfirstlane(q);
+      if (q >= R) break;
+      const int s = lsurv[q];
+      const int n = lperm[s];
+      const PosePts pts{lpos + s * PP, a.x0, a.y0};
+      const float total = wave_sample_total(c, tail.t, use_dc, seg, cap, sup, sz_end, t.cells, t.skip,
+                                            c.b.bx, c.b.by, pts, n, lane, &s_ob[wave], false);
+      if (lane == 0) c.costs[n] = total;
+      if (total < FLT_MAX) {
+        const long long k = key_pack(total, static_cast<uint32_t>(c.first + n));
+        wkey = k < wkey ? k : wkey;
+      }
+    }
+    if (lane == 0 && wkey != KEY_NONE) atomicMin(&s_key, wkey);
+  }
+  __syncthreads();
+  const long long key = s_key;
+  if (key != KEY_NONE && tid < R) {
+    const int s = lsurv[tid];
+    if (static_cast<uint32_t>(c.first + lperm[s]) == static_cast<uint32_t>(key & 0xFFFFFFFFll)) s_bslot = s;
+  }
+  __syncthreads();
+  *best_slot = s_bslot;
+  return key;
+}
+
+// Arrival ticket; the workgroup that arrives last publishes the cycle.
+template <int kBlock, class Tail>
+__device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &tail, long long key,
+                                               unsigned long long mask, int best_slot,
+                                               const double2 *best_row, const int *lperm, int tid) {
+  const int P = a.P;
+  const unsigned b = blockIdx.x, G = gridDim.x;
+  __shared__ int s_last, s_bw;
+  __shared__ long long s_wkey[kBlock / 64];
+  __shared__ int s_wadm[kBlock / 64], s_wcnt[kBlock / 64];
+  __shared__ unsigned int s_rowx;
+  // this workgroup's best row: the floats the roll-out would have stored
+  if (best_slot >= 0) {
+    uint32_t *dst = tail.best_rows + (size_t)b * 2 * P;
+    for (int k = tid; k < 2 * P; k += kBlock) {
+      const int p = k < P ? k : k - P;
+      const double v = p == 0 ? (k < P ? a.x0 : a.y0) : (k < P ? best_row[p - 1].x : best_row[p - 1].y);
+      st_agent(dst + k, __float_as_uint(static_cast<float>(v)));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+  __syncthreads();
+  if (tid == 0) {
+    st_agent(tail.block_keys + b, key);
+    st_agent(tail.masks + b, mask);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t = __hip_atomic_fetch_add(
+        reinterpret_cast<unsigned long long *>(tail.result + W_TICKET), 1ull, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == static_cast<unsigned long long>(G) - 1ull) ? 1 : 0;
+    s_bw = -1;
+    s_rowx = 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- last arriver: every other workgroup's stores are behind its ticket ----
+  const int lane = tid & 63, wave = tid >> 6;
+  long long k = KEY_NONE;
+  int nadm = 0;
+  for (unsigned g = tid; g < G; g += kBlock) {
+    const long long v = ld_agent(tail.block_keys + g);
+    k = v < k ? v : k;
+    nadm += __popcll(ld_agent(tail.masks + g));
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(k, off, 64);
+    k = o < k ? o : k;
+    nadm += __shfl_xor(nadm, off, 64);
+  }
+  if (lane == 0) {
+    s_wkey[wave] = k;
+    s_wadm[wave] = nadm;
+  }
+  __syncthreads();
+  long long fkey = s_wkey[0];
+  int na = s_wadm[0];
+  for (int w = 1; w < kBlock / 64; ++w) {
+    fkey = s_wkey[w] < fkey ? s_wkey[w] : fkey;
+    na += s_wadm[w];
+  }
+  // the reference's index counts the admissible samples in front of the winner
+  // (generation order = local sample id order); slot j of workgroup g is entry
+  // g + j * G of the row-ordered view
+  int cnt = 0;
+  if (fkey != KEY_NONE) {
+    const int lim = static_cast<int>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
+    for (unsigned g = tid; g < G; g += kBlock) {
+      if (ld_agent(tail.block_keys + g) == fkey) s_bw = static_cast<int>(g);  // one owner: indices are unique
+      unsigned long long m = ld_agent(tail.masks + g);
+      while (m) {
+        const int j = __ffsll(static_cast<long long>(m)) - 1;
+        m &= m - 1ull;
+        cnt += a.perm[g + static_cast<unsigned>(j) * G] < lim ? 1 : 0;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  if (lane == 0) s_wcnt[wave] = cnt;
+  __syncthreads();
+  // winner row -> pinned host memory, with a running xor the host checks
+  if (fkey != KEY_NONE && tail.host_row) {
+    const uint32_t *src = tail.best_rows + (size_t)s_bw * 2 * P;
+    unsigned int x = 0u;
+    for (int q = tid; q < 2 * P; q += kBlock) {
+      const uint32_t v = ld_agent(src + q);
+      tail.host_row[q] = v;
+      x ^= v * (2u * static_cast<unsigned>(q) + 1u);
+    }
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if (lane == 0 && x) atomicXor(&s_rowx, x);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int s = 0;
+    for (int w = 0; w < kBlock / 64; ++w) s += s_wcnt[w];
+    if (fkey == KEY_NONE) s = -1;
+    const long long err = static_cast<long long>(ld_agent(reinterpret_cast<const unsigned long long *>(a.dev_err)));
+    const long long na_pub = err ? -1 : na;
+    const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
+    const long long w4 = (static_cast<long long>(s_rowx) << 1) | (fkey != KEY_NONE && tail.host_row ? 1 : 0);
+    if (tail.host_pub) {
+      volatile long long *hp = tail.host_pub;
+      hp[0] = fkey;
+      hp[1] = w1;
+      hp[2] = tail.seq;
+      hp[4] = w4;
+      hp[3] = record_check(fkey, w1, tail.seq, w4);
+    }
+    tail.result[R_KEY] = fkey;
+    tail.result[R_NADM] = na_pub;
+    tail.result[R_COMPACT] = s;
+    tail.result[W_KEY] = KEY_NONE;
+    tail.result[W_NADM] = 0;   // device error word
+    tail.result[W_TICKET] = 0;
+    tail.result[W_LIST] = 0;
+  }
+}
+
+}  // namespace kc

@@ -21,9 +21,12 @@
 #include "kc_internal.h"
 #include "kc_pool.h"
 
+#include <type_traits>
+
 #include "kc_collision_dev.h"
-#include "kc_rollout_kernels.h"
 #include "kc_cost_kernels.h"
+#include "kc_cycle_dev.h"
+#include "kc_rollout_kernels.h"
 #include "kc_sensor_kernels.h"
 #include "kc_segment_kernels.h"
 
@@ -169,6 +172,22 @@ struct kc_dwa {
   PinBuf<float> h_row;         // winner row staging
   kc_result last{};
   bool have_last = false;
+
+  // single-launch cycle (CycleTail form of rollout_collide_kernel)
+  size_t lds_limit_hw = 64 * 1024;  // what the device grants (options toggle lds_limit / cost_lds_ok)
+  bool cost_lds_hw = false, large_bar = false;
+  bool write_paths = false;    // option "write_paths": the single-launch cycle stores the float rows too
+  bool cycle_fused = true;     // option "fused_cycle": kc_dwa_cycle may take the single launch
+  bool cycle_launched = false; // the last roll-out call was a whole cycle
+  bool paths_valid = true;     // d_px / d_py hold the rows of the last roll-out (a fused cycle
+                               // materialises them only on demand)
+  bool in_materialise = false;
+  kc_state last_start{};       // start pose of the last roll-out (re-materialisation)
+  DevBuf<unsigned long long> d_masks;  // survivor slots per workgroup
+  DevBuf<uint32_t> d_best_rows;        // best row per workgroup
+  PinBuf<uint32_t> h_wrow;             // winner row, written by the last workgroup
+  long long rec_w4 = 0;        // row word of the record fetched last
+  bool row_valid = false;      // h_wrow holds the winner row of `last`
 };
 
 namespace {
@@ -984,33 +1003,18 @@ int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
   return KC_OK;
 }
 
-int run_evaluate(kc_dwa *c, size_t n, size_t first) {
+// argument blocks of the cost stage (stand-alone kernels and the cycle tail)
+int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt) {
   const size_t P = c->P;
-  hipStream_t s = c->stream;
-  if (n == 0) {  // empty batch: publish "nothing found"
-    hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, s,
-                       c->d_result.p);
-    c->pub_pending = false;
-    return KC_OK;
-  }
-  if (n > 1024u * kCompactMaxPer)
-    KC_FAIL(KC_ERR_RANGE, "more than %d samples per context", 1024 * kCompactMaxPer);
   const bool use_path = c->ref_len > 0.0f &&
                         c->w.reference_path_distance_weight > 0.0;
   const bool use_goal = c->ref_len > 0.0f && c->w.goal_distance_weight > 0.0;
   if ((use_path || use_goal) && c->S == 0)
     KC_FAIL(KC_ERR_STATE, "tracked segment not set");
-
   const bool use_obs = c->O > 0 && c->w.obstacles_distance_weight > 0.0;
   const float *seg = c->d_seg.p;
   const size_t S = c->S;
-  if (c->need_compact) {  // split roll-out path / external samples
-    KC_TRY(c->timing.start("compact_kernel", s));
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, c->d_flags.p,
-                       static_cast<int>(n), c->d_adm.p, c->d_result.p + W_LIST);
-    KC_TRY(c->timing.stop(s));
-  }
-  CostArgs ca{};
+  ca = CostArgs{};
   ca.n = static_cast<int>(n);
   ca.first = static_cast<int>(first);
   ca.P = static_cast<int>(P);
@@ -1032,7 +1036,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.seg_chunk = c->seg_chunk;
   ca.nch = c->seg_nch;
   ca.nsup = c->seg_nsup;
-  DcArgs dt{};
+  dt = DcArgs{};
   dt.dc = c->have_dc ? c->d_dc.p : nullptr;
   dt.inv_g = c->dc_inv_g;
   dt.h = c->dc_h;
@@ -1056,6 +1060,31 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   ca.w_jerk = c->w.jerk_weight;
   ca.costs = c->d_costs.p;
   ca.result = c->d_result.p;
+  return KC_OK;
+}
+
+int run_evaluate(kc_dwa *c, size_t n, size_t first) {
+  const size_t P = c->P;
+  hipStream_t s = c->stream;
+  c->row_valid = false;
+  if (n == 0) {  // empty batch: publish "nothing found"
+    hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, s,
+                       c->d_result.p);
+    c->pub_pending = false;
+    return KC_OK;
+  }
+  if (n > 1024u * kCompactMaxPer)
+    KC_FAIL(KC_ERR_RANGE, "more than %d samples per context", 1024 * kCompactMaxPer);
+  CostArgs ca{};
+  DcArgs dt{};
+  KC_TRY(build_cost_args(c, n, first, ca, dt));
+  const size_t S = c->S;
+  if (c->need_compact) {  // split roll-out path / external samples
+    KC_TRY(c->timing.start("compact_kernel", s));
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, c->d_flags.p,
+                       static_cast<int>(n), c->d_adm.p, c->d_result.p + W_LIST);
+    KC_TRY(c->timing.stop(s));
+  }
   KC_TRY(c->d_block_keys.reserve(512));
   ca.block_keys = c->d_block_keys.p;
 #ifdef KC_PHASE_STAMPS
@@ -1072,8 +1101,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     // callers that never fetch (multi-GPU: the key is all-reduced on the
     // device) still leave the previous cycle's record in the pinned mirror
     volatile long long *hp = c->h_pub.p;
-    const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
-    if (w2 == c->seq && w3 == (w0 ^ w1 ^ w2 ^ 0x5bd1e9955bd1e995ll)) c->last_nadm = w1 >> 32;
+    const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3], w4 = hp[4];
+    if (w2 == c->seq && w3 == record_check(w0, w1, w2, w4)) c->last_nadm = w1 >> 32;
   }
   bool use_block = c->last_nadm >= 0 && c->last_nadm <= kBlockKernelMaxAdm;
   if (c->cost_kernel_force == 1) use_block = true;
@@ -1153,8 +1182,9 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
     volatile long long *hp = c->h_pub.p;
     const auto t0 = std::chrono::steady_clock::now();
     for (long spins = 0;; ++spins) {
-      const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3];
-      if (w2 == c->seq && w3 == (w0 ^ w1 ^ w2 ^ 0x5bd1e9955bd1e995ll)) {
+      const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3], w4 = hp[4];
+      if (w2 == c->seq && w3 == record_check(w0, w1, w2, w4)) {
+        c->rec_w4 = w4;
         c->h_result.p[0] = w0;
         c->h_result.p[1] = w1 >> 32;  // n_admissible (-1: device error)
         c->h_result.p[2] = static_cast<long long>(static_cast<int32_t>(w1 & 0xFFFFFFFFll));
@@ -1192,6 +1222,27 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
     r.cost = kc_key_cost(key);
     r.raw_index = kc_key_index(key);
     r.index = c->h_result.p[2];
+  }
+  // winner row of a single-launch cycle: arrives in pinned memory beside the
+  // record; its check word is part of the record (stores are not fenced: poll
+  // until the words add up, bounded)
+  c->row_valid = false;
+  if (got && r.found && (c->rec_w4 & 1) && c->h_wrow.p) {
+    const uint32_t want = static_cast<uint32_t>(static_cast<unsigned long long>(c->rec_w4) >> 1);
+    const size_t nw = 2 * c->P;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+      volatile uint32_t *row = c->h_wrow.p;
+      uint32_t x = 0u;
+      for (size_t q = 0; q < nw; ++q) x ^= row[q] * (2u * static_cast<uint32_t>(q) + 1u);
+      if (x == want) {
+        c->row_valid = true;
+        break;
+      }
+      if ((spins & 63) == 63 &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+        break;  // get_best falls back to the device copy
+    }
   }
   c->last = r;
   c->have_last = true;
@@ -1260,7 +1311,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
   c->stream = c->own_stream;
   (void)WorkerPool::instance();  // start the host workers now, not inside the first cycle
   int rc;
-  if ((rc = c->h_pub.reserve(8))) return fail(rc);
+  if ((rc = c->h_pub.reserve(8)) || (rc = c->h_wrow.reserve(2 * p->max_points))) return fail(rc);
   for (int i = 0; i < 8; ++i) c->h_pub.p[i] = 0;
   if ((rc = c->d_result.reserve(R_SLOTS)) ||
       (rc = c->h_result.reserve(R_SLOTS)) ||
@@ -1285,7 +1336,9 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<16, 512>));
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<32, 1024>));
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<64, 1024>));
+    optin(reinterpret_cast<const void *>(rollout_collide_kernel<32, 1024, CycleTail>));
     if (ok) c->lds_limit = 150 * 1024;
+    c->lds_limit_hw = c->lds_limit;
     c->cost_lds_ok =
         hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1300,6 +1353,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(kBlkLdsBudget)) == hipSuccess;
     if (!c->cost_lds_ok) (void)hipGetLastError();
+    c->cost_lds_hw = c->cost_lds_ok;
   }
   if (const char *e = std::getenv("KC_FUSED_CFG")) {  // tuning hook: "samples,threads"
     int sa = 0, th = 0;
@@ -1315,6 +1369,9 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       large_bar = 0;
     }
     c->trig_direct = large_bar != 0;
+    c->large_bar = large_bar != 0;
+    if (const char *e = std::getenv("KC_FUSED_CYCLE"))
+      if (e[0] == '0') c->cycle_fused = false;  // process default; option "fused_cycle" per context
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
@@ -1470,6 +1527,9 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_result.release();
   c->h_pub.release();
   c->h_row.release();
+  c->d_masks.release();
+  c->d_best_rows.release();
+  c->h_wrow.release();
   delete c;
 }
 
@@ -1485,6 +1545,63 @@ int kc_dwa_set_resolution(kc_dwa *c, double res) {
   if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
   if (!(res > 0.0)) KC_FAIL(KC_ERR_RANGE, "octree resolution must be > 0");
   c->res = res;
+  return KC_OK;
+}
+
+// per-context switches (header: kc_dwa_set_option)
+int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
+  if (!c || !name) KC_FAIL(KC_ERR_INVALID, "null argument");
+  KC_TRY(use_device(c));
+  // whatever is queued was built under the old settings
+  KC_HIP(hipStreamSynchronize(c->stream));
+  c->drained = true;
+  c->update_busy = false;
+  const std::string n(name);
+  const bool on = v != 0.0;
+  if (n == "fused_cycle") c->cycle_fused = on;
+  else if (n == "write_paths") c->write_paths = on;
+  else if (n == "cost_kernel") {
+    if (!(v == 0.0 || v == 1.0 || v == 2.0)) KC_FAIL(KC_ERR_RANGE, "cost_kernel: 0 auto, 1 workgroup per sample, 2 wavefront per sample");
+    c->cost_kernel_force = static_cast<int>(v);
+  } else if (n == "cost_dc_cells") {
+    if (v != 0.0 && !(v >= 8.0 && v <= 512.0)) KC_FAIL(KC_ERR_RANGE, "cost_dc_cells: 0 (off) or 8..512");
+    c->no_dc = v == 0.0;
+    if (!c->no_dc) c->dc_side = static_cast<int>(v);
+    c->have_dc = false;  // built by the next sensor update
+  } else if (n == "lazy_dilate") c->lazy_dilate = on;
+  else if (n == "early_launch") c->early_launch = on;
+  else if (n == "sensor_on_host") c->device_sensor = !on;
+  else if (n == "trig_copy") c->trig_direct = c->large_bar && !on;
+  else if (n == "force_split") {
+    c->lds_limit = on ? 0 : c->lds_limit_hw;
+    c->cost_lds_ok = on ? false : c->cost_lds_hw;
+  } else
+    KC_FAIL(KC_ERR_INVALID, "unknown option '%s'", name);
+  return KC_OK;
+}
+
+int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
+  if (!c || !name || !v) KC_FAIL(KC_ERR_INVALID, "null argument");
+  const std::string n(name);
+  if (n == "fused_cycle") *v = c->cycle_fused;
+  else if (n == "write_paths") *v = c->write_paths;
+  else if (n == "cost_kernel") *v = c->cost_kernel_force;
+  else if (n == "cost_dc_cells") *v = c->no_dc ? 0.0 : c->dc_side;
+  else if (n == "lazy_dilate") *v = c->lazy_dilate;
+  else if (n == "early_launch") *v = c->early_launch;
+  else if (n == "sensor_on_host") *v = !c->device_sensor;
+  else if (n == "trig_copy") *v = !c->trig_direct;
+  else if (n == "force_split") *v = c->lds_limit == 0;
+  else if (n == "last_cycle_single_launch") *v = c->cycle_launched;  // read-only
+  else if (n == "host_threads") *v = WorkerPool::instance().workers() + 1;  // read-only here: kc_set_host_threads
+  else
+    KC_FAIL(KC_ERR_INVALID, "unknown option '%s'", name);
+  return KC_OK;
+}
+
+int kc_set_host_threads(int n) {
+  if (n < 1 || n > 64) KC_FAIL(KC_ERR_RANGE, "host threads must be 1..64");
+  WorkerPool::instance().resize(n);
   return KC_OK;
 }
 
@@ -1953,7 +2070,24 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   return KC_OK;
 }
 
-int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
+}  // extern "C"
+
+namespace {
+// LDS bytes of the cost tables of the cycle tail (cycle_tabs, kc_cycle_dev.h)
+size_t cycle_table_bytes(const CostArgs &ca) {
+  size_t b = 0;
+  if (ca.use_seg)
+    b += 16 * static_cast<size_t>(ca.S) + 4 * (8 * static_cast<size_t>(ca.nch) + 4 * static_cast<size_t>(ca.nsup));
+  if (ca.use_obs) {
+    const size_t ncell = static_cast<size_t>(ca.b.W) * ca.b.H;
+    b += 4 * (ncell + 1) + ((ncell + 3) & ~size_t(3));
+  }
+  return b + 2 * static_cast<size_t>(ca.P) * 4;
+}
+
+// kc_dwa_rollout, or -- want_cycle -- the whole cycle in one launch when the
+// cost tables fit beside the roll-out tile (c->cycle_launched tells)
+int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   if (!c || !start) KC_FAIL(KC_ERR_INVALID, "null argument");
   if (P < 2 || P > c->prm.max_points)
     KC_FAIL(KC_ERR_RANGE, "num_points %zu outside [2, %zu]", P,
@@ -1966,12 +2100,15 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   // skipped; commands queued since then only read buffers this call leaves alone.
   if (!c->drained || c->timing.enabled) KC_HIP(hipStreamSynchronize(s));
   c->drained = false;
-  c->timing.begin_cycle();
+  if (!c->in_materialise) c->timing.begin_cycle();
   c->P = P;
   c->rolled = false;
   c->evaluated = false;
   c->external = false;
   c->have_vel = false;
+  c->cycle_launched = false;
+  c->paths_valid = true;
+  c->last_start = *start;
   const size_t n = c->shard_count;
   c->n_roll = n;
   if (n == 0) {
@@ -2035,8 +2172,13 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   a.adm_count = c->d_result.p + W_LIST;
   const bool may_collide = c->have_sensor && any_voxel(c);
   KC_TRY(window_geometry(c, start->x, start->y, cycle_reach(c), a.c));
+  // single-launch cycle: cost arguments up front (their checks must not fail
+  // behind a launched kernel)
+  CycleTail tail{};
+  bool cycle = want_cycle && c->cycle_fused && c->prm.shape != KC_SPHERE && n <= 1024u * kCompactMaxPer;
+  if (cycle) KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
-  const int fs = c->fused_samples, fb = c->fused_block;
+  const int fs = cycle ? 32 : c->fused_samples, fb = cycle ? 1024 : c->fused_block;
   const size_t pos_bytes = static_cast<size_t>(fs) * (P | 1) * sizeof(double2);
   size_t bits_bytes =
       (a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 * (a.c.dil ? 3 : 1) : 0) +
@@ -2061,18 +2203,23 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   }
   const bool fused = c->prm.shape != KC_SPHERE && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
-  c->need_compact = !fused;
+  const size_t tab_off = (pos_bytes + bits_bytes + 15) & ~size_t(15);
+  cycle = cycle && fused && tab_off + cycle_table_bytes(tail.c) + 2048 <= c->lds_limit;
+  if (want_cycle && !cycle && fused && (fs != c->fused_samples || fb != c->fused_block))
+    return rollout_impl(c, start, P, false);  // sized for the cycle shape: start over for the plain one
+  c->need_compact = !fused || cycle;
   // early launch: queue the fused kernel first and let launch + dispatch
   // latency run under the host's libm work (needs the BAR path for the table
   // and its sequence word; not while kernels are being timed, the wait would
   // be charged to the kernel)
   const bool early = fused && c->trig_direct && c->early_launch && !c->timing.enabled;
-  struct PoolJoin {  // an error return below must not leave the job running
-    ~PoolJoin() { WorkerPool::instance().wait(); }
+  struct PoolJoin {  // an error return below must not leave this call's job running
+    WorkerPool::Ticket ticket;
+    ~PoolJoin() { WorkerPool::instance().wait(ticket); }
   } pool_join;
   if (early) {
     // the workers produce the table while this thread queues the kernel
-    WorkerPool::instance().begin(A, 2, trig_rows);
+    pool_join.ticket = WorkerPool::instance().begin(A, 2, trig_rows);
   } else {
     WorkerPool::instance().parallel_for(A, 2, trig_rows);
     c->timing.mark("host:trig_table");
@@ -2093,27 +2240,56 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
       a.dbg = c->d_dbg2.p;
     }
 #endif
-    if (c->list_dirty)  // previous roll-out was never evaluated: re-arm the list
-      KC_HIP(hipMemsetAsync(c->d_result.p + W_LIST, 0, sizeof(long long), s));
-    c->list_dirty = true;
+    if (c->list_dirty)  // previous roll-out was never evaluated: re-arm the list (and the error word a
+                        // roll-out that gave up waiting may have left)
+      KC_HIP(hipMemsetAsync(c->d_result.p + W_NADM, 0, 3 * sizeof(long long), s));
+    c->list_dirty = !cycle;
     a.c.lds = 1;
+    if (cycle) {
+      const unsigned G = blocks_for(n, fs);
+      KC_TRY(c->d_block_keys.reserve(std::max<size_t>(512, G)));
+      KC_TRY(c->d_masks.reserve(G));
+      KC_TRY(c->d_best_rows.reserve(static_cast<size_t>(G) * 2 * P));
+      KC_TRY(c->h_wrow.reserve(2 * c->prm.max_points));
+      tail.tab_off = static_cast<unsigned>(tab_off);
+      tail.write_paths = c->write_paths ? 1 : 0;
+      tail.block_keys = c->d_block_keys.p;
+      tail.masks = c->d_masks.p;
+      tail.best_rows = c->d_best_rows.p;
+      tail.result = c->d_result.p;
+      tail.host_pub = c->h_pub.p;
+      tail.host_row = c->h_wrow.p;
+      tail.seq = ++c->seq;
+      tail.c.block_keys = c->d_block_keys.p;
+      a.dev_err = c->d_result.p + W_NADM;
+    }
     if (early) {
       a.trig_flag = c->d_result.p + R_TRIGSEQ;
       a.trig_seq = ++c->trig_seq;
       a.dev_err = c->d_result.p + W_NADM;
     }
-    KC_TRY(c->timing.start("rollout_collide_kernel", s));
+    KC_TRY(c->timing.start(cycle ? "cycle_kernel" : "rollout_collide_kernel", s));
     const dim3 grid(blocks_for(n, fs)), block(fb);
     const size_t smem = pos_bytes + bits_bytes;
-    if (fs == 16 && fb == 256) hipLaunchKernelGGL((rollout_collide_kernel<16, 256>), grid, block, smem, s, a);
-    else if (fs == 16 && fb == 512) hipLaunchKernelGGL((rollout_collide_kernel<16, 512>), grid, block, smem, s, a);
-    else if (fs == 32 && fb == 1024) hipLaunchKernelGGL((rollout_collide_kernel<32, 1024>), grid, block, smem, s, a);
-    else if (fs == 64 && fb == 1024) hipLaunchKernelGGL((rollout_collide_kernel<64, 1024>), grid, block, smem, s, a);
-    else hipLaunchKernelGGL((rollout_collide_kernel<32, 512>), grid, block, smem, s, a);
+    const NoTail nt{};
+    if (cycle)
+      hipLaunchKernelGGL((rollout_collide_kernel<32, 1024, CycleTail>), grid, block,
+                         tab_off + cycle_table_bytes(tail.c), s, a, tail);
+    else if (fs == 16 && fb == 256) hipLaunchKernelGGL((rollout_collide_kernel<16, 256>), grid, block, smem, s, a, nt);
+    else if (fs == 16 && fb == 512) hipLaunchKernelGGL((rollout_collide_kernel<16, 512>), grid, block, smem, s, a, nt);
+    else if (fs == 32 && fb == 1024) hipLaunchKernelGGL((rollout_collide_kernel<32, 1024>), grid, block, smem, s, a, nt);
+    else if (fs == 64 && fb == 1024) hipLaunchKernelGGL((rollout_collide_kernel<64, 1024>), grid, block, smem, s, a, nt);
+    else hipLaunchKernelGGL((rollout_collide_kernel<32, 512>), grid, block, smem, s, a, nt);
     KC_TRY(c->timing.stop(s));
+    if (cycle) {
+      c->cycle_launched = true;
+      c->paths_valid = c->write_paths;
+      c->pub_pending = true;
+      c->row_valid = false;
+    }
     c->timing.mark("host:launch_rollout");
     if (early) {
-      WorkerPool::instance().wait();
+      WorkerPool::instance().wait(pool_join.ticket);
       if (c->test_late_flag_ms > 0) {  // test hook: a host that does not deliver in time
         std::this_thread::sleep_for(std::chrono::milliseconds(c->test_late_flag_ms));
         c->test_late_flag_ms = 0;      // once
@@ -2159,7 +2335,36 @@ int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
   KC_HIP(hipGetLastError());
   c->timing.mark("host:launch_collision");
   c->rolled = true;
+  if (c->cycle_launched) c->evaluated = true;
   return KC_OK;
+}
+
+// the float rows of the last roll-out, when a single-launch cycle left them out:
+// the same roll-out again through the materialising kernel (same inputs, same
+// bits); costs and result of the cycle stay
+int materialise_paths(kc_dwa *c) {
+  if (c->paths_valid) return KC_OK;
+  const bool evaluated = c->evaluated, have_last = c->have_last, pub = c->pub_pending, row = c->row_valid;
+  const kc_result last = c->last;
+  const kc_state st = c->last_start;
+  if (c->pub_pending) KC_HIP(hipStreamSynchronize(c->stream));  // the cycle itself must be through
+  c->in_materialise = true;
+  const int rc = rollout_impl(c, &st, c->P, false);
+  c->in_materialise = false;
+  KC_TRY(rc);
+  c->evaluated = evaluated;
+  c->have_last = have_last;
+  c->last = last;
+  c->pub_pending = pub;
+  c->row_valid = row;
+  return KC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int kc_dwa_rollout(kc_dwa *c, const kc_state *start, size_t P) {
+  return rollout_impl(c, start, P, false);
 }
 
 int kc_dwa_check_poses(kc_dwa *c, const double *x, const double *y,
@@ -2205,6 +2410,8 @@ int kc_dwa_evaluate(kc_dwa *c) {
   if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
   if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
   KC_TRY(use_device(c));
+  KC_TRY(materialise_paths(c));
+  c->drained = false;  // queued work reads the per-update tables again
   KC_TRY(run_evaluate(c, c->n_roll, c->shard_first));
   c->timing.mark("host:launch_evaluate");
   c->evaluated = true;
@@ -2219,8 +2426,8 @@ int kc_dwa_fetch_result(kc_dwa *c, kc_result *out) {
 }
 
 int kc_dwa_cycle(kc_dwa *c, const kc_state *start, size_t P, kc_result *out) {
-  KC_TRY(kc_dwa_rollout(c, start, P));
-  KC_TRY(kc_dwa_evaluate(c));
+  KC_TRY(rollout_impl(c, start, P, true));
+  if (!c->cycle_launched) KC_TRY(kc_dwa_evaluate(c));
   return kc_dwa_fetch_result(c, out);
 }
 
@@ -2236,14 +2443,20 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
   if (local >= c->n_roll)
     KC_FAIL(KC_ERR_STATE, "winner %lld is not on this shard",
             static_cast<long long>(c->last.raw_index));
-  KC_TRY(c->h_row.reserve(2 * P));
-  KC_HIP(hipMemcpyAsync(c->h_row.p, c->d_px.p + local * P, P * sizeof(float),
-                        hipMemcpyDeviceToHost, c->stream));
-  KC_HIP(hipMemcpyAsync(c->h_row.p + P, c->d_py.p + local * P,
-                        P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  KC_HIP(hipStreamSynchronize(c->stream));
-  if (path_x) std::memcpy(path_x, c->h_row.p, P * sizeof(float));
-  if (path_y) std::memcpy(path_y, c->h_row.p + P, P * sizeof(float));
+  if (c->row_valid) {  // single-launch cycle: the row came with the record, no copy, no stream wait
+    if (path_x) std::memcpy(path_x, c->h_wrow.p, P * sizeof(float));
+    if (path_y) std::memcpy(path_y, c->h_wrow.p + P, P * sizeof(float));
+  } else {
+    KC_TRY(materialise_paths(c));
+    KC_TRY(c->h_row.reserve(2 * P));
+    KC_HIP(hipMemcpyAsync(c->h_row.p, c->d_px.p + local * P, P * sizeof(float),
+                          hipMemcpyDeviceToHost, c->stream));
+    KC_HIP(hipMemcpyAsync(c->h_row.p + P, c->d_py.p + local * P,
+                          P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    KC_HIP(hipStreamSynchronize(c->stream));
+    if (path_x) std::memcpy(path_x, c->h_row.p, P * sizeof(float));
+    if (path_y) std::memcpy(path_y, c->h_row.p + P, P * sizeof(float));
+  }
   if (vvx || vvy || vom) {
     if (c->external)
       KC_FAIL(KC_ERR_STATE, "velocities belong to the caller in evaluate mode");
@@ -2280,6 +2493,7 @@ int kc_dwa_get_samples(kc_dwa *c, float *paths_x, float *paths_y,
   if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
   if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
   KC_TRY(use_device(c));
+  if (paths_x || paths_y) KC_TRY(materialise_paths(c));
   const size_t n = c->n_roll, P = c->P;
   std::vector<uint8_t> flags(n);
   std::vector<float> hx, hy, hc;

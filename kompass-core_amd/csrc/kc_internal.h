@@ -213,6 +213,29 @@ __host__ __device__ inline int64_t key_pack(float cost, uint32_t index) {
   return static_cast<int64_t>((hi << 32) | static_cast<uint64_t>(index));
 }
 
+// ---- checksum of the pinned result record ----------------------------------
+// The device writes the record as separate 8-byte stores without fences; the
+// host accepts it when the sequence word matches and this word over (key,
+// packed counts, sequence, row word) does.  Each input goes through a multiply
+// / shift mix and a different rotation, so a record that mixes words of two
+// cycles cannot pass the way it could with a plain XOR (equal differences
+// cancelling).
+__host__ __device__ inline unsigned long long rec_mix(unsigned long long x) {
+  x *= 0x9E3779B97F4A7C15ull;
+  return x ^ (x >> 29);
+}
+__host__ __device__ inline unsigned long long rec_rot(unsigned long long x, int r) {
+  return (x << r) | (x >> (64 - r));
+}
+__host__ __device__ inline long long record_check(long long w0, long long w1, long long seq,
+                                                  long long w4 = 0) {
+  const unsigned long long c = rec_mix(static_cast<unsigned long long>(w0) + 0x5bd1e9955bd1e995ull) ^
+                               rec_rot(rec_mix(static_cast<unsigned long long>(w1) ^ 0x2545F4914F6CDD1Dull), 21) ^
+                               rec_rot(rec_mix(static_cast<unsigned long long>(seq)), 42) ^
+                               rec_rot(rec_mix(static_cast<unsigned long long>(w4) + 0x9E37ull), 11);
+  return static_cast<long long>(c);
+}
+
 // internal view of a mapper context for the grid hand-off (kc_dwa.hip)
 struct MapperView {
   const int *grid;

@@ -27,27 +27,42 @@ class WorkerPool {
     return pool;
   }
 
-  int workers() const { return static_cast<int>(threads_.size()); }
+  int workers() {
+    std::lock_guard<std::mutex> serial(run_mu_);
+    return static_cast<int>(threads_.size());
+  }
 
   // fn(begin, end) over [0, n) split into one contiguous chunk per thread; the
   // caller takes the first chunk.  Serial when n is small or no workers exist.
   // Asynchronous form: the workers take the whole range while the caller does
   // something else (e.g. a kernel launch); wait() returns when they are done.
   // Without workers the range is processed on the spot.  fn is copied.
+  // A ticket ties wait() to the begin() of the SAME caller: the pool is a
+  // process-wide singleton and several contexts may be driven from several
+  // threads, so the asynchronous state lives with the caller, not in the pool.
+  // begin() returns with run_mu_ held (one job at a time); wait(ticket) of the
+  // same thread joins the job and releases it.  A spent or empty ticket makes
+  // wait() a no-op, so a scope guard may call it again on any exit path.
+  struct Ticket {
+    uint64_t gen = 0;    // 0: nothing to wait for
+    bool self = false;   // the caller carries part 0 inside wait()
+  };
   template <typename F>
-  void begin(size_t n, size_t min_chunk, F fn) {
+  Ticket begin(size_t n, size_t min_chunk, F fn) {
+    Ticket t;
+    if (n == 0) return t;
+    run_mu_.lock();  // released by wait(t) on this thread (the worker set is stable while held)
+    if (threads_.empty()) {
+      run_mu_.unlock();
+      fn(size_t(0), n);
+      return t;
+    }
     // with a small pool the caller takes a share too (run inside wait(), after
     // whatever it does in between); with a large one its share would only delay
     // the result
     const size_t self = threads_.size() <= 3 ? 1 : 0;
     const size_t parts = std::min<size_t>(threads_.size() + self,
                                           min_chunk ? std::max<size_t>(n / min_chunk, 1) : n);
-    if (threads_.empty() || n == 0) {
-      if (n) fn(size_t(0), n);
-      async_gen_ = 0;
-      return;
-    }
-    async_lock_ = std::unique_lock<std::mutex>(run_mu_);  // one job at a time
     job_fn_ = [fn, n, parts, self](size_t part) {
       // worker w carries part w + 1; without a caller share the parts shift down
       const size_t q = part - (self ? 0 : 1);
@@ -55,33 +70,44 @@ class WorkerPool {
       if (b < e) fn(b, e);
     };
     job_parts_ = parts + (self ? 0 : 1);
-    async_self_ = self != 0;
     const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
     {
       std::lock_guard<std::mutex> lk(mu_);
       gen_.store(g, std::memory_order_release);
     }
     if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
-    async_gen_ = g;
+    t.gen = g;
+    t.self = self != 0;
+    return t;
   }
-  void wait() {
-    if (!async_gen_) return;
-    if (async_self_) job_fn_(0);
+  void wait(Ticket &t) {
+    if (!t.gen) return;
+    if (t.self) job_fn_(0);
     for (size_t w = 0; w < threads_.size(); ++w)
-      while (slots_[w].done.load(std::memory_order_acquire) != async_gen_) cpu_relax();
-    async_gen_ = 0;
-    async_lock_.unlock();
+      while (slots_[w].done.load(std::memory_order_acquire) != t.gen) cpu_relax();
+    t.gen = 0;
+    run_mu_.unlock();
+  }
+
+  // Worker count of the process-wide pool (kc_set_host_threads): joins the
+  // current workers and starts `total - 1` new ones (the caller is the first
+  // thread of a job).  Waits for a running job.
+  void resize(int total) {
+    std::lock_guard<std::mutex> serial(run_mu_);
+    stop_workers();
+    start_workers(std::max(0, std::min(total, 64) - 1));
   }
 
   template <typename F>
   void parallel_for(size_t n, size_t min_chunk, F &&fn) {
+    std::unique_lock<std::mutex> serial(run_mu_);  // one job at a time; the worker set is stable while held
     const size_t parts =
         std::min<size_t>(threads_.size() + 1, min_chunk ? n / min_chunk : n);
     if (parts <= 1) {
+      serial.unlock();
       fn(size_t(0), n);
       return;
     }
-    std::lock_guard<std::mutex> serial(run_mu_);  // one job at a time
     job_fn_ = [&fn, n, parts](size_t part) {
       const size_t b = n * part / parts, e = n * (part + 1) / parts;
       if (b < e) fn(b, e);
@@ -146,14 +172,23 @@ class WorkerPool {
   WorkerPool() {
     const unsigned hw = usable_cpus();
     int n = hw >= 16 ? 11 : hw >= 12 ? 7 : hw >= 6 ? 3 : hw >= 3 ? 1 : 0;
-    if (const char *e = std::getenv("KC_HOST_THREADS")) {
+    if (const char *e = std::getenv("KC_HOST_THREADS")) {  // process default; kc_set_host_threads overrides
       const int want = std::atoi(e);
       if (want >= 1 && want <= 64) n = want - 1;
     }
-    slots_ = std::unique_ptr<Slot[]>(new Slot[n > 0 ? n : 1]);
-    for (int i = 0; i < n; ++i) threads_.emplace_back([this, i] { loop(i); });
+    start_workers(n);
   }
-  ~WorkerPool() {
+  ~WorkerPool() { stop_workers(); }
+  void start_workers(int n) {
+    stop_.store(false);
+    slots_ = std::unique_ptr<Slot[]>(new Slot[n > 0 ? n : 1]);
+    // a new worker starts from the generation current at its creation: it must
+    // not take an old job description for a new one
+    const uint64_t g0 = gen_.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i) slots_[i].done.store(g0, std::memory_order_relaxed);
+    for (int i = 0; i < n; ++i) threads_.emplace_back([this, i, g0] { loop(i, g0); });
+  }
+  void stop_workers() {
     {
       std::lock_guard<std::mutex> lk(mu_);
       stop_.store(true);
@@ -161,16 +196,17 @@ class WorkerPool {
     }
     cv_.notify_all();
     for (auto &t : threads_) t.join();
+    threads_.clear();
+    job_parts_ = 0;
   }
   static void cpu_relax() {
 #if defined(__x86_64__)
     __builtin_ia32_pause();
 #endif
   }
-  void loop(int w) {
-    // generation 0 = "nothing published yet"; a job published before this
-    // thread got to run must still be seen (and acknowledged)
-    uint64_t seen = 0;
+  void loop(int w, uint64_t seen) {
+    // `seen` = the generation at creation; a job published before this thread
+    // got to run must still be seen (and acknowledged)
     for (;;) {
       // spin for up to ~0.5 ms of wall time (a controller at a steady rate of a
       // few kHz finds the workers hot), then sleep on the condition variable: an
@@ -202,9 +238,6 @@ class WorkerPool {
   std::vector<std::thread> threads_;
   std::unique_ptr<Slot[]> slots_;
   std::mutex mu_, run_mu_;
-  std::unique_lock<std::mutex> async_lock_;
-  uint64_t async_gen_ = 0;
-  bool async_self_ = false;
   std::condition_variable cv_;
   alignas(64) std::atomic<uint64_t> gen_{0};
   alignas(64) std::atomic<int> sleepers_{0};

@@ -148,8 +148,36 @@ __global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
 // (C) all lanes convert the poses to the float sample-major rows (coalesced)
 // and test one pose each against the LDS bits; a hit marks the sample.
 // ===========================================================================
-template <int kFusedSamples, int kFusedBlock>
-__global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a) {
+//
+// With a CycleTail the same kernel is the whole controller cycle in ONE launch
+// (reference shape dwa.h:215-229): the survivors of a
+// workgroup are costed right here, from the double poses still in LDS (the
+// float of a pose is the one the roll-out would have stored), the workgroup's
+// best key goes through an arrival ticket, and the workgroup whose ticket comes
+// last reduces the keys, counts the admissible samples in front of the winner
+// and hands record + winner row to the host through pinned memory.  Nothing is
+// materialised unless asked for (write_paths).  Samples are dealt to the
+// workgroups round-robin in trig-row order (slot s of workgroup b is entry
+// b + s * gridDim.x of the row-ordered view): survivors cluster in a few omega
+// rows, a contiguous deal would leave most workgroups idle in the cost phase.
+struct NoTail {};
+struct CycleTail {
+  CostArgs c;
+  DcArgs t;
+  unsigned tab_off;               // byte offset of the cost tables in dynamic LDS (16-aligned)
+  int write_paths;                // also store the float rows (debugging samples)
+  long long *block_keys;          // [grid] best key per workgroup        (sc1 stores / loads)
+  unsigned long long *masks;      // [grid] survivor slots per workgroup  (sc1)
+  uint32_t *best_rows;            // [grid][2 P] float bits of each workgroup's best row (sc1)
+  long long *result;              // device record (R_* / W_* slots)
+  long long *host_pub;            // pinned: {key, n_adm << 32 | compact, seq, check, row check}
+  uint32_t *host_row;             // pinned: [2 P] winner row (x | y float bits)
+  long long seq;                  // sequence number of this cycle's record
+};
+
+template <int kFusedSamples, int kFusedBlock, class Tail = NoTail>
+__global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a, Tail tail) {
+  constexpr bool kCycle = !std::is_same<Tail, NoTail>::value;
   extern __shared__ __align__(16) unsigned char smem[];
   const int PP = a.P | 1;  // pitch of a sample's row in 16-byte slots
   double2 *lpos = reinterpret_cast<double2 *>(smem);
@@ -167,8 +195,11 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ double lvx[kFusedSamples], lvy[kFusedSamples];
 
   const int tid = threadIdx.x;
-  const int base = blockIdx.x * kFusedSamples;
-  const int rows = min(kFusedSamples, a.n - base);
+  // entry of slot s in the row-ordered view: a contiguous block, or (cycle) dealt round-robin
+  const int base = kCycle ? static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x) * kFusedSamples;
+  const int stride = kCycle ? static_cast<int>(gridDim.x) : 1;
+  const int rows = kCycle ? min(kFusedSamples, (a.n - base + stride - 1) / stride)
+                          : min(kFusedSamples, a.n - base);
   const int steps = a.P - 1;
 
   KC_RSTAMP(0);
@@ -176,11 +207,13 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   if (tid < kFusedSamples) {
     lhit[tid] = 0;
     const bool in = tid < rows;
-    lperm[tid] = in ? a.perm[base + tid] : 0;
-    lrow[tid] = in ? a.prow[base + tid] : 0;
-    lvx[tid] = in ? a.pvx[base + tid] : 0.0;
-    lvy[tid] = in ? a.pvy[base + tid] : 0.0;
+    const int e = base + tid * stride;
+    lperm[tid] = in ? a.perm[e] : 0;
+    lrow[tid] = in ? a.prow[e] : 0;
+    lvx[tid] = in ? a.pvx[e] : 0.0;
+    lvy[tid] = in ? a.pvy[e] : 0.0;
   }
+  if constexpr (kCycle) cycle_fill_tables(tail, smem, tid, kFusedBlock);
   if (a.c.enabled && a.c.dil == 2) {
     // The dilated masks of this sensor update do not exist yet: the raw bits of
     // the window plus a halo of R rows and one word either way go to LDS, and
@@ -265,7 +298,14 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     KC_RSTAMP(2);
     if (s_late) {  // give the cycle up: nothing admissible, error word set
       if (tid < rows) a.flags[lperm[tid]] = 0;
-      if (tid == 0) *a.dev_err = 1;
+      if constexpr (kCycle) {
+        // the ticket is still taken: the last workgroup publishes the error
+        if (tid == 0)
+          atomicOr(reinterpret_cast<unsigned long long *>(a.dev_err), 1ull);
+        cycle_epilogue<kFusedBlock>(a, tail, KEY_NONE, 0ull, -1, lpos, lperm, tid);
+      } else {
+        if (tid == 0) *a.dev_err = 1;
+      }
       return;
     }
     const int s = tid & (kFusedSamples - 1);
@@ -347,9 +387,13 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       double2 p;
       if (k == 0) p = make_double2(a.x0, a.y0);
       else p = lpos[s * PP + k - 1];
-      const size_t o = (size_t)lperm[s] * a.P + k;  // sample-major rows
-      a.px[o] = static_cast<float>(p.x);
-      a.py[o] = static_cast<float>(p.y);
+      bool store_row = true;
+      if constexpr (kCycle) store_row = tail.write_paths != 0;
+      if (store_row) {
+        const size_t o = (size_t)lperm[s] * a.P + k;  // sample-major rows
+        a.px[o] = static_cast<float>(p.x);
+        a.py[o] = static_cast<float>(p.y);
+      }
       if (a.c.enabled && k > 0) {
         bool exact = true;
         if (a.c.dil) {
@@ -405,20 +449,39 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   }
   __syncthreads();
   KC_RSTAMP(5);
+  __shared__ int lsurv[kFusedSamples];  // cycle: slots of the survivors, ascending
+  __shared__ int nsurv;
+  __shared__ unsigned long long lmask;
   if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
     const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
     if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
     const unsigned long long bal = __ballot(ok);
     const int cnt = __popcll(bal);
-    int start = 0;
-    if (tid == 0 && cnt)
-      start = static_cast<int>(atomicAdd(
-          reinterpret_cast<unsigned long long *>(a.adm_count),
-          static_cast<unsigned long long>(cnt)));
-    start = __shfl(start, 0, 64);
-    if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = lperm[tid];
+    if constexpr (kCycle) {
+      if (ok) lsurv[__popcll(bal & ((1ull << tid) - 1ull))] = tid;
+      if (tid == 0) {
+        nsurv = cnt;
+        lmask = bal;
+      }
+    } else {
+      int start = 0;
+      if (tid == 0 && cnt)
+        start = static_cast<int>(atomicAdd(
+            reinterpret_cast<unsigned long long *>(a.adm_count),
+            static_cast<unsigned long long>(cnt)));
+      start = __shfl(start, 0, 64);
+      if (ok) a.adm_list[start + __popcll(bal & ((1ull << tid) - 1ull))] = lperm[tid];
+    }
   }
   KC_RSTAMP(6);
+  if constexpr (kCycle) {
+    __syncthreads();
+    int best_slot = -1;
+    const long long key = cycle_costs<kFusedSamples, kFusedBlock>(a, tail, smem, lpos, PP, lperm, lsurv,
+                                                                  nsurv, tid, &best_slot);
+    cycle_epilogue<kFusedBlock>(a, tail, key, lmask, best_slot, lpos + (best_slot < 0 ? 0 : best_slot) * PP,
+                                lperm, tid);
+  }
 }
 
 // ===========================================================================

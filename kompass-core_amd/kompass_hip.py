@@ -88,6 +88,9 @@ SIGNATURES = {
     "kc_dwa_set_stream": (C.c_int, [_vp, _vp]),
     "kc_dwa_set_resolution": (C.c_int, [_vp, C.c_double]),
     "kc_dwa_set_weights": (C.c_int, [_vp, C.POINTER(Weights)]),
+    "kc_dwa_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "kc_dwa_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
+    "kc_set_host_threads": (C.c_int, [C.c_int]),
     "kc_dwa_sample_window": (C.c_int, [_vp, C.c_int, C.POINTER(Limits), C.c_double, C.c_double, C.c_double,
                                        C.c_int, C.c_int, C.POINTER(_sz), _dp, _dp, _dp, _sz]),
     "kc_dwa_set_samples": (C.c_int, [_vp, _sz, _dp, _dp, _dp]),
@@ -184,6 +187,11 @@ def device_count() -> int:
     return lib().kc_device_count()
 
 
+def set_host_threads(n: int):
+    """Threads of the process-wide host pool behind the roll-out's libm trig table."""
+    _check(lib().kc_set_host_threads(int(n)))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -251,6 +259,14 @@ class DwaContext:
 
     def set_resolution(self, res):
         _check(lib().kc_dwa_set_resolution(self.h, float(res)))
+
+    def set_option(self, name: str, value):
+        _check(lib().kc_dwa_set_option(self.h, name.encode(), float(value)))
+
+    def get_option(self, name: str) -> float:
+        v = C.c_double(0.0)
+        _check(lib().kc_dwa_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def set_weights(self, w: Weights):
         _check(lib().kc_dwa_set_weights(self.h, C.byref(w)))

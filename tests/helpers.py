@@ -73,10 +73,16 @@ def hip_cycle(kh, inp, scan=None, sensor_pos=(0, 0, 0), sensor_rot=(0, 0, 0, 1),
     ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
     ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
     res = ctx.cycle(st, inp["P"])
+    # the winner row first: after a single-launch cycle it comes from the pinned record, while
+    # get_samples makes the context produce every row again through the materialising kernel
+    best = ctx.get_best() if res.found else None
     px, py, raw, costs = ctx.get_samples(with_costs=True)
     out = dict(px=px.copy(), py=py.copy(), raw=raw.copy(), costs=costs.copy(), res=res.as_dict(), ctx=ctx)
     if res.found:
-        out["best"] = ctx.get_best()
+        out["best"] = best
+        again = ctx.get_best()   # and once more from the device rows
+        np.testing.assert_array_equal(again[0], best[0])
+        np.testing.assert_array_equal(again[1], best[1])
     return out
 
 

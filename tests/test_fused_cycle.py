@@ -1,0 +1,146 @@
+"""The single-launch controller cycle (kc_dwa_cycle with option "fused_cycle",
+default on: roll-out + collision gate + costs + argmin + record in ONE kernel,
+SURVEY 7 step 5 / dwa.h:215-229) against the three-kernel cycle and the oracle;
+the per-context options; the call sequences the synchronisation shortcuts of
+the context have to survive."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kompass_hip as kh  # noqa: E402
+import synthetic as syn  # noqa: E402
+
+from helpers import assert_cycle_equal, hip_context, hip_cycle, oracle_cycle  # noqa: E402
+from test_gpu_parity import _PATH_SCENARIOS, _path_scenario  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert kh.device_count() >= 1, "no HIP device visible: the -m gpu tests need an MI355X"
+
+
+def _prepared(inp, **options):
+    ctx = hip_context(kh, inp)
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    st = inp["state"]
+    ctx.set_weights(kh.make_weights(*inp["weights"]))
+    ctx.set_points(st, inp["points"], inp["max_range"])
+    ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+    ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
+    return ctx
+
+
+@pytest.mark.parametrize("k", range(len(_PATH_SCENARIOS)))
+def test_single_launch_cycle_equals_three_kernel_cycle_and_oracle(k):
+    inp = _path_scenario(*_PATH_SCENARIOS[k])
+    o = oracle_cycle(inp)
+    one = _prepared(inp)
+    three = _prepared(inp, fused_cycle=0)
+    h1 = hip_cycle(kh, inp, ctx=one)
+    h3 = hip_cycle(kh, inp, ctx=three)
+    assert one.get_option("fused_cycle") == 1 and three.get_option("fused_cycle") == 0
+    assert three.get_option("last_cycle_single_launch") == 0
+    if inp["robot"]["shape"] != syn.SPHERE:
+        assert one.get_option("last_cycle_single_launch") == 1, "cost tables must fit beside the roll-out tile here"
+    assert_cycle_equal(o, h1)
+    assert_cycle_equal(o, h3)
+    # the rows stored by the cycle kernel itself (write_paths) are the same rows
+    wp = _prepared(inp, write_paths=1)
+    r = wp.cycle(inp["state"], inp["P"])
+    px, py, raw, costs = wp.get_samples(with_costs=True)
+    np.testing.assert_array_equal(px.view(np.uint32), o["px"].view(np.uint32))
+    np.testing.assert_array_equal(py.view(np.uint32), o["py"].view(np.uint32))
+    np.testing.assert_array_equal(costs.view(np.uint32), o["costs"].view(np.uint32))
+    assert r.index == o["index"]
+    for c in (one, three, wp):
+        c.close()
+
+
+def test_many_cycles_moving_pose_both_paths_agree():
+    """200 cycles with a pose that moves every cycle (nothing reusable), survivors
+    from none to all: the two paths must agree every time; a few against the oracle."""
+    inp = syn.make_controller_inputs("cfg2", seed=3, scale=0.3, scene="mid")
+    one, three = _prepared(inp), _prepared(inp, fused_cycle=0)
+    P = inp["P"]
+    for i in range(200):
+        st = (0.02 * (i % 50) - 0.5, 0.013 * (i % 37) - 0.2, 0.05 * (i % 9) - 0.2, 0.0)
+        a, b = one.cycle(st, P), three.cycle(st, P)
+        assert (a.found, a.index, a.raw_index, a.n_admissible) == (b.found, b.index, b.raw_index, b.n_admissible), i
+        assert np.float32(a.cost) == np.float32(b.cost)
+        if a.found:
+            np.testing.assert_array_equal(one.get_best()[0], three.get_best()[0])
+        if i % 50 == 7:
+            o = oracle_cycle(dict(inp, state=st))
+            assert a.n_admissible == len(o["raw"]) and a.index == o["index"]
+    one.close(); three.close()
+
+
+@pytest.mark.parametrize("opts", [dict(cost_kernel=1), dict(cost_kernel=2), dict(force_split=1), dict(trig_copy=1),
+                                  dict(early_launch=0), dict(sensor_on_host=1), dict(lazy_dilate=0),
+                                  dict(cost_dc_cells=64), dict(fused_cycle=0, cost_kernel=2, cost_dc_cells=128)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
+def test_options_per_context_give_identical_results(opts):
+    """Every switch of kc_dwa_set_option, set on ONE context of a process that
+    also runs a default context: same bits as the oracle."""
+    for sc in (_PATH_SCENARIOS[1], _PATH_SCENARIOS[5]):
+        inp = _path_scenario(*sc)
+        o = oracle_cycle(inp)
+        ctx = hip_context(kh, inp)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+            assert ctx.get_option(k) == v
+        assert_cycle_equal(o, hip_cycle(kh, inp, ctx=ctx))
+        assert_cycle_equal(o, hip_cycle(kh, inp))
+        ctx.close()
+    with pytest.raises(ValueError):
+        hip_context(kh, inp).set_option("no_such_option", 1)
+
+
+def test_evaluate_without_fetch_then_table_updates():
+    """after a fetched cycle, kc_dwa_evaluate again WITHOUT a fetch, then
+    a new tracked segment (host stores into the table the queued kernel reads),
+    then a cycle; and kc_dwa_set_tracked_window followed by kc_dwa_set_tracked_segment."""
+    inp = _path_scenario(*_PATH_SCENARIOS[3])       # open space: the cost kernel has work to do
+    seg2 = inp["seg_xyz"] + np.float32([0.0, 0.35, 0.0])
+    o1 = oracle_cycle(inp)
+    o2 = oracle_cycle(dict(inp, seg_xyz=seg2))
+    for fused in (1, 0):
+        ctx = _prepared(inp, fused_cycle=fused)
+        st, P = inp["state"], inp["P"]
+        for rep in range(5):
+            r = ctx.cycle(st, P)
+            assert r.index == o1["index"] and np.float32(r.cost) == np.float32(o1["cost"])
+            ctx.evaluate()                                   # queued, never fetched
+            ctx.set_tracked_segment(seg2, inp["acc_at_seg"], inp["ref_len"])
+            r = ctx.cycle(st, P)
+            assert r.index == o2["index"] and np.float32(r.cost) == np.float32(o2["cost"]), (fused, rep)
+            _, _, _, costs = ctx.get_samples(with_costs=True)
+            np.testing.assert_array_equal(costs.view(np.uint32), o2["costs"].view(np.uint32))
+            # resident window, then host-built tables over it
+            ctx.set_path(seg2, inp["acc_at_seg"], inp["ref_len"])
+            ctx.set_tracked_window(0, len(seg2))
+            ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+            r = ctx.cycle(st, P)
+            assert r.index == o1["index"] and np.float32(r.cost) == np.float32(o1["cost"]), (fused, rep)
+        ctx.close()
+
+
+def test_rollout_evaluate_after_a_single_launch_cycle():
+    """The split entry points keep working on a context whose last cycle was a
+    single launch (rows are re-materialised, the list is rebuilt from the flags)."""
+    inp = _path_scenario(*_PATH_SCENARIOS[0])
+    o = oracle_cycle(inp)
+    ctx = _prepared(inp)
+    st, P = inp["state"], inp["P"]
+    r0 = ctx.cycle(st, P)
+    ctx.evaluate()                      # second evaluate of the same roll-out
+    r1 = ctx.fetch_result()
+    ctx.rollout(st, P); ctx.evaluate()
+    r2 = ctx.fetch_result()
+    for r in (r0, r1, r2):
+        assert r.index == o["index"] and np.float32(r.cost) == np.float32(o["cost"])
+        assert r.n_admissible == len(o["raw"])
+    assert ctx.count_admissible_before(int(o["raw"][o["index"]])) == o["index"]
+    ctx.close()
