@@ -135,6 +135,24 @@ __device__ __forceinline__ float sq_over(float total, float d, float lim) {
   return static_cast<float>(static_cast<double>(total) +
                             (dd * dd) / static_cast<double>(lim));
 }
+// The pinned result record {key, counts, seq, check, row word}: plain stores, no
+// `volatile` (each volatile store to host memory is followed by a wait for its
+// PCIe completion -- five of them cost microseconds); the words may arrive in
+// any order, the host accepts the record only when record_check adds up.
+__device__ __forceinline__ void store_host_record(long long *hp, long long w0, long long w1, long long seq,
+                                                  long long w4) {
+  const long long chk = record_check(w0, w1, seq, w4);
+  longlong2 *v = reinterpret_cast<longlong2 *>(hp);
+  longlong2 a, b;
+  a.x = w0;
+  a.y = w1;
+  b.x = seq;
+  b.y = chk;
+  hp[4] = w4;
+  v[0] = a;
+  v[1] = b;
+}
+
 // Wave-wide unsigned minimum on the DPP path (four cross-lane ALU steps inside
 // each row of 16, then four scalar row reads) instead of six ds_bpermute round
 // trips: the searches are latency chains, and a bpermute costs about as much
@@ -230,12 +248,15 @@ struct SegRecs {
 // lanes per trajectory point: brute-force segment scan, block search around the
 // query cell.  Leaves s_mind[P], *s_goal, *s_end and the sample-wide minimum in
 // *s_obest (armed by the caller, behind a barrier).  tid = lane id inside the team.
+// cap / sup (chunk capsules and super-chunk spheres): the pruned segment search;
+// null: the plain scan, eight lanes wide.
 template <int kTeam, class Seg, class Pts>
 __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg &seg, float sz_end,
                                                    const int *cells, const uint8_t *skip,
                                                    const float *obx, const float *oby, const Pts &pts,
                                                    int tid, float *s_mind, float *s_goal, float *s_end,
-                                                   unsigned long long *s_obest) {
+                                                   unsigned long long *s_obest, const float *cap = nullptr,
+                                                   const float *sup = nullptr) {
   const BucketDev &b = a.b;
   const int sub = tid & 7;
   for (int p0 = 0; p0 < a.P; p0 += kTeam / 8) {
@@ -248,26 +269,30 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
     if (a.use_seg) {
       float best = FLT_MAX;
       int arg = 0;
+      if (cap) {
+        group8_segment_search(a, seg, cap, sup, x, y, sub, best, arg);
+      } else {
 #pragma unroll 4
-      for (int j = sub; j < a.S; j += 8) {  // j ascending per lane
-        const float4 q = seg.pt(j);
-        const float dx = q.x - x;
-        const float dy = q.y - y;
-        const float xx = dx * dx;
-        const float yy = dy * dy;
-        const float d = xx + (yy + q.z);  // Eigen order a + (b + c)
-        if (d < best) {
-          best = d;
-          arg = j;
+        for (int j = sub; j < a.S; j += 8) {  // j ascending per lane
+          const float4 q = seg.pt(j);
+          const float dx = q.x - x;
+          const float dy = q.y - y;
+          const float xx = dx * dx;
+          const float yy = dy * dy;
+          const float d = xx + (yy + q.z);  // Eigen order a + (b + c)
+          if (d < best) {
+            best = d;
+            arg = j;
+          }
         }
+        // non-negative floats order like their bit patterns; ties go to the
+        // lowest segment index (the reference's strict `<` in index order)
+        const uint32_t mine = __float_as_uint(best);
+        const uint32_t mbits = group8_min_u32(mine);
+        arg = static_cast<int>(
+            group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
+        best = __uint_as_float(mbits);
       }
-      // non-negative floats order like their bit patterns; ties go to the
-      // lowest segment index (the reference's strict `<` in index order)
-      const uint32_t mine = __float_as_uint(best);
-      const uint32_t mbits = group8_min_u32(mine);
-      arg = static_cast<int>(
-          group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
-      best = __uint_as_float(mbits);
       if (sub == 0 && live) {
         s_mind[p] = kc::sqrt_rn(best);
         if (p == a.P - 1) {
@@ -345,6 +370,123 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
   }
 }
 
+// OR inside each aligned group of eight lanes (every lane gets the group's OR)
+__device__ __forceinline__ uint32_t group8_or_u32(uint32_t v) {
+  v |= dpp_u32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v |= dpp_u32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v |= dpp_u32<0x141>(v);  // row_half_mirror
+  return v;
+}
+
+// Nearest tracked-segment point of q = (x, y) by a group of EIGHT lanes (sub =
+// lane id in the group) with the chunk hierarchy of wave_sample_total spread
+// over the lanes: (0) the heads of the (<= 8) super-chunks, one per lane,
+// (1) their bounding spheres, (2) the heads of the chunks of the surviving
+// super-chunks, (3) the capsules of those chunks, (4) every other point of the
+// chunks that may hold something at least as close, eight points per step.
+// Same minimum of d2 = dx*dx + (dy*dy + z^2) and same lowest index as the full
+// scan (cost_evaluator.cpp:120-130 / :157-166).  All eight lanes must be active;
+// best / arg come back group-uniform.
+template <class Seg>
+__device__ __forceinline__ void group8_segment_search(const CostArgs &a, const Seg &seg, const float *cap,
+                                                      const float *sup, float x, float y, int sub,
+                                                      float &best_out, int &arg_out) {
+  auto d2_to = [&](int j) {
+    const float4 q = seg.pt(j);
+    const float dx = q.x - x;
+    const float dy = q.y - y;
+    const float xx = dx * dx;
+    const float yy = dy * dy;
+    return xx + (yy + q.z);  // Eigen order a + (b + c)
+  };
+  auto merge = [&](float &best, int &arg) {
+    // non-negative floats order like their bit patterns (NaN above everything:
+    // `d < best` never took one); ties go to the lowest segment index
+    const uint32_t mine = __float_as_uint(best);
+    const uint32_t mbits = group8_min_u32(mine);
+    arg = static_cast<int>(group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
+    best = __uint_as_float(mbits);
+  };
+  const int sup_pts = 8 * a.seg_chunk;
+  float best = FLT_MAX;
+  int arg = 0;  // (a lane that finds nothing below FLT_MAX keeps index 0, like the reference's scan)
+  // (0) super-chunk heads
+  if (sub < a.nsup) {
+    const float dd = d2_to(sub * sup_pts);
+    if (dd < best) {
+      best = dd;
+      arg = sub * sup_pts;
+    }
+  }
+  merge(best, arg);
+  // (1) spheres: |q - c| - r <= thr on the squares (NaN compares false: qualifies)
+  float thr = __builtin_sqrtf(best) * 1.0001f;
+  bool keep = false;
+  if (sub < a.nsup) {
+    const float dx = sup[sub] - x, dy = sup[a.nsup + sub] - y, dz = sup[2 * a.nsup + sub];
+    const float d2 = dx * dx + dy * dy + dz * dz;
+    const float lim = thr + sup[3 * a.nsup + sub];
+    keep = !(d2 > lim * lim * 1.00001f);
+  }
+  const uint32_t smask = group8_or_u32(keep ? 1u << sub : 0u);
+  // (2) heads of their chunks (lane sub: chunk 8 s + sub)
+  for (uint32_t m = smask; m;) {
+    const int s8 = (__ffs(static_cast<int>(m)) - 1) * 8;
+    m &= m - 1u;
+    const int c = s8 + sub;
+    if (c < a.nch) {
+      const int j = c * a.seg_chunk;
+      const float dd = d2_to(j);
+      if (dd < best || (dd == best && j < arg)) {
+        best = dd;
+        arg = j;
+      }
+    }
+  }
+  merge(best, arg);
+  // (3) capsules of those chunks: distance to the chord minus the largest
+  // deviation of the chunk's points from it
+  thr = __builtin_sqrtf(best) * 1.0001f;
+  uint32_t clo = 0u, chi = 0u;
+  for (uint32_t m = smask; m;) {
+    const int s8 = (__ffs(static_cast<int>(m)) - 1) * 8;
+    m &= m - 1u;
+    const int c = s8 + sub;
+    if (c < a.nch) {
+      const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
+      const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
+      float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
+      t = fminf(fmaxf(t, 0.0f), 1.0f);
+      const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
+      const float d2 = ex * ex + ey * ey + ez * ez;
+      const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+      if (!(d2 > lim * lim * 1.0001f)) {
+        if (c < 32) clo |= 1u << c;
+        else chi |= 1u << (c - 32);
+      }
+    }
+  }
+  clo = group8_or_u32(clo);
+  chi = group8_or_u32(chi);
+  // (4) the remaining points of those chunks, eight per step
+  for (unsigned long long cand = (static_cast<unsigned long long>(chi) << 32) | clo; cand;) {
+    const int c = __ffsll(static_cast<long long>(cand)) - 1;
+    cand &= cand - 1ull;
+    const int j0 = c * a.seg_chunk;
+    const int j1 = min(j0 + a.seg_chunk, a.S);
+    for (int j = j0 + 1 + sub; j < j1; j += 8) {
+      const float dd = d2_to(j);
+      if (dd < best || (dd == best && j < arg)) {
+        best = dd;
+        arg = j;
+      }
+    }
+  }
+  merge(best, arg);
+  best_out = best;
+  arg_out = arg;
+}
+
 // smoothness + jerk of caller-provided velocity profiles (kc_cost_evaluate):
 // serial loops, evaluated redundantly by every lane (wave-uniform addresses)
 __device__ __forceinline__ float add_velocity_costs(const CostArgs &a, int n, float total) {
@@ -395,11 +537,14 @@ __device__ __forceinline__ float team_sample_total(const CostArgs &a, int n, int
     if (a.w_goal > 0.0) total = accum(total, a.w_goal, s_goal);
     if (a.w_path > 0.0) {
       // pathCostFunc, cost_evaluator.cpp:111-141: ordered float sum
+      // (lanes beyond the last point hold +0.0f: adding it leaves the non-negative
+      // sum as it is, so the 64 additions of a tile need no loop or branch)
       float sum = 0.0f;
       for (int base = 0; base < a.P; base += 64) {
         const int cnt = min(64, a.P - base);
         const float v = (lane < cnt) ? s_mind[base + lane] : 0.0f;
-        for (int k = 0; k < cnt; ++k) sum += lane_value(v, k);
+#pragma unroll
+        for (int k = 0; k < 64; ++k) sum += lane_value(v, k);
       }
       const float c = kc::div_rn(
           kc::div_rn(sum, static_cast<float>(a.P)) + s_end, 2.0f);
@@ -866,8 +1011,11 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
     if (st) KC_STAMP(12);
     // ordered path-cost sum of this tile (pathCostFunc, cost_evaluator.cpp:111-141)
     if (a.use_seg) {
-      const int cnt = min(64, a.P - p0);
-      for (int k = 0; k < cnt; ++k) sum += lane_value(mind, k);
+      // (idle lanes contribute +0.0f, which leaves the non-negative sum as it is:
+      // 64 straight-line additions instead of a counted loop)
+      const float mv = live ? mind : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) sum += lane_value(mv, k);
       if (p0 + 64 >= a.P) {
         goal = lane_value(goal_l, a.P - 1 - p0);
         endc = lane_value(end_l, a.P - 1 - p0);
@@ -1060,12 +1208,7 @@ __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
       // words: the fourth is a mixing checksum over the others (record_check,
       // kc_internal.h), so a half-arrived record is never accepted.
       const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
-      volatile long long *hp = a.host_pub;
-      hp[0] = fkey;
-      hp[1] = w1;
-      hp[2] = a.seq;
-      hp[4] = 0;  // no winner row in this record
-      hp[3] = record_check(fkey, w1, a.seq, 0);
+      store_host_record(a.host_pub, fkey, w1, a.seq, 0);  // (no winner row in this record)
     }
     a.result[R_KEY] = fkey;
     a.result[R_NADM] = na_pub;
@@ -1082,12 +1225,7 @@ __global__ void republish_kernel(const long long *result, long long *host_pub, l
   const long long key = result[R_KEY];
   const long long w1 = (result[R_NADM] << 32) |
                        static_cast<long long>(static_cast<uint32_t>(result[R_COMPACT]));
-  volatile long long *hp = host_pub;
-  hp[0] = key;
-  hp[1] = w1;
-  hp[2] = seq;
-  hp[4] = 0;
-  hp[3] = record_check(key, w1, seq, 0);
+  store_host_record(host_pub, key, w1, seq, 0);
 }
 
 // ordered compaction of the admissible flags (one workgroup): adm_list[i] =

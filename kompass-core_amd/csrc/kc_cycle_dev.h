@@ -106,8 +106,11 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
       const PosePts pts{lpos + s * PP, a.x0, a.y0};
       if (active)
         team_sample_search<kTeam>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
-                                  t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h]);
+                                  t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h], t.cap,
+                                  t.cap + 8 * c.nch);
+      if (it == 0) KC_RSTAMP(10);
       __syncthreads();
+      if (it == 0) KC_RSTAMP(11);
       if (active && tt < 64) {
         const int n = lperm[s];
         const float total = team_sample_total(c, n, lane, t.mind + h * c.P, s_goal[h], s_end[h], s_ob[h]);
@@ -117,6 +120,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
             atomicMin(&s_key, key_pack(total, static_cast<uint32_t>(c.first + n)));
         }
       }
+      if (it == 0) KC_RSTAMP(12);
     }
   } else {
     __syncthreads();  // s_next, s_key
@@ -153,48 +157,90 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
 }
 
 // Arrival ticket; the workgroup that arrives last publishes the cycle.
+// R survivors of this workgroup (slots lsurv[0..R)) are OR-ed into the device-wide
+// bitmap of admissible local ids first.
 template <int kBlock, class Tail>
-__device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &tail, long long key,
-                                               unsigned long long mask, int best_slot,
-                                               const double2 *best_row, const int *lperm, int tid) {
+__device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &tail, long long key, int R,
+                                               int best_slot, const double2 *best_row, const int *lperm,
+                                               const int *lsurv, int tid) {
   const int P = a.P;
   const unsigned b = blockIdx.x, G = gridDim.x;
   __shared__ int s_last, s_bw;
   __shared__ long long s_wkey[kBlock / 64];
   __shared__ int s_wadm[kBlock / 64], s_wcnt[kBlock / 64];
-  __shared__ unsigned int s_rowx;
-  // this workgroup's best row: the floats the roll-out would have stored
-  if (best_slot >= 0) {
-    uint32_t *dst = tail.best_rows + (size_t)b * 2 * P;
+  __shared__ unsigned int s_rowx, s_winx;
+  if (tid == 0) {
+    s_rowx = 0u;
+    s_bw = -1;
+  }
+  if (tid < R) {
+    const int id = lperm[lsurv[tid]];
+    __hip_atomic_fetch_or(tail.adm_bits + (id >> 5), 1u << (id & 31), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // This workgroup's best row -- the floats the roll-out would have stored --
+  // straight into its slot of the pinned host buffer (posted writes: nobody on
+  // the device waits for them); a position-weighted xor of the words goes with
+  // the key, the host checks the row of the winning workgroup against it.
+  __syncthreads();  // s_rowx
+  if (best_slot >= 0 && tail.host_rows) {
+    uint32_t *dst = tail.host_rows + (size_t)b * 2 * P;
+    unsigned int x = 0u;
     for (int k = tid; k < 2 * P; k += kBlock) {
       const int p = k < P ? k : k - P;
       const double v = p == 0 ? (k < P ? a.x0 : a.y0) : (k < P ? best_row[p - 1].x : best_row[p - 1].y);
-      st_agent(dst + k, __float_as_uint(static_cast<float>(v)));
+      const uint32_t w = __float_as_uint(static_cast<float>(v));
+      dst[k] = w;
+      x ^= w * (2u * static_cast<unsigned>(k) + 1u);
     }
+    if (tid < ((2 * P + 63) & ~63)) {  // the wavefronts that hold row words
+      for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+      if ((tid & 63) == 0 && x) atomicXor(&s_rowx, x);
+    }
+    __syncthreads();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+  if (tid == 0) {
+    // key + row word as one 16-byte agent-scope record of this workgroup
+    st_agent(tail.block_keys + 2 * b, key);
+    st_agent(tail.block_keys + 2 * b + 1, static_cast<long long>(s_rowx));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its atomics / the record
   __syncthreads();
   if (tid == 0) {
-    st_agent(tail.block_keys + b, key);
-    st_agent(tail.masks + b, mask);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t = __hip_atomic_fetch_add(
         reinterpret_cast<unsigned long long *>(tail.result + W_TICKET), 1ull, __ATOMIC_RELAXED,
         __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == static_cast<unsigned long long>(G) - 1ull) ? 1 : 0;
-    s_bw = -1;
-    s_rowx = 0u;
   }
   __syncthreads();
+  KC_RSTAMP(13);
   if (!s_last) return;
   // ---- last arriver: every other workgroup's stores are behind its ticket ----
+  // one round trip: the keys, the bitmap words and the error word, kept in registers
   const int lane = tid & 63, wave = tid >> 6;
-  long long k = KEY_NONE;
-  int nadm = 0;
-  for (unsigned g = tid; g < G; g += kBlock) {
-    const long long v = ld_agent(tail.block_keys + g);
-    k = v < k ? v : k;
-    nadm += __popcll(ld_agent(tail.masks + g));
+  constexpr int kMaxKeys = 2, kMaxWords = 2;  // per lane: <= 2048 workgroups, <= 65536 samples (host check)
+  long long kreg[kMaxKeys], xreg[kMaxKeys];
+  uint32_t wreg[kMaxWords];
+  const unsigned nwords = (static_cast<unsigned>(a.n) + 31u) >> 5;
+  long long err = 0;
+  if (tid == 0) err = static_cast<long long>(ld_agent(reinterpret_cast<const unsigned long long *>(a.dev_err)));
+#pragma unroll
+  for (int u = 0; u < kMaxKeys; ++u) {
+    const unsigned g = tid + u * kBlock;
+    kreg[u] = g < G ? ld_agent(tail.block_keys + 2 * g) : KEY_NONE;
+    xreg[u] = g < G ? ld_agent(tail.block_keys + 2 * g + 1) : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < kMaxWords; ++u) {
+    const unsigned w = tid + u * kBlock;
+    wreg[u] = w < nwords ? ld_agent(tail.adm_bits + w) : 0u;
+  }
+  long long k = kreg[0] < kreg[1] ? kreg[0] : kreg[1];
+  int nadm = __popc(wreg[0]) + __popc(wreg[1]);
+#pragma unroll
+  for (int u = 0; u < kMaxWords; ++u) {  // the bitmap is clear again for the next cycle
+    const unsigned w = tid + u * kBlock;
+    if (w < nwords && wreg[u]) tail.adm_bits[w] = 0u;
   }
   for (int off = 32; off > 0; off >>= 1) {
     const long long o = __shfl_xor(k, off, 64);
@@ -213,53 +259,39 @@ __device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &ta
     na += s_wadm[w];
   }
   // the reference's index counts the admissible samples in front of the winner
-  // (generation order = local sample id order); slot j of workgroup g is entry
-  // g + j * G of the row-ordered view
+  // (generation order = local id order)
   int cnt = 0;
   if (fkey != KEY_NONE) {
-    const int lim = static_cast<int>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
-    for (unsigned g = tid; g < G; g += kBlock) {
-      if (ld_agent(tail.block_keys + g) == fkey) s_bw = static_cast<int>(g);  // one owner: indices are unique
-      unsigned long long m = ld_agent(tail.masks + g);
-      while (m) {
-        const int j = __ffsll(static_cast<long long>(m)) - 1;
-        m &= m - 1ull;
-        cnt += a.perm[g + static_cast<unsigned>(j) * G] < lim ? 1 : 0;
-      }
+    const unsigned lim = static_cast<uint32_t>(fkey & 0xFFFFFFFFll) - static_cast<unsigned>(a.first);
+#pragma unroll
+    for (int u = 0; u < kMaxWords; ++u) {
+      const unsigned w0 = (tid + u * kBlock) << 5;  // first id of this word
+      if (w0 + 32u <= lim) cnt += __popc(wreg[u]);
+      else if (w0 < lim) cnt += __popc(wreg[u] & ((1u << (lim - w0)) - 1u));
     }
+#pragma unroll
+    for (int u = 0; u < kMaxKeys; ++u)
+      if (kreg[u] == fkey) {  // one owner: indices are unique
+        s_bw = tid + u * kBlock;
+        s_winx = static_cast<unsigned int>(xreg[u]);
+      }
   }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
   if (lane == 0) s_wcnt[wave] = cnt;
   __syncthreads();
-  // winner row -> pinned host memory, with a running xor the host checks
-  if (fkey != KEY_NONE && tail.host_row) {
-    const uint32_t *src = tail.best_rows + (size_t)s_bw * 2 * P;
-    unsigned int x = 0u;
-    for (int q = tid; q < 2 * P; q += kBlock) {
-      const uint32_t v = ld_agent(src + q);
-      tail.host_row[q] = v;
-      x ^= v * (2u * static_cast<unsigned>(q) + 1u);
-    }
-    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
-    if (lane == 0 && x) atomicXor(&s_rowx, x);
-  }
-  __syncthreads();
+  KC_RSTAMP(14);
   if (tid == 0) {
     int s = 0;
     for (int w = 0; w < kBlock / 64; ++w) s += s_wcnt[w];
     if (fkey == KEY_NONE) s = -1;
-    const long long err = static_cast<long long>(ld_agent(reinterpret_cast<const unsigned long long *>(a.dev_err)));
     const long long na_pub = err ? -1 : na;
     const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
-    const long long w4 = (static_cast<long long>(s_rowx) << 1) | (fkey != KEY_NONE && tail.host_row ? 1 : 0);
-    if (tail.host_pub) {
-      volatile long long *hp = tail.host_pub;
-      hp[0] = fkey;
-      hp[1] = w1;
-      hp[2] = tail.seq;
-      hp[4] = w4;
-      hp[3] = record_check(fkey, w1, tail.seq, w4);
-    }
+    // row word: check value of the winner's row, the workgroup slot it lies in, presence bit
+    const bool has_row = fkey != KEY_NONE && tail.host_rows != nullptr;
+    const long long w4 = has_row ? ((static_cast<long long>(s_winx) << 32) |
+                                    (static_cast<long long>(static_cast<uint32_t>(s_bw)) << 1) | 1ll)
+                                 : 0ll;
+    if (tail.host_pub) store_host_record(tail.host_pub, fkey, w1, tail.seq, w4);
     tail.result[R_KEY] = fkey;
     tail.result[R_NADM] = na_pub;
     tail.result[R_COMPACT] = s;

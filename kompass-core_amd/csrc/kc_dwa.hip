@@ -84,6 +84,8 @@ struct kc_dwa {
   DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
   DevBuf<double> d_pvx, d_pvy;          // sample velocities / trig rows in d_perm order
   DevBuf<int32_t> d_prow;
+  DevBuf<double> d_cpvx, d_cpvy;        // the same in the dealt order of the single-launch cycle
+  DevBuf<int32_t> d_cprow, d_cperm;
   DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
   std::vector<int32_t> h_perm;
   double inv_res = 0.0;      // 1.0 / res (octomap resolution_factor)
@@ -183,9 +185,9 @@ struct kc_dwa {
                                // materialises them only on demand)
   bool in_materialise = false;
   kc_state last_start{};       // start pose of the last roll-out (re-materialisation)
-  DevBuf<unsigned long long> d_masks;  // survivor slots per workgroup
-  DevBuf<uint32_t> d_best_rows;        // best row per workgroup
-  PinBuf<uint32_t> h_wrow;             // winner row, written by the last workgroup
+  DevBuf<uint32_t> d_adm_bits;         // admissible local ids of the running cycle (bitmap)
+  PinBuf<uint32_t> h_wrow;             // best row of every workgroup of a single-launch cycle
+  size_t wrow_off = 0;                 // words in front of the winner's row
   long long rec_w4 = 0;        // row word of the record fetched last
   bool row_valid = false;      // h_wrow holds the winner row of `last`
 };
@@ -850,7 +852,12 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
 }
 
 // shard-local sample ids ordered by trig row (stable): consecutive samples of a
-// fused workgroup then share one or two rows of the table
+// fused workgroup then share one or two rows of the table.  The single-launch
+// cycle gets a second order, dealt from the first with a skewed stride:
+// survivors of the collision gate cluster (a few adjacent omega rows, the low
+// speeds of each), and a workgroup costs its own survivors -- block g takes
+// entries j * G + (g + 37 j) mod G, j = 0..31, of the row order, so that a
+// cluster of any shape lands on many workgroups instead of a few.
 int build_perm(kc_dwa *c) {
   const size_t n = c->shard_count, first = c->shard_first;
   c->perm_valid = true;
@@ -860,24 +867,40 @@ int build_perm(kc_dwa *c) {
   const int32_t *row = c->lat.row.data() + first;
   std::stable_sort(c->h_perm.begin(), c->h_perm.end(),
                    [row](int32_t x, int32_t y) { return row[x] < row[y]; });
-  KC_TRY(c->d_perm.reserve(n));
-  KC_TRY(c->d_pvx.reserve(n));
-  KC_TRY(c->d_pvy.reserve(n));
-  KC_TRY(c->d_prow.reserve(n));
+  std::vector<int32_t> dealt;
+  dealt.reserve(n);
+  {
+    const size_t G = (n + 31) / 32;
+    for (size_t g = 0; g < G; ++g)
+      for (size_t j = 0; j < 32; ++j) {
+        const size_t e = j * G + (g + 37 * j) % G;
+        if (e < n) dealt.push_back(c->h_perm[e]);
+      }
+  }
   std::vector<double> pvx(n), pvy(n);
   std::vector<int32_t> prow(n);
-  for (size_t i = 0; i < n; ++i) {
-    const size_t g = first + static_cast<size_t>(c->h_perm[i]);
-    pvx[i] = c->lat.vx[g];
-    pvy[i] = c->lat.vy[g];
-    prow[i] = c->lat.row[g];
+  for (int pass = 0; pass < 2; ++pass) {
+    const std::vector<int32_t> &order = pass == 0 ? c->h_perm : dealt;
+    DevBuf<int32_t> &dperm = pass == 0 ? c->d_perm : c->d_cperm;
+    DevBuf<double> &dvx = pass == 0 ? c->d_pvx : c->d_cpvx;
+    DevBuf<double> &dvy = pass == 0 ? c->d_pvy : c->d_cpvy;
+    DevBuf<int32_t> &drow = pass == 0 ? c->d_prow : c->d_cprow;
+    KC_TRY(dperm.reserve(n));
+    KC_TRY(dvx.reserve(n));
+    KC_TRY(dvy.reserve(n));
+    KC_TRY(drow.reserve(n));
+    for (size_t i = 0; i < n; ++i) {
+      const size_t g = first + static_cast<size_t>(order[i]);
+      pvx[i] = c->lat.vx[g];
+      pvy[i] = c->lat.vy[g];
+      prow[i] = c->lat.row[g];
+    }
+    KC_HIP(hipMemcpyAsync(dperm.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(dvx.p, pvx.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(dvy.p, pvy.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(drow.p, prow.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
   }
-  KC_HIP(hipMemcpyAsync(c->d_perm.p, c->h_perm.data(), n * sizeof(int32_t),
-                        hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipMemcpyAsync(c->d_pvx.p, pvx.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipMemcpyAsync(c->d_pvy.p, pvy.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipMemcpyAsync(c->d_prow.p, prow.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
   return KC_OK;
 }
 
@@ -1228,20 +1251,25 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
   // until the words add up, bounded)
   c->row_valid = false;
   if (got && r.found && (c->rec_w4 & 1) && c->h_wrow.p) {
-    const uint32_t want = static_cast<uint32_t>(static_cast<unsigned long long>(c->rec_w4) >> 1);
+    const unsigned long long w4 = static_cast<unsigned long long>(c->rec_w4);
+    const uint32_t want = static_cast<uint32_t>(w4 >> 32);
+    const size_t bw = static_cast<size_t>((w4 & 0xFFFFFFFFull) >> 1);
     const size_t nw = 2 * c->P;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (long spins = 0;; ++spins) {
-      volatile uint32_t *row = c->h_wrow.p;
-      uint32_t x = 0u;
-      for (size_t q = 0; q < nw; ++q) x ^= row[q] * (2u * static_cast<uint32_t>(q) + 1u);
-      if (x == want) {
-        c->row_valid = true;
-        break;
+    if ((bw + 1) * nw <= c->h_wrow.cap) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (long spins = 0;; ++spins) {
+        volatile uint32_t *row = c->h_wrow.p + bw * nw;
+        uint32_t x = 0u;
+        for (size_t q = 0; q < nw; ++q) x ^= row[q] * (2u * static_cast<uint32_t>(q) + 1u);
+        if (x == want) {
+          c->row_valid = true;
+          c->wrow_off = bw * nw;
+          break;
+        }
+        if ((spins & 63) == 63 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+          break;  // get_best falls back to the device copy
       }
-      if ((spins & 63) == 63 &&
-          std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
-        break;  // get_best falls back to the device copy
     }
   }
   c->last = r;
@@ -1311,7 +1339,9 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
   c->stream = c->own_stream;
   (void)WorkerPool::instance();  // start the host workers now, not inside the first cycle
   int rc;
-  if ((rc = c->h_pub.reserve(8)) || (rc = c->h_wrow.reserve(2 * p->max_points))) return fail(rc);
+  if ((rc = c->h_pub.reserve(8)) ||
+      (rc = c->h_wrow.reserve(((p->max_samples + 31) / 32) * 2 * p->max_points)))
+    return fail(rc);
   for (int i = 0; i < 8; ++i) c->h_pub.p[i] = 0;
   if ((rc = c->d_result.reserve(R_SLOTS)) ||
       (rc = c->h_result.reserve(R_SLOTS)) ||
@@ -1421,9 +1451,9 @@ void kc_dwa_destroy(kc_dwa *c) {
     e = hipMemcpy(h.data(), c->d_dbg2.p, h.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 512; ++b) if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
-    const char *nm[8] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "end", "increments done"};
+    const char *nm[15] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "flags out", "increments done", "costs done", "epilogue done", "pass 0 searched", "pass 0 barrier", "pass 0 total", "ticket taken", "last: reduced"};
     std::fprintf(stderr, "[kc stamps] roll-out kernel, us since first block start (avg / max):\n");
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 15; ++k) {
       double sm = 0, mx = 0; int nb = 0;
       for (int b = 0; b < 512; ++b) {
         if (!h[b * 16] || !h[b * 16 + k]) continue;
@@ -1527,8 +1557,11 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_result.release();
   c->h_pub.release();
   c->h_row.release();
-  c->d_masks.release();
-  c->d_best_rows.release();
+  c->d_adm_bits.release();
+  c->d_cperm.release();
+  c->d_cpvx.release();
+  c->d_cpvy.release();
+  c->d_cprow.release();
   c->h_wrow.release();
   delete c;
 }
@@ -2189,8 +2222,12 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
     // dilate_kernel at all); a second cycle on the same data builds the masks
     // once, and so does a window that does not fit with its halo.
     const size_t halo = static_cast<size_t>(a.c.H + 2 * c->dil_R) * (a.c.wpr + 2) * 4;
+    // (a single-launch cycle whose cost tables fit only without the halo keeps the
+    // tables: one dilate_kernel costs less than two more launches)
+    const size_t cyc_tab = cycle ? cycle_table_bytes(tail.c) + 2048 : 0;
+    const bool cyc_fits = cycle && pos_bytes + bits_bytes + cyc_tab + 512 <= c->lds_limit;
     if (c->dil_uses++ == 0 && c->prm.shape != KC_SPHERE &&
-        pos_bytes + bits_bytes + halo + 512 <= c->lds_limit) {
+        pos_bytes + bits_bytes + halo + (cyc_fits ? cyc_tab : 0) + 512 <= c->lds_limit) {
       bits_bytes += halo;
       a.diltab = c->d_diltab.p;
       a.dilR = c->dil_R;
@@ -2229,10 +2266,10 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   }
   if (fused) {
     if (!c->perm_valid) KC_TRY(build_perm(c));
-    a.perm = c->d_perm.p;
-    a.pvx = c->d_pvx.p;
-    a.pvy = c->d_pvy.p;
-    a.prow = c->d_prow.p;
+    a.perm = cycle ? c->d_cperm.p : c->d_perm.p;
+    a.pvx = cycle ? c->d_cpvx.p : c->d_pvx.p;
+    a.pvy = cycle ? c->d_cpvy.p : c->d_pvy.p;
+    a.prow = cycle ? c->d_cprow.p : c->d_prow.p;
 #ifdef KC_PHASE_STAMPS
     if (c->debug_stamps) {
       KC_TRY(c->d_dbg2.reserve(512 * 16));
@@ -2247,18 +2284,22 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
     a.c.lds = 1;
     if (cycle) {
       const unsigned G = blocks_for(n, fs);
-      KC_TRY(c->d_block_keys.reserve(std::max<size_t>(512, G)));
-      KC_TRY(c->d_masks.reserve(G));
-      KC_TRY(c->d_best_rows.reserve(static_cast<size_t>(G) * 2 * P));
-      KC_TRY(c->h_wrow.reserve(2 * c->prm.max_points));
+      KC_TRY(c->d_block_keys.reserve(std::max<size_t>(512, 2 * static_cast<size_t>(G))));
+      {
+        const size_t words = n / 32 + 2;
+        const uint32_t *before = c->d_adm_bits.p;
+        KC_TRY(c->d_adm_bits.reserve(words));
+        if (c->d_adm_bits.p != before)  // a fresh bitmap starts clear; the last workgroup keeps it so
+          KC_HIP(hipMemsetAsync(c->d_adm_bits.p, 0, c->d_adm_bits.cap * sizeof(uint32_t), s));
+      }
+      KC_TRY(c->h_wrow.reserve(static_cast<size_t>(G) * 2 * P));
       tail.tab_off = static_cast<unsigned>(tab_off);
       tail.write_paths = c->write_paths ? 1 : 0;
       tail.block_keys = c->d_block_keys.p;
-      tail.masks = c->d_masks.p;
-      tail.best_rows = c->d_best_rows.p;
+      tail.adm_bits = c->d_adm_bits.p;
       tail.result = c->d_result.p;
       tail.host_pub = c->h_pub.p;
-      tail.host_row = c->h_wrow.p;
+      tail.host_rows = c->h_wrow.p;
       tail.seq = ++c->seq;
       tail.c.block_keys = c->d_block_keys.p;
       a.dev_err = c->d_result.p + W_NADM;
@@ -2344,7 +2385,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
 // bits); costs and result of the cycle stay
 int materialise_paths(kc_dwa *c) {
   if (c->paths_valid) return KC_OK;
-  const bool evaluated = c->evaluated, have_last = c->have_last, pub = c->pub_pending, row = c->row_valid;
+  const bool evaluated = c->evaluated, have_last = c->have_last, pub = c->pub_pending, row = c->row_valid,
+             was_cycle = c->cycle_launched;
   const kc_result last = c->last;
   const kc_state st = c->last_start;
   if (c->pub_pending) KC_HIP(hipStreamSynchronize(c->stream));  // the cycle itself must be through
@@ -2357,6 +2399,7 @@ int materialise_paths(kc_dwa *c) {
   c->last = last;
   c->pub_pending = pub;
   c->row_valid = row;
+  c->cycle_launched = was_cycle;
   return KC_OK;
 }
 }  // namespace
@@ -2444,8 +2487,8 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
     KC_FAIL(KC_ERR_STATE, "winner %lld is not on this shard",
             static_cast<long long>(c->last.raw_index));
   if (c->row_valid) {  // single-launch cycle: the row came with the record, no copy, no stream wait
-    if (path_x) std::memcpy(path_x, c->h_wrow.p, P * sizeof(float));
-    if (path_y) std::memcpy(path_y, c->h_wrow.p + P, P * sizeof(float));
+    if (path_x) std::memcpy(path_x, c->h_wrow.p + c->wrow_off, P * sizeof(float));
+    if (path_y) std::memcpy(path_y, c->h_wrow.p + c->wrow_off + P, P * sizeof(float));
   } else {
     KC_TRY(materialise_paths(c));
     KC_TRY(c->h_row.reserve(2 * P));

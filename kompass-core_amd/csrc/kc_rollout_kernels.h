@@ -156,22 +156,22 @@ __global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
 // best key goes through an arrival ticket, and the workgroup whose ticket comes
 // last reduces the keys, counts the admissible samples in front of the winner
 // and hands record + winner row to the host through pinned memory.  Nothing is
-// materialised unless asked for (write_paths).  Samples are dealt to the
-// workgroups round-robin in trig-row order (slot s of workgroup b is entry
-// b + s * gridDim.x of the row-ordered view): survivors cluster in a few omega
-// rows, a contiguous deal would leave most workgroups idle in the cost phase.
+// materialised unless asked for (write_paths).  The host deals the samples to
+// the workgroups with a skewed stride over the trig-row order (build_perm):
+// survivors cluster in a few omega rows, contiguous blocks of that order would
+// leave the cost phase to a few workgroups.
 struct NoTail {};
 struct CycleTail {
   CostArgs c;
   DcArgs t;
   unsigned tab_off;               // byte offset of the cost tables in dynamic LDS (16-aligned)
   int write_paths;                // also store the float rows (debugging samples)
-  long long *block_keys;          // [grid] best key per workgroup        (sc1 stores / loads)
-  unsigned long long *masks;      // [grid] survivor slots per workgroup  (sc1)
-  uint32_t *best_rows;            // [grid][2 P] float bits of each workgroup's best row (sc1)
+  long long *block_keys;          // [grid][2] best key + row check word per workgroup (sc1 stores / loads)
+  uint32_t *adm_bits;             // [n / 32 + 1] admissible samples by local id (agent-scope atomic OR;
+                                  // zero at launch, cleared again by the last workgroup)
   long long *result;              // device record (R_* / W_* slots)
-  long long *host_pub;            // pinned: {key, n_adm << 32 | compact, seq, check, row check}
-  uint32_t *host_row;             // pinned: [2 P] winner row (x | y float bits)
+  long long *host_pub;            // pinned: {key, n_adm << 32 | compact, seq, check, row word}
+  uint32_t *host_rows;            // pinned: [grid][2 P] best row of every workgroup (x | y float bits)
   long long seq;                  // sequence number of this cycle's record
 };
 
@@ -195,11 +195,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ double lvx[kFusedSamples], lvy[kFusedSamples];
 
   const int tid = threadIdx.x;
-  // entry of slot s in the row-ordered view: a contiguous block, or (cycle) dealt round-robin
-  const int base = kCycle ? static_cast<int>(blockIdx.x) : static_cast<int>(blockIdx.x) * kFusedSamples;
-  const int stride = kCycle ? static_cast<int>(gridDim.x) : 1;
-  const int rows = kCycle ? min(kFusedSamples, (a.n - base + stride - 1) / stride)
-                          : min(kFusedSamples, a.n - base);
+  const int base = blockIdx.x * kFusedSamples;
+  const int rows = min(kFusedSamples, a.n - base);
   const int steps = a.P - 1;
 
   KC_RSTAMP(0);
@@ -207,11 +204,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   if (tid < kFusedSamples) {
     lhit[tid] = 0;
     const bool in = tid < rows;
-    const int e = base + tid * stride;
-    lperm[tid] = in ? a.perm[e] : 0;
-    lrow[tid] = in ? a.prow[e] : 0;
-    lvx[tid] = in ? a.pvx[e] : 0.0;
-    lvy[tid] = in ? a.pvy[e] : 0.0;
+    lperm[tid] = in ? a.perm[base + tid] : 0;
+    lrow[tid] = in ? a.prow[base + tid] : 0;
+    lvx[tid] = in ? a.pvx[base + tid] : 0.0;
+    lvy[tid] = in ? a.pvy[base + tid] : 0.0;
   }
   if constexpr (kCycle) cycle_fill_tables(tail, smem, tid, kFusedBlock);
   if (a.c.enabled && a.c.dil == 2) {
@@ -302,7 +298,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
         // the ticket is still taken: the last workgroup publishes the error
         if (tid == 0)
           atomicOr(reinterpret_cast<unsigned long long *>(a.dev_err), 1ull);
-        cycle_epilogue<kFusedBlock>(a, tail, KEY_NONE, 0ull, -1, lpos, lperm, tid);
+        cycle_epilogue<kFusedBlock>(a, tail, KEY_NONE, 0, -1, lpos, lperm, lperm, tid);
       } else {
         if (tid == 0) *a.dev_err = 1;
       }
@@ -451,7 +447,6 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   KC_RSTAMP(5);
   __shared__ int lsurv[kFusedSamples];  // cycle: slots of the survivors, ascending
   __shared__ int nsurv;
-  __shared__ unsigned long long lmask;
   if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
     const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
     if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
@@ -459,10 +454,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     const int cnt = __popcll(bal);
     if constexpr (kCycle) {
       if (ok) lsurv[__popcll(bal & ((1ull << tid) - 1ull))] = tid;
-      if (tid == 0) {
-        nsurv = cnt;
-        lmask = bal;
-      }
+      if (tid == 0) nsurv = cnt;
     } else {
       int start = 0;
       if (tid == 0 && cnt)
@@ -479,8 +471,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     int best_slot = -1;
     const long long key = cycle_costs<kFusedSamples, kFusedBlock>(a, tail, smem, lpos, PP, lperm, lsurv,
                                                                   nsurv, tid, &best_slot);
-    cycle_epilogue<kFusedBlock>(a, tail, key, lmask, best_slot, lpos + (best_slot < 0 ? 0 : best_slot) * PP,
-                                lperm, tid);
+    KC_RSTAMP(8);
+    cycle_epilogue<kFusedBlock>(a, tail, key, nsurv, best_slot, lpos + (best_slot < 0 ? 0 : best_slot) * PP,
+                                lperm, lsurv, tid);
+    KC_RSTAMP(9);
   }
 }
 
