@@ -4,10 +4,18 @@
 costmap) on N MI355X, through the C ABI of libkompass_hip.so.
 
 A "step" is one full cycle over one batch of synthetic input: host trig table
-+ reachable-window occupancy bits (H2D), roll-out + collision kernel, path /
-obstacle cost kernels, ordered cost finalisation + argmin, [N>1: one 8-byte
-RCCL all-reduce(min)], result to the host.  Sensor data, tracked segment and
-the sample lattice are resident in HBM before the timed region starts.
+(BAR stores), roll-out + collision gate + path / obstacle costs + ordered cost
+finalisation + argmin + result record in ONE kernel launch (kc_dwa_cycle;
+`--split`: the three-kernel cycle), [N>1: one 8-byte RCCL all-reduce(min)],
+result to the host.  Sensor data, tracked segment and the sample lattice are
+resident in HBM before the timed region starts.
+
+The headline line is BASELINE configs[1] on SURVEY 8(d)'s scene (Bernoulli 0.02
+clutter: only ~5 % of the samples survive the collision gate, so the cost stage
+has little to do -- `config.workload` says how many).  The same JSON line
+therefore carries the cycle on two more scenes of the same lattice, each with
+its own value / roofline / cpu_baseline: `mid_density` (about half admissible)
+and `open_space` (every sample admissible).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
 torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
@@ -83,7 +91,7 @@ def controller_bench(args, rank, world, local_rank):
     cfg = args.config
     base = syn.CONFIGS[cfg]
     # weak scaling: every rank owns one BASELINE-sized block of the lattice
-    inp = syn.make_controller_inputs(cfg, seed=0)
+    inp = syn.make_controller_inputs(cfg, seed=0, scene=args.scene)
     n_vx, n_om = base["n_vx"], base["n_om"]
     if base["ctr"] == syn.OMNI:
         vx, vy, om = syn.lattice_omni(n_vx * world, base["n_vy"], n_om)
@@ -96,6 +104,8 @@ def controller_bench(args, rank, world, local_rank):
     ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1),
                         inp["octree_res"], inp["dt"], max_samples=n_total, max_points=P,
                         max_segment=S, max_obstacles=O, acc_limits=inp["acc_limits"], device=local_rank)
+    if args.split:
+        ctx.set_option("fused_cycle", 0)
     ctx.set_weights(kh.make_weights(*inp["weights"]))
     ctx.set_points(inp["state"], inp["points"], inp["max_range"])
     ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
@@ -175,40 +185,44 @@ def controller_bench(args, rank, world, local_rank):
         ms_per_step = 1e3 * elapsed / args.steps
         steps_total = n_total * P  # trajectory-steps per cycle over all ranks
         value = steps_total * args.steps / elapsed
-        dom = max(kernel_ms, key=lambda k: np.mean(kernel_ms[k]))
-        dom_ms = float(np.mean(kernel_ms[dom]))
-        bytes_launch = algorithmic_bytes(count, P, base["map_side"], S, O)
-        achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(dom)
+        n_adm = int(ctx.cycle(pose(0), P).n_admissible) if not use_dist else None
+        robot = 'omni' if base['ctr'] == 2 else 'diff-drive' if base['ctr'] == 1 else 'Ackermann'
         out = {
             "metric": "trajectory-steps/s", "value": value, "unit": "trajectory-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 roll-out / f32 costs", "data": "synthetic",
             "config": {
-                "workload": f"{cfg}: DWA {'omni' if base['ctr'] == 2 else 'diff-drive' if base['ctr'] == 1 else 'Ackermann'}, "
-                            f"{count} samples x {P} steps per GPU, {base['map_side']}x{base['map_side']}@0.05 costmap "
-                            f"({O} occupied cells), tracked segment {S} pts, weights path/goal/obstacles",
+                "workload": f"{cfg}: DWA {robot}, {count} samples x {P} steps per GPU, "
+                            f"{base['map_side']}x{base['map_side']}@0.05 costmap, scene '{args.scene}' "
+                            f"({O} occupied cells; {n_adm if n_adm is not None else 'n/a'} of {count} samples "
+                            f"admissible after the collision gate), tracked segment {S} pts, weights "
+                            f"path/goal/obstacles; every one of the {count} x {P} steps is rolled out and "
+                            f"collision-checked, costs are computed for the admissible samples",
+                "scene": args.scene, "n_admissible": n_adm,
                 "samples_per_gpu": count, "global_samples": n_total, "points": P,
+                "launches_per_cycle": len(kernel_ms),
+                "cycle": "three kernels (--split)" if args.split else "single launch (kc_dwa_cycle)",
                 "parallelism": f"sample-shard x{world}" if world > 1 else "single GPU",
             },
             "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
             "latency_min_ms": float(np.min(lat) * 1e3), "latency_max_ms": float(np.max(lat) * 1e3),
             "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
             "host_phases_ms": {k: float(np.mean(v)) for k, v in host_ms.items()},
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": dom_ms,
-                "note": "latency/VALU-bound path: the whole cycle moves ~7 MB (SURVEY 8d); "
-                        "`achieved` prices the cycle's algorithmic bytes against the slowest kernel",
-            },
+            "roofline": roofline_of(kernel_ms, count, P, base["map_side"], S, O),
             "winner": {"found": found, "cost": cost, "raw_index": raw},
         }
-        if world == 1:
-            out["extras"] = extras(ctx, inp, P, pose)
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(inp, vx, vy, om, pose(args.steps - 1), found, cost, raw, args)
+            out["cpu_baseline"] = cpu_baseline(inp, vx, vy, om, pose(args.steps - 1), found, cost, raw, args,
+                                               args.cpu_seconds)
+        if world == 1 and not use_dist and not args.only_headline:
+            # the same lattice on the two other scenes: each a bench line of its own
+            for key, scene in (("mid_density", "mid"), ("open_space", "open")):
+                if scene == args.scene:
+                    continue
+                out[key] = scene_leg(ctx, cfg, scene, inp, vx, vy, om, P, S, pose, args)
+            ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+            out["extras"] = extras(ctx, inp, P, pose)
     if use_dist:
         import torch.distributed as dist
 
@@ -218,9 +232,71 @@ def controller_bench(args, rank, world, local_rank):
     return out
 
 
+def roofline_of(kernel_ms, count, P, map_side, S, O):
+    """HBM roofline of the dominant kernel: algorithmic bytes of ONE launch (SURVEY
+    8d: 16 B per trajectory-step + 20 B per sample + per-cycle constants; a launch
+    of any kernel of the cycle covers all N x P steps) / its mean duration by HIP
+    events on the launch stream."""
+    dom = max(kernel_ms, key=lambda k: np.mean(kernel_ms[k]))
+    dom_ms = float(np.mean(kernel_ms[dom]))
+    bytes_launch = algorithmic_bytes(count, P, map_side, S, O)
+    achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(dom)
+    return {
+        "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": dom_ms,
+        "note": "latency / VALU-issue bound path: the whole cycle moves ~7 MB (SURVEY 8d); the single-launch "
+                "cycle keeps the poses in LDS and writes no float rows, so its HBM traffic is far below the "
+                "algorithmic bytes it is priced with (explanatory counters: profiles/*_pmc_sq.json)",
+    }
+
+
+def scene_leg(ctx, cfg, scene, inp, vx, vy, om, P, S, pose, args):
+    """One more bench line on the same context and lattice: another costmap."""
+    import synthetic as syn
+
+    base = syn.CONFIGS[cfg]
+    pts = syn.scene_points(cfg, scene, seed=0)
+    ctx.set_points(inp["state"], pts, inp["max_range"])
+    n = len(vx)
+    for i in range(args.warmup):
+        r = ctx.cycle(pose(i), P)
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        r = ctx.cycle(pose(i), P)
+        lat.append(time.perf_counter() - ts)
+    elapsed = time.perf_counter() - t0
+    ctx.timing_enable(True)
+    kernel_ms = {}
+    for i in range(min(args.steps, 500)):
+        ctx.cycle(pose(i), P)
+        for name, ms in ctx.timings():
+            if not name.startswith("host:"):
+                kernel_ms.setdefault(name, []).append(ms)
+    ctx.timing_enable(False)
+    r = ctx.cycle(pose(args.steps - 1), P)
+    leg = {
+        "metric": "trajectory-steps/s", "value": n * P * args.steps / elapsed, "unit": "trajectory-steps/s",
+        "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
+        "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
+        "config": {"workload": f"{cfg} lattice ({n} x {P}) on scene '{scene}': {len(pts)} occupied cells, "
+                               f"{int(r.n_admissible)} of {n} samples admissible", "scene": scene,
+                   "n_admissible": int(r.n_admissible), "obstacles": int(len(pts))},
+        "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
+        "roofline": roofline_of(kernel_ms, n, P, base["map_side"], S, len(pts)),
+    }
+    if not args.no_cpu:
+        leg["cpu_baseline"] = cpu_baseline(dict(inp, points=pts), vx, vy, om, pose(args.steps - 1), bool(r.found),
+                                           float(r.cost), int(r.raw_index), args, max(2.0, args.cpu_seconds / 3))
+    return leg
+
+
 def extras(ctx, inp, P, pose):
-    """Not part of `value`: what the per-cycle input updates cost, and the same
-    cycle when every sample is admissible (robot in open space)."""
+    """Not part of `value`: what the per-cycle input updates cost (sensor data,
+    tracked segment, mapper hand-off)."""
     def med(fn, n):
         ts = []
         for i in range(n):
@@ -255,13 +331,6 @@ def extras(ctx, inp, P, pose):
     out["update_and_cycle_resident_path_ms"] = med(fresh_inputs_window_cycle, 100)
     out["resident_path_same_result"] = bool(ra.raw_index == rb.raw_index and np.float32(ra.cost) == np.float32(rb.cost))
     ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
-    far = pts[np.hypot(pts[:, 0], pts[:, 1]) > 10.0]
-    ctx.set_points(inp["state"], far, inp["max_range"])
-    for i in range(20):
-        r = ctx.cycle(pose(i), P)
-    out["open_space"] = {"ms_per_step": med(lambda i: ctx.cycle(pose(i), P), 200),
-                         "n_admissible": int(r.n_admissible), "obstacles": int(len(far)),
-                         "what": "same lattice, obstacles nearer than 10 m removed: every sample admissible"}
     out["mapper_handoff"] = handoff_extra(ctx, inp, P, pose, med)
     ctx.set_points(inp["state"], inp["points"], inp["max_range"])
     r = ctx.cycle(pose(0), P)
@@ -322,7 +391,7 @@ def usable_cpus():
     return max(1, n)
 
 
-def cpu_baseline(inp, vx, vy, om, state, found, cost, raw, args):
+def cpu_baseline(inp, vx, vy, om, state, found, cost, raw, args, seconds):
     """The oracle (a port of the reference CPU path, `kind: port`) timed on this
     host's cores on a bounded sample of the same workload, 1 thread (the
     reference default max_num_threads=1, dwa.py:131) and all cores; also checks
@@ -345,16 +414,21 @@ def cpu_baseline(inp, vx, vy, om, state, found, cost, raw, args):
     oi, oc, na = ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx, vy, om, threads=ncores)
     t_mt = time.perf_counter() - t0
     parity = bool((oi >= 0) == found and (not found or (oi == raw and np.float32(oc) == np.float32(cost))))
-    # 1-thread timing on a bounded sample: whole cycles until ~args.cpu_seconds
+    # 1-thread timing on a bounded sample: whole cycles until ~`seconds` (a cycle over every
+    # `stride`-th sample when a full one would take longer than that: the all-core cycle above
+    # tells how long)
+    stride = max(1, int(np.ceil(t_mt * ncores / max(seconds, 0.5))))
+    svx, svy, som = vx[::stride], vy[::stride], om[::stride]
     t0 = time.perf_counter()
     cycles = 0
-    while cycles < 3 or (time.perf_counter() - t0 < args.cpu_seconds and cycles < 1000):
-        ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx, vy, om, threads=1)
+    while cycles < (3 if stride == 1 else 1) or (time.perf_counter() - t0 < seconds and cycles < 1000):
+        ko.baseline_cycle(coll, ci, state, inp["dt"], P, svx, svy, som, threads=1)
         cycles += 1
     t_1 = (time.perf_counter() - t0) / cycles
     return {
-        "value": n * P / t_1, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
-        "sample": f"{cycles} full cycles ({n} samples x {P} steps each), {t_1 * 1e3:.1f} ms per cycle on 1 thread",
+        "value": len(svx) * P / t_1, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{cycles} cycles over {len(svx)} of the {n} samples (every {stride}th) x {P} steps, "
+                  f"{t_1 * 1e3:.1f} ms per cycle on 1 thread",
         "all_cores": {"value": n * P / t_mt, "cores": ncores, "seconds": t_mt,
                       "sample": f"1 full cycle ({n} samples)"},
         "gpu_matches_cpu_winner": parity, "cpu_winner": {"raw_index": int(oi), "cost": float(oc),
@@ -573,6 +647,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--scene", default="survey", choices=["survey", "mid", "open"],
+                    help="costmap of the headline line (SURVEY 8d's by default); the other two follow in the same JSON")
+    ap.add_argument("--split", action="store_true", help="three-kernel cycle instead of the single launch")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="no mid_density / open_space / extras legs (profiling passes: one scene per process)")
     ap.add_argument("--mapper", action="store_true", help="bench the LocalMapper (cfg4) instead")
     ap.add_argument("--bayes", action="store_true", help="with --mapper: the Bayesian mapping loop (8f rank 3)")
     ap.add_argument("--pointcloud", action="store_true", help="SURVEY 8f rank 1 instead of the controller")

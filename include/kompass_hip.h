@@ -269,6 +269,15 @@ int kc_cost_evaluate(kc_dwa *ctx, const float *paths_x, const float *paths_y,
                      const float *vel_omega, size_t n, size_t num_points,
                      float *costs_out, kc_result *out);
 
+/* the same in two steps, for callers that score one set of trajectories again and
+ * again (the reference's own benchmark does: benchmarks/benchmark_runner.cpp:
+ * 152-185 times getMinTrajectoryCost on pre-generated samples): the samples stay
+ * resident in HBM, kc_cost_evaluate_resident runs cost kernels + argmin only */
+int kc_cost_upload(kc_dwa *ctx, const float *paths_x, const float *paths_y,
+                   const float *vel_vx, const float *vel_vy, const float *vel_omega,
+                   size_t n, size_t num_points);
+int kc_cost_evaluate_resident(kc_dwa *ctx, float *costs_out, kc_result *out);
+
 /* multi-GPU exchange: after kc_dwa_evaluate the context
  * holds, on the device, int64 key = (sortable(cost) << 32) | global raw index
  * (signed-comparable; INT64_MAX = nothing found) and int64 n_admissible.

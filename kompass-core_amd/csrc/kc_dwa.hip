@@ -2574,9 +2574,9 @@ int kc_dwa_get_samples(kc_dwa *c, float *paths_x, float *paths_y,
   return KC_OK;
 }
 
-int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
-                     const float *vvx, const float *vvy, const float *vom,
-                     size_t n, size_t P, float *costs_out, kc_result *out) {
+// caller-provided trajectories -> device (kc_cost_evaluate = upload + evaluate)
+int kc_cost_upload(kc_dwa *c, const float *paths_x, const float *paths_y, const float *vvx,
+                   const float *vvy, const float *vom, size_t n, size_t P) {
   if (!c || (n && (!paths_x || !paths_y)))
     KC_FAIL(KC_ERR_INVALID, "null argument");
   if (P < 2) KC_FAIL(KC_ERR_RANGE, "num_points must be >= 2");
@@ -2585,7 +2585,8 @@ int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
   KC_TRY(use_device(c));
   hipStream_t s = c->stream;
   KC_HIP(hipStreamSynchronize(s));
-  c->timing.begin_cycle();
+  c->drained = true;
+  c->update_busy = false;
   c->P = P;
   c->n_roll = n;
   c->external = true;
@@ -2593,6 +2594,9 @@ int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
   c->have_vel = vel;
   c->rolled = true;
   c->evaluated = false;
+  c->cycle_launched = false;
+  c->paths_valid = true;
+  c->row_valid = false;
   KC_TRY(ensure_cycle_buffers(c, std::max<size_t>(n, 1), P));
   if (n) {
     KC_HIP(hipMemcpyAsync(c->d_px.p, paths_x, n * P * 4, hipMemcpyHostToDevice, s));
@@ -2608,13 +2612,33 @@ int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
     }
     hipLaunchKernelGGL(fill_u8_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
                        s, c->d_flags.p, static_cast<int>(n), uint8_t(1));
+    KC_HIP(hipStreamSynchronize(s));  // pageable sources
   }
+  return KC_OK;
+}
+
+int kc_cost_evaluate_resident(kc_dwa *c, float *costs_out, kc_result *out) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!c->external || !c->rolled) KC_FAIL(KC_ERR_STATE, "kc_cost_upload has not run");
+  KC_TRY(use_device(c));
+  const size_t n = c->n_roll;
+  if (!c->drained || c->timing.enabled) KC_HIP(hipStreamSynchronize(c->stream));
+  c->drained = false;
+  c->timing.begin_cycle();
+  c->need_compact = true;
   KC_TRY(run_evaluate(c, n, 0));
   c->evaluated = true;
   KC_TRY(fetch(c, out, n));
   if (costs_out && n)
     KC_HIP(hipMemcpy(costs_out, c->d_costs.p, n * 4, hipMemcpyDeviceToHost));
   return KC_OK;
+}
+
+int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
+                     const float *vvx, const float *vvy, const float *vom,
+                     size_t n, size_t P, float *costs_out, kc_result *out) {
+  KC_TRY(kc_cost_upload(c, paths_x, paths_y, vvx, vvy, vom, n, P));
+  return kc_cost_evaluate_resident(c, costs_out, out);
 }
 
 int kc_dwa_result_device(kc_dwa *c, void **dev) {

@@ -112,6 +112,8 @@ SIGNATURES = {
     "kc_dwa_get_sample_velocity": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),
     "kc_dwa_get_samples": (C.c_int, [_vp, _fp, _fp, _ip, _fp, _sz, C.POINTER(_sz)]),
     "kc_cost_evaluate": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _sz, _sz, _fp, C.POINTER(Result)]),
+    "kc_cost_upload": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _sz, _sz]),
+    "kc_cost_evaluate_resident": (C.c_int, [_vp, _fp, C.POINTER(Result)]),
     "kc_dwa_result_device": (C.c_int, [_vp, C.POINTER(_vp)]),
     "kc_dwa_publish_result": (C.c_int, [_vp]),
     "kc_dwa_count_admissible_before": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64)]),
@@ -396,6 +398,19 @@ class DwaContext:
         _check(lib().kc_cost_evaluate(self.h, _pf(px), _pf(py), _pf(v[0]), _pf(v[1]), _pf(v[2]), N, P,
                                       _pf(costs), C.byref(r)))
         return r, costs[:N]
+
+    def cost_upload(self, paths_x, paths_y, vel=None):
+        px, py = _f32(paths_x), _f32(paths_y)
+        N, P = px.shape
+        self._P, self._N = P, N
+        v = [_f32(a) for a in vel] if vel is not None else [None, None, None]
+        _check(lib().kc_cost_upload(self.h, _pf(px), _pf(py), _pf(v[0]), _pf(v[1]), _pf(v[2]), N, P))
+
+    def cost_evaluate_resident(self, with_costs=True):
+        r = Result()
+        costs = np.zeros(max(self._N, 1), np.float32) if with_costs else None
+        _check(lib().kc_cost_evaluate_resident(self.h, _pf(costs), C.byref(r)))
+        return (r, costs[:self._N]) if with_costs else r
 
     def publish_result(self):
         """After an in-place reduction of the device record: hand it to the host
