@@ -294,6 +294,32 @@ int kc_dwa_publish_result(kc_dwa *ctx);
  * to rebuild the reference's compacted index across shards) */
 int kc_dwa_count_admissible_before(kc_dwa *ctx, int64_t global_raw_index,
                                    int64_t *count_out);
+/* The exchange itself, inside this library (no framework in the product path): one
+ * process per GPU, RCCL over xGMI.  kc_comm_unique_id on one rank, the 128 bytes
+ * to every rank by any transport the caller has, kc_comm_create on all of them
+ * (collective: ncclCommInitRank).  librccl is opened on first use (dlopen). */
+#define KC_COMM_ID_BYTES 128
+typedef struct kc_comm kc_comm;
+int kc_comm_unique_id(uint8_t id_out[KC_COMM_ID_BYTES]);
+int kc_comm_create(int rank, int world, const uint8_t id_in[KC_COMM_ID_BYTES], int device, kc_comm **out);
+void kc_comm_destroy(kc_comm *comm);
+int kc_comm_rank(const kc_comm *comm);
+int kc_comm_world(const kc_comm *comm);
+/* after kc_dwa_evaluate: ONE ncclAllReduce(1 x int64, ncclMin) of the packed key in
+ * the device record, on the context's stream, and the hand-off of the reduced
+ * record to the host (kc_dwa_fetch_result then returns the GLOBAL winner: found,
+ * cost, raw_index; index / n_admissible stay the shard's) */
+int kc_dwa_allreduce_best(kc_dwa *ctx, kc_comm *comm);
+/* DWA::findBestPath body of a sharded controller: this context's shard rolled out
+ * and scored (single launch when it fits), the all-reduce, the result.  Collective:
+ * every rank of the communicator calls it with the same start / num_points. */
+int kc_dwa_cycle_sharded(kc_dwa *ctx, kc_comm *comm, const kc_state *start, size_t num_points,
+                         kc_result *out);
+/* the winner's index in the reference's admissible-only numbering: admissible
+ * samples in front of it on every shard, one ncclAllReduce(1 x int64, ncclSum).
+ * Collective; global_raw_index from the result of kc_dwa_cycle_sharded. */
+int kc_dwa_global_index(kc_dwa *ctx, kc_comm *comm, int64_t global_raw_index, int64_t *index_out);
+
 /* decode helpers for the packed key (pure host functions) */
 float kc_key_cost(int64_t key);
 int64_t kc_key_index(int64_t key);

@@ -487,35 +487,53 @@ __device__ __forceinline__ void group8_segment_search(const CostArgs &a, const S
   arg_out = arg;
 }
 
-// smoothness + jerk of caller-provided velocity profiles (kc_cost_evaluate):
-// serial loops, evaluated redundantly by every lane (wave-uniform addresses)
-__device__ __forceinline__ float add_velocity_costs(const CostArgs &a, int n, float total) {
+// smoothness + jerk of caller-provided velocity profiles (kc_cost_evaluate),
+// by one full wavefront: cost += pow(delta, 2) / accLimit in float, each term a
+// double quotient rounded into the running float (cost_evaluator.cpp:187-233).
+// The quotients do not depend on the running sum, so the lanes form 64 steps'
+// worth of them at once (the f64 divisions are the expensive part); only the
+// additions, whose order fixes the rounding, walk the lanes in step order.
+__device__ __forceinline__ double lane_value_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <bool kJerk>
+__device__ __forceinline__ float velocity_cost_sum(const CostArgs &a, const float *vx, const float *vy,
+                                                   const float *om, int nv, int lane) {
+  constexpr int k_first = kJerk ? 2 : 1;
+  float c = 0.0f;
+  for (int k0 = k_first; k0 < nv; k0 += 64) {
+    const int k = k0 + lane;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (k < nv) {
+      auto term = [&](const float *v, float lim) {
+        const float d = kJerk ? v[k] - 2 * v[k - 1] + v[k - 2] : v[k] - v[k - 1];
+        const double dd = static_cast<double>(d);
+        return (dd * dd) / static_cast<double>(lim);
+      };
+      if (a.acc0 > 0) t0 = term(vx, a.acc0);
+      if (a.acc1 > 0) t1 = term(vy, a.acc1);
+      if (a.acc2 > 0) t2 = term(om, a.acc2);
+    }
+    const int cnt = min(64, nv - k0);
+    for (int j = 0; j < cnt; ++j) {
+      if (a.acc0 > 0) c = static_cast<float>(static_cast<double>(c) + lane_value_f64(t0, j));
+      if (a.acc1 > 0) c = static_cast<float>(static_cast<double>(c) + lane_value_f64(t1, j));
+      if (a.acc2 > 0) c = static_cast<float>(static_cast<double>(c) + lane_value_f64(t2, j));
+    }
+  }
+  return c;
+}
+__device__ __forceinline__ float add_velocity_costs(const CostArgs &a, int n, float total, int lane) {
   const int nv = a.P - 1;
   const float *vx = a.vvx + (size_t)n * nv;
   const float *vy = a.vvy + (size_t)n * nv;
   const float *om = a.vom + (size_t)n * nv;
   const float div = static_cast<float>(3L * nv);
-  if (a.w_smooth > 0.0) {  // cost_evaluator.cpp:187-206
-    float c = 0.0f;
-    for (int k = 1; k < nv; ++k) {
-      if (a.acc0 > 0) c = sq_over(c, vx[k] - vx[k - 1], a.acc0);
-      if (a.acc1 > 0) c = sq_over(c, vy[k] - vy[k - 1], a.acc1);
-      if (a.acc2 > 0) c = sq_over(c, om[k] - om[k - 1], a.acc2);
-    }
-    total = accum(total, a.w_smooth, kc::div_rn(c, div));
-  }
-  if (a.w_jerk > 0.0) {  // cost_evaluator.cpp:209-233
-    float c = 0.0f;
-    for (int k = 2; k < nv; ++k) {
-      if (a.acc0 > 0)
-        c = sq_over(c, vx[k] - 2 * vx[k - 1] + vx[k - 2], a.acc0);
-      if (a.acc1 > 0)
-        c = sq_over(c, vy[k] - 2 * vy[k - 1] + vy[k - 2], a.acc1);
-      if (a.acc2 > 0)
-        c = sq_over(c, om[k] - 2 * om[k - 1] + om[k - 2], a.acc2);
-    }
-    total = accum(total, a.w_jerk, kc::div_rn(c, div));
-  }
+  if (a.w_smooth > 0.0)  // cost_evaluator.cpp:187-206
+    total = accum(total, a.w_smooth, kc::div_rn(velocity_cost_sum<false>(a, vx, vy, om, nv, lane), div));
+  if (a.w_jerk > 0.0)  // cost_evaluator.cpp:209-233
+    total = accum(total, a.w_jerk, kc::div_rn(velocity_cost_sum<true>(a, vx, vy, om, nv, lane), div));
   return total;
 }
 
@@ -554,7 +572,7 @@ __device__ __forceinline__ float team_sample_total(const CostArgs &a, int n, int
   if (a.O > 0 && a.w_obs > 0.0)
     total = accum(total, a.w_obs,
                   obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(s_obest))));
-  if (a.have_vel) total = add_velocity_costs(a, n, total);
+  if (a.have_vel) total = add_velocity_costs(a, n, total, lane);
   // constant-velocity samples: both terms are exactly 0 and `total += w*0`
   // leaves total unchanged, so nothing to do when !have_vel.
   return total;
@@ -1036,7 +1054,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
     total = accum(total, a.w_obs,
                   obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(
                                             *const_cast<volatile unsigned long long *>(obest)))));
-  if (a.have_vel) total = add_velocity_costs(a, n, total);
+  if (a.have_vel) total = add_velocity_costs(a, n, total, lane);
   // constant-velocity samples: both terms are exactly 0 and `total += w*0`
   // leaves total unchanged, so nothing to do when !have_vel.
   return total;

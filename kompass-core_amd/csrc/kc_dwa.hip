@@ -188,6 +188,8 @@ struct kc_dwa {
   DevBuf<uint32_t> d_adm_bits;         // admissible local ids of the running cycle (bitmap)
   PinBuf<uint32_t> h_wrow;             // best row of every workgroup of a single-launch cycle
   size_t wrow_off = 0;                 // words in front of the winner's row
+  bool sharded_call = false;   // kc_dwa_cycle_sharded: the cycle kernel leaves the host record to the
+                               // hand-off behind the all-reduce
   long long rec_w4 = 0;        // row word of the record fetched last
   bool row_valid = false;      // h_wrow holds the winner row of `last`
 };
@@ -2298,8 +2300,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
       tail.block_keys = c->d_block_keys.p;
       tail.adm_bits = c->d_adm_bits.p;
       tail.result = c->d_result.p;
-      tail.host_pub = c->h_pub.p;
-      tail.host_rows = c->h_wrow.p;
+      tail.host_pub = c->sharded_call ? nullptr : c->h_pub.p;
+      tail.host_rows = c->sharded_call ? nullptr : c->h_wrow.p;
       tail.seq = ++c->seq;
       tail.c.block_keys = c->d_block_keys.p;
       a.dev_err = c->d_result.p + W_NADM;
@@ -2655,6 +2657,46 @@ int kc_dwa_publish_result(kc_dwa *c) {
                      c->h_pub.p, ++c->seq);
   KC_HIP(hipGetLastError());
   c->pub_pending = true;
+  return KC_OK;
+}
+
+int kc_dwa_allreduce_best(kc_dwa *c, kc_comm *m) {
+  if (!c || !m) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!c->evaluated) KC_FAIL(KC_ERR_STATE, "nothing evaluated yet");
+  if (kc::comm_device(m) != c->prm.device)
+    KC_FAIL(KC_ERR_INVALID, "communicator on device %d, controller on device %d", kc::comm_device(m), c->prm.device);
+  KC_TRY(use_device(c));
+  KC_TRY(kc::comm_allreduce_i64(m, c->d_result.p + R_KEY, 1, /*sum=*/false, c->stream));
+  return kc_dwa_publish_result(c);
+}
+
+int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P, kc_result *out) {
+  if (!c || !m) KC_FAIL(KC_ERR_INVALID, "null argument");
+  c->sharded_call = true;
+  int rc = rollout_impl(c, start, P, true);
+  c->sharded_call = false;
+  KC_TRY(rc);
+  if (!c->cycle_launched) KC_TRY(kc_dwa_evaluate(c));
+  KC_TRY(kc_dwa_allreduce_best(c, m));
+  return kc_dwa_fetch_result(c, out);
+}
+
+int kc_dwa_global_index(kc_dwa *c, kc_comm *m, int64_t raw, int64_t *index_out) {
+  if (!c || !m || !index_out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (!c->rolled) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
+  KC_TRY(use_device(c));
+  if (c->n_roll == 0 || raw < 0) {
+    KC_HIP(hipMemsetAsync(c->d_result.p + R_SCRATCH, 0, sizeof(long long), c->stream));
+  } else {
+    hipLaunchKernelGGL(count_before_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_flags.p,
+                       static_cast<int>(c->n_roll), static_cast<int>(c->external ? 0 : c->shard_first),
+                       static_cast<long long>(raw), c->d_result.p, R_SCRATCH);
+  }
+  KC_TRY(kc::comm_allreduce_i64(m, c->d_result.p + R_SCRATCH, 1, /*sum=*/true, c->stream));
+  KC_HIP(hipMemcpyAsync(c->h_result.p + R_SCRATCH, c->d_result.p + R_SCRATCH, sizeof(long long),
+                        hipMemcpyDeviceToHost, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));
+  *index_out = raw < 0 ? -1 : c->h_result.p[R_SCRATCH];
   return KC_OK;
 }
 

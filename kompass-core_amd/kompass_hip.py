@@ -117,6 +117,14 @@ SIGNATURES = {
     "kc_dwa_result_device": (C.c_int, [_vp, C.POINTER(_vp)]),
     "kc_dwa_publish_result": (C.c_int, [_vp]),
     "kc_dwa_count_admissible_before": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64)]),
+    "kc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "kc_comm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(_vp)]),
+    "kc_comm_destroy": (None, [_vp]),
+    "kc_comm_rank": (C.c_int, [_vp]),
+    "kc_comm_world": (C.c_int, [_vp]),
+    "kc_dwa_allreduce_best": (C.c_int, [_vp, _vp]),
+    "kc_dwa_cycle_sharded": (C.c_int, [_vp, _vp, C.POINTER(State), _sz, C.POINTER(Result)]),
+    "kc_dwa_global_index": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "kc_key_cost": (C.c_float, [C.c_int64]),
     "kc_key_index": (C.c_int64, [C.c_int64]),
     "kc_key_pack": (C.c_int64, [C.c_float, C.c_int64]),
@@ -216,6 +224,38 @@ def make_limits(vx=(1.0, 10.0, 10.0), vy=(1.0, 10.0, 10.0), omega=(np.pi, 1.0, 1
 
 def make_weights(path=1.0, goal=1.0, obstacles=1.0, smoothness=1.0, jerk=1.0) -> Weights:
     return Weights(path, goal, obstacles, smoothness, jerk)
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI: call on one rank, send the bytes to every rank."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().kc_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """Owner of one kc_comm (an RCCL communicator inside libkompass_hip.so)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes, device: int = 0):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self.h = _vp()
+        _check(lib().kc_comm_create(int(rank), int(world), buf, int(device), C.byref(self.h)))
+        self.rank, self.world = int(rank), int(world)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            lib().kc_comm_destroy(self.h)
+            self.h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DwaContext:
@@ -411,6 +451,22 @@ class DwaContext:
         costs = np.zeros(max(self._N, 1), np.float32) if with_costs else None
         _check(lib().kc_cost_evaluate_resident(self.h, _pf(costs), C.byref(r)))
         return (r, costs[:self._N]) if with_costs else r
+
+    def allreduce_best(self, comm: "Comm"):
+        """ONE ncclAllReduce(int64, min) of the key record + hand-off of the reduced record."""
+        _check(lib().kc_dwa_allreduce_best(self.h, comm.h))
+
+    def cycle_sharded(self, comm: "Comm", state, P) -> Result:
+        st = State(*state)
+        self._P = int(P)
+        r = Result()
+        _check(lib().kc_dwa_cycle_sharded(self.h, comm.h, C.byref(st), int(P), C.byref(r)))
+        return r
+
+    def global_index(self, comm: "Comm", raw_index) -> int:
+        v = C.c_int64(0)
+        _check(lib().kc_dwa_global_index(self.h, comm.h, int(raw_index), C.byref(v)))
+        return v.value
 
     def publish_result(self):
         """After an in-place reduction of the device record: hand it to the host

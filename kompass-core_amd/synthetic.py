@@ -157,3 +157,41 @@ def make_controller_inputs(name: str, seed: int = 0, scale: float = 1.0, scene: 
         weights=c["weights"], max_range=10.0, robot=ROBOT_CYLINDER,
         acc_limits=(LIMITS["vx"][1], LIMITS["vy"][1], LIMITS["omega"][2]),
     )
+
+
+# ---------------------------------------------------------------------------
+# The reference's own published benchmark workloads (inputs restated from
+# src/kompass_cpp/benchmarks/benchmark_runner.cpp; data only)
+# ---------------------------------------------------------------------------
+def ref_cost5k_samples(n_samples: int = 5001, horizon: float = 10.0, dt: float = 0.01):
+    """generate_heavy_trajectory_samples (benchmark_runner.cpp:36-89): one straight
+    trajectory, then pairs with a lateral-velocity / a heading fluctuation of growing
+    amplitude.  -> paths_x, paths_y [N, P] float32, vel (vx, vy, omega) [N, P-1] float32."""
+    P = int(horizon / dt)
+    v1, max_fl = 1.0, 0.5
+    i = np.arange(P, dtype=np.float64)
+    px, py, vx, vy, om = [], [], [], [], []
+
+    def push(x, y, a, b, c):
+        px.append(x.astype(np.float32)); py.append(y.astype(np.float32))
+        vx.append(np.full(P - 1, a, np.float64).astype(np.float32) if np.isscalar(a) else a[:P - 1].astype(np.float32))
+        vy.append(np.full(P - 1, b, np.float64).astype(np.float32) if np.isscalar(b) else b[:P - 1].astype(np.float32))
+        om.append(np.full(P - 1, c, np.float64).astype(np.float32) if np.isscalar(c) else c[:P - 1].astype(np.float32))
+
+    push(dt * v1 * i, np.zeros(P), v1, 0.0, 0.0)
+    pairs = (n_samples - 1) // 2
+    step = max_fl / (pairs if pairs > 0 else 1)
+    for p in range(1, pairs + 1):
+        amp = p * step
+        fl = amp * np.sin(2 * math.pi * i / P)
+        push(dt * v1 * i, dt * fl * i, v1, fl, 0.0)
+        fa = amp * np.cos(2 * math.pi * i / P)
+        push(dt * v1 * i * np.cos(fa), dt * v1 * i * np.sin(fa), v1, 0.0, fa)
+    return (np.stack(px), np.stack(py), [np.stack(vx), np.stack(vy), np.stack(om)])
+
+
+REF_COST5K = dict(path_points=[[0.0, 0.0, 0.0], [5.0, 0.0, 0.0], [10.0, 0.0, 0.0]], interpolation=0.01,
+                  segment_length=1000.0, max_segment_points=1000,
+                  acc_limits=(3.0, 3.0, 5.0),   # x_p(1,3,5), y_p(1,3,5), a_p(3.14,3,5,8): max accelerations
+                  weights=(1.0, 1.0, 0.0, 1.0, 1.0))  # path, goal, (no obstacles set), smoothness, jerk
+REF_MAPPER400 = dict(height=400, width=400, res=0.05, beams=3600)
