@@ -309,7 +309,17 @@ PYBIND11_MODULE(kompass_cpp, m) {
              py::gil_scoped_release rel;
              d.debugVelocitySearch<std::vector<Path::Point>>(v, pts, drop); })
       .def("set_resolution", &DWA::resetOctreeResolution)
-      .def("set_sensor_max_range", &DWA::setSensorMaxRange);
+      .def("set_sensor_max_range", &DWA::setSensorMaxRange)
+      // additions of this build (no counterpart in the reference: its DWA is one device)
+      .def("enable_sharding", [](DWA &d, int rank, int world, const py::bytes &unique_id, int device) {
+             const std::string id = unique_id;
+             if (id.size() != KC_COMM_ID_BYTES) throw std::invalid_argument("unique_id must be 128 bytes (comm_unique_id())");
+             d.enableSharding(rank, world, reinterpret_cast<const uint8_t *>(id.data()), device);
+           }, py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("device") = 0,
+           "One DWA per process / GPU: contiguous sample shards + one 8-byte RCCL all-reduce(min) per cycle")
+      .def("disable_sharding", &DWA::disableSharding)
+      .def("use_resident_path", &DWA::useResidentPath, py::arg("on"),
+           "Tracked-segment tables from a device-resident copy of the path (saves host time, adds a kernel)");
 
   // -------------------------------------------------------------- mapping
   auto mp = m.def_submodule("mapping", "Local Mapping module");
@@ -497,6 +507,13 @@ PYBIND11_MODULE(kompass_cpp, m) {
       .export_values();
   m.def("set_log_level", &setLogLevel, "Set the log level");
   m.def("set_log_file", &setLogFile, "Set the log file");
+  m.def("comm_unique_id", []() {
+    uint8_t id[KC_COMM_ID_BYTES];
+    hip::check(kc_comm_unique_id(id));
+    return py::bytes(reinterpret_cast<const char *>(id), KC_COMM_ID_BYTES);
+  }, "RCCL unique id for DWA.enable_sharding: create on one rank, send to all");
+  m.def("set_host_threads", [](int n) { hip::check(kc_set_host_threads(n)); }, py::arg("n"),
+        "Threads of the host pool behind the roll-out's libm trig table (default: from the CPUs the process may use)");
   m.def("get_available_accelerators", []() {
     const int n = kc_device_count();
     return n > 0 ? std::string("HIP: ") + std::to_string(n) + " device(s) (gfx950)" : std::string("");

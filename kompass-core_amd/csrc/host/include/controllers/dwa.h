@@ -81,6 +81,19 @@ class DWA : public Follower {
     return r;
   }
 
+  // Multi-GPU: one DWA per process / GPU, all fed the same inputs; every
+  // cycle each scores its contiguous block of the sample lattice and ONE 8-byte RCCL
+  // all-reduce(min) picks the winner -- every rank returns the same command.
+  // unique_id: KC_COMM_ID_BYTES from kc_comm_unique_id() of one rank.  Collective.
+  void enableSharding(int rank, int world, const uint8_t *unique_id, int device = 0) {
+    kc_comm *raw = nullptr;
+    hip::check(kc_comm_create(rank, world, unique_id, device, &raw));
+    comm_ = std::shared_ptr<kc_comm>(raw, [](kc_comm *c) { kc_comm_destroy(c); });
+  }
+  void disableSharding() { comm_.reset(); }
+  // see CostEvaluator::useResidentPath
+  void useResidentPath(bool on) { trajCostEvaluator->useResidentPath(on); }
+
   std::tuple<MatrixXfR, MatrixXfR> getDebuggingSamples() const;
   Control::TrajectorySamples2D getDebuggingSamplesPure() const;
 
@@ -109,20 +122,24 @@ class DWA : public Follower {
       return TrajSearchResult{trajectory, true, 0.0};
     }
     adaptPredictionHorizonToCurvature();
-    // one device cycle: lattice + sensor upload + roll-out + collision gate ...
+    // lattice + sensor data of this cycle onto the device ...
     const size_t generated =
-        trajSampler->rolloutOnDevice(global_vel, currentState, scan_points, maxLocalRange_);
+        trajSampler->prepareOnDevice(global_vel, currentState, scan_points, maxLocalRange_);
     if (generated == 0) return TrajSearchResult{Trajectory2D(), false, 0.0};
-    // ... + costs + argmin against the tracked segment
+    // ... then ONE device cycle: roll-out + collision gate + costs + argmin against the
+    // tracked segment (dwa.h:215-229 of the reference as a single kernel launch)
     trajCostEvaluator->sensorDataResident = true;
     auto tracked = findTrackedPathSegment();
-    return trajCostEvaluator->getMinTrajectoryCostOnDevice(
-        currentPath.get(), tracked, trajSampler->numPointsPerTrajectory);
+    TrajectorySampler *smp = trajSampler.get();
+    return trajCostEvaluator->cycleOnDevice(
+        currentPath.get(), tracked, trajSampler->numPointsPerTrajectory, currentState, trajSampler->timeStep(),
+        [smp](size_t raw) { return smp->sampleVelocity(raw); }, generated, comm_.get());
   }
 
  private:
   double max_forward_distance_ = 0.0;
   int maxNumThreads;
+  std::shared_ptr<kc_comm> comm_;
   std::unique_ptr<TrajectorySamples2D> debuggingSamples_ = nullptr;
   float maxLocalRange_ = 10.0;
 

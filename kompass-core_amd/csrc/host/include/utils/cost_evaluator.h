@@ -70,6 +70,27 @@ class CostEvaluator {
       const Path::Path *reference_path, const Path::Path::View &tracked_segment,
       size_t numPointsPerTrajectory);
 
+  // The whole DWA::findBestPath device part on this evaluator's context, whose
+  // sensor data and sample lattice are resident (TrajectorySampler::
+  // prepareOnDevice): tracked segment up, then ONE device cycle -- roll-out,
+  // collision gate, costs, argmin in a single kernel launch when the tables fit
+  // (kc_dwa_cycle) -- and the winner row from the pinned record.  With a
+  // communicator: this context's shard of the lattice + one 8-byte all-reduce
+  // (kc_dwa_cycle_sharded); the winner's path is then re-rolled on the host from
+  // its velocity (same arithmetic, same libm) when another rank owns it.
+  //
+  // Retry contract: the early-launched kernel waits at most 50 ms for the host's
+  // trig table; a host descheduled for longer makes that ONE cycle fail
+  // (KC_ERR_HIP, "gave up waiting"), the context is usable again at once.  This
+  // call repeats such a cycle once before it throws std::runtime_error.
+  TrajSearchResult cycleOnDevice(const Path::Path *reference_path, const Path::Path::View &tracked_segment,
+                                 size_t numPointsPerTrajectory, const Path::State &pose, double time_step,
+                                 const std::function<Velocity2D(size_t)> &sampleVelocity, size_t n_generated,
+                                 kc_comm *comm = nullptr);
+  // tracked-segment tables from a device-resident copy of the path (the window moves, a kernel
+  // builds the tables) instead of host-built tables; default from KOMPASS_RESIDENT_PATH=1
+  void useResidentPath(bool on) { residentPath_ = on; }
+
   void addCustomCost(double weight, CustomCostFunction custom_cost_function) {
     customTrajCostsPtrs_.push_back(std::make_unique<CustomTrajectoryCost>(
         weight, std::move(custom_cost_function)));
@@ -101,6 +122,7 @@ class CostEvaluator {
   std::unique_ptr<TrajectoryCostsWeights> costWeights;
   hip::DwaHandle ctx_;
   unsigned long long residentSerial_ = 0;  // Path::serial() of the path resident on the device
+  bool residentPath_ = false;
 };
 
 }  // namespace Control

@@ -103,6 +103,21 @@ class TrajectorySampler {
                          float max_sensor_range);
   size_t rolloutOnDevice(const Velocity2D &current_vel, const Path::State &pose,
                          const Mapping::LocalMapper &mapper, float max_sensor_range);
+  // the same without the roll-out launch: sensor data + lattice of this cycle are
+  // resident afterwards, CostEvaluator::cycleOnDevice runs the whole cycle (one launch)
+  template <typename T>
+  size_t prepareOnDevice(const Velocity2D &current_vel, const Path::State &pose, const T &sensor_points,
+                         float max_sensor_range) {
+    collChecker->maxSensorRange = max_sensor_range;
+    collChecker->updateState(pose);
+    collChecker->updateSensorData(sensor_points);
+    return sampleWindow(current_vel);
+  }
+  // velocity triple of generated sample `raw` of the last window (host copy of the lattice)
+  Velocity2D sampleVelocity(size_t raw) const {
+    return Velocity2D(last_vx_.at(raw), last_vy_.at(raw), last_omega_.at(raw));
+  }
+  double timeStep() const { return time_step_; }
   const hip::DwaHandle &context() const { return ctx_; }
   ControlType controlType() const { return ctrType; }
   const ControlLimitsParams &limits() const { return ctrlimits; }
@@ -117,6 +132,7 @@ class TrajectorySampler {
   void init(const CollisionChecker::ShapeType shape,
             const std::vector<float> &dims, const Eigen::Vector3f &spos,
             const Eigen::Quaternionf &srot, double octreeRes);
+  size_t sampleWindow(const Velocity2D &current_vel);
   size_t launch(const Velocity2D &current_vel, const Path::State &pose);
   std::unique_ptr<TrajectorySamples2D> collect();
   hip::DwaHandle ctx_;

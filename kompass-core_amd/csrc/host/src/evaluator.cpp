@@ -61,12 +61,14 @@ CostEvaluator::CostEvaluator(TrajectoryCostsWeights &w, const Eigen::Vector3f &s
   accLimits_ = {static_cast<float>(lim.velXParams.maxAcceleration),
                 static_cast<float>(lim.velYParams.maxAcceleration),
                 static_cast<float>(lim.omegaParams.maxAcceleration)};
+  if (const char *e = std::getenv("KOMPASS_RESIDENT_PATH")) residentPath_ = e[0] == '1';
   ctx_ = makeEvaluatorContext(spos, srot, lim, maxN, P, maxSeg);
   updateCostWeights(w);
 }
 
 CostEvaluator::CostEvaluator(TrajectoryCostsWeights &w, hip::DwaHandle ctx) : ctx_(std::move(ctx)) {
   accLimits_ = {0.f, 0.f, 0.f};
+  if (const char *e = std::getenv("KOMPASS_RESIDENT_PATH")) residentPath_ = e[0] == '1';
   updateCostWeights(w);
 }
 
@@ -105,14 +107,11 @@ void CostEvaluator::uploadSegment(const Path::Path *ref, const Path::Path::View 
   const size_t S = seg.getSize();
   // a view into `ref` (what the controllers pass): the path stays resident on
   // the device, only the window moves (kc_dwa_set_path once per path content)
-  // Opt-in (KOMPASS_RESIDENT_PATH=1): it takes 10 us of segment handling off the
-  // host per cycle, but the table kernel then sits in the stream in front of the
-  // cost kernel (+7 us per cycle), while the host-built tables are ready before
-  // the roll-out has finished.
-  static const bool resident = [] {
-    const char *e = std::getenv("KOMPASS_RESIDENT_PATH");
-    return e && e[0] == '1';
-  }();
+  // Opt-in (useResidentPath / KOMPASS_RESIDENT_PATH=1): it takes 10 us of segment
+  // handling off the host per cycle, but the table kernel then sits in the stream
+  // in front of the cycle (+7 us), while the host-built tables are ready before
+  // the kernel needs them.
+  const bool resident = residentPath_;
   const size_t start = seg.getStartIndex();
   if (resident && S > 0 && start + S <= ref->getSize() && seg.getXPointer() == ref->xData() + start &&
       seg.getYPointer() == ref->yData() + start && seg.getZPointer() == ref->zData() + start) {
@@ -212,6 +211,59 @@ CostEvaluator::getMinTrajectoryCost(const std::unique_ptr<TrajectorySamples2D> &
     out.trajCost = r.cost;
     out.trajectory = trajs->getIndex((Eigen::Index)r.index);
   }
+  return out;
+}
+
+TrajSearchResult CostEvaluator::cycleOnDevice(const Path::Path *ref, const Path::Path::View &seg, size_t P,
+                                              const Path::State &pose, double time_step,
+                                              const std::function<Velocity2D(size_t)> &sampleVelocity,
+                                              size_t n_generated, kc_comm *comm) {
+  uploadSegment(ref, seg);
+  const kc_state st{pose.x, pose.y, pose.yaw, pose.speed};
+  if (comm) {
+    // contiguous block of the replicated lattice
+    const size_t world = static_cast<size_t>(kc_comm_world(comm)), rank = static_cast<size_t>(kc_comm_rank(comm));
+    const size_t first = n_generated * rank / world, last = n_generated * (rank + 1) / world;
+    hip::check(kc_dwa_set_shard(ctx_.get(), first, last - first));
+  }
+  kc_result r;
+  auto run = [&]() { return comm ? kc_dwa_cycle_sharded(ctx_.get(), comm, &st, P, &r) : kc_dwa_cycle(ctx_.get(), &st, P, &r); };
+  int rc = run();
+  if (rc == KC_ERR_HIP && std::string(kc_last_error()).find("gave up waiting") != std::string::npos)
+    rc = run();  // the retry contract (see the header): once
+  hip::check(rc);
+  sensorDataResident = false;
+  if (!customTrajCostsPtrs_.empty()) {
+    if (comm) throw std::runtime_error("custom cost callbacks are host-side and serial: not with a sharded DWA");
+    return finishWithCustomCosts(ref, P);
+  }
+  TrajSearchResult out;
+  out.trajectory = Trajectory2D(P);
+  if (!r.found) return out;
+  out.isTrajFound = true;
+  out.trajCost = r.cost;
+  const bool mine = kc_dwa_get_best(ctx_.get(), out.trajectory.path.x.data(), out.trajectory.path.y.data(),
+                                    out.trajectory.velocities.vx.data(), out.trajectory.velocities.vy.data(),
+                                    out.trajectory.velocities.omega.data()) == KC_OK;
+  if (!mine) {
+    if (!comm) hip::check(KC_ERR_STATE);
+    // the winner lives on another rank: its velocity is known here (the lattice is replicated),
+    // its path is Path::State::update (path.h:24-30) from that velocity -- the device's arithmetic
+    const Velocity2D v = sampleVelocity(static_cast<size_t>(r.raw_index));
+    const double dt = static_cast<double>(static_cast<float>(time_step));
+    double x = pose.x, y = pose.y, yaw = pose.yaw;
+    out.trajectory.path.add(0, static_cast<float>(x), static_cast<float>(y), 0.0f);
+    for (size_t i = 0; i + 1 < P; ++i) {
+      const double c = std::cos(yaw), sn = std::sin(yaw);
+      const double ix = (v.vx() * c - v.vy() * sn) * dt, iy = (v.vx() * sn + v.vy() * c) * dt;
+      x += ix;
+      y += iy;
+      yaw += v.omega() * dt;
+      out.trajectory.path.add(i + 1, static_cast<float>(x), static_cast<float>(y), 0.0f);
+      out.trajectory.velocities.add(i, v);
+    }
+  }
+  out.trajectory.path.z.setZero();
   return out;
 }
 

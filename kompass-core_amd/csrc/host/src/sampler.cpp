@@ -208,6 +208,13 @@ void TrajectorySampler::setPredictionHorizon(double horizon) {
 }
 
 size_t TrajectorySampler::launch(const Velocity2D &vel, const Path::State &pose) {
+  const size_t n = sampleWindow(vel);
+  const kc_state st = toKc(pose);
+  hip::check(kc_dwa_rollout(ctx_.get(), &st, numPointsPerTrajectory));
+  return n;
+}
+
+size_t TrajectorySampler::sampleWindow(const Velocity2D &vel) {
   kc_limits L;
   L.vx_max = ctrlimits.velXParams.maxVel;
   L.vx_acc = ctrlimits.velXParams.maxAcceleration;
@@ -227,8 +234,6 @@ size_t TrajectorySampler::launch(const Velocity2D &vel, const Path::State &pose)
                                   vel.omega(), lin_samples_max_, ang_samples_max_raw_, &n,
                                   last_vx_.data(), last_vy_.data(), last_omega_.data(),
                                   last_vx_.size()));
-  const kc_state st = toKc(pose);
-  hip::check(kc_dwa_rollout(ctx_.get(), &st, numPointsPerTrajectory));
   return n;
 }
 

@@ -45,8 +45,7 @@ struct RollArgs {
   const int32_t *row;
   const int32_t *perm;  // fused kernel: local sample ids ordered by omega row, so that the
                         // samples of a workgroup share as few trig rows as possible
-  const double *pvx, *pvy;  // velocities and trig rows in that order (one load, no
-  const int32_t *prow;      // dependent second one)
+  const int32_t *prow;      // trig rows in that order
   const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
   float *px, *py;       // [n][P] sample-major
   double2 *pos;         // [P][n] step-major double poses (collision pass input)

@@ -82,12 +82,12 @@ struct kc_dwa {
   bool lazy_dilate = true;              // KC_LAZY_DILATE=0: dilate_kernel inside every sensor update
   bool have_dil = false;
   DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
-  DevBuf<double> d_pvx, d_pvy;          // sample velocities / trig rows in d_perm order
-  DevBuf<int32_t> d_prow;
-  DevBuf<double> d_cpvx, d_cpvy;        // the same in the dealt order of the single-launch cycle
-  DevBuf<int32_t> d_cprow, d_cperm;
+  DevBuf<int32_t> d_prow;               // trig rows in d_perm order (velocities are read through d_perm)
+  DevBuf<int32_t> d_cprow, d_cperm;     // the same in the dealt order of the single-launch cycle
   DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
   std::vector<int32_t> h_perm;
+  std::vector<int32_t> uploaded_rows;   // trig-row pattern the orders on the device were built for
+  size_t perm_first = 0, perm_count = 0;  // ... and the shard
   double inv_res = 0.0;      // 1.0 / res (octomap resolution_factor)
   bool perm_valid = false;
   bool bar_dirty = false;    // BAR stores not yet fenced
@@ -561,21 +561,40 @@ int upload_samples(kc_dwa *c) {
   c->vmax_lin = 0.0;
   for (size_t i = 0; i < n; ++i)
     c->vmax_lin = std::max(c->vmax_lin, std::hypot(c->lat.vx[i], c->lat.vy[i]));
+  // A controller draws a new window every cycle: the velocities change, the
+  // pattern of trig rows (which sample shares its omega with which) rarely does.
+  // The orders the kernels walk the list in depend on that pattern only.
+  const bool same_rows = c->uploaded_rows == c->lat.row;
   c->shard_first = 0;
   c->shard_count = n;
-  c->perm_valid = false;
+  if (!same_rows) c->perm_valid = false;  // (the orders also belong to one shard: perm_first / perm_count)
   if (n == 0) return KC_OK;
   KC_TRY(c->d_vx.reserve(n));
   KC_TRY(c->d_vy.reserve(n));
   KC_TRY(c->d_row.reserve(n));
-  // pageable sources: hipMemcpy (synchronous) keeps the host vectors reusable
-  KC_HIP(hipMemcpyAsync(c->d_vx.p, c->lat.vx.data(), n * sizeof(double),
-                        hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipMemcpyAsync(c->d_vy.p, c->lat.vy.data(), n * sizeof(double),
-                        hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipMemcpyAsync(c->d_row.p, c->lat.row.data(), n * sizeof(int32_t),
-                        hipMemcpyHostToDevice, c->stream));
-  KC_HIP(hipStreamSynchronize(c->stream));
+  if (c->trig_direct) {
+    // straight into device memory over the BAR (no copy command, no stream wait);
+    // nothing queued may still read the old list
+    if (!c->drained) {
+      KC_HIP(hipStreamSynchronize(c->stream));
+      c->drained = true;
+      c->update_busy = false;
+    }
+    std::memcpy(c->d_vx.p, c->lat.vx.data(), n * sizeof(double));
+    std::memcpy(c->d_vy.p, c->lat.vy.data(), n * sizeof(double));
+    if (!same_rows) std::memcpy(c->d_row.p, c->lat.row.data(), n * sizeof(int32_t));
+    c->bar_dirty = true;
+    bar_flush(c);
+  } else {
+    KC_HIP(hipMemcpyAsync(c->d_vx.p, c->lat.vx.data(), n * sizeof(double),
+                          hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(c->d_vy.p, c->lat.vy.data(), n * sizeof(double),
+                          hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(c->d_row.p, c->lat.row.data(), n * sizeof(int32_t),
+                          hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
+  }
+  if (!same_rows) c->uploaded_rows = c->lat.row;
   return KC_OK;
 }
 
@@ -863,6 +882,8 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
 int build_perm(kc_dwa *c) {
   const size_t n = c->shard_count, first = c->shard_first;
   c->perm_valid = true;
+  c->perm_first = first;
+  c->perm_count = n;
   if (n == 0) return KC_OK;
   c->h_perm.resize(n);
   for (size_t i = 0; i < n; ++i) c->h_perm[i] = static_cast<int32_t>(i);
@@ -879,27 +900,15 @@ int build_perm(kc_dwa *c) {
         if (e < n) dealt.push_back(c->h_perm[e]);
       }
   }
-  std::vector<double> pvx(n), pvy(n);
   std::vector<int32_t> prow(n);
   for (int pass = 0; pass < 2; ++pass) {
     const std::vector<int32_t> &order = pass == 0 ? c->h_perm : dealt;
     DevBuf<int32_t> &dperm = pass == 0 ? c->d_perm : c->d_cperm;
-    DevBuf<double> &dvx = pass == 0 ? c->d_pvx : c->d_cpvx;
-    DevBuf<double> &dvy = pass == 0 ? c->d_pvy : c->d_cpvy;
     DevBuf<int32_t> &drow = pass == 0 ? c->d_prow : c->d_cprow;
     KC_TRY(dperm.reserve(n));
-    KC_TRY(dvx.reserve(n));
-    KC_TRY(dvy.reserve(n));
     KC_TRY(drow.reserve(n));
-    for (size_t i = 0; i < n; ++i) {
-      const size_t g = first + static_cast<size_t>(order[i]);
-      pvx[i] = c->lat.vx[g];
-      pvy[i] = c->lat.vy[g];
-      prow[i] = c->lat.row[g];
-    }
+    for (size_t i = 0; i < n; ++i) prow[i] = c->lat.row[first + static_cast<size_t>(order[i])];
     KC_HIP(hipMemcpyAsync(dperm.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    KC_HIP(hipMemcpyAsync(dvx.p, pvx.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    KC_HIP(hipMemcpyAsync(dvy.p, pvy.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     KC_HIP(hipMemcpyAsync(drow.p, prow.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
   }
@@ -1531,8 +1540,6 @@ void kc_dwa_destroy(kc_dwa *c) {
     (void)ge;
   }
   c->d_perm.release();
-  c->d_pvx.release();
-  c->d_pvy.release();
   c->d_prow.release();
   c->d_vvx.release();
   c->d_vvy.release();
@@ -1561,8 +1568,6 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_row.release();
   c->d_adm_bits.release();
   c->d_cperm.release();
-  c->d_cpvx.release();
-  c->d_cpvy.release();
   c->d_cprow.release();
   c->h_wrow.release();
   delete c;
@@ -1705,7 +1710,6 @@ int kc_dwa_set_shard(kc_dwa *c, size_t first, size_t count) {
             first + count, c->lat.size());
   c->shard_first = first;
   c->shard_count = count;
-  c->perm_valid = false;
   return KC_OK;
 }
 
@@ -2267,10 +2271,9 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
                             hipMemcpyHostToDevice, s));
   }
   if (fused) {
-    if (!c->perm_valid) KC_TRY(build_perm(c));
+    if (!c->perm_valid || c->perm_first != c->shard_first || c->perm_count != c->shard_count)
+      KC_TRY(build_perm(c));
     a.perm = cycle ? c->d_cperm.p : c->d_perm.p;
-    a.pvx = cycle ? c->d_cpvx.p : c->d_pvx.p;
-    a.pvy = cycle ? c->d_cpvy.p : c->d_pvy.p;
     a.prow = cycle ? c->d_cprow.p : c->d_prow.p;
 #ifdef KC_PHASE_STAMPS
     if (c->debug_stamps) {

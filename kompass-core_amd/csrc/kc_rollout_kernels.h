@@ -204,10 +204,11 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   if (tid < kFusedSamples) {
     lhit[tid] = 0;
     const bool in = tid < rows;
-    lperm[tid] = in ? a.perm[base + tid] : 0;
+    const int id = in ? a.perm[base + tid] : 0;
+    lperm[tid] = id;
     lrow[tid] = in ? a.prow[base + tid] : 0;
-    lvx[tid] = in ? a.pvx[base + tid] : 0.0;
-    lvy[tid] = in ? a.pvy[base + tid] : 0.0;
+    lvx[tid] = in ? a.vx[a.first + id] : 0.0;   // velocities change every cycle, the order does not
+    lvy[tid] = in ? a.vy[a.first + id] : 0.0;
   }
   if constexpr (kCycle) cycle_fill_tables(tail, smem, tid, kFusedBlock);
   if (a.c.enabled && a.c.dil == 2) {

@@ -61,8 +61,11 @@ def make_pair(robot_type, geom, dims, vx_lim, om_lim, cfg: DWAConfig, vy_lim=Non
     return robot, gpu, cpu
 
 
-def lockstep(robot, gpu, cpu, pts, start, scan=None, cloud=None, max_controls=100, dt=0.1):
-    """run_control() of tests/test_controllers.py:167-240 with the oracle stepping beside it."""
+def lockstep(robot, gpu, cpu, pts, start, scan=None, cloud=None, max_controls=100, dt=0.1, clearance_to=None):
+    """run_control() of tests/test_controllers.py:167-240 with the oracle stepping beside it.
+    clearance_to: a point cloud; the smallest distance of the driven positions to it comes back as
+    lockstep.min_clearance (dwa_test.cpp:290-295, minDistanceToCloud after every applied control)."""
+    lockstep.min_clearance = float("inf")
     gpu.set_path(_P(pts))
     cpu.set_path(np.array([[x, y, 0.0] for x, y in pts], np.float32))
     robot.state.x, robot.state.y, robot.state.yaw = start
@@ -92,6 +95,9 @@ def lockstep(robot, gpu, cpu, pts, start, scan=None, cloud=None, max_controls=10
         for vx, vy, om in zip(gpu.linear_x_control, gpu.linear_y_control, gpu.angular_control):
             robot.set_control(velocity_x=vx, velocity_y=vy, omega=om)
             robot.get_state(dt=dt)
+            if clearance_to is not None:
+                d = np.hypot(clearance_to[:, 0] - robot.state.x, clearance_to[:, 1] - robot.state.y).min()
+                lockstep.min_clearance = min(lockstep.min_clearance, float(d))
             i += 1
             end = gpu.reached_end()
     return end, i, cycles
@@ -145,9 +151,12 @@ def test_dwa_cpp_scenarios(rtype, with_obstacle):
                                 vy_lim=LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0))
     pts = [(x, 0.0) for x in np.arange(0.0, 10.01, 0.5)]
     cloud = _round_obstacle(3.0, 0.35, 0.2) if with_obstacle else np.array([[50.0, 50.0, 0.0]], np.float32)
-    end, n, cycles = lockstep(robot, gpu, cpu, pts, (0.0, 0.1, 0.0), cloud=cloud, max_controls=400)
+    end, n, cycles = lockstep(robot, gpu, cpu, pts, (0.0, 0.1, 0.0), cloud=cloud, max_controls=400,
+                              clearance_to=cloud if with_obstacle else None)
     assert cycles > 10
     assert end is True, f"goal not reached after {n} controls"
+    if with_obstacle:  # dwa_test.cpp:355-358: BOOST_TEST(min_clearance >= robotRadius)
+        assert lockstep.min_clearance >= 0.1, f"DWA collided with obstacle: clearance {lockstep.min_clearance}"
 
 
 def test_debug_samples_and_custom_cost():
@@ -355,3 +364,31 @@ def test_collision_checker_batch_poses():
         want = np.array([c.check_at(a, b, t) for a, b, t in zip(x, y, yaw)])
         assert 0 < want.sum() < 500
         np.testing.assert_array_equal(got, want)
+
+
+def test_class_level_cycle_is_one_launch_and_shards_through_rccl():
+    """kompass_cpp.control.DWA (what kompass_core drives): every compute_velocity_commands is ONE
+    kernel launch (`last_cycle_single_launch` of the shared context is not reachable from here, so the
+    check is behavioural: results equal the oracle's in the lockstep tests above; here: the sharded
+    controller -- world of one rank through the RCCL all-reduce -- gives the same commands as the
+    plain one, cycle after cycle, and the pinned-row path feeds the trajectory)."""
+    cfg = DWAConfig(max_linear_samples=15, max_angular_samples=15, octree_resolution=0.1,
+                    costs_weights=TrajectoryCostsWeights(reference_path_distance_weight=1.0, goal_distance_weight=3.0,
+                                                         obstacles_distance_weight=1.0, smoothness_weight=0.0,
+                                                         jerk_weight=0.0),
+                    prediction_horizon=20, control_horizon=2, control_time_step=0.1)
+    lim = (LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0),
+           AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0))
+    robot, plain, cpu = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.CYLINDER, [0.1, 0.4], *lim, cfg)
+    robot2, shard, _ = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.CYLINDER, [0.1, 0.4], *lim, cfg)
+    shard._planner.enable_sharding(0, 1, kompass_cpp.comm_unique_id(), 0)
+    pts = [(x, 0.0) for x in np.arange(0.0, 10.01, 0.5)]
+    cloud = _round_obstacle(3.0, 0.35, 0.2)
+    end, n, cycles = lockstep(robot, plain, cpu, pts, (0.0, 0.1, 0.0), cloud=cloud, max_controls=60)
+    end2, n2, cycles2 = lockstep(robot2, shard, cpu, pts, (0.0, 0.1, 0.0), cloud=cloud, max_controls=60)
+    assert (n, cycles) == (n2, cycles2) and cycles >= 25
+    assert (robot.state.x, robot.state.y, robot.state.yaw) == (robot2.state.x, robot2.state.y, robot2.state.yaw)
+    shard._planner.disable_sharding()
+    shard._planner.use_resident_path(True)
+    end3, n3, cycles3 = lockstep(robot2, shard, cpu, pts, (0.0, 0.1, 0.0), cloud=cloud, max_controls=60)
+    assert (n3, cycles3) == (n, cycles)

@@ -510,6 +510,12 @@ except Exception as e:
 r = ctx.cycle(st, inp["P"])
 print("SECOND:", bool(r.found), int(r.raw_index), int(r.n_admissible))
 """
+    # the same through the split entry points (ADVICE r1): a roll-out that gives up waiting, then
+    # another roll-out WITHOUT an evaluate in between, then evaluate + fetch: the good cycle must not
+    # inherit the error word of the abandoned one
+    code_split = code.replace('try:\n    ctx.cycle(st, inp["P"])', 'ctx.set_option("fused_cycle", 0)\ntry:\n    ctx.rollout(st, inp["P"])') \
+                     .replace('r = ctx.cycle(st, inp["P"])', 'ctx.rollout(st, inp["P"]); ctx.evaluate(); r = ctx.fetch_result()')
+    assert code_split != code
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, KC_TEST_LATE_FLAG_MS="120"))
     assert p.returncode == 0, p.stderr[-600:]
@@ -519,3 +525,9 @@ print("SECOND:", bool(r.found), int(r.raw_index), int(r.n_admissible))
         pytest.skip("early launch not active on this device (no large BAR)")
     assert "gave up waiting" in lines[0], p.stdout
     assert lines[1] == f"SECOND: True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p.stdout
+    p2 = subprocess.run([sys.executable, "-c", code_split], capture_output=True, text=True, timeout=120,
+                        env=dict(os.environ, KC_TEST_LATE_FLAG_MS="120"))
+    assert p2.returncode == 0, p2.stderr[-600:]
+    lines2 = p2.stdout.strip().splitlines()
+    assert lines2[0] == "FIRST: no error", p2.stdout   # the roll-out call itself does not fail: the error word is set on the device
+    assert lines2[1] == f"SECOND: True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p2.stdout
