@@ -56,6 +56,7 @@ struct kc_dwa {
   std::vector<double2> scan_cs;         // angle table does not change between scans)
   std::vector<float> scan_xyz;          // sensor-frame points of the last laserscan
   DevBuf<float> d_raw;
+  DevBuf<uint32_t> d_sensor_tmp;        // scratch of the multi-workgroup sensor build
   // grid hand-off (kc_dwa_set_grid_device): the point list is produced on the
   // device; the host copy is fetched only if something walks the lists
   bool raw_on_device = false;
@@ -195,6 +196,10 @@ struct kc_dwa {
 };
 
 namespace {
+
+// largest point list the device-side sensor update takes (bucket grid of at most 64 x 64 cells:
+// about one obstacle per cell up to 4 k points, 64 per cell here); beyond: the host path, finer grid
+constexpr size_t kSensorDeviceMax = 262144;
 
 int use_device(const kc_dwa *c) {
   KC_HIP(hipSetDevice(c->prm.device));
@@ -649,7 +654,7 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   *done = false;
   c->raw_on_device = false;
   if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
-      n == 0 || n > 16384)
+      n == 0 || n > kSensorDeviceMax)
     return KC_OK;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   size_t nfin = 0;
@@ -726,7 +731,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
                                  const float hi[3], bool *done) {
   *done = false;
   if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
-      n == 0 || n > 16384)
+      n == 0 || n > kSensorDeviceMax)
     return KC_OK;
   // bitmap: keys of the bounds (points beyond the 16-level octree are dropped
   // by add_voxel anyway)
@@ -737,12 +742,14 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   bool fits = false;
   KC_TRY(bitmap_extent(c, key(lo[0]), key(lo[1]), key(hi[0]), key(hi[1]), &fits));
   const size_t nwords = fits ? static_cast<size_t>(c->gH) * c->gwpr : 0;
-  if (!fits || nwords * sizeof(uint32_t) > 64 * 1024) {
+  if (!fits) {
     c->have_gbits = false;
     c->dil_lazy = false;
-  c->dil_lazy = false;
     return KC_OK;
   }
+  // one workgroup with everything in LDS, or (large clouds / bitmaps) the points
+  // over many workgroups with device atomics
+  const bool big = n > 16384 || nwords * sizeof(uint32_t) > 64 * 1024;
   // bucket grid: covers the image of the bounding box (an affine map takes the
   // box into the hull of its eight transformed corners)
   double blo[2] = {DBL_MAX, DBL_MAX}, bhi[2] = {-DBL_MAX, -DBL_MAX};
@@ -819,10 +826,33 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   a.obs_z_zero = c->raw_is_scan ? 1 : 0;
   KC_TRY(c->d_dc_enable.reserve(1));
   a.dc_enable = c->d_dc_enable.p;
-  const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
-  KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
-  hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
-  KC_TRY(c->timing.stop(c->stream));
+  if (!big) {
+    const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
+    KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
+    hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
+    KC_TRY(c->timing.stop(c->stream));
+  } else {
+    // scratch: [counts (ncell + 1) | cell records n | ox n | oy n]; bitmap and counts start at zero
+    KC_TRY(c->d_sensor_tmp.reserve(ncell + 1 + 3 * n));
+    SensorBigArgs sb{};
+    sb.a = a;
+    sb.counts = reinterpret_cast<int *>(c->d_sensor_tmp.p);
+    sb.tcell = sb.counts + ncell + 1;
+    sb.tox = reinterpret_cast<float *>(sb.tcell + n);
+    sb.toy = sb.tox + n;
+    KC_HIP(hipMemsetAsync(c->d_gbits.p, 0, nwords * sizeof(uint32_t), c->stream));
+    KC_HIP(hipMemsetAsync(sb.counts, 0, (ncell + 1) * sizeof(int), c->stream));
+    const unsigned nb = blocks_for(n, kSensorBigBlock);
+    KC_TRY(c->timing.start("sensor_points_kernel", c->stream));
+    hipLaunchKernelGGL(sensor_points_kernel, dim3(nb), dim3(kSensorBigBlock), 0, c->stream, sb);
+    KC_TRY(c->timing.stop(c->stream));
+    KC_TRY(c->timing.start("sensor_cells_kernel", c->stream));
+    hipLaunchKernelGGL(sensor_cells_kernel, dim3(1), dim3(kSensorBlock), 0, c->stream, sb);
+    KC_TRY(c->timing.stop(c->stream));
+    KC_TRY(c->timing.start("sensor_scatter_kernel", c->stream));
+    hipLaunchKernelGGL(sensor_scatter_kernel, dim3(nb), dim3(kSensorBigBlock), 0, c->stream, sb);
+    KC_TRY(c->timing.stop(c->stream));
+  }
   KC_HIP(hipGetLastError());
   c->update_busy = true;
   c->have_dc = false;
@@ -1531,6 +1561,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_dbg.release();
   c->d_dbg2.release();
   c->d_raw.release();
+  c->d_sensor_tmp.release();
   c->d_dc.release();
   c->d_dc_enable.release();
   c->d_gridcnt.release();

@@ -200,6 +200,143 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
   for (int i = tid; i < nw; i += kSensorBlock) a.gbits[i] = lbits[i];
 }
 
+// ---------------------------------------------------------------------------
+// The same structure for LARGE clouds (more than 16 k points, or a voxel bitmap
+// beyond 64 KB: a 1000 x 1000 costmap has ~28 k occupied cells): the points are
+// spread over many workgroups, the scatters become device atomics on a zeroed
+// bitmap / count table, the scan + skip table stay one workgroup (the bucket
+// grid is at most 64 x 64), a third launch puts the coordinates in cell order.
+// Same per-point arithmetic as above; the order of the points inside a bucket is
+// as arbitrary as there.  Reference step: collision_check.h:91-136 (octree
+// rebuild) + cost_evaluator.h:174-223 (setPointScan).
+// ---------------------------------------------------------------------------
+struct SensorBigArgs {
+  SensorArgs a;
+  int *counts;      // [W*H + 1] zeroed; slot k + 1 counts cell k
+  float *tox, *toy; // [n] transformed coordinates (scratch)
+  int *tcell;       // [n] cell id | rank << 12, -1: not an obstacle
+};
+constexpr int kSensorBigBlock = 256;
+
+__global__ __launch_bounds__(kSensorBigBlock) void sensor_points_kernel(SensorBigArgs b) {
+  const SensorArgs &a = b.a;
+  const int i = blockIdx.x * kSensorBigBlock + threadIdx.x;
+  if (i >= a.n) return;
+  const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+  // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
+  const double fx = floor(a.inv_res * static_cast<double>(x));
+  const double fy = floor(a.inv_res * static_cast<double>(y));
+  const double fz = floor(a.inv_res * static_cast<double>(z));
+  if (fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0) {
+    const int kz = static_cast<int>(fz);
+    const double zlo = static_cast<double>(kz) * a.res;
+    const double zhi = static_cast<double>(kz + 1) * a.res;
+    if (zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height) {
+      const int cx = static_cast<int>(fx) - a.gkx0, cy = static_cast<int>(fy) - a.gky0;
+      if (cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr)
+        atomicOr(&a.gbits[(size_t)cy * a.gwpr + (cx >> 5)], 1u << (cx & 31));
+    }
+  }
+  float ox, oy;
+  int id;
+  int rec = -1;
+  if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id)) {
+    rec = id | (atomicAdd(&b.counts[id + 1], 1) << 12);  // id < 4096 cells, rank < 2^19
+    b.tox[i] = ox;
+    b.toy[i] = oy;
+  }
+  b.tcell[i] = rec;
+}
+
+// one workgroup: counts -> starts (in place, then to cell_start), skip table, dc_enable
+__global__ __launch_bounds__(kSensorBlock) void sensor_cells_kernel(SensorBigArgs b) {
+  const SensorArgs &a = b.a;
+  const int ncell = a.W * a.H;
+  __shared__ int lstart[64 * 64 + 1];
+  __shared__ unsigned long long lmask[64];
+  __shared__ int wave_tot[kSensorBlock / 64];
+  __shared__ int s_nonempty;
+  const int tid = threadIdx.x;
+  for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = b.counts[i];
+  if (tid == 0) s_nonempty = 0;
+  __syncthreads();
+  {
+    const int N = ncell + 1;
+    const int per = (N + kSensorBlock - 1) / kSensorBlock;
+    const int k0 = tid * per;
+    int v[8];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = k0 + k;
+      if (k < per && idx < N) sum += lstart[idx];
+      v[k] = sum;
+    }
+    int incl = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const int offset = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = k0 + k;
+      if (k < per && idx < N) lstart[idx] = offset + v[k];
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k <= ncell; k += kSensorBlock) a.cell_start[k] = lstart[k];
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int y = wave; y < a.H; y += kSensorBlock / 64) {
+      const bool ne = lane < a.W && lstart[y * a.W + lane + 1] > lstart[y * a.W + lane];
+      const unsigned long long m = __ballot(ne);
+      if (lane == 0) {
+        lmask[y] = m;
+        atomicAdd(&s_nonempty, __popcll(m));
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
+  for (int k = tid; k < ncell; k += kSensorBlock) {
+    const int y = k / a.W, x = k - y * a.W;
+    unsigned long long acc = lmask[y];
+    int r = 0;
+    const int rmax = max(a.W, a.H);
+    for (;;) {
+      const int x0 = max(x - r, 0), x1 = min(x + r, a.W - 1);
+      const unsigned long long win = (x1 - x0 == 63) ? ~0ull : (((1ull << (x1 - x0 + 1)) - 1ull) << x0);
+      if (acc & win) break;
+      ++r;
+      if (r > rmax || r >= 255) {
+        r = 255;
+        break;
+      }
+      if (y - r >= 0) acc |= lmask[y - r];
+      if (y + r < a.H) acc |= lmask[y + r];
+    }
+    a.skip[k] = static_cast<uint8_t>(r);
+  }
+  if (tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
+}
+
+__global__ __launch_bounds__(kSensorBigBlock) void sensor_scatter_kernel(SensorBigArgs b) {
+  const SensorArgs &a = b.a;
+  const int i = blockIdx.x * kSensorBigBlock + threadIdx.x;
+  if (i >= a.n) return;
+  const int rec = b.tcell[i];
+  if (rec < 0) return;
+  const int pos = a.cell_start[rec & 4095] + (rec >> 12);
+  a.bx[pos] = b.tox[i];
+  a.by[pos] = b.toy[i];
+}
+
 // ---- distance table for the far-obstacle searches of the cost kernels ---------------
 // A uniform grid of its own over the obstacles' bounding box: for every cell the
 // distance from the cell CENTRE to the nearest obstacle.  A point p of that cell

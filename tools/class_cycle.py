@@ -16,7 +16,7 @@ lim = ControlLimitsParams(LinearVelocityControlParams(1.0, 2.0, 2.0), LinearVelo
 w = TrajectoryCostWeights()
 w.from_dict(dict(reference_path_distance_weight=1.0, goal_distance_weight=1.0, obstacles_distance_weight=1.0,
                  smoothness_weight=0.0, jerk_weight=0.0))
-d = DWA(lim, ControlType.DIFFERENTIAL_DRIVE, 0.1, 5.0, 0.2, L, A, RobotGeometry.Type.CYLINDER, [0.1, 0.4],
+d = DWA(lim, ControlType.DIFFERENTIAL_DRIVE, 0.1, 5.0, 0.2, L, A, RobotGeometry.get("CYLINDER"), [0.1, 0.4],
         [0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0], 0.05, w, 1)
 d.set_current_path(Path([[x, 0.0, 0.0] for x in np.arange(0.0, 12.01, 1.0)]))
 for scene in ("survey", "mid", "open"):
