@@ -99,6 +99,7 @@ struct CostArgs {
   long long *result;    // R_* published record + W_* working area
   long long *block_keys;  // [gridDim.x] best key of every workgroup (publish_kernel reduces)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS): per-block phase clocks
+  int seg_flat;             // every z of the tracked segment is +0.0f (the common case: planar paths)
   int nsup;                 // super-chunks of 8 chunks (kept at the end: the workgroup-per-sample
                             // kernel lost 5 us when this field sat next to nch -- its scalar
                             // argument loads are sensitive to the layout above)
@@ -704,31 +705,37 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
     const bool st = stamp && p0 == 0;
     if (st) KC_STAMP(7);
     if (a.use_seg) {
-      float best = FLT_MAX;
-      int arg = 0;
-      const int sup_pts = 8 * a.seg_chunk;
-      // (1) the first point of every super-chunk: ascending index, strict `<`
-      for (int s = 0; s < a.nsup; ++s) {
-        const int j = s * sup_pts;
+      // Only the END point needs to know WHICH segment point is nearest (goal
+      // cost); every point needs the nearest distance.  So the lanes track the
+      // minimum alone -- as the bits of the non-negative float: unsigned order =
+      // float order, NaN and +inf sit above FLT_MAX and never win, exactly like
+      // `dist < minDist` -- and the end point's index is found afterwards by the
+      // whole wavefront (lowest index among the minima).
+      uint32_t bestb = 0x7F7FFFFFu;  // FLT_MAX
+      const bool flat = a.seg_flat != 0;  // every z of the segment is +0: the z terms vanish exactly
+      auto d2_bits = [&](int j) {
         const float4 q = seg.pt(j);
         const float dx = q.x - x;
         const float dy = q.y - y;
         const float xx = dx * dx;
         const float yy = dy * dy;
-        const float dd = xx + (yy + q.z);  // Eigen order a + (b + c)
-        if (dd < best) {
-          best = dd;
-          arg = j;
-        }
-      }
+        return __float_as_uint(xx + (yy + q.z));  // Eigen order a + (b + c)
+      };
+      const int sup_pts = 8 * a.seg_chunk;
+      // (1) the first point of every super-chunk
+      for (int s = 0; s < a.nsup; ++s) bestb = min(bestb, d2_bits(s * sup_pts));
       // (2) super-chunks that may hold something at least as close:
       // |q - c| - r <= thr on the squares; 1e-4 relative slack on the bound,
       // 1e-5 on the compared square (NaN compares false: qualifies)
-      float thr = __builtin_sqrtf(best) * 1.0001f;
+      float thr = __builtin_sqrtf(__uint_as_float(bestb)) * 1.0001f;
       unsigned smask = 0u;
       for (int s = 0; s < a.nsup; ++s) {
-        const float dx = sup[s] - x, dy = sup[a.nsup + s] - y, dz = sup[2 * a.nsup + s];
-        const float d2 = dx * dx + dy * dy + dz * dz;
+        const float dx = sup[s] - x, dy = sup[a.nsup + s] - y;
+        float d2 = dx * dx + dy * dy;
+        if (!flat) {
+          const float dz = sup[2 * a.nsup + s];
+          d2 += dz * dz;
+        }
         const float lim = thr + sup[3 * a.nsup + s];
         if (!(d2 > lim * lim * 1.00001f)) smask |= 1u << s;
       }
@@ -740,22 +747,12 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
 #pragma unroll
         for (int u = 1; u < 8; ++u) {
           const int c = s * 8 + u;
-          const int j = min(c, a.nch - 1) * a.seg_chunk;  // a repeat of the last chunk changes nothing
-          const float4 q = seg.pt(j);
-          const float dx = q.x - x;
-          const float dy = q.y - y;
-          const float xx = dx * dx;
-          const float yy = dy * dy;
-          const float dd = xx + (yy + q.z);
-          if (dd < best || (dd == best && j < arg)) {
-            best = dd;
-            arg = j;
-          }
+          bestb = min(bestb, d2_bits(min(c, a.nch - 1) * a.seg_chunk));  // a repeat of the last chunk changes nothing
         }
       }
       // (4) capsule test of their chunks: distance to the chord minus the
       // largest deviation of the chunk's points from it
-      thr = __builtin_sqrtf(best) * 1.0001f;
+      thr = __builtin_sqrtf(__uint_as_float(bestb)) * 1.0001f;
       unsigned long long cand = 0ull;
       for (unsigned m = smask; m;) {
         const int s = __ffs(static_cast<int>(m)) - 1;
@@ -763,13 +760,24 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int c = min(s * 8 + u, a.nch - 1);
-          const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
-          const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
-          float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
-          t = fminf(fmaxf(t, 0.0f), 1.0f);
-          const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
-          const float d2 = ex * ex + ey * ey + ez * ez;
-          const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+          const float qx = x - cap[c], qy = y - cap[a.nch + c];
+          const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c];
+          float d2, mag;
+          if (flat) {
+            float t = (qx * bx + qy * by) * cap[6 * a.nch + c];
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            const float ex = qx - t * bx, ey = qy - t * by;
+            d2 = ex * ex + ey * ey;
+            mag = fabsf(qx) + fabsf(qy);
+          } else {
+            const float qz = 0.0f - cap[2 * a.nch + c], bz = cap[5 * a.nch + c];
+            float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
+            d2 = ex * ex + ey * ey + ez * ez;
+            mag = fabsf(qx) + fabsf(qy) + fabsf(qz);
+          }
+          const float lim = thr + cap[7 * a.nch + c] + 4e-7f * mag;
           if (!(d2 > lim * lim * 1.0001f)) cand |= 1ull << c;
         }
       }
@@ -780,45 +788,51 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
         cand &= cand - 1ull;
         const int j0 = c * a.seg_chunk;
         const int j1 = min(j0 + a.seg_chunk, a.S);
-        // five points per batch: their LDS reads are in flight together
+        // five points per batch: their LDS reads are in flight together (a repeat of
+        // the chunk's last point changes nothing)
         for (int jb = j0 + 1; jb < j1; jb += 5) {
-          float vx[5], vy[5], vz[5];
+          uint32_t v[5];
 #pragma unroll
-          for (int u = 0; u < 5; ++u) {
-            const int j = min(jb + u, j1 - 1);
-            const float4 q = seg.pt(j);
-            vx[u] = q.x;
-            vy[u] = q.y;
-            vz[u] = q.z;
-          }
-#pragma unroll
-          for (int u = 0; u < 5; ++u) {
-            const int j = jb + u;
-            const float dx = vx[u] - x;
-            const float dy = vy[u] - y;
-            const float xx = dx * dx;
-            const float yy = dy * dy;
-            const float dd = xx + (yy + vz[u]);
-            if (j < j1 && (dd < best || (dd == best && j < arg))) {
-              best = dd;
-              arg = j;
-            }
-          }
+          for (int u = 0; u < 5; ++u) v[u] = d2_bits(min(jb + u, j1 - 1));
+          bestb = min(min(min(bestb, v[0]), min(v[1], v[2])), min(v[3], v[4]));
         }
       }
       if (st) KC_STAMP(10);
+      const float best = __uint_as_float(bestb);
       mind = kc::sqrt_rn(best);
-      if (pp == a.P - 1) {
-        // goalCostFunc, cost_evaluator.cpp:168-176, from the search above
-        const float acc_arg = seg.acc(arg);
-        const float arc = kc::div_rn(a.ref_len - acc_arg, a.ref_len);
-        goal_l = arc + kc::div_rn(mind, a.ref_len);
-        // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
-        const int e = a.S - 1;
-        const float4 qe = seg.pt(e);
-        const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
-        const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-        end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
+      if (p0 + 64 >= a.P) {
+        // The end point (lane a.P - 1 - p0 of this tile): goalCostFunc,
+        // cost_evaluator.cpp:157-176.  Its nearest segment point = the LOWEST
+        // index whose squared distance equals the minimum found above (the
+        // reference's strict `<` in index order; index 0 when nothing is below
+        // FLT_MAX), looked for by all lanes, 64 segment points per step.
+        const int le = a.P - 1 - p0;
+        const float xe = lane_value(x, le), ye = lane_value(y, le);
+        const uint32_t be = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bestb), le));
+        uint32_t arg_l = 0xFFFFFFFFu;
+        if (be < 0x7F7FFFFFu) {
+          for (int j = lane; j < a.S && arg_l == 0xFFFFFFFFu; j += 64) {
+            const float4 q = seg.pt(j);
+            const float dx = q.x - xe;
+            const float dy = q.y - ye;
+            const float xx = dx * dx;
+            const float yy = dy * dy;
+            if (__float_as_uint(xx + (yy + q.z)) == be) arg_l = static_cast<uint32_t>(j);
+          }
+        }
+        const uint32_t argm = wave_min_u32(arg_l);
+        const int arg = argm == 0xFFFFFFFFu ? 0 : static_cast<int>(argm);
+        if (pp == a.P - 1) {
+          const float acc_arg = seg.acc(arg);
+          const float arc = kc::div_rn(a.ref_len - acc_arg, a.ref_len);
+          goal_l = arc + kc::div_rn(mind, a.ref_len);
+          // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
+          const int e = a.S - 1;
+          const float4 qe = seg.pt(e);
+          const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
+          const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+          end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
+        }
       }
     }
     if (st) KC_STAMP(11);

@@ -93,6 +93,7 @@ struct kc_dwa {
   bool perm_valid = false;
   bool bar_dirty = false;    // BAR stores not yet fenced
   bool update_busy = false;  // an update call queued device work since the last idle point
+  bool seg_busy = false;     // ... a kernel that writes the tracked-segment table (resident-path window)
   std::vector<int> cell_id, cell_cursor;  // bucketing scratch (reused)
   std::vector<uint8_t> skip_pad;
   int test_late_flag_ms = 0;            // KC_TEST_LATE_FLAG_MS: delay the trig sequence word once
@@ -137,6 +138,8 @@ struct kc_dwa {
   // tracked segment + obstacles
   size_t S = 0, O = 0;
   float seg_len = 0.f, ref_len = 0.f, max_obs_dist = 0.f;
+  bool seg_flat = false;      // every z of the tracked segment is +0.0f
+  bool path_flat = false;     // ... of the resident path
   PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
   DevBuf<float> d_seg;
   // resident reference path (kc_dwa_set_path): rows x | y | z | acc on the
@@ -240,9 +243,10 @@ inline void bar_flush(kc_dwa *c) {
 int quiesce_for_update(kc_dwa *c, bool sensor_tables = true) {
   // (the tracked-segment table is only read by cost kernels, i.e. by cycles:
   // work queued by a sensor update since the last cycle does not touch it)
-  if (!c->drained || (sensor_tables && c->update_busy)) {
+  if (!c->drained || (sensor_tables && c->update_busy) || (!sensor_tables && c->seg_busy)) {
     KC_HIP(hipStreamSynchronize(c->stream));
     c->update_busy = false;
+    c->seg_busy = false;
     c->drained = true;
   }
   return KC_OK;
@@ -1100,6 +1104,7 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
   ca.seg_chunk = c->seg_chunk;
   ca.nch = c->seg_nch;
   ca.nsup = c->seg_nsup;
+  ca.seg_flat = c->seg_flat ? 1 : 0;
   dt = DcArgs{};
   dt.dc = c->have_dc ? c->d_dc.p : nullptr;
   dt.inv_g = c->dc_inv_g;
@@ -1255,6 +1260,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
         got = true;
         c->drained = true;
         c->update_busy = false;  // queued in front of the cycle whose record just arrived
+        c->seg_busy = false;
         break;
       }
       if ((spins & 1023) == 1023 &&
@@ -1950,14 +1956,19 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   KC_TRY(c->h_seg.reserve(seg_words));
   KC_TRY(c->d_seg.reserve(seg_words));
   float *h = c->h_seg.p;
+  bool flat = true;
   for (size_t j = 0; j < S; ++j) {
     const float zz = z ? z[j] : 0.0f;
+    uint32_t zb;
+    std::memcpy(&zb, &zz, 4);
+    flat = flat && zb == 0u;  // +0.0f exactly (z^2 of -0.0f is +0 as well, but keep the test plain)
     h[j] = x[j];
     h[S + j] = y[j];
     h[2 * S + j] = zz;
     h[3 * S + j] = zz * zz;  // (seg.z - 0)^2 of Path::distance
     h[4 * S + j] = acc[j];
   }
+  c->seg_flat = flat;
   const float kInf = std::numeric_limits<float>::infinity();
   auto up = [](double v) {  // to float, rounded up
     return std::nextafter(static_cast<float>(v), std::numeric_limits<float>::infinity());
@@ -2075,12 +2086,17 @@ int kc_dwa_set_path(kc_dwa *c, const float *x, const float *y, const float *z, c
   if (n == 0) return KC_OK;
   KC_TRY(c->d_path.reserve(4 * n));
   std::vector<float> rows(4 * n);
+  bool flat = true;
   for (size_t j = 0; j < n; ++j) {
     rows[j] = x[j];
     rows[n + j] = y[j];
     rows[2 * n + j] = z ? z[j] : 0.0f;
     rows[3 * n + j] = acc[j];
+    uint32_t zb;
+    std::memcpy(&zb, &rows[2 * n + j], 4);
+    flat = flat && zb == 0u;
   }
+  c->path_flat = flat;
   for (size_t j = 0; j + 1 < n; ++j) {  // the terms of View::totalSegmentLength, path.h:85-91
     const float dx = rows[j] - rows[j + 1], dy = rows[n + j] - rows[n + j + 1],
                 dz = rows[2 * n + j] - rows[2 * n + j + 1];
@@ -2100,6 +2116,7 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   KC_TRY(use_device(c));
   c->S = S;
   c->ref_len = c->path_len;
+  c->seg_flat = c->path_flat;
   if (S == 0) return KC_OK;
   const size_t chunk = std::max<size_t>(kSegChunkMin, (S + 63) / 64);
   const size_t nch = (S + chunk - 1) / chunk;
@@ -2137,6 +2154,7 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   hipLaunchKernelGGL(segment_window_kernel, dim3(1), dim3(kSegWinBlock), 0, c->stream, a);
   KC_TRY(c->timing.stop(c->stream));
   KC_HIP(hipGetLastError());
+  c->seg_busy = true;  // a queued kernel writes d_seg: host stores into the table wait for the stream
   return KC_OK;
 }
 
@@ -2690,6 +2708,8 @@ int kc_dwa_publish_result(kc_dwa *c) {
   hipLaunchKernelGGL(republish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_result.p,
                      c->h_pub.p, ++c->seq);
   KC_HIP(hipGetLastError());
+  c->drained = false;  // (set again by the fetch that sees this record)
+  c->row_valid = false;
   c->pub_pending = true;
   return KC_OK;
 }
