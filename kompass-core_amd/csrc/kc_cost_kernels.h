@@ -216,22 +216,18 @@ constexpr size_t kBlkLdsBudget = 78 * 1024;
 
 // Where the float points of one sample come from: the sample-major rows in
 // global memory (split path, kc_cost_evaluate) or the double poses the fused
-// cycle kernel still holds in LDS (pose k at row[k - 1], the start pose in
-// front; the float is the one the roll-out would have stored).
+// cycle kernel still holds in LDS (the float is the one the roll-out would have
+// stored).
 struct RowPts {
   const float *rx, *ry;
   __device__ __forceinline__ float x(int p) const { return rx[p]; }
   __device__ __forceinline__ float y(int p) const { return ry[p]; }
 };
 struct PosePts {
-  const double2 *row;
-  double x0, y0;
-  __device__ __forceinline__ float x(int p) const {
-    return static_cast<float>(p == 0 ? x0 : row[p - 1].x);
-  }
-  __device__ __forceinline__ float y(int p) const {
-    return static_cast<float>(p == 0 ? y0 : row[p - 1].y);
-  }
+  const double2 *row;  // pose k at row[k - 1]; the start pose in the spare slot row[start] (the rows have an
+  int start;           // odd pitch >= P: a plain index select, nothing of this struct has to live in memory)
+  __device__ __forceinline__ float x(int p) const { return static_cast<float>(row[p == 0 ? start : p - 1].x); }
+  __device__ __forceinline__ float y(int p) const { return static_cast<float>(row[p == 0 ? start : p - 1].y); }
 };
 // tracked segment as five rows (x | y | z | z^2 | acc) or as (x, y, z^2, acc) records
 struct SegRows {
@@ -254,7 +250,7 @@ struct SegRecs {
 template <int kTeam, class Seg, class Pts>
 __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg &seg, float sz_end,
                                                    const int *cells, const uint8_t *skip,
-                                                   const float *obx, const float *oby, const Pts &pts,
+                                                   const float *obx, const float *oby, const Pts pts,
                                                    int tid, float *s_mind, float *s_goal, float *s_end,
                                                    unsigned long long *s_obest, const float *cap = nullptr,
                                                    const float *sup = nullptr) {
@@ -688,7 +684,7 @@ template <class Seg, class Pts>
 __device__ __forceinline__ float wave_sample_total(const CostArgs &a, const DcArgs &t, bool use_dc,
                                                    const Seg &seg, const float *cap, const float *sup,
                                                    float sz_end, const int *cells, const uint8_t *skip,
-                                                   const float *obx, const float *oby, const Pts &pts,
+                                                   const float *obx, const float *oby, const Pts pts,
                                                    int n, int lane, unsigned long long *obest,
                                                    bool stamp) {
   const BucketDev &b = a.b;

@@ -103,7 +103,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
       if (tt == 0) s_ob[h] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
       __syncthreads();  // (first pass: also s_key)
       const int s = active ? lsurv[q] : 0;
-      const PosePts pts{lpos + s * PP, a.x0, a.y0};
+      const PosePts pts{lpos + s * PP, PP - 1};
       if (active)
         team_sample_search<kTeam>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
                                   t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h], t.cap,
@@ -134,7 +134,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
       if (q >= R) break;
       const int s = lsurv[q];
       const int n = lperm[s];
-      const PosePts pts{lpos + s * PP, a.x0, a.y0};
+      const PosePts pts{lpos + s * PP, PP - 1};
       const float total = wave_sample_total(c, tail.t, use_dc, seg, cap, sup, sz_end, t.cells, t.skip,
                                             c.b.bx, c.b.by, pts, n, lane, &s_ob[wave], false);
       if (lane == 0) c.costs[n] = total;
@@ -188,8 +188,8 @@ __device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &ta
     unsigned int x = 0u;
     for (int k = tid; k < 2 * P; k += kBlock) {
       const int p = k < P ? k : k - P;
-      const double v = p == 0 ? (k < P ? a.x0 : a.y0) : (k < P ? best_row[p - 1].x : best_row[p - 1].y);
-      const uint32_t w = __float_as_uint(static_cast<float>(v));
+      const double2 r = best_row[p == 0 ? (P | 1) - 1 : p - 1];  // pose 0 sits in the spare slot of the row
+      const uint32_t w = __float_as_uint(static_cast<float>(k < P ? r.x : r.y));
       dst[k] = w;
       x ^= w * (2u * static_cast<unsigned>(k) + 1u);
     }

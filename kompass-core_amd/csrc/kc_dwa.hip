@@ -908,11 +908,10 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
 
 // shard-local sample ids ordered by trig row (stable): consecutive samples of a
 // fused workgroup then share one or two rows of the table.  The single-launch
-// cycle gets a second order, dealt from the first with a skewed stride:
-// survivors of the collision gate cluster (a few adjacent omega rows, the low
-// speeds of each), and a workgroup costs its own survivors -- block g takes
-// entries j * G + (g + 37 j) mod G, j = 0..31, of the row order, so that a
-// cluster of any shape lands on many workgroups instead of a few.
+// cycle gets a second order, dealt from the first: survivors of the collision
+// gate cluster (a few adjacent omega rows, the low speeds of each), and a
+// workgroup costs its own survivors, so a cluster of any shape has to land on
+// many workgroups instead of a few (see below).
 int build_perm(kc_dwa *c) {
   const size_t n = c->shard_count, first = c->shard_first;
   c->perm_valid = true;
@@ -927,12 +926,37 @@ int build_perm(kc_dwa *c) {
   std::vector<int32_t> dealt;
   dealt.reserve(n);
   {
-    const size_t G = (n + 31) / 32;
-    for (size_t g = 0; g < G; ++g)
-      for (size_t j = 0; j < 32; ++j) {
-        const size_t e = j * G + (g + 37 * j) % G;
-        if (e < n) dealt.push_back(c->h_perm[e]);
-      }
+    // Rectangular lattice (R trig rows of L samples each -- the non-holonomic
+    // window is one): a workgroup takes 8 rows, R/8 apart, and 4 samples of each,
+    // L/4 apart.  Survivors cluster in adjacent rows and adjacent speeds, so at
+    // most a couple land in one workgroup, and a workgroup reads 8 rows of the
+    // trig table instead of 32.  Anything else (omni windows, ragged shards): the
+    // skewed stride, one sample per row.
+    size_t R = 0, L = 0;
+    bool rect = true;
+    for (size_t i = 0; i < n && rect;) {
+      size_t j = i;
+      while (j < n && row[c->h_perm[j]] == row[c->h_perm[i]]) ++j;
+      if (R == 0) L = j - i;
+      rect = (j - i) == L;
+      ++R;
+      i = j;
+    }
+    rect = rect && R * L == n && R % 8 == 0 && L % 4 == 0;
+    if (rect) {
+      const size_t A = R / 8, B = L / 4;
+      for (size_t a = 0; a < A; ++a)
+        for (size_t b = 0; b < B; ++b)
+          for (size_t i = 0; i < 8; ++i)
+            for (size_t k = 0; k < 4; ++k) dealt.push_back(c->h_perm[(a + A * i) * L + b + B * k]);
+    } else {
+      const size_t G = (n + 31) / 32;
+      for (size_t g = 0; g < G; ++g)
+        for (size_t j = 0; j < 32; ++j) {
+          const size_t e = j * G + (g + 37 * j) % G;
+          if (e < n) dealt.push_back(c->h_perm[e]);
+        }
+    }
   }
   std::vector<int32_t> prow(n);
   for (int pass = 0; pass < 2; ++pass) {

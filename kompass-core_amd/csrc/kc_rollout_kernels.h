@@ -209,6 +209,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     lrow[tid] = in ? a.prow[base + tid] : 0;
     lvx[tid] = in ? a.vx[a.first + id] : 0.0;   // velocities change every cycle, the order does not
     lvy[tid] = in ? a.vy[a.first + id] : 0.0;
+    if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
   }
   if constexpr (kCycle) cycle_fill_tables(tail, smem, tid, kFusedBlock);
   if (a.c.enabled && a.c.dil == 2) {
