@@ -182,6 +182,30 @@ __device__ __forceinline__ uint32_t group8_min_u32(uint32_t v) {
   v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
   return v;
 }
+// ... and inside each aligned group of kL = 4 or 8 lanes (quads need no third step)
+template <int kL>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
+  static_assert(kL == 4 || kL == 8, "four or eight lanes per point");
+  v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+  if (kL == 8) v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
+  return v;
+}
+template <int kL>
+__device__ __forceinline__ uint32_t group_or_u32(uint32_t v) {
+  v |= dpp_u32<0xB1>(v);
+  v |= dpp_u32<0x4E>(v);
+  if (kL == 8) v |= dpp_u32<0x141>(v);
+  return v;
+}
+template <int kL>
+__device__ __forceinline__ double group_min_nonneg(double v) {
+  const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
+  const uint32_t hi = static_cast<uint32_t>(u >> 32), lo = static_cast<uint32_t>(u);
+  const uint32_t mh = group_min_u32<kL>(hi);
+  const uint32_t ml = group_min_u32<kL>(hi == mh ? lo : 0xFFFFFFFFu);
+  return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(mh) << 32) | ml));
+}
 __device__ __forceinline__ double group8_min_nonneg(double v) {
   const uint64_t u = static_cast<uint64_t>(__double_as_longlong(v));
   const uint32_t hi = static_cast<uint32_t>(u >> 32), lo = static_cast<uint32_t>(u);
@@ -247,7 +271,12 @@ struct SegRecs {
 // *s_obest (armed by the caller, behind a barrier).  tid = lane id inside the team.
 // cap / sup (chunk capsules and super-chunk spheres): the pruned segment search;
 // null: the plain scan, eight lanes wide.
-template <int kTeam, class Seg, class Pts>
+template <class Seg, int kL>
+__device__ __forceinline__ void group_segment_search(const CostArgs &a, const Seg &seg, const float *cap,
+                                                     const float *sup, float x, float y, int sub,
+                                                     float &best_out, int &arg_out);
+
+template <int kTeam, class Seg, class Pts, int kL = 8>
 __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg &seg, float sz_end,
                                                    const int *cells, const uint8_t *skip,
                                                    const float *obx, const float *oby, const Pts pts,
@@ -255,11 +284,11 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
                                                    unsigned long long *s_obest, const float *cap = nullptr,
                                                    const float *sup = nullptr) {
   const BucketDev &b = a.b;
-  const int sub = tid & 7;
-  for (int p0 = 0; p0 < a.P; p0 += kTeam / 8) {
+  const int sub = tid & (kL - 1);
+  for (int p0 = 0; p0 < a.P; p0 += kTeam / kL) {
     // Idle groups (beyond P) work on a clamped point and write nothing, so
     // the cross-lane steps always see active lanes.
-    const int pp = p0 + (tid >> 3);
+    const int pp = p0 + tid / kL;
     const bool live = pp < a.P;
     const int p = live ? pp : a.P - 1;
     const float x = pts.x(p), y = pts.y(p);
@@ -267,10 +296,10 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
       float best = FLT_MAX;
       int arg = 0;
       if (cap) {
-        group8_segment_search(a, seg, cap, sup, x, y, sub, best, arg);
+        group_segment_search<Seg, kL>(a, seg, cap, sup, x, y, sub, best, arg);
       } else {
 #pragma unroll 4
-        for (int j = sub; j < a.S; j += 8) {  // j ascending per lane
+        for (int j = sub; j < a.S; j += kL) {  // j ascending per lane
           const float4 q = seg.pt(j);
           const float dx = q.x - x;
           const float dy = q.y - y;
@@ -285,9 +314,9 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
         // non-negative floats order like their bit patterns; ties go to the
         // lowest segment index (the reference's strict `<` in index order)
         const uint32_t mine = __float_as_uint(best);
-        const uint32_t mbits = group8_min_u32(mine);
+        const uint32_t mbits = group_min_u32<kL>(mine);
         arg = static_cast<int>(
-            group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
+            group_min_u32<kL>(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
         best = __uint_as_float(mbits);
       }
       if (sub == 0 && live) {
@@ -326,8 +355,8 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
         const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
         const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
         // a row of the block is a contiguous run of the cell-ordered obstacle
-        // list: four rows per pass, two lanes per row
-        for (int row = y0 + (sub >> 1); row <= y1; row += 4) {
+        // list: two lanes per row, kL / 2 rows per pass
+        for (int row = y0 + (sub >> 1); row <= y1; row += kL / 2) {
           const int beg = cells[row * b.W + x0];
           const int end = cells[row * b.W + x1 + 1];
           for (int j = beg + (sub & 1); j < end; j += 2) {
@@ -337,7 +366,7 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
             best = dd < best ? dd : best;
           }
         }
-        best = group8_min_nonneg(best);
+        best = group_min_nonneg<kL>(best);
         // Only the minimum over the whole sample is used (trajectory.h:218-235
         // inside obstaclesDistCostFunc), so the points of a sample share
         // their best distance: a point stops as soon as everything it has
@@ -375,19 +404,19 @@ __device__ __forceinline__ uint32_t group8_or_u32(uint32_t v) {
   return v;
 }
 
-// Nearest tracked-segment point of q = (x, y) by a group of EIGHT lanes (sub =
-// lane id in the group) with the chunk hierarchy of wave_sample_total spread
-// over the lanes: (0) the heads of the (<= 8) super-chunks, one per lane,
-// (1) their bounding spheres, (2) the heads of the chunks of the surviving
-// super-chunks, (3) the capsules of those chunks, (4) every other point of the
-// chunks that may hold something at least as close, eight points per step.
-// Same minimum of d2 = dx*dx + (dy*dy + z^2) and same lowest index as the full
-// scan (cost_evaluator.cpp:120-130 / :157-166).  All eight lanes must be active;
-// best / arg come back group-uniform.
-template <class Seg>
-__device__ __forceinline__ void group8_segment_search(const CostArgs &a, const Seg &seg, const float *cap,
-                                                      const float *sup, float x, float y, int sub,
-                                                      float &best_out, int &arg_out) {
+// Nearest tracked-segment point of q = (x, y) by a group of kL (four or eight)
+// lanes (sub = lane id in the group) with the chunk hierarchy of
+// wave_sample_total spread over the lanes: (0) the heads of the (<= 8)
+// super-chunks, (1) their bounding spheres, (2) the heads of the chunks of the
+// surviving super-chunks, (3) the capsules of those chunks, (4) every other
+// point of the chunks that may hold something at least as close, kL points per
+// step.  Same minimum of d2 = dx*dx + (dy*dy + z^2) and same lowest index as the
+// full scan (cost_evaluator.cpp:120-130 / :157-166).  All lanes of the group must
+// be active; best / arg come back group-uniform.
+template <class Seg, int kL>
+__device__ __forceinline__ void group_segment_search(const CostArgs &a, const Seg &seg, const float *cap,
+                                                     const float *sup, float x, float y, int sub,
+                                                     float &best_out, int &arg_out) {
   auto d2_to = [&](int j) {
     const float4 q = seg.pt(j);
     const float dx = q.x - x;
@@ -400,43 +429,52 @@ __device__ __forceinline__ void group8_segment_search(const CostArgs &a, const S
     // non-negative floats order like their bit patterns (NaN above everything:
     // `d < best` never took one); ties go to the lowest segment index
     const uint32_t mine = __float_as_uint(best);
-    const uint32_t mbits = group8_min_u32(mine);
-    arg = static_cast<int>(group8_min_u32(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
+    const uint32_t mbits = group_min_u32<kL>(mine);
+    arg = static_cast<int>(group_min_u32<kL>(mine == mbits ? static_cast<uint32_t>(arg) : 0xFFFFFFFFu));
     best = __uint_as_float(mbits);
   };
   const int sup_pts = 8 * a.seg_chunk;
   float best = FLT_MAX;
   int arg = 0;  // (a lane that finds nothing below FLT_MAX keeps index 0, like the reference's scan)
-  // (0) super-chunk heads
-  if (sub < a.nsup) {
-    const float dd = d2_to(sub * sup_pts);
-    if (dd < best) {
-      best = dd;
-      arg = sub * sup_pts;
+  // (0) super-chunk heads (ascending per lane)
+#pragma unroll
+  for (int s = sub; s < 8; s += kL) {
+    if (s < a.nsup) {
+      const float dd = d2_to(s * sup_pts);
+      if (dd < best) {
+        best = dd;
+        arg = s * sup_pts;
+      }
     }
   }
   merge(best, arg);
   // (1) spheres: |q - c| - r <= thr on the squares (NaN compares false: qualifies)
   float thr = __builtin_sqrtf(best) * 1.0001f;
-  bool keep = false;
-  if (sub < a.nsup) {
-    const float dx = sup[sub] - x, dy = sup[a.nsup + sub] - y, dz = sup[2 * a.nsup + sub];
-    const float d2 = dx * dx + dy * dy + dz * dz;
-    const float lim = thr + sup[3 * a.nsup + sub];
-    keep = !(d2 > lim * lim * 1.00001f);
+  uint32_t keep = 0u;
+#pragma unroll
+  for (int s = sub; s < 8; s += kL) {
+    if (s < a.nsup) {
+      const float dx = sup[s] - x, dy = sup[a.nsup + s] - y, dz = sup[2 * a.nsup + s];
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      const float lim = thr + sup[3 * a.nsup + s];
+      if (!(d2 > lim * lim * 1.00001f)) keep |= 1u << s;
+    }
   }
-  const uint32_t smask = group8_or_u32(keep ? 1u << sub : 0u);
-  // (2) heads of their chunks (lane sub: chunk 8 s + sub)
+  const uint32_t smask = group_or_u32<kL>(keep);
+  // (2) heads of their chunks (chunk 8 s + u, u over the lanes)
   for (uint32_t m = smask; m;) {
     const int s8 = (__ffs(static_cast<int>(m)) - 1) * 8;
     m &= m - 1u;
-    const int c = s8 + sub;
-    if (c < a.nch) {
-      const int j = c * a.seg_chunk;
-      const float dd = d2_to(j);
-      if (dd < best || (dd == best && j < arg)) {
-        best = dd;
-        arg = j;
+#pragma unroll
+    for (int u = sub; u < 8; u += kL) {
+      const int c = s8 + u;
+      if (c < a.nch) {
+        const int j = c * a.seg_chunk;
+        const float dd = d2_to(j);
+        if (dd < best || (dd == best && j < arg)) {
+          best = dd;
+          arg = j;
+        }
       }
     }
   }
@@ -448,30 +486,33 @@ __device__ __forceinline__ void group8_segment_search(const CostArgs &a, const S
   for (uint32_t m = smask; m;) {
     const int s8 = (__ffs(static_cast<int>(m)) - 1) * 8;
     m &= m - 1u;
-    const int c = s8 + sub;
-    if (c < a.nch) {
-      const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
-      const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
-      float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
-      t = fminf(fmaxf(t, 0.0f), 1.0f);
-      const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
-      const float d2 = ex * ex + ey * ey + ez * ez;
-      const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
-      if (!(d2 > lim * lim * 1.0001f)) {
-        if (c < 32) clo |= 1u << c;
-        else chi |= 1u << (c - 32);
+#pragma unroll
+    for (int u = sub; u < 8; u += kL) {
+      const int c = s8 + u;
+      if (c < a.nch) {
+        const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
+        const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
+        float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
+        const float d2 = ex * ex + ey * ey + ez * ez;
+        const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+        if (!(d2 > lim * lim * 1.0001f)) {
+          if (c < 32) clo |= 1u << c;
+          else chi |= 1u << (c - 32);
+        }
       }
     }
   }
-  clo = group8_or_u32(clo);
-  chi = group8_or_u32(chi);
-  // (4) the remaining points of those chunks, eight per step
+  clo = group_or_u32<kL>(clo);
+  chi = group_or_u32<kL>(chi);
+  // (4) the remaining points of those chunks, kL per step
   for (unsigned long long cand = (static_cast<unsigned long long>(chi) << 32) | clo; cand;) {
     const int c = __ffsll(static_cast<long long>(cand)) - 1;
     cand &= cand - 1ull;
     const int j0 = c * a.seg_chunk;
     const int j1 = min(j0 + a.seg_chunk, a.S);
-    for (int j = j0 + 1 + sub; j < j1; j += 8) {
+    for (int j = j0 + 1 + sub; j < j1; j += kL) {
       const float dd = d2_to(j);
       if (dd < best || (dd == best && j < arg)) {
         best = dd;

@@ -17,8 +17,9 @@
 namespace kc {
 
 struct CycleTail;  // kc_rollout_kernels.h
-constexpr int kTeamMaxSurvivors = 8;  // up to here a workgroup costs its survivors two at a time,
-                                      // half its lanes each (eight per point); beyond, one per wavefront
+constexpr int kTeamMaxSurvivors = 4;  // one or two survivors: half the workgroup each, eight lanes per
+                                      // trajectory point; three or four: a quarter each, four lanes per
+                                      // point (one pass either way); more: one per wavefront
 
 template <typename T>
 __device__ __forceinline__ void st_agent(T *p, T v) {
@@ -36,7 +37,7 @@ struct CycleTabs {
   float *cap;       // [8][nch] capsules, then [4][nsup] spheres
   int *cells;       // [ncell + 1]
   uint8_t *skip;    // [ncell padded to 4]
-  float *mind;      // [2][P] team scratch
+  float *mind;      // [4][P] team scratch
 };
 __device__ __forceinline__ CycleTabs cycle_tabs(const CostArgs &c, unsigned char *smem, unsigned tab_off) {
   CycleTabs t;
@@ -82,7 +83,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
   const CostArgs &c = tail.c;
   __shared__ long long s_key;
   __shared__ unsigned long long s_ob[kBlock / 64];
-  __shared__ float s_goal[2], s_end[2];
+  __shared__ float s_goal[4], s_end[4];
   __shared__ int s_next, s_bslot;
   const CycleTabs t = cycle_tabs(c, smem, tail.tab_off);
   const float sz_end = (c.use_seg && c.S > 0) ? c.sz[c.S - 1] : 0.0f;
@@ -95,33 +96,38 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
   }
   const SegRecs seg{t.pts};
   if (R <= kTeamMaxSurvivors) {
-    constexpr int kTeam = kBlock / 2;
-    const int h = tid / kTeam, tt = tid - h * kTeam;
-    for (int it = 0; 2 * it < R; ++it) {
-      const int q = 2 * it + h;
-      const bool active = q < R;
-      if (tt == 0) s_ob[h] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
-      __syncthreads();  // (first pass: also s_key)
-      const int s = active ? lsurv[q] : 0;
-      const PosePts pts{lpos + s * PP, PP - 1};
-      if (active)
-        team_sample_search<kTeam>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
-                                  t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h], t.cap,
-                                  t.cap + 8 * c.nch);
-      if (it == 0) KC_RSTAMP(10);
-      __syncthreads();
-      if (it == 0) KC_RSTAMP(11);
-      if (active && tt < 64) {
-        const int n = lperm[s];
-        const float total = team_sample_total(c, n, lane, t.mind + h * c.P, s_goal[h], s_end[h], s_ob[h]);
-        if (lane == 0) {
-          c.costs[n] = total;
-          if (total < FLT_MAX)  // `total_cost < minCost`, minCost starts at FLT_MAX
-            atomicMin(&s_key, key_pack(total, static_cast<uint32_t>(c.first + n)));
-        }
-      }
-      if (it == 0) KC_RSTAMP(12);
+    // every survivor at once: R teams (two halves or four quarters of the workgroup)
+    const bool quarters = R > 2;
+    const int team = quarters ? kBlock / 4 : kBlock / 2;
+    const int h = tid / team, tt = tid - h * team;
+    const bool active = h < R;
+    if (tt == 0) s_ob[h] = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
+    __syncthreads();  // (also s_key)
+    const int s = active ? lsurv[h] : 0;
+    const PosePts pts{lpos + s * PP, PP - 1};
+    if (active) {
+      if (quarters)
+        team_sample_search<kBlock / 4, SegRecs, PosePts, 4>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
+                                                            t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h],
+                                                            t.cap, t.cap + 8 * c.nch);
+      else
+        team_sample_search<kBlock / 2, SegRecs, PosePts, 8>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
+                                                            t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h],
+                                                            t.cap, t.cap + 8 * c.nch);
     }
+    KC_RSTAMP(10);
+    __syncthreads();
+    KC_RSTAMP(11);
+    if (active && tt < 64) {
+      const int n = lperm[s];
+      const float total = team_sample_total(c, n, lane, t.mind + h * c.P, s_goal[h], s_end[h], s_ob[h]);
+      if (lane == 0) {
+        c.costs[n] = total;
+        if (total < FLT_MAX)  // `total_cost < minCost`, minCost starts at FLT_MAX
+          atomicMin(&s_key, key_pack(total, static_cast<uint32_t>(c.first + n)));
+      }
+    }
+    KC_RSTAMP(12);
   } else {
     __syncthreads();  // s_next, s_key
     const bool use_dc = tail.t.dc != nullptr && *tail.t.enable != 0;
@@ -178,25 +184,28 @@ __device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &ta
     __hip_atomic_fetch_or(tail.adm_bits + (id >> 5), 1u << (id & 31), __ATOMIC_RELAXED,
                           __HIP_MEMORY_SCOPE_AGENT);
   }
-  // This workgroup's best row -- the floats the roll-out would have stored --
+  // This workgroup's best row -- the floats the roll-out would have stored -- goes
   // straight into its slot of the pinned host buffer (posted writes: nobody on
-  // the device waits for them); a position-weighted xor of the words goes with
-  // the key, the host checks the row of the winning workgroup against it.
+  // the device waits for them -- they are issued BEHIND the ticket); a position-
+  // weighted xor of the words goes with the key, the host checks the row of the
+  // winning workgroup against it.
   __syncthreads();  // s_rowx
-  if (best_slot >= 0 && tail.host_rows) {
-    uint32_t *dst = tail.host_rows + (size_t)b * 2 * P;
+  const bool have_row = best_slot >= 0 && tail.host_rows != nullptr;
+  uint32_t roww[2] = {0u, 0u};  // this lane's words of the row (2 P <= 2 * kBlock)
+  if (have_row) {
     unsigned int x = 0u;
-    for (int k = tid; k < 2 * P; k += kBlock) {
-      const int p = k < P ? k : k - P;
-      const double2 r = best_row[p == 0 ? (P | 1) - 1 : p - 1];  // pose 0 sits in the spare slot of the row
-      const uint32_t w = __float_as_uint(static_cast<float>(k < P ? r.x : r.y));
-      dst[k] = w;
-      x ^= w * (2u * static_cast<unsigned>(k) + 1u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = tid + u * kBlock;
+      if (k < 2 * P) {
+        const int p = k < P ? k : k - P;
+        const double2 r = best_row[p == 0 ? (P | 1) - 1 : p - 1];  // pose 0 sits in the spare slot of the row
+        roww[u] = __float_as_uint(static_cast<float>(k < P ? r.x : r.y));
+        x ^= roww[u] * (2u * static_cast<unsigned>(k) + 1u);
+      }
     }
-    if (tid < ((2 * P + 63) & ~63)) {  // the wavefronts that hold row words
-      for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
-      if ((tid & 63) == 0 && x) atomicXor(&s_rowx, x);
-    }
+    for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
+    if ((tid & 63) == 0 && x) atomicXor(&s_rowx, x);
     __syncthreads();
   }
   if (tid == 0) {
@@ -211,6 +220,14 @@ __device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &ta
         reinterpret_cast<unsigned long long *>(tail.result + W_TICKET), 1ull, __ATOMIC_RELAXED,
         __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == static_cast<unsigned long long>(G) - 1ull) ? 1 : 0;
+  }
+  if (have_row) {  // behind the ticket: posted PCIe writes nothing here waits for
+    uint32_t *dst = tail.host_rows + (size_t)b * 2 * P;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = tid + u * kBlock;
+      if (k < 2 * P) dst[k] = roww[u];
+    }
   }
   __syncthreads();
   KC_RSTAMP(13);

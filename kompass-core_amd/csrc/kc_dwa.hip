@@ -2194,7 +2194,7 @@ size_t cycle_table_bytes(const CostArgs &ca) {
     const size_t ncell = static_cast<size_t>(ca.b.W) * ca.b.H;
     b += 4 * (ncell + 1) + ((ncell + 3) & ~size_t(3));
   }
-  return b + 2 * static_cast<size_t>(ca.P) * 4;
+  return b + 4 * static_cast<size_t>(ca.P) * 4;
 }
 
 // kc_dwa_rollout, or -- want_cycle -- the whole cycle in one launch when the
