@@ -134,8 +134,9 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  * SYCL path has none; every setting gives bit-identical results -- tests/
  * test_gpu_parity.py runs the cycle under each).  value: 0 / 1 unless stated.
  *   "fused_cycle"    (1) kc_dwa_cycle runs the whole cycle as ONE launch when the
- *                        cost tables fit in LDS beside the roll-out tile; 0: roll-out,
- *                        cost and publish kernels
+ *                        cost tables fit in LDS beside the roll-out tile and the shard is
+ *                        one resident wave of workgroups (<= 32 samples x CUs); 2: whenever
+ *                        the tables fit; 0: roll-out, cost and publish kernels
  *   "write_paths"    (0) the single-launch cycle also stores every float row
  *                        (otherwise rows are produced on demand by kc_dwa_get_samples)
  *   "cost_kernel"    (0) stand-alone cost stage: 0 chosen from the admissible count

@@ -184,6 +184,8 @@ struct kc_dwa {
   bool cost_lds_hw = false, large_bar = false;
   bool write_paths = false;    // option "write_paths": the single-launch cycle stores the float rows too
   bool cycle_fused = true;     // option "fused_cycle": kc_dwa_cycle may take the single launch
+  bool cycle_forced = false;   // ... value 2: also when the shard needs more than one workgroup per CU
+  int num_cus = 256;
   bool cycle_launched = false; // the last roll-out call was a whole cycle
   bool paths_valid = true;     // d_px / d_py hold the rows of the last roll-out (a fused cycle
                                // materialises them only on demand)
@@ -1471,6 +1473,13 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     }
     c->trig_direct = large_bar != 0;
     c->large_bar = large_bar != 0;
+    {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && cus > 0)
+        c->num_cus = cus;
+      else
+        (void)hipGetLastError();
+    }
     if (const char *e = std::getenv("KC_FUSED_CYCLE"))
       if (e[0] == '0') c->cycle_fused = false;  // process default; option "fused_cycle" per context
     if (const char *e = std::getenv("KC_TRIG_COPY"))
@@ -1659,7 +1668,11 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   c->update_busy = false;
   const std::string n(name);
   const bool on = v != 0.0;
-  if (n == "fused_cycle") c->cycle_fused = on;
+  if (n == "fused_cycle") {
+    if (!(v == 0.0 || v == 1.0 || v == 2.0)) KC_FAIL(KC_ERR_RANGE, "fused_cycle: 0 off, 1 when it pays, 2 whenever it fits");
+    c->cycle_fused = on;
+    c->cycle_forced = v == 2.0;
+  }
   else if (n == "write_paths") c->write_paths = on;
   else if (n == "cost_kernel") {
     if (!(v == 0.0 || v == 1.0 || v == 2.0)) KC_FAIL(KC_ERR_RANGE, "cost_kernel: 0 auto, 1 workgroup per sample, 2 wavefront per sample");
@@ -1684,7 +1697,7 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
 int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   if (!c || !name || !v) KC_FAIL(KC_ERR_INVALID, "null argument");
   const std::string n(name);
-  if (n == "fused_cycle") *v = c->cycle_fused;
+  if (n == "fused_cycle") *v = c->cycle_fused ? (c->cycle_forced ? 2.0 : 1.0) : 0.0;
   else if (n == "write_paths") *v = c->write_paths;
   else if (n == "cost_kernel") *v = c->cost_kernel_force;
   else if (n == "cost_dc_cells") *v = c->no_dc ? 0.0 : c->dc_side;
@@ -2287,7 +2300,13 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   // single-launch cycle: cost arguments up front (their checks must not fail
   // behind a launched kernel)
   CycleTail tail{};
-  bool cycle = want_cycle && c->cycle_fused && c->prm.shape != KC_SPHERE && n <= 1024u * kCompactMaxPer;
+  // One launch pays while every workgroup of the shard is resident at once (32 samples per
+  // workgroup, one workgroup per CU: 8192 samples on an MI355X -- the per-GPU share of every
+  // BASELINE config on 8 GPUs).  Beyond, the cycle kernel's LDS footprint (one workgroup per CU)
+  // loses to the three-kernel cycle, whose roll-out kernel fits two per CU (cfg5 on ONE GPU,
+  // 65536 samples: 0.214 against 0.129 ms).
+  bool cycle = want_cycle && c->cycle_fused && c->prm.shape != KC_SPHERE && n <= 1024u * kCompactMaxPer &&
+               (c->cycle_forced || blocks_for(n, 32) <= static_cast<unsigned>(c->num_cus));
   if (cycle) KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
   const int fs = cycle ? 32 : c->fused_samples, fb = cycle ? 1024 : c->fused_block;

@@ -43,11 +43,17 @@ def _need_gpu():
     assert kh.device_count() >= 1, "no HIP device visible: the -m gpu tests need an MI355X"
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["auto", "single-launch-forced"])
 @pytest.mark.parametrize("name,scene,n", FULL, ids=[f"{a}-{b}" for a, b, _ in FULL])
-def test_full_size_cycle_equals_oracle(name, scene, n):
+def test_full_size_cycle_equals_oracle(name, scene, n, mode):
+    """mode 1: what kc_dwa_cycle picks by itself (one launch up to 8192 samples per GPU, three
+    kernels beyond); mode 2: the single launch at every size."""
     inp, o = _oracle(name, scene)
     assert len(inp["vx"]) == n
-    h = hip_cycle(kh, inp)
+    ctx0 = hip_context(kh, inp)
+    ctx0.set_option("fused_cycle", mode)
+    h = hip_cycle(kh, inp, ctx=ctx0)
+    assert ctx0.get_option("last_cycle_single_launch") == (1 if (mode == 2 or n <= 8192) else 0)
     assert h["res"]["n_samples"] == n
     if scene == "open":
         assert len(o["raw"]) == n
@@ -79,7 +85,7 @@ def test_eight_sequential_shards_equal_unsharded_and_oracle(name, scene):
 
     inp, o = _oracle(name, scene)
     n = len(inp["vx"])
-    ctx = hip_context(kh, inp)
+    ctx = hip_context(kh, inp)   # shards of n / 8 <= 8192 samples: the single-launch cycle
     st = inp["state"]
     ctx.set_weights(kh.make_weights(*inp["weights"]))
     ctx.set_points(st, inp["points"], inp["max_range"])
