@@ -87,7 +87,8 @@ struct CostArgs {
   const long long *adm_count;     // device-side count (result[W_LIST])
   const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the chunk capsules
                                                // [8][nch]: ax ay az abx aby abz 1/|ab|^2 eps, then
-                                               // the super-chunk spheres [4][nsup]: cx cy cz r
+                                               // the super-chunk spheres [4][nsup]: cx cy cz r, then
+                                               // the super-chunk capsules [8][nsup] (same rows as the chunks')
   int seg_chunk, nch;             // points per chunk, chunk count (<= 64)
   float seg_len, ref_len;
   BucketDev b;
@@ -776,6 +777,34 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
         const float lim = thr + sup[3 * a.nsup + s];
         if (!(d2 > lim * lim * 1.00001f)) smask |= 1u << s;
       }
+      // ... and whose capsule (chord of the whole super-chunk + largest deviation) does: on a
+      // smooth path a far query keeps one or two super-chunks where the spheres keep them all
+      {
+        const float *sc = sup + 4 * a.nsup;  // [8][nsup]: ax ay az abx aby abz 1/|ab|^2 eps
+        for (unsigned m = smask; m;) {
+          const int s = __ffs(static_cast<int>(m)) - 1;
+          m &= m - 1u;
+          const float qx = x - sc[s], qy = y - sc[a.nsup + s];
+          const float bx = sc[3 * a.nsup + s], by = sc[4 * a.nsup + s];
+          float d2, mag;
+          if (flat) {
+            float t = (qx * bx + qy * by) * sc[6 * a.nsup + s];
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            const float ex = qx - t * bx, ey = qy - t * by;
+            d2 = ex * ex + ey * ey;
+            mag = fabsf(qx) + fabsf(qy);
+          } else {
+            const float qz = 0.0f - sc[2 * a.nsup + s], bz = sc[5 * a.nsup + s];
+            float t = (qx * bx + qy * by + qz * bz) * sc[6 * a.nsup + s];
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
+            d2 = ex * ex + ey * ey + ez * ez;
+            mag = fabsf(qx) + fabsf(qy) + fabsf(qz);
+          }
+          const float lim = thr + sc[7 * a.nsup + s] + 4e-7f * mag;
+          if (d2 > lim * lim * 1.0001f) smask &= ~(1u << s);
+        }
+      }
       if (st) KC_STAMP(8);
       // (3) the first points of their other chunks
       for (unsigned m = smask; m;) {
@@ -1127,7 +1156,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   KC_STAMP(1);
   const BucketDev &b = a.b;
   const int ncell = b.W * b.H;
-  const int seg_words = a.use_seg ? 5 * a.S + 8 * a.nch + 4 * a.nsup : 0;
+  const int seg_words = a.use_seg ? 5 * a.S + 8 * a.nch + 12 * a.nsup : 0;
   // LDS layout: segment rows + chunk spheres | cell table | skip table (padded
   // to words) | obstacle coordinates.  The pointers are chosen at compile time
   // so that the LDS variants issue ds_read, not flat loads.
@@ -1159,7 +1188,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
         wp[j] = make_float4(a.sx[j], a.sy[j], a.szz[j], a.acc_seg[j]);
       float *const wc = l_seg + 4 * a.S;
       const float *const gc = a.sx + 5 * a.S;
-      for (int j = threadIdx.x; j < 8 * a.nch + 4 * a.nsup; j += kCostBlock) wc[j] = gc[j];
+      for (int j = threadIdx.x; j < 8 * a.nch + 12 * a.nsup; j += kCostBlock) wc[j] = gc[j];
     }
     if (a.use_obs) {
 #pragma unroll 8

@@ -34,7 +34,7 @@ __device__ __forceinline__ T ld_agent(const T *p) {
 // cycle_table_bytes in kc_dwa.hip)
 struct CycleTabs {
   float4 *pts;      // [S] (x, y, z^2, accumulated length)
-  float *cap;       // [8][nch] capsules, then [4][nsup] spheres
+  float *cap;       // [8][nch] capsules, then [4][nsup] spheres, then [8][nsup] super-chunk capsules
   int *cells;       // [ncell + 1]
   uint8_t *skip;    // [ncell padded to 4]
   float *mind;      // [4][P] team scratch
@@ -44,7 +44,7 @@ __device__ __forceinline__ CycleTabs cycle_tabs(const CostArgs &c, unsigned char
   const int ncell = c.b.W * c.b.H;
   t.pts = reinterpret_cast<float4 *>(smem + tab_off);
   t.cap = reinterpret_cast<float *>(t.pts + (c.use_seg ? c.S : 0));
-  t.cells = reinterpret_cast<int *>(t.cap + (c.use_seg ? 8 * c.nch + 4 * c.nsup : 0));
+  t.cells = reinterpret_cast<int *>(t.cap + (c.use_seg ? 8 * c.nch + 12 * c.nsup : 0));
   t.skip = reinterpret_cast<uint8_t *>(t.cells + (c.use_obs ? ncell + 1 : 0));
   t.mind = reinterpret_cast<float *>(t.skip + (c.use_obs ? ((ncell + 3) & ~3) : 0));
   return t;
@@ -58,7 +58,7 @@ __device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned cha
 #pragma unroll 2
     for (int j = tid; j < c.S; j += nthreads) t.pts[j] = make_float4(c.sx[j], c.sy[j], c.szz[j], c.acc_seg[j]);
     const float *gc = c.sx + 5 * c.S;
-    for (int j = tid; j < 8 * c.nch + 4 * c.nsup; j += nthreads) t.cap[j] = gc[j];
+    for (int j = tid; j < 8 * c.nch + 12 * c.nsup; j += nthreads) t.cap[j] = gc[j];
   }
   if (c.use_obs) {
     const int ncell = c.b.W * c.b.H;

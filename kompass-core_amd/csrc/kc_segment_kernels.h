@@ -2,7 +2,7 @@
 // interpolated reference path stays resident (kc_dwa_set_path), a cycle only
 // moves the window (kc_dwa_set_tracked_window) and this kernel writes what
 // kc_dwa_set_tracked_segment builds on the host -- the rows [5][S], the chunk
-// capsules [8][nch] and the super-chunk spheres [4][nsup] -- with the same
+// capsules [8][nch], the super-chunk spheres [4][nsup] and capsules [8][nsup] -- with the same
 // double arithmetic and the same slack.  The bounds only prune the searches of
 // the cost kernels, so validity is what matters; they come out identical to the
 // host's (maxima and minima do not depend on the order).  Part of kc_dwa.hip.
@@ -53,9 +53,15 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int kWaves = kSegWinBlock / 64;
   float *cap = h + 5 * S;
-  // capsules: one wavefront per chunk, lanes over its points
-  for (int k = wave; k < nch; k += kWaves) {
-    const int j0 = k * a.chunk, j1 = min(j0 + a.chunk, S);
+  // capsules: one wavefront per chunk (then per super-chunk of eight chunks), lanes over its points
+  float *supc = cap + 8 * nch + 4 * nsup;  // [8][nsup] behind the spheres
+  for (int kk = wave; kk < nch + nsup; kk += kWaves) {
+    const bool super = kk >= nch;
+    const int k = super ? kk - nch : kk;
+    const int span = super ? 8 * a.chunk : a.chunk;
+    float *out = super ? supc : cap;
+    const int stride = super ? nsup : nch;
+    const int j0 = k * span, j1 = min(j0 + span, S);
     bool fin = true;
     for (int j = j0 + lane; j < j1; j += 64)
       fin = fin && isfinite(a.px[j]) && isfinite(a.py[j]) && isfinite(a.pz[j]);
@@ -83,14 +89,14 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
     eps = wave_max_f64(eps);
     mag = wave_max_f64(mag);
     if (lane == 0) {
-      cap[k] = static_cast<float>(A[0]);
-      cap[nch + k] = static_cast<float>(A[1]);
-      cap[2 * nch + k] = static_cast<float>(A[2]);
-      cap[3 * nch + k] = finite ? ab[0] : 0.0f;
-      cap[4 * nch + k] = finite ? ab[1] : 0.0f;
-      cap[5 * nch + k] = finite ? ab[2] : 0.0f;
-      cap[6 * nch + k] = inv;
-      cap[7 * nch + k] =
+      out[k] = static_cast<float>(A[0]);
+      out[stride + k] = static_cast<float>(A[1]);
+      out[2 * stride + k] = static_cast<float>(A[2]);
+      out[3 * stride + k] = finite ? ab[0] : 0.0f;
+      out[4 * stride + k] = finite ? ab[1] : 0.0f;
+      out[5 * stride + k] = finite ? ab[2] : 0.0f;
+      out[6 * stride + k] = inv;
+      out[7 * stride + k] =
           finite ? seg_round_up(eps * (1.0 + 1e-6) + 2e-6 * sqrt(l2) + 1e-6 * mag + 1e-30) : __builtin_inff();
     }
   }
