@@ -137,6 +137,10 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        cost tables fit in LDS beside the roll-out tile and the shard is
  *                        one resident wave of workgroups (<= 32 samples x CUs); 2: whenever
  *                        the tables fit; 0: roll-out, cost and publish kernels
+ *   "host_reduce"    (1) single-GPU single-launch cycles end without a device-side reduction:
+ *                        every workgroup posts a 32-byte slot to pinned memory, the host
+ *                        reduces them in kc_dwa_fetch_result; 0: arrival ticket + last
+ *                        workgroup (what kc_dwa_cycle_sharded always uses)
  *   "write_paths"    (0) the single-launch cycle also stores every float row
  *                        (otherwise rows are produced on demand by kc_dwa_get_samples)
  *   "cost_kernel"    (0) stand-alone cost stage: 0 chosen from the admissible count

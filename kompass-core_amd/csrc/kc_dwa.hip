@@ -22,6 +22,9 @@
 #include "kc_pool.h"
 
 #include <type_traits>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include "kc_collision_dev.h"
 #include "kc_cost_kernels.h"
@@ -194,6 +197,13 @@ struct kc_dwa {
   DevBuf<uint32_t> d_adm_bits;         // admissible local ids of the running cycle (bitmap)
   PinBuf<uint32_t> h_wrow;             // best row of every workgroup of a single-launch cycle
   size_t wrow_off = 0;                 // words in front of the winner's row
+  bool host_reduce = true;     // option "host_reduce": single-GPU cycles leave the reduction over the workgroups
+                               // to the host (32-byte slots in pinned memory; no device-side epilogue)
+  bool slots_pending = false;  // the last launch was such a cycle: fetch reduces the slots
+  unsigned slots_G = 0;
+  bool device_record_valid = true;  // d_result holds the last cycle's record (not after a host-reduced cycle)
+  PinBuf<long long> h_slots;   // [grid][4]
+  std::vector<int32_t> h_dealt;     // host copy of the dealt order (compacted index of the winner)
   bool sharded_call = false;   // kc_dwa_cycle_sharded: the cycle kernel leaves the host record to the
                                // hand-off behind the all-reduce
   long long rec_w4 = 0;        // row word of the record fetched last
@@ -925,7 +935,8 @@ int build_perm(kc_dwa *c) {
   const int32_t *row = c->lat.row.data() + first;
   std::stable_sort(c->h_perm.begin(), c->h_perm.end(),
                    [row](int32_t x, int32_t y) { return row[x] < row[y]; });
-  std::vector<int32_t> dealt;
+  std::vector<int32_t> &dealt = c->h_dealt;
+  dealt.clear();
   dealt.reserve(n);
   {
     // Rectangular lattice (R trig rows of L samples each -- the non-holonomic
@@ -1162,6 +1173,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   const size_t P = c->P;
   hipStream_t s = c->stream;
   c->row_valid = false;
+  c->slots_pending = false;
+  c->device_record_valid = true;
   if (n == 0) {  // empty batch: publish "nothing found"
     hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, s,
                        c->d_result.p);
@@ -1269,7 +1282,116 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   return KC_OK;
 }
 
+// Single-GPU cycle without a device-side epilogue: wait for the slot of every
+// workgroup (sequence number + checksum: the 32 bytes of a slot are two unfenced
+// stores), then the reduction the last workgroup would have done -- minimum key,
+// admissible count, the winner's index in the admissible-only numbering from
+// the survivor masks and the dealt order this host built (build_perm).
+int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
+  const unsigned G = c->slots_G;
+  volatile long long *hs = c->h_slots.p;
+  const long long seq_mask = (1ll << 61) - 1;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool synced = false;
+  for (unsigned g = 0; g < G;) {
+    const long long w0 = hs[4 * g], w1 = hs[4 * g + 1], w2 = hs[4 * g + 2], w3 = hs[4 * g + 3];
+    if ((w2 & seq_mask) == c->seq && w3 == record_check(w0, w1, w2, static_cast<long long>(g))) {
+      ++g;
+      continue;
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      if (synced) KC_FAIL(KC_ERR_HIP, "workgroup %u of the cycle kernel never reported", g);
+      KC_HIP(hipStreamSynchronize(c->stream));  // a kernel fault surfaces here
+      synced = true;
+    }
+  }
+  c->slots_pending = false;
+  c->drained = true;        // every workgroup is past its last table read
+  c->update_busy = false;
+  c->seg_busy = false;
+  c->timing.mark("host:wait_result");
+  long long fkey = KEY_NONE;
+  unsigned bw = 0;
+  long long na = 0;
+  bool late = false;
+  for (unsigned g = 0; g < G; ++g) {
+    const long long k = c->h_slots.p[4 * g];
+    if (k < fkey) {
+      fkey = k;
+      bw = g;
+    }
+    na += __builtin_popcountll(static_cast<unsigned long long>(c->h_slots.p[4 * g + 1]) & 0xFFFFFFFFull);
+    late = late || ((c->h_slots.p[4 * g + 2] >> 62) & 1);
+  }
+  if (late) KC_FAIL(KC_ERR_HIP, "roll-out kernel gave up waiting for the host's trig table");
+  kc_result r{};
+  r.n_admissible = na;
+  c->last_nadm = na;
+  r.n_samples = static_cast<int64_t>(n);
+  c->row_valid = false;
+  if (fkey == KEY_NONE) {
+    r.found = 0;
+    r.cost = 0.0f;
+    r.index = -1;
+    r.raw_index = -1;
+  } else {
+    r.found = 1;
+    r.cost = kc_key_cost(fkey);
+    r.raw_index = kc_key_index(fkey);
+    // admissible samples in front of the winner (generation order = local id order)
+    const int lim = static_cast<int>(r.raw_index - static_cast<int64_t>(c->shard_first));
+    const int32_t *ids = c->h_dealt.data();
+    const size_t nd = c->h_dealt.size();
+    long long cnt = 0;
+    for (unsigned g = 0; g < G; ++g) {
+      const uint32_t m = static_cast<uint32_t>(static_cast<unsigned long long>(c->h_slots.p[4 * g + 1]) & 0xFFFFFFFFull);
+      if (!m) continue;
+      const size_t base = static_cast<size_t>(g) * 32;
+      uint32_t below = 0u;
+#if defined(__SSE2__)
+      if (base + 32 <= nd) {
+        const __m128i vl = _mm_set1_epi32(lim);
+        for (int q = 0; q < 8; ++q) {
+          const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(ids + base + 4 * q));
+          below |= static_cast<uint32_t>(_mm_movemask_ps(_mm_castsi128_ps(_mm_cmplt_epi32(v, vl)))) << (4 * q);
+        }
+      } else
+#endif
+      {
+        for (size_t s = 0; s < 32 && base + s < nd; ++s)
+          if (ids[base + s] < lim) below |= 1u << s;
+      }
+      cnt += __builtin_popcount(m & below);
+    }
+    r.index = cnt;
+    // the winner's row: slot bw of the pinned row buffer, checked against the word of its slot
+    const unsigned long long w1 = static_cast<unsigned long long>(c->h_slots.p[4 * bw + 1]);
+    const bool has_row = (c->h_slots.p[4 * bw + 2] >> 61) & 1;
+    const size_t nw = 2 * c->P;
+    if (has_row && c->h_wrow.p && (static_cast<size_t>(bw) + 1) * nw <= c->h_wrow.cap) {
+      const uint32_t want = static_cast<uint32_t>(w1 >> 32);
+      const auto t1 = std::chrono::steady_clock::now();
+      for (long spins = 0;; ++spins) {
+        volatile uint32_t *row = c->h_wrow.p + bw * nw;
+        uint32_t x = 0u;
+        for (size_t q = 0; q < nw; ++q) x ^= row[q] * (2u * static_cast<uint32_t>(q) + 1u);
+        if (x == want) {
+          c->row_valid = true;
+          c->wrow_off = bw * nw;
+          break;
+        }
+        if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t1 > std::chrono::milliseconds(20)) break;
+      }
+    }
+  }
+  c->last = r;
+  c->have_last = true;
+  if (out) *out = r;
+  return KC_OK;
+}
+
 int fetch(kc_dwa *c, kc_result *out, size_t n) {
+  if (c->slots_pending) return fetch_slots(c, out, n);
   bool got = false;
   if (c->pub_pending) {
     // spin on the sequence word the last finalize block writes into pinned
@@ -1640,6 +1762,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_cperm.release();
   c->d_cprow.release();
   c->h_wrow.release();
+  c->h_slots.release();
   delete c;
 }
 
@@ -1674,6 +1797,7 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     c->cycle_forced = v == 2.0;
   }
   else if (n == "write_paths") c->write_paths = on;
+  else if (n == "host_reduce") c->host_reduce = on;
   else if (n == "cost_kernel") {
     if (!(v == 0.0 || v == 1.0 || v == 2.0)) KC_FAIL(KC_ERR_RANGE, "cost_kernel: 0 auto, 1 workgroup per sample, 2 wavefront per sample");
     c->cost_kernel_force = static_cast<int>(v);
@@ -1699,6 +1823,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   const std::string n(name);
   if (n == "fused_cycle") *v = c->cycle_fused ? (c->cycle_forced ? 2.0 : 1.0) : 0.0;
   else if (n == "write_paths") *v = c->write_paths;
+  else if (n == "host_reduce") *v = c->host_reduce;
   else if (n == "cost_kernel") *v = c->cost_kernel_force;
   else if (n == "cost_dc_cells") *v = c->no_dc ? 0.0 : c->dc_side;
   else if (n == "lazy_dilate") *v = c->lazy_dilate;
@@ -2238,6 +2363,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   c->external = false;
   c->have_vel = false;
   c->cycle_launched = false;
+  c->slots_pending = false;
   c->paths_valid = true;
   c->last_start = *start;
   const size_t n = c->shard_count;
@@ -2403,6 +2529,12 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
       tail.result = c->d_result.p;
       tail.host_pub = c->sharded_call ? nullptr : c->h_pub.p;
       tail.host_rows = c->sharded_call ? nullptr : c->h_wrow.p;
+      tail.host_slots = nullptr;
+      if (!c->sharded_call && c->host_reduce) {
+        KC_TRY(c->h_slots.reserve(4 * static_cast<size_t>(G)));
+        tail.host_slots = c->h_slots.p;
+        tail.host_pub = nullptr;
+      }
       tail.seq = ++c->seq;
       tail.c.block_keys = c->d_block_keys.p;
       a.dev_err = c->d_result.p + W_NADM;
@@ -2428,7 +2560,10 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
     if (cycle) {
       c->cycle_launched = true;
       c->paths_valid = c->write_paths;
-      c->pub_pending = true;
+      c->slots_pending = tail.host_slots != nullptr;
+      c->slots_G = grid.x;
+      c->pub_pending = !c->slots_pending;
+      c->device_record_valid = !c->slots_pending;
       c->row_valid = false;
     }
     c->timing.mark("host:launch_rollout");
@@ -2753,6 +2888,8 @@ int kc_dwa_result_device(kc_dwa *c, void **dev) {
 int kc_dwa_publish_result(kc_dwa *c) {
   if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
   if (!c->evaluated) KC_FAIL(KC_ERR_STATE, "nothing evaluated yet");
+  if (!c->device_record_valid)
+    KC_FAIL(KC_ERR_STATE, "the last cycle was reduced on the host (kc_dwa_cycle): no device-resident record");
   KC_TRY(use_device(c));
   hipLaunchKernelGGL(republish_kernel, dim3(1), dim3(1), 0, c->stream, c->d_result.p,
                      c->h_pub.p, ++c->seq);
@@ -2766,6 +2903,9 @@ int kc_dwa_publish_result(kc_dwa *c) {
 int kc_dwa_allreduce_best(kc_dwa *c, kc_comm *m) {
   if (!c || !m) KC_FAIL(KC_ERR_INVALID, "null argument");
   if (!c->evaluated) KC_FAIL(KC_ERR_STATE, "nothing evaluated yet");
+  if (!c->device_record_valid)
+    KC_FAIL(KC_ERR_STATE, "the last cycle was reduced on the host (kc_dwa_cycle): use kc_dwa_cycle_sharded, or "
+                          "kc_dwa_rollout + kc_dwa_evaluate, for a device-resident record");
   if (kc::comm_device(m) != c->prm.device)
     KC_FAIL(KC_ERR_INVALID, "communicator on device %d, controller on device %d", kc::comm_device(m), c->prm.device);
   KC_TRY(use_device(c));

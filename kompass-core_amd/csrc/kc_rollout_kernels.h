@@ -173,6 +173,13 @@ struct CycleTail {
   long long *host_pub;            // pinned: {key, n_adm << 32 | compact, seq, check, row word}
   uint32_t *host_rows;            // pinned: [grid][2 P] best row of every workgroup (x | y float bits)
   long long seq;                  // sequence number of this cycle's record
+  // Single GPU: no device-side reduction at all.  Every workgroup leaves a 32-byte
+  // slot {key, survivor mask | row check << 32, seq | error << 62, checksum} in
+  // pinned host memory (posted writes) and ends; the HOST waits for the G slots of
+  // this sequence number and reduces them (min key, popcounts, compacted index
+  // from the dealt order it built itself).  No drain, no ticket, no round trip on
+  // the device.  Null: the ticket epilogue (device record for the all-reduce).
+  long long *host_slots;          // pinned: [grid][4]
 };
 
 template <int kFusedSamples, int kFusedBlock, class Tail = NoTail>
@@ -300,7 +307,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
         // the ticket is still taken: the last workgroup publishes the error
         if (tid == 0)
           atomicOr(reinterpret_cast<unsigned long long *>(a.dev_err), 1ull);
-        cycle_epilogue<kFusedBlock>(a, tail, KEY_NONE, 0, -1, lpos, lperm, lperm, tid);
+        if (tail.host_slots)
+          cycle_epilogue_host<kFusedBlock>(a, tail, KEY_NONE, 0ull, -1, lpos, 1, tid);
+        else
+          cycle_epilogue<kFusedBlock>(a, tail, KEY_NONE, 0, -1, lpos, lperm, lperm, tid);
       } else {
         if (tid == 0) *a.dev_err = 1;
       }
@@ -449,6 +459,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   KC_RSTAMP(5);
   __shared__ int lsurv[kFusedSamples];  // cycle: slots of the survivors, ascending
   __shared__ int nsurv;
+  __shared__ unsigned long long lmask;  // ... as a mask over the slots
   if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
     const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
     if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
@@ -456,7 +467,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     const int cnt = __popcll(bal);
     if constexpr (kCycle) {
       if (ok) lsurv[__popcll(bal & ((1ull << tid) - 1ull))] = tid;
-      if (tid == 0) nsurv = cnt;
+      if (tid == 0) {
+        nsurv = cnt;
+        lmask = bal;
+      }
     } else {
       int start = 0;
       if (tid == 0 && cnt)
@@ -474,8 +488,12 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     const long long key = cycle_costs<kFusedSamples, kFusedBlock>(a, tail, smem, lpos, PP, lperm, lsurv,
                                                                   nsurv, tid, &best_slot);
     KC_RSTAMP(8);
-    cycle_epilogue<kFusedBlock>(a, tail, key, nsurv, best_slot, lpos + (best_slot < 0 ? 0 : best_slot) * PP,
-                                lperm, lsurv, tid);
+    if (tail.host_slots)
+      cycle_epilogue_host<kFusedBlock>(a, tail, key, lmask, best_slot,
+                                       lpos + (best_slot < 0 ? 0 : best_slot) * PP, 0, tid);
+    else
+      cycle_epilogue<kFusedBlock>(a, tail, key, nsurv, best_slot, lpos + (best_slot < 0 ? 0 : best_slot) * PP,
+                                  lperm, lsurv, tid);
     KC_RSTAMP(9);
   }
 }

@@ -40,6 +40,10 @@ def test_single_launch_cycle_equals_three_kernel_cycle_and_oracle(k):
     three = _prepared(inp, fused_cycle=0)
     h1 = hip_cycle(kh, inp, ctx=one)
     h3 = hip_cycle(kh, inp, ctx=three)
+    # the single launch with its device-side epilogue (arrival ticket; what a sharded cycle runs)
+    tick = _prepared(inp, host_reduce=0)
+    assert_cycle_equal(o, hip_cycle(kh, inp, ctx=tick))
+    tick.close()
     assert one.get_option("fused_cycle") == 1 and three.get_option("fused_cycle") == 0
     assert three.get_option("last_cycle_single_launch") == 0
     if inp["robot"]["shape"] != syn.SPHERE:
@@ -62,11 +66,13 @@ def test_many_cycles_moving_pose_both_paths_agree():
     """200 cycles with a pose that moves every cycle (nothing reusable), survivors
     from none to all: the two paths must agree every time; a few against the oracle."""
     inp = syn.make_controller_inputs("cfg2", seed=3, scale=0.3, scene="mid")
-    one, three = _prepared(inp), _prepared(inp, fused_cycle=0)
+    one, three, tick = _prepared(inp), _prepared(inp, fused_cycle=0), _prepared(inp, host_reduce=0)
     P = inp["P"]
     for i in range(200):
         st = (0.02 * (i % 50) - 0.5, 0.013 * (i % 37) - 0.2, 0.05 * (i % 9) - 0.2, 0.0)
         a, b = one.cycle(st, P), three.cycle(st, P)
+        t = tick.cycle(st, P)
+        assert (t.found, t.index, t.raw_index, t.n_admissible) == (a.found, a.index, a.raw_index, a.n_admissible), i
         assert (a.found, a.index, a.raw_index, a.n_admissible) == (b.found, b.index, b.raw_index, b.n_admissible), i
         assert np.float32(a.cost) == np.float32(b.cost)
         if a.found:
@@ -74,10 +80,10 @@ def test_many_cycles_moving_pose_both_paths_agree():
         if i % 50 == 7:
             o = oracle_cycle(dict(inp, state=st))
             assert a.n_admissible == len(o["raw"]) and a.index == o["index"]
-    one.close(); three.close()
+    one.close(); three.close(); tick.close()
 
 
-@pytest.mark.parametrize("opts", [dict(fused_cycle=2), dict(cost_kernel=1), dict(cost_kernel=2), dict(force_split=1), dict(trig_copy=1),
+@pytest.mark.parametrize("opts", [dict(fused_cycle=2), dict(host_reduce=0), dict(cost_kernel=1), dict(cost_kernel=2), dict(force_split=1), dict(trig_copy=1),
                                   dict(early_launch=0), dict(sensor_on_host=1), dict(lazy_dilate=0),
                                   dict(cost_dc_cells=64), dict(fused_cycle=0, cost_kernel=2, cost_dc_cells=128)],
                          ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))

@@ -461,6 +461,9 @@ def test_publish_result_hands_over_the_device_record():
     ctx.set_points(st, inp["points"], inp["max_range"])
     ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
     ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
+    ctx.cycle(st, inp["P"])
+    with pytest.raises(kh.KompassHipError):   # a host-reduced cycle leaves no device record to hand over
+        ctx.publish_result()
     for _ in range(3):
         ctx.rollout(st, inp["P"])
         ctx.evaluate()
