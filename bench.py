@@ -200,7 +200,9 @@ def controller_bench(args, rank, world, local_rank):
                 "scene": args.scene, "n_admissible": n_adm,
                 "samples_per_gpu": count, "global_samples": n_total, "points": P,
                 "launches_per_cycle": len(kernel_ms),
-                "cycle": "three kernels (--split)" if args.split else "single launch (kc_dwa_cycle)",
+                "cycle": "single launch (kc_dwa_cycle)" if "cycle_kernel" in kernel_ms else
+                         "three kernels" + (" (--split)" if args.split else " (kc_dwa_cycle keeps them beyond one resident "
+                                            "wave of workgroups and for small shards with many survivors)"),
                 "parallelism": f"sample-shard x{world}" if world > 1 else "single GPU",
             },
             "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),

@@ -134,9 +134,10 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  * SYCL path has none; every setting gives bit-identical results -- tests/
  * test_gpu_parity.py runs the cycle under each).  value: 0 / 1 unless stated.
  *   "fused_cycle"    (1) kc_dwa_cycle runs the whole cycle as ONE launch when the
- *                        cost tables fit in LDS beside the roll-out tile and the shard is
- *                        one resident wave of workgroups (<= 32 samples x CUs); 2: whenever
- *                        the tables fit; 0: roll-out, cost and publish kernels
+ *                        cost tables fit in LDS beside the roll-out tile, the shard is one
+ *                        resident wave of workgroups (<= 32 samples x CUs) and either fills
+ *                        half the CUs or left few survivors last cycle; 2: whenever the
+ *                        tables fit; 0: roll-out, cost and publish kernels
  *   "host_reduce"    (1) single-GPU single-launch cycles end without a device-side reduction:
  *                        every workgroup posts a 32-byte slot to pinned memory, the host
  *                        reduces them in kc_dwa_fetch_result; 0: arrival ticket + last

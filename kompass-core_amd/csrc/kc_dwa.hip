@@ -204,6 +204,7 @@ struct kc_dwa {
   bool device_record_valid = true;  // d_result holds the last cycle's record (not after a host-reduced cycle)
   PinBuf<long long> h_slots;   // [grid][4]
   std::vector<int32_t> h_dealt;     // host copy of the dealt order (compacted index of the winner)
+  std::vector<uint64_t> slot_pending;   // scratch of fetch_slots
   bool sharded_call = false;   // kc_dwa_cycle_sharded: the cycle kernel leaves the host record to the
                                // hand-off behind the all-reduce
   long long rec_w4 = 0;        // row word of the record fetched last
@@ -1293,14 +1294,37 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
   const long long seq_mask = (1ll << 61) - 1;
   const auto t0 = std::chrono::steady_clock::now();
   bool synced = false;
-  for (unsigned g = 0; g < G;) {
-    const long long w0 = hs[4 * g], w1 = hs[4 * g + 1], w2 = hs[4 * g + 2], w3 = hs[4 * g + 3];
-    if ((w2 & seq_mask) == c->seq && w3 == record_check(w0, w1, w2, static_cast<long long>(g))) {
-      ++g;
-      continue;
+  // Slots are taken in whatever order they arrive (a pending set, swept until it is empty) and
+  // folded into the reduction at once: when the slowest workgroup reports, nothing else is left to do
+  // but the index of the winner.
+  std::vector<uint64_t> &pend = c->slot_pending;
+  pend.assign((G + 63) / 64, ~0ull);
+  if (G & 63) pend.back() = (1ull << (G & 63)) - 1ull;
+  unsigned remaining = G;
+  long long fkey = KEY_NONE;
+  unsigned bw = 0;
+  long long na = 0;
+  bool late = false;
+  for (long sweeps = 0; remaining; ++sweeps) {
+    for (size_t w = 0; w < pend.size(); ++w) {
+      for (uint64_t m = pend[w]; m;) {
+        const unsigned g = static_cast<unsigned>(w * 64 + __builtin_ctzll(m));
+        m &= m - 1;
+        const long long w0 = hs[4 * g], w1 = hs[4 * g + 1], w2 = hs[4 * g + 2], w3 = hs[4 * g + 3];
+        if ((w2 & seq_mask) != c->seq || w3 != record_check(w0, w1, w2, static_cast<long long>(g))) continue;
+        pend[w] &= ~(1ull << (g & 63));
+        --remaining;
+        if (w0 < fkey || (w0 == fkey && g < bw)) {
+          fkey = w0;
+          bw = g;
+        }
+        na += __builtin_popcountll(static_cast<unsigned long long>(w1) & 0xFFFFFFFFull);
+        late = late || ((w2 >> 62) & 1);
+      }
     }
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-      if (synced) KC_FAIL(KC_ERR_HIP, "workgroup %u of the cycle kernel never reported", g);
+    if (remaining && (sweeps & 255) == 255 &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      if (synced) KC_FAIL(KC_ERR_HIP, "%u workgroups of the cycle kernel never reported", remaining);
       KC_HIP(hipStreamSynchronize(c->stream));  // a kernel fault surfaces here
       synced = true;
     }
@@ -1310,19 +1334,6 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
   c->update_busy = false;
   c->seg_busy = false;
   c->timing.mark("host:wait_result");
-  long long fkey = KEY_NONE;
-  unsigned bw = 0;
-  long long na = 0;
-  bool late = false;
-  for (unsigned g = 0; g < G; ++g) {
-    const long long k = c->h_slots.p[4 * g];
-    if (k < fkey) {
-      fkey = k;
-      bw = g;
-    }
-    na += __builtin_popcountll(static_cast<unsigned long long>(c->h_slots.p[4 * g + 1]) & 0xFFFFFFFFull);
-    late = late || ((c->h_slots.p[4 * g + 2] >> 62) & 1);
-  }
   if (late) KC_FAIL(KC_ERR_HIP, "roll-out kernel gave up waiting for the host's trig table");
   kc_result r{};
   r.n_admissible = na;
@@ -2437,8 +2448,15 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   // BASELINE config on 8 GPUs).  Beyond, the cycle kernel's LDS footprint (one workgroup per CU)
   // loses to the three-kernel cycle, whose roll-out kernel fits two per CU (cfg5 on ONE GPU,
   // 65536 samples: 0.214 against 0.129 ms).
+  // And a small shard with many survivors (cfg1: 128 samples in 4 workgroups, 104 admissible) is
+  // better served by the stand-alone cost kernels, which spread the survivors over all CUs; the
+  // admissible count of the previous cycle is the predictor (as for the choice of cost kernel).
+  const unsigned cyc_G = blocks_for(n, 32);
+  const bool cyc_wave = cyc_G <= static_cast<unsigned>(c->num_cus);
+  const bool cyc_few = c->last_nadm < 0 || c->last_nadm <= 4ll * cyc_G;
+  const bool cyc_full = 2 * cyc_G >= static_cast<unsigned>(c->num_cus);
   bool cycle = want_cycle && c->cycle_fused && c->prm.shape != KC_SPHERE && n <= 1024u * kCompactMaxPer &&
-               (c->cycle_forced || blocks_for(n, 32) <= static_cast<unsigned>(c->num_cus));
+               (c->cycle_forced || (cyc_wave && (cyc_few || cyc_full)));
   if (cycle) KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
   const int fs = cycle ? 32 : c->fused_samples, fb = cycle ? 1024 : c->fused_block;

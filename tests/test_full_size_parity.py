@@ -53,7 +53,8 @@ def test_full_size_cycle_equals_oracle(name, scene, n, mode):
     ctx0 = hip_context(kh, inp)
     ctx0.set_option("fused_cycle", mode)
     h = hip_cycle(kh, inp, ctx=ctx0)
-    assert ctx0.get_option("last_cycle_single_launch") == (1 if (mode == 2 or n <= 8192) else 0)
+    assert ctx0.get_option("last_cycle_single_launch") == (1 if (mode == 2 or n <= 8192) else 0)   # first cycle: no
+    # admissible count of a previous cycle to go by
     assert h["res"]["n_samples"] == n
     if scene == "open":
         assert len(o["raw"]) == n

@@ -36,22 +36,22 @@ def _prepared(inp, **options):
 def test_single_launch_cycle_equals_three_kernel_cycle_and_oracle(k):
     inp = _path_scenario(*_PATH_SCENARIOS[k])
     o = oracle_cycle(inp)
-    one = _prepared(inp)
+    one = _prepared(inp, fused_cycle=2)
     three = _prepared(inp, fused_cycle=0)
     h1 = hip_cycle(kh, inp, ctx=one)
     h3 = hip_cycle(kh, inp, ctx=three)
     # the single launch with its device-side epilogue (arrival ticket; what a sharded cycle runs)
-    tick = _prepared(inp, host_reduce=0)
+    tick = _prepared(inp, fused_cycle=2, host_reduce=0)
     assert_cycle_equal(o, hip_cycle(kh, inp, ctx=tick))
     tick.close()
-    assert one.get_option("fused_cycle") == 1 and three.get_option("fused_cycle") == 0
+    assert one.get_option("fused_cycle") == 2 and three.get_option("fused_cycle") == 0
     assert three.get_option("last_cycle_single_launch") == 0
     if inp["robot"]["shape"] != syn.SPHERE:
         assert one.get_option("last_cycle_single_launch") == 1, "cost tables must fit beside the roll-out tile here"
     assert_cycle_equal(o, h1)
     assert_cycle_equal(o, h3)
     # the rows stored by the cycle kernel itself (write_paths) are the same rows
-    wp = _prepared(inp, write_paths=1)
+    wp = _prepared(inp, write_paths=1, fused_cycle=2)
     r = wp.cycle(inp["state"], inp["P"])
     px, py, raw, costs = wp.get_samples(with_costs=True)
     np.testing.assert_array_equal(px.view(np.uint32), o["px"].view(np.uint32))
@@ -66,7 +66,8 @@ def test_many_cycles_moving_pose_both_paths_agree():
     """200 cycles with a pose that moves every cycle (nothing reusable), survivors
     from none to all: the two paths must agree every time; a few against the oracle."""
     inp = syn.make_controller_inputs("cfg2", seed=3, scale=0.3, scene="mid")
-    one, three, tick = _prepared(inp), _prepared(inp, fused_cycle=0), _prepared(inp, host_reduce=0)
+    # (fused_cycle = 2: by itself kc_dwa_cycle would hand this small, survivor-rich shard to the cost kernels)
+    one, three, tick = _prepared(inp, fused_cycle=2), _prepared(inp, fused_cycle=0), _prepared(inp, fused_cycle=2, host_reduce=0)
     P = inp["P"]
     for i in range(200):
         st = (0.02 * (i % 50) - 0.5, 0.013 * (i % 37) - 0.2, 0.05 * (i % 9) - 0.2, 0.0)
@@ -112,7 +113,7 @@ def test_evaluate_without_fetch_then_table_updates():
     seg2 = inp["seg_xyz"] + np.float32([0.0, 0.35, 0.0])
     o1 = oracle_cycle(inp)
     o2 = oracle_cycle(dict(inp, seg_xyz=seg2))
-    for fused in (1, 0):
+    for fused in (2, 1, 0):
         ctx = _prepared(inp, fused_cycle=fused)
         st, P = inp["state"], inp["P"]
         for rep in range(5):
