@@ -151,3 +151,45 @@ def test_rollout_evaluate_after_a_single_launch_cycle():
         assert r.n_admissible == len(o["raw"])
     assert ctx.count_admissible_before(int(o["raw"][o["index"]])) == o["index"]
     ctx.close()
+
+
+def test_two_threads_with_differently_configured_contexts():
+    """contexts that take different paths through the shared host pool and the BAR hand-offs,
+    driven from two threads at once -- a single-launch early-launched cycle beside a split / timed /
+    copy-path one -- 60 cycles each with fresh sensor data and lattice every few cycles."""
+    import threading
+
+    inps = [_path_scenario(*_PATH_SCENARIOS[1]), _path_scenario(*_PATH_SCENARIOS[5])]
+    want = [oracle_cycle(i) for i in inps]
+    configs = [(dict(fused_cycle=2), dict(force_split=1)), (dict(fused_cycle=2, host_reduce=0), dict(trig_copy=1)),
+               (dict(), dict(fused_cycle=0, early_launch=0))]
+    for opts_a, opts_b in configs:
+        ctxs = [_prepared(inps[0], **opts_a), _prepared(inps[1], **opts_b)]
+        ctxs[1].timing_enable(True)
+        errors = []
+
+        def drive(k):
+            try:
+                inp, ctx = inps[k], ctxs[k]
+                for rep in range(60):
+                    if rep % 4 == 0:
+                        ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+                        ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
+                    if rep % 7 == 0:
+                        ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+                    r = ctx.cycle(inp["state"], inp["P"])
+                    assert r.index == want[k]["index"] and np.float32(r.cost) == np.float32(want[k]["cost"]), rep
+                    assert r.n_admissible == len(want[k]["raw"])
+                    if r.found and rep % 5 == 0:
+                        np.testing.assert_array_equal(ctx.get_best()[0], want[k]["px"][want[k]["index"]])
+            except Exception as e:  # noqa: BLE001 -- reported by the main thread
+                errors.append((k, repr(e)))
+
+        threads = [threading.Thread(target=drive, args=(k,)) for k in (0, 1)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, (opts_a, opts_b, errors)
+        for c in ctxs:
+            c.close()
