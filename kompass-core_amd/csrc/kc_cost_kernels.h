@@ -86,9 +86,9 @@ struct CostArgs {
   const int *adm_list;            // admissible local sample ids (any order)
   const long long *adm_count;     // device-side count (result[W_LIST])
   const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the chunk capsules
-                                               // [8][nch]: ax ay az abx aby abz 1/|ab|^2 eps, then
-                                               // the super-chunk spheres [4][nsup]: cx cy cz r, then
-                                               // the super-chunk capsules [8][nsup] (same rows as the chunks')
+                                               // (from a 16-byte boundary) [nch] records of 8 floats
+                                               // (struct Capsule), then the super-chunk spheres
+                                               // [4][nsup]: cx cy cz r, then [nsup] super-chunk capsules
   int seg_chunk, nch;             // points per chunk, chunk count (<= 64)
   float seg_len, ref_len;
   BucketDev b;
@@ -126,6 +126,40 @@ struct DcArgs {
 #else
 #define KC_STAMP(slot) do { } while (0)
 #endif
+
+// Chunk / super-chunk capsules are records of eight floats (two 16-byte reads, one address):
+// ax ay abx aby | 1/|ab|^2 eps az abz  -- a planar segment needs the first six only.  In the
+// tracked-segment table they start at a 16-byte boundary behind the five rows.
+__host__ __device__ inline int seg_cap_offset(int S) { return (5 * S + 3) & ~3; }
+struct Capsule {
+  float ax, ay, abx, aby, inv, eps, az, abz;
+};
+__device__ __forceinline__ Capsule load_capsule(const float *tab, int c) {
+  const float4 u = *reinterpret_cast<const float4 *>(tab + 8 * c);
+  const float4 v = *reinterpret_cast<const float4 *>(tab + 8 * c + 4);
+  return Capsule{u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+}
+// squared distance of (x, y, 0) to the chord, and the slack the comparison needs
+__device__ __forceinline__ bool capsule_may_hold(const Capsule &k, float x, float y, float thr, bool flat) {
+  const float qx = x - k.ax, qy = y - k.ay;
+  float d2, mag;
+  if (flat) {
+    float t = (qx * k.abx + qy * k.aby) * k.inv;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float ex = qx - t * k.abx, ey = qy - t * k.aby;
+    d2 = ex * ex + ey * ey;
+    mag = fabsf(qx) + fabsf(qy);
+  } else {
+    const float qz = 0.0f - k.az;
+    float t = (qx * k.abx + qy * k.aby + qz * k.abz) * k.inv;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float ex = qx - t * k.abx, ey = qy - t * k.aby, ez = qz - t * k.abz;
+    d2 = ex * ex + ey * ey + ez * ez;
+    mag = fabsf(qx) + fabsf(qy) + fabsf(qz);
+  }
+  const float lim = thr + k.eps + 4e-7f * mag;
+  return !(d2 > lim * lim * 1.0001f);  // NaN compares false: qualifies
+}
 
 __device__ __forceinline__ float accum(float total, double w, float c) {
   return static_cast<float>(static_cast<double>(total) +
@@ -491,14 +525,7 @@ __device__ __forceinline__ void group_segment_search(const CostArgs &a, const Se
     for (int u = sub; u < 8; u += kL) {
       const int c = s8 + u;
       if (c < a.nch) {
-        const float qx = x - cap[c], qy = y - cap[a.nch + c], qz = 0.0f - cap[2 * a.nch + c];
-        const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c], bz = cap[5 * a.nch + c];
-        float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
-        t = fminf(fmaxf(t, 0.0f), 1.0f);
-        const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
-        const float d2 = ex * ex + ey * ey + ez * ez;
-        const float lim = thr + cap[7 * a.nch + c] + 4e-7f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
-        if (!(d2 > lim * lim * 1.0001f)) {
+        if (capsule_may_hold(load_capsule(cap, c), x, y, thr, false)) {
           if (c < 32) clo |= 1u << c;
           else chi |= 1u << (c - 32);
         }
@@ -780,29 +807,11 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       // ... and whose capsule (chord of the whole super-chunk + largest deviation) does: on a
       // smooth path a far query keeps one or two super-chunks where the spheres keep them all
       {
-        const float *sc = sup + 4 * a.nsup;  // [8][nsup]: ax ay az abx aby abz 1/|ab|^2 eps
+        const float *sc = sup + 4 * a.nsup;  // [nsup] capsule records
         for (unsigned m = smask; m;) {
           const int s = __ffs(static_cast<int>(m)) - 1;
           m &= m - 1u;
-          const float qx = x - sc[s], qy = y - sc[a.nsup + s];
-          const float bx = sc[3 * a.nsup + s], by = sc[4 * a.nsup + s];
-          float d2, mag;
-          if (flat) {
-            float t = (qx * bx + qy * by) * sc[6 * a.nsup + s];
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            const float ex = qx - t * bx, ey = qy - t * by;
-            d2 = ex * ex + ey * ey;
-            mag = fabsf(qx) + fabsf(qy);
-          } else {
-            const float qz = 0.0f - sc[2 * a.nsup + s], bz = sc[5 * a.nsup + s];
-            float t = (qx * bx + qy * by + qz * bz) * sc[6 * a.nsup + s];
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
-            d2 = ex * ex + ey * ey + ez * ez;
-            mag = fabsf(qx) + fabsf(qy) + fabsf(qz);
-          }
-          const float lim = thr + sc[7 * a.nsup + s] + 4e-7f * mag;
-          if (d2 > lim * lim * 1.0001f) smask &= ~(1u << s);
+          if (!capsule_may_hold(load_capsule(sc, s), x, y, thr, flat)) smask &= ~(1u << s);
         }
       }
       if (st) KC_STAMP(8);
@@ -826,25 +835,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int c = min(s * 8 + u, a.nch - 1);
-          const float qx = x - cap[c], qy = y - cap[a.nch + c];
-          const float bx = cap[3 * a.nch + c], by = cap[4 * a.nch + c];
-          float d2, mag;
-          if (flat) {
-            float t = (qx * bx + qy * by) * cap[6 * a.nch + c];
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            const float ex = qx - t * bx, ey = qy - t * by;
-            d2 = ex * ex + ey * ey;
-            mag = fabsf(qx) + fabsf(qy);
-          } else {
-            const float qz = 0.0f - cap[2 * a.nch + c], bz = cap[5 * a.nch + c];
-            float t = (qx * bx + qy * by + qz * bz) * cap[6 * a.nch + c];
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            const float ex = qx - t * bx, ey = qy - t * by, ez = qz - t * bz;
-            d2 = ex * ex + ey * ey + ez * ez;
-            mag = fabsf(qx) + fabsf(qy) + fabsf(qz);
-          }
-          const float lim = thr + cap[7 * a.nch + c] + 4e-7f * mag;
-          if (!(d2 > lim * lim * 1.0001f)) cand |= 1ull << c;
+          if (capsule_may_hold(load_capsule(cap, c), x, y, thr, flat)) cand |= 1ull << c;
         }
       }
       if (st) KC_STAMP(9);
@@ -1172,7 +1163,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   // 16-byte read per point instead of three reads from three rows; the
   // capsules and spheres follow (the space of the fifth row stays unused)
   const float4 *const l_pts = reinterpret_cast<const float4 *>(l_seg);
-  const float *const cap = kLds ? l_seg + 4 * a.S : a.sx + 5 * a.S;  // [8][nch]
+  const float *const cap = kLds ? l_seg + 4 * a.S : a.sx + seg_cap_offset(a.S);  // [nch] capsule records
   const float *const sup = cap + 8 * a.nch;                          // [4][nsup]
   const bool use_dc = t.dc != nullptr && *t.enable != 0;
   const float sz_end = (a.use_seg && a.S > 0) ? a.sz[a.S - 1] : 0.0f;  // z of the last segment point (end term)
@@ -1187,7 +1178,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
       for (int j = threadIdx.x; j < a.S; j += kCostBlock)
         wp[j] = make_float4(a.sx[j], a.sy[j], a.szz[j], a.acc_seg[j]);
       float *const wc = l_seg + 4 * a.S;
-      const float *const gc = a.sx + 5 * a.S;
+      const float *const gc = a.sx + seg_cap_offset(a.S);
       for (int j = threadIdx.x; j < 8 * a.nch + 12 * a.nsup; j += kCostBlock) wc[j] = gc[j];
     }
     if (a.use_obs) {

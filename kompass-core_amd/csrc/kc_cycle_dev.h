@@ -57,7 +57,7 @@ __device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned cha
   if (c.use_seg) {
 #pragma unroll 2
     for (int j = tid; j < c.S; j += nthreads) t.pts[j] = make_float4(c.sx[j], c.sy[j], c.szz[j], c.acc_seg[j]);
-    const float *gc = c.sx + 5 * c.S;
+    const float *gc = c.sx + seg_cap_offset(c.S);
     for (int j = tid; j < 8 * c.nch + 12 * c.nsup; j += nthreads) t.cap[j] = gc[j];
   }
   if (c.use_obs) {

@@ -1243,7 +1243,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     // one workgroup per CU, sixteen samples (wavefronts) in flight in each
     cost_blocks = static_cast<unsigned>(std::min<size_t>(n, kCostGrid));
     if (ca.use_seg)
-      lds_tab += (5 * S + 8 * static_cast<size_t>(ca.nch) + 12 * static_cast<size_t>(ca.nsup)) * sizeof(float);
+      lds_tab += (5 * S + 8 * static_cast<size_t>(ca.nch) + 12 * static_cast<size_t>(ca.nsup)) * sizeof(float);  // (in LDS: 4 S of records)
     const bool tab_lds = c->cost_lds_ok && lds_tab + 64 <= kCostLdsBudget;
     const bool obs_lds = tab_lds && ca.use_obs && lds_tab + lds_obs + 64 <= kCostLdsBudget;
     if (c->debug_stamps && c->seq <= 2)
@@ -1552,8 +1552,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
   if ((rc = c->d_result.reserve(R_SLOTS)) ||
       (rc = c->h_result.reserve(R_SLOTS)) ||
       (rc = ensure_cycle_buffers(c, p->max_samples, p->max_points)) ||
-      (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 8 * 64 + 12 * 8)) ||
-      (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 8 * 64 + 12 * 8)) ||
+      (rc = c->d_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 4 + 8 * 64 + 12 * 8)) ||
+      (rc = c->h_seg.reserve(5 * std::max<size_t>(p->max_segment, 16) + 4 + 8 * 64 + 12 * 8)) ||
       (rc = c->h_obs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->d_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))) ||
       (rc = c->h_bobs.reserve(2 * std::max<size_t>(p->max_obstacles, 16))))
@@ -2125,7 +2125,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   c->seg_chunk = static_cast<int>(chunk);
   c->seg_nch = static_cast<int>(nch);
   c->seg_nsup = static_cast<int>(nsup);
-  const size_t seg_words = 5 * S + 8 * nch + 12 * nsup;
+  const size_t seg_words = static_cast<size_t>(seg_cap_offset(static_cast<int>(S))) + 8 * nch + 12 * nsup;
   KC_TRY(c->h_seg.reserve(seg_words));
   KC_TRY(c->d_seg.reserve(seg_words));
   float *h = c->h_seg.p;
@@ -2152,10 +2152,10 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     p[2] = h[2 * S + j];
   };
   {
-    float *cap = h + 5 * S;
+    float *cap = h + seg_cap_offset(static_cast<int>(S));
     // capsule of the points [j0, j1): chord A -> B of the first and last point as the kernels see it
     // (float A, float AB, float 1/|AB|^2) + the largest deviation of the points from it, rounded up
-    auto capsule = [&](size_t j0, size_t j1, float *out, size_t stride, size_t k) {
+    auto capsule = [&](size_t j0, size_t j1, float *out, size_t k) {  // record k of `out` (struct Capsule)
       bool finite = true;
       for (size_t j = j0; j < j1; ++j)
         finite = finite && std::isfinite(h[j]) && std::isfinite(h[S + j]) && std::isfinite(h[2 * S + j]);
@@ -2179,22 +2179,23 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
         mag = std::max(mag, std::fabs(P[0]) + std::fabs(P[1]) + std::fabs(P[2]));
       }
       eps = std::sqrt(eps);  // sqrt is monotonic and correctly rounded: max of the roots
-      out[k] = static_cast<float>(A[0]);
-      out[stride + k] = static_cast<float>(A[1]);
-      out[2 * stride + k] = static_cast<float>(A[2]);
-      out[3 * stride + k] = finite ? ab[0] : 0.0f;
-      out[4 * stride + k] = finite ? ab[1] : 0.0f;
-      out[5 * stride + k] = finite ? ab[2] : 0.0f;
-      out[6 * stride + k] = inv;
+      float *rec = out + 8 * k;
+      rec[0] = static_cast<float>(A[0]);
+      rec[1] = static_cast<float>(A[1]);
+      rec[2] = finite ? ab[0] : 0.0f;
+      rec[3] = finite ? ab[1] : 0.0f;
+      rec[4] = inv;
       // deviation of the points from the chord, plus slack for the float chord
       // parameter and coordinate rounding
-      out[7 * stride + k] = finite ? up(eps * (1.0 + 1e-6) + 2e-6 * std::sqrt(l2) + 1e-6 * mag + 1e-30) : kInf;
+      rec[5] = finite ? up(eps * (1.0 + 1e-6) + 2e-6 * std::sqrt(l2) + 1e-6 * mag + 1e-30) : kInf;
+      rec[6] = static_cast<float>(A[2]);
+      rec[7] = finite ? ab[2] : 0.0f;
     };
-    for (size_t k = 0; k < nch; ++k) capsule(k * chunk, std::min(k * chunk + chunk, S), cap, nch, k);
+    for (size_t k = 0; k < nch; ++k) capsule(k * chunk, std::min(k * chunk + chunk, S), cap, k);
     {
-      float *supc = cap + 8 * nch + 4 * nsup;  // [8][nsup] behind the spheres
+      float *supc = cap + 8 * nch + 4 * nsup;  // [nsup] records behind the spheres
       for (size_t sidx = 0; sidx < nsup; ++sidx)
-        capsule(sidx * 8 * chunk, std::min(sidx * 8 * chunk + 8 * chunk, S), supc, nsup, sidx);
+        capsule(sidx * 8 * chunk, std::min(sidx * 8 * chunk + 8 * chunk, S), supc, sidx);
     }
     float *sup = cap + 8 * nch;
     for (size_t s = 0; s < nsup; ++s) {
@@ -2303,7 +2304,7 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   c->seg_chunk = static_cast<int>(chunk);
   c->seg_nch = static_cast<int>(nch);
   c->seg_nsup = static_cast<int>(nsup);
-  const size_t seg_words = 5 * S + 8 * nch + 12 * nsup;
+  const size_t seg_words = static_cast<size_t>(seg_cap_offset(static_cast<int>(S))) + 8 * nch + 12 * nsup;
   if (seg_words > c->d_seg.cap) {  // growing frees the old table: nothing may still read or write it
     KC_HIP(hipStreamSynchronize(c->stream));
     c->update_busy = false;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int kWaves = kSegWinBlock / 64;
-  float *cap = h + 5 * S;
+  float *cap = h + seg_cap_offset(S);
   // capsules: one wavefront per chunk (then per super-chunk of eight chunks), lanes over its points
   float *supc = cap + 8 * nch + 4 * nsup;  // [8][nsup] behind the spheres
   for (int kk = wave; kk < nch + nsup; kk += kWaves) {
@@ -60,7 +60,6 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
     const int k = super ? kk - nch : kk;
     const int span = super ? 8 * a.chunk : a.chunk;
     float *out = super ? supc : cap;
-    const int stride = super ? nsup : nch;
     const int j0 = k * span, j1 = min(j0 + span, S);
     bool fin = true;
     for (int j = j0 + lane; j < j1; j += 64)
@@ -89,15 +88,15 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
     eps = wave_max_f64(eps);
     mag = wave_max_f64(mag);
     if (lane == 0) {
-      out[k] = static_cast<float>(A[0]);
-      out[stride + k] = static_cast<float>(A[1]);
-      out[2 * stride + k] = static_cast<float>(A[2]);
-      out[3 * stride + k] = finite ? ab[0] : 0.0f;
-      out[4 * stride + k] = finite ? ab[1] : 0.0f;
-      out[5 * stride + k] = finite ? ab[2] : 0.0f;
-      out[6 * stride + k] = inv;
-      out[7 * stride + k] =
-          finite ? seg_round_up(eps * (1.0 + 1e-6) + 2e-6 * sqrt(l2) + 1e-6 * mag + 1e-30) : __builtin_inff();
+      float *rec = out + 8 * k;  // struct Capsule (kc_cost_kernels.h)
+      rec[0] = static_cast<float>(A[0]);
+      rec[1] = static_cast<float>(A[1]);
+      rec[2] = finite ? ab[0] : 0.0f;
+      rec[3] = finite ? ab[1] : 0.0f;
+      rec[4] = inv;
+      rec[5] = finite ? seg_round_up(eps * (1.0 + 1e-6) + 2e-6 * sqrt(l2) + 1e-6 * mag + 1e-30) : __builtin_inff();
+      rec[6] = static_cast<float>(A[2]);
+      rec[7] = finite ? ab[2] : 0.0f;
     }
   }
   // spheres: one wavefront per super-chunk of eight chunks
