@@ -71,6 +71,88 @@ __device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned cha
   }
 }
 
+// The same in two halves -- every global load first (into registers), the LDS
+// stores later -- so that the caller can put its other phase-A loads (window
+// bits) in between and pay ONE memory latency for all of them instead of one
+// per copy loop.  Capacity: two segment records, two capsule words, five cell
+// words and two skip words per thread; `ok` false: the plain loops above.
+template <int kBlock>
+struct CycleTabRegs {
+  float4 seg[2];
+  float cap[2];
+  int cells[5];
+  uint32_t skip[2];
+  bool ok;
+};
+template <int kBlock, class Tail>
+__device__ __forceinline__ void cycle_tables_load(const Tail &tail, int tid, CycleTabRegs<kBlock> &r) {
+  const CostArgs &c = tail.c;
+  const int ncell = c.use_obs ? c.b.W * c.b.H : 0;
+  const int capw = c.use_seg ? 8 * c.nch + 12 * c.nsup : 0;
+  r.ok = (!c.use_seg || c.S <= 2 * kBlock) && capw <= 2 * kBlock && ncell + 1 <= 5 * kBlock &&
+         (ncell + 3) / 4 <= 2 * kBlock;
+  if (!r.ok) return;
+  if (c.use_seg) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = tid + u * kBlock;
+      if (j < c.S) r.seg[u] = make_float4(c.sx[j], c.sy[j], c.szz[j], c.acc_seg[j]);
+    }
+    const float *gc = c.sx + seg_cap_offset(c.S);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = tid + u * kBlock;
+      if (j < capw) r.cap[u] = gc[j];
+    }
+  }
+  if (c.use_obs) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int j = tid + u * kBlock;
+      if (j <= ncell) r.cells[u] = c.b.cell_start[j];
+    }
+    const uint32_t *gs = reinterpret_cast<const uint32_t *>(c.b.skip);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = tid + u * kBlock;
+      if (j < (ncell + 3) / 4) r.skip[u] = gs[j];
+    }
+  }
+}
+template <int kBlock, class Tail>
+__device__ __forceinline__ void cycle_tables_store(const Tail &tail, unsigned char *smem, int tid,
+                                                   const CycleTabRegs<kBlock> &r) {
+  const CostArgs &c = tail.c;
+  if (!r.ok) {
+    cycle_fill_tables(tail, smem, tid, kBlock);
+    return;
+  }
+  const CycleTabs t = cycle_tabs(c, smem, tail.tab_off);
+  const int ncell = c.use_obs ? c.b.W * c.b.H : 0;
+  if (c.use_seg) {
+    const int capw = 8 * c.nch + 12 * c.nsup;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = tid + u * kBlock;
+      if (j < c.S) t.pts[j] = r.seg[u];
+      if (j < capw) t.cap[j] = r.cap[u];
+    }
+  }
+  if (c.use_obs) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int j = tid + u * kBlock;
+      if (j <= ncell) t.cells[j] = r.cells[u];
+    }
+    uint32_t *ls = reinterpret_cast<uint32_t *>(t.skip);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = tid + u * kBlock;
+      if (j < (ncell + 3) / 4) ls[j] = r.skip[u];
+    }
+  }
+}
+
 // Cost of the R survivors of this workgroup (slots lsurv[0..R), ascending).  Few
 // survivors: two at a time, half the workgroup each, eight lanes per point
 // (team_sample_search); many: one per wavefront, pulled from an LDS counter

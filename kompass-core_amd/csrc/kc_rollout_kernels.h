@@ -218,7 +218,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     lvy[tid] = in ? a.vy[a.first + id] : 0.0;
     if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
   }
-  if constexpr (kCycle) cycle_fill_tables(tail, smem, tid, kFusedBlock);
+  // Cycle: the cost tables' global loads are issued here and land in LDS at the end of the
+  // phase; the window loads below are in flight at the same time.
+  CycleTabRegs<kFusedBlock> tabregs;
+  if constexpr (kCycle) cycle_tables_load<kFusedBlock>(tail, tid, tabregs);
   if (a.c.enabled && a.c.dil == 2) {
     // The dilated masks of this sensor update do not exist yet: the raw bits of
     // the window plus a halo of R rows and one word either way go to LDS, and
@@ -258,28 +261,43 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       louter[i] = inside ? out_acc : 0u;
     }
   } else if (a.c.enabled) {
-    // window origin is word aligned with the sensor bitmap: whole-word copies
+    // window origin is word aligned with the sensor bitmap: whole-word copies (up to three
+    // words of each mask per thread held in registers: all loads first, then the stores)
     const int nwords = a.c.H * a.c.wpr;
     const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;  // exact: difference is a multiple of 32
-    for (int i = tid; i < nwords; i += kFusedBlock) {
-      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
-      const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
-      uint32_t v = 0u, vi = 0u, vo = 0u;
-      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
-        const size_t g = (size_t)gy * a.c.gwpr + gw;
-        v = a.c.gbits[g];
-        if (a.c.dil) {
-          vi = a.c.ginner[g];
-          vo = a.c.gouter[g];
+    for (int i0 = 0; i0 < nwords; i0 += 3 * kFusedBlock) {
+      uint32_t v[3], vi[3], vo[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = i0 + tid + u * kFusedBlock;
+        v[u] = vi[u] = vo[u] = 0u;
+        if (i < nwords) {
+          const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
+          const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
+          if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
+            const size_t g = (size_t)gy * a.c.gwpr + gw;
+            v[u] = a.c.gbits[g];
+            if (a.c.dil) {
+              vi[u] = a.c.ginner[g];
+              vo[u] = a.c.gouter[g];
+            }
+          }
         }
       }
-      lbits[i] = v;
-      if (a.c.dil) {
-        linner[i] = vi;
-        louter[i] = vo;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int i = i0 + tid + u * kFusedBlock;
+        if (i < nwords) {
+          lbits[i] = v[u];
+          if (a.c.dil) {
+            linner[i] = vi[u];
+            louter[i] = vo[u];
+          }
+        }
       }
     }
   }
+  if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, tabregs);
   if (tid == 0) ncand = 0;
   KC_RSTAMP(1);
   if (a.trig_flag) {
