@@ -74,7 +74,7 @@ struct RollArgs {
 #ifdef KC_PHASE_STAMPS
 #define KC_RSTAMP(slot)                                                    \
   do {                                                                     \
-    if (a.dbg && threadIdx.x == 0)                                         \
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 512)                                    \
       a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else

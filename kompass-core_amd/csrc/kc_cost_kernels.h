@@ -115,12 +115,20 @@ struct DcArgs {
   double inv_g, h;          // 1 / cell edge, half a cell diagonal
   int W, H;
   const int *enable;        // device flag of the sensor build: table filled in or not
+  // Near table of the tracked segment (segment_near_kernel, kc_segment_kernels.h), or null: for
+  // every cell of a grid over the reachable box, the range of chunks that can hold the nearest
+  // segment point of ANY point of the cell, and the index of the point nearest to its centre:
+  // clo | chi << 8 | j* << 16
+  const uint32_t *near;
+  float nx0, ny0, ninv;     // origin and 1 / cell edge (floats: the kernels index with float arithmetic,
+                            // the slack for that is in the table)
+  int nW, nH;
 };
 
 #ifdef KC_PHASE_STAMPS
 #define KC_STAMP(slot)                                                     \
   do {                                                                     \
-    if (a.dbg && threadIdx.x == 0)                                         \
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 512)                                    \
       a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
@@ -140,9 +148,9 @@ __device__ __forceinline__ Capsule load_capsule(const float *tab, int c) {
   return Capsule{u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
 }
 // squared distance of (x, y, 0) to the chord, and the slack the comparison needs
-__device__ __forceinline__ bool capsule_may_hold(const Capsule &k, float x, float y, float thr, bool flat) {
+__device__ __forceinline__ void capsule_dist2(const Capsule &k, float x, float y, bool flat, float &d2,
+                                              float &mag) {
   const float qx = x - k.ax, qy = y - k.ay;
-  float d2, mag;
   if (flat) {
     float t = (qx * k.abx + qy * k.aby) * k.inv;
     t = fminf(fmaxf(t, 0.0f), 1.0f);
@@ -157,6 +165,10 @@ __device__ __forceinline__ bool capsule_may_hold(const Capsule &k, float x, floa
     d2 = ex * ex + ey * ey + ez * ez;
     mag = fabsf(qx) + fabsf(qy) + fabsf(qz);
   }
+}
+__device__ __forceinline__ bool capsule_may_hold(const Capsule &k, float x, float y, float thr, bool flat) {
+  float d2, mag;
+  capsule_dist2(k, x, y, flat, d2, mag);
   const float lim = thr + k.eps + 4e-7f * mag;
   return !(d2 > lim * lim * 1.0001f);  // NaN compares false: qualifies
 }
@@ -288,17 +300,84 @@ struct PosePts {
   __device__ __forceinline__ float x(int p) const { return static_cast<float>(row[p == 0 ? start : p - 1].x); }
   __device__ __forceinline__ float y(int p) const { return static_cast<float>(row[p == 0 ? start : p - 1].y); }
 };
-// tracked segment as five rows (x | y | z | z^2 | acc) or as (x, y, z^2, acc) records
+// Tracked segment as five rows (x | y | z | z^2 | acc: the table in global memory, or the same rows
+// in LDS) or, in LDS, as PAIR records: points 2k and 2k+1 as (x0, x1, y0, y1) and (zz0, zz1, acc0, acc1).
+// A pair is what one packed-fp32 instruction works on (v_pk_add_f32 / v_pk_mul_f32: two IEEE single
+// operations per lane, each rounded like the scalar one), so a scan costs five packed operations and one
+// three-way minimum per TWO segment points.  The pair table is padded with x = +inf behind the last point
+// (their distance is +inf: above FLT_MAX, never a minimum) up to the end of the last chunk and four pairs
+// beyond, so the scans read whole batches without clamping.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__host__ __device__ inline int seg_pairs_padded(int nch, int chunk) { return (nch * chunk) / 2 + 4; }
 struct SegRows {
   const float *sx, *sy, *szz, *sacc;
-  __device__ __forceinline__ float4 pt(int j) const { return make_float4(sx[j], sy[j], szz[j], 0.0f); }
+  int S;
+  static constexpr bool kPadded = false;
+  __device__ __forceinline__ float2 xy1(int j) const { return make_float2(sx[j], sy[j]); }
+  __device__ __forceinline__ float zz1(int j) const { return szz[j]; }
   __device__ __forceinline__ float acc(int j) const { return sacc[j]; }
+  // (a pair that reaches beyond the table repeats the last point: changes no minimum)
+  __device__ __forceinline__ float4 pair_xy(int k) const {
+    const int j0 = min(2 * k, S - 1), j1 = min(2 * k + 1, S - 1);
+    return make_float4(sx[j0], sx[j1], sy[j0], sy[j1]);
+  }
+  __device__ __forceinline__ f32x2 pair_zz(int k) const {
+    const int j0 = min(2 * k, S - 1), j1 = min(2 * k + 1, S - 1);
+    return f32x2{szz[j0], szz[j1]};
+  }
 };
-struct SegRecs {
-  const float4 *rec;
-  __device__ __forceinline__ float4 pt(int j) const { return rec[j]; }
-  __device__ __forceinline__ float acc(int j) const { return rec[j].w; }
+struct SegPairs {
+  const float4 *xy, *za;
+  static constexpr bool kPadded = true;
+  __device__ __forceinline__ float2 xy1(int j) const {
+    const float *f = reinterpret_cast<const float *>(xy) + 4 * (j >> 1) + (j & 1);
+    return make_float2(f[0], f[2]);
+  }
+  __device__ __forceinline__ float zz1(int j) const {
+    return (reinterpret_cast<const float *>(za) + 4 * (j >> 1) + (j & 1))[0];
+  }
+  __device__ __forceinline__ float acc(int j) const {
+    return (reinterpret_cast<const float *>(za) + 4 * (j >> 1) + (j & 1))[2];
+  }
+  __device__ __forceinline__ float4 pair_xy(int k) const { return xy[k]; }
+  __device__ __forceinline__ f32x2 pair_zz(int k) const {
+    const float2 v = *reinterpret_cast<const float2 *>(za + k);
+    return f32x2{v.x, v.y};
+  }
 };
+// pair k of the table in global memory, padded as above
+__device__ __forceinline__ void seg_pair_from_rows(const float *sx, const float *sy, const float *szz,
+                                                   const float *acc, int S, int k, float4 &xy, float4 &za) {
+  const int j0 = 2 * k, j1 = j0 + 1;
+  const float inf = __builtin_inff();
+  xy = make_float4(j0 < S ? sx[j0] : inf, j1 < S ? sx[j1] : inf, j0 < S ? sy[j0] : 0.0f, j1 < S ? sy[j1] : 0.0f);
+  za = make_float4(j0 < S ? szz[j0] : 0.0f, j1 < S ? szz[j1] : 0.0f, j0 < S ? acc[j0] : 0.0f,
+                   j1 < S ? acc[j1] : 0.0f);
+}
+// squared distances of (x, y, 0) to the two points of pair k: dx*dx + (dy*dy + z^2) each, Eigen's
+// a + (b + c); a flat segment (every z^2 == +0) leaves dy*dy + 0 == dy*dy out, bit for bit
+template <class Seg>
+__device__ __forceinline__ f32x2 pair_d2(const Seg &seg, int k, float x, float y, bool flat) {
+  const float4 q = seg.pair_xy(k);
+  const f32x2 dx = f32x2{q.x, q.y} - x, dy = f32x2{q.z, q.w} - y;
+  const f32x2 xx = dx * dx, yy = dy * dy;
+  if (flat) return xx + yy;
+  return xx + (yy + seg.pair_zz(k));
+}
+// minimum (as bits) over the pairs [k0, k1), four pairs per batch (a padded table lets the last batch
+// run into the next chunk or the padding; an unpadded one repeats its last point)
+template <class Seg>
+__device__ __forceinline__ uint32_t pairs_min_bits(const Seg &seg, int k0, int k1, float x, float y, bool flat,
+                                                   uint32_t bestb) {
+  for (int kb = k0; kb < k1; kb += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x2 d = pair_d2(seg, kb + u, x, y, flat);
+      bestb = min(bestb, min(__float_as_uint(d.x), __float_as_uint(d.y)));
+    }
+  }
+  return bestb;
+}
 
 // The searches of ONE sample by a team of kTeam lanes (a multiple of 64), eight
 // lanes per trajectory point: brute-force segment scan, block search around the
@@ -333,17 +412,17 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
       if (cap) {
         group_segment_search<Seg, kL>(a, seg, cap, sup, x, y, sub, best, arg);
       } else {
-#pragma unroll 4
-        for (int j = sub; j < a.S; j += kL) {  // j ascending per lane
-          const float4 q = seg.pt(j);
-          const float dx = q.x - x;
-          const float dy = q.y - y;
-          const float xx = dx * dx;
-          const float yy = dy * dy;
-          const float d = xx + (yy + q.z);  // Eigen order a + (b + c)
-          if (d < best) {
-            best = d;
-            arg = j;
+        const bool flat = a.seg_flat != 0;
+#pragma unroll 2
+        for (int k = sub; 2 * k < a.S; k += kL) {  // j ascending per lane
+          const f32x2 d = pair_d2(seg, k, x, y, flat);
+          if (d.x < best) {
+            best = d.x;
+            arg = 2 * k;
+          }
+          if (d.y < best) {  // (a repeat of the last point or the padding never is)
+            best = d.y;
+            arg = 2 * k + 1;
           }
         }
         // non-negative floats order like their bit patterns; ties go to the
@@ -361,7 +440,7 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
           const float arc = kc::div_rn(a.ref_len - seg.acc(arg), a.ref_len);
           *s_goal = arc + kc::div_rn(kc::sqrt_rn(best), a.ref_len);
           // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
-          const float4 qe = seg.pt(a.S - 1);
+          const float2 qe = seg.xy1(a.S - 1);
           const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
           const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
           *s_end = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
@@ -452,13 +531,15 @@ template <class Seg, int kL>
 __device__ __forceinline__ void group_segment_search(const CostArgs &a, const Seg &seg, const float *cap,
                                                      const float *sup, float x, float y, int sub,
                                                      float &best_out, int &arg_out) {
-  auto d2_to = [&](int j) {
-    const float4 q = seg.pt(j);
+  const bool flat = a.seg_flat != 0;
+  auto d2_to = [&](int j) {  // (chunk heads: even indices, the first half of a pair record)
+    const float4 q = seg.pair_xy(j >> 1);
     const float dx = q.x - x;
-    const float dy = q.y - y;
+    const float dy = q.z - y;
     const float xx = dx * dx;
     const float yy = dy * dy;
-    return xx + (yy + q.z);  // Eigen order a + (b + c)
+    if (flat) return xx + yy;
+    return xx + (yy + seg.pair_zz(j >> 1).x);  // Eigen order a + (b + c)
   };
   auto merge = [&](float &best, int &arg) {
     // non-negative floats order like their bit patterns (NaN above everything:
@@ -525,7 +606,7 @@ __device__ __forceinline__ void group_segment_search(const CostArgs &a, const Se
     for (int u = sub; u < 8; u += kL) {
       const int c = s8 + u;
       if (c < a.nch) {
-        if (capsule_may_hold(load_capsule(cap, c), x, y, thr, false)) {
+        if (capsule_may_hold(load_capsule(cap, c), x, y, thr, flat)) {
           if (c < 32) clo |= 1u << c;
           else chi |= 1u << (c - 32);
         }
@@ -538,13 +619,17 @@ __device__ __forceinline__ void group_segment_search(const CostArgs &a, const Se
   for (unsigned long long cand = (static_cast<unsigned long long>(chi) << 32) | clo; cand;) {
     const int c = __ffsll(static_cast<long long>(cand)) - 1;
     cand &= cand - 1ull;
-    const int j0 = c * a.seg_chunk;
-    const int j1 = min(j0 + a.seg_chunk, a.S);
-    for (int j = j0 + 1 + sub; j < j1; j += kL) {
-      const float dd = d2_to(j);
-      if (dd < best || (dd == best && j < arg)) {
-        best = dd;
-        arg = j;
+    const int j1 = min((c + 1) * a.seg_chunk, a.S);
+    for (int k = ((c * a.seg_chunk) >> 1) + sub; 2 * k < j1; k += kL) {  // (chunks hold an even number of points)
+      const f32x2 d = pair_d2(seg, k, x, y, flat);
+      const int ja = 2 * k, jb = min(2 * k + 1, a.S - 1);
+      if (d.x < best || (d.x == best && ja < arg)) {
+        best = d.x;
+        arg = ja;
+      }
+      if (jb != ja && (d.y < best || (d.y == best && jb < arg))) {
+        best = d.y;
+        arg = jb;
       }
     }
   }
@@ -705,7 +790,7 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
       }
     }
   }
-  const SegRows seg{sx, sy, szz, sacc};
+  const SegRows seg{sx, sy, szz, sacc, a.S};
   const RowPts pts{s_px, s_py};
 
   for (int i = blockIdx.x; i < na; i += gridDim.x) {
@@ -779,80 +864,94 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       uint32_t bestb = 0x7F7FFFFFu;  // FLT_MAX
       const bool flat = a.seg_flat != 0;  // every z of the segment is +0: the z terms vanish exactly
       auto d2_bits = [&](int j) {
-        const float4 q = seg.pt(j);
+        const float2 q = seg.xy1(j);
         const float dx = q.x - x;
         const float dy = q.y - y;
         const float xx = dx * dx;
         const float yy = dy * dy;
-        return __float_as_uint(xx + (yy + q.z));  // Eigen order a + (b + c)
+        if (flat) return __float_as_uint(xx + yy);      // yy + (+0) == yy
+        return __float_as_uint(xx + (yy + seg.zz1(j)));  // Eigen order a + (b + c)
       };
-      const int sup_pts = 8 * a.seg_chunk;
-      // (1) the first point of every super-chunk
-      for (int s = 0; s < a.nsup; ++s) bestb = min(bestb, d2_bits(s * sup_pts));
-      // (2) super-chunks that may hold something at least as close:
-      // |q - c| - r <= thr on the squares; 1e-4 relative slack on the bound,
-      // 1e-5 on the compared square (NaN compares false: qualifies)
-      float thr = __builtin_sqrtf(__uint_as_float(bestb)) * 1.0001f;
-      unsigned smask = 0u;
-      for (int s = 0; s < a.nsup; ++s) {
-        const float dx = sup[s] - x, dy = sup[a.nsup + s] - y;
-        float d2 = dx * dx + dy * dy;
-        if (!flat) {
-          const float dz = sup[2 * a.nsup + s];
-          d2 += dz * dz;
+      unsigned long long cand = 0ull;
+      if (t.near != nullptr) {
+        // Near table: the cell of this point names the chunks that can hold its nearest
+        // segment point (a contiguous range along the path, conservative for every point of
+        // the cell) and a seed, the segment point nearest to the cell centre: an attained
+        // upper bound within a fraction of the cell of the answer.  What is left is the
+        // capsule test of that range against the seed's distance and the scan of the one
+        // or two chunks that pass.  A point outside the table (the host lays it over
+        // everything a roll-out can reach) tests every chunk.
+        const float fx = (x - t.nx0) * t.ninv, fy = (y - t.ny0) * t.ninv;
+        const bool inside = fx >= 0.0f && fy >= 0.0f && fx < static_cast<float>(t.nW) &&
+                            fy < static_cast<float>(t.nH);  // NaN: outside
+        uint32_t e = static_cast<uint32_t>(a.nch - 1) << 8;   // clo 0, chi nch - 1, seed 0
+        if (inside) e = t.near[static_cast<int>(fy) * t.nW + static_cast<int>(fx)];
+        bestb = d2_bits(static_cast<int>(e >> 16));
+        if (st) KC_STAMP(8);
+        const float thr = __builtin_sqrtf(__uint_as_float(bestb)) * 1.0001f;
+        const int chi = static_cast<int>((e >> 8) & 0xFFu);
+        for (int c = static_cast<int>(e & 0xFFu); c <= chi; ++c)
+          if (capsule_may_hold(load_capsule(cap, c), x, y, thr, flat)) cand |= 1ull << c;
+      } else {
+        const int sup_pts = 8 * a.seg_chunk;
+        // (1) the first point of every super-chunk
+        for (int s = 0; s < a.nsup; ++s) bestb = min(bestb, d2_bits(s * sup_pts));
+        // (2) super-chunks that may hold something at least as close:
+        // |q - c| - r <= thr on the squares; 1e-4 relative slack on the bound,
+        // 1e-5 on the compared square (NaN compares false: qualifies)
+        float thr = __builtin_sqrtf(__uint_as_float(bestb)) * 1.0001f;
+        unsigned smask = 0u;
+        for (int s = 0; s < a.nsup; ++s) {
+          const float dx = sup[s] - x, dy = sup[a.nsup + s] - y;
+          float d2 = dx * dx + dy * dy;
+          if (!flat) {
+            const float dz = sup[2 * a.nsup + s];
+            d2 += dz * dz;
+          }
+          const float lim = thr + sup[3 * a.nsup + s];
+          if (!(d2 > lim * lim * 1.00001f)) smask |= 1u << s;
         }
-        const float lim = thr + sup[3 * a.nsup + s];
-        if (!(d2 > lim * lim * 1.00001f)) smask |= 1u << s;
-      }
-      // ... and whose capsule (chord of the whole super-chunk + largest deviation) does: on a
-      // smooth path a far query keeps one or two super-chunks where the spheres keep them all
-      {
-        const float *sc = sup + 4 * a.nsup;  // [nsup] capsule records
+        // ... and whose capsule (chord of the whole super-chunk + largest deviation) does: on a
+        // smooth path a far query keeps one or two super-chunks where the spheres keep them all
+        {
+          const float *sc = sup + 4 * a.nsup;  // [nsup] capsule records
+          for (unsigned m = smask; m;) {
+            const int s = __ffs(static_cast<int>(m)) - 1;
+            m &= m - 1u;
+            if (!capsule_may_hold(load_capsule(sc, s), x, y, thr, flat)) smask &= ~(1u << s);
+          }
+        }
+        if (st) KC_STAMP(8);
+        // (3) the first points of their other chunks
         for (unsigned m = smask; m;) {
           const int s = __ffs(static_cast<int>(m)) - 1;
           m &= m - 1u;
-          if (!capsule_may_hold(load_capsule(sc, s), x, y, thr, flat)) smask &= ~(1u << s);
-        }
-      }
-      if (st) KC_STAMP(8);
-      // (3) the first points of their other chunks
-      for (unsigned m = smask; m;) {
-        const int s = __ffs(static_cast<int>(m)) - 1;
-        m &= m - 1u;
 #pragma unroll
-        for (int u = 1; u < 8; ++u) {
-          const int c = s * 8 + u;
-          bestb = min(bestb, d2_bits(min(c, a.nch - 1) * a.seg_chunk));  // a repeat of the last chunk changes nothing
+          for (int u = 1; u < 8; ++u) {
+            const int c = s * 8 + u;
+            bestb = min(bestb, d2_bits(min(c, a.nch - 1) * a.seg_chunk));  // a repeat of the last chunk changes nothing
+          }
         }
-      }
-      // (4) capsule test of their chunks: distance to the chord minus the
-      // largest deviation of the chunk's points from it
-      thr = __builtin_sqrtf(__uint_as_float(bestb)) * 1.0001f;
-      unsigned long long cand = 0ull;
-      for (unsigned m = smask; m;) {
-        const int s = __ffs(static_cast<int>(m)) - 1;
-        m &= m - 1u;
+        // (4) capsule test of their chunks: distance to the chord minus the
+        // largest deviation of the chunk's points from it
+        thr = __builtin_sqrtf(__uint_as_float(bestb)) * 1.0001f;
+        for (unsigned m = smask; m;) {
+          const int s = __ffs(static_cast<int>(m)) - 1;
+          m &= m - 1u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int c = min(s * 8 + u, a.nch - 1);
-          if (capsule_may_hold(load_capsule(cap, c), x, y, thr, flat)) cand |= 1ull << c;
+          for (int u = 0; u < 8; ++u) {
+            const int c = min(s * 8 + u, a.nch - 1);
+            if (capsule_may_hold(load_capsule(cap, c), x, y, thr, flat)) cand |= 1ull << c;
+          }
         }
       }
       if (st) KC_STAMP(9);
-      // (5) the remaining points of those chunks
+      // (5) the points of those chunks, two per packed operation
       while (cand) {
         const int c = __ffsll(static_cast<long long>(cand)) - 1;
         cand &= cand - 1ull;
-        const int j0 = c * a.seg_chunk;
-        const int j1 = min(j0 + a.seg_chunk, a.S);
-        // five points per batch: their LDS reads are in flight together (a repeat of
-        // the chunk's last point changes nothing)
-        for (int jb = j0 + 1; jb < j1; jb += 5) {
-          uint32_t v[5];
-#pragma unroll
-          for (int u = 0; u < 5; ++u) v[u] = d2_bits(min(jb + u, j1 - 1));
-          bestb = min(min(min(bestb, v[0]), min(v[1], v[2])), min(v[3], v[4]));
-        }
+        const int k0 = (c * a.seg_chunk) >> 1;  // (chunks hold an even number of points)
+        bestb = pairs_min_bits(seg, k0, k0 + (a.seg_chunk >> 1), x, y, flat, bestb);
       }
       if (st) KC_STAMP(10);
       const float best = __uint_as_float(bestb);
@@ -868,13 +967,10 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
         const uint32_t be = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bestb), le));
         uint32_t arg_l = 0xFFFFFFFFu;
         if (be < 0x7F7FFFFFu) {
-          for (int j = lane; j < a.S && arg_l == 0xFFFFFFFFu; j += 64) {
-            const float4 q = seg.pt(j);
-            const float dx = q.x - xe;
-            const float dy = q.y - ye;
-            const float xx = dx * dx;
-            const float yy = dy * dy;
-            if (__float_as_uint(xx + (yy + q.z)) == be) arg_l = static_cast<uint32_t>(j);
+          for (int k = lane; 2 * k < a.S && arg_l == 0xFFFFFFFFu; k += 64) {
+            const f32x2 d = pair_d2(seg, k, xe, ye, flat);
+            if (__float_as_uint(d.x) == be) arg_l = static_cast<uint32_t>(2 * k);
+            else if (__float_as_uint(d.y) == be) arg_l = static_cast<uint32_t>(2 * k + 1);
           }
         }
         const uint32_t argm = wave_min_u32(arg_l);
@@ -885,7 +981,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
           goal_l = arc + kc::div_rn(mind, a.ref_len);
           // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
           const int e = a.S - 1;
-          const float4 qe = seg.pt(e);
+          const float2 qe = seg.xy1(e);
           const float dx = x - qe.x, dy = y - qe.y, dz = 0.0f - sz_end;
           const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
           end_l = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
@@ -1147,9 +1243,10 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   KC_STAMP(1);
   const BucketDev &b = a.b;
   const int ncell = b.W * b.H;
-  const int seg_words = a.use_seg ? 5 * a.S + 8 * a.nch + 12 * a.nsup : 0;
-  // LDS layout: segment rows + chunk spheres | cell table | skip table (padded
-  // to words) | obstacle coordinates.  The pointers are chosen at compile time
+  const int npp = seg_pairs_padded(a.nch, a.seg_chunk);
+  const int seg_words = a.use_seg ? 8 * npp + 8 * a.nch + 12 * a.nsup : 0;
+  // LDS layout: segment pair records + chunk capsules + super-chunk spheres | cell table | skip table
+  // (padded to words) | obstacle coordinates.  The pointers are chosen at compile time
   // so that the LDS variants issue ds_read, not flat loads.
   float *const l_seg = reinterpret_cast<float *>(smem);
   int *const l_cells = reinterpret_cast<int *>(l_seg + seg_words);
@@ -1159,11 +1256,11 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   const uint8_t *const skip = kLds ? l_skip : b.skip;
   const float *const obx = kObsLds ? l_obs : b.bx;
   const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
-  // In LDS the segment points are records (x, y, z^2, accumulated length): one
-  // 16-byte read per point instead of three reads from three rows; the
-  // capsules and spheres follow (the space of the fifth row stays unused)
-  const float4 *const l_pts = reinterpret_cast<const float4 *>(l_seg);
-  const float *const cap = kLds ? l_seg + 4 * a.S : a.sx + seg_cap_offset(a.S);  // [nch] capsule records
+  // In LDS the segment points are pair records (struct SegPairs): one 16-byte read per TWO points
+  // instead of three reads from three rows per point; the capsules and spheres follow
+  float4 *const l_xy = reinterpret_cast<float4 *>(l_seg);
+  float4 *const l_za = l_xy + npp;
+  const float *const cap = kLds ? l_seg + 8 * npp : a.sx + seg_cap_offset(a.S);  // [nch] capsule records
   const float *const sup = cap + 8 * a.nch;                          // [4][nsup]
   const bool use_dc = t.dc != nullptr && *t.enable != 0;
   const float sz_end = (a.use_seg && a.S > 0) ? a.sz[a.S - 1] : 0.0f;  // z of the last segment point (end term)
@@ -1173,11 +1270,9 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   }
   if (na > 0 && kLds) {
     if (a.use_seg) {
-      float4 *const wp = reinterpret_cast<float4 *>(l_seg);
-#pragma unroll 4
-      for (int j = threadIdx.x; j < a.S; j += kCostBlock)
-        wp[j] = make_float4(a.sx[j], a.sy[j], a.szz[j], a.acc_seg[j]);
-      float *const wc = l_seg + 4 * a.S;
+      for (int k = threadIdx.x; k < npp; k += kCostBlock)
+        seg_pair_from_rows(a.sx, a.sy, a.szz, a.acc_seg, a.S, k, l_xy[k], l_za[k]);
+      float *const wc = l_seg + 8 * npp;
       const float *const gc = a.sx + seg_cap_offset(a.S);
       for (int j = threadIdx.x; j < 8 * a.nch + 12 * a.nsup; j += kCostBlock) wc[j] = gc[j];
     }
@@ -1215,10 +1310,10 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
 #endif
     float total;
     if (kLds)
-      total = wave_sample_total(a, t, use_dc, SegRecs{l_pts}, cap, sup, sz_end, cells, skip, obx, oby, pts,
+      total = wave_sample_total(a, t, use_dc, SegPairs{l_xy, l_za}, cap, sup, sz_end, cells, skip, obx, oby, pts,
                                 n, lane, &s_obest[wave], stamp);
     else
-      total = wave_sample_total(a, t, use_dc, SegRows{a.sx, a.sy, a.szz, a.acc_seg}, cap, sup, sz_end,
+      total = wave_sample_total(a, t, use_dc, SegRows{a.sx, a.sy, a.szz, a.acc_seg, a.S}, cap, sup, sz_end,
                                 cells, skip, obx, oby, pts, n, lane, &s_obest[wave], stamp);
     if (lane == 0) a.costs[n] = total;
     if (i == static_cast<int>(blockIdx.x)) KC_STAMP(3);

@@ -33,7 +33,7 @@ __device__ __forceinline__ T ld_agent(const T *p) {
 // LDS layout of the cost tables behind tab_off (the host sizes it the same way:
 // cycle_table_bytes in kc_dwa.hip)
 struct CycleTabs {
-  float4 *pts;      // [S] (x, y, z^2, accumulated length)
+  float4 *xy, *za;  // [seg_pairs_padded] pair records of the segment points (struct SegPairs)
   float *cap;       // [8][nch] capsules, then [4][nsup] spheres, then [8][nsup] super-chunk capsules
   int *cells;       // [ncell + 1]
   uint8_t *skip;    // [ncell padded to 4]
@@ -42,8 +42,10 @@ struct CycleTabs {
 __device__ __forceinline__ CycleTabs cycle_tabs(const CostArgs &c, unsigned char *smem, unsigned tab_off) {
   CycleTabs t;
   const int ncell = c.b.W * c.b.H;
-  t.pts = reinterpret_cast<float4 *>(smem + tab_off);
-  t.cap = reinterpret_cast<float *>(t.pts + (c.use_seg ? c.S : 0));
+  const int npp = c.use_seg ? seg_pairs_padded(c.nch, c.seg_chunk) : 0;
+  t.xy = reinterpret_cast<float4 *>(smem + tab_off);
+  t.za = t.xy + npp;
+  t.cap = reinterpret_cast<float *>(t.za + npp);
   t.cells = reinterpret_cast<int *>(t.cap + (c.use_seg ? 8 * c.nch + 12 * c.nsup : 0));
   t.skip = reinterpret_cast<uint8_t *>(t.cells + (c.use_obs ? ncell + 1 : 0));
   t.mind = reinterpret_cast<float *>(t.skip + (c.use_obs ? ((ncell + 3) & ~3) : 0));
@@ -55,8 +57,8 @@ __device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned cha
   const CostArgs &c = tail.c;
   const CycleTabs t = cycle_tabs(c, smem, tail.tab_off);
   if (c.use_seg) {
-#pragma unroll 2
-    for (int j = tid; j < c.S; j += nthreads) t.pts[j] = make_float4(c.sx[j], c.sy[j], c.szz[j], c.acc_seg[j]);
+    const int npp = seg_pairs_padded(c.nch, c.seg_chunk);
+    for (int k = tid; k < npp; k += nthreads) seg_pair_from_rows(c.sx, c.sy, c.szz, c.acc_seg, c.S, k, t.xy[k], t.za[k]);
     const float *gc = c.sx + seg_cap_offset(c.S);
     for (int j = tid; j < 8 * c.nch + 12 * c.nsup; j += nthreads) t.cap[j] = gc[j];
   }
@@ -74,11 +76,11 @@ __device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned cha
 // The same in two halves -- every global load first (into registers), the LDS
 // stores later -- so that the caller can put its other phase-A loads (window
 // bits) in between and pay ONE memory latency for all of them instead of one
-// per copy loop.  Capacity: two segment records, two capsule words, five cell
+// per copy loop.  Capacity: one segment pair, two capsule words, five cell
 // words and two skip words per thread; `ok` false: the plain loops above.
 template <int kBlock>
 struct CycleTabRegs {
-  float4 seg[2];
+  float4 sxy, sza;
   float cap[2];
   int cells[5];
   uint32_t skip[2];
@@ -89,15 +91,12 @@ __device__ __forceinline__ void cycle_tables_load(const Tail &tail, int tid, Cyc
   const CostArgs &c = tail.c;
   const int ncell = c.use_obs ? c.b.W * c.b.H : 0;
   const int capw = c.use_seg ? 8 * c.nch + 12 * c.nsup : 0;
-  r.ok = (!c.use_seg || c.S <= 2 * kBlock) && capw <= 2 * kBlock && ncell + 1 <= 5 * kBlock &&
+  const int npp = c.use_seg ? seg_pairs_padded(c.nch, c.seg_chunk) : 0;
+  r.ok = npp <= kBlock && capw <= 2 * kBlock && ncell + 1 <= 5 * kBlock &&
          (ncell + 3) / 4 <= 2 * kBlock;
   if (!r.ok) return;
   if (c.use_seg) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int j = tid + u * kBlock;
-      if (j < c.S) r.seg[u] = make_float4(c.sx[j], c.sy[j], c.szz[j], c.acc_seg[j]);
-    }
+    if (tid < npp) seg_pair_from_rows(c.sx, c.sy, c.szz, c.acc_seg, c.S, tid, r.sxy, r.sza);
     const float *gc = c.sx + seg_cap_offset(c.S);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -131,10 +130,13 @@ __device__ __forceinline__ void cycle_tables_store(const Tail &tail, unsigned ch
   const int ncell = c.use_obs ? c.b.W * c.b.H : 0;
   if (c.use_seg) {
     const int capw = 8 * c.nch + 12 * c.nsup;
+    if (tid < seg_pairs_padded(c.nch, c.seg_chunk)) {
+      t.xy[tid] = r.sxy;
+      t.za[tid] = r.sza;
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int j = tid + u * kBlock;
-      if (j < c.S) t.pts[j] = r.seg[u];
       if (j < capw) t.cap[j] = r.cap[u];
     }
   }
@@ -176,7 +178,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
     s_next = 0;
     s_bslot = -1;
   }
-  const SegRecs seg{t.pts};
+  const SegPairs seg{t.xy, t.za};
   if (R <= kTeamMaxSurvivors) {
     // every survivor at once: R teams (two halves or four quarters of the workgroup)
     const bool quarters = R > 2;
@@ -189,11 +191,11 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
     const PosePts pts{lpos + s * PP, PP - 1};
     if (active) {
       if (quarters)
-        team_sample_search<kBlock / 4, SegRecs, PosePts, 4>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
+        team_sample_search<kBlock / 4, SegPairs, PosePts, 4>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
                                                             t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h],
                                                             t.cap, t.cap + 8 * c.nch);
       else
-        team_sample_search<kBlock / 2, SegRecs, PosePts, 8>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
+        team_sample_search<kBlock / 2, SegPairs, PosePts, 8>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
                                                             t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h],
                                                             t.cap, t.cap + 8 * c.nch);
     }

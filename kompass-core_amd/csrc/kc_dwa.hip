@@ -145,6 +145,14 @@ struct kc_dwa {
   bool path_flat = false;     // ... of the resident path
   PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
   DevBuf<float> d_seg;
+  // near table of the tracked segment (segment_near_kernel): rebuilt when the segment or the
+  // reachable box changes, and only for cycles whose cost stage is expected to run the
+  // wavefront-per-sample search (option "near_table": cells per side, 0 off)
+  DevBuf<uint32_t> d_near;
+  int near_side = 128;
+  unsigned long long seg_version = 0, near_version = ~0ull;  // segment the table was built from
+  float near_x0 = 0.f, near_y0 = 0.f, near_g = 0.f;
+  bool near_ok = false;       // the table covers the running cycle
   // resident reference path (kc_dwa_set_path): rows x | y | z | acc on the
   // device, edge lengths on the host (the window length is an ordered float sum)
   DevBuf<float> d_path;
@@ -1109,6 +1117,54 @@ int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
   return KC_OK;
 }
 
+// Near table for the cycle that starts at (x, y): kept when the segment is the one it was built
+// from and the reachable box still lies inside it.
+int ensure_near_table(kc_dwa *c, double x, double y) {
+  c->near_ok = false;
+  const bool use_seg = c->ref_len > 0.0f && (c->w.reference_path_distance_weight > 0.0 ||
+                                             c->w.goal_distance_weight > 0.0);
+  if (c->near_side == 0 || !use_seg || c->S == 0 || c->S >= 65536 || !std::isfinite(x) || !std::isfinite(y))
+    return KC_OK;
+  const double reach = cycle_reach(c);
+  if (!(reach > 0.0) || !std::isfinite(reach)) return KC_OK;
+  const int N = c->near_side;
+  if (c->near_version == c->seg_version && c->near_g > 0.f) {
+    const double lo_x = c->near_x0, lo_y = c->near_y0, side = static_cast<double>(c->near_g) * N;
+    if (x - reach >= lo_x && y - reach >= lo_y && x + reach <= lo_x + side && y + reach <= lo_y + side) {
+      c->near_ok = true;
+      return KC_OK;
+    }
+  }
+  const double half = reach * 1.02 + 1e-3;
+  c->near_x0 = static_cast<float>(x - half);
+  c->near_y0 = static_cast<float>(y - half);
+  // the float origins may have been rounded up: the edge covers that too
+  const double side = std::max(x + half - c->near_x0, y + half - c->near_y0) * 1.0001;
+  c->near_g = static_cast<float>(side / N);
+  if (!(c->near_g > 0.f) || !std::isfinite(c->near_g) || !std::isfinite(1.0f / c->near_g)) return KC_OK;
+  KC_TRY(c->d_near.reserve(static_cast<size_t>(N) * N));
+  SegNearArgs na{};
+  na.seg = c->d_seg.p;
+  na.S = static_cast<int>(c->S);
+  na.chunk = c->seg_chunk;
+  na.nch = c->seg_nch;
+  na.flat = c->seg_flat ? 1 : 0;
+  na.x0 = c->near_x0;
+  na.y0 = c->near_y0;
+  na.g = c->near_g;
+  // the kernels take a point's cell from (x - x0) * (1 / g) in float
+  na.slack = static_cast<float>(1e-5 * side + 1e-6 * (std::fabs(c->near_x0) + std::fabs(c->near_y0) + side));
+  na.W = na.H = N;
+  na.out = c->d_near.p;
+  KC_TRY(c->timing.start("segment_near_kernel", c->stream));
+  hipLaunchKernelGGL(segment_near_kernel, dim3((N * N + kSegNearBlock / 8 - 1) / (kSegNearBlock / 8)),
+                     dim3(kSegNearBlock), 0, c->stream, na);
+  KC_TRY(c->timing.stop(c->stream));
+  c->near_version = c->seg_version;
+  c->near_ok = true;
+  return KC_OK;
+}
+
 // argument blocks of the cost stage (stand-alone kernels and the cycle tail)
 int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt) {
   const size_t P = c->P;
@@ -1150,6 +1206,13 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
   dt.W = c->dc_W;
   dt.H = c->dc_H;
   dt.enable = c->d_dc_enable.p;
+  if (c->near_ok && ca.use_seg) {
+    dt.near = c->d_near.p;
+    dt.nx0 = c->near_x0;
+    dt.ny0 = c->near_y0;
+    dt.ninv = 1.0f / c->near_g;
+    dt.nW = dt.nH = c->near_side;
+  }
   ca.seg_len = c->seg_len;
   ca.ref_len = c->ref_len;
   ca.b = c->bucket;
@@ -1184,6 +1247,22 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   }
   if (n > 1024u * kCompactMaxPer)
     KC_FAIL(KC_ERR_RANGE, "more than %d samples per context", 1024 * kCompactMaxPer);
+  // Short admissible lists (the count of the previous cycle is the predictor)
+  // go to the workgroup-per-sample kernel, long ones to the wavefront-per-
+  // sample kernel; both are correct for any list.
+  if (c->h_pub.p && c->seq > 0) {
+    // callers that never fetch (multi-GPU: the key is all-reduced on the
+    // device) still leave the previous cycle's record in the pinned mirror
+    volatile long long *hp = c->h_pub.p;
+    const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3], w4 = hp[4];
+    if (w2 == c->seq && w3 == record_check(w0, w1, w2, w4)) c->last_nadm = w1 >> 32;
+  }
+  bool use_block = c->last_nadm >= 0 && c->last_nadm <= kBlockKernelMaxAdm;
+  if (c->cost_kernel_force == 1) use_block = true;
+  if (c->cost_kernel_force == 2) use_block = false;
+  // the wavefront-per-sample search of a roll-out's samples goes through the near table
+  c->near_ok = false;
+  if (!use_block && !c->external) KC_TRY(ensure_near_table(c, c->last_start.x, c->last_start.y));
   CostArgs ca{};
   DcArgs dt{};
   KC_TRY(build_cost_args(c, n, first, ca, dt));
@@ -1203,19 +1282,6 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     ca.dbg = c->d_dbg.p;
   }
 #endif
-  // Short admissible lists (the count of the previous cycle is the predictor)
-  // go to the workgroup-per-sample kernel, long ones to the wavefront-per-
-  // sample kernel; both are correct for any list.
-  if (c->h_pub.p && c->seq > 0) {
-    // callers that never fetch (multi-GPU: the key is all-reduced on the
-    // device) still leave the previous cycle's record in the pinned mirror
-    volatile long long *hp = c->h_pub.p;
-    const long long w0 = hp[0], w1 = hp[1], w2 = hp[2], w3 = hp[3], w4 = hp[4];
-    if (w2 == c->seq && w3 == record_check(w0, w1, w2, w4)) c->last_nadm = w1 >> 32;
-  }
-  bool use_block = c->last_nadm >= 0 && c->last_nadm <= kBlockKernelMaxAdm;
-  if (c->cost_kernel_force == 1) use_block = true;
-  if (c->cost_kernel_force == 2) use_block = false;
   unsigned cost_blocks;
   size_t lds_tab = 0, lds_obs = 0;
   if (ca.use_obs) {
@@ -1243,7 +1309,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     // one workgroup per CU, sixteen samples (wavefronts) in flight in each
     cost_blocks = static_cast<unsigned>(std::min<size_t>(n, kCostGrid));
     if (ca.use_seg)
-      lds_tab += (5 * S + 8 * static_cast<size_t>(ca.nch) + 12 * static_cast<size_t>(ca.nsup)) * sizeof(float);  // (in LDS: 4 S of records)
+      lds_tab += (8 * static_cast<size_t>(seg_pairs_padded(ca.nch, ca.seg_chunk)) + 8 * static_cast<size_t>(ca.nch) +
+                  12 * static_cast<size_t>(ca.nsup)) * sizeof(float);  // pair records, capsules, spheres
     const bool tab_lds = c->cost_lds_ok && lds_tab + 64 <= kCostLdsBudget;
     const bool obs_lds = tab_lds && ca.use_obs && lds_tab + lds_obs + 64 <= kCostLdsBudget;
     if (c->debug_stamps && c->seq <= 2)
@@ -1817,6 +1884,11 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     c->no_dc = v == 0.0;
     if (!c->no_dc) c->dc_side = static_cast<int>(v);
     c->have_dc = false;  // built by the next sensor update
+  } else if (n == "near_table") {
+    if (v != 0.0 && !(v >= 16.0 && v <= 512.0)) KC_FAIL(KC_ERR_RANGE, "near_table: 0 (off) or 16..512 cells per side");
+    c->near_side = static_cast<int>(v);
+    c->near_version = ~0ull;
+    c->near_ok = false;
   } else if (n == "lazy_dilate") c->lazy_dilate = on;
   else if (n == "early_launch") c->early_launch = on;
   else if (n == "sensor_on_host") c->device_sensor = !on;
@@ -1838,6 +1910,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "cost_kernel") *v = c->cost_kernel_force;
   else if (n == "cost_dc_cells") *v = c->no_dc ? 0.0 : c->dc_side;
   else if (n == "lazy_dilate") *v = c->lazy_dilate;
+  else if (n == "near_table") *v = c->near_side;
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "sensor_on_host") *v = !c->device_sensor;
   else if (n == "trig_copy") *v = !c->trig_direct;
@@ -2119,7 +2192,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   if (S == 0) return KC_OK;
   // rows [5][S], then capsules of the chunks [8][nch] and bounding spheres of
   // the super-chunks (8 chunks) [4][nsup] (sample_cost_kernel, steps 2 and 4)
-  const size_t chunk = std::max<size_t>(kSegChunkMin, (S + 63) / 64);
+  const size_t chunk = (std::max<size_t>(kSegChunkMin, (S + 63) / 64) + 1) & ~size_t(1);  // even: whole pair records
   const size_t nch = (S + chunk - 1) / chunk;
   const size_t nsup = (nch + 7) / 8;
   c->seg_chunk = static_cast<int>(chunk);
@@ -2142,6 +2215,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     h[4 * S + j] = acc[j];
   }
   c->seg_flat = flat;
+  ++c->seg_version;
   const float kInf = std::numeric_limits<float>::infinity();
   auto up = [](double v) {  // to float, rounded up
     return std::nextafter(static_cast<float>(v), std::numeric_limits<float>::infinity());
@@ -2297,8 +2371,9 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   c->S = S;
   c->ref_len = c->path_len;
   c->seg_flat = c->path_flat;
+  ++c->seg_version;
   if (S == 0) return KC_OK;
-  const size_t chunk = std::max<size_t>(kSegChunkMin, (S + 63) / 64);
+  const size_t chunk = (std::max<size_t>(kSegChunkMin, (S + 63) / 64) + 1) & ~size_t(1);  // even: whole pair records
   const size_t nch = (S + chunk - 1) / chunk;
   const size_t nsup = (nch + 7) / 8;
   c->seg_chunk = static_cast<int>(chunk);
@@ -2345,7 +2420,8 @@ namespace {
 size_t cycle_table_bytes(const CostArgs &ca) {
   size_t b = 0;
   if (ca.use_seg)
-    b += 16 * static_cast<size_t>(ca.S) + 4 * (8 * static_cast<size_t>(ca.nch) + 12 * static_cast<size_t>(ca.nsup));
+    b += 32 * static_cast<size_t>(seg_pairs_padded(ca.nch, ca.seg_chunk)) +
+         4 * (8 * static_cast<size_t>(ca.nch) + 12 * static_cast<size_t>(ca.nsup));
   if (ca.use_obs) {
     const size_t ncell = static_cast<size_t>(ca.b.W) * ca.b.H;
     b += 4 * (ncell + 1) + ((ncell + 3) & ~size_t(3));
@@ -2458,7 +2534,13 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   const bool cyc_full = 2 * cyc_G >= static_cast<unsigned>(c->num_cus);
   bool cycle = want_cycle && c->cycle_fused && c->prm.shape != KC_SPHERE && n <= 1024u * kCompactMaxPer &&
                (c->cycle_forced || (cyc_wave && (cyc_few || cyc_full)));
-  if (cycle) KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
+  if (cycle) {
+    // workgroups with more than a handful of survivors search wavefront-per-sample: through the
+    // near table when the last cycle had that many
+    c->near_ok = false;
+    if (c->last_nadm < 0 || c->last_nadm > 2ll * cyc_G) KC_TRY(ensure_near_table(c, start->x, start->y));
+    KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
+  }
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
   const int fs = cycle ? 32 : c->fused_samples, fb = cycle ? 1024 : c->fused_block;
   const size_t pos_bytes = static_cast<size_t>(fs) * (P | 1) * sizeof(double2);

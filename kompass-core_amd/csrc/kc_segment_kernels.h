@@ -142,4 +142,114 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
   }
 }
 
+// ---------------------------------------------------------------------------
+// Near table of the tracked segment (DcArgs::near): a grid of W x H cells of
+// edge g over the box a roll-out can reach; per cell
+//   clo | chi << 8 | j* << 16
+// j* = a segment point nearest to the cell centre c (distance m), [clo, chi] =
+// the hull of the chunks whose capsule comes within m + 2 h of c (h = half a
+// cell diagonal + the slack of the kernels' float cell arithmetic).  For a
+// point p of the cell the seed is at most m + h away, and every point of a
+// chunk outside the range is farther than (m + 2 h) - h from p: the range
+// holds p's nearest point and every tie.  Eight lanes per cell (chunk k belongs
+// to lane k mod 8), the tables read from LDS.
+// ---------------------------------------------------------------------------
+struct SegNearArgs {
+  const float *seg;     // d_seg: rows [5][S], capsule records from seg_cap_offset(S)
+  int S, chunk, nch, flat;
+  float x0, y0, g;      // origin, cell edge
+  float slack;          // added to half a cell diagonal
+  int W, H;
+  uint32_t *out;
+};
+constexpr int kSegNearBlock = 512;  // 64 cells per workgroup
+
+__global__ __launch_bounds__(kSegNearBlock) void segment_near_kernel(SegNearArgs a) {
+  __shared__ __align__(16) float l_cap[8 * 64];
+  __shared__ float4 l_head[64];
+  const int S = a.S, nch = a.nch;
+  const float *sx = a.seg, *sy = a.seg + S, *szz = a.seg + 3 * S;
+  const float *gcap = a.seg + seg_cap_offset(S);
+  for (int j = threadIdx.x; j < 8 * nch; j += kSegNearBlock) l_cap[j] = gcap[j];
+  for (int k = threadIdx.x; k < nch; k += kSegNearBlock) {
+    const int j = k * a.chunk;
+    l_head[k] = make_float4(sx[j], sy[j], szz[j], 0.0f);
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 7;
+  const int cell = blockIdx.x * (kSegNearBlock / 8) + (threadIdx.x >> 3);
+  const int ncell = a.W * a.H;
+  const int cc = min(cell, ncell - 1);  // whole groups stay in step (DPP reductions)
+  const int ix = cc % a.W, iy = cc / a.W;
+  const float x = a.x0 + (static_cast<float>(ix) + 0.5f) * a.g;
+  const float y = a.y0 + (static_cast<float>(iy) + 0.5f) * a.g;
+  const bool flat = a.flat != 0;
+  auto d2_of = [&](float qx, float qy, float qzz) {
+    const float dx = qx - x, dy = qy - y;
+    return dx * dx + (dy * dy + qzz);
+  };
+  // (1) upper bound of m: the chunk heads
+  uint32_t ub = 0x7F7FFFFFu;
+  for (int k = sub; k < nch; k += 8) {
+    const float4 q = l_head[k];
+    ub = min(ub, __float_as_uint(d2_of(q.x, q.y, q.z)));  // NaN / inf bits never win
+  }
+  ub = group_min_u32<8>(ub);
+  const float uthr = __builtin_sqrtf(__uint_as_float(ub)) * 1.0001f;
+  // (2) lower bound of every chunk of this lane (the kernels' capsule test, solved for the
+  // threshold); chunks that may hold something as close as the bound are scanned: exact m
+  float lb[8];
+  uint32_t mb = ub;
+  uint32_t jb = 0xFFFFFFFFu;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = sub + 8 * u;
+    lb[u] = __builtin_inff();
+    if (k < nch) {
+      const Capsule cp = load_capsule(l_cap, k);
+      float d2, mag;
+      capsule_dist2(cp, x, y, flat, d2, mag);
+      // capsule_may_hold(thr): !(d2 > (thr + eps + 4e-7 mag)^2 * 1.0001)
+      float v = __builtin_sqrtf(d2) * 0.9999f - cp.eps - 4e-7f * mag;
+      if (!(v == v)) v = -__builtin_inff();  // NaN: always a candidate
+      lb[u] = v;
+      if (v <= uthr) {
+        const int j0 = k * a.chunk, j1 = min(j0 + a.chunk, S);
+        for (int j = j0; j < j1; ++j) {
+          const uint32_t b = __float_as_uint(d2_of(sx[j], sy[j], szz[j]));
+          if (b < mb || (b == mb && static_cast<uint32_t>(j) < jb)) {
+            mb = b;
+            jb = static_cast<uint32_t>(j);
+          }
+        }
+      }
+    }
+  }
+  const uint32_t mg = group_min_u32<8>(mb);
+  const uint32_t jg = group_min_u32<8>(mb == mg ? jb : 0xFFFFFFFFu);
+  // (3) the chunks within m + 2 h
+  const float h = a.g * 0.70710679f * 1.0001f + a.slack;
+  const float R = __builtin_sqrtf(__uint_as_float(mg)) * 1.0001f + 2.0f * h;  // +inf when nothing is finite
+  uint32_t lo = 0xFFu, hi_inv = 0xFFu;  // hi tracked as 255 - k (a minimum again)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int k = sub + 8 * u;
+    if (k < nch && lb[u] <= R) {
+      lo = min(lo, static_cast<uint32_t>(k));
+      hi_inv = min(hi_inv, static_cast<uint32_t>(255 - k));
+    }
+  }
+  lo = group_min_u32<8>(lo);
+  hi_inv = group_min_u32<8>(hi_inv);
+  if (sub == 0 && cell < ncell) {
+    uint32_t clo = lo, chi = 255u - hi_inv;
+    if (lo == 0xFFu) {  // cannot happen (the chunk of j* is always in); never trust a table that says "nothing"
+      clo = 0u;
+      chi = static_cast<uint32_t>(nch - 1);
+    }
+    const uint32_t seed = jg == 0xFFFFFFFFu ? 0u : jg;
+    a.out[cell] = clo | (chi << 8) | (seed << 16);
+  }
+}
+
 }  // namespace kc
