@@ -150,26 +150,29 @@ __device__ __forceinline__ Capsule load_capsule(const float *tab, int c) {
 // squared distance of (x, y, 0) to the chord, and the slack the comparison needs
 __device__ __forceinline__ void capsule_dist2(const Capsule &k, float x, float y, bool flat, float &d2,
                                               float &mag) {
+  // (a pruning bound, not part of the exactness contract: fused multiply-adds are fine here,
+  // the slack of the comparison covers any rounding)
   const float qx = x - k.ax, qy = y - k.ay;
   if (flat) {
-    float t = (qx * k.abx + qy * k.aby) * k.inv;
+    float t = __builtin_fmaf(qx, k.abx, qy * k.aby) * k.inv;
     t = fminf(fmaxf(t, 0.0f), 1.0f);
-    const float ex = qx - t * k.abx, ey = qy - t * k.aby;
-    d2 = ex * ex + ey * ey;
+    const float ex = __builtin_fmaf(-t, k.abx, qx), ey = __builtin_fmaf(-t, k.aby, qy);
+    d2 = __builtin_fmaf(ex, ex, ey * ey);
     mag = fabsf(qx) + fabsf(qy);
   } else {
     const float qz = 0.0f - k.az;
-    float t = (qx * k.abx + qy * k.aby + qz * k.abz) * k.inv;
+    float t = __builtin_fmaf(qx, k.abx, __builtin_fmaf(qy, k.aby, qz * k.abz)) * k.inv;
     t = fminf(fmaxf(t, 0.0f), 1.0f);
-    const float ex = qx - t * k.abx, ey = qy - t * k.aby, ez = qz - t * k.abz;
-    d2 = ex * ex + ey * ey + ez * ez;
+    const float ex = __builtin_fmaf(-t, k.abx, qx), ey = __builtin_fmaf(-t, k.aby, qy),
+                ez = __builtin_fmaf(-t, k.abz, qz);
+    d2 = __builtin_fmaf(ex, ex, __builtin_fmaf(ey, ey, ez * ez));
     mag = fabsf(qx) + fabsf(qy) + fabsf(qz);
   }
 }
 __device__ __forceinline__ bool capsule_may_hold(const Capsule &k, float x, float y, float thr, bool flat) {
   float d2, mag;
   capsule_dist2(k, x, y, flat, d2, mag);
-  const float lim = thr + k.eps + 4e-7f * mag;
+  const float lim = __builtin_fmaf(4e-7f, mag, thr + k.eps);
   return !(d2 > lim * lim * 1.0001f);  // NaN compares false: qualifies
 }
 
@@ -271,6 +274,22 @@ __device__ __forceinline__ double wave_min_nonneg(double v) {
 }
 __device__ __forceinline__ float lane_value(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// Ordered float sum ((carry + v0) + v1) + ... + v63 of one value per lane, the order in which
+// pathCostFunc adds them (cost_evaluator.cpp:111-141): lane k takes lane k-1's partial sum through
+// the DPP wave shift and adds its own value, 63 dependent v_add_f32_dpp instead of 64 v_readlane +
+// 64 v_add.  All 64 lanes active; v >= +0 or NaN (so 0 + v == v bit for bit in lane 0, which reads
+// 0 from beyond the wave); wave-uniform result.
+__device__ __forceinline__ float wave_ordered_sum(float carry, float v, int lane) {
+  const float m = lane == 0 ? carry + v : v;
+  float r = m;
+#pragma unroll
+  for (int i = 0; i < 63; ++i) {
+    const float prev =
+        __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+    r = prev + m;
+  }
+  return lane_value(r, 63);
 }
 
 // ---------------------------------------------------------------------------
@@ -712,8 +731,7 @@ __device__ __forceinline__ float team_sample_total(const CostArgs &a, int n, int
       for (int base = 0; base < a.P; base += 64) {
         const int cnt = min(64, a.P - base);
         const float v = (lane < cnt) ? s_mind[base + lane] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) sum += lane_value(v, k);
+        sum = wave_ordered_sum(sum, v, lane);
       }
       const float c = kc::div_rn(
           kc::div_rn(sum, static_cast<float>(a.P)) + s_end, 2.0f);
@@ -946,6 +964,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
         }
       }
       if (st) KC_STAMP(9);
+      const unsigned long long cand0 = cand;  // (the end point's search below looks at its chunks again)
       // (5) the points of those chunks, two per packed operation
       while (cand) {
         const int c = __ffsll(static_cast<long long>(cand)) - 1;
@@ -965,12 +984,33 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
         const int le = a.P - 1 - p0;
         const float xe = lane_value(x, le), ye = lane_value(y, le);
         const uint32_t be = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bestb), le));
+        // Points as close as the minimum lie in the chunks the end point scanned (everything else was
+        // proven farther): eight lanes per candidate chunk, eight chunks per pass.
+        unsigned long long ce =
+            (static_cast<unsigned long long>(static_cast<uint32_t>(
+                 __builtin_amdgcn_readlane(static_cast<int>(cand0 >> 32), le))) << 32) |
+            static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cand0), le));
         uint32_t arg_l = 0xFFFFFFFFu;
         if (be < 0x7F7FFFFFu) {
-          for (int k = lane; 2 * k < a.S && arg_l == 0xFFFFFFFFu; k += 64) {
-            const f32x2 d = pair_d2(seg, k, xe, ye, flat);
-            if (__float_as_uint(d.x) == be) arg_l = static_cast<uint32_t>(2 * k);
-            else if (__float_as_uint(d.y) == be) arg_l = static_cast<uint32_t>(2 * k + 1);
+          const int hp = a.seg_chunk >> 1;
+          while (ce) {
+            int myc = -1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              if (ce) {
+                const int c = __ffsll(static_cast<long long>(ce)) - 1;
+                ce &= ce - 1ull;
+                if ((lane >> 3) == i) myc = c;
+              }
+            }
+            if (myc >= 0) {
+              const int k0 = (myc * a.seg_chunk) >> 1;
+              for (int k = k0 + (lane & 7); k < k0 + hp && 2 * k < a.S && arg_l == 0xFFFFFFFFu; k += 8) {
+                const f32x2 d = pair_d2(seg, k, xe, ye, flat);
+                if (__float_as_uint(d.x) == be) arg_l = static_cast<uint32_t>(2 * k);
+                else if (__float_as_uint(d.y) == be) arg_l = static_cast<uint32_t>(2 * k + 1);
+              }
+            }
           }
         }
         const uint32_t argm = wave_min_u32(arg_l);
@@ -1199,8 +1239,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       // (idle lanes contribute +0.0f, which leaves the non-negative sum as it is:
       // 64 straight-line additions instead of a counted loop)
       const float mv = live ? mind : 0.0f;
-#pragma unroll
-      for (int k = 0; k < 64; ++k) sum += lane_value(mv, k);
+      sum = wave_ordered_sum(sum, mv, lane);
       if (p0 + 64 >= a.P) {
         goal = lane_value(goal_l, a.P - 1 - p0);
         endc = lane_value(end_l, a.P - 1 - p0);
@@ -1377,7 +1416,18 @@ __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
     long long lim =
         static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
     if (lim > a.n) lim = a.n;
-    for (long long i = threadIdx.x; i < lim; i += kPubBlock) cnt += a.flags[i];
+    // the flags are 0 / 1 bytes: sixteen per load, eight loads in flight per thread (a 65536-sample
+    // lattice is 8 loads per thread; byte by byte this loop was 21 us of a 0.2 ms cycle)
+    const int full = static_cast<int>(lim >> 4);
+    const uint4 *f16 = reinterpret_cast<const uint4 *>(a.flags);
+#pragma unroll 8
+    for (int i = threadIdx.x; i < full; i += kPubBlock) {
+      const uint4 v = f16[i];
+      cnt += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
+             __popc(v.w & 0x01010101u);
+    }
+    for (long long i = (static_cast<long long>(full) << 4) + threadIdx.x; i < lim; i += kPubBlock)
+      cnt += a.flags[i] & 1;
   }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
   if (lane == 0) wsum[wave] = cnt;

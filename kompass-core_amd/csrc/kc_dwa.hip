@@ -108,6 +108,7 @@ struct kc_dwa {
   bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
   bool cost_lds_ok = false;             // sample_cost_kernel<true> may take kCostLdsBudget
   int fused_samples = 32, fused_block = 1024;
+  bool fused_shape_fixed = false;  // KC_FUSED_CFG given: no per-lattice choice of the roll-out tile
   bool have_sensor = false;
 
   // samples
@@ -1663,6 +1664,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (std::sscanf(e, "%d,%d", &sa, &th) == 2) {
       c->fused_samples = sa;
       c->fused_block = th;
+      c->fused_shape_fixed = true;
     }
   }
   {
@@ -1816,6 +1818,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_vom.release();
   c->h_seg.release();
   c->d_seg.release();
+  c->d_near.release();
   c->d_path.release();
   c->h_obs.release();
   c->h_cells.release();
@@ -2542,7 +2545,12 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
     KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
   }
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
-  const int fs = cycle ? 32 : c->fused_samples, fb = cycle ? 1024 : c->fused_block;
+  // Roll-out tile of the three-kernel cycle: 32 samples per workgroup; 1024 threads, or 512 for a large
+  // lattice of short trajectories (cfg5, 65536 x 50: more workgroups resident per CU hide the serial
+  // recurrence of each other, 80 -> 45 us; P = 100 or one resident round: 1024 is better, tools/fused_cfg_sweep.sh)
+  int plain_fb = c->fused_block;
+  if (!c->fused_shape_fixed && P <= 64 && blocks_for(n, 32) > 4u * static_cast<unsigned>(c->num_cus)) plain_fb = 512;
+  const int fs = cycle ? 32 : c->fused_samples, fb = cycle ? 1024 : plain_fb;
   const size_t pos_bytes = static_cast<size_t>(fs) * (P | 1) * sizeof(double2);
   size_t bits_bytes =
       (a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 * (a.c.dil ? 3 : 1) : 0) +
@@ -2573,7 +2581,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
   const size_t tab_off = (pos_bytes + bits_bytes + 15) & ~size_t(15);
   cycle = cycle && fused && tab_off + cycle_table_bytes(tail.c) + 2048 <= c->lds_limit;
-  if (want_cycle && !cycle && fused && (fs != c->fused_samples || fb != c->fused_block))
+  if (want_cycle && !cycle && fused && (fs != c->fused_samples || fb != plain_fb))
     return rollout_impl(c, start, P, false);  // sized for the cycle shape: start over for the plain one
   c->need_compact = !fused || cycle;
   // early launch: queue the fused kernel first and let launch + dispatch

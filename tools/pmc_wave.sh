@@ -5,7 +5,7 @@ O=gpurun_out/r2p
 mkdir -p $O
 export KC_FUSED_CYCLE=0 KC_COST_KERNEL=wave
 for w in 1,1,1,0,0 1,1,0,0,0 0,0,1,0,0 0,1,0,0,0; do
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/w -o p -- python3 tools/run_cycles.py cfg2 open $w 30 > $O/w.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace --output-format csv -d $O/w -o p -- python3 tools/run_cycles.py cfg2 ${SCENE:-open} $w 30 > $O/w.log 2>&1
   f=$(find $O/w -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$w" <<'PY'
 import csv, sys

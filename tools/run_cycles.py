@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "kompass-core_amd"))
 import kompass_hip as kh, synthetic as syn
 cfg, scene = sys.argv[1], sys.argv[2]
 inp = syn.make_controller_inputs(cfg, seed=0, scene=scene)
-w = tuple(float(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else inp["weights"]
+w = tuple(float(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 and sys.argv[3] else inp["weights"]
 n = int(sys.argv[4]) if len(sys.argv) > 4 else 50
 P, S = inp["P"], len(inp["seg_xyz"])
 ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"], inp["dt"],
