@@ -45,20 +45,19 @@ for p in (ROOT, ROOT / "kompass-core_amd"):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(kernel, scene="survey"):
-    """HBM bytes per launch of `kernel` from the newest committed PMC pass of that scene
-    (profiles/*_<scene>_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE runs of this same
-    command, gfx950 correction applied; falls back to any *_pmc_hbm.json); None when there is none."""
+def pmc_traffic(kernel, scene="survey", cfg="cfg2"):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass of that config and scene
+    (profiles/*_<cfg>_<scene>_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE runs of this same
+    command, gfx950 correction applied); (None, None) when no pass of this workload is committed."""
     import glob
     import json as _json
 
-    files = sorted(glob.glob(str(ROOT / "profiles" / f"*_{scene}_pmc_hbm.json"))) or \
-        sorted(glob.glob(str(ROOT / "profiles" / "*_pmc_hbm.json")))
+    files = sorted(glob.glob(str(ROOT / "profiles" / f"*_{cfg}_{scene}_pmc_hbm.json")))
     if not files:
         return None, None
     rec = _json.load(open(files[-1])).get("kernels", {}).get(kernel)
     if not rec:
-        return None, os.path.basename(files[-1])
+        return None, None
     return rec.get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1])
 
 
@@ -83,6 +82,9 @@ def controller_bench(args, rank, world, local_rank):
         import torch
         import torch.distributed as dist
 
+        if world == 1:  # forced: no launcher has set the rendezvous up
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -209,7 +211,7 @@ def controller_bench(args, rank, world, local_rank):
             "latency_min_ms": float(np.min(lat) * 1e3), "latency_max_ms": float(np.max(lat) * 1e3),
             "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
             "host_phases_ms": {k: float(np.mean(v)) for k, v in host_ms.items()},
-            "roofline": roofline_of(kernel_ms, count, P, base["map_side"], S, O, args.scene),
+            "roofline": roofline_of(kernel_ms, count, P, base["map_side"], S, O, args.scene, cfg),
             "winner": {"found": found, "cost": cost, "raw_index": raw},
         }
         if world == 1 and not args.no_cpu:
@@ -287,7 +289,7 @@ def strong_leg(kh, syn, sharding, cfg, rank, world, local_rank, comm, args, barr
             "winner": {"found": bool(r.found), "cost": float(r.cost), "raw_index": int(r.raw_index), "index": int(idx)}}
 
 
-def roofline_of(kernel_ms, count, P, map_side, S, O, scene="survey"):
+def roofline_of(kernel_ms, count, P, map_side, S, O, scene="survey", cfg="cfg2"):
     """HBM roofline of the dominant kernel: algorithmic bytes of ONE launch (SURVEY
     8d: 16 B per trajectory-step + 20 B per sample + per-cycle constants; a launch
     of any kernel of the cycle covers all N x P steps) / its mean duration by HIP
@@ -296,7 +298,7 @@ def roofline_of(kernel_ms, count, P, map_side, S, O, scene="survey"):
     dom_ms = float(np.mean(kernel_ms[dom]))
     bytes_launch = algorithmic_bytes(count, P, map_side, S, O)
     achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(dom, scene)
+    traffic, traffic_src = pmc_traffic(dom, scene, cfg)
     return {
         "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -341,7 +343,7 @@ def scene_leg(ctx, cfg, scene, inp, vx, vy, om, P, S, pose, args):
                                f"{int(r.n_admissible)} of {n} samples admissible", "scene": scene,
                    "n_admissible": int(r.n_admissible), "obstacles": int(len(pts))},
         "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
-        "roofline": roofline_of(kernel_ms, n, P, base["map_side"], S, len(pts), scene),
+        "roofline": roofline_of(kernel_ms, n, P, base["map_side"], S, len(pts), scene, cfg),
     }
     if not args.no_cpu:
         leg["cpu_baseline"] = cpu_baseline(dict(inp, points=pts), vx, vy, om, pose(args.steps - 1), bool(r.found),

@@ -235,17 +235,19 @@ __device__ __forceinline__ uint32_t group8_min_u32(uint32_t v) {
 // ... and inside each aligned group of kL = 4 or 8 lanes (quads need no third step)
 template <int kL>
 __device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
-  static_assert(kL == 4 || kL == 8, "four or eight lanes per point");
+  static_assert(kL == 4 || kL == 8 || kL == 16, "four, eight or sixteen lanes per group");
   v = min(v, dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
   v = min(v, dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
-  if (kL == 8) v = min(v, dpp_u32<0x141>(v));  // row_half_mirror
+  if (kL >= 8) v = min(v, dpp_u32<0x141>(v));   // row_half_mirror
+  if (kL >= 16) v = min(v, dpp_u32<0x140>(v));  // row_mirror
   return v;
 }
 template <int kL>
 __device__ __forceinline__ uint32_t group_or_u32(uint32_t v) {
   v |= dpp_u32<0xB1>(v);
   v |= dpp_u32<0x4E>(v);
-  if (kL == 8) v |= dpp_u32<0x141>(v);
+  if (kL >= 8) v |= dpp_u32<0x141>(v);
+  if (kL >= 16) v |= dpp_u32<0x140>(v);
   return v;
 }
 template <int kL>

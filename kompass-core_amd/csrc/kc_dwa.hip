@@ -154,6 +154,7 @@ struct kc_dwa {
   unsigned long long seg_version = 0, near_version = ~0ull;  // segment the table was built from
   float near_x0 = 0.f, near_y0 = 0.f, near_g = 0.f;
   bool near_ok = false;       // the table covers the running cycle
+  bool near_wanted = false;   // the last cycle asked for the table: the next segment update builds it ahead
   // resident reference path (kc_dwa_set_path): rows x | y | z | acc on the
   // device, edge lengths on the host (the window length is an ordered float sum)
   DevBuf<float> d_path;
@@ -1120,7 +1121,7 @@ int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
 
 // Near table for the cycle that starts at (x, y): kept when the segment is the one it was built
 // from and the reachable box still lies inside it.
-int ensure_near_table(kc_dwa *c, double x, double y) {
+int ensure_near_table(kc_dwa *c, double x, double y, double margin = 0.0) {
   c->near_ok = false;
   const bool use_seg = c->ref_len > 0.0f && (c->w.reference_path_distance_weight > 0.0 ||
                                              c->w.goal_distance_weight > 0.0);
@@ -1136,7 +1137,7 @@ int ensure_near_table(kc_dwa *c, double x, double y) {
       return KC_OK;
     }
   }
-  const double half = reach * 1.02 + 1e-3;
+  const double half = reach * 1.02 + 1e-3 + margin;
   c->near_x0 = static_cast<float>(x - half);
   c->near_y0 = static_cast<float>(y - half);
   // the float origins may have been rounded up: the edge covers that too
@@ -1158,11 +1159,30 @@ int ensure_near_table(kc_dwa *c, double x, double y) {
   na.W = na.H = N;
   na.out = c->d_near.p;
   KC_TRY(c->timing.start("segment_near_kernel", c->stream));
-  hipLaunchKernelGGL(segment_near_kernel, dim3((N * N + kSegNearBlock / 8 - 1) / (kSegNearBlock / 8)),
-                     dim3(kSegNearBlock), 0, c->stream, na);
+  {
+    const dim3 grid((N * N + kSegNearBlock / kSegNearLanes - 1) / (kSegNearBlock / kSegNearLanes));
+    const size_t lds = 32 * static_cast<size_t>(seg_pairs_padded(na.nch, na.chunk));
+    if (lds <= kSegNearLdsMax && lds <= c->lds_limit_hw)
+      hipLaunchKernelGGL(segment_near_kernel<true>, grid, dim3(kSegNearBlock), lds, c->stream, na);
+    else
+      hipLaunchKernelGGL(segment_near_kernel<false>, grid, dim3(kSegNearBlock), 0, c->stream, na);
+  }
   KC_TRY(c->timing.stop(c->stream));
   c->near_version = c->seg_version;
   c->near_ok = true;
+  return KC_OK;
+}
+
+// A new tracked segment while the cycles use the table: build the next one now, around the last start
+// pose with room for the robot to have moved, so that the kernel runs under the host's preparation of
+// the next cycle and under that cycle's launch latency instead of in front of its kernel.  The cycle
+// keeps it when its reachable box lies inside (ensure_near_table), else builds its own.
+int near_table_ahead(kc_dwa *c) {
+  if (!c->near_wanted || c->P < 2) return KC_OK;
+  const double reach = cycle_reach(c);
+  KC_TRY(ensure_near_table(c, c->last_start.x, c->last_start.y, std::max(0.1 * reach, 0.25)));
+  if (c->near_ok) c->seg_busy = true;  // a queued kernel reads the segment table: the next host write waits
+  c->near_ok = false;                  // (the cycle decides)
   return KC_OK;
 }
 
@@ -1263,7 +1283,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   if (c->cost_kernel_force == 2) use_block = false;
   // the wavefront-per-sample search of a roll-out's samples goes through the near table
   c->near_ok = false;
-  if (!use_block && !c->external) KC_TRY(ensure_near_table(c, c->last_start.x, c->last_start.y));
+  c->near_wanted = !use_block && !c->external;
+  if (c->near_wanted) KC_TRY(ensure_near_table(c, c->last_start.x, c->last_start.y));
   CostArgs ca{};
   DcArgs dt{};
   KC_TRY(build_cost_args(c, n, first, ca, dt));
@@ -2324,6 +2345,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   KC_TRY(upload_table(c, c->d_seg.p, h, seg_words * sizeof(float)));
   if (!c->trig_direct) c->update_busy = true;
   bar_flush(c);
+  KC_TRY(near_table_ahead(c));
   return KC_OK;
 }
 
@@ -2412,6 +2434,7 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
   hipLaunchKernelGGL(segment_window_kernel, dim3(1), dim3(kSegWinBlock), 0, c->stream, a);
   KC_TRY(c->timing.stop(c->stream));
   KC_HIP(hipGetLastError());
+  KC_TRY(near_table_ahead(c));  // (in stream order behind the kernel that writes the table)
   c->seg_busy = true;  // a queued kernel writes d_seg: host stores into the table wait for the stream
   return KC_OK;
 }
@@ -2541,7 +2564,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
     // workgroups with more than a handful of survivors search wavefront-per-sample: through the
     // near table when the last cycle had that many
     c->near_ok = false;
-    if (c->last_nadm < 0 || c->last_nadm > 2ll * cyc_G) KC_TRY(ensure_near_table(c, start->x, start->y));
+    c->near_wanted = c->last_nadm < 0 || c->last_nadm > 2ll * cyc_G;
+    if (c->near_wanted) KC_TRY(ensure_near_table(c, start->x, start->y));
     KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
   }
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS

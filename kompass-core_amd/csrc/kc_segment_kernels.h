@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
 // cell diagonal + the slack of the kernels' float cell arithmetic).  For a
 // point p of the cell the seed is at most m + h away, and every point of a
 // chunk outside the range is farther than (m + 2 h) - h from p: the range
-// holds p's nearest point and every tie.  Eight lanes per cell (chunk k belongs
-// to lane k mod 8), the tables read from LDS.
+// holds p's nearest point and every tie.  Sixteen lanes per cell (chunk k belongs
+// to lane k mod 16), the tables read from LDS.
 // ---------------------------------------------------------------------------
 struct SegNearArgs {
   const float *seg;     // d_seg: rows [5][S], capsule records from seg_cap_offset(S)
@@ -162,48 +162,50 @@ struct SegNearArgs {
   int W, H;
   uint32_t *out;
 };
-constexpr int kSegNearBlock = 512;  // 64 cells per workgroup
+constexpr int kSegNearBlock = 512;  // 32 cells per workgroup
+constexpr int kSegNearLanes = 8;     // lanes per cell (16 = a DPP row: no faster)
+constexpr size_t kSegNearLdsMax = 60 * 1024;  // pair records of the segment in LDS up to here (S < ~3800)
 
+// kLds: the segment's pair records (struct SegPairs) are staged in dynamic LDS -- one global round
+// trip per workgroup instead of one per scanned point (a lane's scan of a chunk is a dependent chain:
+// 13 us per table from global memory, 3 from LDS)
+template <bool kLds>
 __global__ __launch_bounds__(kSegNearBlock) void segment_near_kernel(SegNearArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
   __shared__ __align__(16) float l_cap[8 * 64];
-  __shared__ float4 l_head[64];
   const int S = a.S, nch = a.nch;
-  const float *sx = a.seg, *sy = a.seg + S, *szz = a.seg + 3 * S;
+  const float *sx = a.seg, *sy = a.seg + S, *szz = a.seg + 3 * S, *sacc = a.seg + 4 * S;
   const float *gcap = a.seg + seg_cap_offset(S);
   for (int j = threadIdx.x; j < 8 * nch; j += kSegNearBlock) l_cap[j] = gcap[j];
-  for (int k = threadIdx.x; k < nch; k += kSegNearBlock) {
-    const int j = k * a.chunk;
-    l_head[k] = make_float4(sx[j], sy[j], szz[j], 0.0f);
+  const int npp = seg_pairs_padded(nch, a.chunk);
+  float4 *l_xy = reinterpret_cast<float4 *>(smem);
+  float4 *l_za = l_xy + npp;
+  if (kLds) {
+    for (int k = threadIdx.x; k < npp; k += kSegNearBlock) seg_pair_from_rows(sx, sy, szz, sacc, S, k, l_xy[k], l_za[k]);
   }
   __syncthreads();
-  const int sub = threadIdx.x & 7;
-  const int cell = blockIdx.x * (kSegNearBlock / 8) + (threadIdx.x >> 3);
+  constexpr int kL = kSegNearLanes, kPer = 64 / kL;  // chunks per lane (<= 64 chunks)
+  const int sub = threadIdx.x & (kL - 1);
+  const int cell = blockIdx.x * (kSegNearBlock / kL) + threadIdx.x / kL;
   const int ncell = a.W * a.H;
   const int cc = min(cell, ncell - 1);  // whole groups stay in step (DPP reductions)
   const int ix = cc % a.W, iy = cc / a.W;
   const float x = a.x0 + (static_cast<float>(ix) + 0.5f) * a.g;
   const float y = a.y0 + (static_cast<float>(iy) + 0.5f) * a.g;
   const bool flat = a.flat != 0;
-  auto d2_of = [&](float qx, float qy, float qzz) {
-    const float dx = qx - x, dy = qy - y;
-    return dx * dx + (dy * dy + qzz);
+  // squared distances of the cell centre to the two points of pair k (the cost kernels' expression)
+  auto pair_of = [&](int k) {
+    if (kLds) return pair_d2(SegPairs{l_xy, l_za}, k, x, y, flat);
+    return pair_d2(SegRows{sx, sy, szz, sacc, S}, k, x, y, flat);
   };
-  // (1) upper bound of m: the chunk heads
+  // (1) one pass over this lane's chunks: lower bound of the chunk (the kernels' capsule test, solved for
+  // the threshold) and the distance to its head (the chord's first end: |q|^2 of the same computation) --
+  // the smallest head distance is an upper bound of m
+  float lb[kPer];
   uint32_t ub = 0x7F7FFFFFu;
-  for (int k = sub; k < nch; k += 8) {
-    const float4 q = l_head[k];
-    ub = min(ub, __float_as_uint(d2_of(q.x, q.y, q.z)));  // NaN / inf bits never win
-  }
-  ub = group_min_u32<8>(ub);
-  const float uthr = __builtin_sqrtf(__uint_as_float(ub)) * 1.0001f;
-  // (2) lower bound of every chunk of this lane (the kernels' capsule test, solved for the
-  // threshold); chunks that may hold something as close as the bound are scanned: exact m
-  float lb[8];
-  uint32_t mb = ub;
-  uint32_t jb = 0xFFFFFFFFu;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int k = sub + 8 * u;
+  for (int u = 0; u < kPer; ++u) {
+    const int k = sub + kL * u;
     lb[u] = __builtin_inff();
     if (k < nch) {
       const Capsule cp = load_capsule(l_cap, k);
@@ -213,34 +215,61 @@ __global__ __launch_bounds__(kSegNearBlock) void segment_near_kernel(SegNearArgs
       float v = __builtin_sqrtf(d2) * 0.9999f - cp.eps - 4e-7f * mag;
       if (!(v == v)) v = -__builtin_inff();  // NaN: always a candidate
       lb[u] = v;
-      if (v <= uthr) {
-        const int j0 = k * a.chunk, j1 = min(j0 + a.chunk, S);
-        for (int j = j0; j < j1; ++j) {
-          const uint32_t b = __float_as_uint(d2_of(sx[j], sy[j], szz[j]));
-          if (b < mb || (b == mb && static_cast<uint32_t>(j) < jb)) {
-            mb = b;
-            jb = static_cast<uint32_t>(j);
-          }
-        }
+      ub = min(ub, __float_as_uint(pair_of((k * a.chunk) >> 1).x));  // NaN / inf bits never win
+    }
+  }
+  ub = group_min_u32<kL>(ub);
+  const float uthr = __builtin_sqrtf(__uint_as_float(ub)) * 1.0001f;
+  // (2) chunks that may hold something as close as that bound are scanned by the whole group, one
+  // pair per lane and step: exact m and a point that attains it
+  uint32_t qlo = 0u, qhi = 0u;
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int k = sub + kL * u;
+    if (k < nch && lb[u] <= uthr) {
+      if (k < 32) qlo |= 1u << k;
+      else qhi |= 1u << (k - 32);
+    }
+  }
+  qlo = group_or_u32<kL>(qlo);
+  qhi = group_or_u32<kL>(qhi);
+  uint32_t mb = ub;
+  uint32_t jb = 0xFFFFFFFFu;
+  const int hp = a.chunk >> 1;
+  for (unsigned long long q = (static_cast<unsigned long long>(qhi) << 32) | qlo; q;) {  // uniform in the group
+    const int k = __ffsll(static_cast<long long>(q)) - 1;
+    q &= q - 1ull;
+    const int k0 = k * hp;
+    for (int kk = k0 + sub; kk < k0 + hp && 2 * kk < S; kk += kL) {
+      const f32x2 d = pair_of(kk);
+      const uint32_t b0 = __float_as_uint(d.x), b1 = __float_as_uint(d.y);
+      const uint32_t j0 = static_cast<uint32_t>(2 * kk), j1 = static_cast<uint32_t>(min(2 * kk + 1, S - 1));
+      if (b0 < mb || (b0 == mb && j0 < jb)) {
+        mb = b0;
+        jb = j0;
+      }
+      if (b1 < mb || (b1 == mb && j1 < jb)) {
+        mb = b1;
+        jb = j1;
       }
     }
   }
-  const uint32_t mg = group_min_u32<8>(mb);
-  const uint32_t jg = group_min_u32<8>(mb == mg ? jb : 0xFFFFFFFFu);
+  const uint32_t mg = group_min_u32<kL>(mb);
+  const uint32_t jg = group_min_u32<kL>(mb == mg ? jb : 0xFFFFFFFFu);
   // (3) the chunks within m + 2 h
   const float h = a.g * 0.70710679f * 1.0001f + a.slack;
   const float R = __builtin_sqrtf(__uint_as_float(mg)) * 1.0001f + 2.0f * h;  // +inf when nothing is finite
   uint32_t lo = 0xFFu, hi_inv = 0xFFu;  // hi tracked as 255 - k (a minimum again)
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int k = sub + 8 * u;
+  for (int u = 0; u < kPer; ++u) {
+    const int k = sub + kL * u;
     if (k < nch && lb[u] <= R) {
       lo = min(lo, static_cast<uint32_t>(k));
       hi_inv = min(hi_inv, static_cast<uint32_t>(255 - k));
     }
   }
-  lo = group_min_u32<8>(lo);
-  hi_inv = group_min_u32<8>(hi_inv);
+  lo = group_min_u32<kL>(lo);
+  hi_inv = group_min_u32<kL>(hi_inv);
   if (sub == 0 && cell < ncell) {
     uint32_t clo = lo, chi = 255u - hi_inv;
     if (lo == 0xFFu) {  // cannot happen (the chunk of j* is always in); never trust a table that says "nothing"

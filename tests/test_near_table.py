@@ -36,6 +36,7 @@ def _segments():
     out = {}
     for S in (2, 3, 17, 33, 500, 1001):
         out[f"straight{S}"] = syn.straight_segment(S, 0.013)
+    out["straight5000"] = syn.straight_segment(5000, 0.003)   # pair records beyond the table builder's LDS: rows from global memory
     xyz, acc = syn.arc_segment(1300, 6.0, 0.012)      # chunk 21 -> 22 points
     out["arc1300"] = (xyz, acc)
     xyz, acc = syn.arc_segment(777, 2.5, 0.01)        # tight arc: the robot sits near the centre of curvature
