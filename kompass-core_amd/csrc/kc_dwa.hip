@@ -108,6 +108,9 @@ struct kc_dwa {
   bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
   bool cost_lds_ok = false;             // sample_cost_kernel<true> may take kCostLdsBudget
   int fused_samples = 32, fused_block = 1024;
+  int cycle_samples = 32;  // samples per workgroup of the single-launch cycle: 16 when 32 would leave half the CUs idle
+  int perm_cs = 0;         // ... the dealt order on the device was built for
+  int cycle_samples_opt = 0;  // option "cycle_samples": 0 auto, 16, 32
   bool fused_shape_fixed = false;  // KC_FUSED_CFG given: no per-lattice choice of the roll-out tile
   bool have_sensor = false;
 
@@ -966,22 +969,25 @@ int build_perm(kc_dwa *c) {
       ++R;
       i = j;
     }
-    rect = rect && R * L == n && R % 8 == 0 && L % 4 == 0;
+    const size_t cs = static_cast<size_t>(c->cycle_samples);  // 32: 8 rows x 4 samples, 16: 4 x 4
+    const size_t rows_per = cs / 4;
+    rect = rect && R * L == n && R % rows_per == 0 && L % 4 == 0;
     if (rect) {
-      const size_t A = R / 8, B = L / 4;
+      const size_t A = R / rows_per, B = L / 4;
       for (size_t a = 0; a < A; ++a)
         for (size_t b = 0; b < B; ++b)
-          for (size_t i = 0; i < 8; ++i)
+          for (size_t i = 0; i < rows_per; ++i)
             for (size_t k = 0; k < 4; ++k) dealt.push_back(c->h_perm[(a + A * i) * L + b + B * k]);
     } else {
-      const size_t G = (n + 31) / 32;
+      const size_t G = (n + cs - 1) / cs;
       for (size_t g = 0; g < G; ++g)
-        for (size_t j = 0; j < 32; ++j) {
+        for (size_t j = 0; j < cs; ++j) {
           const size_t e = j * G + (g + 37 * j) % G;
           if (e < n) dealt.push_back(c->h_perm[e]);
         }
     }
   }
+  c->perm_cs = c->cycle_samples;
   std::vector<int32_t> prow(n);
   for (int pass = 0; pass < 2; ++pass) {
     const std::vector<int32_t> &order = pass == 0 ? c->h_perm : dealt;
@@ -1446,19 +1452,20 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
     for (unsigned g = 0; g < G; ++g) {
       const uint32_t m = static_cast<uint32_t>(static_cast<unsigned long long>(c->h_slots.p[4 * g + 1]) & 0xFFFFFFFFull);
       if (!m) continue;
-      const size_t base = static_cast<size_t>(g) * 32;
+      const size_t cs = static_cast<size_t>(c->perm_cs);
+      const size_t base = static_cast<size_t>(g) * cs;
       uint32_t below = 0u;
 #if defined(__SSE2__)
-      if (base + 32 <= nd) {
+      if (base + cs <= nd) {
         const __m128i vl = _mm_set1_epi32(lim);
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < static_cast<int>(cs / 4); ++q) {
           const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(ids + base + 4 * q));
           below |= static_cast<uint32_t>(_mm_movemask_ps(_mm_castsi128_ps(_mm_cmplt_epi32(v, vl)))) << (4 * q);
         }
       } else
 #endif
       {
-        for (size_t s = 0; s < 32 && base + s < nd; ++s)
+        for (size_t s = 0; s < cs && base + s < nd; ++s)
           if (ids[base + s] < lim) below |= 1u << s;
       }
       cnt += __builtin_popcount(m & below);
@@ -1662,6 +1669,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<32, 1024>));
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<64, 1024>));
     optin(reinterpret_cast<const void *>(rollout_collide_kernel<32, 1024, CycleTail>));
+    optin(reinterpret_cast<const void *>(rollout_collide_kernel<16, 1024, CycleTail>));
     if (ok) c->lds_limit = 150 * 1024;
     c->lds_limit_hw = c->lds_limit;
     c->cost_lds_ok =
@@ -1908,6 +1916,9 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     c->no_dc = v == 0.0;
     if (!c->no_dc) c->dc_side = static_cast<int>(v);
     c->have_dc = false;  // built by the next sensor update
+  } else if (n == "cycle_samples") {
+    if (!(v == 0.0 || v == 16.0 || v == 32.0)) KC_FAIL(KC_ERR_RANGE, "cycle_samples: 0 (by shard size), 16 or 32");
+    c->cycle_samples_opt = static_cast<int>(v);
   } else if (n == "near_table") {
     if (v != 0.0 && !(v >= 16.0 && v <= 512.0)) KC_FAIL(KC_ERR_RANGE, "near_table: 0 (off) or 16..512 cells per side");
     c->near_side = static_cast<int>(v);
@@ -1935,6 +1946,8 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "cost_dc_cells") *v = c->no_dc ? 0.0 : c->dc_side;
   else if (n == "lazy_dilate") *v = c->lazy_dilate;
   else if (n == "near_table") *v = c->near_side;
+  else if (n == "cycle_samples") *v = c->cycle_samples_opt;
+  else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "sensor_on_host") *v = !c->device_sensor;
   else if (n == "trig_copy") *v = !c->trig_direct;
@@ -2554,7 +2567,13 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   // And a small shard with many survivors (cfg1: 128 samples in 4 workgroups, 104 admissible) is
   // better served by the stand-alone cost kernels, which spread the survivors over all CUs; the
   // admissible count of the previous cycle is the predictor (as for the choice of cost kernel).
-  const unsigned cyc_G = blocks_for(n, 32);
+  // 32 samples per workgroup; 16 when that would leave half of the CUs without one (a 4096-sample
+  // shard -- cfg3 split over 8 GPUs -- or any mid-size lattice): twice the workgroups, half the poses
+  // and survivors in each.  (Option "cycle_samples": 0 = this rule, 16 / 32 = fixed.)
+  int cs = c->cycle_samples_opt;
+  if (cs == 0) cs = 2 * blocks_for(n, 32) <= static_cast<unsigned>(c->num_cus) ? 16 : 32;
+  c->cycle_samples = cs;
+  const unsigned cyc_G = blocks_for(n, static_cast<unsigned>(cs));
   const bool cyc_wave = cyc_G <= static_cast<unsigned>(c->num_cus);
   const bool cyc_few = c->last_nadm < 0 || c->last_nadm <= 4ll * cyc_G;
   const bool cyc_full = 2 * cyc_G >= static_cast<unsigned>(c->num_cus);
@@ -2574,7 +2593,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   // recurrence of each other, 80 -> 45 us; P = 100 or one resident round: 1024 is better, tools/fused_cfg_sweep.sh)
   int plain_fb = c->fused_block;
   if (!c->fused_shape_fixed && P <= 64 && blocks_for(n, 32) > 4u * static_cast<unsigned>(c->num_cus)) plain_fb = 512;
-  const int fs = cycle ? 32 : c->fused_samples, fb = cycle ? 1024 : plain_fb;
+  const int fs = cycle ? cs : c->fused_samples, fb = cycle ? 1024 : plain_fb;
   const size_t pos_bytes = static_cast<size_t>(fs) * (P | 1) * sizeof(double2);
   size_t bits_bytes =
       (a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 * (a.c.dil ? 3 : 1) : 0) +
@@ -2628,7 +2647,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
                             hipMemcpyHostToDevice, s));
   }
   if (fused) {
-    if (!c->perm_valid || c->perm_first != c->shard_first || c->perm_count != c->shard_count)
+    if (!c->perm_valid || c->perm_first != c->shard_first || c->perm_count != c->shard_count ||
+        (cycle && c->perm_cs != cs))
       KC_TRY(build_perm(c));
     a.perm = cycle ? c->d_cperm.p : c->d_perm.p;
     a.prow = cycle ? c->d_cprow.p : c->d_prow.p;
@@ -2681,7 +2701,10 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
     const dim3 grid(blocks_for(n, fs)), block(fb);
     const size_t smem = pos_bytes + bits_bytes;
     const NoTail nt{};
-    if (cycle)
+    if (cycle && cs == 16)
+      hipLaunchKernelGGL((rollout_collide_kernel<16, 1024, CycleTail>), grid, block,
+                         tab_off + cycle_table_bytes(tail.c), s, a, tail);
+    else if (cycle)
       hipLaunchKernelGGL((rollout_collide_kernel<32, 1024, CycleTail>), grid, block,
                          tab_off + cycle_table_bytes(tail.c), s, a, tail);
     else if (fs == 16 && fb == 256) hipLaunchKernelGGL((rollout_collide_kernel<16, 256>), grid, block, smem, s, a, nt);

@@ -84,7 +84,8 @@ def test_many_cycles_moving_pose_both_paths_agree():
     one.close(); three.close(); tick.close()
 
 
-@pytest.mark.parametrize("opts", [dict(fused_cycle=2), dict(host_reduce=0), dict(cost_kernel=1), dict(cost_kernel=2), dict(force_split=1), dict(trig_copy=1),
+@pytest.mark.parametrize("opts", [dict(fused_cycle=2), dict(fused_cycle=2, cycle_samples=16), dict(fused_cycle=2, cycle_samples=32),
+                                  dict(fused_cycle=2, cycle_samples=16, host_reduce=0), dict(near_table=0, fused_cycle=2), dict(host_reduce=0), dict(cost_kernel=1), dict(cost_kernel=2), dict(force_split=1), dict(trig_copy=1),
                                   dict(early_launch=0), dict(sensor_on_host=1), dict(lazy_dilate=0),
                                   dict(cost_dc_cells=64), dict(fused_cycle=0, cost_kernel=2, cost_dc_cells=128)],
                          ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
