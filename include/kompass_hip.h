@@ -138,6 +138,14 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        resident wave of workgroups (<= 32 samples x CUs) and either fills
  *                        half the CUs or left few survivors last cycle; 2: whenever the
  *                        tables fit; 0: roll-out, cost and publish kernels
+ *   "cycle_samples"  (0) samples per workgroup of the single-launch cycle: 0 = 32, or 16 when
+ *                        32 would give at most half of the CUs a workgroup (shards <= 4096
+ *                        samples on an MI355X); 16 / 32: fixed
+ *   "near_table"   (128) cells per side (16..512) of the near table of the tracked segment
+ *                        (per cell of a grid over the reachable box: the chunk range that can
+ *                        hold a point's nearest segment point + a seed), built when the
+ *                        wavefront-per-sample cost search is expected to run; 0: off (the
+ *                        chunk hierarchy alone).  Same minimum, same index, same bits
  *   "host_reduce"    (1) single-GPU single-launch cycles end without a device-side reduction:
  *                        every workgroup posts a 32-byte slot to pinned memory, the host
  *                        reduces them in kc_dwa_fetch_result; 0: arrival ticket + last
@@ -154,7 +162,8 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host
  *   "trig_copy"      (0) trig table through pinned memory + H2D copy instead of BAR stores
  *   "force_split"    (0) roll-out, collision and compaction as separate kernels
- * kc_dwa_get_option also reads "last_cycle_single_launch" and "host_threads".
+ * kc_dwa_get_option also reads "last_cycle_single_launch", "last_cycle_samples" and
+ * "host_threads".
  * Waits for the context's stream.  Process-wide defaults may be preset with the
  * environment variables listed in DESIGN.md (test hooks). */
 int kc_dwa_set_option(kc_dwa *ctx, const char *name, double value);

@@ -1712,7 +1712,10 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
         (void)hipGetLastError();
     }
     if (const char *e = std::getenv("KC_FUSED_CYCLE"))
-      if (e[0] == '0') c->cycle_fused = false;  // process default; option "fused_cycle" per context
+      {  // process default; option "fused_cycle" per context
+        if (e[0] == '0') c->cycle_fused = false;
+        if (e[0] == '2') c->cycle_forced = true;
+      }
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
