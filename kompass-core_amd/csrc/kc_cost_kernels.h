@@ -1083,7 +1083,17 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
             int end = inner ? cells[row * b.W + max(cx - pm, x0)]
                             : cells[row * b.W + x1 + 1];
             for (int pass = 0; pass < 2; ++pass) {
-              for (int jb = beg; jb < end; jb += 4) {
+              // (a run of a thinned scene holds one or two obstacles: a first batch of two, fours behind it)
+              if (beg < end) {
+                const int j1 = min(beg + 1, end - 1);
+                const float ox0 = obx[beg], oy0 = oby[beg], ox1 = obx[j1], oy1 = oby[j1];
+                const double dx0 = static_cast<double>(ox0 - x), dy0 = static_cast<double>(oy0 - y);
+                const double dx1 = static_cast<double>(ox1 - x), dy1 = static_cast<double>(oy1 - y);
+                const double d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
+                best = __builtin_fmin(d0, best);  // (NaN distances never win either way)
+                best = __builtin_fmin(d1, best);
+              }
+              for (int jb = beg + 2; jb < end; jb += 4) {
                 float ox[4], oy[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1096,7 +1106,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
                   const double dx = static_cast<double>(ox[u] - x);
                   const double dy = static_cast<double>(oy[u] - y);
                   const double dd = dx * dx + dy * dy;
-                  best = dd < best ? dd : best;
+                  best = __builtin_fmin(dd, best);
                 }
               }
               if (!inner) break;
