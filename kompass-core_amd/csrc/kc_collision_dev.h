@@ -86,7 +86,7 @@ struct RollArgs {
 // ===========================================================================
 template <typename BitsPtr>
 __device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
-                                          double x, double y) {
+                                          double x, double y, int row0 = 0, int row_step = 1) {
   const double dx = x - c.tx, dy = y - c.ty;
   const double xf = c.r00 * dx + c.r10 * dy;
   const double yf = c.r01 * dx + c.r11 * dy;
@@ -99,7 +99,9 @@ __device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
   cy0 = max(cy0, 0);
   cx1 = min(cx1, c.W - 1);
   cy1 = min(cy1, c.H - 1);
-  for (int cy = cy0; cy <= cy1; ++cy) {
+  // (row0, row_step: the rows of the window can be shared out among several lanes; a hit is a hit
+  // whoever finds it)
+  for (int cy = cy0 + row0; cy <= cy1; cy += row_step) {
     const int ky = c.ky0 + cy;
     const double ylo = static_cast<double>(ky) * c.res;
     const double yhi = static_cast<double>(ky + 1) * c.res;
@@ -136,7 +138,7 @@ __device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
 template <typename BitsPtr>
 __device__ __forceinline__ bool hit_box(const CollDev &c, BitsPtr bits,
                                         double x, double y, double cw,
-                                        double sw) {
+                                        double sw, int row0 = 0, int row_step = 1) {
   const double dx = x - c.tx, dy = y - c.ty;
   const double xf = c.r00 * dx + c.r10 * dy;
   const double yf = c.r01 * dx + c.r11 * dy;
@@ -156,7 +158,7 @@ __device__ __forceinline__ bool hit_box(const CollDev &c, BitsPtr bits,
   const double h = c.res / 2.0;
   const double hu = h * (fabs(ux) + fabs(uy));
   const double hv = h * (fabs(vx) + fabs(vy));
-  for (int cy = cy0; cy <= cy1; ++cy) {
+  for (int cy = cy0 + row0; cy <= cy1; cy += row_step) {
     const int ky = c.ky0 + cy;
     const double qy = (static_cast<double>(ky) + 0.5) * c.res - yf;
     for (int wbase = cx0 & ~31; wbase <= cx1; wbase += 32) {

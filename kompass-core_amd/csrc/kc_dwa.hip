@@ -1765,7 +1765,7 @@ void kc_dwa_destroy(kc_dwa *c) {
     e = hipMemcpy(h.data(), c->d_dbg2.p, h.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 512; ++b) if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
-    const char *nm[15] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "flags out", "increments done", "costs done", "epilogue done", "pass 0 searched", "pass 0 barrier", "pass 0 total", "ticket taken", "last: reduced"};
+    const char *nm[15] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "flags out", "increments done", "costs done", "epilogue done", "pass 0 searched", "pass 0 barrier", "pass 0 total", "poses classified / ticket", "last: reduced"};
     std::fprintf(stderr, "[kc stamps] roll-out kernel, us since first block start (avg / max):\n");
     for (int k = 0; k < 15; ++k) {
       double sm = 0, mx = 0; int nb = 0;
@@ -1775,6 +1775,14 @@ void kc_dwa_destroy(kc_dwa *c) {
         sm += us; mx = std::max(mx, us); ++nb;
       }
       std::fprintf(stderr, "  %-18s %7.2f / %7.2f  (%d blocks)\n", nm[k], nb ? sm / nb : 0.0, mx, nb);
+    }
+    {
+      double sm = 0, mx = 0; int nb = 0;
+      for (int b = 0; b < 512; ++b) {
+        if (!h[b * 16]) continue;
+        sm += static_cast<double>(h[b * 16 + 15]); mx = std::max(mx, static_cast<double>(h[b * 16 + 15])); ++nb;
+      }
+      std::fprintf(stderr, "  undecided poses per workgroup (exact shell tests): %.1f / %.0f\n", nb ? sm / nb : 0.0, mx);
     }
   }
   if (c->debug_stamps && c->d_dbg.p) {  // diagnostic dump of the last cycle

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   uint32_t *louter = linner + (a.c.dil ? nwin : 0);
   int *lcand = reinterpret_cast<int *>(louter + (a.c.dil ? nwin : 0));  // [samples * P]
   uint32_t *lhalo = reinterpret_cast<uint32_t *>(lcand + kFusedSamples * a.P);  // a.c.dil == 2 only
-  __shared__ int ncand;
+  __shared__ int ncand, ncand2;
   __shared__ int lhit[kFusedSamples];
   __shared__ int lperm[kFusedSamples];  // local sample id of slot s
   __shared__ int lrow[kFusedSamples];   // its trig row
@@ -298,7 +298,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   }
   if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, tabregs);
-  if (tid == 0) ncand = 0;
+  if (tid == 0) {
+    ncand = 0;
+    ncand2 = 0;
+  }
   KC_RSTAMP(1);
   if (a.trig_flag) {
     // wait for the host's table (system-scope loads: the word and the table
@@ -403,55 +406,106 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   // ---- C: float rows out; poses classified with the dilated masks, the
   // undecided ones queued and tested exactly by densely packed lanes ----------
   {
-    const int total = rows * a.P;
-    int s = 0, k = tid;
-    while (k >= a.P) {
-      k -= a.P;
-      ++s;
-    }
-    for (int i = tid; i < total; i += kFusedBlock) {
+    bool store_row = true;
+    if constexpr (kCycle) store_row = tail.write_paths != 0;
+    // one pose: float row out (when rows are kept), cell of the dilated masks, queue
+    auto classify = [&](int s, int k) {
       double2 p;
       if (k == 0) p = make_double2(a.x0, a.y0);
       else p = lpos[s * PP + k - 1];
-      bool store_row = true;
-      if constexpr (kCycle) store_row = tail.write_paths != 0;
       if (store_row) {
         const size_t o = (size_t)lperm[s] * a.P + k;  // sample-major rows
         a.px[o] = static_cast<float>(p.x);
         a.py[o] = static_cast<float>(p.y);
       }
-      if (a.c.enabled && k > 0) {
-        bool exact = true;
-        if (a.c.dil) {
-          const double dx = p.x - a.c.tx, dy = p.y - a.c.ty;
-          const double xf = a.c.r00 * dx + a.c.r10 * dy;
-          const double yf = a.c.r01 * dx + a.c.r11 * dy;
-          const int cx = static_cast<int>(floor(xf * a.c.inv)) - a.c.kx0;
-          const int cy = static_cast<int>(floor(yf * a.c.inv)) - a.c.ky0;
-          if (cx >= 0 && cx < a.c.W && cy >= 0 && cy < a.c.H) {
-            const int w = cy * a.c.wpr + (cx >> 5);
-            const uint32_t bit = 1u << (cx & 31);
-            if (linner[w] & bit) {
-              lhit[s] = 1;  // every writer stores the same value
-              exact = false;
-            } else if (!(louter[w] & bit)) {
-              exact = false;
-            }
+      bool exact = a.c.enabled && k > 0;
+      if (exact && a.c.dil) {
+        const double dx = p.x - a.c.tx, dy = p.y - a.c.ty;
+        const double xf = a.c.r00 * dx + a.c.r10 * dy;
+        const double yf = a.c.r01 * dx + a.c.r11 * dy;
+        const int cx = static_cast<int>(floor(xf * a.c.inv)) - a.c.kx0;
+        const int cy = static_cast<int>(floor(yf * a.c.inv)) - a.c.ky0;
+        if (cx >= 0 && cx < a.c.W && cy >= 0 && cy < a.c.H) {
+          const int w = cy * a.c.wpr + (cx >> 5);
+          const uint32_t bit = 1u << (cx & 31);
+          if (linner[w] & bit) {
+            lhit[s] = 1;  // every writer stores the same value
+            exact = false;
+          } else if (!(louter[w] & bit)) {
+            exact = false;
           }
         }
-        if (exact) lcand[atomicAdd(&ncand, 1)] = (s << 16) | k;
       }
-      k += kFusedBlock;
-      while (k >= a.P) {
-        k -= a.P;
-        ++s;
+      // queue slots: one LDS atomic per wavefront (hundreds of undecided poses per workgroup in clutter)
+      const unsigned long long bal = __ballot(exact);
+      if (bal) {
+        const int lane = tid & 63;
+        int base = 0;
+        if (lane == __ffsll(static_cast<long long>(bal)) - 1) base = atomicAdd(&ncand, __popcll(bal));
+        base = __shfl(base, __ffsll(static_cast<long long>(bal)) - 1, 64);
+        if (exact) lcand[base + __popcll(bal & ((1ull << lane) - 1ull))] = (s << 16) | k;
+      }
+    };
+    if (!store_row) {
+      // sample = low bits of the thread id, poses strided: no division, and the LDS reads of a
+      // wavefront go to different samples' rows (odd pitch: conflict free)
+      const int s = tid % kFusedSamples;
+      if (s < rows)
+        for (int k = tid / kFusedSamples; k < a.P; k += kFusedBlock / kFusedSamples) classify(s, k);
+    } else {
+      // rows are written: consecutive threads take consecutive poses of a sample (coalesced stores)
+      const int total = rows * a.P;
+      const float inv_p = 1.0f / static_cast<float>(a.P);
+      for (int i = tid; i < total; i += kFusedBlock) {
+        int s = min(static_cast<int>(static_cast<float>(i) * inv_p), rows - 1);
+        int k = i - s * a.P;
+        if (k < 0) {
+          --s;
+          k += a.P;
+        } else if (k >= a.P) {
+          ++s;
+          k -= a.P;
+        }
+        classify(s, k);
       }
     }
   }
   __syncthreads();
+  KC_RSTAMP(13);
   {
-    const int nc = ncand;
-    for (int i = tid; i < nc; i += kFusedBlock) {
+    int nc = ncand;
+    constexpr int kMine = 8;  // queue entries a thread holds across the barrier
+    if (nc * 8 > kFusedBlock && nc <= kMine * kFusedBlock) {
+      // A long queue is mostly poses of samples that an inner-mask hit has decided meanwhile
+      // (dense clutter): squeeze those out first, so that the live ones get several lanes each.
+      int mine[kMine];
+      int cnt = 0;
+      for (int i = tid; i < nc; i += kFusedBlock) mine[cnt++] = lcand[i];
+      __syncthreads();
+      for (int q = 0; q < cnt; ++q) {
+        const bool keep = !lhit[mine[q] >> 16];
+        const unsigned long long bal = __ballot(keep);
+        if (bal) {
+          const int lane = tid & 63, lead = __ffsll(static_cast<long long>(bal)) - 1;
+          int base = 0;
+          if (lane == lead) base = atomicAdd(&ncand2, __popcll(bal));
+          base = __shfl(base, lead, 64);
+          if (keep) lcand[base + __popcll(bal & ((1ull << lane) - 1ull))] = mine[q];
+        }
+      }
+      __syncthreads();
+      nc = ncand2;
+    }
+#ifdef KC_PHASE_STAMPS
+    if (a.dbg && tid == 0 && blockIdx.x < 512) a.dbg[(size_t)blockIdx.x * 16 + 15] = static_cast<unsigned long long>(nc);
+#endif
+    // 2, 4 or 8 lanes per undecided pose when the queue is short enough for that (the rows of the
+    // voxel window go round the lanes: each exact test is a chain of dependent LDS reads and f64
+    // arithmetic per row, and any lane's hit decides the sample)
+    int lanes_per = 1;
+    while (lanes_per < 8 && nc * lanes_per * 2 <= kFusedBlock) lanes_per *= 2;
+    const int sub = tid & (lanes_per - 1);
+    for (int i = tid / lanes_per; i < nc; i += kFusedBlock / lanes_per) {
       const int s = lcand[i] >> 16, k = lcand[i] & 0xFFFF;
       if (lhit[s]) continue;  // already decided (stale reads only cost work)
       const double2 p = lpos[s * PP + k - 1];
@@ -466,9 +520,9 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
         } else {
           t = a.trig[e];
         }
-        hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y);
+        hit = hit_box(a.c, lbits, p.x, p.y, t.x, t.y, sub, lanes_per);
       } else {
-        hit = hit_round(a.c, lbits, p.x, p.y);
+        hit = hit_round(a.c, lbits, p.x, p.y, sub, lanes_per);
       }
       if (hit) lhit[s] = 1;
     }
