@@ -199,7 +199,6 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ int lhit[kFusedSamples];
   __shared__ int lperm[kFusedSamples];  // local sample id of slot s
   __shared__ int lrow[kFusedSamples];   // its trig row
-  __shared__ double lvx[kFusedSamples], lvy[kFusedSamples];
 
   const int tid = threadIdx.x;
   const int base = blockIdx.x * kFusedSamples;
@@ -208,15 +207,12 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
 
   KC_RSTAMP(0);
   // ---- A: window bits + trig rows -----------------------------------------
-  if (tid < kFusedSamples) {
-    lhit[tid] = 0;
-    const bool in = tid < rows;
-    const int id = in ? a.perm[base + tid] : 0;
-    lperm[tid] = id;
-    lrow[tid] = in ? a.prow[base + tid] : 0;
-    lvx[tid] = in ? a.vx[a.first + id] : 0.0;   // velocities change every cycle, the order does not
-    lvy[tid] = in ? a.vy[a.first + id] : 0.0;
-    if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
+  // (the sample ids of this workgroup: loads issued here, used behind the table copies -- a wait
+  // for them in front would put wavefront 0 a memory round trip behind the others)
+  int my_id = 0, my_row = 0;
+  if (tid < rows) {
+    my_id = a.perm[base + tid];
+    my_row = a.prow[base + tid];
   }
   // Cycle: the cost tables' global loads are issued here and land in LDS at the end of the
   // phase; the window loads below are in flight at the same time.
@@ -298,6 +294,12 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   }
   if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, tabregs);
+  if (tid < kFusedSamples) {
+    lhit[tid] = 0;
+    lperm[tid] = my_id;
+    lrow[tid] = my_row;
+    if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
+  }
   if (tid == 0) {
     ncand = 0;
     ncand2 = 0;
@@ -337,43 +339,45 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       }
       return;
     }
+    // trig entries of this thread's (sample, step) pairs and the sample's velocity (read through
+    // the dealt view: velocities change every cycle, the order does not) -> increments
+    //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt   (datatypes/path.h:24-30)
+    // straight into LDS; only the additions -- whose order fixes the rounding -- run as a serial
+    // chain per sample below.
     const int s = tid & (kFusedSamples - 1);
     if (s < rows) {
       const int r = lrow[s];
+      const int id = lperm[s];
+      const double vx = a.vx[a.first + id], vy = a.vy[a.first + id];
       const double *tg = reinterpret_cast<const double *>(a.trig);
       for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
         const size_t e = ((size_t)k * a.A + r) * 2;
         const double cs = __hip_atomic_load(tg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const double sn = __hip_atomic_load(tg + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        lpos[s * PP + k] = make_double2(cs, sn);
+        const double tx = vx * cs - vy * sn;
+        const double ty = vx * sn + vy * cs;
+        lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
       }
     }
   } else {
-    __syncthreads();  // lrow
+    __syncthreads();  // lrow, lperm
     const int s = tid & (kFusedSamples - 1);
     if (s < rows) {
       const int r = lrow[s];
-      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples)
-        lpos[s * PP + k] = a.trig[(size_t)k * a.A + r];
+      const int id = lperm[s];
+      const double vx = a.vx[a.first + id], vy = a.vy[a.first + id];
+      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
+        const double2 cs = a.trig[(size_t)k * a.A + r];
+        const double tx = vx * cs.x - vy * cs.y;
+        const double ty = vx * cs.y + vy * cs.x;
+        lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
+      }
     }
   }
   __syncthreads();
   KC_RSTAMP(3);
-  // ---- B: recurrences.  Path::State::update (datatypes/path.h:24-30) is
-  //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt;
-  // the increments do not depend on the running sums, so every lane forms some
-  // of them first (in place over the trig entries), and only the additions -
-  // whose order fixes the rounding - run as a serial chain per sample.
-  for (int i = tid; i < rows * steps; i += kFusedBlock) {
-    const int s = i / steps, k = i - s * steps;
-    const double vx = lvx[s], vy = lvy[s];
-    const double2 cs = lpos[s * PP + k];
-    const double tx = vx * cs.x - vy * cs.y;
-    const double ty = vx * cs.y + vy * cs.x;
-    lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
-  }
-  __syncthreads();
   KC_RSTAMP(7);
+  // ---- B: the serial sums ------------------------------------------------------
   if (tid < rows) {
     // sixteen increments per register chunk: one LDS latency per chunk instead
     // of one per step
