@@ -157,6 +157,22 @@ struct kc_dwa {
   unsigned long long seg_version = 0, near_version = ~0ull;  // segment the table was built from
   float near_x0 = 0.f, near_y0 = 0.f, near_g = 0.f;
   bool near_ok = false;       // the table covers the running cycle
+  // KC_DEBUG_HOST=1: where the host side of a cycle goes (steady_clock marks, printed at destroy)
+  struct HostProf {
+    bool on = false;
+    std::chrono::steady_clock::time_point t[10];
+    double sum[10] = {0};
+    long n = 0;
+    void mark(int i) { if (on) t[i] = std::chrono::steady_clock::now(); }
+    long seen = 0;
+    void close() {
+      if (!on || ++seen <= 200) return;  // (the first cycles build orders and tables once)
+      for (int i = 1; i < 8; ++i) sum[i] += std::chrono::duration<double, std::micro>(t[i] - t[i - 1]).count();
+      sum[8] += std::chrono::duration<double, std::micro>(t[8] - t[0]).count();
+      sum[9] += std::chrono::duration<double, std::micro>(t[9] - t[8]).count();
+      ++n;
+    }
+  } hprof;
   bool near_wanted = false;   // the last cycle asked for the table: the next segment update builds it ahead
   // resident reference path (kc_dwa_set_path): rows x | y | z | acc on the
   // device, edge lengths on the host (the window length is an ordered float sum)
@@ -1424,6 +1440,7 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
       synced = true;
     }
   }
+  c->hprof.mark(6);
   c->slots_pending = false;
   c->drained = true;        // every workgroup is past its last table read
   c->update_busy = false;
@@ -1716,6 +1733,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
         if (e[0] == '0') c->cycle_fused = false;
         if (e[0] == '2') c->cycle_forced = true;
       }
+    if (const char *e = std::getenv("KC_DEBUG_HOST")) c->hprof.on = e[0] == '1';
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
@@ -1758,6 +1776,13 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
 
 void kc_dwa_destroy(kc_dwa *c) {
   if (!c) return;
+  if (c->hprof.on && c->hprof.n) {
+    const char *nm[8] = {"", "entry -> launch call", "launch call", "wait for the trig pool", "flag store", "back in kc_dwa_cycle", "wait for the slots", "fetch (slots + reduce + row)"};
+    std::fprintf(stderr, "[kc host] %ld single-launch cycles, us per cycle:\n", c->hprof.n);
+    for (int i = 1; i < 8; ++i) std::fprintf(stderr, "  %-28s %6.2f\n", nm[i], c->hprof.sum[i] / c->hprof.n);
+    std::fprintf(stderr, "  (of the first: entry -> pool start %.2f, starting the pool %.2f)\n", c->hprof.sum[8] / c->hprof.n,
+                 c->hprof.sum[9] / c->hprof.n);
+  }
   hipError_t e = hipSetDevice(c->prm.device);
   if (c->debug_stamps && c->d_dbg2.p) {
     std::vector<unsigned long long> h(512 * 16);
@@ -2481,7 +2506,7 @@ size_t cycle_table_bytes(const CostArgs &ca) {
 
 // kc_dwa_rollout, or -- want_cycle -- the whole cycle in one launch when the
 // cost tables fit beside the roll-out tile (c->cycle_launched tells)
-int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
+int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bool trig_ready = false) {
   if (!c || !start) KC_FAIL(KC_ERR_INVALID, "null argument");
   if (P < 2 || P > c->prm.max_points)
     KC_FAIL(KC_ERR_RANGE, "num_points %zu outside [2, %zu]", P,
@@ -2547,6 +2572,16 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
     __builtin_ia32_sfence();  // write-combined stores leave the core before "done"
 #endif
   };
+  // The workers start on the table at once (BAR path: straight into d_trig) -- before this thread
+  // has put the kernel arguments together, so that the table is complete when the kernel asks for it.
+  const bool trig_ahead = !trig_ready && c->trig_direct && c->early_launch && !c->timing.enabled;
+  struct PoolJoin {  // an error return below must not leave this call's job running
+    WorkerPool::Ticket ticket;
+    ~PoolJoin() { WorkerPool::instance().wait(ticket); }
+  } pool_join;
+  c->hprof.mark(8);
+  if (trig_ahead) pool_join.ticket = WorkerPool::instance().begin(A, 2, trig_rows);
+  c->hprof.mark(9);
   RollArgs a{};
   KC_TRY(ensure_cycle_buffers(c, n, P));
   a.n = static_cast<int>(n);
@@ -2636,22 +2671,24 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
   const size_t tab_off = (pos_bytes + bits_bytes + 15) & ~size_t(15);
   cycle = cycle && fused && tab_off + cycle_table_bytes(tail.c) + 2048 <= c->lds_limit;
   if (want_cycle && !cycle && fused && (fs != c->fused_samples || fb != plain_fb))
-    return rollout_impl(c, start, P, false);  // sized for the cycle shape: start over for the plain one
+  {
+    // sized for the cycle shape: start over for the plain one (the table this call's workers are
+    // writing stays valid: same pose, same rows)
+    const bool had = trig_ahead || trig_ready;
+    if (trig_ahead) WorkerPool::instance().wait(pool_join.ticket);
+    return rollout_impl(c, start, P, false, had);
+  }
   c->need_compact = !fused || cycle;
   // early launch: queue the fused kernel first and let launch + dispatch
   // latency run under the host's libm work (needs the BAR path for the table
   // and its sequence word; not while kernels are being timed, the wait would
   // be charged to the kernel)
-  const bool early = fused && c->trig_direct && c->early_launch && !c->timing.enabled;
-  struct PoolJoin {  // an error return below must not leave this call's job running
-    WorkerPool::Ticket ticket;
-    ~PoolJoin() { WorkerPool::instance().wait(ticket); }
-  } pool_join;
+  const bool early = fused && trig_ahead;
   if (early) {
     // the workers produce the table while this thread queues the kernel
-    pool_join.ticket = WorkerPool::instance().begin(A, 2, trig_rows);
   } else {
-    WorkerPool::instance().parallel_for(A, 2, trig_rows);
+    if (trig_ahead) WorkerPool::instance().wait(pool_join.ticket);  // (split path: the table first)
+    else if (!trig_ready) WorkerPool::instance().parallel_for(A, 2, trig_rows);
     c->timing.mark("host:trig_table");
     if (!c->trig_direct)
       KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
@@ -2708,6 +2745,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
       a.trig_seq = ++c->trig_seq;
       a.dev_err = c->d_result.p + W_NADM;
     }
+    c->hprof.mark(1);
     KC_TRY(c->timing.start(cycle ? "cycle_kernel" : "rollout_collide_kernel", s));
     const dim3 grid(blocks_for(n, fs)), block(fb);
     const size_t smem = pos_bytes + bits_bytes;
@@ -2734,8 +2772,10 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
       c->row_valid = false;
     }
     c->timing.mark("host:launch_rollout");
+    c->hprof.mark(2);
     if (early) {
       WorkerPool::instance().wait(pool_join.ticket);
+      c->hprof.mark(3);
       if (c->test_late_flag_ms > 0) {  // test hook: a host that does not deliver in time
         std::this_thread::sleep_for(std::chrono::milliseconds(c->test_late_flag_ms));
         c->test_late_flag_ms = 0;      // once
@@ -2746,6 +2786,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle) {
 #if defined(__x86_64__)
       __builtin_ia32_sfence();
 #endif
+      c->hprof.mark(4);
     }
   } else {
     // split path (sphere, very long horizons, windows beyond LDS): roll-out
@@ -2874,9 +2915,14 @@ int kc_dwa_fetch_result(kc_dwa *c, kc_result *out) {
 }
 
 int kc_dwa_cycle(kc_dwa *c, const kc_state *start, size_t P, kc_result *out) {
+  if (c) c->hprof.mark(0);
   KC_TRY(rollout_impl(c, start, P, true));
   if (!c->cycle_launched) KC_TRY(kc_dwa_evaluate(c));
-  return kc_dwa_fetch_result(c, out);
+  c->hprof.mark(5);
+  const int rc = kc_dwa_fetch_result(c, out);
+  c->hprof.mark(7);
+  c->hprof.close();
+  return rc;
 }
 
 int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
