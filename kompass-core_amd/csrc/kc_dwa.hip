@@ -1734,6 +1734,10 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
         if (e[0] == '2') c->cycle_forced = true;
       }
     if (const char *e = std::getenv("KC_DEBUG_HOST")) c->hprof.on = e[0] == '1';
+    if (const char *e = std::getenv("KC_NEAR_TABLE")) {  // process default of option "near_table"
+      const int v = std::atoi(e);
+      if (v == 0 || (v >= 16 && v <= 512)) c->near_side = v;
+    }
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
