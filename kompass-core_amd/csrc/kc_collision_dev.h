@@ -19,7 +19,12 @@ struct CollDev {
   double radius, rr;          // cylinder / sphere radius, radius^2
   double a, b;                // box half extents
   const uint32_t *bits;       // [H][wpr] occupancy bits (global)
-  const double *ddz;          // sphere only: per-cell z gap [H][W]
+  const double *ddz;          // sphere only: per-cell z gap [H][W] (split path: window built on the host)
+  // sphere on the fused path: per cell of the sensor bitmap a code (0 none, k + 1 = k-th smallest
+  // z gap of this sensor update) and the gaps themselves -- a handful of voxel layers lie within
+  // a sphere's height, so a byte per cell replaces 8; read from global memory by the exact tests only
+  const uint8_t *gz;          // [gH][gwpr * 32] or null
+  const double *zlut;         // [<= 255]
   // occupancy bits of ALL accepted voxel columns (built once per sensor
   // update); the fused kernel copies its window out of it, word aligned
   const uint32_t *gbits;      // [gH][gwpr]
@@ -124,7 +129,13 @@ __device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
         if (xf - xhi > gx) gx = xf - xhi;
         double zz = 0.0;
         if (c.shape == KC_SPHERE) {
-          const double g = c.ddz[cy * c.W + cx];
+          double g;
+          if (c.gz) {
+            const int code = c.gz[static_cast<size_t>(c.ky0 + cy - c.gky0) * (c.gwpr * 32) + (kx - c.gkx0)];
+            g = c.zlut[code - 1];  // (a set bit has a code)
+          } else {
+            g = c.ddz[cy * c.W + cx];
+          }
           zz = g * g;
         }
         const double d2 = gx * gx + gy * gy + zz;

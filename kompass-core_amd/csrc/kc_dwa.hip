@@ -73,6 +73,11 @@ struct kc_dwa {
   std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
   // occupancy bits of all accepted voxel columns over their bounding box
   PinBuf<uint32_t> h_gbits;
+  PinBuf<uint8_t> h_gz;      // sphere: z-gap code per cell of the sensor bitmap (CollDev::gz)
+  DevBuf<uint8_t> d_gz;
+  PinBuf<double> h_zlut;
+  DevBuf<double> d_zlut;
+  bool gz_valid = false;
   DevBuf<uint32_t> d_gbits;
   int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
   bool have_gbits = false;
@@ -461,6 +466,32 @@ int upload_voxels(kc_dwa *c) {
     c->h_gbits.p[static_cast<size_t>(cy) * c->gwpr + (cx >> 5)] |= 1u << (cx & 31);
   }
   KC_TRY(upload_table(c, c->d_gbits.p, c->h_gbits.p, nwords * sizeof(uint32_t)));
+  c->gz_valid = false;
+  if (c->prm.shape == KC_SPHERE) {
+    // z gaps of the accepted voxels: one value per voxel layer within the sphere's height
+    std::vector<double> lut(c->vox_ddz.begin(), c->vox_ddz.end());
+    std::sort(lut.begin(), lut.end());
+    lut.erase(std::unique(lut.begin(), lut.end()), lut.end());
+    if (lut.size() <= 255) {
+      const size_t gW = static_cast<size_t>(c->gwpr) * 32, ncell = gW * c->gH;
+      KC_TRY(c->h_gz.reserve(ncell));
+      KC_TRY(c->d_gz.reserve(ncell));
+      KC_TRY(c->h_zlut.reserve(256));
+      KC_TRY(c->d_zlut.reserve(256));
+      std::memset(c->h_gz.p, 0, ncell);
+      for (size_t i = 0; i < nv; ++i) {
+        const size_t cell = static_cast<size_t>(c->vox_ky[i] - c->gky0) * gW + (c->vox_kx[i] - c->gkx0);
+        const uint8_t code =
+            static_cast<uint8_t>(std::lower_bound(lut.begin(), lut.end(), c->vox_ddz[i]) - lut.begin() + 1);
+        uint8_t &g = c->h_gz.p[cell];
+        if (g == 0 || code < g) g = code;  // the smallest gap of the column decides
+      }
+      for (size_t k = 0; k < lut.size(); ++k) c->h_zlut.p[k] = lut[k];
+      KC_TRY(upload_table(c, c->d_gz.p, c->h_gz.p, ncell));
+      KC_TRY(upload_table(c, c->d_zlut.p, c->h_zlut.p, lut.size() * sizeof(double)));
+      c->gz_valid = true;
+    }
+  }
   if (!c->trig_direct) c->update_busy = true;
   bar_flush(c);  // the kernels behind it read the bitmap
   KC_TRY(defer_dilate(c));
@@ -1070,6 +1101,10 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
     cd.W += static_cast<int>(rel - aligned);
     cd.kx0 = static_cast<int>(c->gkx0 + aligned);
     cd.gbits = c->d_gbits.p;
+    if (c->prm.shape == KC_SPHERE && c->gz_valid) {
+      cd.gz = c->d_gz.p;
+      cd.zlut = c->d_zlut.p;
+    }
     cd.ginner = c->d_ginner.p;
     cd.gouter = c->d_gouter.p;
     cd.dil = c->have_dil ? (c->dil_lazy ? 2 : 1) : 0;
@@ -1897,6 +1932,10 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_skip.release();
   c->d_skip.release();
   c->h_gbits.release();
+  c->h_gz.release();
+  c->d_gz.release();
+  c->h_zlut.release();
+  c->d_zlut.release();
   c->d_block_keys.release();
   c->d_gbits.release();
   c->d_ginner.release();
@@ -2627,7 +2666,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   const bool cyc_wave = cyc_G <= static_cast<unsigned>(c->num_cus);
   const bool cyc_few = c->last_nadm < 0 || c->last_nadm <= 4ll * cyc_G;
   const bool cyc_full = 2 * cyc_G >= static_cast<unsigned>(c->num_cus);
-  bool cycle = want_cycle && c->cycle_fused && c->prm.shape != KC_SPHERE && n <= 1024u * kCompactMaxPer &&
+  const bool sphere_ok = c->prm.shape != KC_SPHERE || (c->have_gbits && c->gz_valid);  // (fused path)
+  bool cycle = want_cycle && c->cycle_fused && sphere_ok && n <= 1024u * kCompactMaxPer &&
                (c->cycle_forced || (cyc_wave && (cyc_few || cyc_full)));
   if (cycle) {
     // workgroups with more than a handful of survivors search wavefront-per-sample: through the
@@ -2670,7 +2710,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   } else if (c->dil_lazy && !a.c.enabled) {
     // nothing within reach this cycle: the masks are still owed to the next one
   }
-  const bool fused = c->prm.shape != KC_SPHERE && (!a.c.enabled || c->have_gbits) &&
+  const bool fused = sphere_ok && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
   const size_t tab_off = (pos_bytes + bits_bytes + 15) & ~size_t(15);
   cycle = cycle && fused && tab_off + cycle_table_bytes(tail.c) + 2048 <= c->lds_limit;

@@ -46,8 +46,7 @@ def test_single_launch_cycle_equals_three_kernel_cycle_and_oracle(k):
     tick.close()
     assert one.get_option("fused_cycle") == 2 and three.get_option("fused_cycle") == 0
     assert three.get_option("last_cycle_single_launch") == 0
-    if inp["robot"]["shape"] != syn.SPHERE:
-        assert one.get_option("last_cycle_single_launch") == 1, "cost tables must fit beside the roll-out tile here"
+    assert one.get_option("last_cycle_single_launch") == 1, "cost tables must fit beside the roll-out tile here"
     assert_cycle_equal(o, h1)
     assert_cycle_equal(o, h3)
     # the rows stored by the cycle kernel itself (write_paths) are the same rows
@@ -194,3 +193,31 @@ def test_two_threads_with_differently_configured_contexts():
         assert not errors, (opts_a, opts_b, errors)
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("zoff", [0.0, 0.12, -0.2])
+def test_sphere_on_the_single_launch_path(zoff):
+    """Spheres: the z gap of a voxel column is a byte code into a table of the few
+    voxel layers within the sphere's height, read by the exact tests of the fused kernel.  Points at
+    several heights, the sensor above / below the sphere's centre: single launch, three kernels and the
+    split path (window built on the host) against the oracle."""
+    inp = syn.make_controller_inputs("cfg2", seed=6, scale=0.25)
+    inp["robot"] = dict(shape=syn.SPHERE, dims=[0.22])
+    rng = np.random.default_rng(9)
+    pts = np.asarray(inp["points"], np.float32).copy()
+    pts[:, 2] = rng.choice([-0.31, -0.2, -0.05, 0.0, 0.07, 0.12, 0.21, 0.4], size=len(pts)).astype(np.float32)
+    inp["points"] = pts
+    spos = (0.05, -0.02, zoff)
+    o = oracle_cycle(inp, sensor_pos=spos)
+    assert 0 < len(o["raw"]) < len(inp["vx"])
+    for opts, single in ((dict(fused_cycle=2), 1), (dict(fused_cycle=0), 0), (dict(force_split=1), 0),
+                         (dict(fused_cycle=2, host_reduce=0), 1), (dict(fused_cycle=2, cycle_samples=16), 1)):
+        ctx = hip_context(kh, inp, sensor_pos=spos)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        assert_cycle_equal(o, hip_cycle(kh, inp, sensor_pos=spos, ctx=ctx))
+        assert ctx.get_option("last_cycle_single_launch") == single
+        # and again on the same context (tables resident)
+        r = ctx.cycle(inp["state"], inp["P"])
+        assert r.index == o["index"] and r.n_admissible == len(o["raw"])
+        ctx.close()
