@@ -25,6 +25,8 @@ struct CollDev {
   // a sphere's height, so a byte per cell replaces 8; read from global memory by the exact tests only
   const uint8_t *gz;          // [gH][gwpr * 32] or null
   const double *zlut;         // [<= 255]
+  double zconst;              // ... or, when every accepted voxel lies in one layer (a planar scan), its gap
+  int zmode;                  // 0: ddz (window table), 1: gz + zlut, 2: zconst
   // occupancy bits of ALL accepted voxel columns (built once per sensor
   // update); the fused kernel copies its window out of it, word aligned
   const uint32_t *gbits;      // [gH][gwpr]
@@ -130,7 +132,9 @@ __device__ __forceinline__ bool hit_round(const CollDev &c, BitsPtr bits,
         double zz = 0.0;
         if (c.shape == KC_SPHERE) {
           double g;
-          if (c.gz) {
+          if (c.zmode == 2) {
+            g = c.zconst;
+          } else if (c.zmode == 1) {
             const int code = c.gz[static_cast<size_t>(c.ky0 + cy - c.gky0) * (c.gwpr * 32) + (kx - c.gkx0)];
             g = c.zlut[code - 1];  // (a set bit has a code)
           } else {

@@ -78,6 +78,8 @@ struct kc_dwa {
   PinBuf<double> h_zlut;
   DevBuf<double> d_zlut;
   bool gz_valid = false;
+  size_t sphere_layers = 0;
+  double sphere_ddz_max = -1.0;  // largest z gap among the accepted voxels of this sensor update (< 0: unknown)
   DevBuf<uint32_t> d_gbits;
   int gkx0 = 0, gky0 = 0, gH = 0, gwpr = 0;
   bool have_gbits = false;
@@ -335,6 +337,14 @@ DilGeom dil_geom(const kc_dwa *c) {
   g.rho_in = (c->prm.shape == KC_BOX ? std::min(static_cast<double>(c->prm.dims[0]),
                                                 static_cast<double>(c->prm.dims[1])) / 2.0
                                      : c->radius) / c->res;
+  if (c->prm.shape == KC_SPHERE) {
+    // a voxel column with z gap g collides within the horizontal radius sqrt(R^2 - g^2): every column
+    // of this update does so at least within the radius of the largest gap (certain hits), and at most
+    // within R (possible hits)
+    const double gmax = c->sphere_ddz_max;
+    const double r2 = c->radius * c->radius - gmax * gmax;
+    g.rho_in = (gmax >= 0.0 && r2 > 0.0) ? std::sqrt(r2) * (1.0 - 1e-9) / c->res : -1.0;
+  }
   g.rho_out = (c->prm.shape == KC_BOX
                    ? std::sqrt(std::pow(static_cast<double>(c->prm.dims[0]) / 2.0, 2) +
                                std::pow(static_cast<double>(c->prm.dims[1]) / 2.0, 2))
@@ -348,8 +358,8 @@ DilGeom dil_geom(const kc_dwa *c) {
 // path.  Reserves the three device bitmaps.
 int bitmap_extent(kc_dwa *c, int lox, int loy, int hix, int hiy, bool *fits) {
   const DilGeom dg = dil_geom(c);
-  c->have_dil = c->prm.shape != KC_SPHERE && std::isfinite(dg.rho_out) && dg.R <= 30 &&
-                dg.rho_in >= 0.0;
+  c->have_dil = (c->prm.shape != KC_SPHERE || c->sphere_ddz_max >= 0.0) && std::isfinite(dg.rho_out) &&
+                dg.R <= 30 && (dg.rho_in >= 0.0 || c->prm.shape == KC_SPHERE);
   if (c->have_dil) {
     const int pad = dg.R + 1;
     lox -= pad;
@@ -455,6 +465,9 @@ int upload_voxels(kc_dwa *c) {
     loy = std::min(loy, c->vox_ky[i]);
     hiy = std::max(hiy, c->vox_ky[i]);
   }
+  c->sphere_ddz_max = -1.0;
+  if (c->prm.shape == KC_SPHERE && c->vox_ddz.size() == nv)
+    c->sphere_ddz_max = *std::max_element(c->vox_ddz.begin(), c->vox_ddz.end());
   bool fits = false;
   KC_TRY(bitmap_extent(c, lox, loy, hix, hiy, &fits));
   if (!fits) return KC_OK;  // too sparse/far: split path only
@@ -487,6 +500,7 @@ int upload_voxels(kc_dwa *c) {
         if (g == 0 || code < g) g = code;  // the smallest gap of the column decides
       }
       for (size_t k = 0; k < lut.size(); ++k) c->h_zlut.p[k] = lut[k];
+      c->sphere_layers = lut.size();
       KC_TRY(upload_table(c, c->d_gz.p, c->h_gz.p, ncell));
       KC_TRY(upload_table(c, c->d_zlut.p, c->h_zlut.p, lut.size() * sizeof(double)));
       c->gz_valid = true;
@@ -1104,6 +1118,11 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
     if (c->prm.shape == KC_SPHERE && c->gz_valid) {
       cd.gz = c->d_gz.p;
       cd.zlut = c->d_zlut.p;
+      cd.zmode = 1;
+      if (c->sphere_layers == 1) {
+        cd.zmode = 2;
+        cd.zconst = c->h_zlut.p[0];
+      }
     }
     cd.ginner = c->d_ginner.p;
     cd.gouter = c->d_gouter.p;
