@@ -1343,6 +1343,9 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   __syncthreads();
   KC_STAMP(6);
 
+#ifdef KC_PHASE_STAMPS
+  bool stamped = false;
+#endif
   long long wkey = KEY_NONE;
   // sample i of the list belongs to workgroup (i % grid): a short list spreads
   // over all CUs; inside the workgroup the wavefronts pull the next one
@@ -1355,7 +1358,8 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
     const int n = a.adm_list[i];
     const RowPts pts{a.px + (size_t)n * a.P, a.py + (size_t)n * a.P};
 #ifdef KC_PHASE_STAMPS
-    const bool stamp = a.dbg && i == static_cast<int>(blockIdx.x);  // first sample of wavefront 0
+    const bool stamp = a.dbg && wave == 0 && !stamped;  // first sample of wavefront 0
+    stamped = true;
 #else
     constexpr bool stamp = false;
 #endif
@@ -1367,7 +1371,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
       total = wave_sample_total(a, t, use_dc, SegRows{a.sx, a.sy, a.szz, a.acc_seg, a.S}, cap, sup, sz_end,
                                 cells, skip, obx, oby, pts, n, lane, &s_obest[wave], stamp);
     if (lane == 0) a.costs[n] = total;
-    if (i == static_cast<int>(blockIdx.x)) KC_STAMP(3);
+    if (stamp) KC_STAMP(3);
     if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
       const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
       wkey = k < wkey ? k : wkey;
