@@ -1553,6 +1553,43 @@ __global__ void init_result_kernel(long long *result) {
   result[R_TRIGSEQ] = 0;
 }
 
+// Bounding box of caller-provided sample points (kc_cost_upload): min / max of the finite x and y as
+// order-preserving unsigned keys (atomicMin / atomicMax), out = {min x, min y, max x, max y}, armed by
+// the host with {~0, ~0, 0, 0}; a non-finite coordinate sets out[4] (the box is not used then).
+__device__ __forceinline__ unsigned int float_order_key(float v) {
+  const unsigned int b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void bbox_kernel(const float *px, const float *py, size_t count, unsigned int *out) {
+  unsigned int lo_x = 0xFFFFFFFFu, lo_y = 0xFFFFFFFFu, hi_x = 0u, hi_y = 0u, bad = 0u;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = px[i], y = py[i];
+    if (!(fabsf(x) <= FLT_MAX) || !(fabsf(y) <= FLT_MAX)) {
+      bad = 1u;
+      continue;
+    }
+    const unsigned int kx = float_order_key(x), ky = float_order_key(y);
+    lo_x = min(lo_x, kx);
+    hi_x = max(hi_x, kx);
+    lo_y = min(lo_y, ky);
+    hi_y = max(hi_y, ky);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_x = min(lo_x, static_cast<unsigned int>(__shfl_xor(static_cast<int>(lo_x), off, 64)));
+    lo_y = min(lo_y, static_cast<unsigned int>(__shfl_xor(static_cast<int>(lo_y), off, 64)));
+    hi_x = max(hi_x, static_cast<unsigned int>(__shfl_xor(static_cast<int>(hi_x), off, 64)));
+    hi_y = max(hi_y, static_cast<unsigned int>(__shfl_xor(static_cast<int>(hi_y), off, 64)));
+    bad |= static_cast<unsigned int>(__shfl_xor(static_cast<int>(bad), off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(out + 0, lo_x);
+    atomicMin(out + 1, lo_y);
+    atomicMax(out + 2, hi_x);
+    atomicMax(out + 3, hi_y);
+    if (bad) atomicOr(out + 4, 1u);
+  }
+}
+
 __global__ void fill_u8_kernel(uint8_t *p, int n, uint8_t v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

@@ -180,6 +180,9 @@ struct kc_dwa {
       ++n;
     }
   } hprof;
+  bool ext_box_valid = false;  // bounding box of the caller-provided samples (kc_cost_upload / kc_cost_evaluate)
+  double ext_box[4] = {0, 0, 0, 0};
+  DevBuf<unsigned int> d_bbox;
   bool near_wanted = false;   // the last cycle asked for the table: the next segment update builds it ahead
   // resident reference path (kc_dwa_set_path): rows x | y | z | acc on the
   // device, edge lengths on the host (the window length is an ordered float sum)
@@ -1197,27 +1200,30 @@ int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P) {
 
 // Near table for the cycle that starts at (x, y): kept when the segment is the one it was built
 // from and the reachable box still lies inside it.
-int ensure_near_table(kc_dwa *c, double x, double y, double margin = 0.0) {
+// Near table over the box [lo, hi] (every query point of the coming cost stage lies inside): kept when
+// the segment is the one it was built from and the box still lies inside it.
+int ensure_near_table_box(kc_dwa *c, double lo_x, double lo_y, double hi_x, double hi_y, double margin) {
   c->near_ok = false;
   const bool use_seg = c->ref_len > 0.0f && (c->w.reference_path_distance_weight > 0.0 ||
                                              c->w.goal_distance_weight > 0.0);
-  if (c->near_side == 0 || !use_seg || c->S == 0 || c->S >= 65536 || !std::isfinite(x) || !std::isfinite(y))
+  if (c->near_side == 0 || !use_seg || c->S == 0 || c->S >= 65536) return KC_OK;
+  if (!std::isfinite(lo_x) || !std::isfinite(lo_y) || !std::isfinite(hi_x) || !std::isfinite(hi_y) ||
+      !(hi_x >= lo_x) || !(hi_y >= lo_y))
     return KC_OK;
-  const double reach = cycle_reach(c);
-  if (!(reach > 0.0) || !std::isfinite(reach)) return KC_OK;
   const int N = c->near_side;
   if (c->near_version == c->seg_version && c->near_g > 0.f) {
-    const double lo_x = c->near_x0, lo_y = c->near_y0, side = static_cast<double>(c->near_g) * N;
-    if (x - reach >= lo_x && y - reach >= lo_y && x + reach <= lo_x + side && y + reach <= lo_y + side) {
+    const double t_lo_x = c->near_x0, t_lo_y = c->near_y0, side = static_cast<double>(c->near_g) * N;
+    if (lo_x >= t_lo_x && lo_y >= t_lo_y && hi_x <= t_lo_x + side && hi_y <= t_lo_y + side) {
       c->near_ok = true;
       return KC_OK;
     }
   }
-  const double half = reach * 1.02 + 1e-3 + margin;
-  c->near_x0 = static_cast<float>(x - half);
-  c->near_y0 = static_cast<float>(y - half);
+  const double ext = std::max(hi_x - lo_x, hi_y - lo_y);
+  const double pad = 0.01 * ext + 1e-3 + margin;
+  c->near_x0 = static_cast<float>(lo_x - pad);
+  c->near_y0 = static_cast<float>(lo_y - pad);
   // the float origins may have been rounded up: the edge covers that too
-  const double side = std::max(x + half - c->near_x0, y + half - c->near_y0) * 1.0001;
+  const double side = std::max(hi_x + pad - c->near_x0, hi_y + pad - c->near_y0) * 1.0001;
   c->near_g = static_cast<float>(side / N);
   if (!(c->near_g > 0.f) || !std::isfinite(c->near_g) || !std::isfinite(1.0f / c->near_g)) return KC_OK;
   KC_TRY(c->d_near.reserve(static_cast<size_t>(N) * N));
@@ -1247,6 +1253,13 @@ int ensure_near_table(kc_dwa *c, double x, double y, double margin = 0.0) {
   c->near_version = c->seg_version;
   c->near_ok = true;
   return KC_OK;
+}
+// ... for the cycle that starts at (x, y): everything a roll-out can reach
+int ensure_near_table(kc_dwa *c, double x, double y, double margin = 0.0) {
+  c->near_ok = false;
+  const double reach = cycle_reach(c);
+  if (!(reach > 0.0) || !std::isfinite(reach) || !std::isfinite(x) || !std::isfinite(y)) return KC_OK;
+  return ensure_near_table_box(c, x - reach, y - reach, x + reach, y + reach, margin);
 }
 
 // A new tracked segment while the cycles use the table: build the next one now, around the last start
@@ -1361,6 +1374,9 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   c->near_ok = false;
   c->near_wanted = !use_block && !c->external;
   if (c->near_wanted) KC_TRY(ensure_near_table(c, c->last_start.x, c->last_start.y));
+  // caller-provided samples: the box found when they were uploaded
+  if (!use_block && c->external && c->ext_box_valid)
+    KC_TRY(ensure_near_table_box(c, c->ext_box[0], c->ext_box[1], c->ext_box[2], c->ext_box[3], 0.0));
   CostArgs ca{};
   DcArgs dt{};
   KC_TRY(build_cost_args(c, n, first, ca, dt));
@@ -1942,6 +1958,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->h_seg.release();
   c->d_seg.release();
   c->d_near.release();
+  c->d_bbox.release();
   c->d_path.release();
   c->h_obs.release();
   c->h_cells.release();
@@ -3111,6 +3128,7 @@ int kc_cost_upload(kc_dwa *c, const float *paths_x, const float *paths_y, const 
   c->cycle_launched = false;
   c->paths_valid = true;
   c->row_valid = false;
+  c->ext_box_valid = false;
   KC_TRY(ensure_cycle_buffers(c, std::max<size_t>(n, 1), P));
   if (n) {
     KC_HIP(hipMemcpyAsync(c->d_px.p, paths_x, n * P * 4, hipMemcpyHostToDevice, s));
@@ -3126,7 +3144,29 @@ int kc_cost_upload(kc_dwa *c, const float *paths_x, const float *paths_y, const 
     }
     hipLaunchKernelGGL(fill_u8_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
                        s, c->d_flags.p, static_cast<int>(n), uint8_t(1));
+    // bounding box of the points: the wavefront-per-sample search lays its near table over it
+    c->ext_box_valid = false;
+    unsigned int hb[5] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    if (c->near_side != 0) {
+      KC_TRY(c->d_bbox.reserve(8));
+      KC_HIP(hipMemcpyAsync(c->d_bbox.p, hb, sizeof(hb), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(bbox_kernel, dim3(512), dim3(256), 0, s, c->d_px.p, c->d_py.p, n * P, c->d_bbox.p);
+      KC_HIP(hipMemcpyAsync(hb, c->d_bbox.p, sizeof(hb), hipMemcpyDeviceToHost, s));
+    }
     KC_HIP(hipStreamSynchronize(s));  // pageable sources
+    if (c->near_side != 0 && hb[4] == 0u && hb[0] <= hb[2] && hb[1] <= hb[3]) {
+      auto unkey = [](unsigned int k) {
+        const unsigned int b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+        float f;
+        std::memcpy(&f, &b, 4);
+        return static_cast<double>(f);
+      };
+      c->ext_box[0] = unkey(hb[0]);
+      c->ext_box[1] = unkey(hb[1]);
+      c->ext_box[2] = unkey(hb[2]);
+      c->ext_box[3] = unkey(hb[3]);
+      c->ext_box_valid = true;
+    }
   }
   return KC_OK;
 }
