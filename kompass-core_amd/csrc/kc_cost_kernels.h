@@ -687,12 +687,21 @@ __device__ __forceinline__ float velocity_cost_sum(const CostArgs &a, const floa
       if (a.acc1 > 0) t1 = term(vy, a.acc1);
       if (a.acc2 > 0) t2 = term(om, a.acc2);
     }
-    const int cnt = min(64, nv - k0);
-    for (int j = 0; j < cnt; ++j) {
-      if (a.acc0 > 0) c = static_cast<float>(static_cast<double>(c) + lane_value_f64(t0, j));
-      if (a.acc1 > 0) c = static_cast<float>(static_cast<double>(c) + lane_value_f64(t1, j));
-      if (a.acc2 > 0) c = static_cast<float>(static_cast<double>(c) + lane_value_f64(t2, j));
+    // The running float takes the three quotients of a step one after the other (each sum formed in
+    // double and rounded back, cost_evaluator.cpp:187-233), step after step: lane j continues from lane
+    // j-1's value, handed on by the DPP wave shift (lane 0: the carry of the previous 64 steps) -- nine
+    // dependent instructions per step where v_readlane of the double quotients took fifteen.  Steps
+    // beyond nv and axes without a limit add +0.0, which leaves the non-negative sum as it is.
+    float r = 0.0f;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) {
+      const float prev = __int_as_float(
+          __builtin_amdgcn_update_dpp(__float_as_int(c), __float_as_int(r), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+      float v = static_cast<float>(static_cast<double>(prev) + t0);
+      v = static_cast<float>(static_cast<double>(v) + t1);
+      r = static_cast<float>(static_cast<double>(v) + t2);
     }
+    c = lane_value(r, 63);
   }
   return c;
 }
