@@ -367,7 +367,10 @@ int kc_mapper_set_stream(kc_mapper *ctx, void *hip_stream);
 int kc_mapper_scan_to_grid(kc_mapper *ctx, const double *angles,
                            const double *ranges, size_t n, int32_t *grid_out);
 /* same, but the grid stays on the device (no D2H); the address of the int32
- * column-major device grid is returned by kc_mapper_grid_device */
+ * column-major device grid is returned by kc_mapper_grid_device.  Plain scans
+ * alternate between two device grids (the scan that follows clears the other
+ * one while it runs): ask for the address after every scan; the grid of a scan
+ * stays intact until the NEXT scan's kernels have run. */
 int kc_mapper_scan_to_grid_device(kc_mapper *ctx, const double *angles,
                                   const double *ranges, size_t n);
 int kc_mapper_grid_device(kc_mapper *ctx, void **dev_grid_int32);

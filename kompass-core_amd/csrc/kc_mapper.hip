@@ -465,20 +465,35 @@ __global__ __launch_bounds__(kTileThreads) void near_tiles_kernel(
 // The last workgroup to finish tells the host (sequence number into pinned
 // memory, polled by kc_mapper_sync instead of a stream wait); every workgroup
 // releases its stores (device scope) before it takes its ticket.
+// Plain scans alternate between two grids: the workgroups behind the beam blocks fill the OTHER grid
+// with UNEXPLORED for the next scan (16-byte stores; the runtime's memset kernel in front of every scan
+// was 8 us of a 36 us scan).
 __global__ void endpoints_kernel(MapGeom g, const float *__restrict__ ranges,
                                  const double2 *__restrict__ trig, int n, int *__restrict__ grid,
-                                 unsigned int *ticket, long long *host_seq, long long seq) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n) {
-    const int2 t = beam_endpoint(g, ranges[b], trig[b]);
-    if (t.x >= 0 && t.x < g.H && t.y >= 0 && t.y < g.W)
-      grid[(size_t)t.x + (size_t)t.y * (size_t)g.H] = KC_OCCUPIED;
+                                 unsigned int *ticket, long long *host_seq, long long seq,
+                                 int4 *__restrict__ clear, size_t clear_vec, int beam_blocks) {
+  if (static_cast<int>(blockIdx.x) < beam_blocks) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) {
+      const int2 t = beam_endpoint(g, ranges[b], trig[b]);
+      if (t.x >= 0 && t.x < g.H && t.y >= 0 && t.y < g.W)
+        grid[(size_t)t.x + (size_t)t.y * (size_t)g.H] = KC_OCCUPIED;
+    }
+  } else {
+    const size_t stride = static_cast<size_t>(gridDim.x - beam_blocks) * blockDim.x;
+    const int4 v = make_int4(KC_UNEXPLORED, KC_UNEXPLORED, KC_UNEXPLORED, KC_UNEXPLORED);
+    for (size_t i = static_cast<size_t>(blockIdx.x - beam_blocks) * blockDim.x + threadIdx.x; i < clear_vec; i += stride)
+      clear[i] = v;
+    // (no fence, no ticket: the other grid is next read by the kernels of the next scan, in stream
+    // order behind this kernel -- a device-scope release per clearing workgroup writes the L2 back a
+    // thousand times: 75 us)
+    return;
   }
   if (host_seq == nullptr) return;  // Bayesian scan: the cell pass reports
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    if (atomicAdd(ticket, 1u) == static_cast<unsigned int>(beam_blocks) - 1u) {
       *ticket = 0u;
       *reinterpret_cast<volatile long long *>(host_seq) = seq;
     }
@@ -589,7 +604,9 @@ struct kc_mapper {
   size_t cap = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   Timing timing;
-  DevBuf<int> d_grid;
+  DevBuf<int> d_grid;      // the grid of the last scan (plain scans alternate between the two)
+  DevBuf<int> d_grid_alt;  // ... the other one
+  bool alt_cleared = false;  // d_grid_alt holds UNEXPLORED everywhere (left so by the last plain scan)
   DevBuf<float> d_ranges;
   DevBuf<double2> d_trig;
   DevBuf<unsigned int> d_ticket;
@@ -651,7 +668,13 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   m->timing.begin_cycle();
   const size_t cells = static_cast<size_t>(m->g.H) * m->g.W;
   m->tiles = m->tile_mode == 2 || (m->tile_mode == 1 && bayes);
-  if (!m->tiles || n == 0) {  // the tiled scan writes every cell itself
+  const bool plain = !bayes && !m->tiles && n != 0;
+  if (plain && m->alt_cleared && m->d_grid_alt.p) {
+    // the previous plain scan left the other grid UNEXPLORED: this scan takes it (the old one stays
+    // readable until this scan's endpoint kernel clears it for the next)
+    std::swap(m->d_grid, m->d_grid_alt);
+    m->alt_cleared = false;
+  } else if (!m->tiles || n == 0) {  // the tiled scan writes every cell itself
     KC_TRY(m->timing.start("grid_clear", s));
     KC_HIP(hipMemsetAsync(m->d_grid.p, 0xFF, cells * sizeof(int), s));  // -1
     KC_TRY(m->timing.stop(s));
@@ -747,9 +770,19 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   KC_TRY(m->timing.stop(s));
   ++m->seq;
   KC_TRY(m->timing.start("endpoints_kernel", s));
-  hipLaunchKernelGGL(endpoints_kernel, dim3((ni + 255) / 256), dim3(256), 0, s,
-                     m->g, m->d_ranges.p, m->d_trig.p, ni, m->d_grid.p, m->d_ticket.p,
-                     bayes ? static_cast<long long *>(nullptr) : m->h_seq.p, m->seq);
+  {
+    const int beam_blocks = (ni + 255) / 256;
+    int clear_blocks = 0;
+    int4 *clear = nullptr;
+    if (plain && m->d_grid_alt.p && cells % 4 == 0) {
+      clear = reinterpret_cast<int4 *>(m->d_grid_alt.p);
+      clear_blocks = static_cast<int>(std::min<size_t>(1024, (cells / 4 + 255) / 256));
+    }
+    hipLaunchKernelGGL(endpoints_kernel, dim3(beam_blocks + clear_blocks), dim3(256), 0, s,
+                       m->g, m->d_ranges.p, m->d_trig.p, ni, m->d_grid.p, m->d_ticket.p,
+                       bayes ? static_cast<long long *>(nullptr) : m->h_seq.p, m->seq, clear, cells / 4, beam_blocks);
+    if (clear) m->alt_cleared = true;
+  }
   KC_TRY(m->timing.stop(s));
   if (bayes) {
     KC_TRY(m->timing.start("bayes_cells_kernel", s));
@@ -814,7 +847,7 @@ int kc_mapper_create(int H, int W, float res, const float pos[3], float orient,
   m->stream = m->own_stream;
   const size_t cells = static_cast<size_t>(H) * W;
   int rc;
-  if ((rc = m->d_grid.reserve(cells)) || (rc = m->h_grid.reserve(cells)) ||
+  if ((rc = m->d_grid.reserve(cells)) || (rc = m->d_grid_alt.reserve(cells)) || (rc = m->h_grid.reserve(cells)) ||
       (rc = m->d_ranges.reserve(std::max<size_t>(max_scan, 16))) ||
       (rc = m->d_ticket.reserve(1)) || (rc = m->h_seq.reserve(1)))
     return fail(rc);
@@ -847,6 +880,7 @@ void kc_mapper_destroy(kc_mapper *m) {
   (void)e;
   m->timing.release();
   m->d_grid.release();
+  m->d_grid_alt.release();
   m->d_prob.release();
   m->d_prev.release();
   m->d_prev_tmp.release();
