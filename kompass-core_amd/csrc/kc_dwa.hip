@@ -883,15 +883,15 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   // the raw points: host copy for the lazy lists, device copy through the BAR
   c->host_lists_valid = false;
   if (xyz) {
-    c->raw_xyz.assign(xyz, xyz + 3 * n);
+    // (no host copy: the lists that the split path and the debug getters need are rebuilt from the
+    // device copy on demand, ensure_host_lists)
     std::memcpy(c->d_raw.p, xyz, 3 * n * sizeof(float));
     c->bar_dirty = true;
     bar_flush(c);
-  } else {
-    c->raw_xyz.clear();
-    c->raw_on_device = true;
-    c->raw_n = n;
   }
+  c->raw_xyz.clear();
+  c->raw_on_device = true;
+  c->raw_n = n;
   SensorArgs a{};
   a.xyz = c->d_raw.p;
   a.n = static_cast<int>(n);
