@@ -885,9 +885,13 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   if (xyz) {
     // (no host copy: the lists that the split path and the debug getters need are rebuilt from the
     // device copy on demand, ensure_host_lists)
+    const auto tb0 = std::chrono::steady_clock::now();
     std::memcpy(c->d_raw.p, xyz, 3 * n * sizeof(float));
     c->bar_dirty = true;
     bar_flush(c);
+    if (c->hprof.on)
+      std::fprintf(stderr, "[kc host] raw points over the BAR: %zu bytes in %.1f us\n", 3 * n * sizeof(float),
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb0).count());
   }
   c->raw_xyz.clear();
   c->raw_on_device = true;
