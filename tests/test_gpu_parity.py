@@ -534,3 +534,29 @@ print("SECOND:", bool(r.found), int(r.raw_index), int(r.n_admissible))
     lines2 = p2.stdout.strip().splitlines()
     assert lines2[0] == "FIRST: no error", p2.stdout   # the roll-out call itself does not fail: the error word is set on the device
     assert lines2[1] == f"SECOND: True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p2.stdout
+
+
+@pytest.mark.parametrize("H,W", [(200, 200), (123, 77), (401, 399)])
+def test_mapper_scan_sequences_on_one_context(H, W):
+    """Plain scans alternate between two device grids (the endpoint kernel of a scan clears the other
+    grid for the next; odd cell counts fall back to the memset): many different scans on ONE context,
+    an empty scan and a device-resident scan in between, every grid equal to the oracle's."""
+    r = np.random.default_rng(5 + H)
+    res = 0.05
+    m = kh.MapperContext(H, W, res, (0.1, -0.2, 0.0), 0.3, 720)
+    ext = min(H, W) * res
+    for case in range(12):
+        n = int(r.choice([1, 90, 720]))
+        ang = np.sort(r.uniform(-np.pi, np.pi, n))
+        rng = r.uniform(0.05, 0.9 * ext, n)
+        if case == 5:
+            g = m.scan_to_grid(np.zeros(0), np.zeros(0))
+            assert (g == -1).all()
+            continue
+        want = ko.scan_to_grid(H, W, res, (0.1, -0.2, 0.0), 0.3, ang, rng)
+        if case % 4 == 3:   # device-resident scan, then the same scan copied out: two scans, same grid
+            m.scan_to_grid_device(ang, rng)
+            m.sync()
+        got = m.scan_to_grid(ang, rng)
+        assert np.array_equal(got, want), (case, n, int((got != want).sum()))
+    m.close()
