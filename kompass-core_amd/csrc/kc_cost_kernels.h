@@ -485,8 +485,23 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
       const int mmax = max(b.W, b.H);
       // first block: just large enough to contain the nearest non-empty cell;
       // following blocks: just large enough to prove the best distance found
-      int m = max(1, static_cast<int>(skip[cy * b.W + cx]));
-      for (;;) {  // uniform within the group of eight, divergent between groups
+      const int sk = static_cast<int>(skip[cy * b.W + cx]);
+      int m = max(1, sk);
+      // Cells nearer (Chebyshev) than sk are empty: nothing is closer than lb.  A point whose lb lies
+      // beyond max_obstacles_dist costs nothing, and one whose lb lies beyond what another point of the
+      // sample has already found cannot lower the sample's minimum: neither walks any block (in open
+      // space that was every point, each scanning a block out to the cap).
+      bool search = true;
+      {
+        const double lb = (static_cast<double>(sk - 1) - off) * b.g;
+        if (lb >= b.cap) search = false;
+        else if (lb > 0.0) {
+          const double seen = __longlong_as_double(static_cast<long long>(
+              *const_cast<volatile unsigned long long *>(s_obest)));
+          if (lb * lb * (1.0 - 1e-6) >= seen) search = false;
+        }
+      }
+      while (search) {  // uniform within the group of eight, divergent between groups
         const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
         const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
         // a row of the block is a contiguous run of the cell-ordered obstacle
