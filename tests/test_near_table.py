@@ -152,3 +152,35 @@ def test_near_table_option_range():
     ctx.set_option("near_table", 0)
     assert ctx.get_option("near_table") == 0
     ctx.close()
+
+
+def test_near_table_with_the_resident_path_window():
+    """The tracked segment as a window of a device-resident path (kc_dwa_set_path +
+    kc_dwa_set_tracked_window: tables written by segment_window_kernel, the near table built behind it in
+    stream order): a sliding window, every cycle against a context that gets the same points through
+    kc_dwa_set_tracked_segment and runs without the table."""
+    inp = _base(scene="open", scale=0.3)
+    xyz, acc = syn.arc_segment(1500, 8.0, 0.01)
+    a = hip_context(kh, dict(inp, seg_xyz=xyz[:600]))
+    b = hip_context(kh, dict(inp, seg_xyz=xyz[:600]))
+    for c, nt in ((a, 128), (b, 0)):
+        c.set_option("near_table", nt)
+        c.set_option("cost_kernel", 2)
+        c.set_weights(kh.make_weights(*inp["weights"]))
+        c.set_points(inp["state"], inp["points"], inp["max_range"])
+        c.set_samples(inp["vx"], inp["vy"], inp["omega"])
+    a.set_path(xyz, acc, float(acc[-1]))
+    P = inp["P"]
+    for i in range(40):
+        start, size = 15 * i, 420 + (i % 5) * 37
+        a.set_tracked_window(start, size)
+        seg = xyz[start:start + size]
+        b.set_tracked_segment(seg, acc[start:start + size], float(acc[-1]))
+        st = (float(seg[0, 0]), float(seg[0, 1]), 0.02 * (i % 9), 0.0)
+        ra, rb = a.cycle(st, P), b.cycle(st, P)
+        assert (ra.found, ra.index, ra.raw_index, ra.n_admissible) == (rb.found, rb.index, rb.raw_index, rb.n_admissible), i
+        assert np.float32(ra.cost) == np.float32(rb.cost), i
+        if i % 13 == 5:
+            np.testing.assert_array_equal(a.get_samples(with_costs=True)[3].view(np.uint32),
+                                          b.get_samples(with_costs=True)[3].view(np.uint32))
+    a.close(); b.close()
