@@ -931,15 +931,15 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     KC_TRY(c->timing.stop(c->stream));
   } else {
     // scratch: [counts (ncell + 1) | cell records n | ox n | oy n]; bitmap and counts start at zero
-    KC_TRY(c->d_sensor_tmp.reserve(ncell + 1 + 3 * n));
+    KC_TRY(c->d_sensor_tmp.reserve((ncell + 1) * kCntStride + 3 * n));
     SensorBigArgs sb{};
     sb.a = a;
     sb.counts = reinterpret_cast<int *>(c->d_sensor_tmp.p);
-    sb.tcell = sb.counts + ncell + 1;
+    sb.tcell = sb.counts + (ncell + 1) * kCntStride;
     sb.tox = reinterpret_cast<float *>(sb.tcell + n);
     sb.toy = sb.tox + n;
     KC_HIP(hipMemsetAsync(c->d_gbits.p, 0, nwords * sizeof(uint32_t), c->stream));
-    KC_HIP(hipMemsetAsync(sb.counts, 0, (ncell + 1) * sizeof(int), c->stream));
+    KC_HIP(hipMemsetAsync(sb.counts, 0, (ncell + 1) * kCntStride * sizeof(int), c->stream));
     const unsigned nb = blocks_for(n, kSensorBigBlock);
     KC_TRY(c->timing.start("sensor_points_kernel", c->stream));
     hipLaunchKernelGGL(sensor_points_kernel, dim3(nb), dim3(kSensorBigBlock), 0, c->stream, sb);

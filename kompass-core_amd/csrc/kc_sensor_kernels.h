@@ -210,9 +210,12 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
 // as arbitrary as there.  Reference step: collision_check.h:91-136 (octree
 // rebuild) + cost_evaluator.h:174-223 (setPointScan).
 // ---------------------------------------------------------------------------
+constexpr int kCntStride = 16;  // ints between two bucket counters of the multi-workgroup build
 struct SensorBigArgs {
   SensorArgs a;
-  int *counts;      // [W*H + 1] zeroed; slot k + 1 counts cell k
+  int *counts;      // [(W*H + 1) * kCntStride] zeroed; slot (k + 1) * kCntStride counts cell k -- one counter per
+                    // 64-byte line: the returning device-scope atomics of sensor_points_kernel execute at the memory
+                    // side, where sixteen counters of one line queue behind each other
   float *tox, *toy; // [n] transformed coordinates (scratch)
   int *tcell;       // [n] cell id | rank << 12, -1: not an obstacle
 };
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(kSensorBigBlock) void sensor_points_kernel(SensorBi
   int id;
   int rec = -1;
   if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id)) {
-    rec = id | (atomicAdd(&b.counts[id + 1], 1) << 12);  // id < 4096 cells, rank < 2^19
+    rec = id | (atomicAdd(&b.counts[(id + 1) * kCntStride], 1) << 12);  // id < 4096 cells, rank < 2^19
     b.tox[i] = ox;
     b.toy[i] = oy;
   }
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_cells_kernel(SensorBigArg
   __shared__ int wave_tot[kSensorBlock / 64];
   __shared__ int s_nonempty;
   const int tid = threadIdx.x;
-  for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = b.counts[i];
+  for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = b.counts[i * kCntStride];
   if (tid == 0) s_nonempty = 0;
   __syncthreads();
   {
