@@ -60,6 +60,7 @@ struct kc_dwa {
   std::vector<float> scan_xyz;          // sensor-frame points of the last laserscan
   DevBuf<float> d_raw;
   DevBuf<uint32_t> d_sensor_tmp;        // scratch of the multi-workgroup sensor build
+  DevBuf<uint8_t> d_sensor_bytes;       // its voxel byte map (zero between updates)
   // grid hand-off (kc_dwa_set_grid_device): the point list is produced on the
   // device; the host copy is fetched only if something walks the lists
   bool raw_on_device = false;
@@ -742,7 +743,7 @@ inline bool any_voxel(const kc_dwa *c) {
 // the bounds, stores the raw points through the BAR and queues two kernels.
 // *done = false: conditions not met, the caller takes the host path.
 int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
-                                 const float hi[3], bool *done);
+                                 const float hi[3], bool *done, bool raw_copied = false);
 
 int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   *done = false;
@@ -752,12 +753,16 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
     return KC_OK;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   size_t nfin = 0;
-  bool bounded = false;
+  bool bounded = false, raw_copied = false;
 #if defined(__x86_64__)
   // This pass sits on the critical path of a sensor update (nothing is launched
   // before the bounds are known): four points per step with SSE min / max;
   // any non-finite coordinate (v - v != 0) sends the whole list to the loop below.
+  // The same pass stores the points to their device buffer through the BAR
+  // (write-combining stores): one trip over the list instead of two.
+  KC_TRY(c->d_raw.reserve(3 * n));
   {
+    float *dst = c->d_raw.p;
     typedef float v4 __attribute__((vector_size(16)));
     typedef int v4i __attribute__((vector_size(16)));
     const v4 big = {FLT_MAX, FLT_MAX, FLT_MAX, FLT_MAX}, zero = {0.f, 0.f, 0.f, 0.f};
@@ -770,6 +775,7 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
       for (int q = 0; q < 3; ++q) {
         v4 v;
         std::memcpy(&v, xyz + i + 4 * q, sizeof(v));
+        __builtin_nontemporal_store(v, reinterpret_cast<v4 *>(dst + i + 4 * q));
         mn[q] = __builtin_ia32_minps(mn[q], v);
         mx[q] = __builtin_ia32_maxps(mx[q], v);
         const v4 dv = v - v;
@@ -788,10 +794,12 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
       bool tail_ok = true;
       for (; i < total; ++i) {  // fewer than four points
         const float v = xyz[i];
+        dst[i] = v;
         tail_ok = tail_ok && std::isfinite(v);
         lo[i % 3] = std::min(lo[i % 3], v);
         hi[i % 3] = std::max(hi[i % 3], v);
       }
+      raw_copied = true;
       if (tail_ok) {
         bounded = true;
         nfin = n;
@@ -816,13 +824,13 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
     ++nfin;
   }
   if (nfin == 0) return KC_OK;
-  return sensor_update_device_bounded(c, xyz, n, lo, hi, done);
+  return sensor_update_device_bounded(c, xyz, n, lo, hi, done, raw_copied);
 }
 
 // the part behind the bounds; xyz == nullptr: the points are in d_raw already
 // (grid hand-off)
 int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
-                                 const float hi[3], bool *done) {
+                                 const float hi[3], bool *done, bool raw_copied) {
   *done = false;
   if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
       n == 0 || n > kSensorDeviceMax)
@@ -880,13 +888,20 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   KC_TRY(c->d_skip.reserve(ncell + 4));
   KC_TRY(c->d_bobs.reserve(2 * n));
   KC_TRY(c->d_raw.reserve(3 * n));
+  if (big) {
+    // byte map of the voxels: zero between updates (sensor_place_kernel clears what it packs)
+    const uint8_t *was = c->d_sensor_bytes.p;
+    KC_TRY(c->d_sensor_bytes.reserve(nwords * 32));
+    if (c->d_sensor_bytes.p != was)
+      KC_HIP(hipMemsetAsync(c->d_sensor_bytes.p, 0, c->d_sensor_bytes.cap, c->stream));
+  }
   // the raw points: host copy for the lazy lists, device copy through the BAR
   c->host_lists_valid = false;
   if (xyz) {
     // (no host copy: the lists that the split path and the debug getters need are rebuilt from the
     // device copy on demand, ensure_host_lists)
     const auto tb0 = std::chrono::steady_clock::now();
-    std::memcpy(c->d_raw.p, xyz, 3 * n * sizeof(float));
+    if (!raw_copied) std::memcpy(c->d_raw.p, xyz, 3 * n * sizeof(float));
     c->bar_dirty = true;
     bar_flush(c);
     if (c->hprof.on)
@@ -930,25 +945,22 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
     KC_TRY(c->timing.stop(c->stream));
   } else {
-    // scratch: [counts (ncell + 1) | cell records n | ox n | oy n]; bitmap and counts start at zero
-    KC_TRY(c->d_sensor_tmp.reserve((ncell + 1) * kCntStride + 3 * n));
+    // scratch: [cell records n | ox n | oy n | histogram rows]
     SensorBigArgs sb{};
     sb.a = a;
-    sb.counts = reinterpret_cast<int *>(c->d_sensor_tmp.p);
-    sb.tcell = sb.counts + (ncell + 1) * kCntStride;
+    sb.ppt = static_cast<int>((n + static_cast<size_t>(kHistRowsMax) * kSensorBlock - 1) / (static_cast<size_t>(kHistRowsMax) * kSensorBlock));
+    sb.rows = static_cast<int>(blocks_for(n, static_cast<size_t>(kSensorBlock) * sb.ppt));
+    KC_TRY(c->d_sensor_tmp.reserve(3 * n + static_cast<size_t>(sb.rows) * kHistRow + 4));
+    sb.tcell = reinterpret_cast<int *>(c->d_sensor_tmp.p);
     sb.tox = reinterpret_cast<float *>(sb.tcell + n);
     sb.toy = sb.tox + n;
-    KC_HIP(hipMemsetAsync(c->d_gbits.p, 0, nwords * sizeof(uint32_t), c->stream));
-    KC_HIP(hipMemsetAsync(sb.counts, 0, (ncell + 1) * kCntStride * sizeof(int), c->stream));
-    const unsigned nb = blocks_for(n, kSensorBigBlock);
+    sb.hist = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(sb.toy + n) + 15) & ~uintptr_t(15));
+    sb.bytes = c->d_sensor_bytes.p;
     KC_TRY(c->timing.start("sensor_points_kernel", c->stream));
-    hipLaunchKernelGGL(sensor_points_kernel, dim3(nb), dim3(kSensorBigBlock), 0, c->stream, sb);
+    hipLaunchKernelGGL(sensor_points_kernel, dim3(sb.rows), dim3(kSensorBlock), 0, c->stream, sb);
     KC_TRY(c->timing.stop(c->stream));
-    KC_TRY(c->timing.start("sensor_cells_kernel", c->stream));
-    hipLaunchKernelGGL(sensor_cells_kernel, dim3(1), dim3(kSensorBlock), 0, c->stream, sb);
-    KC_TRY(c->timing.stop(c->stream));
-    KC_TRY(c->timing.start("sensor_scatter_kernel", c->stream));
-    hipLaunchKernelGGL(sensor_scatter_kernel, dim3(nb), dim3(kSensorBigBlock), 0, c->stream, sb);
+    KC_TRY(c->timing.start("sensor_place_kernel", c->stream));
+    hipLaunchKernelGGL(sensor_place_kernel, dim3(sb.rows), dim3(kSensorBlock), 0, c->stream, sb);
     KC_TRY(c->timing.stop(c->stream));
   }
   KC_HIP(hipGetLastError());
@@ -1946,6 +1958,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_dbg2.release();
   c->d_raw.release();
   c->d_sensor_tmp.release();
+  c->d_sensor_bytes.release();
   c->d_dc.release();
   c->d_dc_enable.release();
   c->d_gridcnt.release();

@@ -202,67 +202,147 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
 
 // ---------------------------------------------------------------------------
 // The same structure for LARGE clouds (more than 16 k points, or a voxel bitmap
-// beyond 64 KB: a 1000 x 1000 costmap has ~28 k occupied cells): the points are
-// spread over many workgroups, the scatters become device atomics on a zeroed
-// bitmap / count table, the scan + skip table stay one workgroup (the bucket
-// grid is at most 64 x 64), a third launch puts the coordinates in cell order.
+// beyond 64 KB: a 1000 x 1000 costmap has ~28 k occupied cells), two launches and
+// NO global atomics: device-scope atomics execute at the memory side on this
+// chip (55 k of them took 13 us, and 18 us with sixteen counters per cache line
+// queueing behind each other).
+//   sensor_points_kernel  one workgroup per 1024 * ppt points: voxel -> ONE BYTE of a
+//                         byte map (plain idempotent stores; the L2s merge bytes), bucket
+//                         rank from a histogram in LDS, the histogram written as one row
+//                         of a [workgroups][4096] matrix
+//   sensor_place_kernel   the same workgroups: each sums the matrix columns (its own row's
+//                         prefix on the way) and scans them (redundant, 2 us, instead of a
+//                         launch in between), puts its points into cell order, writes its
+//                         share of cell starts / skip table, and packs its share of the byte
+//                         map into the bitmap, clearing it behind (so neither needs a memset)
 // Same per-point arithmetic as above; the order of the points inside a bucket is
 // as arbitrary as there.  Reference step: collision_check.h:91-136 (octree
 // rebuild) + cost_evaluator.h:174-223 (setPointScan).
 // ---------------------------------------------------------------------------
-constexpr int kCntStride = 16;  // ints between two bucket counters of the multi-workgroup build
+constexpr int kHistRow = 64 * 64;  // ints per row of the histogram matrix
+constexpr int kHistRowsMax = 16;   // the host picks points per thread so that the rows fit
 struct SensorBigArgs {
   SensorArgs a;
-  int *counts;      // [(W*H + 1) * kCntStride] zeroed; slot (k + 1) * kCntStride counts cell k -- one counter per
-                    // 64-byte line: the returning device-scope atomics of sensor_points_kernel execute at the memory
-                    // side, where sixteen counters of one line queue behind each other
+  int ppt;          // points per thread (1 .. 16): a workgroup takes 1024 * ppt consecutive points
+  int rows;         // workgroups of the points kernel = rows of hist
+  int *hist;        // [rows][kHistRow] points per bucket of each workgroup
+  uint8_t *bytes;   // [gH][gwpr * 32] zero on entry, zero again when sensor_place_kernel is done
   float *tox, *toy; // [n] transformed coordinates (scratch)
-  int *tcell;       // [n] cell id | rank << 12, -1: not an obstacle
+  int *tcell;       // [n] cell id | rank inside its workgroup (< 16 k) << 12, -1: not an obstacle
 };
-constexpr int kSensorBigBlock = 256;
 
-__global__ __launch_bounds__(kSensorBigBlock) void sensor_points_kernel(SensorBigArgs b) {
+__global__ __launch_bounds__(kSensorBlock) void sensor_points_kernel(SensorBigArgs b) {
   const SensorArgs &a = b.a;
-  const int i = blockIdx.x * kSensorBigBlock + threadIdx.x;
-  if (i >= a.n) return;
-  const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-  // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
-  const double fx = floor(a.inv_res * static_cast<double>(x));
-  const double fy = floor(a.inv_res * static_cast<double>(y));
-  const double fz = floor(a.inv_res * static_cast<double>(z));
-  if (fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0) {
-    const int kz = static_cast<int>(fz);
-    const double zlo = static_cast<double>(kz) * a.res;
-    const double zhi = static_cast<double>(kz + 1) * a.res;
-    if (zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height) {
-      const int cx = static_cast<int>(fx) - a.gkx0, cy = static_cast<int>(fy) - a.gky0;
-      if (cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr)
-        atomicOr(&a.gbits[(size_t)cy * a.gwpr + (cx >> 5)], 1u << (cx & 31));
+  __shared__ __align__(16) int lhist[kHistRow];
+  const int tid = threadIdx.x;
+  reinterpret_cast<int4 *>(lhist)[tid] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  auto point = [&](int i, float x, float y, float z) {
+    // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
+    const double fx = floor(a.inv_res * static_cast<double>(x));
+    const double fy = floor(a.inv_res * static_cast<double>(y));
+    const double fz = floor(a.inv_res * static_cast<double>(z));
+    if (fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0) {
+      const int kz = static_cast<int>(fz);
+      const double zlo = static_cast<double>(kz) * a.res;
+      const double zhi = static_cast<double>(kz + 1) * a.res;
+      if (zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height) {
+        const int cx = static_cast<int>(fx) - a.gkx0, cy = static_cast<int>(fy) - a.gky0;
+        if (cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr)
+          b.bytes[(static_cast<size_t>(cy) * a.gwpr << 5) + cx] = 1;
+      }
     }
+    float ox, oy;
+    int id;
+    int rec = -1;
+    if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id)) {
+      rec = id | (atomicAdd(&lhist[id], 1) << 12);  // id < 4096 cells, rank < 16 k
+      b.tox[i] = ox;
+      b.toy[i] = oy;
+    }
+    b.tcell[i] = rec;
+  };
+  // four points per trip, their loads issued together
+  const int i0 = blockIdx.x * kSensorBlock * b.ppt;
+  for (int q = 0; q < b.ppt; q += 4) {
+    float px[4], py[4], pz[4];
+    int pi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + (q + u) * kSensorBlock + tid;
+      pi[u] = (q + u < b.ppt && i < a.n) ? i : -1;
+      const int j = pi[u] >= 0 ? i : 0;  // idle slots shadow point 0, used for nothing
+      px[u] = a.xyz[3 * j];
+      py[u] = a.xyz[3 * j + 1];
+      pz[u] = a.xyz[3 * j + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (pi[u] >= 0) point(pi[u], px[u], py[u], pz[u]);
   }
-  float ox, oy;
-  int id;
-  int rec = -1;
-  if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id)) {
-    rec = id | (atomicAdd(&b.counts[(id + 1) * kCntStride], 1) << 12);  // id < 4096 cells, rank < 2^19
-    b.tox[i] = ox;
-    b.toy[i] = oy;
-  }
-  b.tcell[i] = rec;
+  __syncthreads();
+  reinterpret_cast<int4 *>(b.hist + static_cast<size_t>(blockIdx.x) * kHistRow)[tid] = reinterpret_cast<int4 *>(lhist)[tid];
 }
 
-// one workgroup: counts -> starts (in place, then to cell_start), skip table, dc_enable
-__global__ __launch_bounds__(kSensorBlock) void sensor_cells_kernel(SensorBigArgs b) {
+__global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArgs b) {
   const SensorArgs &a = b.a;
   const int ncell = a.W * a.H;
-  __shared__ int lstart[64 * 64 + 1];
+  __shared__ __align__(16) int lstart[kHistRow + 4];  // slot k + 1: count, then start, of cell k
+  __shared__ __align__(16) int lbase[kHistRow];       // points of the cell in the workgroups before this one
   __shared__ unsigned long long lmask[64];
   __shared__ int wave_tot[kSensorBlock / 64];
   __shared__ int s_nonempty;
   const int tid = threadIdx.x;
-  for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = b.counts[i * kCntStride];
-  if (tid == 0) s_nonempty = 0;
+  const int me = blockIdx.x;
+  // ---- byte map -> bitmap, bytes cleared behind -------------------------------------------------------
+  {
+    const size_t nwords = static_cast<size_t>(a.gH) * a.gwpr;
+    for (size_t w = static_cast<size_t>(me) * kSensorBlock + tid; w < nwords; w += static_cast<size_t>(gridDim.x) * kSensorBlock) {
+      ulonglong2 *src = reinterpret_cast<ulonglong2 *>(b.bytes + (w << 5));
+      const ulonglong2 lo = src[0], hi = src[1];
+      // bytes are 0 / 1: (v * 0x0102040810204080) >> 56 gathers byte i into bit i (all partial products
+      // fall on distinct bit positions: no carries)
+      constexpr unsigned long long kGather = 0x0102040810204080ull;
+      const uint32_t bits = static_cast<uint32_t>((lo.x * kGather) >> 56) | static_cast<uint32_t>((lo.y * kGather) >> 56) << 8 |
+                            static_cast<uint32_t>((hi.x * kGather) >> 56) << 16 | static_cast<uint32_t>((hi.y * kGather) >> 56) << 24;
+      a.gbits[w] = bits;
+      if (bits) {
+        src[0] = make_ulonglong2(0ull, 0ull);
+        src[1] = make_ulonglong2(0ull, 0ull);
+      }
+    }
+  }
+  // ---- column sums of the histogram matrix (four cells per thread) -----------------------------------------
+  {
+    int4 acc = make_int4(0, 0, 0, 0), mine = make_int4(0, 0, 0, 0);
+    for (int w0 = 0; w0 < b.rows; w0 += 16) {  // sixteen loads in flight (all of them: the host keeps rows <= 16)
+      int4 h[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        h[j] = w0 + j < b.rows ? reinterpret_cast<const int4 *>(b.hist + static_cast<size_t>(w0 + j) * kHistRow)[tid]
+                               : make_int4(0, 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (w0 + j == me) mine = acc;
+        acc.x += h[j].x;
+        acc.y += h[j].y;
+        acc.z += h[j].z;
+        acc.w += h[j].w;
+      }
+    }
+    if (tid == 0) {
+      lstart[0] = 0;
+      s_nonempty = 0;
+    }
+    lstart[4 * tid + 1] = acc.x;
+    lstart[4 * tid + 2] = acc.y;
+    lstart[4 * tid + 3] = acc.z;
+    lstart[4 * tid + 4] = acc.w;
+    reinterpret_cast<int4 *>(lbase)[tid] = mine;
+  }
   __syncthreads();
+  // ---- starts: in-place inclusive scan of the ncell + 1 slots (consecutive slots per thread, <= 8: the host
+  // keeps the grid at 64 x 64; wave scan of the thread totals)
   {
     const int N = ncell + 1;
     const int per = (N + kSensorBlock - 1) / kSensorBlock;
@@ -293,7 +373,8 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_cells_kernel(SensorBigArg
     }
   }
   __syncthreads();
-  for (int k = tid; k <= ncell; k += kSensorBlock) a.cell_start[k] = lstart[k];
+  // ---- what the cost kernels read: cell starts, skip table, dc_enable -- 64 cells per wavefront, the wavefronts
+  // of all workgroups interleaved
   {
     const int lane = tid & 63, wave = tid >> 6;
     for (int y = wave; y < a.H; y += kSensorBlock / 64) {
@@ -301,43 +382,47 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_cells_kernel(SensorBigArg
       const unsigned long long m = __ballot(ne);
       if (lane == 0) {
         lmask[y] = m;
-        atomicAdd(&s_nonempty, __popcll(m));
+        if (me == 0) atomicAdd(&s_nonempty, __popcll(m));
       }
     }
-  }
-  __syncthreads();
-  if (tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
-  for (int k = tid; k < ncell; k += kSensorBlock) {
-    const int y = k / a.W, x = k - y * a.W;
-    unsigned long long acc = lmask[y];
-    int r = 0;
-    const int rmax = max(a.W, a.H);
-    for (;;) {
-      const int x0 = max(x - r, 0), x1 = min(x + r, a.W - 1);
-      const unsigned long long win = (x1 - x0 == 63) ? ~0ull : (((1ull << (x1 - x0 + 1)) - 1ull) << x0);
-      if (acc & win) break;
-      ++r;
-      if (r > rmax || r >= 255) {
-        r = 255;
-        break;
+    __syncthreads();
+    if (me == 0 && tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
+    if (me == 0 && tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
+    const int nb = gridDim.x;
+    for (int k = (wave * nb + me) * 64 + lane; k <= ncell; k += nb * kSensorBlock) {
+      a.cell_start[k] = lstart[k];
+      if (k == ncell) break;
+      const int y = k / a.W, x = k - y * a.W;
+      unsigned long long acc = lmask[y];
+      int r = 0;
+      const int rmax = max(a.W, a.H);
+      for (;;) {
+        const int x0 = max(x - r, 0), x1 = min(x + r, a.W - 1);
+        const unsigned long long win = (x1 - x0 == 63) ? ~0ull : (((1ull << (x1 - x0 + 1)) - 1ull) << x0);
+        if (acc & win) break;
+        ++r;
+        if (r > rmax || r >= 255) {
+          r = 255;
+          break;
+        }
+        if (y - r >= 0) acc |= lmask[y - r];
+        if (y + r < a.H) acc |= lmask[y + r];
       }
-      if (y - r >= 0) acc |= lmask[y - r];
-      if (y + r < a.H) acc |= lmask[y + r];
+      a.skip[k] = static_cast<uint8_t>(r);
     }
-    a.skip[k] = static_cast<uint8_t>(r);
   }
-  if (tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
-}
-
-__global__ __launch_bounds__(kSensorBigBlock) void sensor_scatter_kernel(SensorBigArgs b) {
-  const SensorArgs &a = b.a;
-  const int i = blockIdx.x * kSensorBigBlock + threadIdx.x;
-  if (i >= a.n) return;
-  const int rec = b.tcell[i];
-  if (rec < 0) return;
-  const int pos = a.cell_start[rec & 4095] + (rec >> 12);
-  a.bx[pos] = b.tox[i];
-  a.by[pos] = b.toy[i];
+  // ---- this workgroup's points into cell order
+  const int i0 = me * kSensorBlock * b.ppt;
+  for (int q = 0; q < b.ppt; ++q) {
+    const int i = i0 + q * kSensorBlock + tid;
+    if (i >= a.n) break;
+    const int rec = b.tcell[i];
+    if (rec < 0) continue;
+    const int id = rec & 4095;
+    const int pos = lstart[id] + lbase[id] + (rec >> 12);
+    a.bx[pos] = b.tox[i];
+    a.by[pos] = b.toy[i];
+  }
 }
 
 // ---- distance table for the far-obstacle searches of the cost kernels ---------------
