@@ -70,6 +70,8 @@ struct kc_dwa {
   long long grid_seq = 0;
   hipEvent_t grid_ready = nullptr;  // mapper stream -> this stream
   bool device_sensor = true;            // KC_SENSOR_HOST=1 turns the device-side update off
+  size_t sensor_big_min = 4096;         // clouds beyond this take the multi-workgroup build (crossover measured with
+                                        // tools/sensor_update_time.py; KC_SENSOR_BIG_MIN for that measurement)
   bool sensor_lds_ok = false;
   std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
   // occupancy bits of all accepted voxel columns over their bounding box
@@ -851,7 +853,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   }
   // one workgroup with everything in LDS, or (large clouds / bitmaps) the points
   // over many workgroups with device atomics
-  const bool big = n > 16384 || nwords * sizeof(uint32_t) > 64 * 1024;
+  const bool big = n > c->sensor_big_min || nwords * sizeof(uint32_t) > 64 * 1024;
   // bucket grid: covers the image of the bounding box (an affine map takes the
   // box into the hull of its eight transformed corners)
   double blo[2] = {DBL_MAX, DBL_MAX}, bhi[2] = {-DBL_MAX, -DBL_MAX};
@@ -956,12 +958,41 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     sb.toy = sb.tox + n;
     sb.hist = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(sb.toy + n) + 15) & ~uintptr_t(15));
     sb.bytes = c->d_sensor_bytes.p;
+#ifdef KC_PHASE_STAMPS
+    if (c->debug_stamps) {
+      KC_TRY(c->d_dbg.reserve(512 * 16));
+      KC_HIP(hipMemsetAsync(c->d_dbg.p, 0, 16 * 16 * 8, c->stream));
+      sb.dbg = c->d_dbg.p;
+    }
+#endif
     KC_TRY(c->timing.start("sensor_points_kernel", c->stream));
     hipLaunchKernelGGL(sensor_points_kernel, dim3(sb.rows), dim3(kSensorBlock), 0, c->stream, sb);
     KC_TRY(c->timing.stop(c->stream));
     KC_TRY(c->timing.start("sensor_place_kernel", c->stream));
-    hipLaunchKernelGGL(sensor_place_kernel, dim3(sb.rows), dim3(kSensorBlock), 0, c->stream, sb);
+    const unsigned pack_blocks = std::min(240u, blocks_for(nwords, kSensorBlock));  // pack-only workgroups behind the rows
+    hipLaunchKernelGGL(sensor_place_kernel, dim3(sb.rows + pack_blocks), dim3(kSensorBlock), 0, c->stream, sb);
     KC_TRY(c->timing.stop(c->stream));
+#ifdef KC_PHASE_STAMPS
+    if (sb.dbg) {
+      std::vector<unsigned long long> h(16 * 16);
+      KC_HIP(hipStreamSynchronize(c->stream));
+      KC_HIP(hipMemcpy(h.data(), c->d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull;
+      for (int r = 0; r < 16; ++r) if (h[r * 16]) t0 = std::min(t0, h[r * 16]);
+      static const char *nm[12] = {"points: start", "lds zero", "points done", "row out", "place: start", "sums", "scan", "masks",
+                                   "cells", "placed", "pack: start", "pack: end"};
+      std::fprintf(stderr, "[kc stamps] sensor build, us since the first points workgroup (avg / max over workgroups):\n");
+      for (int k = 0; k < 12; ++k) {
+        double sm = 0, mx = 0; int cnt = 0;
+        for (int r = 0; r < 16; ++r) {
+          if (!h[r * 16 + k]) continue;
+          const double us = (h[r * 16 + k] - t0) / 100.0;
+          sm += us; mx = std::max(mx, us); ++cnt;
+        }
+        if (cnt) std::fprintf(stderr, "  %-14s %6.2f / %6.2f\n", nm[k], sm / cnt, mx);
+      }
+    }
+#endif
   }
   KC_HIP(hipGetLastError());
   c->update_busy = true;
@@ -1826,6 +1857,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     }
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
+    if (const char *e = std::getenv("KC_SENSOR_BIG_MIN")) c->sensor_big_min = std::min<size_t>(16384, std::strtoul(e, nullptr, 10));
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
     if (const char *e = std::getenv("KC_LAZY_DILATE"))

@@ -212,9 +212,10 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
 //                         of a [workgroups][4096] matrix
 //   sensor_place_kernel   the same workgroups: each sums the matrix columns (its own row's
 //                         prefix on the way) and scans them (redundant, 2 us, instead of a
-//                         launch in between), puts its points into cell order, writes its
-//                         share of cell starts / skip table, and packs its share of the byte
-//                         map into the bitmap, clearing it behind (so neither needs a memset)
+//                         launch in between), puts its points into cell order and writes its
+//                         share of cell starts / skip table; further workgroups of the same
+//                         launch pack the byte map into the bitmap, clearing it behind (so
+//                         neither needs a memset)
 // Same per-point arithmetic as above; the order of the points inside a bucket is
 // as arbitrary as there.  Reference step: collision_check.h:91-136 (octree
 // rebuild) + cost_evaluator.h:174-223 (setPointScan).
@@ -229,14 +230,25 @@ struct SensorBigArgs {
   uint8_t *bytes;   // [gH][gwpr * 32] zero on entry, zero again when sensor_place_kernel is done
   float *tox, *toy; // [n] transformed coordinates (scratch)
   int *tcell;       // [n] cell id | rank inside its workgroup (< 16 k) << 12, -1: not an obstacle
+  unsigned long long *dbg;  // KC_PHASE_STAMPS builds: [16 workgroups][16] s_memrealtime stamps, or null
 };
+#ifdef KC_PHASE_STAMPS
+#define KC_SSTAMP(row, slot)                                                                         \
+  do {                                                                                               \
+    if (b.dbg && threadIdx.x == 0 && (row) < 16) b.dbg[(row) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define KC_SSTAMP(row, slot) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(kSensorBlock) void sensor_points_kernel(SensorBigArgs b) {
   const SensorArgs &a = b.a;
   __shared__ __align__(16) int lhist[kHistRow];
   const int tid = threadIdx.x;
+  KC_SSTAMP(blockIdx.x, 0);
   reinterpret_cast<int4 *>(lhist)[tid] = make_int4(0, 0, 0, 0);
   __syncthreads();
+  KC_SSTAMP(blockIdx.x, 1);
   auto point = [&](int i, float x, float y, float z) {
     // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
     const double fx = floor(a.inv_res * static_cast<double>(x));
@@ -281,7 +293,9 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_points_kernel(SensorBigAr
       if (pi[u] >= 0) point(pi[u], px[u], py[u], pz[u]);
   }
   __syncthreads();
+  KC_SSTAMP(blockIdx.x, 2);
   reinterpret_cast<int4 *>(b.hist + static_cast<size_t>(blockIdx.x) * kHistRow)[tid] = reinterpret_cast<int4 *>(lhist)[tid];
+  KC_SSTAMP(blockIdx.x, 3);
 }
 
 __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArgs b) {
@@ -294,24 +308,46 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
   __shared__ int s_nonempty;
   const int tid = threadIdx.x;
   const int me = blockIdx.x;
-  // ---- byte map -> bitmap, bytes cleared behind -------------------------------------------------------
-  {
+  // ---- byte map -> bitmap, bytes cleared behind: the workgroups beyond the rows do only this -------------
+  if (me >= b.rows) {
+    KC_SSTAMP(me - b.rows, 10);
     const size_t nwords = static_cast<size_t>(a.gH) * a.gwpr;
-    for (size_t w = static_cast<size_t>(me) * kSensorBlock + tid; w < nwords; w += static_cast<size_t>(gridDim.x) * kSensorBlock) {
-      ulonglong2 *src = reinterpret_cast<ulonglong2 *>(b.bytes + (w << 5));
-      const ulonglong2 lo = src[0], hi = src[1];
+    const size_t stride = static_cast<size_t>(gridDim.x - b.rows) * kSensorBlock;
+    for (size_t w0 = static_cast<size_t>(me - b.rows) * kSensorBlock + tid; w0 < nwords; w0 += 4 * stride) {
       // bytes are 0 / 1: (v * 0x0102040810204080) >> 56 gathers byte i into bit i (all partial products
-      // fall on distinct bit positions: no carries)
+      // fall on distinct bit positions: no carries).  Four words per trip, their loads issued together.
       constexpr unsigned long long kGather = 0x0102040810204080ull;
-      const uint32_t bits = static_cast<uint32_t>((lo.x * kGather) >> 56) | static_cast<uint32_t>((lo.y * kGather) >> 56) << 8 |
-                            static_cast<uint32_t>((hi.x * kGather) >> 56) << 16 | static_cast<uint32_t>((hi.y * kGather) >> 56) << 24;
-      a.gbits[w] = bits;
-      if (bits) {
-        src[0] = make_ulonglong2(0ull, 0ull);
-        src[1] = make_ulonglong2(0ull, 0ull);
+      ulonglong2 lo[4], hi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t w = w0 + u * stride;
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(b.bytes + ((w < nwords ? w : w0) << 5));
+        lo[u] = src[0];
+        hi[u] = src[1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t w = w0 + u * stride;
+        if (w >= nwords) break;
+        const uint32_t bits = static_cast<uint32_t>((lo[u].x * kGather) >> 56) | static_cast<uint32_t>((lo[u].y * kGather) >> 56) << 8 |
+                              static_cast<uint32_t>((hi[u].x * kGather) >> 56) << 16 | static_cast<uint32_t>((hi[u].y * kGather) >> 56) << 24;
+        a.gbits[w] = bits;
+        if (bits) {
+          ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(b.bytes + (w << 5));
+          dst[0] = make_ulonglong2(0ull, 0ull);
+          dst[1] = make_ulonglong2(0ull, 0ull);
+        }
       }
     }
+    KC_SSTAMP(me - b.rows, 11);
+    return;
   }
+  KC_SSTAMP(me, 4);
+  // this workgroup's first point records, asked for now and used at the very end
+  const int i_first = me * kSensorBlock * b.ppt + tid;
+  const bool have_first = i_first < a.n;
+  const int rec_first = have_first ? b.tcell[i_first] : -1;
+  const float ox_first = have_first ? b.tox[i_first] : 0.0f, oy_first = have_first ? b.toy[i_first] : 0.0f;
   // ---- column sums of the histogram matrix (four cells per thread) -----------------------------------------
   {
     int4 acc = make_int4(0, 0, 0, 0), mine = make_int4(0, 0, 0, 0);
@@ -341,6 +377,7 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
     reinterpret_cast<int4 *>(lbase)[tid] = mine;
   }
   __syncthreads();
+  KC_SSTAMP(me, 5);
   // ---- starts: in-place inclusive scan of the ncell + 1 slots (consecutive slots per thread, <= 8: the host
   // keeps the grid at 64 x 64; wave scan of the thread totals)
   {
@@ -373,6 +410,7 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
     }
   }
   __syncthreads();
+  KC_SSTAMP(me, 6);
   // ---- what the cost kernels read: cell starts, skip table, dc_enable -- 64 cells per wavefront, the wavefronts
   // of all workgroups interleaved
   {
@@ -386,9 +424,10 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
       }
     }
     __syncthreads();
+    KC_SSTAMP(me, 7);
     if (me == 0 && tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
     if (me == 0 && tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
-    const int nb = gridDim.x;
+    const int nb = b.rows;
     for (int k = (wave * nb + me) * 64 + lane; k <= ncell; k += nb * kSensorBlock) {
       a.cell_start[k] = lstart[k];
       if (k == ncell) break;
@@ -411,10 +450,16 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
       a.skip[k] = static_cast<uint8_t>(r);
     }
   }
+  KC_SSTAMP(me, 8);
   // ---- this workgroup's points into cell order
-  const int i0 = me * kSensorBlock * b.ppt;
-  for (int q = 0; q < b.ppt; ++q) {
-    const int i = i0 + q * kSensorBlock + tid;
+  if (rec_first >= 0) {
+    const int id = rec_first & 4095;
+    const int pos = lstart[id] + lbase[id] + (rec_first >> 12);
+    a.bx[pos] = ox_first;
+    a.by[pos] = oy_first;
+  }
+  for (int q = 1; q < b.ppt; ++q) {
+    const int i = i_first + q * kSensorBlock;
     if (i >= a.n) break;
     const int rec = b.tcell[i];
     if (rec < 0) continue;
@@ -423,6 +468,7 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
     a.bx[pos] = b.tox[i];
     a.by[pos] = b.toy[i];
   }
+  KC_SSTAMP(me, 9);
 }
 
 // ---- distance table for the far-obstacle searches of the cost kernels ---------------

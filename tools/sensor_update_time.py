@@ -12,6 +12,8 @@ ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 
                     max_points=P, max_segment=S, max_obstacles=len(inp["points"]), acc_limits=inp["acc_limits"])
 ctx.set_weights(kh.make_weights(*inp["weights"]))
 pts = np.ascontiguousarray(inp["points"], dtype=np.float32)
+if len(sys.argv) > 3:   # a subset of the points (every k-th)
+    pts = np.ascontiguousarray(pts[:: max(1, len(pts) // int(sys.argv[3]))][: int(sys.argv[3])])
 print(name, "points", len(pts))
 ctx.set_points(inp["state"], pts, inp["max_range"])
 ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
