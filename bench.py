@@ -755,8 +755,14 @@ def ref_cost5k_bench(args):
     ms = 1e3 * el / steps
     dom = max(kms, key=lambda k: np.mean(kms[k]))
     dom_ms = float(np.mean(kms[dom]))
-    # per launch: every trajectory point read once (8 B) + velocities (12 B per step) + cost out + segment
-    bytes_launch = 8 * N * P + 12 * N * (P - 1) + 4 * N + 16 * S
+    # algorithmic bytes of the dominant kernel.  velocity_sums_kernel: velocities (12 B per step) + two sums per
+    # trajectory; sample_cost_kernel: every trajectory point once (8 B) + cost out + segment, plus the
+    # velocities when it forms the sums itself (option velocity_group = 1 / small batches)
+    vel_bytes = 12 * N * (P - 1)
+    if dom == "velocity_sums_kernel":
+        bytes_launch = vel_bytes + 8 * N
+    else:
+        bytes_launch = 8 * N * P + 4 * N + 16 * S + (0 if "velocity_sums_kernel" in kms else vel_bytes)
     out = {
         "metric": "CostEvaluator_5k_Trajs (reference benchmark suite), ms per getMinTrajectoryCost",
         "value": ms, "unit": "ms", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": ms,
@@ -773,7 +779,9 @@ def ref_cost5k_bench(args):
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_launch / (dom_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_launch / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": dom_ms,
-                     "note": "VALU-bound: 5.0e9 point x segment-point pairs per call before pruning"},
+                     "note": "not an HBM-bound path: the smoothness / jerk sums are serial f64 chains (9 dependent "
+                             "instructions per step, velocity_sums_kernel: 4 samples per wavefront), the segment search "
+                             "is VALU-issue bound (5.0e9 point x segment-point pairs per call before pruning)"},
         "winner": {"found": bool(r.found), "index": int(r.index), "cost": float(r.cost)},
     }
     if not args.no_cpu:

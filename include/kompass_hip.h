@@ -141,6 +141,10 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "cycle_samples"  (0) samples per workgroup of the single-launch cycle: 0 = 32, or 16 when
  *                        32 would give at most half of the CUs a workgroup (shards <= 4096
  *                        samples on an MI355X); 16 / 32: fixed
+ *   "velocity_group" (0) kc_cost_evaluate with velocity profiles: samples per wavefront of the
+ *                        ordered smoothness / jerk sums -- 1: inside the cost kernel, 4 / 16: a
+ *                        pass of its own (velocity_sums_kernel); 0: by batch size (1 below
+ *                        ~5 profiles per SIMD, 16 from ~96)
  *   "near_table"   (128) cells per side (16..512) of the near table of the tracked segment
  *                        (per cell of a grid over the reachable box: the chunk range that can
  *                        hold a point's nearest segment point + a seed), built when the

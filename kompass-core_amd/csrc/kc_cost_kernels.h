@@ -93,6 +93,7 @@ struct CostArgs {
   float seg_len, ref_len;
   BucketDev b;
   const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
+  const float *vsum_smooth, *vsum_jerk;  // [n] ordered sums of velocity_sums_kernel, or null: formed in the cost kernel
   float max_obs_dist;
   float acc0, acc1, acc2;
   double w_path, w_goal, w_obs, w_smooth, w_jerk;
@@ -726,11 +727,77 @@ __device__ __forceinline__ float add_velocity_costs(const CostArgs &a, int n, fl
   const float *vy = a.vvy + (size_t)n * nv;
   const float *om = a.vom + (size_t)n * nv;
   const float div = static_cast<float>(3L * nv);
+  // (large batches: the sums come from velocity_sums_kernel, several samples per wavefront)
   if (a.w_smooth > 0.0)  // cost_evaluator.cpp:187-206
-    total = accum(total, a.w_smooth, kc::div_rn(velocity_cost_sum<false>(a, vx, vy, om, nv, lane), div));
+    total = accum(total, a.w_smooth,
+                  kc::div_rn(a.vsum_smooth ? a.vsum_smooth[n] : velocity_cost_sum<false>(a, vx, vy, om, nv, lane), div));
   if (a.w_jerk > 0.0)  // cost_evaluator.cpp:209-233
-    total = accum(total, a.w_jerk, kc::div_rn(velocity_cost_sum<true>(a, vx, vy, om, nv, lane), div));
+    total = accum(total, a.w_jerk,
+                  kc::div_rn(a.vsum_jerk ? a.vsum_jerk[n] : velocity_cost_sum<true>(a, vx, vy, om, nv, lane), div));
   return total;
+}
+
+// The same sums for LARGE batches of velocity profiles (the reference's CostEvaluator_5k workload: 5001
+// profiles of 999 steps).  The additions of one profile are a serial chain -- nine dependent instructions per
+// step however many lanes watch -- so a wavefront per sample spends 9 wave instructions per step (5001 x 999 x
+// 9 x 2 = 90 M of the 164 M the whole evaluation issued, VALU-issue bound).  Here a wavefront carries
+// 64 / kLanes samples at once: kLanes consecutive steps of a sample sit in neighbouring lanes, the running float
+// walks them by a DPP rotation inside the group (row_ror for 16 lanes, quad_perm for 4), and the last lane of a
+// group keeps the sum between tiles -- lane 0 reads it back through the rotation, so no carry is handed
+// around.  Lanes a rotation has not reached yet compute on stale values; only the last lane's value after
+// kLanes rounds is used.  Fewer, longer-running wavefronts: a lone wavefront issues one of these dependent f64
+// instructions every ~14-26 cycles (SQ_WAVE_CYCLES / SQ_INSTS_VALU), six per SIMD hide that -- 4 samples per
+// wavefront pay from ~5 chains per SIMD on (cost5k: 222 -> 115 us for both sums), 16 only for batches near 10^5.
+// blockIdx.y: 0 smoothness, 1 jerk (when both are asked for).
+struct VelSumArgs {
+  const float *vx, *vy, *om;  // [n][nv]
+  int n, nv;
+  float acc0, acc1, acc2;
+  float *out[2];              // [n] smoothness / jerk sums (the float the reference divides by 3 (P - 1))
+  int first_kind;             // 0: blockIdx.y = 0 is smoothness; 1: only jerk is asked for
+};
+template <bool kJerk, int kLanes>
+__device__ __forceinline__ void velocity_sums_group(const VelSumArgs &a, float *out) {
+  constexpr int k_first = kJerk ? 2 : 1;
+  constexpr int kGroups = 64 / kLanes;
+  constexpr int kRotate = kLanes == 4 ? 0x93 /* quad_perm:[3,0,1,2] */ : 0x121 /* row_ror:1 */;
+  const int lane = threadIdx.x & 63;
+  const int j = lane % kLanes;
+  const int n = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kGroups + lane / kLanes;
+  const bool valid = n < a.n;
+  const float *vx = a.vx + static_cast<size_t>(valid ? n : 0) * a.nv;
+  const float *vy = a.vy + static_cast<size_t>(valid ? n : 0) * a.nv;
+  const float *om = a.om + static_cast<size_t>(valid ? n : 0) * a.nv;
+  float r = 0.0f;
+  for (int k0 = k_first; k0 < a.nv; k0 += kLanes) {
+    const int k = k0 + j;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if (valid && k < a.nv) {
+      auto term = [&](const float *v, float lim) {
+        const float d = kJerk ? v[k] - 2 * v[k - 1] + v[k - 2] : v[k] - v[k - 1];
+        const double dd = static_cast<double>(d);
+        return (dd * dd) / static_cast<double>(lim);
+      };
+      if (a.acc0 > 0) t0 = term(vx, a.acc0);
+      if (a.acc1 > 0) t1 = term(vy, a.acc1);
+      if (a.acc2 > 0) t2 = term(om, a.acc2);
+    }
+#pragma unroll
+    for (int q = 0; q < kLanes; ++q) {
+      const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), kRotate, 0xf, 0xf, false));
+      float v = static_cast<float>(static_cast<double>(prev) + t0);
+      v = static_cast<float>(static_cast<double>(v) + t1);
+      r = static_cast<float>(static_cast<double>(v) + t2);
+    }
+  }
+  if (valid && j == kLanes - 1) out[n] = r;
+}
+template <int kLanes>
+__global__ __launch_bounds__(256) void velocity_sums_kernel(VelSumArgs a) {
+  if (blockIdx.y + a.first_kind == 0)
+    velocity_sums_group<false, kLanes>(a, a.out[0]);
+  else
+    velocity_sums_group<true, kLanes>(a, a.out[1]);
 }
 
 // obstaclesDistCostFunc, cost_evaluator.cpp:179-184, from the minimum squared distance (double)

@@ -121,6 +121,8 @@ struct kc_dwa {
   int cycle_samples = 32;  // samples per workgroup of the single-launch cycle: 16 when 32 would leave half the CUs idle
   int perm_cs = 0;         // ... the dealt order on the device was built for
   int cycle_samples_opt = 0;  // option "cycle_samples": 0 auto, 16, 32
+  int velocity_group = 0;     // option "velocity_group": samples per wavefront of the velocity sums (0 auto, 1, 4, 16)
+  DevBuf<float> d_vsum;       // [2][n] smoothness / jerk sums of velocity_sums_kernel
   bool fused_shape_fixed = false;  // KC_FUSED_CFG given: no per-lattice choice of the roll-out tile
   bool have_sensor = false;
 
@@ -1428,6 +1430,40 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   DcArgs dt{};
   KC_TRY(build_cost_args(c, n, first, ca, dt));
   const size_t S = c->S;
+  if (ca.have_vel && (ca.w_smooth > 0.0 || ca.w_jerk > 0.0) && n == c->n_roll && first == 0) {
+    // ordered sums of the velocity profiles.  One sample per wavefront inside the cost kernel while the
+    // batch leaves a SIMD fewer than ~5 of these serial chains (latency bound either way); beyond, 4 samples
+    // per wavefront in a pass of their own (a quarter of the chain instructions), 16 for batches that still
+    // give every SIMD several chains then (tools/cost5k_terms.py)
+    const int kinds = (ca.w_smooth > 0.0 ? 1 : 0) + (ca.w_jerk > 0.0 ? 1 : 0);
+    const size_t simds = 4 * static_cast<size_t>(c->num_cus);
+    int group = c->velocity_group;
+    if (group == 0) group = kinds * n < 5 * simds ? 1 : (kinds * n < 96 * simds ? 4 : 16);
+    if (group > 1) {
+      KC_TRY(c->d_vsum.reserve(2 * n));
+      VelSumArgs va{};
+      va.vx = c->d_vvx.p;
+      va.vy = c->d_vvy.p;
+      va.om = c->d_vom.p;
+      va.n = static_cast<int>(n);
+      va.nv = static_cast<int>(P - 1);
+      va.acc0 = ca.acc0;
+      va.acc1 = ca.acc1;
+      va.acc2 = ca.acc2;
+      va.out[0] = c->d_vsum.p;
+      va.out[1] = c->d_vsum.p + n;
+      va.first_kind = ca.w_smooth > 0.0 ? 0 : 1;
+      const dim3 grid(blocks_for(n, 4 * static_cast<size_t>(group)), kinds);  // four wavefronts per workgroup
+      KC_TRY(c->timing.start("velocity_sums_kernel", s));
+      if (group == 4)
+        hipLaunchKernelGGL(velocity_sums_kernel<16>, grid, dim3(256), 0, s, va);
+      else
+        hipLaunchKernelGGL(velocity_sums_kernel<4>, grid, dim3(256), 0, s, va);
+      KC_TRY(c->timing.stop(s));
+      if (ca.w_smooth > 0.0) ca.vsum_smooth = va.out[0];
+      if (ca.w_jerk > 0.0) ca.vsum_jerk = va.out[1];
+    }
+  }
   if (c->need_compact) {  // split roll-out path / external samples
     KC_TRY(c->timing.start("compact_kernel", s));
     hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, c->d_flags.p,
@@ -1991,6 +2027,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_raw.release();
   c->d_sensor_tmp.release();
   c->d_sensor_bytes.release();
+  c->d_vsum.release();
   c->d_dc.release();
   c->d_dc_enable.release();
   c->d_gridcnt.release();
@@ -2083,6 +2120,9 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   } else if (n == "cycle_samples") {
     if (!(v == 0.0 || v == 16.0 || v == 32.0)) KC_FAIL(KC_ERR_RANGE, "cycle_samples: 0 (by shard size), 16 or 32");
     c->cycle_samples_opt = static_cast<int>(v);
+  } else if (n == "velocity_group") {
+    if (!(v == 0.0 || v == 1.0 || v == 4.0 || v == 16.0)) KC_FAIL(KC_ERR_RANGE, "velocity_group: 0 (by batch size), 1, 4 or 16");
+    c->velocity_group = static_cast<int>(v);
   } else if (n == "near_table") {
     if (v != 0.0 && !(v >= 16.0 && v <= 512.0)) KC_FAIL(KC_ERR_RANGE, "near_table: 0 (off) or 16..512 cells per side");
     c->near_side = static_cast<int>(v);
@@ -2111,6 +2151,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "lazy_dilate") *v = c->lazy_dilate;
   else if (n == "near_table") *v = c->near_side;
   else if (n == "cycle_samples") *v = c->cycle_samples_opt;
+  else if (n == "velocity_group") *v = c->velocity_group;
   else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "sensor_on_host") *v = !c->device_sensor;

@@ -191,6 +191,12 @@ def test_cost_evaluate_random_with_velocities():
     r, hcosts = ctx.cost_evaluate(px, py, vel)
     np.testing.assert_array_equal(hcosts.view(np.uint32), ocosts.view(np.uint32))
     assert r.found and r.index == oi and np.float32(r.cost) == np.float32(oc)
+    # the velocity sums by the pass of their own (N and P - 1 multiples of neither 4 nor 16, an axis without a limit)
+    for group in (4, 16, 1):
+        ctx.set_option("velocity_group", group)
+        r, hcosts = ctx.cost_evaluate(px, py, vel)
+        np.testing.assert_array_equal(hcosts.view(np.uint32), ocosts.view(np.uint32))
+        assert r.found and r.index == oi
     # lowest-index tie-break: duplicate the winner in front of itself
     px2 = np.concatenate([px[oi:oi + 1], px]); py2 = np.concatenate([py[oi:oi + 1], py])
     vel2 = [np.concatenate([v[oi:oi + 1], v]) for v in vel]

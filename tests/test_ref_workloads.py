@@ -45,6 +45,33 @@ def test_cost5k_every_cost_equals_oracle(cost5k, kernel):
     ctx.close()
 
 
+@pytest.mark.parametrize("group", [1, 4, 16])
+@pytest.mark.parametrize("weights", [(1, 1, 0, 1, 1), (0, 0, 0, 1, 0), (0, 0, 0, 0, 1)], ids=["all", "smoothness", "jerk"])
+def test_cost5k_velocity_sums_by_group(cost5k, group, weights):
+    """Option velocity_group: the ordered smoothness / jerk sums inside the cost kernel (1 sample per wavefront)
+    or by velocity_sums_kernel (4 / 16 samples per wavefront, DPP rotation inside 16- / 4-lane groups) --
+    the same bits; also with only one of the two costs asked for (the pass then runs one kind)."""
+    w, oi, oc, ocosts = cost5k
+    N, P = w["px"].shape
+    if weights != tuple(w["weights"]):
+        ci = ko.CostInputs(w["seg"], w["s0"], w["acc"], w["total"], None, np.float32(10.0) / np.float32(3.0),
+                           w["acc_limits"], ko.make_weights(*weights))
+        oi, oc, ocosts = ko.costs_mt(ci, w["px"], w["py"], w["vel"])
+    ctx = kh.DwaContext(syn.CYLINDER, [0.1, 0.4], max_samples=N, max_points=P, max_segment=len(w["seg"]),
+                        acc_limits=w["acc_limits"])
+    assert ctx.get_option("velocity_group") == 0
+    ctx.set_option("velocity_group", group)
+    ctx.set_weights(kh.make_weights(*weights))
+    ctx.set_tracked_segment(w["seg"], w["acc"][w["s0"]:w["s0"] + len(w["seg"])], w["total"])
+    ctx.cost_upload(w["px"], w["py"], w["vel"])
+    r, costs = ctx.cost_evaluate_resident()
+    np.testing.assert_array_equal(costs.view(np.uint32), ocosts.view(np.uint32))
+    assert r.found and r.index == oi and np.float32(r.cost) == np.float32(oc)
+    with pytest.raises(IndexError):   # KC_ERR_RANGE
+        ctx.set_option("velocity_group", 8)
+    ctx.close()
+
+
 def test_mapper400_grid_equals_oracle():
     g = syn.REF_MAPPER400
     ang, rng = syn.dense_scan(g["beams"], 1.0)
