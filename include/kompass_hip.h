@@ -145,6 +145,9 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        ordered smoothness / jerk sums -- 1: inside the cost kernel, 4 / 16: a
  *                        pass of its own (velocity_sums_kernel); 0: by batch size (1 below
  *                        ~5 profiles per SIMD, 16 from ~96)
+ *   "velocity_beside" (1) that pass on a second stream beside the wavefront-per-sample cost kernel
+ *                        (its serial chains leave most issue slots idle); a short kernel behind both
+ *                        adds the two terms and forms the keys.  0: one after the other
  *   "near_table"   (128) cells per side (16..512) of the near table of the tracked segment
  *                        (per cell of a grid over the reachable box: the chunk range that can
  *                        hold a point's nearest segment point + a seed), built when the

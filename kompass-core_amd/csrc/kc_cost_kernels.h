@@ -85,6 +85,8 @@ struct CostArgs {
   const uint8_t *flags;
   const int *adm_list;            // admissible local sample ids (any order)
   const long long *adm_count;     // device-side count (result[W_LIST])
+  int identity_n;                 // > 0: caller-provided batch, every sample admissible -- the list is 0 .. identity_n - 1
+                                  // and neither adm_list nor adm_count is read (no compact_kernel in front)
   const float *sx, *sy, *sz, *szz, *acc_seg;  // contiguous rows [5][S], then the chunk capsules
                                                // (from a 16-byte boundary) [nch] records of 8 floats
                                                // (struct Capsule), then the super-chunk spheres
@@ -94,6 +96,8 @@ struct CostArgs {
   BucketDev b;
   const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
   const float *vsum_smooth, *vsum_jerk;  // [n] ordered sums of velocity_sums_kernel, or null: formed in the cost kernel
+  int defer_vel;                  // 1: velocity_sums_kernel runs beside this kernel (second stream); the totals
+                                  // stop in front of smoothness / jerk, velocity_finish_kernel adds them and forms the keys
   float max_obs_dist;
   float acc0, acc1, acc2;
   double w_path, w_goal, w_obs, w_smooth, w_jerk;
@@ -800,6 +804,21 @@ __global__ __launch_bounds__(256) void velocity_sums_kernel(VelSumArgs a) {
     velocity_sums_group<true, kLanes>(a, a.out[1]);
 }
 
+// Behind a cost kernel that ran with defer_vel (beside velocity_sums_kernel on a second stream): the last two
+// terms of getMinTrajectoryCost (cost_evaluator.cpp:49-109: ... smoothness, jerk) onto the stored totals, and
+// the per-workgroup keys for publish_kernel.
+struct VelFinishArgs {
+  const int *adm_list;
+  const long long *adm_count;
+  int identity_n;               // as in CostArgs
+  float *costs;                 // [n] in: total in front of smoothness; out: total
+  const float *vsum_smooth, *vsum_jerk;  // null: weight 0
+  double w_smooth, w_jerk;
+  float div;                    // 3 (P - 1)
+  int first;
+  long long *block_keys;        // [gridDim.x]
+};
+
 // obstaclesDistCostFunc, cost_evaluator.cpp:179-184, from the minimum squared distance (double)
 __device__ __forceinline__ float obstacle_cost_from(const CostArgs &a, double best) {
   const float min_d2 = static_cast<float>(best);
@@ -851,7 +870,7 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
   __shared__ unsigned long long s_obest;  // sample-wide min squared obstacle distance (double bits)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
-    const int na = static_cast<int>(*a.adm_count);
+    const int na = a.identity_n > 0 ? a.identity_n : static_cast<int>(*a.adm_count);
   // blocks beyond the admissible count have nothing to do and take no ticket
   const unsigned working = static_cast<unsigned>(min(static_cast<int>(gridDim.x), max(na, 1)));
   if (blockIdx.x >= working) {
@@ -905,7 +924,7 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
   const RowPts pts{s_px, s_py};
 
   for (int i = blockIdx.x; i < na; i += gridDim.x) {
-    const int n = a.adm_list[i];
+    const int n = a.identity_n > 0 ? i : a.adm_list[i];
     if (threadIdx.x == 0)
       s_obest = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
     if (threadIdx.x < a.P) {
@@ -1363,7 +1382,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
     total = accum(total, a.w_obs,
                   obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(
                                             *const_cast<volatile unsigned long long *>(obest)))));
-  if (a.have_vel) total = add_velocity_costs(a, n, total, lane);
+  if (a.have_vel && !a.defer_vel) total = add_velocity_costs(a, n, total, lane);
   // constant-velocity samples: both terms are exactly 0 and `total += w*0`
   // leaves total unchanged, so nothing to do when !have_vel.
   return total;
@@ -1381,7 +1400,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform
   KC_STAMP(0);
-  const int na = static_cast<int>(*a.adm_count);
+  const int na = a.identity_n > 0 ? a.identity_n : static_cast<int>(*a.adm_count);
   KC_STAMP(1);
   const BucketDev &b = a.b;
   const int ncell = b.W * b.H;
@@ -1446,7 +1465,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
     slot = __builtin_amdgcn_readfirstlane(slot);
     const int i = slot * static_cast<int>(gridDim.x) + static_cast<int>(blockIdx.x);
     if (i >= na) break;
-    const int n = a.adm_list[i];
+    const int n = a.identity_n > 0 ? i : a.adm_list[i];
     const RowPts pts{a.px + (size_t)n * a.P, a.py + (size_t)n * a.P};
 #ifdef KC_PHASE_STAMPS
     const bool stamp = a.dbg && wave == 0 && !stamped;  // first sample of wavefront 0
@@ -1463,7 +1482,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
                                 cells, skip, obx, oby, pts, n, lane, &s_obest[wave], stamp);
     if (lane == 0) a.costs[n] = total;
     if (stamp) KC_STAMP(3);
-    if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
+    if (total < FLT_MAX && !a.defer_vel) {  // `total_cost < minCost`, minCost starts at FLT_MAX
       const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
       wkey = k < wkey ? k : wkey;
     }
@@ -1482,6 +1501,28 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
 // stream wait) and the re-arming of the working slots.  A kernel boundary
 // instead of a device-wide "last block" ticket: hundreds of same-address
 // atomics cost more than the dispatch of this kernel.
+__global__ __launch_bounds__(256) void velocity_finish_kernel(VelFinishArgs a) {
+  __shared__ long long s_key;
+  if (threadIdx.x == 0) s_key = KEY_NONE;
+  __syncthreads();
+  const int na = a.identity_n > 0 ? a.identity_n : static_cast<int>(*a.adm_count);
+  long long wkey = KEY_NONE;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < na; i += gridDim.x * 256) {
+    const int n = a.identity_n > 0 ? i : a.adm_list[i];
+    float total = a.costs[n];
+    if (a.vsum_smooth) total = accum(total, a.w_smooth, kc::div_rn(a.vsum_smooth[n], a.div));
+    if (a.vsum_jerk) total = accum(total, a.w_jerk, kc::div_rn(a.vsum_jerk[n], a.div));
+    a.costs[n] = total;
+    if (total < FLT_MAX) {  // `total_cost < minCost`, minCost starts at FLT_MAX
+      const long long k = key_pack(total, static_cast<uint32_t>(a.first + n));
+      wkey = k < wkey ? k : wkey;
+    }
+  }
+  if (wkey != KEY_NONE) atomicMin(&s_key, wkey);
+  __syncthreads();
+  if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
+}
+
 struct PubArgs {
   const long long *block_keys;
   int nblocks;
@@ -1490,6 +1531,7 @@ struct PubArgs {
   long long *result;
   long long *host_pub;
   long long seq;
+  int identity_n;  // > 0: the admissible count of a batch that had no list (CostArgs::identity_n)
 };
 constexpr int kPubBlock = 512;
 __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
@@ -1502,7 +1544,7 @@ __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
     const long long v = a.block_keys[b];
     k = v < k ? v : k;
   }
-  const long long na = a.result[W_LIST];
+  const long long na = a.identity_n > 0 ? a.identity_n : a.result[W_LIST];
   const long long err = a.result[W_NADM];  // device error word (roll-out gave up waiting)
   for (int off = 32; off > 0; off >>= 1) {
     const long long o = __shfl_xor(k, off, 64);

@@ -122,6 +122,9 @@ struct kc_dwa {
   int perm_cs = 0;         // ... the dealt order on the device was built for
   int cycle_samples_opt = 0;  // option "cycle_samples": 0 auto, 16, 32
   int velocity_group = 0;     // option "velocity_group": samples per wavefront of the velocity sums (0 auto, 1, 4, 16)
+  bool velocity_beside = true;  // option "velocity_beside": velocity_sums_kernel on a second stream beside the cost kernel
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   DevBuf<float> d_vsum;       // [2][n] smoothness / jerk sums of velocity_sums_kernel
   bool fused_shape_fixed = false;  // KC_FUSED_CFG given: no per-lattice choice of the roll-out tile
   bool have_sensor = false;
@@ -1430,6 +1433,9 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   DcArgs dt{};
   KC_TRY(build_cost_args(c, n, first, ca, dt));
   const size_t S = c->S;
+  bool vel_beside = false;
+  VelFinishArgs vf{};
+  std::function<int()> vel_launch;
   if (ca.have_vel && (ca.w_smooth > 0.0 || ca.w_jerk > 0.0) && n == c->n_roll && first == 0) {
     // ordered sums of the velocity profiles.  One sample per wavefront inside the cost kernel while the
     // batch leaves a SIMD fewer than ~5 of these serial chains (latency bound either way); beyond, 4 samples
@@ -1454,17 +1460,53 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
       va.out[1] = c->d_vsum.p + n;
       va.first_kind = ca.w_smooth > 0.0 ? 0 : 1;
       const dim3 grid(blocks_for(n, 4 * static_cast<size_t>(group)), kinds);  // four wavefronts per workgroup
-      KC_TRY(c->timing.start("velocity_sums_kernel", s));
-      if (group == 4)
-        hipLaunchKernelGGL(velocity_sums_kernel<16>, grid, dim3(256), 0, s, va);
-      else
-        hipLaunchKernelGGL(velocity_sums_kernel<4>, grid, dim3(256), 0, s, va);
-      KC_TRY(c->timing.stop(s));
-      if (ca.w_smooth > 0.0) ca.vsum_smooth = va.out[0];
-      if (ca.w_jerk > 0.0) ca.vsum_jerk = va.out[1];
+      // Beside the wavefront-per-sample cost kernel on a second stream: these chains leave most issue slots
+      // of their SIMDs idle, the segment searches fill them (not while kernels are being timed one by one)
+      vel_beside = !use_block && !c->timing.enabled && c->velocity_beside;
+      hipStream_t vs = s;
+      if (vel_beside) {
+        if (!c->aux_stream) {
+          KC_HIP(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+          KC_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+          KC_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+        }
+        vs = c->aux_stream;
+        KC_HIP(hipEventRecord(c->aux_fork, s));  // behind everything queued so far (the last reader of d_vsum too)
+        KC_HIP(hipStreamWaitEvent(vs, c->aux_fork, 0));
+      }
+      vel_launch = [=]() -> int {
+        KC_TRY(c->timing.start("velocity_sums_kernel", vs));
+        if (group == 4)
+          hipLaunchKernelGGL(velocity_sums_kernel<16>, grid, dim3(256), 0, vs, va);
+        else
+          hipLaunchKernelGGL(velocity_sums_kernel<4>, grid, dim3(256), 0, vs, va);
+        KC_TRY(c->timing.stop(vs));
+        return KC_OK;
+      };
+      if (!vel_beside) KC_TRY(vel_launch());  // in front of the cost kernel, same stream
+      if (vel_beside) {
+        ca.defer_vel = 1;
+        vf.adm_list = ca.adm_list;
+        vf.adm_count = ca.adm_count;
+        vf.costs = ca.costs;
+        vf.vsum_smooth = ca.w_smooth > 0.0 ? va.out[0] : nullptr;
+        vf.vsum_jerk = ca.w_jerk > 0.0 ? va.out[1] : nullptr;
+        vf.w_smooth = ca.w_smooth;
+        vf.w_jerk = ca.w_jerk;
+        vf.div = static_cast<float>(3L * static_cast<long>(P - 1));
+        vf.first = ca.first;
+      } else {
+        if (ca.w_smooth > 0.0) ca.vsum_smooth = va.out[0];
+        if (ca.w_jerk > 0.0) ca.vsum_jerk = va.out[1];
+      }
     }
   }
-  if (c->need_compact) {  // split roll-out path / external samples
+  // caller-provided batches: every sample is admissible (kc_cost_upload), the list is the identity
+  if (c->external && n == c->n_roll && first == 0) {
+    ca.identity_n = static_cast<int>(n);
+    vf.identity_n = ca.identity_n;
+  }
+  if (c->need_compact && ca.identity_n == 0) {  // split roll-out path
     KC_TRY(c->timing.start("compact_kernel", s));
     hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, s, c->d_flags.p,
                        static_cast<int>(n), c->d_adm.p, c->d_result.p + W_LIST);
@@ -1524,6 +1566,16 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
                          0, s, ca, dt);
   }
   KC_TRY(c->timing.stop(s));
+  if (vel_beside) {
+    // queued BEHIND the cost kernel: its one-per-CU workgroups take their registers first, the chains' small
+    // workgroups fill what is left (the other way round the cost kernel waits for CUs the chains have filled)
+    KC_TRY(vel_launch());
+    KC_HIP(hipEventRecord(c->aux_join, c->aux_stream));
+    KC_HIP(hipStreamWaitEvent(s, c->aux_join, 0));
+    cost_blocks = std::min(512u, blocks_for(n, 256));
+    vf.block_keys = c->d_block_keys.p;
+    hipLaunchKernelGGL(velocity_finish_kernel, dim3(cost_blocks), dim3(256), 0, s, vf);
+  }
   {
     PubArgs pa{};
     pa.block_keys = c->d_block_keys.p;
@@ -1534,6 +1586,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     pa.result = c->d_result.p;
     pa.host_pub = c->h_pub.p;
     pa.seq = ++c->seq;
+    pa.identity_n = ca.identity_n;
     c->pub_pending = true;
     KC_TRY(c->timing.start("publish_kernel", s));
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kPubBlock), 0, s, pa);
@@ -2032,6 +2085,13 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_dc_enable.release();
   c->d_gridcnt.release();
   c->h_gridrec.release();
+  if (c->aux_stream) {
+    hipError_t ae = hipStreamSynchronize(c->aux_stream);
+    ae = hipStreamDestroy(c->aux_stream);
+    ae = hipEventDestroy(c->aux_fork);
+    ae = hipEventDestroy(c->aux_join);
+    (void)ae;
+  }
   if (c->grid_ready) {
     hipError_t ge = hipEventDestroy(c->grid_ready);
     (void)ge;
@@ -2120,7 +2180,8 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   } else if (n == "cycle_samples") {
     if (!(v == 0.0 || v == 16.0 || v == 32.0)) KC_FAIL(KC_ERR_RANGE, "cycle_samples: 0 (by shard size), 16 or 32");
     c->cycle_samples_opt = static_cast<int>(v);
-  } else if (n == "velocity_group") {
+  } else if (n == "velocity_beside") c->velocity_beside = on;
+  else if (n == "velocity_group") {
     if (!(v == 0.0 || v == 1.0 || v == 4.0 || v == 16.0)) KC_FAIL(KC_ERR_RANGE, "velocity_group: 0 (by batch size), 1, 4 or 16");
     c->velocity_group = static_cast<int>(v);
   } else if (n == "near_table") {
@@ -2152,6 +2213,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "near_table") *v = c->near_side;
   else if (n == "cycle_samples") *v = c->cycle_samples_opt;
   else if (n == "velocity_group") *v = c->velocity_group;
+  else if (n == "velocity_beside") *v = c->velocity_beside;
   else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "sensor_on_host") *v = !c->device_sensor;

@@ -64,9 +64,13 @@ def test_cost5k_velocity_sums_by_group(cost5k, group, weights):
     ctx.set_weights(kh.make_weights(*weights))
     ctx.set_tracked_segment(w["seg"], w["acc"][w["s0"]:w["s0"] + len(w["seg"])], w["total"])
     ctx.cost_upload(w["px"], w["py"], w["vel"])
-    r, costs = ctx.cost_evaluate_resident()
-    np.testing.assert_array_equal(costs.view(np.uint32), ocosts.view(np.uint32))
-    assert r.found and r.index == oi and np.float32(r.cost) == np.float32(oc)
+    for beside in (1, 0):   # the pass on a second stream beside the cost kernel (+ velocity_finish_kernel), or in front of it
+        ctx.set_option("velocity_beside", beside)
+        for _ in range(2):
+            r, costs = ctx.cost_evaluate_resident()
+            np.testing.assert_array_equal(costs.view(np.uint32), ocosts.view(np.uint32))
+            assert r.found and r.index == oi and np.float32(r.cost) == np.float32(oc)
+            assert r.n_admissible == N
     with pytest.raises(IndexError):   # KC_ERR_RANGE
         ctx.set_option("velocity_group", 8)
     ctx.close()
