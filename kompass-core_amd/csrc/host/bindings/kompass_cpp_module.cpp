@@ -293,7 +293,12 @@ PYBIND11_MODULE(kompass_cpp, m) {
       .def("compute_velocity_commands", [](DWA &d, const Control::Velocity2D &v, const Mapping::LocalMapper &m) {
              return d.computeVelocityCommandsSet<Mapping::LocalMapper>(v, m); })
       .def("compute_velocity_commands", [](DWA &d, const Control::Velocity2D &v, const py::object &cloud) {
-             return d.computeVelocityCommandsSet<std::vector<Path::Point>>(v, points(cloud)); })
+             // an (N, 3) float32 C-contiguous array is consumed where it lies; anything else (lists of
+             // tuples, other dtypes) is converted first
+             const FArr a = py::cast<FArr>(cloud);
+             if (a.ndim() != 2 || a.shape(1) != 3) throw std::invalid_argument("expected an (N, 3) array of points");
+             return d.computeVelocityCommandsSet<Control::PointCloudView>(
+                 v, Control::PointCloudView{a.data(), static_cast<size_t>(a.shape(0))}); })
       .def("add_custom_cost", &DWA::addCustomCost)
       .def("get_debugging_samples", [](const DWA &d) {
              auto [x, y] = d.getDebuggingSamples();

@@ -3,6 +3,9 @@
 // and tracked-segment selection; sampling, roll-out, collision gate, costs and
 // argmin run as one device cycle.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <memory>
 #include <stdexcept>
@@ -121,19 +124,30 @@ class DWA : public Follower {
           -currentTrackedTarget_->heading_error * ctrlimitsParams.omegaParams.maxOmega / M_PI));
       return TrajSearchResult{trajectory, true, 0.0};
     }
+    const auto T0 = std::chrono::steady_clock::now();
     adaptPredictionHorizonToCurvature();
+    const auto T1 = std::chrono::steady_clock::now();
     // lattice + sensor data of this cycle onto the device ...
     const size_t generated =
         trajSampler->prepareOnDevice(global_vel, currentState, scan_points, maxLocalRange_);
+    const auto T2 = std::chrono::steady_clock::now();
     if (generated == 0) return TrajSearchResult{Trajectory2D(), false, 0.0};
     // ... then ONE device cycle: roll-out + collision gate + costs + argmin against the
     // tracked segment (dwa.h:215-229 of the reference as a single kernel launch)
     trajCostEvaluator->sensorDataResident = true;
     auto tracked = findTrackedPathSegment();
+    const auto T3 = std::chrono::steady_clock::now();
     TrajectorySampler *smp = trajSampler.get();
-    return trajCostEvaluator->cycleOnDevice(
+    auto rr = trajCostEvaluator->cycleOnDevice(
         currentPath.get(), tracked, trajSampler->numPointsPerTrajectory, currentState, trajSampler->timeStep(),
         [smp](size_t raw) { return smp->sampleVelocity(raw); }, generated, comm_.get());
+    const auto T4 = std::chrono::steady_clock::now();
+    static const bool dbg = std::getenv("KC_DEBUG_CLASS") != nullptr;
+    if (dbg) {
+      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      std::fprintf(stderr, "[class] horizon %.1f | prepare %.1f | tracked %.1f | cycleOnDevice %.1f\n", us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4));
+    }
+    return rr;
   }
 
  private:

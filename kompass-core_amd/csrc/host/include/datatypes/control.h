@@ -63,5 +63,13 @@ struct LaserScan {
       : ranges(std::move(ranges)), angles(std::move(angles)) {}
 };
 
+// A point cloud the caller already holds as packed (x, y, z) floats -- a numpy (N, 3) float32 array from
+// the Python layer: consumed where it lies (the sensor update stores it straight to the device), no
+// std::vector<Path::Point> in between.  Same meaning as the vector form (global_frame = true).
+struct PointCloudView {
+  const float *xyz;
+  size_t n;
+};
+
 }  // namespace Control
 }  // namespace Kompass

@@ -37,6 +37,7 @@ class CollisionChecker {
   // LaserScan (sensor frame) or point list (world frame when global_frame)
   void updateSensorData(const Control::LaserScan &scan, const bool global_frame = true);
   void updateSensorData(const std::vector<Path::Point> &cloud, const bool global_frame = true);
+  void updateSensorData(const Control::PointCloudView &cloud, const bool global_frame = true);
   // the OCCUPIED cells of the mapper's device-resident grid as the point list
   // (no host round trip)
   void updateSensorData(const Mapping::LocalMapper &mapper, const bool global_frame = true);

@@ -3,6 +3,9 @@
 // lattice are built on the host in the reference's order; roll-out and the
 // collision gate run on the device through the C ABI.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <memory>
 #include <vector>
@@ -109,13 +112,18 @@ class TrajectorySampler {
   size_t prepareOnDevice(const Velocity2D &current_vel, const Path::State &pose, const T &sensor_points,
                          float max_sensor_range) {
     collChecker->maxSensorRange = max_sensor_range;
+    // the lattice first: its upload needs an idle stream (the list is written over the BAR under the
+    // kernels' feet otherwise) -- behind the sensor update it would wait for the device-side sensor build
+    const size_t n = sampleWindow(current_vel, /*host_copy=*/false);
     collChecker->updateState(pose);
     collChecker->updateSensorData(sensor_points);
-    return sampleWindow(current_vel);
+    return n;
   }
   // velocity triple of generated sample `raw` of the last window (host copy of the lattice)
   Velocity2D sampleVelocity(size_t raw) const {
-    return Velocity2D(last_vx_.at(raw), last_vy_.at(raw), last_omega_.at(raw));
+    double vx = 0.0, vy = 0.0, om = 0.0;
+    hip::check(kc_dwa_get_sample_velocity(ctx_.get(), static_cast<int64_t>(raw), &vx, &vy, &om));
+    return Velocity2D(vx, vy, om);
   }
   double timeStep() const { return time_step_; }
   const hip::DwaHandle &context() const { return ctx_; }
@@ -132,7 +140,7 @@ class TrajectorySampler {
   void init(const CollisionChecker::ShapeType shape,
             const std::vector<float> &dims, const Eigen::Vector3f &spos,
             const Eigen::Quaternionf &srot, double octreeRes);
-  size_t sampleWindow(const Velocity2D &current_vel);
+  size_t sampleWindow(const Velocity2D &current_vel, bool host_copy = true);
   size_t launch(const Velocity2D &current_vel, const Path::State &pose);
   std::unique_ptr<TrajectorySamples2D> collect();
   hip::DwaHandle ctx_;

@@ -91,14 +91,17 @@ void CollisionChecker::updateSensorData(const std::vector<Path::Point> &cloud,
     throw std::runtime_error(
         "CollisionChecker: sensor-frame point lists are not supported by this "
         "build (the controllers always pass global_frame = true)");
+  // Path::Point is three packed floats: the list goes to the device as it lies
+  static_assert(sizeof(Path::Point) == 3 * sizeof(float), "Path::Point must be packed (x, y, z)");
+  updateSensorData(Control::PointCloudView{cloud.empty() ? nullptr : cloud.data()->data(), cloud.size()}, true);
+}
+void CollisionChecker::updateSensorData(const Control::PointCloudView &cloud, const bool global_frame) {
+  if (!global_frame)
+    throw std::runtime_error(
+        "CollisionChecker: sensor-frame point lists are not supported by this "
+        "build (the controllers always pass global_frame = true)");
   const kc_state st = toKc(state_);
-  std::vector<float> xyz(cloud.size() * 3);
-  for (size_t i = 0; i < cloud.size(); ++i) {
-    xyz[3 * i] = cloud[i].x();
-    xyz[3 * i + 1] = cloud[i].y();
-    xyz[3 * i + 2] = cloud[i].z();
-  }
-  hip::check(kc_dwa_set_points(ctx_.get(), &st, xyz.data(), cloud.size(), maxSensorRange));
+  hip::check(kc_dwa_set_points(ctx_.get(), &st, cloud.xyz, cloud.n, maxSensorRange));
 }
 void CollisionChecker::updateSensorData(const Mapping::LocalMapper &mapper, const bool) {
   const kc_state st = toKc(state_);
@@ -214,7 +217,7 @@ size_t TrajectorySampler::launch(const Velocity2D &vel, const Path::State &pose)
   return n;
 }
 
-size_t TrajectorySampler::sampleWindow(const Velocity2D &vel) {
+size_t TrajectorySampler::sampleWindow(const Velocity2D &vel, bool host_copy) {
   kc_limits L;
   L.vx_max = ctrlimits.velXParams.maxVel;
   L.vx_acc = ctrlimits.velXParams.maxAcceleration;
@@ -227,13 +230,15 @@ size_t TrajectorySampler::sampleWindow(const Velocity2D &vel) {
   L.omega_acc = ctrlimits.omegaParams.maxAcceleration;
   L.omega_dec = ctrlimits.omegaParams.maxDeceleration;
   size_t n = 0;
-  last_vx_.resize(numTrajectories + 8);
-  last_vy_.resize(numTrajectories + 8);
-  last_omega_.resize(numTrajectories + 8);
+  if (host_copy) {  // collect() reads the lattice back sample by sample; the device cycle does not
+    last_vx_.resize(numTrajectories + 8);
+    last_vy_.resize(numTrajectories + 8);
+    last_omega_.resize(numTrajectories + 8);
+  }
   hip::check(kc_dwa_sample_window(ctx_.get(), static_cast<int>(ctrType), &L, vel.vx(), vel.vy(),
                                   vel.omega(), lin_samples_max_, ang_samples_max_raw_, &n,
-                                  last_vx_.data(), last_vy_.data(), last_omega_.data(),
-                                  last_vx_.size()));
+                                  host_copy ? last_vx_.data() : nullptr, host_copy ? last_vy_.data() : nullptr,
+                                  host_copy ? last_omega_.data() : nullptr, host_copy ? last_vx_.size() : 0));
   return n;
 }
 

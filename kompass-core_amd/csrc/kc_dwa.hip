@@ -665,9 +665,10 @@ int upload_samples(kc_dwa *c) {
   if (n > c->prm.max_samples)
     KC_FAIL(KC_ERR_RANGE, "sample count %zu exceeds max_samples %zu", n,
             c->prm.max_samples);
-  c->vmax_lin = 0.0;
-  for (size_t i = 0; i < n; ++i)
-    c->vmax_lin = std::max(c->vmax_lin, std::hypot(c->lat.vx[i], c->lat.vy[i]));
+  // (the reach radius it feeds carries a 1e-4 slack: one sqrt of the largest square, not a hypot per sample)
+  double v2max = 0.0;
+  for (size_t i = 0; i < n; ++i) v2max = std::max(v2max, c->lat.vx[i] * c->lat.vx[i] + c->lat.vy[i] * c->lat.vy[i]);
+  c->vmax_lin = std::sqrt(v2max) * (1.0 + 1e-12);
   // A controller draws a new window every cycle: the velocities change, the
   // pattern of trig rows (which sample shares its omega with which) rarely does.
   // The orders the kernels walk the list in depend on that pattern only.
