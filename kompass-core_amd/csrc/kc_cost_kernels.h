@@ -788,7 +788,7 @@ __device__ __forceinline__ void velocity_sums_group(const VelSumArgs &a, float *
     }
 #pragma unroll
     for (int q = 0; q < kLanes; ++q) {
-      const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), kRotate, 0xf, 0xf, false));
+      const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), kRotate, 0xf, 0xf, true));
       float v = static_cast<float>(static_cast<double>(prev) + t0);
       v = static_cast<float>(static_cast<double>(v) + t1);
       r = static_cast<float>(static_cast<double>(v) + t2);
