@@ -152,6 +152,13 @@ PYBIND11_MODULE(kompass_cpp, m) {
       .def_readonly("path", &Control::Trajectory2D::path);
 
   py::class_<Control::LaserScan>(t, "LaserScan")
+      // numpy arrays first (one memcpy each); lists and other sequences fall through to the element-wise form
+      .def(py::init([](const py::array_t<double, py::array::c_style | py::array::forcecast> &ranges,
+                       const py::array_t<double, py::array::c_style | py::array::forcecast> &angles) {
+             if (ranges.ndim() != 1 || angles.ndim() != 1) throw std::invalid_argument("ranges and angles must be 1-D");
+             return Control::LaserScan(std::vector<double>(ranges.data(), ranges.data() + ranges.size()),
+                                       std::vector<double>(angles.data(), angles.data() + angles.size()));
+           }), py::arg("ranges").noconvert(), py::arg("angles").noconvert())
       .def(py::init<std::vector<double>, std::vector<double>>(), py::arg("ranges"), py::arg("angles"))
       .def_readonly("ranges", &Control::LaserScan::ranges)
       .def_readonly("angles", &Control::LaserScan::angles);

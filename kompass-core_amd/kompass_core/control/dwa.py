@@ -99,8 +99,9 @@ class DWA(FollowerTemplate):
             if len(laser_scan.angles) != len(laser_scan.ranges):
                 logging.error("Received incompatible LaserScan data -> Cannot compute control")
                 return False
-            sensor = kompass_cpp.types.LaserScan(ranges=list(map(float, laser_scan.ranges)),
-                                                 angles=list(map(float, laser_scan.angles)))
+            # (float64 arrays: one copy each into the C++ vectors instead of a Python float per beam)
+            sensor = kompass_cpp.types.LaserScan(ranges=np.ascontiguousarray(laser_scan.ranges, dtype=np.float64),
+                                                 angles=np.ascontiguousarray(laser_scan.angles, dtype=np.float64))
         elif point_cloud is not None:
             sensor = np.asarray(getattr(point_cloud, "data", point_cloud), dtype=np.float32)
         else:
