@@ -41,6 +41,13 @@ std::vector<Path::Point> points(const py::object &o) {
   for (py::ssize_t i = 0; i < a.shape(0); ++i) out[(size_t)i] = Path::Point(r(i, 0), r(i, 1), r(i, 2));
   return out;
 }
+using DArr = py::array_t<double, py::array::c_style | py::array::forcecast>;
+// a 1-D float64 array as the std::vector<double> the reference signatures take: one memcpy (the element-wise
+// sequence caster costs ~70 ns per beam)
+std::vector<double> dvec(const DArr &a) {
+  if (a.ndim() != 1) throw std::invalid_argument("expected a 1-D array");
+  return std::vector<double>(a.data(), a.data() + a.size());
+}
 py::array_t<float> view1(const Eigen::VectorXf &v, py::handle owner) {
   return py::array_t<float>({(py::ssize_t)v.size()}, {(py::ssize_t)sizeof(float)}, v.data(), owner);
 }
@@ -370,9 +377,17 @@ PYBIND11_MODULE(kompass_cpp, m) {
            py::arg("p_occupied"), py::arg("p_empty"), py::arg("range_sure"), py::arg("range_max"), py::arg("wall_size"),
            py::arg("angle_step"), py::arg("max_height"), py::arg("min_height"), py::arg("max_points_per_line"),
            py::arg("max_num_threads") = 1)
+      .def("scan_to_grid", [gridView](py::object self, const DArr &angles, const DArr &ranges) {
+             return gridView(self.cast<Mapping::LocalMapper &>().scanToGrid(dvec(angles), dvec(ranges)), self);
+           }, "Convert laser scan data to occupancy grid (float64 arrays: one copy each)", py::arg("angles").noconvert(),
+           py::arg("ranges").noconvert())
       .def("scan_to_grid", [gridView](py::object self, const std::vector<double> &angles, const std::vector<double> &ranges) {
              return gridView(self.cast<Mapping::LocalMapper &>().scanToGrid(angles, ranges), self);
            }, "Convert laser scan data to occupancy grid", py::arg("angles"), py::arg("ranges"))
+      .def("scan_to_grid_on_device", [](Mapping::LocalMapper &m, const DArr &angles, const DArr &ranges) {
+             m.scanToGridOnDevice(dvec(angles), dvec(ranges));
+           }, "Scan into the device-resident grid only (float64 arrays: one copy each)", py::arg("angles").noconvert(),
+           py::arg("ranges").noconvert())
       .def("scan_to_grid_on_device", &Mapping::LocalMapper::scanToGridOnDevice,
            "Scan into the device-resident grid only (for DWA.compute_velocity_commands(vel, mapper))",
            py::arg("angles"), py::arg("ranges"))
@@ -387,6 +402,11 @@ PYBIND11_MODULE(kompass_cpp, m) {
       // (bindings_mapping.cpp:59-75) while its own Python caller unpacks two
       // grids (mapping/local_mapper.py:289-306): bound here to the real
       // scanToGridBaysian, which is what that caller needs.
+      .def("scan_to_grid_baysian", [gridView, probView](py::object self, const DArr &angles, const DArr &ranges) {
+             auto r = self.cast<Mapping::LocalMapper &>().scanToGridBaysian(dvec(angles), dvec(ranges));
+             return py::make_tuple(gridView(std::get<0>(r), self), probView(std::get<1>(r), self));
+           }, "Convert laser scan data to occupancy grid, with baysian update (float64 arrays: one copy each)",
+           py::arg("angles").noconvert(), py::arg("ranges").noconvert())
       .def("scan_to_grid_baysian", [gridView, probView](py::object self, const std::vector<double> &angles,
                                                         const std::vector<double> &ranges) {
              auto r = self.cast<Mapping::LocalMapper &>().scanToGridBaysian(angles, ranges);

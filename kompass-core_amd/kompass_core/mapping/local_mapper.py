@@ -116,8 +116,9 @@ class LocalMapper:
             # local_mapper.py:286-320
             if self.processed and robot_state is not None and self._previous_state is not None:
                 self._calculate_grid_shift(robot_state)
-            grid, prob = self._mapper.scan_to_grid_baysian(angles=list(map(float, laser_scan.angles)),
-                                                           ranges=list(map(float, ranges)))
+            grid, prob = self._mapper.scan_to_grid_baysian(
+                angles=np.ascontiguousarray(laser_scan.angles, dtype=np.float64),
+                ranges=np.ascontiguousarray(ranges, dtype=np.float64))
             self.grid_data.occupancy = np.copy(grid)
             self.scan_occupancy_prob = np.copy(prob)
             p_prior = np.float32(self.scan_model.p_prior)
@@ -129,7 +130,8 @@ class LocalMapper:
                 self._previous_state = RobotState(x=robot_state.x, y=robot_state.y, yaw=robot_state.yaw)
             self.processed = True
             return
-        grid = self._mapper.scan_to_grid(angles=list(map(float, laser_scan.angles)), ranges=list(map(float, ranges)))
+        grid = self._mapper.scan_to_grid(angles=np.ascontiguousarray(laser_scan.angles, dtype=np.float64),
+                                         ranges=np.ascontiguousarray(ranges, dtype=np.float64))
         self.grid_data.occupancy = np.copy(grid)
         self.processed = True
 
