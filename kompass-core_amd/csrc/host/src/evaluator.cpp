@@ -93,14 +93,10 @@ void CostEvaluator::setPointScan(const std::vector<Path::Point> &cloud, const Pa
                                  const float range, const float multiple) {
   if (sensorDataResident) return;
   const kc_state st{s.x, s.y, s.yaw, s.speed};
-  std::vector<float> xyz(cloud.size() * 3);
-  for (size_t i = 0; i < cloud.size(); ++i) {
-    xyz[3 * i] = cloud[i].x();
-    xyz[3 * i + 1] = cloud[i].y();
-    xyz[3 * i + 2] = cloud[i].z();
-  }
+  // Path::Point is three packed floats: the list goes to the device as it lies
+  static_assert(sizeof(Path::Point) == 3 * sizeof(float), "Path::Point must be packed (x, y, z)");
   const float eff = range / multiple * 3.0f;
-  hip::check(kc_dwa_set_points(ctx_.get(), &st, xyz.data(), cloud.size(), eff));
+  hip::check(kc_dwa_set_points(ctx_.get(), &st, cloud.empty() ? nullptr : cloud.data()->data(), cloud.size(), eff));
 }
 
 void CostEvaluator::uploadSegment(const Path::Path *ref, const Path::Path::View &seg) {
