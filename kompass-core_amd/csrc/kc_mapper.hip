@@ -57,7 +57,12 @@ constexpr int kBeamsPerBlock = 4;
 __global__ __launch_bounds__(64 * kBeamsPerBlock) void rays_kernel(
     MapGeom g, const float *__restrict__ ranges, const double2 *__restrict__ trig, int n,
     int *__restrict__ grid, int step_limit) {
-  const int beam = blockIdx.x * kBeamsPerBlock + (threadIdx.x >> 6);
+  // Workgroups go to the eight XCDs round-robin, each with an L2 of its own: XCD x takes the x-th EIGHTH of the
+  // beams (a sector of an ordered scan), so the dirty partial lines of a grid region collect in one L2 instead of
+  // all eight
+  const int per_xcd = static_cast<int>(gridDim.x >> 3);  // (the host launches a multiple of eight workgroups)
+  const int block = static_cast<int>(blockIdx.x & 7u) * per_xcd + static_cast<int>(blockIdx.x >> 3);
+  const int beam = block * kBeamsPerBlock + (threadIdx.x >> 6);
   if (beam >= n) return;
   const int lane = threadIdx.x & 63;
   const int2 t = beam_endpoint(g, ranges[beam], trig[beam]);
@@ -753,8 +758,8 @@ int run_scan(kc_mapper *m, const double *angles, const double *ranges,
   } else if (bayes)
     hipLaunchKernelGGL(rays_bayes_kernel, rgrid, rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p,
                        ni, m->d_grid.p, m->d_last.p, hb, 1, step_limit);
-  else
-    hipLaunchKernelGGL(rays_kernel, rgrid, rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p, ni,
+  else  // (a multiple of eight workgroups: the kernel deals the beams to the XCDs by eighths)
+    hipLaunchKernelGGL(rays_kernel, dim3((rgrid.x + 7u) & ~7u), rblock, 0, s, m->g, m->d_ranges.p, m->d_trig.p, ni,
                        m->d_grid.p, step_limit);
   KC_TRY(m->timing.stop(s));
   ++m->seq;
