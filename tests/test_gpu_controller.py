@@ -418,3 +418,44 @@ def test_non_planar_sensor_mount_raises_at_the_class_level():
     assert "planar" in str(e.value) or "rotation" in str(e.value)
     cloud = _round_obstacle(3.0, 0.35, 0.2)
     assert gpu.loop_step(current_state=robot.state, local_map=cloud) and gpu.has_result()
+
+
+def test_sensor_input_forms_give_the_same_command():
+    """The bindings consume numpy inputs where they lie (an (N, 3) float32 cloud: Control::PointCloudView; float64
+    range / angle arrays: one copy each) and convert everything else element by element: a list of tuples, a
+    float64 array, a Fortran-ordered array and the float32 array must give the same command, cost and path;
+    LaserScan from arrays must equal LaserScan from lists."""
+    cfg = DWAConfig(max_linear_samples=11, max_angular_samples=11, octree_resolution=0.1, prediction_horizon=12,
+                    control_horizon=2, control_time_step=0.1)
+    lim = (LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0),
+           AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0))
+    robot, gpu, _ = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.CYLINDER, [0.1, 0.4], *lim, cfg)
+    gpu.set_path(_P([(x, 0.0) for x in np.arange(0.0, 6.01, 0.5)]))
+    robot.state.x, robot.state.y, robot.state.yaw = 0.0, 0.05, 0.0
+    gpu._planner.set_current_state(0.0, 0.05, 0.0, 0.3)
+    vel = kompass_cpp.types.Velocity2D(0.3, 0.0, 0.0, 0.0)
+    cloud32 = np.ascontiguousarray(_round_obstacle(2.0, 0.4, 0.25), dtype=np.float32)
+    forms = [cloud32, [tuple(float(v) for v in p) for p in cloud32], cloud32.astype(np.float64),
+             np.asfortranarray(cloud32), cloud32[::1].copy()]
+    got = []
+    for f in forms:
+        r = gpu._planner.compute_velocity_commands(vel, f)
+        assert r.is_found
+        got.append((np.float32(r.cost), np.array(r.trajectory.path.x), np.array(r.trajectory.velocities.omega)))
+    for g in got[1:]:
+        assert g[0] == got[0][0]
+        np.testing.assert_array_equal(g[1], got[0][1])
+        np.testing.assert_array_equal(g[2], got[0][2])
+    with pytest.raises(Exception):
+        gpu._planner.compute_velocity_commands(vel, np.zeros((5, 2), np.float32))
+    # laser scans: arrays and lists
+    ang = np.linspace(-1.5, 1.5, 181)
+    rng = 2.0 + 0.5 * np.cos(3 * ang)
+    a = kompass_cpp.types.LaserScan(ranges=rng, angles=ang)
+    b = kompass_cpp.types.LaserScan(ranges=list(map(float, rng)), angles=list(map(float, ang)))
+    c = kompass_cpp.types.LaserScan(ranges=rng.astype(np.float32), angles=ang.astype(np.float32))   # converted
+    assert list(a.ranges) == list(b.ranges) and list(a.angles) == list(b.angles)
+    assert list(c.ranges) == [float(np.float32(v)) for v in rng]
+    ra = gpu._planner.compute_velocity_commands(vel, a)
+    rb = gpu._planner.compute_velocity_commands(vel, b)
+    assert ra.is_found == rb.is_found and (not ra.is_found or np.float32(ra.cost) == np.float32(rb.cost))
