@@ -221,3 +221,24 @@ def test_sphere_on_the_single_launch_path(zoff):
         r = ctx.cycle(inp["state"], inp["P"])
         assert r.index == o["index"] and r.n_admissible == len(o["raw"])
         ctx.close()
+
+
+@pytest.mark.parametrize("beams", [360, 1440, 4096])
+def test_room_like_scans_far_walls_dense_rows(beams):
+    """Laser scans of a room: every trajectory point is metres from the nearest wall, and a dense scan puts
+    hundreds of points into one bucket row -- the cooperative far search of the wavefront-per-sample cost stage
+    walks such rows with all 64 lanes (kLongRun), short runs with one lane.  Single launch, three kernels and
+    the workgroup-per-sample kernel against the oracle, two poses (one near a wall: mixed near / far points)."""
+    inp = syn.make_controller_inputs("cfg2", seed=4, scale=0.22, scene="open")
+    ang = np.linspace(-np.pi, np.pi, beams, endpoint=False)
+    rng = 3.0 + 1.2 * np.cos(5 * ang) + 0.3 * np.sin(17 * ang)
+    for st in ((0.0, 0.0, 0.3, 0.0), (1.1, -0.6, -1.0, 0.0)):
+        cur = dict(inp, state=st)
+        o = oracle_cycle(cur, scan=(rng, ang))
+        assert len(o["raw"]) > 40
+        for opts in (dict(fused_cycle=2), dict(fused_cycle=0, cost_kernel=2), dict(fused_cycle=0, cost_kernel=1)):
+            ctx = hip_context(kh, cur)
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+            assert_cycle_equal(o, hip_cycle(kh, cur, scan=(rng, ang), ctx=ctx))
+            ctx.close()
