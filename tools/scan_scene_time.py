@@ -11,9 +11,13 @@ P, S = inp["P"], len(inp["seg_xyz"])
 ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"], inp["dt"],
                     max_samples=len(inp["vx"]), max_points=P, max_segment=S, max_obstacles=max(beams, 16),
                     acc_limits=inp["acc_limits"])
+wts = inp["weights"]
 for k, v in [a.split("=") for a in sys.argv[2:]]:
-    ctx.set_option(k, float(v))
-ctx.set_weights(kh.make_weights(*inp["weights"]))
+    if k == "weights":
+        wts = tuple(float(t) for t in v.split(","))
+    else:
+        ctx.set_option(k, float(v))
+ctx.set_weights(kh.make_weights(*wts))
 ang = np.linspace(-np.pi, np.pi, beams, endpoint=False)
 rng = 4.0 + 1.5 * np.cos(5 * ang)
 st = (0.0, 0.0, 0.0, 0.0)
