@@ -3,7 +3,7 @@
 # headline set of tools/profile_round2.sh: other configs and scenes, --split, the reference's workloads,
 # the multi-GPU code path with a world of one, mapper / Bayes / point cloud modes, class-level cycle.
 set -e
-TAG=${1:-r02_g}
+TAG=${1:-r02_i}
 O=gpurun_out/$TAG
 mkdir -p $O
 for c in cfg1 cfg3 cfg5; do python bench.py --config $c > $O/${c}_bench.json 2>> $O/extra.err; done
