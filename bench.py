@@ -17,8 +17,16 @@ therefore carries the cycle on two more scenes of the same lattice, each with
 its own value / roofline / cpu_baseline: `mid_density` (about half admissible)
 and `open_space` (every sample admissible).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
-torch.distributed.run (one rank per GPU).  Rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the ranks are one
+process per GPU: either the caller starts them (`python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`), or -- no
+WORLD_SIZE in the environment -- this script starts them itself, as child processes, BEFORE it
+touches the GPU (a process that has initialised HIP must never be replaced or forked into ranks),
+relays rank 0's line and exits with the launcher's return code.  Rank 0 prints ONE JSON line.
+
+With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks share the devices and exchange
+through the library's shared-memory transport instead of RCCL (which refuses two ranks on one
+device); `config.collective` says which transport ran.
 """
 from __future__ import annotations
 
@@ -69,27 +77,74 @@ def algorithmic_bytes(N, P, map_side, S, O):
     return 16 * N * P + 20 * N + map_side * map_side // 8 + 12 * S + 8 * O
 
 
+class Ranks:
+    """torch.distributed as the control plane of a multi-rank run (rendezvous, barriers, max over
+    ranks of the timing contract) -- the data path is the library's own collective.  `rehearsal`:
+    more ranks than GPUs, the ranks share devices (gloo barriers, shared-memory exchange)."""
+
+    def __init__(self, rank, world, local_rank):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = rank, world
+        ndev = torch.cuda.device_count()  # (does not initialise the GPU)
+        if ndev < 1:
+            raise SystemExit("bench.py needs a HIP device; none visible (no CPU fallback)")
+        self.rehearsal = world > ndev
+        self.device = local_rank % ndev
+        if world == 1:  # forced (KC_BENCH_FORCE_DIST=1): no launcher has set the rendezvous up
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+        torch.cuda.set_device(self.device)
+        if self.rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", self.device))
+
+    def barrier(self):
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max(self, *vals):
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device="cpu" if self.rehearsal else "cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    def gather(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def comm(self, kh):
+        """The library's communicator: RCCL (unique id from rank 0), or the shared-memory rehearsal transport."""
+        if self.rehearsal:
+            import uuid
+
+            name = [uuid.uuid4().hex[:16] if self.rank == 0 else None]
+            self.dist.broadcast_object_list(name, src=0)
+            return kh.Comm(self.rank, self.world, device=self.device, shm_name=name[0])
+        ids = [kh.comm_unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(ids, src=0)
+        return kh.Comm(self.rank, self.world, ids[0], device=self.device)
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
 def controller_bench(args, rank, world, local_rank):
+    # KC_BENCH_FORCE_DIST=1 exercises the multi-GPU code path (the exchange record through a real
+    # ncclAllReduce) with a single rank, e.g. on a one-GPU box
+    use_dist = world > 1 or os.environ.get("KC_BENCH_FORCE_DIST") == "1"
+    ranks = Ranks(rank, world, local_rank) if use_dist else None
     import kompass_hip as kh
     import sharding
     import synthetic as syn
 
-    # KC_BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL all-reduce on the
-    # device-resident key) with a single rank, e.g. on a one-GPU box
-    use_dist = world > 1 or os.environ.get("KC_BENCH_FORCE_DIST") == "1"
-    torch = None
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-
-        if world == 1:  # forced: no launcher has set the rendezvous up
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29517")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
     if kh.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device; none visible (no CPU fallback)")
+    device = ranks.device if ranks else local_rank
 
     cfg = args.config
     base = syn.CONFIGS[cfg]
@@ -106,25 +161,22 @@ def controller_bench(args, rank, world, local_rank):
 
     ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1),
                         inp["octree_res"], inp["dt"], max_samples=n_total, max_points=P,
-                        max_segment=S, max_obstacles=O, acc_limits=inp["acc_limits"], device=local_rank)
+                        max_segment=S, max_obstacles=O, acc_limits=inp["acc_limits"], device=device)
     if args.split:
         ctx.set_option("fused_cycle", 0)
     ctx.set_weights(kh.make_weights(*inp["weights"]))
     ctx.set_points(inp["state"], inp["points"], inp["max_range"])
     ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
-    ctx.set_samples(vx, vy, om)
-    ctx.set_shard(first, count)
-
-    comm = None
+    # weak scaling: rank r's share is the r-th BASELINE-sized block of the (vx-major) lattice
+    # (kc_dwa_set_shard_rule: every rank is handed the full list and keeps its share)
     if use_dist:
-        # data path: the library's own RCCL communicator (kc_comm_*: no framework between the
-        # kernels and the collective, everything on the context's stream); torch.distributed only
-        # carries the 128-byte unique id and the barriers / max-over-ranks of the timing contract
-        import torch.distributed as dist
+        ctx.set_shard_rule(rank, world, kh.SHARD_BLOCKS)
+    ctx.set_samples(vx, vy, om)
 
-        ids = [kh.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = kh.Comm(rank, world, ids[0], device=local_rank)
+    # data path: the library's own communicator (kc_comm_*: no framework between the kernels and
+    # the collective, everything on the context's stream); torch.distributed only carries the
+    # 128-byte unique id and the barriers / max-over-ranks of the timing contract
+    comm = ranks.comm(kh) if use_dist else None
 
     def pose(i):  # a new pose every cycle: nothing can be reused between steps
         return (0.0, 0.0, 1e-3 * ((i % 7) - 3), 0.0)
@@ -132,16 +184,13 @@ def controller_bench(args, rank, world, local_rank):
     def one_cycle(i):
         if not use_dist:
             return ctx.cycle(pose(i), P)  # the whole cycle in one ABI call (one launch)
-        # shard cycle + ONE 8-byte ncclAllReduce(min) of the device record + hand-off, one ABI call
-        r = ctx.cycle_sharded(comm, pose(i), P)
-        return sharding.key_pack(float(r.cost), int(r.raw_index)) if r.found else sharding.KEY_NONE
+        # this rank's share + ONE all-reduce(min) of the exchange record (best key, error word, every rank's
+        # admissible bitmap) + hand-off: one ABI call, the same result on every rank
+        return ctx.cycle_sharded(comm, pose(i), P)
 
     def barrier():
         if use_dist:
-            import torch.distributed as dist
-
-            dist.barrier()
-            torch.cuda.synchronize()
+            ranks.barrier()
 
     for i in range(args.warmup):
         one_cycle(i)
@@ -157,11 +206,7 @@ def controller_bench(args, rank, world, local_rank):
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        import torch.distributed as dist
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = ranks.max(elapsed)[0]
     # ---- same cycles again with HIP events around every kernel, recorded on the
     # stream the kernels are launched on (roofline leg; events cost a few us per
     # cycle, so they stay out of `value`)
@@ -175,10 +220,9 @@ def controller_bench(args, rank, world, local_rank):
     last = one_cycle(args.steps - 1)
 
     # ---- result of the last cycle (for the parity check below) -------------
-    if use_dist:
-        found, cost, raw = sharding.key_unpack(last)
-    else:
-        found, cost, raw = bool(last.found), float(last.cost), int(last.raw_index)
+    found, cost, raw = bool(last.found), float(last.cost), int(last.raw_index)
+    seen = ranks.gather({"rank": rank, "device": device, "pid": os.getpid(), "comm_world": comm.world,
+                         "transport": comm.transport, "winner": [found, cost, raw, int(last.index)]}) if use_dist else None
 
     out = None
     if rank == 0:
@@ -186,6 +230,7 @@ def controller_bench(args, rank, world, local_rank):
         steps_total = n_total * P  # trajectory-steps per cycle over all ranks
         value = steps_total * args.steps / elapsed
         n_adm = int(ctx.cycle(pose(0), P).n_admissible) if not use_dist else None
+        n_adm_global = int(last.n_admissible) if use_dist else n_adm
         robot = 'omni' if base['ctr'] == 2 else 'diff-drive' if base['ctr'] == 1 else 'Ackermann'
         out = {
             "metric": "trajectory-steps/s", "value": value, "unit": "trajectory-steps/s",
@@ -199,7 +244,7 @@ def controller_bench(args, rank, world, local_rank):
                             f"admissible after the collision gate), tracked segment {S} pts, weights "
                             f"path/goal/obstacles; every one of the {count} x {P} steps is rolled out and "
                             f"collision-checked, costs are computed for the admissible samples",
-                "scene": args.scene, "n_admissible": n_adm,
+                "scene": args.scene, "n_admissible": n_adm, "n_admissible_all_ranks": n_adm_global,
                 "samples_per_gpu": count, "global_samples": n_total, "points": P,
                 "launches_per_cycle": len(kernel_ms),
                 "cycle": "single launch (kc_dwa_cycle)" if "cycle_kernel" in kernel_ms else
@@ -218,7 +263,17 @@ def controller_bench(args, rank, world, local_rank):
             out["cpu_baseline"] = cpu_baseline(inp, vx, vy, om, pose(args.steps - 1), found, cost, raw, args,
                                                args.cpu_seconds)
         if use_dist:
-            out["config"]["collective"] = "kc_dwa_cycle_sharded: 1 x ncclAllReduce(int64, min) per cycle (RCCL inside libkompass_hip.so)"
+            rw = sharding.words_per_rank([count])
+            out["config"]["collective"] = (
+                f"kc_dwa_cycle_sharded: ONE all-reduce(int64 x {2 + world * rw}, min) per cycle -- best key, error word, "
+                f"every rank's admissible bitmap ({rw} words per rank) -- " +
+                ("RCCL inside libkompass_hip.so" if comm.transport == "rccl" else
+                 "REHEARSAL: the ranks share GPUs, host shared-memory transport instead of RCCL"))
+            out["config"]["transport"] = comm.transport
+            out["n_ranks_seen"] = int(kh.lib().kc_comm_world(comm.h))
+            out["ranks"] = seen
+            out["ranks_agree"] = all(s_["winner"] == seen[0]["winner"] for s_ in seen)
+            out["winner"]["index"] = int(last.index)
         if world == 1 and not use_dist and not args.only_headline:
             # the same lattice on the two other scenes: each a bench line of its own
             for key, scene in (("mid_density", "mid"), ("open_space", "open")):
@@ -230,63 +285,60 @@ def controller_bench(args, rank, world, local_rank):
     if use_dist and not args.only_headline:
         strong = {}
         for scfg in ("cfg3", "cfg5"):
-            leg = strong_leg(kh, syn, sharding, scfg, rank, world, local_rank, comm, args, barrier, torch)
+            leg = strong_leg(kh, syn, sharding, scfg, rank, world, device, comm, args, ranks)
             if rank == 0:
                 strong[scfg] = leg
         if rank == 0:
             out["strong"] = strong
     if use_dist:
-        import torch.distributed as dist
-
-        dist.barrier()
-        if comm is not None:
-            comm.close()
-        dist.destroy_process_group()
+        ranks.barrier()
+        comm.close()
+        ranks.close()
     ctx.close()
     return out
 
 
-def strong_leg(kh, syn, sharding, cfg, rank, world, local_rank, comm, args, barrier, torch):
+def strong_leg(kh, syn, sharding, cfg, rank, world, device, comm, args, ranks):
     """BASELINE configs[2] / configs[4] as they are named: ONE fixed batch (32768 / 65536 samples)
     split over the N GPUs -- strong scaling; per N the p50 cycle latency and the whole-job rate.
+    Shares dealt by trig row (KC_SHARD_ROWS): a rank evaluates 1 / N of the host's cos / sin table.
     Scene 'mid' (about half of the samples admissible: SURVEY 8d's scene leaves cfg3 none)."""
-    import torch.distributed as dist
-
     inp = syn.make_controller_inputs(cfg, seed=0, scene="mid")
     n_total, P = len(inp["vx"]), inp["P"]
-    first, count = sharding.shard_range(n_total, rank, world)
     ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"],
                         inp["dt"], max_samples=n_total, max_points=P, max_segment=len(inp["seg_xyz"]),
-                        max_obstacles=len(inp["points"]), acc_limits=inp["acc_limits"], device=local_rank)
+                        max_obstacles=len(inp["points"]), acc_limits=inp["acc_limits"], device=device)
     ctx.set_weights(kh.make_weights(*inp["weights"]))
     ctx.set_points(inp["state"], inp["points"], inp["max_range"])
     ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+    ctx.set_shard_rule(rank, world, kh.SHARD_ROWS)
     ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
-    ctx.set_shard(first, count)
+    count, trig_rows = int(ctx.get_option("shard_samples")), int(ctx.get_option("trig_rows"))
     pose = lambda i: (0.0, 0.0, 1e-3 * ((i % 7) - 3), 0.0)
     steps, warm = max(50, args.steps // 4), max(10, args.warmup // 4)
     for i in range(warm):
         ctx.cycle_sharded(comm, pose(i), P)
     lat = []
-    barrier()
+    ranks.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         ts = time.perf_counter()
         r = ctx.cycle_sharded(comm, pose(i), P)
         lat.append(time.perf_counter() - ts)
-    barrier()
+    ranks.barrier()
     el = time.perf_counter() - t0
-    t = torch.tensor([el, float(np.percentile(np.array(lat) * 1e3, 50))], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el, p50 = float(t[0].item()), float(t[1].item())
-    idx = ctx.global_index(comm, int(r.raw_index) if r.found else -1)
-    n_adm = torch.tensor([int(r.n_admissible)], dtype=torch.int64, device="cuda")
-    dist.all_reduce(n_adm)
+    el, p50 = ranks.max(el, float(np.percentile(np.array(lat) * 1e3, 50)))
+    single = int(ctx.get_option("last_cycle_single_launch"))
+    shares = ranks.gather({"samples": count, "trig_rows": trig_rows, "single_launch": single,
+                           "winner": [bool(r.found), float(r.cost), int(r.raw_index), int(r.index), int(r.n_admissible)]})
     ctx.close()
-    return {"scaling": "strong", "workload": f"{cfg}: {n_total} samples x {P} steps in all, {count} per GPU, scene 'mid'",
+    return {"scaling": "strong", "workload": f"{cfg}: {n_total} samples x {P} steps in all, dealt by trig row, scene 'mid'",
             "value": n_total * P * steps / el, "unit": "trajectory-steps/s", "ms_per_step": 1e3 * el / steps,
-            "latency_p50_ms": p50, "steps": steps, "n_gpus": world, "n_admissible_global": int(n_adm.item()),
-            "winner": {"found": bool(r.found), "cost": float(r.cost), "raw_index": int(r.raw_index), "index": int(idx)}}
+            "latency_p50_ms": p50, "steps": steps, "n_gpus": world, "n_admissible_global": int(r.n_admissible),
+            "samples_per_rank": [s_["samples"] for s_ in shares], "trig_rows_per_rank": [s_["trig_rows"] for s_ in shares],
+            "single_launch_per_rank": [s_["single_launch"] for s_ in shares],
+            "ranks_agree": all(s_["winner"] == shares[0]["winner"] for s_ in shares),
+            "winner": {"found": bool(r.found), "cost": float(r.cost), "raw_index": int(r.raw_index), "index": int(r.index)}}
 
 
 def roofline_of(kernel_ms, count, P, map_side, S, O, scene="survey", cfg="cfg2"):
@@ -869,6 +921,63 @@ def ref_mapper400_bench(args):
     }
 
 
+def hip_library_loaded():
+    """True when this process has mapped libkompass_hip.so or the HIP runtime."""
+    try:
+        maps = open("/proc/self/maps").read()
+    except OSError:
+        return None
+    return ("libkompass_hip" in maps) or ("libamdhip64" in maps)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes (torch.distributed.run,
+    rendezvous on 127.0.0.1) as CHILDREN of this process, which has not touched the GPU and never will;
+    rank 0's JSON line is relayed, the launcher's return code is this script's."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this pool)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+    print(f"[bench] launcher pid {os.getpid()}: {n} ranks, rc {p.returncode}, "
+          f"launcher_loaded_hip_library={hip_library_loaded()}", file=sys.stderr, flush=True)
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        print("[bench] the ranks printed no JSON line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
+def dry_rank(args, rank, world, local_rank):
+    """--dry-launch: what a rank would start from -- no GPU work (launcher test on CPU)."""
+    import torch.distributed as dist
+
+    if args.dry_fail_rank == rank:
+        sys.exit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "ppid": os.getppid(),
+          "master": os.environ.get("MASTER_ADDR"), "hip_library_loaded": hip_library_loaded()}
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "ranks": out}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -887,6 +996,9 @@ def main():
     ap.add_argument("--pointcloud", action="store_true", help="SURVEY 8f rank 1 instead of the controller")
     ap.add_argument("--ref", choices=["cost5k", "mapper400"],
                     help="the reference's own published benchmark workloads (benchmark_runner.cpp) instead")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, report their environment, do no GPU work (launcher test)")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="with --dry-launch: this rank exits with code 3")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -895,9 +1007,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if args.dry_launch:
+        return dry_rank(args, rank, world, local_rank)
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version
     # banner on stdout when the first communicator comes up) are pointed at stderr
     sys.stdout.flush()

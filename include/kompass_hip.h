@@ -106,8 +106,10 @@ typedef struct {
                           numbering); -1 if not found */
   int64_t raw_index;   /* index into the generated sample list (global, i.e.
                           including the shard offset); -1 if not found */
-  int64_t n_admissible;/* samples->size() on this context's shard */
-  int64_t n_samples;   /* samples rolled out on this context's shard */
+  int64_t n_admissible;/* samples->size() on this context's shard (kc_dwa_cycle_sharded:
+                          over all ranks) */
+  int64_t n_samples;   /* samples rolled out on this context's shard
+                          (kc_dwa_cycle_sharded: over all ranks) */
 } kc_result;
 
 /* ------------------------------------------------------------------------ */
@@ -169,8 +171,9 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host
  *   "trig_copy"      (0) trig table through pinned memory + H2D copy instead of BAR stores
  *   "force_split"    (0) roll-out, collision and compaction as separate kernels
- * kc_dwa_get_option also reads "last_cycle_single_launch", "last_cycle_samples" and
- * "host_threads".
+ * kc_dwa_get_option also reads "last_cycle_single_launch", "last_cycle_samples",
+ * "host_threads", "trig_rows" (rows of the host's cos / sin table: distinct omegas of
+ * this context's share) and "shard_samples".
  * Waits for the context's stream.  Process-wide defaults may be preset with the
  * environment variables listed in DESIGN.md (test hooks). */
 int kc_dwa_set_option(kc_dwa *ctx, const char *name, double value);
@@ -197,8 +200,39 @@ int kc_dwa_sample_window(kc_dwa *ctx, int ctr_type, const kc_limits *limits,
 int kc_dwa_set_samples(kc_dwa *ctx, size_t n, const double *vx,
                        const double *vy, const double *omega);
 /* multi-GPU sharding: this context rolls out only samples [first, first+count)
- * of the list; raw indices and the packed key carry the global index */
+ * of the list; raw indices and the packed key carry the global index.  Clears a
+ * rule set with kc_dwa_set_shard_rule. */
 int kc_dwa_set_shard(kc_dwa *ctx, size_t first, size_t count);
+/* Sharding by RULE (what kc_dwa_cycle_sharded needs with more than one rank: every
+ * rank must know every rank's share to turn the exchanged bitmaps into the
+ * reference's admissible-only index).  Every rank passes the FULL list to
+ * kc_dwa_sample_window / kc_dwa_set_samples (the reference generates the whole
+ * lattice on the host too, trajectory_sampler.cpp:181-275); the context keeps its
+ * share.  Applies to the current list and to every later one.
+ *   KC_SHARD_BLOCKS  rank r owns the contiguous block [n r / W, n (r + 1) / W)
+ *   KC_SHARD_ROWS    samples are dealt by trig row (distinct omega): row k (in order
+ *                    of first appearance) -> rank k mod W, a row with more than twice
+ *                    the mean number of samples (omni: the omega = 0 row) sample by
+ *                    sample.  A rank then evaluates 1 / W of the host's cos / sin
+ *                    table (path.h:24-30: one libm pair per step and omega) instead
+ *                    of all of it, and uploads only its own samples.
+ * Raw indices in results, keys and kc_dwa_get_samples stay GLOBAL (positions in the
+ * full list = the reference's generation order) under either rule.
+ * mode < 0 clears the rule (the context owns the whole list again). */
+enum { KC_SHARD_BLOCKS = 0, KC_SHARD_ROWS = 1 };
+int kc_dwa_set_shard_rule(kc_dwa *ctx, int rank, int world, int mode);
+/* the deal itself, as a pure host function (no device): rows[i] = trig row of
+ * sample i (any labelling of the distinct omegas), owner_out[i] = rank that owns it */
+int kc_shard_plan(const int32_t *rows, size_t n, int world, int mode, int32_t *owner_out);
+/* the reduced exchange record of a sharded cycle -> result (pure host function;
+ * layout in kc_shard.h / DESIGN.md section 8: [key, error, world x words_per_rank
+ * bitmap words]).  owner: as from kc_shard_plan (NULL with KC_SHARD_BLOCKS).
+ * Returns KC_ERR_HIP when the record carries a rank's error word. */
+int kc_shard_merge(const int64_t *record, size_t words_per_rank, int world, int mode,
+                   const int32_t *owner, size_t n_total, kc_result *out);
+/* 1 when sample global_raw_index of the current list belongs to this context's
+ * share (its row can be fetched here), else 0 */
+int kc_dwa_owns_sample(kc_dwa *ctx, int64_t global_raw_index, int *owned_out);
 
 /* sensor data for BOTH consumers, once per cycle:
  *  CollisionChecker::updateState + updateSensorData<T> (collision_check.cpp:
@@ -324,22 +358,42 @@ int kc_dwa_count_admissible_before(kc_dwa *ctx, int64_t global_raw_index,
 typedef struct kc_comm kc_comm;
 int kc_comm_unique_id(uint8_t id_out[KC_COMM_ID_BYTES]);
 int kc_comm_create(int rank, int world, const uint8_t id_in[KC_COMM_ID_BYTES], int device, kc_comm **out);
+/* Rehearsal / test transport for hosts with fewer GPUs than ranks (RCCL refuses two
+ * ranks on one device): the ranks are processes of ONE host that meet in a POSIX
+ * shared-memory segment called `name` (unique per communicator; rank 0 creates it),
+ * the exchange record is reduced by the host (D2H, min, H2D in stream order).  Same
+ * kc_dwa_cycle_sharded code on both sides of the one all-reduce call; not the
+ * multi-GPU product path.  KC_SHM_TIMEOUT_MS bounds every wait for a peer (20 s). */
+int kc_comm_create_shm(int rank, int world, const char *name, int device, kc_comm **out);
 void kc_comm_destroy(kc_comm *comm);
 int kc_comm_rank(const kc_comm *comm);
 int kc_comm_world(const kc_comm *comm);
+enum { KC_COMM_RCCL = 0, KC_COMM_SHM = 1 };
+int kc_comm_transport(const kc_comm *comm);
 /* after kc_dwa_evaluate: ONE ncclAllReduce(1 x int64, ncclMin) of the packed key in
  * the device record, on the context's stream, and the hand-off of the reduced
  * record to the host (kc_dwa_fetch_result then returns the GLOBAL winner: found,
- * cost, raw_index; index / n_admissible stay the shard's) */
+ * cost, raw_index; index / n_admissible stay the shard's).  Building block for
+ * callers with a protocol of their own; kc_dwa_cycle_sharded does not use it. */
 int kc_dwa_allreduce_best(kc_dwa *ctx, kc_comm *comm);
-/* DWA::findBestPath body of a sharded controller: this context's shard rolled out
- * and scored (single launch when it fits), the all-reduce, the result.  Collective:
- * every rank of the communicator calls it with the same start / num_points. */
+/* DWA::findBestPath body of a sharded controller: this context's share rolled out
+ * and scored (single launch when it fits), ONE all-reduce(int64 x (2 + world x
+ * words), min) of the exchange record -- best key, error word, every rank's
+ * admissible bitmap -- and the result, the same on every rank: found, cost,
+ * raw_index, index (the reference's admissible-only numbering over ALL ranks) and
+ * n_admissible / n_samples over all ranks.  Collective: every rank of the
+ * communicator calls it with the same start / num_points, after
+ * kc_dwa_set_shard_rule(rank, world, ...) (a world of one may use kc_dwa_set_shard).
+ * Errors are collective too: when any rank fails (its roll-out gave up waiting for
+ * the host's trig table, or a call failed before the exchange) EVERY rank returns an
+ * error for this cycle and all of them have taken part in exactly one all-reduce, so
+ * the next cycle pairs up again. */
 int kc_dwa_cycle_sharded(kc_dwa *ctx, kc_comm *comm, const kc_state *start, size_t num_points,
                          kc_result *out);
 /* the winner's index in the reference's admissible-only numbering: admissible
  * samples in front of it on every shard, one ncclAllReduce(1 x int64, ncclSum).
- * Collective; global_raw_index from the result of kc_dwa_cycle_sharded. */
+ * Collective.  kc_dwa_cycle_sharded returns that index already; this remains for
+ * callers of kc_dwa_allreduce_best. */
 int kc_dwa_global_index(kc_dwa *ctx, kc_comm *comm, int64_t global_raw_index, int64_t *index_out);
 
 /* decode helpers for the packed key (pure host functions) */

@@ -330,12 +330,18 @@ PYBIND11_MODULE(kompass_cpp, m) {
       .def("set_resolution", &DWA::resetOctreeResolution)
       .def("set_sensor_max_range", &DWA::setSensorMaxRange)
       // additions of this build (no counterpart in the reference: its DWA is one device)
-      .def("enable_sharding", [](DWA &d, int rank, int world, const py::bytes &unique_id, int device) {
+      .def("enable_sharding", [](DWA &d, int rank, int world, const py::bytes &unique_id, int device, bool by_rows) {
              const std::string id = unique_id;
              if (id.size() != KC_COMM_ID_BYTES) throw std::invalid_argument("unique_id must be 128 bytes (comm_unique_id())");
-             d.enableSharding(rank, world, reinterpret_cast<const uint8_t *>(id.data()), device);
-           }, py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("device") = 0,
-           "One DWA per process / GPU: contiguous sample shards + one 8-byte RCCL all-reduce(min) per cycle")
+             d.enableSharding(rank, world, reinterpret_cast<const uint8_t *>(id.data()), device,
+                              by_rows ? KC_SHARD_ROWS : KC_SHARD_BLOCKS);
+           }, py::arg("rank"), py::arg("world"), py::arg("unique_id"), py::arg("device") = 0, py::arg("by_rows") = true,
+           "One DWA per process / GPU: shares of the sample lattice (dealt by trig row, or contiguous blocks) + ONE "
+           "RCCL all-reduce(min) of the exchange record per cycle")
+      .def("enable_sharding_shm", [](DWA &d, int rank, int world, const std::string &name, int device, bool by_rows) {
+             d.enableShardingShm(rank, world, name, device, by_rows ? KC_SHARD_ROWS : KC_SHARD_BLOCKS);
+           }, py::arg("rank"), py::arg("world"), py::arg("name"), py::arg("device") = 0, py::arg("by_rows") = true,
+           "The same over the shared-memory rehearsal transport (ranks that share a GPU)")
       .def("disable_sharding", &DWA::disableSharding)
       .def("use_resident_path", &DWA::useResidentPath, py::arg("on"),
            "Tracked-segment tables from a device-resident copy of the path (saves host time, adds a kernel)");

@@ -85,15 +85,26 @@ class DWA : public Follower {
   }
 
   // Multi-GPU: one DWA per process / GPU, all fed the same inputs; every
-  // cycle each scores its contiguous block of the sample lattice and ONE 8-byte RCCL
-  // all-reduce(min) picks the winner -- every rank returns the same command.
+  // cycle each scores its share of the sample lattice -- dealt by trig row, so that a
+  // rank evaluates 1 / world of the host's cos / sin table -- and ONE RCCL
+  // all-reduce(min) of the exchange record (best key, error word, admissible bitmaps)
+  // picks the winner: every rank returns the same command, or every rank fails the cycle.
   // unique_id: KC_COMM_ID_BYTES from kc_comm_unique_id() of one rank.  Collective.
-  void enableSharding(int rank, int world, const uint8_t *unique_id, int device = 0) {
+  void enableSharding(int rank, int world, const uint8_t *unique_id, int device = 0, int mode = KC_SHARD_ROWS) {
     kc_comm *raw = nullptr;
     hip::check(kc_comm_create(rank, world, unique_id, device, &raw));
-    comm_ = std::shared_ptr<kc_comm>(raw, [](kc_comm *c) { kc_comm_destroy(c); });
+    adoptComm(raw, mode);
   }
-  void disableSharding() { comm_.reset(); }
+  // rehearsal transport for ranks that share a GPU (kc_comm_create_shm)
+  void enableShardingShm(int rank, int world, const std::string &name, int device = 0, int mode = KC_SHARD_ROWS) {
+    kc_comm *raw = nullptr;
+    hip::check(kc_comm_create_shm(rank, world, name.c_str(), device, &raw));
+    adoptComm(raw, mode);
+  }
+  void disableSharding() {
+    comm_.reset();
+    hip::check(kc_dwa_set_shard_rule(trajCostEvaluator->context().get(), 0, 1, -1));
+  }
   // see CostEvaluator::useResidentPath
   void useResidentPath(bool on) { trajCostEvaluator->useResidentPath(on); }
 
@@ -154,6 +165,11 @@ class DWA : public Follower {
   double max_forward_distance_ = 0.0;
   int maxNumThreads;
   std::shared_ptr<kc_comm> comm_;
+  void adoptComm(kc_comm *raw, int mode) {
+    comm_ = std::shared_ptr<kc_comm>(raw, [](kc_comm *c) { kc_comm_destroy(c); });
+    // the context keeps this rank's share of every lattice it is handed from now on
+    hip::check(kc_dwa_set_shard_rule(trajCostEvaluator->context().get(), kc_comm_rank(raw), kc_comm_world(raw), mode));
+  }
   std::unique_ptr<TrajectorySamples2D> debuggingSamples_ = nullptr;
   float maxLocalRange_ = 10.0;
 

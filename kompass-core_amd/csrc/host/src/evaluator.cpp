@@ -216,17 +216,18 @@ TrajSearchResult CostEvaluator::cycleOnDevice(const Path::Path *ref, const Path:
                                               size_t n_generated, kc_comm *comm) {
   uploadSegment(ref, seg);
   const kc_state st{pose.x, pose.y, pose.yaw, pose.speed};
-  if (comm) {
-    // contiguous block of the replicated lattice
-    const size_t world = static_cast<size_t>(kc_comm_world(comm)), rank = static_cast<size_t>(kc_comm_rank(comm));
-    const size_t first = n_generated * rank / world, last = n_generated * (rank + 1) / world;
-    hip::check(kc_dwa_set_shard(ctx_.get(), first, last - first));
-  }
+  // (sharded: the context already holds this rank's share of the lattice -- DWA::enableSharding set the
+  // rule, kc_dwa_sample_window applied it)
+  (void)n_generated;
   kc_result r;
   auto run = [&]() { return comm ? kc_dwa_cycle_sharded(ctx_.get(), comm, &st, P, &r) : kc_dwa_cycle(ctx_.get(), &st, P, &r); };
   int rc = run();
+  // The retry contract (see the header): once.  With a communicator the error is collective -- the
+  // exchange record carries an error word, so EVERY rank sees "gave up waiting" for the same cycle and
+  // every rank repeats it: the ranks stay paired (a lone retry used to put one rank a
+  // collective out of step).
   if (rc == KC_ERR_HIP && std::string(kc_last_error()).find("gave up waiting") != std::string::npos)
-    rc = run();  // the retry contract (see the header): once
+    rc = run();
   hip::check(rc);
   sensorDataResident = false;
   if (!customTrajCostsPtrs_.empty()) {
@@ -238,11 +239,13 @@ TrajSearchResult CostEvaluator::cycleOnDevice(const Path::Path *ref, const Path:
   if (!r.found) return out;
   out.isTrajFound = true;
   out.trajCost = r.cost;
-  const bool mine = kc_dwa_get_best(ctx_.get(), out.trajectory.path.x.data(), out.trajectory.path.y.data(),
-                                    out.trajectory.velocities.vx.data(), out.trajectory.velocities.vy.data(),
-                                    out.trajectory.velocities.omega.data()) == KC_OK;
+  int mine = 1;
+  if (comm) hip::check(kc_dwa_owns_sample(ctx_.get(), r.raw_index, &mine));
+  if (mine)
+    hip::check(kc_dwa_get_best(ctx_.get(), out.trajectory.path.x.data(), out.trajectory.path.y.data(),
+                               out.trajectory.velocities.vx.data(), out.trajectory.velocities.vy.data(),
+                               out.trajectory.velocities.omega.data()));
   if (!mine) {
-    if (!comm) hip::check(KC_ERR_STATE);
     // the winner lives on another rank: its velocity is known here (the lattice is replicated),
     // its path is Path::State::update (path.h:24-30) from that velocity -- the device's arithmetic
     const Velocity2D v = sampleVelocity(static_cast<size_t>(r.raw_index));

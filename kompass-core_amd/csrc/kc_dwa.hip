@@ -32,6 +32,7 @@
 #include "kc_rollout_kernels.h"
 #include "kc_sensor_kernels.h"
 #include "kc_segment_kernels.h"
+#include "kc_shard.h"
 
 // ===========================================================================
 // host context
@@ -256,6 +257,18 @@ struct kc_dwa {
                                // hand-off behind the all-reduce
   long long rec_w4 = 0;        // row word of the record fetched last
   bool row_valid = false;      // h_wrow holds the winner row of `last`
+
+  // sharding by rule + the exchange record of a sharded cycle (kc_shard.h)
+  ShardLayout layout;
+  hm::VelocityLattice full;    // KC_SHARD_ROWS: the full list (`lat` is this rank's share of it)
+  std::vector<int32_t> gid;    // KC_SHARD_ROWS: id in `lat` -> global id (position in `full`)
+  DevBuf<int32_t> d_gid;
+  DevBuf<long long> d_xs, d_xr;      // send / reduced record
+  PinBuf<long long> h_xvec, h_xrec;  // the reduced record and its 5-word hand-off record, written by the GPU
+  int x_world = 0, x_rank = -1;      // what d_xs is armed for (the other ranks' words hold INT64_MAX)
+  size_t x_rw = 0;
+  long long xseq = 0;
+  int64_t last_lat = -1;       // id in `lat` of the last winner when it lives on this context, else -1
 };
 
 namespace {
@@ -705,6 +718,60 @@ int upload_samples(kc_dwa *c) {
   if (!same_rows) c->uploaded_rows = c->lat.row;
   return KC_OK;
 }
+
+// global id (position in the caller's full list) of sample `lat_id` of this context's list
+inline int64_t global_of(const kc_dwa *c, int64_t lat_id) {
+  return (c->gid.empty() || lat_id < 0) ? lat_id : static_cast<int64_t>(c->gid[static_cast<size_t>(lat_id)]);
+}
+
+// c->lat holds the caller's FULL list: keep this rank's share under the shard rule and upload
+int apply_shard_rule(kc_dwa *c) {
+  ShardLayout &L = c->layout;
+  c->gid.clear();
+  c->full.clear();
+  if (L.mode < 0) return upload_samples(c);
+  const size_t n = c->lat.size();
+  L.n_total = n;
+  const size_t me = static_cast<size_t>(L.rank);
+  if (L.mode == KC_SHARD_BLOCKS) {
+    shard_blocks(n, L.world, L);
+    KC_TRY(upload_samples(c));
+    c->shard_first = L.first[me];
+    c->shard_count = L.count[me];
+    return KC_OK;
+  }
+  // KC_SHARD_ROWS: the deal depends on the pattern of trig rows only (a controller draws a new
+  // window every cycle: the velocities change, the pattern rarely does)
+  const bool same = L.rows_seen == c->lat.row && L.gids.size() == static_cast<size_t>(L.world);
+  if (!same) shard_rows(c->lat.row, L.world, L);
+  c->full = std::move(c->lat);
+  c->lat.clear();
+  const std::vector<int32_t> &mine = L.gids[me];
+  c->gid = mine;
+  // this rank's rows, relabelled in ascending order of the full list's labels
+  std::vector<int32_t> relabel(c->full.omega_values.size(), -1);
+  for (int32_t g : mine) relabel[static_cast<size_t>(c->full.row[static_cast<size_t>(g)])] = 0;
+  for (size_t a = 0; a < relabel.size(); ++a)
+    if (relabel[a] == 0) {
+      relabel[a] = static_cast<int32_t>(c->lat.omega_values.size());
+      c->lat.omega_values.push_back(c->full.omega_values[a]);
+    }
+  c->lat.vx.reserve(mine.size());
+  c->lat.vy.reserve(mine.size());
+  c->lat.row.reserve(mine.size());
+  for (int32_t g : mine)
+    c->lat.push(c->full.vx[static_cast<size_t>(g)], c->full.vy[static_cast<size_t>(g)],
+                relabel[static_cast<size_t>(c->full.row[static_cast<size_t>(g)])]);
+  KC_TRY(upload_samples(c));  // (shard = the whole of `lat`)
+  if (!same || c->d_gid.cap < mine.size()) {
+    KC_TRY(c->d_gid.reserve(std::max<size_t>(mine.size(), 1)));
+    if (!mine.empty()) KC_HIP(hipMemcpy(c->d_gid.p, mine.data(), mine.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return KC_OK;
+}
+
+// the caller's full list (sample_window output, velocity look-ups by global id)
+inline const hm::VelocityLattice &full_list(const kc_dwa *c) { return c->gid.empty() ? c->lat : c->full; }
 
 // host lists of a global-frame point update (add_voxel per point, obstacle
 // coordinates through obs_tf): the sensor path of the host, and the lazy
@@ -1715,6 +1782,8 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
       }
     }
   }
+  c->last_lat = r.found ? r.raw_index : -1;
+  if (r.found && !c->external) r.raw_index = global_of(c, r.raw_index);
   c->last = r;
   c->have_last = true;
   if (out) *out = r;
@@ -1797,6 +1866,15 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
           break;  // get_best falls back to the device copy
       }
     }
+  }
+  // (a key that came back from kc_dwa_allreduce_best may name another rank's sample)
+  c->last_lat = r.found ? r.raw_index : -1;
+  if (r.found && !c->external) {
+    if (c->last_lat < static_cast<int64_t>(c->shard_first) ||
+        c->last_lat >= static_cast<int64_t>(c->shard_first + c->n_roll))
+      c->last_lat = -1;
+    else
+      r.raw_index = global_of(c, r.raw_index);
   }
   c->last = r;
   c->have_last = true;
@@ -2222,6 +2300,8 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "force_split") *v = c->lds_limit == 0;
   else if (n == "last_cycle_single_launch") *v = c->cycle_launched;  // read-only
   else if (n == "host_threads") *v = WorkerPool::instance().workers() + 1;  // read-only here: kc_set_host_threads
+  else if (n == "trig_rows") *v = static_cast<double>(c->lat.omega_values.size());  // read-only: rows of the host's cos / sin table
+  else if (n == "shard_samples") *v = static_cast<double>(c->shard_count);          // read-only: samples this context rolls out
   else
     KC_FAIL(KC_ERR_INVALID, "unknown option '%s'", name);
   return KC_OK;
@@ -2251,15 +2331,16 @@ int kc_dwa_sample_window(kc_dwa *c, int ctr_type, const kc_limits *limits,
   KC_TRY(use_device(c));
   hm::build_window_lattice(ctr_type, *limits, cvx, cvy, com, c->prm.time_step,
                            max_lin, max_ang, c->lat);
-  KC_TRY(upload_samples(c));
-  const size_t n = c->lat.size();
+  KC_TRY(apply_shard_rule(c));
+  const hm::VelocityLattice &fl = full_list(c);
+  const size_t n = fl.size();
   if (n_out) *n_out = n;
   if (vx || vy || omega) {
     if (cap < n) KC_FAIL(KC_ERR_RANGE, "output capacity %zu < %zu", cap, n);
     for (size_t i = 0; i < n; ++i) {
-      if (vx) vx[i] = c->lat.vx[i];
-      if (vy) vy[i] = c->lat.vy[i];
-      if (omega) omega[i] = c->lat.omega_values[c->lat.row[i]];
+      if (vx) vx[i] = fl.vx[i];
+      if (vy) vy[i] = fl.vy[i];
+      if (omega) omega[i] = fl.omega_values[fl.row[i]];
     }
   }
   return KC_OK;
@@ -2288,16 +2369,97 @@ int kc_dwa_set_samples(kc_dwa *c, size_t n, const double *vx, const double *vy,
     }
     c->lat.push(vx[i], vy[i], r);
   }
-  return upload_samples(c);
+  return apply_shard_rule(c);
 }
 
 int kc_dwa_set_shard(kc_dwa *c, size_t first, size_t count) {
   if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  KC_TRY(use_device(c));
+  if (c->layout.mode == KC_SHARD_ROWS && !c->gid.empty()) {  // the full list again
+    c->lat = std::move(c->full);
+    c->layout.mode = -1;
+    KC_TRY(apply_shard_rule(c));
+  }
+  c->layout.mode = -1;
   if (first + count > c->lat.size())
     KC_FAIL(KC_ERR_RANGE, "shard [%zu, %zu) outside the %zu samples", first,
             first + count, c->lat.size());
   c->shard_first = first;
   c->shard_count = count;
+  return KC_OK;
+}
+
+int kc_dwa_set_shard_rule(kc_dwa *c, int rank, int world, int mode) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (mode >= 0 && mode != KC_SHARD_BLOCKS && mode != KC_SHARD_ROWS) KC_FAIL(KC_ERR_INVALID, "unknown shard mode %d", mode);
+  if (mode >= 0 && (world < 1 || rank < 0 || rank >= world)) KC_FAIL(KC_ERR_RANGE, "rank %d outside world %d", rank, world);
+  KC_TRY(use_device(c));
+  if (!c->gid.empty()) c->lat = std::move(c->full);  // the full list back in front of the rule
+  c->layout = ShardLayout{};
+  c->layout.mode = mode < 0 ? -1 : mode;
+  c->layout.rank = mode < 0 ? 0 : rank;
+  c->layout.world = mode < 0 ? 1 : world;
+  return apply_shard_rule(c);
+}
+
+int kc_shard_plan(const int32_t *rows, size_t n, int world, int mode, int32_t *owner_out) {
+  if ((n && (!rows || !owner_out))) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (world < 1) KC_FAIL(KC_ERR_RANGE, "world %d", world);
+  if (mode == KC_SHARD_ROWS) {
+    for (size_t i = 0; i < n; ++i)
+      if (rows[i] < 0) KC_FAIL(KC_ERR_RANGE, "negative row label at %zu", i);
+    shard_rows_owner(rows, n, world, owner_out);
+  } else if (mode == KC_SHARD_BLOCKS) {
+    ShardLayout L;
+    shard_blocks(n, world, L);
+    for (int r = 0; r < world; ++r)
+      for (size_t i = 0; i < L.count[static_cast<size_t>(r)]; ++i) owner_out[L.first[static_cast<size_t>(r)] + i] = r;
+  } else {
+    KC_FAIL(KC_ERR_INVALID, "unknown shard mode %d", mode);
+  }
+  return KC_OK;
+}
+
+int kc_shard_merge(const int64_t *record, size_t words_per_rank, int world, int mode, const int32_t *owner,
+                   size_t n_total, kc_result *out) {
+  if (!record || !out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (world < 1) KC_FAIL(KC_ERR_RANGE, "world %d", world);
+  ShardLayout L;
+  L.mode = mode;
+  L.world = world;
+  L.n_total = n_total;
+  if (mode == KC_SHARD_BLOCKS) {
+    shard_blocks(n_total, world, L);
+  } else if (mode == KC_SHARD_ROWS) {
+    if (n_total && !owner) KC_FAIL(KC_ERR_INVALID, "KC_SHARD_ROWS needs the owner table");
+    L.count.assign(static_cast<size_t>(world), 0);
+    L.first.assign(static_cast<size_t>(world), 0);
+    L.gids.assign(static_cast<size_t>(world), {});
+    for (size_t g = 0; g < n_total; ++g) {
+      if (owner[g] < 0 || owner[g] >= world) KC_FAIL(KC_ERR_RANGE, "owner[%zu] = %d outside world %d", g, owner[g], world);
+      L.gids[static_cast<size_t>(owner[g])].push_back(static_cast<int32_t>(g));
+    }
+    for (int r = 0; r < world; ++r) L.count[static_cast<size_t>(r)] = L.gids[static_cast<size_t>(r)].size();
+  } else {
+    KC_FAIL(KC_ERR_INVALID, "unknown shard mode %d", mode);
+  }
+  if (64 * words_per_rank < L.max_count())
+    KC_FAIL(KC_ERR_RANGE, "%zu words per rank cannot hold a share of %zu samples", words_per_rank, L.max_count());
+  bool failed = false;
+  static_assert(sizeof(long long) == sizeof(int64_t), "record words");
+  merge_exchange(L, reinterpret_cast<const long long *>(record), words_per_rank, out, &failed);
+  if (failed) KC_FAIL(KC_ERR_HIP, "the exchange record carries a rank's error word (%lld)", static_cast<long long>(record[X_ERR]));
+  return KC_OK;
+}
+
+int kc_dwa_owns_sample(kc_dwa *c, int64_t raw, int *owned) {
+  if (!c || !owned) KC_FAIL(KC_ERR_INVALID, "null argument");
+  int64_t lat_id = raw;
+  if (!c->gid.empty()) {
+    const auto it = std::lower_bound(c->gid.begin(), c->gid.end(), static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(raw, -1), INT32_MAX)));
+    lat_id = (raw >= 0 && it != c->gid.end() && *it == raw) ? static_cast<int64_t>(it - c->gid.begin()) : -1;
+  }
+  *owned = (lat_id >= static_cast<int64_t>(c->shard_first) && lat_id < static_cast<int64_t>(c->shard_first + c->shard_count)) ? 1 : 0;
   return KC_OK;
 }
 
@@ -2850,6 +3012,9 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   // and survivors in each.  (Option "cycle_samples": 0 = this rule, 16 / 32 = fixed.)
   int cs = c->cycle_samples_opt;
   if (cs == 0) cs = 2 * blocks_for(n, 32) <= static_cast<unsigned>(c->num_cus) ? 16 : 32;
+  // the last arriver of the ticket epilogue holds two workgroup keys per lane (kc_cycle_dev.h): at most
+  // 2048 workgroups, whatever the option says (65536 samples in 16-sample workgroups would be 4096)
+  if (blocks_for(n, static_cast<unsigned>(cs)) > 2048u) cs = 32;
   c->cycle_samples = cs;
   const unsigned cyc_G = blocks_for(n, static_cast<unsigned>(cs));
   const bool cyc_wave = cyc_G <= static_cast<unsigned>(c->num_cus);
@@ -3165,8 +3330,10 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
     KC_FAIL(KC_ERR_STATE, "no trajectory found in the last cycle");
   KC_TRY(use_device(c));
   const size_t P = c->P;
-  const size_t local = static_cast<size_t>(c->last.raw_index) -
-                       (c->external ? 0 : c->shard_first);
+  if (c->last_lat < 0)
+    KC_FAIL(KC_ERR_STATE, "winner %lld is not on this shard",
+            static_cast<long long>(c->last.raw_index));
+  const size_t local = static_cast<size_t>(c->last_lat) - (c->external ? 0 : c->shard_first);
   if (local >= c->n_roll)
     KC_FAIL(KC_ERR_STATE, "winner %lld is not on this shard",
             static_cast<long long>(c->last.raw_index));
@@ -3187,7 +3354,7 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
   if (vvx || vvy || vom) {
     if (c->external)
       KC_FAIL(KC_ERR_STATE, "velocities belong to the caller in evaluate mode");
-    const size_t g = static_cast<size_t>(c->last.raw_index);
+    const size_t g = static_cast<size_t>(c->last_lat);
     // TrajectoryVelocities2D::add: float = double (trajectory.h:96-103)
     const float fx = static_cast<float>(c->lat.vx[g]);
     const float fy = static_cast<float>(c->lat.vy[g]);
@@ -3204,13 +3371,14 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
 int kc_dwa_get_sample_velocity(kc_dwa *c, int64_t raw, double *vx, double *vy,
                                double *omega) {
   if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
-  if (raw < 0 || static_cast<size_t>(raw) >= c->lat.size())
+  const hm::VelocityLattice &fl = full_list(c);
+  if (raw < 0 || static_cast<size_t>(raw) >= fl.size())
     KC_FAIL(KC_ERR_RANGE, "sample %lld outside the %zu samples",
-            static_cast<long long>(raw), c->lat.size());
+            static_cast<long long>(raw), fl.size());
   const size_t g = static_cast<size_t>(raw);
-  if (vx) *vx = c->lat.vx[g];
-  if (vy) *vy = c->lat.vy[g];
-  if (omega) *omega = c->lat.omega_values[c->lat.row[g]];
+  if (vx) *vx = fl.vx[g];
+  if (vy) *vy = fl.vy[g];
+  if (omega) *omega = fl.omega_values[fl.row[g]];
   return KC_OK;
 }
 
@@ -3249,7 +3417,7 @@ int kc_dwa_get_samples(kc_dwa *c, float *paths_x, float *paths_y,
       if (paths_y) std::memcpy(paths_y + row * P, hy.data() + i * P, P * 4);
       if (raw_index)
         raw_index[row] = static_cast<int32_t>(
-            i + (c->external ? 0 : c->shard_first));
+            c->external ? static_cast<int64_t>(i) : global_of(c, static_cast<int64_t>(i + c->shard_first)));
       if (costs) costs[row] = hc[i];
     }
     ++row;
@@ -3348,6 +3516,95 @@ int kc_cost_evaluate(kc_dwa *c, const float *paths_x, const float *paths_y,
   return kc_cost_evaluate_resident(c, costs_out, out);
 }
 
+namespace {
+// shard-local ids in front of global sample `raw` on this context
+long long local_bound(const kc_dwa *c, int64_t raw) {
+  if (raw <= 0) return 0;
+  long long lat_lim;
+  if (c->gid.empty() || c->external)
+    lat_lim = raw;
+  else
+    lat_lim = std::lower_bound(c->gid.begin(), c->gid.end(), static_cast<int32_t>(std::min<int64_t>(raw, INT32_MAX))) -
+              c->gid.begin();
+  const long long first = c->external ? 0 : static_cast<long long>(c->shard_first);
+  return std::min<long long>(std::max<long long>(lat_lim - first, 0), static_cast<long long>(c->n_roll));
+}
+
+// d_xs / d_xr / pinned mirrors of the exchange record for (world, rank, words per rank); the
+// words of the OTHER ranks in the send record hold INT64_MAX for good (the minimum passes the
+// owner's words through), this rank's are rewritten every cycle
+int ensure_xchg(kc_dwa *c, int world, int rank, size_t rw) {
+  const size_t len = X_REGIONS + static_cast<size_t>(world) * rw;
+  if (c->x_world == world && c->x_rank == rank && c->x_rw == rw && c->d_xs.p) return KC_OK;
+  KC_HIP(hipStreamSynchronize(c->stream));
+  KC_TRY(c->d_xs.reserve(len));
+  KC_TRY(c->d_xr.reserve(len));
+  KC_TRY(c->h_xvec.reserve(len));
+  KC_TRY(c->h_xrec.reserve(8));
+  std::vector<long long> init(len, INT64_MAX);
+  init[X_KEY] = KEY_NONE;
+  init[X_ERR] = 0;
+  for (size_t j = 0; j < rw; ++j) init[X_REGIONS + static_cast<size_t>(rank) * rw + j] = 0;
+  KC_HIP(hipMemcpy(c->d_xs.p, init.data(), len * sizeof(long long), hipMemcpyHostToDevice));
+  std::memset(c->h_xrec.p, 0, 8 * sizeof(long long));
+  c->x_world = world;
+  c->x_rank = rank;
+  c->x_rw = rw;
+  return KC_OK;
+}
+
+// the reduced record of a sharded cycle -> result (the same on every rank)
+int fetch_xchg(kc_dwa *c, const ShardLayout &L, size_t rw, kc_result *out) {
+  const size_t len = X_REGIONS + static_cast<size_t>(L.world) * rw;
+  volatile long long *hr = c->h_xrec.p;
+  const long long *xv = c->h_xvec.p;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool synced = false;
+  for (long spins = 0;; ++spins) {
+    const long long w0 = hr[0], w1 = hr[1], w2 = hr[2], w3 = hr[3], w4 = hr[4];
+    if (w2 == c->xseq && w3 == record_check(w0, w1, w2, w4) && w1 == static_cast<long long>(len)) {
+      unsigned long long sum = 0ull;
+      for (size_t i = 0; i < len; ++i)
+        sum += xchg_word_mix(const_cast<const volatile long long *>(xv)[i], static_cast<unsigned>(i));
+      if (static_cast<long long>(sum) == w0) break;
+    }
+    if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+      // a peer may be late by its own bounded wait (50 ms) and more: wait for the stream, which ends behind
+      // the all-reduce and the hand-off kernel; a record that still does not add up then is an error
+      if (synced) KC_FAIL(KC_ERR_HIP, "the reduced exchange record never arrived intact");
+      KC_HIP(hipStreamSynchronize(c->stream));
+      synced = true;
+    }
+  }
+  c->pub_pending = false;
+  c->drained = true;
+  c->update_busy = false;
+  c->seg_busy = false;
+  c->timing.mark("host:wait_result");
+  kc_result r{};
+  bool failed = false;
+  merge_exchange(L, xv, rw, &r, &failed);
+  c->last_nadm = popcount_prefix(xv + X_REGIONS + static_cast<size_t>(L.rank) * rw, L.count[static_cast<size_t>(L.rank)]);
+  c->row_valid = false;
+  c->last_lat = -1;
+  if (failed) {
+    c->have_last = false;
+    if (xv[X_ERR] == -1)
+      KC_FAIL(KC_ERR_HIP, "sharded cycle: a rank's roll-out kernel gave up waiting for the host's trig table "
+                          "(every rank fails this cycle)");
+    KC_FAIL(KC_ERR_HIP, "sharded cycle: a rank failed before the exchange (every rank fails this cycle)");
+  }
+  if (r.found) {
+    const int64_t loc = L.local_of(L.rank, r.raw_index);
+    if (loc >= 0) c->last_lat = static_cast<int64_t>(c->shard_first) + loc;
+  }
+  c->last = r;
+  c->have_last = true;
+  if (out) *out = r;
+  return KC_OK;
+}
+}  // namespace
+
 int kc_dwa_result_device(kc_dwa *c, void **dev) {
   if (!c || !dev) KC_FAIL(KC_ERR_INVALID, "null argument");
   *dev = c->d_result.p;
@@ -3377,20 +3634,86 @@ int kc_dwa_allreduce_best(kc_dwa *c, kc_comm *m) {
                           "kc_dwa_rollout + kc_dwa_evaluate, for a device-resident record");
   if (kc::comm_device(m) != c->prm.device)
     KC_FAIL(KC_ERR_INVALID, "communicator on device %d, controller on device %d", kc::comm_device(m), c->prm.device);
+  if (!c->gid.empty())
+    KC_FAIL(KC_ERR_STATE, "KC_SHARD_ROWS: the device record carries this rank's own numbering; use kc_dwa_cycle_sharded");
   KC_TRY(use_device(c));
-  KC_TRY(kc::comm_allreduce_i64(m, c->d_result.p + R_KEY, 1, /*sum=*/false, c->stream));
+  KC_TRY(kc::comm_allreduce_i64(m, c->d_result.p + R_KEY, c->d_result.p + R_KEY, 1, /*sum=*/false, c->stream));
   return kc_dwa_publish_result(c);
 }
 
 int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P, kc_result *out) {
   if (!c || !m) KC_FAIL(KC_ERR_INVALID, "null argument");
+  const int world = kc::comm_world(m), rank = kc::comm_rank(m);
+  // ---- everything that can fail without the peers noticing comes first: a rank that returns
+  // here has not entered the collective, and must not be the only one (argument errors are
+  // the same on every rank, or a caller bug)
+  if (kc::comm_device(m) != c->prm.device)
+    KC_FAIL(KC_ERR_INVALID, "communicator on device %d, controller on device %d", kc::comm_device(m), c->prm.device);
+  ShardLayout implicit;
+  const ShardLayout *L = &c->layout;
+  if (c->layout.mode < 0) {
+    if (world > 1)
+      KC_FAIL(KC_ERR_STATE, "a sharded cycle over %d ranks needs kc_dwa_set_shard_rule (every rank must know every "
+                            "rank's share)", world);
+    implicit.mode = KC_SHARD_BLOCKS;
+    implicit.first = {c->shard_first};
+    implicit.count = {c->shard_count};
+    implicit.n_total = c->shard_count;
+    L = &implicit;
+  } else if (c->layout.world != world || c->layout.rank != rank) {
+    KC_FAIL(KC_ERR_INVALID, "shard rule is for rank %d of %d, the communicator is rank %d of %d", c->layout.rank,
+            c->layout.world, rank, world);
+  }
+  KC_TRY(use_device(c));
+  const size_t rw = std::max<size_t>((L->max_count() + 63) / 64, 1);
+  KC_TRY(ensure_xchg(c, world, rank, rw));
+  const size_t len = X_REGIONS + static_cast<size_t>(world) * rw;
+  hipStream_t s = c->stream;
+  // ---- this rank's cycle.  From here on the rank takes part in the exchange whatever happens:
+  // a failure travels in the record's error word and fails the cycle on EVERY rank.
   c->sharded_call = true;
   int rc = rollout_impl(c, start, P, true);
   c->sharded_call = false;
-  KC_TRY(rc);
-  if (!c->cycle_launched) KC_TRY(kc_dwa_evaluate(c));
-  KC_TRY(kc_dwa_allreduce_best(c, m));
-  return kc_dwa_fetch_result(c, out);
+  if (rc == KC_OK && !c->cycle_launched) rc = kc_dwa_evaluate(c);
+  std::string why;
+  if (rc != KC_OK) why = kc_last_error();
+  c->pub_pending = false;  // (a sharded cycle hands its record over through the exchange, not h_pub)
+  if (rc == KC_OK) {
+    PackArgs pa{};
+    pa.result = c->d_result.p;
+    pa.flags = c->d_flags.p;
+    pa.n = static_cast<int>(c->n_roll);
+    pa.first = static_cast<int>(c->shard_first);
+    pa.gid = c->gid.empty() ? nullptr : c->d_gid.p;
+    pa.xs = c->d_xs.p;
+    pa.rank = rank;
+    pa.rw = static_cast<int>(rw);
+    int trc = c->timing.start("xchg_pack_kernel", s);
+    hipLaunchKernelGGL(xchg_pack_kernel, dim3(1), dim3(1024), 0, s, pa);
+    if (trc == KC_OK) trc = c->timing.stop(s);
+  } else {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(xchg_fail_kernel, dim3(1), dim3(256), 0, s, c->d_xs.p, rank, static_cast<int>(rw));
+  }
+  int trc = c->timing.start("all_reduce", s);
+  const int rc_x = kc::comm_allreduce_i64(m, c->d_xs.p, c->d_xr.p, len, /*sum=*/false, s);
+  if (trc == KC_OK) trc = c->timing.stop(s);
+  if (rc_x != KC_OK) {
+    if (rc != KC_OK) set_error("%s", why.c_str());
+    return rc != KC_OK ? rc : rc_x;
+  }
+  hipLaunchKernelGGL(xchg_publish_kernel, dim3(1), dim3(256), 0, s, c->d_xr.p, static_cast<int>(len), c->h_xvec.p,
+                     c->h_xrec.p, ++c->xseq);
+  c->drained = false;
+  kc_result r{};
+  const int rc_f = fetch_xchg(c, *L, rw, &r);
+  if (rc != KC_OK) {  // this rank's own failure is the more specific message
+    set_error("%s", why.c_str());
+    return rc;
+  }
+  KC_TRY(rc_f);
+  if (out) *out = r;
+  return KC_OK;
 }
 
 int kc_dwa_global_index(kc_dwa *c, kc_comm *m, int64_t raw, int64_t *index_out) {
@@ -3401,10 +3724,9 @@ int kc_dwa_global_index(kc_dwa *c, kc_comm *m, int64_t raw, int64_t *index_out) 
     KC_HIP(hipMemsetAsync(c->d_result.p + R_SCRATCH, 0, sizeof(long long), c->stream));
   } else {
     hipLaunchKernelGGL(count_before_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_flags.p,
-                       static_cast<int>(c->n_roll), static_cast<int>(c->external ? 0 : c->shard_first),
-                       static_cast<long long>(raw), c->d_result.p, R_SCRATCH);
+                       static_cast<int>(c->n_roll), 0, local_bound(c, raw), c->d_result.p, R_SCRATCH);
   }
-  KC_TRY(kc::comm_allreduce_i64(m, c->d_result.p + R_SCRATCH, 1, /*sum=*/true, c->stream));
+  KC_TRY(kc::comm_allreduce_i64(m, c->d_result.p + R_SCRATCH, c->d_result.p + R_SCRATCH, 1, /*sum=*/true, c->stream));
   KC_HIP(hipMemcpyAsync(c->h_result.p + R_SCRATCH, c->d_result.p + R_SCRATCH, sizeof(long long),
                         hipMemcpyDeviceToHost, c->stream));
   KC_HIP(hipStreamSynchronize(c->stream));
@@ -3421,9 +3743,7 @@ int kc_dwa_count_admissible_before(kc_dwa *c, int64_t raw, int64_t *count) {
     return KC_OK;
   }
   hipLaunchKernelGGL(count_before_kernel, dim3(1), dim3(1024), 0, c->stream,
-                     c->d_flags.p, static_cast<int>(c->n_roll),
-                     static_cast<int>(c->external ? 0 : c->shard_first),
-                     static_cast<long long>(raw), c->d_result.p, R_SCRATCH);
+                     c->d_flags.p, static_cast<int>(c->n_roll), 0, local_bound(c, raw), c->d_result.p, R_SCRATCH);
   KC_HIP(hipMemcpyAsync(c->h_result.p + R_SCRATCH, c->d_result.p + R_SCRATCH,
                         sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   KC_HIP(hipStreamSynchronize(c->stream));

@@ -246,9 +246,11 @@ struct MapperView {
 };
 int mapper_view(kc_mapper *m, MapperView *out);
 
-// kc_comm.hip: in-place all-reduce (min, or sum) of int64 words on a stream
-int comm_allreduce_i64(kc_comm *m, long long *dev, size_t count, bool sum, hipStream_t stream);
+// kc_comm.hip: all-reduce (min, or sum) of int64 words on a stream; send == recv is allowed
+int comm_allreduce_i64(kc_comm *m, const long long *send, long long *recv, size_t count, bool sum,
+                       hipStream_t stream);
 int comm_world(const kc_comm *m);
+int comm_rank(const kc_comm *m);
 int comm_device(const kc_comm *m);
 
 }  // namespace kc

@@ -95,6 +95,10 @@ SIGNATURES = {
                                        C.c_int, C.c_int, C.POINTER(_sz), _dp, _dp, _dp, _sz]),
     "kc_dwa_set_samples": (C.c_int, [_vp, _sz, _dp, _dp, _dp]),
     "kc_dwa_set_shard": (C.c_int, [_vp, _sz, _sz]),
+    "kc_dwa_set_shard_rule": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "kc_shard_plan": (C.c_int, [_ip, _sz, C.c_int, C.c_int, _ip]),
+    "kc_shard_merge": (C.c_int, [C.POINTER(C.c_int64), _sz, C.c_int, C.c_int, _ip, _sz, C.POINTER(Result)]),
+    "kc_dwa_owns_sample": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int)]),
     "kc_dwa_set_scan": (C.c_int, [_vp, C.POINTER(State), _dp, _dp, _sz, C.c_float]),
     "kc_dwa_set_points": (C.c_int, [_vp, C.POINTER(State), _fp, _sz, C.c_float]),
     "kc_dwa_set_path": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _sz, C.c_float]),
@@ -119,6 +123,8 @@ SIGNATURES = {
     "kc_dwa_count_admissible_before": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int64)]),
     "kc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "kc_comm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(_vp)]),
+    "kc_comm_create_shm": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "kc_comm_transport": (C.c_int, [_vp]),
     "kc_comm_destroy": (None, [_vp]),
     "kc_comm_rank": (C.c_int, [_vp]),
     "kc_comm_world": (C.c_int, [_vp]),
@@ -236,15 +242,46 @@ def comm_unique_id() -> bytes:
     return bytes(buf)
 
 
-class Comm:
-    """Owner of one kc_comm (an RCCL communicator inside libkompass_hip.so)."""
+SHARD_BLOCKS, SHARD_ROWS = 0, 1
+COMM_RCCL, COMM_SHM = 0, 1
 
-    def __init__(self, rank: int, world: int, unique_id: bytes, device: int = 0):
-        assert len(unique_id) == COMM_ID_BYTES
-        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+
+def shard_plan(rows, world: int, mode: int = SHARD_ROWS):
+    """kc_shard_plan: owner rank of every sample from its trig row (pure host function)."""
+    rows = np.ascontiguousarray(rows, np.int32)
+    owner = np.zeros(len(rows), np.int32)
+    _check(lib().kc_shard_plan(rows.ctypes.data_as(_ip), len(rows), int(world), int(mode),
+                               owner.ctypes.data_as(_ip)))
+    return owner
+
+
+def shard_merge(record, words_per_rank: int, world: int, mode: int, owner, n_total: int) -> Result:
+    """kc_shard_merge: the reduced exchange record -> result (pure host function)."""
+    rec = np.ascontiguousarray(record, np.int64)
+    own = None if owner is None else np.ascontiguousarray(owner, np.int32)
+    r = Result()
+    _check(lib().kc_shard_merge(rec.ctypes.data_as(C.POINTER(C.c_int64)), int(words_per_rank), int(world), int(mode),
+                                None if own is None else own.ctypes.data_as(_ip), int(n_total), C.byref(r)))
+    return r
+
+
+class Comm:
+    """Owner of one kc_comm: an RCCL communicator inside libkompass_hip.so, or -- shm_name given --
+    the shared-memory rehearsal transport for ranks that share a GPU (kc_comm_create_shm)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes = None, device: int = 0, shm_name: str = None):
         self.h = _vp()
-        _check(lib().kc_comm_create(int(rank), int(world), buf, int(device), C.byref(self.h)))
+        if shm_name is not None:
+            _check(lib().kc_comm_create_shm(int(rank), int(world), shm_name.encode(), int(device), C.byref(self.h)))
+        else:
+            assert len(unique_id) == COMM_ID_BYTES
+            buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+            _check(lib().kc_comm_create(int(rank), int(world), buf, int(device), C.byref(self.h)))
         self.rank, self.world = int(rank), int(world)
+
+    @property
+    def transport(self) -> str:
+        return "shm" if lib().kc_comm_transport(self.h) == COMM_SHM else "rccl"
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -334,6 +371,15 @@ class DwaContext:
     def set_shard(self, first, count):
         _check(lib().kc_dwa_set_shard(self.h, int(first), int(count)))
 
+    def set_shard_rule(self, rank, world, mode=SHARD_BLOCKS):
+        """This context keeps rank `rank`'s share of every list it is given (mode < 0: all of it)."""
+        _check(lib().kc_dwa_set_shard_rule(self.h, int(rank), int(world), int(mode)))
+
+    def owns_sample(self, raw_index) -> bool:
+        v = C.c_int(0)
+        _check(lib().kc_dwa_owns_sample(self.h, int(raw_index), C.byref(v)))
+        return bool(v.value)
+
     def set_scan(self, state, ranges, angles, max_sensor_range=10.0):
         r, a = _f64(ranges), _f64(angles)
         st = State(*state)
@@ -415,18 +461,26 @@ class DwaContext:
         _check(lib().kc_dwa_get_best(self.h, _pf(px), _pf(py), _pf(v[0]), _pf(v[1]), _pf(v[2])))
         return px, py, v
 
-    def get_samples(self, with_costs=False):
+    def get_samples(self, with_costs=False, with_paths=True):
         P = self._P
         n = _sz(0)
         _check(lib().kc_dwa_get_samples(self.h, None, None, None, None, 0, C.byref(n)))
         k = n.value
-        px, py = np.zeros((max(k, 1), P), np.float32), np.zeros((max(k, 1), P), np.float32)
+        if with_paths:
+            px, py = np.zeros((max(k, 1), P), np.float32), np.zeros((max(k, 1), P), np.float32)
+        else:
+            px = py = None
         raw = np.zeros(max(k, 1), np.int32)
         costs = np.zeros(max(k, 1), np.float32) if with_costs else None
         _check(lib().kc_dwa_get_samples(self.h, _pf(px), _pf(py), raw.ctypes.data_as(_ip), _pf(costs), k,
                                         C.byref(n)))
-        out = (px[:k], py[:k], raw[:k])
+        out = (px[:k], py[:k], raw[:k]) if with_paths else (None, None, raw[:k])
         return out + (costs[:k],) if with_costs else out
+
+    def get_sample_velocity(self, raw_index):
+        vx, vy, om = C.c_double(0), C.c_double(0), C.c_double(0)
+        _check(lib().kc_dwa_get_sample_velocity(self.h, int(raw_index), C.byref(vx), C.byref(vy), C.byref(om)))
+        return vx.value, vy.value, om.value
 
     def cost_evaluate(self, paths_x, paths_y, vel=None):
         px, py = _f32(paths_x), _f32(paths_y)

@@ -9,6 +9,14 @@ LowestCost::combine (datatypes/trajectory.h:630-636) because the global sample
 index order is the reference's generation order.  The reference-numbered
 (admissible-only) index is rebuilt on demand with one all-reduce(sum).
 
+Round 3: the product path (kc_dwa_cycle_sharded) makes ONE all-reduce(int64 x (2 +
+world x words), min) of an exchange record -- [best key, error word, every rank's
+admissible bitmap] -- so that the reference-numbered index and the global
+admissible count need no second collective; shares are dealt by rule
+(kc_dwa_set_shard_rule: contiguous blocks, or by trig row).  `exchange_record`
+below builds that record from a shard's result the way xchg_pack_kernel does;
+the merge is the library's own host function (kompass_hip.shard_merge).
+
 Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) on GPUs,
 "gloo" on CPU for the tests.
 """
@@ -24,6 +32,29 @@ def shard_range(n_total: int, rank: int, world: int):
     first = n_total * rank // world
     last = n_total * (rank + 1) // world
     return first, last - first
+
+
+INT64_MAX = (1 << 63) - 1
+
+
+def words_per_rank(counts) -> int:
+    """64-bit bitmap words every rank's region of the exchange record holds."""
+    return max((max(counts) + 63) // 64, 1) if len(counts) else 1
+
+
+def exchange_record(rank: int, world: int, rw: int, key: int, admissible_local_ids, error: int = 0):
+    """This rank's contribution to the exchange record (csrc/kc_shard.h): word 0 the packed key with
+    the GLOBAL raw index, word 1 0 / -1 (error), then world regions of rw bitmap words -- this rank's
+    admissible samples by shard-local id in its own region, INT64_MAX everywhere else."""
+    x = np.full(2 + world * rw, INT64_MAX, np.int64)
+    x[0] = key if not error else KEY_NONE
+    x[1] = -1 if error else 0
+    bits = np.zeros(rw * 64, np.uint8)
+    ids = np.asarray(admissible_local_ids, np.int64)
+    if not error and len(ids):
+        bits[ids] = 1
+    x[2 + rank * rw: 2 + (rank + 1) * rw] = np.packbits(bits, bitorder="little").view(np.int64)
+    return x
 
 
 def float_sortable(cost) -> int:

@@ -56,9 +56,45 @@ def test_two_rank_gloo_matches_unsharded(tmp_path):
            str(ROOT / "tests" / "_gloo_worker.py"), str(out)]
     subprocess.run(cmd, check=True, env=env, timeout=280, capture_output=True)
     got = json.loads(out.read_text())
-    for g, (name, scale, seed) in zip(got, [("cfg1", 1.0, 1), ("cfg2", 0.25, 2), ("cfg5", 0.08, 3)]):
+    cases = [("cfg1", 1.0, 1), ("cfg2", 0.25, 2), ("cfg5", 0.08, 3)]
+    assert len(got) == 4 * len(cases)
+    for i, (name, scale, seed) in enumerate(cases):
         o = oracle_cycle(syn.make_controller_inputs(name, seed=seed, scale=scale))
-        assert g["found"] == (o["index"] >= 0)
-        assert g["index"] == o["index"], name
-        assert g["raw"] == int(o["raw"][o["index"]])
-        assert np.float32(g["cost"]) == np.float32(o["cost"])
+        # [0] round-1 protocol (key all-reduce + count all-reduce); [1], [2] the product's single
+        # all-reduce of the exchange record with block / trig-row shares, merged by kc_shard_merge
+        for g in got[4 * i: 4 * i + 3]:
+            assert g["found"] == (o["index"] >= 0)
+            assert g["index"] == o["index"], (name, g)
+            assert g["raw"] == int(o["raw"][o["index"]])
+            assert np.float32(g["cost"]) == np.float32(o["cost"])
+            if "n_admissible" in g:
+                assert g["n_admissible"] == len(o["raw"])
+        assert got[4 * i + 3]["failed"] is True  # one rank's error word fails the cycle on every rank
+
+
+def test_shard_plan_rules():
+    """kc_shard_plan (pure host): blocks are shard_range; rows deal whole trig rows round-robin, a heavy
+    row (omni: omega = 0) sample by sample; every sample has exactly one owner."""
+    import kompass_hip as kh
+
+    for name, scale in [("cfg2", 0.25), ("cfg3", 0.05), ("cfg5", 0.08)]:
+        inp = syn.make_controller_inputs(name, seed=0, scale=scale)
+        n = len(inp["vx"])
+        _, rows = np.unique(np.asarray(inp["omega"], np.float64) + 0.0, return_inverse=True)
+        for w in (1, 2, 3, 8):
+            ob = kh.shard_plan(rows, w, kh.SHARD_BLOCKS)
+            for r in range(w):
+                f, c = sharding.shard_range(n, r, w)
+                assert (ob[f:f + c] == r).all()
+            orow = kh.shard_plan(rows, w, kh.SHARD_ROWS)
+            assert orow.min() >= 0 and orow.max() < w
+            counts = np.bincount(orow, minlength=w)
+            per_row = np.bincount(rows)
+            heavy = per_row > 2 * -(-n // len(per_row))
+            # light rows are never split; shares are balanced to within one light row
+            for a in np.nonzero(~heavy)[0]:
+                assert len(set(orow[rows == a])) == 1
+            assert counts.max() - counts.min() <= per_row[~heavy].max() + 1
+            # trig rows a rank needs: about 1 / w of them (+ the heavy ones)
+            need = [len(set(rows[orow == r])) for r in range(w)]
+            assert max(need) <= -(-int((~heavy).sum()) // w) + int(heavy.sum())

@@ -1,0 +1,122 @@
+"""kc_dwa_cycle_sharded with MORE THAN ONE RANK on a one-GPU box: W processes, each with its own
+context on device 0, exchange through the library's shared-memory transport (kc_comm_create_shm;
+RCCL refuses two ranks on one device).  Every rank must return the unsharded oracle's result -- found,
+cost bits, raw index, the reference-numbered index and the global admissible count out of the ONE
+exchange -- and an error on one rank must fail THAT cycle on every rank and leave the next cycle paired
+up (the late-host retry used to put a rank one collective out of step)."""
+import json
+import os
+import subprocess
+import sys
+import uuid
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kompass_hip as kh  # noqa: E402
+import synthetic as syn  # noqa: E402
+
+from helpers import oracle_cycle  # noqa: E402
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+from _shm_worker import poses  # noqa: E402
+
+
+def _run(tmp_path, world, scenario, cfg, scale, seed, mode, late_rank=None):
+    name = uuid.uuid4().hex[:16]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, KC_SHM_TIMEOUT_MS="60000", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+        env["KC_HOST_THREADS"] = "2"
+        if late_rank == r:
+            env["KC_TEST_LATE_FLAG_MS"] = "120"
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "_shm_worker.py"), str(r), str(world), name,
+                                       str(tmp_path), scenario, cfg, str(scale), str(seed), str(mode)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    import time
+
+    t_end = time.time() + 240
+    while time.time() < t_end and any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            break   # a rank died: the others would only wait for it
+        time.sleep(0.2)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    errs = [p.communicate()[1] for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} rc {p.returncode}: {errs[r][-1500:]}"
+    return [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(world)]
+
+
+def _oracles(cfg, scale, seed):
+    inp = syn.make_controller_inputs(cfg, seed=seed, scale=scale)
+    res = []
+    for k in range(6):
+        i2 = dict(inp, state=poses(inp, k))
+        if k >= 3:
+            i2 = dict(i2, vx=inp["vx"] * 0.97, vy=inp["vy"] * 0.97)
+        res.append(oracle_cycle(i2))
+    return res
+
+
+def _check_cycle(rec, o, n_total):
+    assert rec["ok"], rec
+    assert rec["found"] == (o["index"] >= 0)
+    assert rec["n_admissible"] == len(o["raw"]) and rec["n_samples"] == n_total
+    if rec["found"]:
+        assert rec["raw"] == int(o["raw"][o["index"]]) and rec["index"] == o["index"]
+        assert np.float32(rec["cost"]) == np.float32(o["cost"])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,cfg,scale,seed,mode", [
+    (2, "cfg2", 0.25, 11, kh.SHARD_BLOCKS), (2, "cfg2", 0.25, 12, kh.SHARD_ROWS),
+    (4, "cfg5", 0.08, 13, kh.SHARD_ROWS), (3, "cfg1", 1.0, 14, kh.SHARD_BLOCKS)])
+def test_ranks_agree_with_the_unsharded_oracle(tmp_path, world, cfg, scale, seed, mode):
+    got = _run(tmp_path, world, "plain", cfg, scale, seed, mode)
+    ora = _oracles(cfg, scale, seed)
+    n_total = len(syn.make_controller_inputs(cfg, seed=seed, scale=scale)["vx"])
+    for k, o in enumerate(ora):
+        owners = 0
+        for r in range(world):
+            _check_cycle(got[r][k], o, n_total)
+            if got[r][k].get("owns"):
+                owners += 1
+                np.testing.assert_array_equal(np.float32(got[r][k]["best_x"]), o["px"][o["index"]])
+        assert owners == (1 if o["index"] >= 0 else 0)   # exactly one rank holds the winner's row
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", [kh.SHARD_BLOCKS, kh.SHARD_ROWS])
+def test_a_late_host_on_one_rank_fails_that_cycle_on_every_rank(tmp_path, mode):
+    world, cfg, scale, seed = 2, "cfg2", 0.25, 21
+    got = _run(tmp_path, world, "late", cfg, scale, seed, mode, late_rank=1)
+    ora = _oracles(cfg, scale, seed)
+    n_total = len(syn.make_controller_inputs(cfg, seed=seed, scale=scale)["vx"])
+    if all(g[0]["ok"] for g in got):
+        pytest.skip("early launch not active on this device (no large BAR): nothing can be late")
+    for r in range(world):
+        assert not got[r][0]["ok"] and "gave up waiting" in got[r][0]["error"], got[r][0]
+        for k in range(1, 6):   # ... and every later cycle pairs up again, on every rank
+            _check_cycle(got[r][k], ora[k], n_total)
+
+
+@pytest.mark.timeout(600)
+def test_a_failure_before_the_exchange_is_collective(tmp_path):
+    world, cfg, scale, seed = 3, "cfg2", 0.25, 31
+    got = _run(tmp_path, world, "prefail", cfg, scale, seed, kh.SHARD_ROWS)
+    ora = _oracles(cfg, scale, seed)
+    n_total = len(syn.make_controller_inputs(cfg, seed=seed, scale=scale)["vx"])
+    for r in range(world):
+        assert not got[r][1]["ok"]
+        if r == world - 1:
+            assert "num_points" in got[r][1]["error"]        # its own, specific error
+        else:
+            assert "failed before the exchange" in got[r][1]["error"]
+        for k in (0, 2, 3, 4, 5):
+            _check_cycle(got[r][k], ora[k], n_total)
