@@ -69,6 +69,40 @@ def pmc_traffic(kernel, scene="survey", cfg="cfg2"):
     return rec.get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1])
 
 
+GPU_SIMDS, GPU_CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz
+
+
+def pmc_explain(kernel, scene, cfg, launch_ms):
+    """What binds the kernel when HBM does not ('VALU utilisation + launch count as the explanatory
+    figures'), from the newest committed SQ counter passes of this workload (profiles/*_<cfg>_<scene>_pmc_sq.json:
+    separate rocprofv3 --pmc passes, means per launch summed over the chip) and the phase clocks of the kernel
+    (profiles/*_<cfg>_<scene>_phase_stamps.json: s_memrealtime stamps of a -DKC_PHASE_STAMPS build)."""
+    import glob
+    import json as _json
+
+    out = {}
+    files = sorted(glob.glob(str(ROOT / "profiles" / f"*_{cfg}_{scene}_pmc_sq.json")))
+    rec = _json.load(open(files[-1])).get("kernels", {}).get(kernel) if files else None
+    if rec and rec.get("SQ_ACTIVE_INST_VALU") and launch_ms:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues VALU work: x 4 = SIMD cycles, over the
+        # SIMD cycles the launch lasted on the whole chip
+        out["valu_issue_frac"] = rec["SQ_ACTIVE_INST_VALU"] * 4.0 / (GPU_SIMDS * GPU_CLOCK_HZ * launch_ms * 1e-3)
+        if rec.get("SQ_INSTS_SALU") and rec.get("SQ_INSTS_VALU"):
+            out["salu_per_valu"] = rec["SQ_INSTS_SALU"] / rec["SQ_INSTS_VALU"]
+        if rec.get("SQ_LDS_BANK_CONFLICT") is not None and rec.get("SQ_ACTIVE_INST_LDS"):
+            out["lds_conflict_frac"] = rec["SQ_LDS_BANK_CONFLICT"] / (4.0 * rec["SQ_ACTIVE_INST_LDS"])
+        if rec.get("SQ_INSTS_VALU") and rec.get("SQ_WAVES"):
+            out["valu_insts_per_wave"] = rec["SQ_INSTS_VALU"] / rec["SQ_WAVES"]
+        out["counters_source"] = os.path.basename(files[-1])
+    files = sorted(glob.glob(str(ROOT / "profiles" / f"*_{cfg}_{scene}_phase_stamps.json")))
+    if files:
+        st = _json.load(open(files[-1]))
+        if st.get("kernel") == kernel:
+            out["critical_path_us"] = st.get("phases_us")
+            out["critical_path_source"] = os.path.basename(files[-1])
+    return out
+
+
 def algorithmic_bytes(N, P, map_side, S, O):
     """16 B per trajectory-step (8 B x,y written by the
     roll-out + 8 B read back by the cost pass) + 20 B per sample (12 B velocity
@@ -159,8 +193,10 @@ def controller_bench(args, rank, world, local_rank):
     first, count = sharding.shard_range(n_total, rank, world)
     P, S, O = inp["P"], len(inp["seg_xyz"]), len(inp["points"])
 
+    cl, ca = CLASS_SAMPLES[cfg]
+    cap = n_total if use_dist else min(65536, max(n_total, (cl + 2) * (ca + 2)))  # (the fresh_inputs leg draws a class-level window)
     ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1),
-                        inp["octree_res"], inp["dt"], max_samples=n_total, max_points=P,
+                        inp["octree_res"], inp["dt"], max_samples=cap, max_points=P,
                         max_segment=S, max_obstacles=O, acc_limits=inp["acc_limits"], device=device)
     if args.split:
         ctx.set_option("fused_cycle", 0)
@@ -192,6 +228,12 @@ def controller_bench(args, rank, world, local_rank):
         if use_dist:
             ranks.barrier()
 
+    if args.fresh and not use_dist:
+        leg = fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args)
+        leg.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f64 roll-out / f32 costs", "data": "synthetic"})
+        ctx.close()
+        return leg
     for i in range(args.warmup):
         one_cycle(i)
     # ---- timed region: EXACTLY args.steps cycles, barrier + sync on both sides
@@ -229,7 +271,8 @@ def controller_bench(args, rank, world, local_rank):
         ms_per_step = 1e3 * elapsed / args.steps
         steps_total = n_total * P  # trajectory-steps per cycle over all ranks
         value = steps_total * args.steps / elapsed
-        n_adm = int(ctx.cycle(pose(0), P).n_admissible) if not use_dist else None
+        # (the same pose as the cpu_baseline's winner and count: the last timed cycle)
+        n_adm = int(ctx.cycle(pose(args.steps - 1), P).n_admissible) if not use_dist else None
         n_adm_global = int(last.n_admissible) if use_dist else n_adm
         robot = 'omni' if base['ctr'] == 2 else 'diff-drive' if base['ctr'] == 1 else 'Ackermann'
         out = {
@@ -282,6 +325,12 @@ def controller_bench(args, rank, world, local_rank):
                 out[key] = scene_leg(ctx, cfg, scene, inp, vx, vy, om, P, S, pose, args)
             ctx.set_points(inp["state"], inp["points"], inp["max_range"])
             out["extras"] = extras(ctx, inp, P, pose)
+            # one REFERENCE cycle per step: fresh sensor data, window + lattice, tracked segment, cycle
+            out["fresh_inputs"] = fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args)
+            # BASELINE configs[3] in the same record: 4096-beam scan -> 1000 x 1000 grid
+            margs = argparse.Namespace(**vars(args))
+            margs.steps, margs.warmup = min(args.steps, 500), min(args.warmup, 50)
+            out["mapper_cfg4"] = mapper_bench(margs)
     if use_dist and not args.only_headline:
         strong = {}
         for scfg in ("cfg3", "cfg5"):
@@ -351,14 +400,18 @@ def roofline_of(kernel_ms, count, P, map_side, S, O, scene="survey", cfg="cfg2")
     bytes_launch = algorithmic_bytes(count, P, map_side, S, O)
     achieved = bytes_launch / (dom_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(dom, scene, cfg)
-    return {
+    out = {
         "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": dom_ms,
         "note": "latency / VALU-issue bound path: the whole cycle moves ~7 MB (SURVEY 8d); the single-launch "
                 "cycle keeps the poses in LDS and writes no float rows, so its HBM traffic is far below the "
-                "algorithmic bytes it is priced with (explanatory counters: profiles/*_pmc_sq.json)",
+                "algorithmic bytes it is priced with; valu_issue_frac (share of the chip's SIMD cycles that issue "
+                "VALU work during the launch), salu_per_valu, lds_conflict_frac and critical_path_us (phase clocks "
+                "of the slowest workgroup chain) say what binds it instead",
     }
+    out.update(pmc_explain(dom, scene, cfg, dom_ms))
+    return out
 
 
 def scene_leg(ctx, cfg, scene, inp, vx, vy, om, P, S, pose, args):
@@ -401,6 +454,134 @@ def scene_leg(ctx, cfg, scene, inp, vx, vy, om, P, S, pose, args):
         leg["cpu_baseline"] = cpu_baseline(dict(inp, points=pts), vx, vy, om, pose(args.steps - 1), bool(r.found),
                                            float(r.cost), int(r.raw_index), args, max(2.0, args.cpu_seconds / 3))
     return leg
+
+
+# class-level sample counts of SURVEY.md section 8 (max_linear_samples, max_angular_samples) per config
+CLASS_SAMPLES = {"cfg1": (11, 11), "cfg2": (91, 91), "cfg3": (181, 181), "cfg5": (300, 215)}
+
+
+def fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args):
+    """One REFERENCE controller cycle per step (DWA::findBestPath, include/controllers/dwa.h:183-230):
+    new sensor data (octree rebuild + setPointScan -> kc_dwa_set_points), a new dynamic window and
+    lattice (UpdateReachableVelocityRange + the lattice loops -> kc_dwa_sample_window), a new tracked
+    segment (findTrackedPathSegment -> kc_dwa_set_tracked_segment), then roll-out + collision gate +
+    costs + argmin (kc_dwa_cycle).  Nothing is resident between steps except buffers."""
+    base = syn.CONFIGS[cfg]
+    lim = kh.make_limits(syn.LIMITS["vx"], syn.LIMITS["vy"], syn.LIMITS["omega"])
+    max_lin, max_ang = CLASS_SAMPLES[cfg]
+    P, S, O = inp["P"], len(inp["seg_xyz"]), len(inp["points"])
+    cur = lambda i: (0.5 + 0.002 * ((i % 5) - 2), 0.0, 0.01 * ((i % 3) - 1))   # the window moves every cycle
+
+    def step(i):
+        st = pose(i)
+        ctx.sample_window(base["ctr"], lim, cur(i), max_lin, max_ang, want_list=False)
+        ctx.set_points(st, inp["points"], inp["max_range"])
+        ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+        return ctx.cycle(st, P)
+
+    n = int(ctx.sample_window(base["ctr"], lim, cur(0), max_lin, max_ang, want_list=False))
+    steps, warm = min(args.steps, 1000), min(args.warmup, 100)
+    for i in range(warm):
+        step(i)
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ts = time.perf_counter()
+        r = step(i)
+        lat.append(time.perf_counter() - ts)
+    elapsed = time.perf_counter() - t0
+    ctx.timing_enable(True)
+    kernel_ms = {}
+    for i in range(min(steps, 300)):
+        st = pose(i)
+        ctx.sample_window(base["ctr"], lim, cur(i), max_lin, max_ang, want_list=False)
+        ctx.set_points(st, inp["points"], inp["max_range"])
+        for name, ms in ctx.timings():
+            if not name.startswith("host:"):
+                kernel_ms.setdefault(name, []).append(ms)
+        ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+        ctx.cycle(st, P)
+        for name, ms in ctx.timings():
+            if not name.startswith("host:"):
+                kernel_ms.setdefault(name, []).append(ms)
+    ctx.timing_enable(False)
+    last_i = steps - 1
+    r = step(last_i)
+    leg = {
+        "metric": "trajectory-steps/s", "value": n * P * steps / elapsed, "unit": "trajectory-steps/s",
+        "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warm,
+        "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
+        "config": {"workload": f"{cfg}, one reference controller cycle per step: kc_dwa_sample_window (max_linear_samples "
+                               f"{max_lin}, max_angular_samples {max_ang}: {n} samples) + kc_dwa_set_points ({O} points: "
+                               f"voxel set + obstacle list) + kc_dwa_set_tracked_segment ({S} points) + kc_dwa_cycle "
+                               f"({n} x {P} steps), scene '{inp['scene']}', {int(r.n_admissible)} of {n} admissible at the last pose",
+                   "samples": n, "points": P, "n_admissible": int(r.n_admissible), "reference": "controllers/dwa.h:183-230"},
+        "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
+        "launches_per_step": len(kernel_ms),
+        "roofline": roofline_of({k: v for k, v in kernel_ms.items()}, n, P, base["map_side"], S, O, inp["scene"], cfg),
+        "winner": {"found": bool(r.found), "cost": float(r.cost), "raw_index": int(r.raw_index), "index": int(r.index)},
+    }
+    if not args.no_cpu:
+        leg["cpu_baseline"] = cpu_baseline_fresh(syn, inp, base["ctr"], cur(last_i), max_lin, max_ang, pose(last_i), r, args,
+                                                 max(3.0, args.cpu_seconds / 2))
+    return leg
+
+
+def cpu_baseline_fresh(syn, inp, ctr, cur_vel, max_lin, max_ang, state, r, args, seconds):
+    """The oracle's whole reference cycle on this host's cores: window + lattice, voxel-set build
+    (CollisionChecker::updateSensorData restated), setPointScan, roll-out + collision + costs + argmin."""
+    from oracle import ko
+
+    rb = inp["robot"]
+    lim = ko.make_limits(syn.LIMITS["vx"], syn.LIMITS["vy"], syn.LIMITS["omega"])
+    P = inp["P"]
+    ncores = usable_cpus()
+
+    def inputs():
+        vx, vy, om = ko.sample_velocities(ctr, lim, cur_vel, inp["dt"], max_lin, max_ang)
+        coll = ko.Collision(rb["shape"], rb["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"])
+        coll.update_state(*state[:3])
+        coll.update_points(inp["points"], True)
+        ox, oy = ko.obstacles_from_points((0, 0, 0), (0, 0, 0, 1), state, inp["points"])
+        ci = ko.CostInputs(inp["seg_xyz"], 0, inp["acc_at_seg"], inp["ref_len"], np.stack([ox, oy], 1),
+                           np.float32(inp["max_range"]) / np.float32(3.0), inp["acc_limits"],
+                           ko.make_weights(*inp["weights"]))
+        return vx, vy, om, coll, ci
+
+    t0 = time.perf_counter()
+    vx, vy, om, coll, ci = inputs()
+    t_in = time.perf_counter() - t0
+    n = len(vx)
+    t0 = time.perf_counter()
+    oi, oc, na = ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx, vy, om, threads=ncores)
+    t_mt = time.perf_counter() - t0
+    parity = bool((oi >= 0) == bool(r.found) and (not r.found or (oi == int(r.raw_index) and
+                                                                  np.float32(oc) == np.float32(r.cost))))
+    stride = max(1, int(np.ceil(t_mt * ncores / max(seconds, 0.5))))
+    t0 = time.perf_counter()
+    cycles = 0
+    t_inputs = []
+    while cycles < (3 if stride == 1 else 1) or (time.perf_counter() - t0 < seconds and cycles < 1000):
+        ti = time.perf_counter()
+        vx, vy, om, coll, ci = inputs()
+        t_inputs.append(time.perf_counter() - ti)
+        ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx[::stride], vy[::stride], om[::stride], threads=1)
+        cycles += 1
+    t_all = (time.perf_counter() - t0) / cycles
+    t_inp = float(np.mean(t_inputs))
+    # a full cycle = the per-cycle inputs once + every sample: the strided samples scaled back up
+    t_cycle = t_inp + (t_all - t_inp) * stride
+    return {
+        "value": n * P / t_cycle, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
+        "sample": f"{cycles} cycles on 1 thread: window + lattice + voxel set + obstacle list every cycle ({t_inp * 1e3:.2f} ms), "
+                  f"every {stride}th of the {n} samples rolled out and scored ({(t_all - t_inp) * 1e3:.1f} ms), scaled to all "
+                  f"samples: {t_cycle * 1e3:.1f} ms per reference cycle",
+        "inputs_ms": t_inp * 1e3, "first_inputs_ms": t_in * 1e3,
+        "all_cores": {"value": n * P / (t_in + t_mt), "cores": ncores, "seconds": t_in + t_mt,
+                      "sample": "inputs on one core + 1 full cycle on all"},
+        "gpu_matches_cpu_winner": parity,
+        "cpu_winner": {"raw_index": int(oi), "cost": float(oc), "n_admissible": int(na)},
+    }
 
 
 def extras(ctx, inp, P, pose):
@@ -595,9 +776,14 @@ def mapper_bench(args):
         "config": {"workload": "cfg4: LocalMapper 4096 beams -> 1000x1000@0.05 grid, grid resident on device"},
         "pcie_inclusive_scans_per_s": args.steps / el_host,
         "kernels_ms": {k: float(np.mean(v)) for k, v in kms.items()},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": bytes_scan / (dom_ms * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": bytes_scan / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "roofline": dict({"bound": "hbm", "kernel": dom, "achieved": bytes_scan / (dom_ms * 1e-3) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": bytes_scan / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "traffic": pmc_traffic(dom, "mapper", "cfg4")[0], "traffic_source": pmc_traffic(dom, "mapper", "cfg4")[1],
+                          "algorithmic_bytes_per_launch": bytes_scan, "avg_launch_ms": dom_ms,
+                          "note": "bytes of one scan (SURVEY 8d: clear 4 HW + beams 12 B + 12 B per traversed cell) over the "
+                                  "slowest of its kernels; store-issue bound (three ordered passes of scattered 4-byte stores)"},
+                         **pmc_explain(dom, "mapper", "cfg4", dom_ms)),
         "cpu_baseline": {"value": 1.0 / t_cpu, "unit": "scans/s", "cores": 1, "kind": "port",
                          "sample": "1 scan", "grid_matches": bool(np.array_equal(g, want))},
     }
@@ -989,6 +1175,8 @@ def main():
     ap.add_argument("--scene", default="survey", choices=["survey", "mid", "open"],
                     help="costmap of the headline line (SURVEY 8d's by default); the other two follow in the same JSON")
     ap.add_argument("--split", action="store_true", help="three-kernel cycle instead of the single launch")
+    ap.add_argument("--fresh", action="store_true",
+                    help="only the fresh_inputs leg (one reference cycle per step), as the top-level line (profiling passes)")
     ap.add_argument("--only-headline", action="store_true",
                     help="no mid_density / open_space / extras legs (profiling passes: one scene per process)")
     ap.add_argument("--mapper", action="store_true", help="bench the LocalMapper (cfg4) instead")

@@ -166,6 +166,13 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "cost_dc_cells"  (0) n = 8..512: cell-centre distance table of n cells along the
  *                        longer side for the far-obstacle searches (pays when several
  *                        cycles share one sensor update); 0: off
+ *   "drop_samples"   (1) TrajectorySampler::setSampleDroppingMode (trajectory_sampler.cpp:103-105).  0: a
+ *                        sample that collides at loop step i with last_free_index = i - 1 beyond
+ *                        "num_ctrl_points" is KEPT (:157-168): path points i + 1 .. P - 1 repeat point
+ *                        i - 1, velocities i .. P - 2 are zero, and smoothness / jerk see that step
+ *   "num_ctrl_points" (0) numCtrlPoints_ = control_horizon / time_step as size_t (:88: the config-object
+ *                        constructor's definition; the explicit-argument constructor leaves it
+ *                        uninitialised)
  *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
  *   "early_launch"   (1) the roll-out kernel is queued before the host trig table exists
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host
@@ -281,7 +288,7 @@ int kc_dwa_set_path(kc_dwa *ctx, const float *x, const float *y, const float *z,
 int kc_dwa_set_tracked_window(kc_dwa *ctx, size_t start, size_t size);
 
 /* A2-A4: TrajectorySampler::generateTrajectories (trajectory_sampler.cpp:
- * 295-314 -> :118-179) for the context's samples, drop_samples = true.
+ * 295-314 -> :118-179) for the context's samples; option "drop_samples" selects the mode.
  * num_points = numPointsPerTrajectory of this cycle (<= max_points). */
 int kc_dwa_rollout(kc_dwa *ctx, const kc_state *start, size_t num_points);
 /* CollisionChecker::checkCollisions (collision_check.cpp:149-162, 225-246) /
@@ -315,6 +322,11 @@ int kc_dwa_get_sample_velocity(kc_dwa *ctx, int64_t raw_index, double *vx,
 int kc_dwa_get_samples(kc_dwa *ctx, float *paths_x, float *paths_y,
                        int32_t *raw_index, float *costs, size_t cap_rows,
                        size_t *n_rows_out);
+
+/* drop_samples = 0 only: per row of kc_dwa_get_samples the first zero-velocity step of a frozen
+ * sample (its velocity profile is the sample's velocity before that step and zero from it on), 0 for
+ * a sample that never collided.  All zero with drop_samples = 1. */
+int kc_dwa_get_freeze_steps(kc_dwa *ctx, int32_t *steps_out, size_t cap_rows, size_t *n_rows_out);
 
 /* CostEvaluator::getMinTrajectoryCost on caller-provided trajectories
  * (sample-major host matrices exactly as TrajectorySamples2D stores them;

@@ -190,12 +190,13 @@ void TrajectorySampler::init(const CollisionChecker::ShapeType shape,
 
 void TrajectorySampler::updateState(const Path::State &s) { collChecker->updateState(s); }
 void TrajectorySampler::setSampleDroppingMode(const bool drop) {
-  if (!drop)
-    throw std::invalid_argument(
-        "drop_samples = false (keep the collision-free prefix of a sample) is "
-        "outside this build's parity domain (reference quirk Q3: the prefix "
-        "length depends on an uninitialised member)");
+  // trajectory_sampler.cpp:103-105 / :157-168.  numCtrlPoints_ is control_horizon / time_step as size_t (:88,
+  // the config-object constructor; the explicit-argument constructor of the reference leaves the member
+  // uninitialised -- reference quirk Q3 -- and gets the same definition here)
   drop_samples_ = drop;
+  hip::check(kc_dwa_set_option(ctx_.get(), "num_ctrl_points",
+                               static_cast<double>(static_cast<size_t>(control_time_ / time_step_))));
+  hip::check(kc_dwa_set_option(ctx_.get(), "drop_samples", drop ? 1.0 : 0.0));
 }
 void TrajectorySampler::resetOctreeResolution(const double r) {
   collChecker->resetOctreeResolution(r);
@@ -276,12 +277,17 @@ std::unique_ptr<TrajectorySamples2D> TrajectorySampler::collect() {
   hip::check(kc_dwa_get_samples(ctx_.get(), out->paths.x.data(), out->paths.y.data(), raw.data(),
                                 nullptr, rows, &rows));
   out->paths.z.fill(0.0f);
+  // drop_samples = false: a frozen sample's profile is zero from its freeze step on (trajectory_sampler.cpp:160-163)
+  std::vector<int32_t> frozen(rows ? rows : 1, 0);
+  if (!drop_samples_) hip::check(kc_dwa_get_freeze_steps(ctx_.get(), frozen.data(), rows, &rows));
   for (size_t r = 0; r < rows; ++r) {
     const size_t g = static_cast<size_t>(raw[r]);
+    const size_t stop = frozen[r] > 0 ? static_cast<size_t>(frozen[r]) : P;
     for (size_t i = 0; i + 1 < P; ++i) {  // TrajectoryVelocities2D::add: float = double
-      out->velocities.vx((Eigen::Index)r, (Eigen::Index)i) = last_vx_[g];
-      out->velocities.vy((Eigen::Index)r, (Eigen::Index)i) = last_vy_[g];
-      out->velocities.omega((Eigen::Index)r, (Eigen::Index)i) = last_omega_[g];
+      const bool z = i >= stop;
+      out->velocities.vx((Eigen::Index)r, (Eigen::Index)i) = z ? 0.0f : static_cast<float>(last_vx_[g]);
+      out->velocities.vy((Eigen::Index)r, (Eigen::Index)i) = z ? 0.0f : static_cast<float>(last_vy_[g]);
+      out->velocities.omega((Eigen::Index)r, (Eigen::Index)i) = z ? 0.0f : static_cast<float>(last_omega_[g]);
     }
   }
   out->paths.pathIndex_ = static_cast<Eigen::Index>(rows) - 1;

@@ -73,7 +73,44 @@ struct RollArgs {
   // half-widths of the two discs per row offset, win[0..R] | wout[0..R], and R
   const signed char *diltab;
   int dilR;
+  // drop_samples_ == false (trajectory_sampler.cpp:157-168): a sample whose first collision comes at loop
+  // step i with last_free_index = i - 1 > num_ctrl stays admissible -- path points i + 1 .. P - 1 repeat point
+  // i - 1, velocities i .. P - 2 are zero.  Needs the FIRST colliding pose of a sample, not just any.
+  int freeze;                     // 1: that mode
+  int num_ctrl;                   // numCtrlPoints_ (:88)
+  int *freeze_step;               // [n] by shard-local id: 0, or the first zero-velocity step i of a frozen sample
+  float *frz_smooth, *frz_jerk;   // [n] the smoothness / jerk sums of the frozen profile (0 when not frozen)
+  const double *omega_values;     // [A] omega of every trig row (the frozen profile's velocity step)
+  float acc0, acc1, acc2;         // cost_evaluator.cpp:18-20
+  int *first_hit;                 // split path only: [n] first colliding pose index (INT_MAX: none)
 };
+
+// smoothness / jerk sums of a profile that is (fvx, fvy, fom) up to step f - 1 and zero from step f
+// (cost_evaluator.cpp:187-233: float += pow(delta, 2) / accLimit per axis, in index order; every other term of
+// the two loops is +0.0).  smoothness: delta = 0 - v at index f; jerk: v[f] - 2 v[f-1] + v[f-2] = -v at index
+// f and v[f+1] - 2 v[f] + v[f-1] = +v at index f + 1 (when f + 1 <= nv - 1).
+__host__ __device__ inline void frozen_velocity_sums(float fvx, float fvy, float fom, int f, int nv, float acc0,
+                                                     float acc1, float acc2, float *smooth, float *jerk) {
+  auto sq = [](float v, float lim) { return (static_cast<double>(v) * static_cast<double>(v)) / static_cast<double>(lim); };
+  const double tx = acc0 > 0 ? sq(fvx, acc0) : 0.0, ty = acc1 > 0 ? sq(fvy, acc1) : 0.0, to = acc2 > 0 ? sq(fom, acc2) : 0.0;
+  float s = 0.0f;
+  if (f >= 1 && f < nv) {
+    s = static_cast<float>(static_cast<double>(s) + tx);
+    s = static_cast<float>(static_cast<double>(s) + ty);
+    s = static_cast<float>(static_cast<double>(s) + to);
+  }
+  float j = 0.0f;
+  for (int q = 0; q < 2; ++q) {
+    const int idx = f + q;
+    if (idx >= 2 && idx < nv) {
+      j = static_cast<float>(static_cast<double>(j) + tx);
+      j = static_cast<float>(static_cast<double>(j) + ty);
+      j = static_cast<float>(static_cast<double>(j) + to);
+    }
+  }
+  *smooth = s;
+  *jerk = j;
+}
 
 // Phase clocks for kernel tuning: compiled in only with -DKC_PHASE_STAMPS (the
 // product build carries none of it); KC_DEBUG_STAMPS=1 then dumps them when the

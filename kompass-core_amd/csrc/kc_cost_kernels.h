@@ -96,6 +96,8 @@ struct CostArgs {
   BucketDev b;
   const float *vvx, *vvy, *vom;   // [n][P-1] when have_vel
   const float *vsum_smooth, *vsum_jerk;  // [n] ordered sums of velocity_sums_kernel, or null: formed in the cost kernel
+  const float *frz_smooth, *frz_jerk;    // [n] drop_samples = false: the sums of a frozen sample's profile (0 for the
+                                         // others), left by the roll-out; null: every sample has a constant profile
   int defer_vel;                  // 1: velocity_sums_kernel runs beside this kernel (second stream); the totals
                                   // stop in front of smoothness / jerk, velocity_finish_kernel adds them and forms the keys
   float max_obs_dist;
@@ -804,6 +806,14 @@ __global__ __launch_bounds__(256) void velocity_sums_kernel(VelSumArgs a) {
     velocity_sums_group<true, kLanes>(a, a.out[1]);
 }
 
+// drop_samples = false: the profile of a frozen sample steps to zero once, its two sums come from the roll-out
+__device__ __forceinline__ float add_frozen_costs(const CostArgs &a, int n, float total) {
+  const float div = static_cast<float>(3L * (a.P - 1));
+  if (a.w_smooth > 0.0) total = accum(total, a.w_smooth, kc::div_rn(a.frz_smooth[n], div));  // cost_evaluator.cpp:187-206
+  if (a.w_jerk > 0.0) total = accum(total, a.w_jerk, kc::div_rn(a.frz_jerk[n], div));        // :209-233
+  return total;
+}
+
 // Behind a cost kernel that ran with defer_vel (beside velocity_sums_kernel on a second stream): the last two
 // terms of getMinTrajectoryCost (cost_evaluator.cpp:49-109: ... smoothness, jerk) onto the stored totals, and
 // the per-workgroup keys for publish_kernel.
@@ -854,6 +864,7 @@ __device__ __forceinline__ float team_sample_total(const CostArgs &a, int n, int
     total = accum(total, a.w_obs,
                   obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(s_obest))));
   if (a.have_vel) total = add_velocity_costs(a, n, total, lane);
+  else if (a.frz_smooth) total = add_frozen_costs(a, n, total);
   // constant-velocity samples: both terms are exactly 0 and `total += w*0`
   // leaves total unchanged, so nothing to do when !have_vel.
   return total;
@@ -1415,6 +1426,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
                   obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(
                                             *const_cast<volatile unsigned long long *>(obest)))));
   if (a.have_vel && !a.defer_vel) total = add_velocity_costs(a, n, total, lane);
+  else if (!a.have_vel && a.frz_smooth) total = add_frozen_costs(a, n, total);
   // constant-velocity samples: both terms are exactly 0 and `total += w*0`
   // leaves total unchanged, so nothing to do when !have_vel.
   return total;

@@ -269,6 +269,14 @@ struct kc_dwa {
   size_t x_rw = 0;
   long long xseq = 0;
   int64_t last_lat = -1;       // id in `lat` of the last winner when it lives on this context, else -1
+
+  // drop_samples_ == false (trajectory_sampler.cpp:157-168; option "drop_samples" = 0)
+  bool drop_samples = true;
+  size_t num_ctrl_points = 0;  // numCtrlPoints_ = control_horizon / time_step (:88; option "num_ctrl_points")
+  DevBuf<int> d_freeze, d_first_hit;   // [n] first zero-velocity step of a frozen sample (0: not frozen) / split path scratch
+  DevBuf<float> d_frz;                 // [2][n] smoothness | jerk sums of the frozen profiles
+  DevBuf<double> d_omega;              // [A] omega of every trig row
+  bool freeze_valid = false;           // d_freeze describes the last roll-out
 };
 
 namespace {
@@ -673,6 +681,16 @@ int upload_obstacles(kc_dwa *c, size_t n) {
   return KC_OK;
 }
 
+// omega of every trig row on the device (drop_samples = false: the velocity step of a frozen profile)
+int upload_omega(kc_dwa *c) {
+  const size_t A = c->lat.omega_values.size();
+  if (A == 0) return KC_OK;
+  KC_TRY(c->d_omega.reserve(A));
+  KC_HIP(hipMemcpyAsync(c->d_omega.p, c->lat.omega_values.data(), A * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  KC_HIP(hipStreamSynchronize(c->stream));  // pageable source
+  return KC_OK;
+}
+
 int upload_samples(kc_dwa *c) {
   const size_t n = c->lat.size();
   if (n > c->prm.max_samples)
@@ -716,6 +734,7 @@ int upload_samples(kc_dwa *c) {
     KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
   }
   if (!same_rows) c->uploaded_rows = c->lat.row;
+  if (!c->drop_samples) KC_TRY(upload_omega(c));
   return KC_OK;
 }
 
@@ -1460,6 +1479,10 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
   ca.w_jerk = c->w.jerk_weight;
   ca.costs = c->d_costs.p;
   ca.result = c->d_result.p;
+  if (!c->drop_samples && !c->external && c->d_frz.p) {
+    ca.frz_smooth = c->d_frz.p;
+    ca.frz_jerk = c->d_frz.p + c->n_roll;
+  }
   return KC_OK;
 }
 
@@ -2213,6 +2236,15 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_cprow.release();
   c->h_wrow.release();
   c->h_slots.release();
+  c->d_freeze.release();
+  c->d_first_hit.release();
+  c->d_frz.release();
+  c->d_omega.release();
+  c->d_gid.release();
+  c->d_xs.release();
+  c->d_xr.release();
+  c->h_xvec.release();
+  c->h_xrec.release();
   delete c;
 }
 
@@ -2268,6 +2300,13 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     c->near_side = static_cast<int>(v);
     c->near_version = ~0ull;
     c->near_ok = false;
+  } else if (n == "drop_samples") {
+    c->drop_samples = on;
+    c->freeze_valid = false;
+    if (!on) KC_TRY(upload_omega(c));
+  } else if (n == "num_ctrl_points") {
+    if (!(v >= 0.0 && v <= 1e9)) KC_FAIL(KC_ERR_RANGE, "num_ctrl_points: a count >= 0");
+    c->num_ctrl_points = static_cast<size_t>(v);
   } else if (n == "lazy_dilate") c->lazy_dilate = on;
   else if (n == "early_launch") c->early_launch = on;
   else if (n == "sensor_on_host") c->device_sensor = !on;
@@ -2300,6 +2339,8 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "force_split") *v = c->lds_limit == 0;
   else if (n == "last_cycle_single_launch") *v = c->cycle_launched;  // read-only
   else if (n == "host_threads") *v = WorkerPool::instance().workers() + 1;  // read-only here: kc_set_host_threads
+  else if (n == "drop_samples") *v = c->drop_samples;
+  else if (n == "num_ctrl_points") *v = static_cast<double>(c->num_ctrl_points);
   else if (n == "trig_rows") *v = static_cast<double>(c->lat.omega_values.size());  // read-only: rows of the host's cos / sin table
   else if (n == "shard_samples") *v = static_cast<double>(c->shard_count);          // read-only: samples this context rolls out
   else
@@ -2994,6 +3035,22 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   a.flags = c->d_flags.p;
   a.adm_list = c->d_adm.p;
   a.adm_count = c->d_result.p + W_LIST;
+  c->freeze_valid = false;
+  if (!c->drop_samples) {
+    KC_TRY(c->d_freeze.reserve(n));
+    KC_TRY(c->d_frz.reserve(2 * n));
+    if (!c->d_omega.p || c->d_omega.cap < A) KC_TRY(upload_omega(c));
+    a.freeze = 1;
+    a.num_ctrl = static_cast<int>(std::min<size_t>(c->num_ctrl_points, 0x3FFFFFFF));
+    a.freeze_step = c->d_freeze.p;
+    a.frz_smooth = c->d_frz.p;
+    a.frz_jerk = c->d_frz.p + n;
+    a.omega_values = c->d_omega.p;
+    a.acc0 = c->prm.acc_limits[0];
+    a.acc1 = c->prm.acc_limits[1];
+    a.acc2 = c->prm.acc_limits[2];
+    c->freeze_valid = true;
+  }
   const bool may_collide = c->have_sensor && any_voxel(c);
   KC_TRY(window_geometry(c, start->x, start->y, cycle_reach(c), a.c));
   // single-launch cycle: cost arguments up front (their checks must not fail
@@ -3196,6 +3253,10 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       a.pos = c->d_pos.p;
     }
     a.c.enabled = may_collide ? 1 : 0;  // roll-out: "store the double poses"
+    if (a.freeze) {
+      KC_TRY(c->d_first_hit.reserve(n));
+      a.first_hit = c->d_first_hit.p;
+    }
     const size_t tile_bytes = 2 * static_cast<size_t>(kRollBlock) * (P | 1) * 4;
     a.stage = (tile_bytes <= 64 * 1024) ? 1 : 0;
     KC_TRY(c->timing.start("rollout_kernel", s));
@@ -3216,6 +3277,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
         KC_TRY(c->timing.stop(s));
       }
     }
+    if (a.freeze)  // (no collision pass: first_hit stays INT_MAX everywhere, nothing is frozen)
+      hipLaunchKernelGGL(freeze_fixup_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, a);
   }
   KC_HIP(hipGetLastError());
   c->timing.mark("host:launch_collision");
@@ -3359,10 +3422,19 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
     const float fx = static_cast<float>(c->lat.vx[g]);
     const float fy = static_cast<float>(c->lat.vy[g]);
     const float fo = static_cast<float>(c->lat.omega_values[c->lat.row[g]]);
+    // drop_samples = false: a frozen winner's profile is zero from its freeze step on (trajectory_sampler.cpp:160-163)
+    size_t fstep = P;
+    if (!c->drop_samples && c->freeze_valid) {
+      int fs = 0;
+      KC_HIP(hipMemcpyAsync(&fs, c->d_freeze.p + local, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      KC_HIP(hipStreamSynchronize(c->stream));
+      if (fs > 0) fstep = static_cast<size_t>(fs);
+    }
     for (size_t i = 0; i + 1 < P; ++i) {
-      if (vvx) vvx[i] = fx;
-      if (vvy) vvy[i] = fy;
-      if (vom) vom[i] = fo;
+      const bool z = i >= fstep;
+      if (vvx) vvx[i] = z ? 0.0f : fx;
+      if (vvy) vvy[i] = z ? 0.0f : fy;
+      if (vom) vom[i] = z ? 0.0f : fo;
     }
   }
   return KC_OK;
@@ -3420,6 +3492,29 @@ int kc_dwa_get_samples(kc_dwa *c, float *paths_x, float *paths_y,
             c->external ? static_cast<int64_t>(i) : global_of(c, static_cast<int64_t>(i + c->shard_first)));
       if (costs) costs[row] = hc[i];
     }
+    ++row;
+  }
+  if (n_rows_out) *n_rows_out = row;
+  return KC_OK;
+}
+
+int kc_dwa_get_freeze_steps(kc_dwa *c, int32_t *steps, size_t cap_rows, size_t *n_rows_out) {
+  if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
+  if (!c->rolled || c->external) KC_FAIL(KC_ERR_STATE, "kc_dwa_rollout has not run");
+  KC_TRY(use_device(c));
+  const size_t n = c->n_roll;
+  std::vector<uint8_t> flags(n);
+  std::vector<int> fz(n, 0);
+  KC_HIP(hipStreamSynchronize(c->stream));
+  if (n) {
+    KC_HIP(hipMemcpy(flags.data(), c->d_flags.p, n, hipMemcpyDeviceToHost));
+    if (!c->drop_samples && c->freeze_valid)
+      KC_HIP(hipMemcpy(fz.data(), c->d_freeze.p, n * sizeof(int), hipMemcpyDeviceToHost));
+  }
+  size_t row = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (!flags[i]) continue;
+    if (steps && row < cap_rows) steps[row] = fz[i];
     ++row;
   }
   if (n_rows_out) *n_rows_out = row;

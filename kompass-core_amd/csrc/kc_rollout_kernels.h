@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
       }
     }
     a.flags[n] = 1;
+    if (a.first_hit) a.first_hit[n] = 0x7FFFFFFF;
   }
 
   if (a.stage) {
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   }
   if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, tabregs);
   if (tid < kFusedSamples) {
-    lhit[tid] = 0;
+    lhit[tid] = a.freeze ? 0x7FFFFFFF : 0;  // freeze mode: the FIRST colliding pose index of the sample (minimum)
     lperm[tid] = my_id;
     lrow[tid] = my_row;
     if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
@@ -327,13 +328,16 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     if (s_late) {  // give the cycle up: nothing admissible, error word set
       if (tid < rows) a.flags[lperm[tid]] = 0;
       if constexpr (kCycle) {
-        // the ticket is still taken: the last workgroup publishes the error
-        if (tid == 0)
-          atomicOr(reinterpret_cast<unsigned long long *>(a.dev_err), 1ull);
-        if (tail.host_slots)
+        if (tail.host_slots) {
+          // the slot's own late bit carries the error: the device error word stays untouched (nothing on
+          // this path would re-arm it, and a later ticket / three-kernel cycle would inherit it)
           cycle_epilogue_host<kFusedBlock>(a, tail, KEY_NONE, 0ull, -1, lpos, 1, tid);
-        else
+        } else {
+          // the ticket is still taken: the last workgroup publishes the error and re-arms the word
+          if (tid == 0)
+            atomicOr(reinterpret_cast<unsigned long long *>(a.dev_err), 1ull);
           cycle_epilogue<kFusedBlock>(a, tail, KEY_NONE, 0, -1, lpos, lperm, lperm, tid);
+        }
       } else {
         if (tid == 0) *a.dev_err = 1;
       }
@@ -433,7 +437,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
           const int w = cy * a.c.wpr + (cx >> 5);
           const uint32_t bit = 1u << (cx & 31);
           if (linner[w] & bit) {
-            lhit[s] = 1;  // every writer stores the same value
+            if (a.freeze) atomicMin(&lhit[s], k);
+            else lhit[s] = 1;  // every writer stores the same value
             exact = false;
           } else if (!(louter[w] & bit)) {
             exact = false;
@@ -487,7 +492,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       for (int i = tid; i < nc; i += kFusedBlock) mine[cnt++] = lcand[i];
       __syncthreads();
       for (int q = 0; q < cnt; ++q) {
-        const bool keep = !lhit[mine[q] >> 16];
+        // (freeze mode: a pose behind a known hit of its sample cannot be the first one)
+        const bool keep = a.freeze ? lhit[mine[q] >> 16] > (mine[q] & 0xFFFF) : !lhit[mine[q] >> 16];
         const unsigned long long bal = __ballot(keep);
         if (bal) {
           const int lane = tid & 63, lead = __ffsll(static_cast<long long>(bal)) - 1;
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     const int sub = tid & (lanes_per - 1);
     for (int i = tid / lanes_per; i < nc; i += kFusedBlock / lanes_per) {
       const int s = lcand[i] >> 16, k = lcand[i] & 0xFFFF;
-      if (lhit[s]) continue;  // already decided (stale reads only cost work)
+      if (a.freeze ? lhit[s] <= k : lhit[s] != 0) continue;  // already decided (stale reads only cost work)
       const double2 p = lpos[s * PP + k - 1];
       bool hit;
       if (a.c.shape == KC_BOX) {
@@ -528,7 +534,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       } else {
         hit = hit_round(a.c, lbits, p.x, p.y, sub, lanes_per);
       }
-      if (hit) lhit[s] = 1;
+      if (hit) {
+        if (a.freeze) atomicMin(&lhit[s], k);
+        else lhit[s] = 1;
+      }
     }
   }
   __syncthreads();
@@ -536,8 +545,32 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ int lsurv[kFusedSamples];  // cycle: slots of the survivors, ascending
   __shared__ int nsurv;
   __shared__ unsigned long long lmask;  // ... as a mask over the slots
+  __shared__ int lfrz[kFusedSamples];   // freeze mode: first zero-velocity step of a frozen sample, else 0
   if (tid < 64) {  // wavefront 0: publish the flags, append the survivors
-    const bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
+    bool ok = tid < rows && !lhit[tid < kFusedSamples ? tid : 0];
+    if (a.freeze) {
+      // trajectory_sampler.cpp:147-168: collision at loop step i = k - 1 -> last_free_index = i - 1 (i > 0);
+      // kept when last_free_index > numCtrlPoints_ (and < P - 1, which it always is)
+      const int kc = lhit[tid < kFusedSamples ? tid : 0];
+      int fstep = 0;
+      if (kc != 0x7FFFFFFF) {
+        const int i = kc - 1;
+        if (i >= 1 && (i - 1) > a.num_ctrl) fstep = i;
+      }
+      ok = tid < rows && (kc == 0x7FFFFFFF || fstep > 0);
+      if (tid < kFusedSamples) lfrz[tid] = tid < rows ? fstep : 0;
+      if (tid < rows) {
+        const int id = lperm[tid];
+        float fs = 0.0f, fj = 0.0f;
+        if (fstep > 0)
+          frozen_velocity_sums(static_cast<float>(a.vx[a.first + id]), static_cast<float>(a.vy[a.first + id]),
+                               static_cast<float>(a.omega_values[lrow[tid]]), fstep, a.P - 1, a.acc0, a.acc1, a.acc2,
+                               &fs, &fj);
+        a.freeze_step[id] = fstep;
+        a.frz_smooth[id] = fs;
+        a.frz_jerk[id] = fj;
+      }
+    }
     if (tid < rows) a.flags[lperm[tid]] = ok ? 1 : 0;
     const unsigned long long bal = __ballot(ok);
     const int cnt = __popcll(bal);
@@ -558,6 +591,26 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   }
   KC_RSTAMP(6);
+  if (a.freeze) {
+    // frozen samples: points i + 1 .. P - 1 repeat point i - 1 -- in the LDS rows the cost phase reads and in
+    // the float rows (the sums above went to global memory: visible to this workgroup behind the barrier)
+    __syncthreads();
+    bool store_row = true;
+    if constexpr (kCycle) store_row = tail.write_paths != 0;
+    const int s = tid % kFusedSamples;
+    const int i = s < rows ? lfrz[s] : 0;
+    if (i > 0) {
+      const double2 fp = (i - 1 == 0) ? make_double2(a.x0, a.y0) : lpos[s * PP + i - 2];
+      for (int k = i + 1 + tid / kFusedSamples; k < a.P; k += kFusedBlock / kFusedSamples) {
+        lpos[s * PP + k - 1] = fp;
+        if (store_row) {
+          const size_t o = (size_t)lperm[s] * a.P + k;
+          a.px[o] = static_cast<float>(fp.x);
+          a.py[o] = static_cast<float>(fp.y);
+        }
+      }
+    }
+  }
   if constexpr (kCycle) {
     __syncthreads();
     int best_slot = -1;
@@ -605,7 +658,40 @@ __global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
     hit = a.c.lds ? hit_round(a.c, lbits, p.x, p.y)
                   : hit_round(a.c, a.c.bits, p.x, p.y);
   }
-  if (hit) a.flags[n] = 0;
+  if (hit) {
+    a.flags[n] = 0;
+    if (a.first_hit) atomicMin(&a.first_hit[n], k);  // drop_samples = false: which pose collides FIRST decides
+  }
+}
+
+// split path, drop_samples = false: from the first colliding pose of every sample decide what
+// trajectory_sampler.cpp:157-168 decides, freeze the float rows of the kept samples (the row already holds the
+// float of the point it repeats) and leave the frozen profile's smoothness / jerk sums.  One lane per sample.
+__global__ __launch_bounds__(256) void freeze_fixup_kernel(RollArgs a) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.n) return;
+  const int kc = a.first_hit[n];
+  int fstep = 0;
+  float fs = 0.0f, fj = 0.0f;
+  if (kc != 0x7FFFFFFF) {
+    const int i = kc - 1;  // loop step of the collision: last_free_index = i - 1 (when i > 0)
+    if (i >= 1 && (i - 1) > a.num_ctrl) {
+      fstep = i;
+      float *rx = a.px + (size_t)n * a.P, *ry = a.py + (size_t)n * a.P;
+      const float lx = rx[i - 1], ly = ry[i - 1];
+      for (int k = i + 1; k < a.P; ++k) {
+        rx[k] = lx;
+        ry[k] = ly;
+      }
+      frozen_velocity_sums(static_cast<float>(a.vx[a.first + n]), static_cast<float>(a.vy[a.first + n]),
+                           static_cast<float>(a.omega_values[a.row[a.first + n]]), i, a.P - 1, a.acc0, a.acc1, a.acc2,
+                           &fs, &fj);
+      a.flags[n] = 1;
+    }
+  }
+  a.freeze_step[n] = fstep;
+  a.frz_smooth[n] = fs;
+  a.frz_jerk[n] = fj;
 }
 
 // batch pose check (CollisionChecker::checkCollisions for arbitrary poses):

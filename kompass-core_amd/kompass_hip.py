@@ -115,6 +115,7 @@ SIGNATURES = {
     "kc_dwa_get_best": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
     "kc_dwa_get_sample_velocity": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),
     "kc_dwa_get_samples": (C.c_int, [_vp, _fp, _fp, _ip, _fp, _sz, C.POINTER(_sz)]),
+    "kc_dwa_get_freeze_steps": (C.c_int, [_vp, _ip, _sz, C.POINTER(_sz)]),
     "kc_cost_evaluate": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _sz, _sz, _fp, C.POINTER(Result)]),
     "kc_cost_upload": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp, _sz, _sz]),
     "kc_cost_evaluate_resident": (C.c_int, [_vp, _fp, C.POINTER(Result)]),
@@ -476,6 +477,13 @@ class DwaContext:
                                         C.byref(n)))
         out = (px[:k], py[:k], raw[:k]) if with_paths else (None, None, raw[:k])
         return out + (costs[:k],) if with_costs else out
+
+    def get_freeze_steps(self):
+        n = _sz(0)
+        _check(lib().kc_dwa_get_freeze_steps(self.h, None, 0, C.byref(n)))
+        st = np.zeros(max(n.value, 1), np.int32)
+        _check(lib().kc_dwa_get_freeze_steps(self.h, st.ctypes.data_as(_ip), n.value, C.byref(n)))
+        return st[:n.value]
 
     def get_sample_velocity(self, raw_index):
         vx, vy, om = C.c_double(0), C.c_double(0), C.c_double(0)

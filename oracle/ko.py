@@ -133,6 +133,10 @@ def lib():
         "ko_coll_num_voxels": (sz, [vp]),
         "ko_rollout": (C.c_long, [vp, C.POINTER(State), C.c_double, sz, _dp, _dp, _dp, sz,
                                   _fp, _fp, _fp, _fp, _fp, _ip]),
+        "ko_rollout_mode": (C.c_long, [vp, C.POINTER(State), C.c_double, sz, _dp, _dp, _dp, sz, C.c_int, sz,
+                                       _fp, _fp, _fp, _fp, _fp, _ip]),
+        "ko_full_cycle_mode": (C.c_long, [vp, C.POINTER(CostCtx), C.POINTER(State), C.c_double, sz, _dp, _dp, _dp, sz,
+                                          C.c_int, C.c_int, sz, _fp, _fp, _fp, _fp, _fp, C.POINTER(C.c_uint8), _fp]),
         "ko_min_trajectory_cost": (C.c_long, [C.POINTER(CostCtx), _fp, _fp, _fp, _fp, _fp, sz, sz,
                                               sz, sz, _fp, _fp]),
         "ko_path_cost": (C.c_float, [C.POINTER(CostCtx), _fp, _fp, sz]),
@@ -657,6 +661,49 @@ def host_threads() -> int:
     except (OSError, ValueError):
         pass
     return max(1, min(n, 64))
+
+
+def rollout_mode(coll, start, dt, P, vx, vy, omega, drop_samples=True, num_ctrl_points=0):
+    """rollout() with both values of drop_samples_ (trajectory_sampler.cpp:157-168); always returns the
+    velocity profiles: (paths_x[Na,P], paths_y[Na,P], raw_index[Na], [vx, vy, omega] each [Na,P-1])."""
+    L = lib()
+    vx, vy, omega = _f64(vx), _f64(vy), _f64(omega)
+    n = len(vx)
+    px = np.zeros((max(n, 1), P), np.float32)
+    py = np.zeros((max(n, 1), P), np.float32)
+    raw = np.zeros(max(n, 1), np.int32)
+    st = State(*start) if not isinstance(start, State) else start
+    v = [np.zeros((max(n, 1), P - 1), np.float32) for _ in range(3)]
+    na = L.ko_rollout_mode(coll.h if coll is not None else None, C.byref(st), dt, P, _pd(vx), _pd(vy), _pd(omega), n,
+                           int(bool(drop_samples)), int(num_ctrl_points), _pf(px), _pf(py), _pf(v[0]), _pf(v[1]),
+                           _pf(v[2]), _pi(raw))
+    return px[:na].copy(), py[:na].copy(), raw[:na].copy(), [a[:na].copy() for a in v]
+
+
+def full_cycle_mode(coll, ci: CostInputs | None, start, dt, P, vx, vy, omega, drop_samples=True, num_ctrl_points=0,
+                    threads=None):
+    """full_cycle() with both values of drop_samples_; also returns the velocity profiles (`vel`)."""
+    vx, vy, omega = _f64(vx), _f64(vy), _f64(omega)
+    n = len(vx)
+    px = np.zeros((max(n, 1), P), np.float32)
+    py = np.zeros((max(n, 1), P), np.float32)
+    v = [np.zeros((max(n, 1), P - 1), np.float32) for _ in range(3)]
+    adm = np.zeros(max(n, 1), np.uint8)
+    costs = np.zeros(max(n, 1), np.float32)
+    st = State(*start)
+    lib().ko_full_cycle_mode(coll.h if coll is not None else None, C.byref(ci.cx) if ci is not None else None,
+                             C.byref(st), dt, P, _pd(vx), _pd(vy), _pd(omega), n, int(threads or host_threads()),
+                             int(bool(drop_samples)), int(num_ctrl_points), _pf(px), _pf(py), _pf(v[0]), _pf(v[1]),
+                             _pf(v[2]), adm.ctypes.data_as(C.POINTER(C.c_uint8)), _pf(costs))
+    raw = np.flatnonzero(adm[:n]).astype(np.int32)
+    c = costs[raw]
+    ok = np.flatnonzero(c < np.finfo(np.float32).max)
+    if len(ok):
+        idx = int(ok[np.argmin(c[ok])])
+        cost = float(c[idx])
+    else:
+        idx, cost = -1, 0.0
+    return dict(px=px[raw], py=py[raw], raw=raw, costs=c, index=idx, cost=cost, vel=[a[raw] for a in v])
 
 
 def full_cycle(coll, ci: CostInputs | None, start, dt, P, vx, vy, omega, threads=None):

@@ -812,6 +812,79 @@ static int rollout_one(ko_coll *coll, const ko_state *start, double dt_d,
   return 1;
 }
 
+/* TrajectorySampler::getAdmissibleTrajsFromVel, trajectory_sampler.cpp:118-179, with both values of
+ * drop_samples_: the loop breaks at the first colliding step i and remembers last_free_index = i - 1
+ * (when i > 0; else it stays P - 1, :130,147-152); with drop_samples_ == false a sample whose
+ * last_free_index lies beyond numCtrlPoints_ (= control_horizon / time_step as size_t, :88) is kept:
+ * velocities j = last_free_index + 1 .. P - 2 become zero and path points j + 1 repeat the point at
+ * last_free_index (:157-168) -- i.e. points 0 .. i are the rolled-out ones, points i + 1 .. P - 1 repeat
+ * point i - 1.  fvx / fvy / fom: the sample's velocity profile [P - 1] (TrajectoryVelocities2D::add:
+ * float = double, trajectory.h:96-103).  Returns 1 when the sample is admissible. */
+static int rollout_one_mode(ko_coll *coll, const ko_state *start, double dt_d, size_t P, double vx,
+                            double vy, double om, int drop, size_t num_ctrl, float *px, float *py,
+                            float *fvx, float *fvy, float *fom) {
+  const double dt = (double)(float)dt_d;
+  double x = start->x, y = start->y, yaw = start->yaw;
+  px[0] = (float)x;
+  py[0] = (float)y;
+  int is_collision = 0;
+  size_t last_free = P - 1;
+  for (size_t i = 0; i + 1 < P; ++i) {
+    const double c = cos(yaw), s = sin(yaw);
+    x += (vx * c - vy * s) * dt;
+    y += (vx * s + vy * c) * dt;
+    yaw += om * dt;
+    if (coll && ko_coll_check_at(coll, x, y, yaw)) {
+      is_collision = 1;
+      if (i > 0) last_free = i - 1;
+      break;
+    }
+    fvx[i] = (float)vx;
+    fvy[i] = (float)vy;
+    fom[i] = (float)om;
+    px[i + 1] = (float)x;
+    py[i + 1] = (float)y;
+  }
+  if (!drop && is_collision && last_free > num_ctrl && last_free < P - 1) {
+    const float lx = px[last_free], ly = py[last_free];
+    for (size_t j = last_free + 1; j < P - 1; ++j) {
+      fvx[j] = 0.0f;
+      fvy[j] = 0.0f;
+      fom[j] = 0.0f;
+      px[j + 1] = lx;
+      py[j + 1] = ly;
+    }
+    is_collision = 0;
+  }
+  return !is_collision;
+}
+
+long ko_rollout_mode(ko_coll *coll, const ko_state *start, double time_step, size_t P,
+                     const double *vx, const double *vy, const double *omega, size_t n,
+                     int drop_samples, size_t num_ctrl_points, float *paths_x, float *paths_y,
+                     float *vel_vx, float *vel_vy, float *vel_omega, int32_t *raw_index) {
+  long na = 0;
+  const size_t nv = P - 1;
+  float *tx = (float *)malloc(sizeof(float) * (P ? P : 1) * 5);
+  float *ty = tx + P, *tvx = ty + P, *tvy = tvx + P, *tom = tvy + P;
+  for (size_t k = 0; k < n; ++k) {
+    if (!rollout_one_mode(coll, start, time_step, P, vx[k], vy[k], omega[k], drop_samples,
+                          num_ctrl_points, tx, ty, tvx, tvy, tom))
+      continue;
+    memcpy(paths_x + (size_t)na * P, tx, sizeof(float) * P);
+    memcpy(paths_y + (size_t)na * P, ty, sizeof(float) * P);
+    if (vel_vx) {
+      memcpy(vel_vx + (size_t)na * nv, tvx, sizeof(float) * nv);
+      memcpy(vel_vy + (size_t)na * nv, tvy, sizeof(float) * nv);
+      memcpy(vel_omega + (size_t)na * nv, tom, sizeof(float) * nv);
+    }
+    if (raw_index) raw_index[na] = (int32_t)k;
+    na++;
+  }
+  free(tx);
+  return na;
+}
+
 long ko_rollout(ko_coll *coll, const ko_state *start, double time_step,
                 size_t P, const double *vx, const double *vy,
                 const double *omega, size_t n, float *paths_x, float *paths_y,
@@ -1904,6 +1977,9 @@ typedef struct {
   size_t *next;
   pthread_mutex_t *mu;
   long n_adm;
+  int mode, drop;          /* mode: ko_full_cycle_mode (velocity profiles kept, both drop_samples values) */
+  size_t num_ctrl;
+  float *fvx, *fvy, *fom;  /* [n][P - 1] */
 } fc_job;
 
 static void *fc_worker(void *arg) {
@@ -1918,6 +1994,17 @@ static void *fc_worker(void *arg) {
     const size_t k1 = k0 + 16 < j->n ? k0 + 16 : j->n;
     for (size_t k = k0; k < k1; ++k) {
       float *px = j->px + k * j->P, *py = j->py + k * j->P;
+      if (j->mode) {
+        const size_t nv = j->P - 1;
+        float *fx = j->fvx + k * nv, *fy = j->fvy + k * nv, *fo = j->fom + k * nv;
+        const int ok = rollout_one_mode(j->coll, j->start, j->dt, j->P, j->vx[k], j->vy[k], j->om[k], j->drop,
+                                        j->num_ctrl, px, py, fx, fy, fo);
+        j->adm[k] = ok ? 1 : 0;
+        if (!ok) continue;
+        j->n_adm++;
+        if (j->cx && j->costs) j->costs[k] = total_cost_one(j->cx, px, py, fx, fy, fo, j->P);
+        continue;
+      }
       const int ok = rollout_one(j->coll, j->start, j->dt, j->P, j->vx[k],
                                  j->vy[k], j->om[k], px, py);
       j->adm[k] = ok ? 1 : 0;
@@ -1930,10 +2017,22 @@ static void *fc_worker(void *arg) {
   return NULL;
 }
 
+long ko_full_cycle_mode(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start, double dt, size_t P,
+                        const double *vx, const double *vy, const double *om, size_t n, int threads,
+                        int drop_samples, size_t num_ctrl_points, float *px, float *py, float *fvx,
+                        float *fvy, float *fom, uint8_t *adm, float *costs);
+
 long ko_full_cycle(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start,
                    double dt, size_t P, const double *vx, const double *vy,
                    const double *om, size_t n, int threads, float *px,
                    float *py, uint8_t *adm, float *costs) {
+  return ko_full_cycle_mode(coll, cx, start, dt, P, vx, vy, om, n, threads, 1, 0, px, py, NULL, NULL, NULL, adm, costs);
+}
+
+long ko_full_cycle_mode(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start, double dt, size_t P,
+                        const double *vx, const double *vy, const double *om, size_t n, int threads,
+                        int drop_samples, size_t num_ctrl_points, float *px, float *py, float *fvx,
+                        float *fvy, float *fom, uint8_t *adm, float *costs) {
   if (threads < 1) threads = 1;
   if (threads > 64) threads = 64;
   fc_job jobs[64];
@@ -1958,6 +2057,12 @@ long ko_full_cycle(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start,
     j->next = &next;
     j->mu = &mu;
     j->n_adm = 0;
+    j->mode = fvx != NULL;
+    j->drop = drop_samples;
+    j->num_ctrl = num_ctrl_points;
+    j->fvx = fvx;
+    j->fvy = fvy;
+    j->fom = fom;
     if (threads == 1)
       fc_worker(j);
     else

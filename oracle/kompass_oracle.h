@@ -132,6 +132,14 @@ long ko_rollout(ko_coll *coll, const ko_state *start, double time_step,
                 const double *omega, size_t n, float *paths_x, float *paths_y,
                 float *vel_vx, float *vel_vy, float *vel_omega,
                 int32_t *raw_index);
+/* the same with both values of drop_samples_ (trajectory_sampler.cpp:157-168: a colliding sample whose
+ * last free index lies beyond num_ctrl_points is frozen at that point with zero velocities and stays
+ * admissible); vel_* [Na x (P - 1)] receive the velocity profiles */
+long ko_rollout_mode(ko_coll *coll, const ko_state *start, double time_step, size_t P,
+                     const double *vx, const double *vy, const double *omega, size_t n,
+                     int drop_samples, size_t num_ctrl_points, float *paths_x, float *paths_y,
+                     float *vel_vx, float *vel_vy, float *vel_omega, int32_t *raw_index);
+
 
 /* ---- A5-A10: cost evaluator ---------------------------------------------- */
 typedef struct {
@@ -323,6 +331,12 @@ long ko_full_cycle(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start,
                    double time_step, size_t P, const double *vx,
                    const double *vy, const double *omega, size_t n, int threads,
                    float *px, float *py, uint8_t *admissible, float *costs);
+/* ... with velocity profiles kept and both values of drop_samples_ (see ko_rollout_mode) */
+long ko_full_cycle_mode(ko_coll *coll, const ko_cost_ctx *cx, const ko_state *start, double dt, size_t P,
+                        const double *vx, const double *vy, const double *om, size_t n, int threads,
+                        int drop_samples, size_t num_ctrl_points, float *px, float *py, float *fvx,
+                        float *fvy, float *fom, uint8_t *adm, float *costs);
+
 void ko_costs_mt(const ko_cost_ctx *cx, const float *px, const float *py,
                  const float *vx, const float *vy, const float *om, size_t n,
                  size_t P, int threads, float *costs);

@@ -518,6 +518,11 @@ except Exception as e:
     print("FIRST:", type(e).__name__, str(e)[:80])
 r = ctx.cycle(st, inp["P"])
 print("SECOND:", bool(r.found), int(r.raw_index), int(r.n_admissible))
+# a later cycle on the ticket / three-kernel path must not inherit an error word of the late one
+for opt, val in (("host_reduce", 0), ("fused_cycle", 0)):
+    ctx.set_option(opt, val)
+    r = ctx.cycle(st, inp["P"])
+    print("THEN:", opt, bool(r.found), int(r.raw_index), int(r.n_admissible))
 """
     # the same through the split entry points (ADVICE r1): a roll-out that gives up waiting, then
     # another roll-out WITHOUT an evaluate in between, then evaluate + fetch: the good cycle must not
@@ -534,6 +539,8 @@ print("SECOND:", bool(r.found), int(r.raw_index), int(r.n_admissible))
         pytest.skip("early launch not active on this device (no large BAR)")
     assert "gave up waiting" in lines[0], p.stdout
     assert lines[1] == f"SECOND: True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p.stdout
+    assert lines[2] == f"THEN: host_reduce True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p.stdout
+    assert lines[3] == f"THEN: fused_cycle True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p.stdout
     p2 = subprocess.run([sys.executable, "-c", code_split], capture_output=True, text=True, timeout=120,
                         env=dict(os.environ, KC_TEST_LATE_FLAG_MS="120"))
     assert p2.returncode == 0, p2.stderr[-600:]
