@@ -511,6 +511,20 @@ int kc_cloud_to_laserscan(kc_cloud *ctx, const int8_t *data, size_t nbytes,
                           double max_z, double angle_step, int num_bins,
                           double *ranges_out, double *angles_out, size_t cap,
                           size_t *bins_out);
+/* the same for x / y / z fields of any PointCloud2 datatype (PointFieldType, utils/pointcloud.h:37-46:
+ * ids 1-8), decoded as load_and_cast_val does (:49-87: byte by byte, value cast to float) -- what the
+ * reference's device paths accept (local_mapper_gpu.cpp:117-140, critical_zone_check_gpu.h:36-53); the
+ * bounds check uses the field's own size.  KC_FIELD_FLOAT32 is kc_cloud_to_laserscan.  The reference
+ * holds no vector for the other types: parity is against this build's restatement. */
+enum { KC_FIELD_INT8 = 1, KC_FIELD_UINT8 = 2, KC_FIELD_INT16 = 3, KC_FIELD_UINT16 = 4, KC_FIELD_INT32 = 5,
+       KC_FIELD_UINT32 = 6, KC_FIELD_FLOAT32 = 7, KC_FIELD_FLOAT64 = 8 };
+int kc_cloud_to_laserscan_typed(kc_cloud *ctx, const int8_t *data, size_t nbytes,
+                                int data_on_device, int point_step, int row_step,
+                                int height, int width, int x_offset, int y_offset,
+                                int z_offset, int field_type, double max_range, double min_z,
+                                double max_z, double angle_step, int num_bins,
+                                double *ranges_out, double *angles_out, size_t cap,
+                                size_t *bins_out);
 /* points the last call sent back to the host for exact binning */
 int kc_cloud_last_rebinned(kc_cloud *ctx, size_t *count_out);
 int kc_cloud_timing_enable(kc_cloud *ctx, int enable);
@@ -545,6 +559,11 @@ int kc_zone_check_cloud(kc_zone *ctx, const int8_t *data, size_t nbytes,
                         int point_step, int row_step, int height, int width,
                         int x_offset, int y_offset, int z_offset, int forward,
                         float *factor_out);
+/* ... with the cloud_field_type of CriticalZoneCheckerGPU's constructor (critical_zone_check_gpu.h:36-53) */
+int kc_zone_check_cloud_typed(kc_zone *ctx, const int8_t *data, size_t nbytes,
+                              int point_step, int row_step, int height, int width,
+                              int x_offset, int y_offset, int z_offset, int field_type, int forward,
+                              float *factor_out);
 /* the preset index sets (tests / debugging) */
 int kc_zone_indices(kc_zone *ctx, int forward, int64_t *out, size_t cap,
                     size_t *count_out);

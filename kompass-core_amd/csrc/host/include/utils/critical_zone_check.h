@@ -48,18 +48,20 @@ class CriticalZoneChecker {
   float check(const std::vector<int8_t> &data, int point_step, int row_step, int height, int width,
               int x_offset, int y_offset, int z_offset, const bool forward) {
     float f = 1.0f;
-    hip::check(kc_zone_check_cloud(ctx_.get(), data.data(), data.size(), point_step, row_step, height,
-                                   width, x_offset, y_offset, z_offset, forward ? 1 : 0, &f));
+    hip::check(kc_zone_check_cloud_typed(ctx_.get(), data.data(), data.size(), point_step, row_step, height,
+                                         width, x_offset, y_offset, z_offset, static_cast<int>(field_type_),
+                                         forward ? 1 : 0, &f));
     return f;
   }
 
  protected:
+  PointFieldType field_type_ = PointFieldType::FLOAT32;
   InputType input_type_;
   std::shared_ptr<kc_zone> ctx_;
 };
 
-// critical_zone_check_gpu.h: same surface plus the cloud field type (only
-// FLOAT32 clouds exist on the CPU path this build reproduces)
+// critical_zone_check_gpu.h:36-53: same surface plus the datatype of the cloud's x / y / z fields, decoded as
+// load_and_cast_val does (utils/pointcloud.h:49-87)
 class CriticalZoneCheckerGPU : public CriticalZoneChecker {
  public:
   CriticalZoneCheckerGPU(InputType input_type, const CollisionChecker::ShapeType robot_shape_type,
@@ -73,8 +75,7 @@ class CriticalZoneCheckerGPU : public CriticalZoneChecker {
       : CriticalZoneChecker(input_type, robot_shape_type, robot_dimensions, sensor_position_body,
                             sensor_rotation_body, critical_angle, critical_distance,
                             slowdown_distance, angles, min_height, max_height, range_max) {
-    if (cloud_field_type != PointFieldType::FLOAT32)
-      throw std::invalid_argument("CriticalZoneCheckerGPU: only FLOAT32 point fields are supported");
+    field_type_ = cloud_field_type;
   }
 };
 

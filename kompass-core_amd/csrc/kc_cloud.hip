@@ -45,7 +45,33 @@ struct CloudArgs {
   float2 *list;                  // (x, y) of the points the host has to bin
   int packed16;                  // aligned 16-byte records with x, y, z in front, rows contiguous
   long long n_packed;            // ... and how many of them fit the buffer
+  int ftype, fsize;              // PointFieldType of the x / y / z fields (utils/pointcloud.h:37-46) and its size
 };
+
+// load_and_cast_val, utils/pointcloud.h:49-87: a field of any PointCloud2 datatype as float, byte by byte
+__device__ __forceinline__ float load_field(const uint8_t *p, int t) {
+  auto u16 = [&]() { return static_cast<uint16_t>(static_cast<uint16_t>(p[0]) | (static_cast<uint16_t>(p[1]) << 8)); };
+  auto u32 = [&]() {
+    return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) |
+           (static_cast<uint32_t>(p[3]) << 24);
+  };
+  switch (t) {
+    case KC_FIELD_INT8: return static_cast<float>(static_cast<int8_t>(p[0]));
+    case KC_FIELD_UINT8: return static_cast<float>(p[0]);
+    case KC_FIELD_INT16: return static_cast<float>(static_cast<int16_t>(u16()));
+    case KC_FIELD_UINT16: return static_cast<float>(u16());
+    case KC_FIELD_INT32: return static_cast<float>(static_cast<int32_t>(u32()));
+    case KC_FIELD_UINT32: return static_cast<float>(u32());
+    case KC_FIELD_FLOAT32: return __uint_as_float(u32());
+    case KC_FIELD_FLOAT64: {
+      const uint64_t lo = u32();
+      p += 4;
+      const uint64_t hi = u32();
+      return static_cast<float>(__longlong_as_double(static_cast<long long>(lo | (hi << 32))));
+    }
+    default: return 0.0f;
+  }
+}
 
 __device__ __forceinline__ float load_f32(const uint8_t *p) {
   uint32_t u;
@@ -137,9 +163,13 @@ __global__ __launch_bounds__(kCloudBlock) void cloud_bins_kernel(CloudArgs a) {
       const long long row = i / a.per_row;
       const long long col = (i - row * a.per_row) * a.point_step;
       const size_t start = static_cast<size_t>(row) * a.row_step + static_cast<size_t>(col);
-      if (start + static_cast<size_t>(a.max_off) + sizeof(float) > a.nbytes) continue;  // :139-146
-      cloud_point<kLds>(a, lbins, load_f32(a.data + start + a.x_off), load_f32(a.data + start + a.y_off),
-                        load_f32(a.data + start + a.z_off));
+      if (start + static_cast<size_t>(a.max_off) + static_cast<size_t>(a.fsize) > a.nbytes) continue;  // :139-146
+      if (a.ftype == KC_FIELD_FLOAT32)
+        cloud_point<kLds>(a, lbins, load_f32(a.data + start + a.x_off), load_f32(a.data + start + a.y_off),
+                          load_f32(a.data + start + a.z_off));
+      else
+        cloud_point<kLds>(a, lbins, load_field(a.data + start + a.x_off, a.ftype),
+                          load_field(a.data + start + a.y_off, a.ftype), load_field(a.data + start + a.z_off, a.ftype));
     }
   }
   if (kLds) {
@@ -288,8 +318,23 @@ int kc_cloud_to_laserscan(kc_cloud *c, const int8_t *data, size_t nbytes,
                           double max_z, double angle_step, int num_bins,
                           double *ranges_out, double *angles_out, size_t cap,
                           size_t *bins_out) {
+  return kc_cloud_to_laserscan_typed(c, data, nbytes, data_on_device, point_step, row_step, height, width, x_offset,
+                                     y_offset, z_offset, KC_FIELD_FLOAT32, max_range, min_z, max_z, angle_step, num_bins,
+                                     ranges_out, angles_out, cap, bins_out);
+}
+
+int kc_cloud_to_laserscan_typed(kc_cloud *c, const int8_t *data, size_t nbytes,
+                                int data_on_device, int point_step, int row_step,
+                                int height, int width, int x_offset, int y_offset,
+                                int z_offset, int field_type, double max_range, double min_z,
+                                double max_z, double angle_step, int num_bins,
+                                double *ranges_out, double *angles_out, size_t cap,
+                                size_t *bins_out) {
   (void)width;  // pointcloud.h:137-138: the loops use row_step / point_step only
   if (!c || !ranges_out || (nbytes && !data)) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (field_type < KC_FIELD_INT8 || field_type > KC_FIELD_FLOAT64)
+    KC_FAIL(KC_ERR_INVALID, "Invalid integer for PointFieldType. Must be 1-8.");
+  static const int kFieldSize[9] = {0, 1, 1, 2, 2, 4, 4, 4, 8};
   if (point_step <= 0 || row_step < 0 || height < 0 || x_offset < 0 || y_offset < 0 ||
       z_offset < 0)
     KC_FAIL(KC_ERR_INVALID, "point_step must be positive, sizes and offsets non-negative");
@@ -345,7 +390,9 @@ int kc_cloud_to_laserscan(kc_cloud *c, const int8_t *data, size_t nbytes,
   a.num_bins = num_bins;
   a.edge = 1e-6 / (by_step ? angle_step : two_pi / num_bins);
   std::memcpy(&a.max_bits, &max_r, sizeof(double));
-  a.packed16 = point_step == 16 && x_offset == 0 && y_offset == 4 && z_offset == 8 &&
+  a.ftype = field_type;
+  a.fsize = kFieldSize[field_type];
+  a.packed16 = field_type == KC_FIELD_FLOAT32 && point_step == 16 && x_offset == 0 && y_offset == 4 && z_offset == 8 &&
                row_step % 16 == 0 && (reinterpret_cast<uintptr_t>(dev) & 15u) == 0;
   a.n_packed = std::min<long long>(n_rec, static_cast<long long>(nbytes / 16));
   a.bins = c->d_bins.p;

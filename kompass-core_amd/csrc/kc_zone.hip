@@ -226,6 +226,13 @@ int kc_zone_check(kc_zone *z, const double *ranges, size_t n, int forward, float
 int kc_zone_check_cloud(kc_zone *z, const int8_t *data, size_t nbytes, int point_step,
                         int row_step, int height, int width, int x_offset, int y_offset,
                         int z_offset, int forward, float *factor_out) {
+  return kc_zone_check_cloud_typed(z, data, nbytes, point_step, row_step, height, width, x_offset, y_offset, z_offset,
+                                   KC_FIELD_FLOAT32, forward, factor_out);
+}
+
+int kc_zone_check_cloud_typed(kc_zone *z, const int8_t *data, size_t nbytes, int point_step,
+                              int row_step, int height, int width, int x_offset, int y_offset,
+                              int z_offset, int field_type, int forward, float *factor_out) {
   if (!z || !factor_out) KC_FAIL(KC_ERR_INVALID, "null argument");
   *factor_out = 1.0f;
   if (z->n == 0) return KC_OK;
@@ -233,11 +240,11 @@ int kc_zone_check_cloud(kc_zone *z, const int8_t *data, size_t nbytes, int point
   z->cloud_ranges.resize(z->n);
   size_t bins = 0;
   // critical_zone_check.cpp:124-129: num_bins overload over the preset angle count
-  KC_TRY(kc_cloud_to_laserscan(z->cloud, data, nbytes, 0, point_step, row_step, height, width,
-                               x_offset, y_offset, z_offset, static_cast<double>(z->range_max),
-                               static_cast<double>(z->min_height), static_cast<double>(z->max_height),
-                               0.0, static_cast<int>(z->n), z->cloud_ranges.data(), nullptr, z->n,
-                               &bins));
+  KC_TRY(kc_cloud_to_laserscan_typed(z->cloud, data, nbytes, 0, point_step, row_step, height, width,
+                                     x_offset, y_offset, z_offset, field_type, static_cast<double>(z->range_max),
+                                     static_cast<double>(z->min_height), static_cast<double>(z->max_height),
+                                     0.0, static_cast<int>(z->n), z->cloud_ranges.data(), nullptr, z->n,
+                                     &bins));
   return kc_zone_check(z, z->cloud_ranges.data(), z->n, forward, factor_out);
 }
 

@@ -165,6 +165,11 @@ SIGNATURES = {
     "kc_cloud_to_laserscan": (C.c_int, [_vp, C.c_void_p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_double, C.c_int, _dp, _dp, _sz, C.POINTER(_sz)]),
+    "kc_cloud_to_laserscan_typed": (C.c_int, [_vp, C.c_void_p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                              C.c_int, _dp, _dp, _sz, C.POINTER(_sz)]),
+    "kc_zone_check_cloud_typed": (C.c_int, [_vp, C.c_void_p, _sz, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, _fp]),
     "kc_cloud_last_rebinned": (C.c_int, [_vp, C.POINTER(_sz)]),
     "kc_cloud_timing_enable": (C.c_int, [_vp, C.c_int]),
     "kc_cloud_timing_get": (C.c_int, [_vp, C.POINTER(C.c_char_p), _fp, _sz, C.POINTER(_sz)]),
@@ -675,7 +680,8 @@ class CloudContext:
             pass
 
     def to_laserscan(self, data, point_step, row_step, height, width, x_offset, y_offset, z_offset,
-                     max_range, min_z, max_z, angle_step=None, num_bins=None, device_ptr=None, nbytes=None):
+                     max_range, min_z, max_z, angle_step=None, num_bins=None, device_ptr=None, nbytes=None,
+                     field_type=7):
         """pointCloudToLaserScanFromRaw: (ranges, angles) with angle_step,
         ranges with num_bins.  `data`: bytes / int8 array on the host, or pass
         device_ptr + nbytes for a buffer that already lives on the device."""
@@ -691,11 +697,11 @@ class CloudContext:
             buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.int8)
                                        if not isinstance(data, np.ndarray) else data.view(np.int8).reshape(-1))
             ptr, size, on_dev = buf.ctypes.data, buf.size, 0
-        _check(lib().kc_cloud_to_laserscan(self.h, ptr, size, on_dev, int(point_step), int(row_step), int(height),
-                                           int(width), int(x_offset), int(y_offset), int(z_offset),
-                                           float(max_range), float(min_z), float(max_z),
-                                           float(angle_step) if by_step else 0.0, nb, _pd(ranges), _pd(angles),
-                                           cap, C.byref(n)))
+        _check(lib().kc_cloud_to_laserscan_typed(self.h, ptr, size, on_dev, int(point_step), int(row_step), int(height),
+                                                 int(width), int(x_offset), int(y_offset), int(z_offset), int(field_type),
+                                                 float(max_range), float(min_z), float(max_z),
+                                                 float(angle_step) if by_step else 0.0, nb, _pd(ranges), _pd(angles),
+                                                 cap, C.byref(n)))
         return (ranges[:n.value], angles[:n.value]) if by_step else ranges[:n.value]
 
     def last_rebinned(self) -> int:
@@ -745,13 +751,14 @@ class ZoneContext:
         _check(lib().kc_zone_check(self.h, _pd(r), len(r), int(bool(forward)), C.byref(f)))
         return float(f.value)
 
-    def check_cloud(self, data, point_step, row_step, height, width, x_offset, y_offset, z_offset, forward) -> float:
+    def check_cloud(self, data, point_step, row_step, height, width, x_offset, y_offset, z_offset, forward,
+                    field_type=7) -> float:
         buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.int8) if not isinstance(data, np.ndarray)
                                    else data.view(np.int8).reshape(-1))
         f = C.c_float(0)
-        _check(lib().kc_zone_check_cloud(self.h, buf.ctypes.data, buf.size, int(point_step), int(row_step),
-                                         int(height), int(width), int(x_offset), int(y_offset), int(z_offset),
-                                         int(bool(forward)), C.byref(f)))
+        _check(lib().kc_zone_check_cloud_typed(self.h, buf.ctypes.data, buf.size, int(point_step), int(row_step),
+                                               int(height), int(width), int(x_offset), int(y_offset), int(z_offset),
+                                               int(field_type), int(bool(forward)), C.byref(f)))
         return float(f.value)
 
     def indices(self, forward):

@@ -174,6 +174,10 @@ def lib():
         "ko_pointcloud_to_laserscan": (C.c_long, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                                  C.c_double, C.c_int, _dp, _dp, C.c_size_t]),
+        "ko_pointcloud_to_laserscan_typed": (C.c_long, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                       C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                       C.c_double, C.c_int, C.c_int, _dp, _dp, C.c_size_t]),
+        "ko_czc_set_field_type": (None, [C.c_void_p, C.c_int]),
         "ko_mapper_scan_to_grid": (C.c_int, [C.c_int, C.c_int, C.c_float, _fp, C.c_float, _dp, _dp,
                                              sz, _ip]),
         "ko_bmap_create": (C.c_void_p, [C.c_int, C.c_int, C.c_float, _fp, C.c_float, C.c_float, C.c_float,
@@ -580,8 +584,11 @@ class BayesMapper:
         lib().ko_bmap_set_previous(self.h, _pf(flat))
 
 
+FIELD_INT8, FIELD_UINT8, FIELD_INT16, FIELD_UINT16, FIELD_INT32, FIELD_UINT32, FIELD_FLOAT32, FIELD_FLOAT64 = range(1, 9)
+
+
 def pointcloud_to_laserscan(data, point_step, row_step, height, width, x_offset, y_offset, z_offset,
-                            max_range, min_z, max_z, angle_step=None, num_bins=None):
+                            max_range, min_z, max_z, angle_step=None, num_bins=None, field_type=FIELD_FLOAT32):
     """pointCloudToLaserScanFromRaw: (ranges, angles) for the angle_step
     overload, ranges for the num_bins overload."""
     buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.int8) if not isinstance(data, np.ndarray)
@@ -591,10 +598,10 @@ def pointcloud_to_laserscan(data, point_step, row_step, height, width, x_offset,
     cap = max(nb, 1)
     ranges = np.zeros(cap, np.float64)
     angles = np.zeros(cap, np.float64)
-    n = lib().ko_pointcloud_to_laserscan(buf.ctypes.data, buf.size, point_step, row_step, height, width,
-                                         x_offset, y_offset, z_offset, float(max_range), float(min_z),
-                                         float(max_z), float(angle_step) if by_step else 0.0, nb,
-                                         _pd(ranges), _pd(angles), cap)
+    n = lib().ko_pointcloud_to_laserscan_typed(buf.ctypes.data, buf.size, point_step, row_step, height, width,
+                                               x_offset, y_offset, z_offset, float(max_range), float(min_z),
+                                               float(max_z), float(angle_step) if by_step else 0.0, nb, int(field_type),
+                                               _pd(ranges), _pd(angles), cap)
     if n < 0:
         raise ValueError("invalid point cloud arguments")
     return (ranges[:n], angles[:n]) if by_step else ranges[:n]
@@ -604,7 +611,7 @@ class CriticalZone:
     """CriticalZoneChecker (utils/critical_zone_check.cpp), CPU semantics."""
 
     def __init__(self, shape, dims, sensor_pos, sensor_rot_xyzw, critical_angle, critical_distance,
-                 slowdown_distance, angles, min_height, max_height, range_max):
+                 slowdown_distance, angles, min_height, max_height, range_max, field_type=FIELD_FLOAT32):
         d, sp, sr = _f32(dims), _f32(sensor_pos), _f32(sensor_rot_xyzw)
         self.angles = _f64(angles)
         self.h = lib().ko_czc_create(int(shape), _pf(d), _pf(sp), _pf(sr), float(np.float32(critical_angle)),
@@ -613,6 +620,7 @@ class CriticalZone:
                                      float(np.float32(max_height)), float(np.float32(range_max)))
         if not self.h:
             raise ValueError("SlowDown distance must be greater than the Critical distance / invalid shape")
+        lib().ko_czc_set_field_type(self.h, int(field_type))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -2129,12 +2129,58 @@ void ko_costs_mt(const ko_cost_ctx *cx, const float *px, const float *py,
 /* ===========================================================================
  * M5: pointCloudToLaserScanFromRaw, utils/pointcloud.h:116-177 and :205-259
  * =========================================================================== */
+/* load_and_cast_val, utils/pointcloud.h:49-87: a field of any PointCloud2 datatype (ids 1-8, :37-46) as
+ * float, read byte by byte (no alignment assumed); unknown ids give 0 */
+static size_t field_size(int t) {
+  switch (t) {
+    case 1: case 2: return 1;
+    case 3: case 4: return 2;
+    case 5: case 6: case 7: return 4;
+    case 8: return 8;
+    default: return 4;
+  }
+}
+static float load_and_cast(const int8_t *addr, int t) {
+  switch (t) {
+    case 1: return (float)*addr;
+    case 2: return (float)*(const uint8_t *)addr;
+    case 3: { int16_t v; memcpy(&v, addr, 2); return (float)v; }
+    case 4: { uint16_t v; memcpy(&v, addr, 2); return (float)v; }
+    case 5: { int32_t v; memcpy(&v, addr, 4); return (float)v; }
+    case 6: { uint32_t v; memcpy(&v, addr, 4); return (float)v; }
+    case 7: { float v; memcpy(&v, addr, 4); return v; }
+    case 8: { double v; memcpy(&v, addr, 8); return (float)v; }
+    default: return 0.0f;
+  }
+}
+
+long ko_pointcloud_to_laserscan_typed(const int8_t *data, size_t nbytes, int point_step,
+                                      int row_step, int height, int width, int x_offset,
+                                      int y_offset, int z_offset, double max_range,
+                                      double min_z, double max_z, double angle_step,
+                                      int num_bins, int field_type, double *ranges_out,
+                                      double *angles_out, size_t cap);
+
 long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_step,
                                 int row_step, int height, int width, int x_offset,
                                 int y_offset, int z_offset, double max_range,
                                 double min_z, double max_z, double angle_step,
                                 int num_bins, double *ranges_out,
                                 double *angles_out, size_t cap) {
+  return ko_pointcloud_to_laserscan_typed(data, nbytes, point_step, row_step, height, width, x_offset,
+                                          y_offset, z_offset, max_range, min_z, max_z, angle_step, num_bins,
+                                          7, ranges_out, angles_out, cap);
+}
+
+/* The CPU loop of pointcloud.h:116-177 / :205-259 with the fields decoded by load_and_cast_val (what the
+ * reference's device paths do for non-FLOAT32 clouds, local_mapper_gpu.cpp:117-140,
+ * critical_zone_check_gpu.cpp; bounds check with the field's own size).  FLOAT32 (7) is the CPU function. */
+long ko_pointcloud_to_laserscan_typed(const int8_t *data, size_t nbytes, int point_step,
+                                      int row_step, int height, int width, int x_offset,
+                                      int y_offset, int z_offset, double max_range,
+                                      double min_z, double max_z, double angle_step,
+                                      int num_bins, int field_type, double *ranges_out,
+                                      double *angles_out, size_t cap) {
   (void)width; /* pointcloud.h:137-138: the loops use row_step / point_step only */
   const double two_pi = 2.0 * M_PI;
   const int by_step = angle_step > 0.0;
@@ -2152,11 +2198,10 @@ long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_ste
   for (int row = 0; row < height; ++row) {
     for (int col = 0; col < row_step; col += point_step) {
       const size_t point_start = (size_t)row * (size_t)row_step + (size_t)col;
-      if (point_start + (size_t)max_off + sizeof(float) > nbytes) continue; /* :139-146 */
-      float x, y, z;
-      memcpy(&x, data + point_start + x_offset, sizeof(float));
-      memcpy(&y, data + point_start + y_offset, sizeof(float));
-      memcpy(&z, data + point_start + z_offset, sizeof(float));
+      if (point_start + (size_t)max_off + field_size(field_type) > nbytes) continue; /* :139-146 */
+      const float x = load_and_cast(data + point_start + x_offset, field_type);
+      const float y = load_and_cast(data + point_start + y_offset, field_type);
+      const float z = load_and_cast(data + point_start + z_offset, field_type);
       const float xx = x * x, yy = y * y;
       const float range_sq = xx + yy; /* :153 */
       if ((double)range_sq < 1e-6) continue;
@@ -2179,6 +2224,7 @@ long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_ste
  * CriticalZoneChecker, utils/critical_zone_check.cpp
  * =========================================================================== */
 struct ko_czc {
+  int field_type;          /* PointFieldType of raw clouds (0 / 7: FLOAT32) */
   double robot_radius;     /* robotRadius_ (double member) */
   float min_height, max_height, range_max;
   float critical_angle;    /* half cone, normalised, stored as float */
@@ -2281,12 +2327,14 @@ float ko_czc_check_cloud(const ko_czc *z, const int8_t *data, size_t nbytes,
                          int x_offset, int y_offset, int z_offset, int forward) { /* :119-131 */
   if (z->n == 0) return 1.0f;
   double *ranges = (double *)malloc(sizeof(double) * z->n);
-  const long nb = ko_pointcloud_to_laserscan(data, nbytes, point_step, row_step, height, width,
-                                             x_offset, y_offset, z_offset, (double)z->range_max,
-                                             (double)z->min_height, (double)z->max_height, 0.0,
-                                             (int)z->n, ranges, NULL, z->n);
+  const long nb = ko_pointcloud_to_laserscan_typed(data, nbytes, point_step, row_step, height, width,
+                                                   x_offset, y_offset, z_offset, (double)z->range_max,
+                                                   (double)z->min_height, (double)z->max_height, 0.0,
+                                                   (int)z->n, z->field_type ? z->field_type : 7, ranges, NULL, z->n);
   float r = 1.0f;
   if (nb == (long)z->n) r = ko_czc_check(z, ranges, forward);
   free(ranges);
   return r;
 }
+
+void ko_czc_set_field_type(ko_czc *z, int field_type) { z->field_type = field_type; }

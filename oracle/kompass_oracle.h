@@ -293,6 +293,14 @@ long ko_pointcloud_to_laserscan(const int8_t *data, size_t nbytes, int point_ste
                                 double min_z, double max_z, double angle_step,
                                 int num_bins, double *ranges_out,
                                 double *angles_out, size_t cap);
+/* ... with the x / y / z fields of any PointCloud2 datatype (utils/pointcloud.h:37-87 ids 1-8) */
+long ko_pointcloud_to_laserscan_typed(const int8_t *data, size_t nbytes, int point_step,
+                                      int row_step, int height, int width, int x_offset,
+                                      int y_offset, int z_offset, double max_range,
+                                      double min_z, double max_z, double angle_step,
+                                      int num_bins, int field_type, double *ranges_out,
+                                      double *angles_out, size_t cap);
+
 
 /* ---- CriticalZoneChecker (CPU semantics), SURVEY 8f rank 2 ------------------- */
 /* utils/critical_zone_check.{h,cpp}: ctor :13-58 (shape -> radius, sensor
@@ -311,6 +319,8 @@ float ko_czc_check(const ko_czc *z, const double *ranges, int forward);
 float ko_czc_check_cloud(const ko_czc *z, const int8_t *data, size_t nbytes,
                          int point_step, int row_step, int height, int width,
                          int x_offset, int y_offset, int z_offset, int forward);
+void ko_czc_set_field_type(ko_czc *z, int field_type);
+
 /* introspection for the tests: index sets and trig tables */
 size_t ko_czc_indices(const ko_czc *z, int forward, size_t *out, size_t cap);
 

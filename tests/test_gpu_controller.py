@@ -198,6 +198,43 @@ def test_debug_samples_and_custom_cost():
     np.testing.assert_array_equal(np.asarray(gpu.optimal_path().y), o["samples_y"][k])
 
 
+def test_debug_velocity_search_without_sample_dropping():
+    """DWA::debugVelocitySearch(vel, data, drop_samples = false) (controllers/dwa.h:146-158): samples that collide
+    beyond the control horizon are frozen and kept -- class level against the oracle's restatement of
+    trajectory_sampler.cpp:118-179 (numCtrlPoints_ = control_horizon / time_step, :88)."""
+    cfg = DWAConfig(max_linear_samples=9, max_angular_samples=9, octree_resolution=0.1, prediction_horizon=40,
+                    control_horizon=4, control_time_step=0.1, drop_samples=False,
+                    costs_weights=TrajectoryCostsWeights(reference_path_distance_weight=1.0, goal_distance_weight=1.0,
+                                                         obstacles_distance_weight=1.0, smoothness_weight=1.0, jerk_weight=1.0))
+    vx_lim = LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0)
+    om_lim = AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0)
+    robot, gpu, cpu = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.CYLINDER, [0.1, 0.4], vx_lim, om_lim, cfg)
+    pts = [(x, 0.0) for x in np.arange(0.0, 6.01, 0.5)]
+    gpu.set_path(_P(pts))
+    robot.state.x, robot.state.y, robot.state.yaw = 0.0, 0.1, 0.05
+    robot.state.vx = 0.5
+    cloud = _round_obstacle(1.2, 0.1, 0.25)
+    s = robot.state
+    assert gpu.loop_step(current_state=s, local_map=cloud, debug=True)   # debug -> debug_velocity_search(drop_samples=False)
+    px, py = gpu.planner.get_debugging_samples()
+    # the oracle: same window, same voxels, both modes
+    vel = tuple(float(np.float32(v)) for v in (s.vx, s.vy, s.omega))
+    lim = ko.make_limits((vx_lim.max_vel, vx_lim.max_acc, vx_lim.max_decel), (0.0, 0.0, 0.0),
+                         (om_lim.max_steer, om_lim.max_vel, om_lim.max_acc, om_lim.max_decel))
+    svx, svy, som = ko.sample_velocities(CTR[RobotType.DIFFERENTIAL_DRIVE], lim, vel, 0.1, 9, 9)
+    coll = ko.Collision(SHP[RobotGeometry.Type.CYLINDER], [0.1, 0.4], (0, 0, 0), (0, 0, 0, 1), 0.1)
+    coll.update_state(s.x, s.y, s.yaw)
+    coll.update_points(np.asarray(cloud, np.float32).reshape(-1, 3), True)
+    P = int(40 * 0.1 / 0.1)
+    kx, ky, kraw, kvel = ko.rollout_mode(coll, (s.x, s.y, s.yaw, 0.0), 0.1, P, svx, svy, som, False, int(0.4 / 0.1))
+    dx, dy, draw, _ = ko.rollout_mode(coll, (s.x, s.y, s.yaw, 0.0), 0.1, P, svx, svy, som, True, 0)
+    assert len(kraw) > len(draw) > 0            # some samples are kept only because they are frozen
+    np.testing.assert_array_equal(np.asarray(px), kx)
+    np.testing.assert_array_equal(np.asarray(py), ky)
+    # the command of the cycle comes from the same mode (the sampler keeps it, as the reference's does)
+    assert gpu.has_result()
+
+
 def test_local_mapper_frontend():
     """kompass_core.mapping.LocalMapper.update_from_scan (tests/test_local_mapper_
     pytest.py invariants) + cell-exact agreement with the CPU mapper semantics."""

@@ -220,3 +220,80 @@ def test_local_mapper_pointcloud_overload():
         want = ko.scan_to_grid(H, W, 0.05, (0, 0, 0), 0.0, np.arange(scan) * (2.0 * np.pi / scan), ranges)
         np.testing.assert_array_equal(g, want)
         assert (g == 100).sum() > 50
+
+
+# ---- PointCloud2 fields of any datatype (PointFieldType 1-8, utils/pointcloud.h:37-87) ------------------------
+FIELD_DTYPES = {1: np.int8, 2: np.uint8, 3: np.int16, 4: np.uint16, 5: np.int32, 6: np.uint32, 7: np.float32, 8: np.float64}
+
+
+def typed_cloud(xyz, ftype, pad=3, lead=1):
+    """records of [lead bytes][x][y][z][pad bytes] with fields of datatype `ftype` (values cast, not scaled)."""
+    dt = np.dtype(FIELD_DTYPES[ftype])
+    vals = np.asarray(xyz, np.float64)
+    if dt.kind in "iu":
+        info = np.iinfo(dt)
+        vals = np.clip(np.rint(vals), info.min, info.max)
+    vals = vals.astype(dt)
+    step = lead + 3 * dt.itemsize + pad
+    rec = np.zeros((len(vals), step), np.uint8)
+    rec[:, lead:lead + 3 * dt.itemsize] = vals.view(np.uint8).reshape(len(vals), -1)
+    return rec.reshape(-1).view(np.int8), step, (lead, lead + dt.itemsize, lead + 2 * dt.itemsize), vals
+
+
+@pytest.mark.parametrize("ftype", sorted(FIELD_DTYPES))
+def test_oracle_typed_fields_decode_like_load_and_cast_val(ftype):
+    rng = np.random.default_rng(ftype)
+    xyz = np.column_stack([rng.uniform(-20, 20, 300), rng.uniform(-20, 20, 300), rng.uniform(0, 2, 300)])
+    data, step, (xo, yo, zo), vals = typed_cloud(xyz, ftype)
+    r = ko.pointcloud_to_laserscan(data, step, len(vals) * step, 1, len(vals), xo, yo, zo, 50.0, -1.0, -1.0,
+                                   num_bins=90, field_type=ftype)
+    # the same points as float32 records: the decode is `static_cast<float>(value)`
+    f = vals.astype(np.float32)
+    want = ko.pointcloud_to_laserscan(cloud_bytes(f), STRIDE, len(f) * STRIDE, 1, len(f), 0, 4, 8, 50.0, -1.0, -1.0,
+                                      num_bins=90)
+    np.testing.assert_array_equal(r, want)
+    assert (r < 50.0).sum() > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ftype", sorted(FIELD_DTYPES))
+def test_hip_typed_fields_match_oracle(ftype):
+    import kompass_hip as kh
+
+    rng = np.random.default_rng(100 + ftype)
+    n = 20000
+    scale = 100.0 if ftype in (1, 2) else 30.0
+    xyz = np.column_stack([rng.uniform(-scale, scale, n), rng.uniform(-scale, scale, n), rng.uniform(0, 3, n)])
+    data, step, (xo, yo, zo), vals = typed_cloud(xyz, ftype, pad=int(rng.integers(0, 5)), lead=int(rng.integers(0, 4)))
+    ctx = kh.CloudContext(max_bytes=data.size, max_bins=720)
+    for kw in (dict(angle_step=0.01), dict(num_bins=360)):
+        for nbytes in (data.size, data.size - step // 2 - 1):   # the last record cut short: bounds check with the field's size
+            d = data[:nbytes]
+            got = ctx.to_laserscan(d, step, len(vals) * step, 1, len(vals), xo, yo, zo, 120.0, 0.5, 2.5, field_type=ftype, **kw)
+            want = ko.pointcloud_to_laserscan(d, step, len(vals) * step, 1, len(vals), xo, yo, zo, 120.0, 0.5, 2.5,
+                                              field_type=ftype, **kw)
+            if "angle_step" in kw:
+                np.testing.assert_array_equal(got[0].view(np.uint64), want[0].view(np.uint64))
+                np.testing.assert_array_equal(got[1], want[1])
+            else:
+                np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64))
+    with pytest.raises(ValueError):
+        ctx.to_laserscan(data, step, len(vals) * step, 1, len(vals), xo, yo, zo, 120.0, 0.5, 2.5, num_bins=8, field_type=9)
+
+
+@pytest.mark.gpu
+def test_zone_checker_takes_typed_clouds():
+    import kompass_hip as kh
+
+    ang = np.linspace(0.0, 2.0 * np.pi, 360, endpoint=False)
+    args = (kh.CYLINDER, [0.3, 0.5], (0.2, 0.0, 0.1), (0, 0, 0, 1), 160.0, 1.0, 4.0, ang, 0.0, 3.0, 40.0)
+    rng = np.random.default_rng(7)
+    for ftype in (3, 5, 8):
+        xyz = np.column_stack([rng.uniform(-9, 9, 4000), rng.uniform(-9, 9, 4000), rng.uniform(0, 2, 4000)])
+        data, step, (xo, yo, zo), vals = typed_cloud(xyz, ftype)
+        z = kh.ZoneContext(*args)
+        o = ko.CriticalZone(*args, field_type=ftype)
+        for fwd in (True, False):
+            got = z.check_cloud(data, step, len(vals) * step, 1, len(vals), xo, yo, zo, fwd, field_type=ftype)
+            want = o.check_cloud(data, step, len(vals) * step, 1, len(vals), xo, yo, zo, fwd)
+            assert np.float32(got) == np.float32(want)
