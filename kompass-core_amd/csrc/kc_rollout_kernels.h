@@ -24,8 +24,8 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
   const int n = base + tid;
 
   if (n < a.n) {
-    const double vx = a.vx[a.first + n];
-    const double vy = a.vy[a.first + n];
+    const double vx = sample_vx(a, n);
+    const double vy = sample_vy(a, n);
     const int r = a.row[a.first + n];
     double x = a.x0, y = a.y0;
     const float fx0 = static_cast<float>(x), fy0 = static_cast<float>(y);
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ int lhit[kFusedSamples];
   __shared__ int lperm[kFusedSamples];  // local sample id of slot s
   __shared__ int lrow[kFusedSamples];   // its trig row
+  __shared__ uint32_t lvi[kFusedSamples];  // its value indices (vx | vy << 16)
 
   const int tid = threadIdx.x;
   const int base = blockIdx.x * kFusedSamples;
@@ -211,9 +212,11 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   // (the sample ids of this workgroup: loads issued here, used behind the table copies -- a wait
   // for them in front would put wavefront 0 a memory round trip behind the others)
   int my_id = 0, my_row = 0;
+  uint32_t my_vi = 0u;
   if (tid < rows) {
     my_id = a.perm[base + tid];
     my_row = a.prow[base + tid];
+    my_vi = a.pvi[base + tid];
   }
   // Cycle: the cost tables' global loads are issued here and land in LDS at the end of the
   // phase; the window loads below are in flight at the same time.
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     lhit[tid] = a.freeze ? 0x7FFFFFFF : 0;  // freeze mode: the FIRST colliding pose index of the sample (minimum)
     lperm[tid] = my_id;
     lrow[tid] = my_row;
+    lvi[tid] = my_vi;
     if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
   }
   if (tid == 0) {
@@ -351,8 +355,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     const int s = tid & (kFusedSamples - 1);
     if (s < rows) {
       const int r = lrow[s];
-      const int id = lperm[s];
-      const double vx = a.vx[a.first + id], vy = a.vy[a.first + id];
+      const uint32_t vi = lvi[s];
+      const double vx = a.vxt[vi & 0xFFFFu], vy = a.vyt[vi >> 16];
       const double *tg = reinterpret_cast<const double *>(a.trig);
       for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
         const size_t e = ((size_t)k * a.A + r) * 2;
@@ -368,8 +372,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     const int s = tid & (kFusedSamples - 1);
     if (s < rows) {
       const int r = lrow[s];
-      const int id = lperm[s];
-      const double vx = a.vx[a.first + id], vy = a.vy[a.first + id];
+      const uint32_t vi = lvi[s];
+      const double vx = a.vxt[vi & 0xFFFFu], vy = a.vyt[vi >> 16];
       for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
         const double2 cs = a.trig[(size_t)k * a.A + r];
         const double tx = vx * cs.x - vy * cs.y;
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
         const int id = lperm[tid];
         float fs = 0.0f, fj = 0.0f;
         if (fstep > 0)
-          frozen_velocity_sums(static_cast<float>(a.vx[a.first + id]), static_cast<float>(a.vy[a.first + id]),
+          frozen_velocity_sums(static_cast<float>(a.vxt[lvi[tid] & 0xFFFFu]), static_cast<float>(a.vyt[lvi[tid] >> 16]),
                                static_cast<float>(a.omega_values[lrow[tid]]), fstep, a.P - 1, a.acc0, a.acc1, a.acc2,
                                &fs, &fj);
         a.freeze_step[id] = fstep;
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256) void freeze_fixup_kernel(RollArgs a) {
         rx[k] = lx;
         ry[k] = ly;
       }
-      frozen_velocity_sums(static_cast<float>(a.vx[a.first + n]), static_cast<float>(a.vy[a.first + n]),
+      frozen_velocity_sums(static_cast<float>(sample_vx(a, n)), static_cast<float>(sample_vy(a, n)),
                            static_cast<float>(a.omega_values[a.row[a.first + n]]), i, a.P - 1, a.acc0, a.acc1, a.acc2,
                            &fs, &fj);
       a.flags[n] = 1;

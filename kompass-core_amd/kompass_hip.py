@@ -426,8 +426,12 @@ class DwaContext:
 
     def set_tracked_segment(self, seg_xyz, acc_at_seg, ref_path_length):
         seg = _f32(seg_xyz).reshape(-1, 3)
-        x, y, z = _f32(seg[:, 0]), _f32(seg[:, 1]), _f32(seg[:, 2])
-        acc = _f32(acc_at_seg)
+        self.set_tracked_segment_columns(seg[:, 0], seg[:, 1], seg[:, 2], acc_at_seg, ref_path_length)
+
+    def set_tracked_segment_columns(self, x, y, z, acc_at_seg, ref_path_length):
+        """The same from separate x / y / z arrays (what the C ABI takes: contiguous float32 arrays are passed
+        where they lie, without the column copies of set_tracked_segment)."""
+        x, y, z, acc = _f32(x), _f32(y), _f32(z), _f32(acc_at_seg)
         assert len(acc) == len(x)
         _check(lib().kc_dwa_set_tracked_segment(self.h, _pf(x), _pf(y), _pf(z), _pf(acc), len(x),
                                                 float(np.float32(ref_path_length))))
