@@ -33,6 +33,7 @@
 #include "kc_sensor_kernels.h"
 #include "kc_segment_kernels.h"
 #include "kc_shard.h"
+#include "kc_tilt_dev.h"
 
 // ===========================================================================
 // host context
@@ -276,6 +277,10 @@ struct kc_dwa {
   long long xseq = 0;
   int64_t last_lat = -1;       // id in `lat` of the last winner when it lives on this context, else -1
 
+  // non-planar sensor mount with LaserScan input: the octree frame is tilted (kc_tilt_dev.h)
+  bool tilted = false;
+  int tilt_kz = 0;             // the scan's voxel layer in the octree frame
+
   // drop_samples_ == false (trajectory_sampler.cpp:157-168; option "drop_samples" = 0)
   bool drop_samples = true;
   size_t num_ctrl_points = 0;  // numCtrlPoints_ = control_horizon / time_step (:88; option "num_ctrl_points")
@@ -348,6 +353,12 @@ inline void add_voxel(kc_dwa *c, float px, float py, float pz) {
         std::fabs(fz) < 32768.0))
     return;  // outside the 16-level octree: octomap drops the point
   const int32_t kz = static_cast<int32_t>(fz);
+  if (c->tilted) {  // tilted octree frame: no z interval to gate with, the exact 3-D test decides
+    c->tilt_kz = kz;
+    c->vox_kx.push_back(static_cast<int32_t>(fx));
+    c->vox_ky.push_back(static_cast<int32_t>(fy));
+    return;
+  }
   const double zlo = static_cast<double>(kz) * c->res;
   const double zhi = static_cast<double>(kz + 1) * c->res;
   const double zc = -static_cast<double>(c->frame.t[2]);
@@ -2569,9 +2580,9 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   // CollisionChecker::updateState + updateSensorData<LaserScan>
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->frame = body * c->sensor_tf_body;
-  if (!c->frame.planar())
-    KC_FAIL(KC_ERR_UNSUPPORTED,
-            "sensor rotation must be about the z axis (planar octree frame)");
+  // a mount that is not a rotation about z tilts the octree against the upright robot shape: exact
+  // 3-D tests on the split roll-out path (kc_tilt_dev.h), host-built voxel columns, no dilated masks
+  c->tilted = !c->frame.planar();
   const float hz = static_cast<float>(
       -static_cast<double>(c->sensor_tf_body.t[2]) / 2.0);
   // CostEvaluator::setPointScan(LaserScan): sensor_tf_body * body_tf_world
@@ -2598,10 +2609,16 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;  // cost_evaluator.h:179
   bool done = false;
-  KC_TRY(sensor_update_device(c, c->scan_xyz.data(), n, &done));
+  if (!c->tilted) KC_TRY(sensor_update_device(c, c->scan_xyz.data(), n, &done));
   if (done) return KC_OK;
   build_host_lists(c, c->scan_xyz.data(), n);
   KC_TRY(upload_voxels(c));
+  if (c->tilted) {
+    c->have_dil = false;
+    c->dil_lazy = false;
+    if (!c->vox_kx.empty() && !c->have_gbits)
+      KC_FAIL(KC_ERR_UNSUPPORTED, "tilted sensor frame: the scan's voxel columns span more than 8192 cells");
+  }
   return upload_obstacles(c, n);
 }
 
@@ -2614,6 +2631,7 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   const auto dbg_t1 = std::chrono::steady_clock::now();
   // updateSensorData<std::vector<Path::Point>>(cloud, global_frame = true)
   c->frame = hm::Rigid3f::identity();
+  c->tilted = false;
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->obs_tf = c->sensor_tf_body * body;
   c->raw_is_scan = false;
@@ -2653,6 +2671,7 @@ int kc_dwa_set_grid_device(kc_dwa *c, const kc_state *st, const int32_t *dev_gri
   KC_TRY(use_device(c));
   KC_TRY(quiesce_for_update(c));
   c->frame = hm::Rigid3f::identity();
+  c->tilted = false;
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->obs_tf = c->sensor_tf_body * body;
   c->raw_is_scan = false;
@@ -3031,6 +3050,35 @@ size_t cycle_table_bytes(const CostArgs &ca) {
   return b + 4 * static_cast<size_t>(ca.P) * 4;
 }
 
+// parameters of the tilted-octree tests (kc_tilt_dev.h) from the frame captured by kc_dwa_set_scan
+int tilt_params(kc_dwa *c, TiltDev &t) {
+  if (!c->have_gbits) KC_FAIL(KC_ERR_STATE, "tilted sensor frame without a voxel bitmap");
+  std::memset(&t, 0, sizeof(t));
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) t.R[i][j] = c->frame.R[i][j];
+    t.t[i] = c->frame.t[i];
+  }
+  t.res = c->res;
+  t.inv = 1.0 / c->res;
+  t.h = c->res / 2.0;
+  t.kz = c->tilt_kz;
+  t.shape = c->prm.shape;
+  t.radius = c->radius;
+  t.hh = c->height / 2.0;
+  t.a = static_cast<double>(c->prm.dims[0]) / 2.0;
+  t.b = static_cast<double>(c->prm.dims[1]) / 2.0;
+  t.c = static_cast<double>(c->prm.dims[2]) / 2.0;
+  if (c->prm.shape == KC_SPHERE) t.rho = c->radius;
+  else if (c->prm.shape == KC_BOX) t.rho = std::sqrt(t.a * t.a + t.b * t.b + t.c * t.c);
+  else t.rho = std::sqrt(c->radius * c->radius + t.hh * t.hh);
+  t.gbits = c->d_gbits.p;
+  t.gkx0 = c->gkx0;
+  t.gky0 = c->gky0;
+  t.gH = c->gH;
+  t.gwpr = c->gwpr;
+  return KC_OK;
+}
+
 // kc_dwa_rollout, or -- want_cycle -- the whole cycle in one launch when the
 // cost tables fit beside the roll-out tile (c->cycle_launched tells)
 int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bool trig_ready = false) {
@@ -3214,7 +3262,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   } else if (c->dil_lazy && !a.c.enabled) {
     // nothing within reach this cycle: the masks are still owed to the next one
   }
-  const bool fused = sphere_ok && (!a.c.enabled || c->have_gbits) &&
+  const bool fused = sphere_ok && !c->tilted && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
   const size_t tab_off = (pos_bytes + bits_bytes + 15) & ~size_t(15);
   cycle = cycle && fused && tab_off + cycle_table_bytes(tail.c) + 2048 <= c->lds_limit;
@@ -3358,7 +3406,23 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
                        dim3(kRollBlock), a.stage ? tile_bytes : 0, s, a);
     KC_TRY(c->timing.stop(s));
     c->timing.mark("host:launch_rollout");
-    if (may_collide) {
+    if (may_collide && c->tilted) {
+      // tilted octree frame: every pose against the voxel columns within its reach, exact 3-D tests
+      TiltArgs ta{};
+      KC_TRY(tilt_params(c, ta.c));
+      ta.pos = c->d_pos.p;
+      ta.trig = c->d_trig.p;
+      ta.row = c->d_row.p;
+      ta.n = static_cast<int>(n);
+      ta.first = static_cast<int>(c->shard_first);
+      ta.P = static_cast<int>(P);
+      ta.A = static_cast<int>(A);
+      ta.flags = c->d_flags.p;
+      ta.first_hit = a.first_hit;
+      KC_TRY(c->timing.start("collision_tilted_kernel", s));
+      hipLaunchKernelGGL(collision_tilted_kernel, dim3(blocks_for(n * (P - 1), 256)), dim3(256), 0, s, ta);
+      KC_TRY(c->timing.stop(s));
+    } else if (may_collide) {
       a.c = geom;
       KC_TRY(window_bits_host(c, a.c));
       c->timing.mark("host:window_bits");
@@ -3423,6 +3487,30 @@ int kc_dwa_check_poses(kc_dwa *c, const double *x, const double *y,
   double reach = 0.0;
   for (size_t i = 1; i < n; ++i)
     reach = std::max(reach, std::hypot(x[i] - x[0], y[i] - y[0]));
+  if (c->tilted) {
+    if (!c->have_sensor || c->vox_kx.empty()) {
+      std::memset(hit_out, 0, n);
+      return KC_OK;
+    }
+    TiltDev td;
+    KC_TRY(tilt_params(c, td));
+    KC_TRY(c->h_trig.reserve(2 * n));
+    KC_TRY(c->d_trig.reserve(2 * n));
+    for (size_t i = 0; i < n; ++i) {
+      c->h_trig.p[i] = make_double2(x[i], y[i]);
+      c->h_trig.p[n + i] = make_double2(std::cos(yaw[i]), std::sin(yaw[i]));
+    }
+    KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, 2 * n * sizeof(double2), hipMemcpyHostToDevice, s));
+    KC_TRY(c->d_flags.reserve(n));
+    hipLaunchKernelGGL(pose_check_tilted_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, td, c->d_trig.p,
+                       c->d_trig.p + n, static_cast<int>(n), c->d_flags.p);
+    KC_HIP(hipGetLastError());
+    KC_HIP(hipMemcpyAsync(hit_out, c->d_flags.p, n, hipMemcpyDeviceToHost, s));
+    KC_HIP(hipStreamSynchronize(s));
+    c->rolled = false;
+    c->evaluated = false;
+    return KC_OK;
+  }
   CollDev cd;
   KC_TRY(build_window_at(c, x[0], y[0], reach * 1.0001 + 1e-9, cd));
   if (!cd.enabled) {

@@ -545,6 +545,11 @@ struct ko_coll {
   iso3f body_tf;        /* at the state last set */
   iso3f F;              /* sensor_tf_world_ captured at update time */
   double sx, sy, syaw;  /* state last set (double, for ko_coll_check) */
+  /* a LaserScan seen through a mount that is not a rotation about z: the octree frame F is tilted
+   * against the upright robot shape (collision_check.cpp:61-68 takes any quaternion); the scan's voxels
+   * are one layer kz of F, kept without a z gate and tested in 3-D (tilted_cube_hit) */
+  int tilted;
+  int32_t tilt_kz;
   /* hash set of occupied (kx,ky) columns that can touch the robot in z */
   cell_slot *tab;
   size_t tab_cap; /* power of two */
@@ -673,6 +678,11 @@ static void coll_add_point(ko_coll *c, float px, float py, float pz) {
   if (!(fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0))
     return; /* outside the 16-level octree: coordToKeyChecked fails */
   const int32_t kx = (int32_t)fx, ky = (int32_t)fy, kz = (int32_t)fz;
+  if (c->tilted) {
+    c->tilt_kz = kz;
+    coll_insert(c, kx, ky, 0.0);
+    return;
+  }
   /* z extent of the voxel in F and of the robot (centre z_w = 0) in F */
   const double zlo = (double)kz * c->res, zhi = (double)(kz + 1) * c->res;
   const double zc = -(double)c->F.t[2];
@@ -692,7 +702,7 @@ static void coll_add_point(ko_coll *c, float px, float py, float pz) {
 int ko_coll_update_scan(ko_coll *c, const double *ranges, const double *angles,
                         size_t n) {
   c->F = iso_mul(&c->body_tf, &c->sensor_tf_body);
-  if (!frame_is_planar(&c->F)) return -2;
+  c->tilted = !frame_is_planar(&c->F);
   coll_reserve(c, n);
   /* float height_in_sensor = -sensor_tf_body_.translation().z() / 2.0; */
   float height_in_sensor = (float)(-(double)c->sensor_tf_body.t[2] / 2.0);
@@ -709,22 +719,172 @@ int ko_coll_update_scan(ko_coll *c, const double *ranges, const double *angles,
 /* collision_check.h:119-131,134 */
 int ko_coll_update_points(ko_coll *c, const float *xyz, size_t n,
                           int global_frame) {
+  c->tilted = 0;
   if (global_frame) {
     memset(&c->F, 0, sizeof(iso3f));
     c->F.R[0][0] = c->F.R[1][1] = c->F.R[2][2] = 1.0f;
   } else {
     c->F = iso_mul(&c->body_tf, &c->sensor_tf_body);
   }
-  if (!frame_is_planar(&c->F)) return -2;
+  if (!frame_is_planar(&c->F)) return -2; /* (several voxel layers in a tilted frame: not restated) */
   coll_reserve(c, n);
   for (size_t i = 0; i < n; ++i)
     coll_add_point(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
   return 0;
 }
 
+/* ---- tilted octree frame: the shape (upright in the world, centre (x, y, 0)) against ONE voxel cube of F.
+ * Closed sets, f64, fixed operation order (kc_tilt_dev.h of the build repeats it).
+ *   sphere:   distance from the centre, taken into F, to the cube
+ *   box:      separating axes of two boxes (3 + 3 + 9)
+ *   cylinder: in the robot's frame it is {|z| <= hh} x disc(r): the cube is clipped to the slab and projected
+ *             onto xy -- the hull of the kept vertices and of the edge / plane crossings -- and that convex
+ *             polygon meets the disc when the origin lies strictly inside it or some chord of the point set
+ *             comes within r of the origin */
+static double seg_d2_origin(double ax, double ay, double bx, double by) {
+  const double dx = bx - ax, dy = by - ay;
+  const double l2 = dx * dx + dy * dy;
+  double t = 0.0;
+  if (l2 > 0.0) {
+    t = -(ax * dx + ay * dy) / l2;
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  }
+  const double qx = ax + t * dx, qy = ay + t * dy;
+  return qx * qx + qy * qy;
+}
+static int sat_separated(const double T[3], double A[3][3], const double e[3], double h, double l0, double l1,
+                         double l2) {
+  const double lhs = fabs(T[0] * l0 + T[1] * l1 + T[2] * l2);
+  double rhs = h * (fabs(l0) + fabs(l1) + fabs(l2));
+  for (int k = 0; k < 3; ++k) rhs = rhs + e[k] * fabs(A[k][0] * l0 + A[k][1] * l1 + A[k][2] * l2);
+  return lhs > rhs;
+}
+static int tilted_cube_hit(const ko_coll *c, const double m[3], const double cf[3], double x, double y,
+                           double cw, double sw) {
+  const double h = c->res / 2.0;
+  double R[3][3], t[3];
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) R[i][j] = (double)c->F.R[i][j];
+    t[i] = (double)c->F.t[i];
+  }
+  if (c->shape == KO_SPHERE) {
+    double d2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      double g = fabs(cf[i] - m[i]) - h;
+      g = g > 0.0 ? g : 0.0;
+      d2 = d2 + g * g;
+    }
+    return d2 <= c->radius * c->radius;
+  }
+  if (c->shape == KO_BOX) {
+    double A[3][3];
+    for (int i = 0; i < 3; ++i) {
+      A[0][i] = R[0][i] * cw + R[1][i] * sw;
+      A[1][i] = R[1][i] * cw - R[0][i] * sw;
+      A[2][i] = R[2][i];
+    }
+    const double e[3] = {(double)c->dims[0] / 2.0, (double)c->dims[1] / 2.0, (double)c->dims[2] / 2.0};
+    const double T[3] = {m[0] - cf[0], m[1] - cf[1], m[2] - cf[2]};
+    if (sat_separated(T, A, e, h, 1.0, 0.0, 0.0) || sat_separated(T, A, e, h, 0.0, 1.0, 0.0) ||
+        sat_separated(T, A, e, h, 0.0, 0.0, 1.0))
+      return 0;
+    for (int k = 0; k < 3; ++k)
+      if (sat_separated(T, A, e, h, A[k][0], A[k][1], A[k][2])) return 0;
+    for (int k = 0; k < 3; ++k) {
+      if (sat_separated(T, A, e, h, 0.0, -A[k][2], A[k][1])) return 0;
+      if (sat_separated(T, A, e, h, A[k][2], 0.0, -A[k][0])) return 0;
+      if (sat_separated(T, A, e, h, -A[k][1], A[k][0], 0.0)) return 0;
+    }
+    return 1;
+  }
+  /* cylinder */
+  double O[3], E[3][3];
+  for (int i = 0; i < 3; ++i) {
+    O[i] = (R[i][0] * m[0] + R[i][1] * m[1] + R[i][2] * m[2]) + t[i];
+    for (int k = 0; k < 3; ++k) E[k][i] = R[i][k] * h;
+  }
+  O[0] = O[0] - x;
+  O[1] = O[1] - y;
+  double V[8][3];
+  for (int s = 0; s < 8; ++s)
+    for (int i = 0; i < 3; ++i)
+      V[s][i] = O[i] + ((s & 1) ? E[0][i] : -E[0][i]) + ((s & 2) ? E[1][i] : -E[1][i]) +
+                ((s & 4) ? E[2][i] : -E[2][i]);
+  double px[32], py[32];
+  int np = 0;
+  const double hh = c->height / 2.0;
+  for (int s = 0; s < 8; ++s)
+    if (fabs(V[s][2]) <= hh) {
+      px[np] = V[s][0];
+      py[np] = V[s][1];
+      ++np;
+    }
+  for (int s = 0; s < 8; ++s)
+    for (int bit = 1; bit < 8; bit <<= 1) {
+      if (s & bit) continue;
+      const double *P = V[s], *Q = V[s | bit];
+      for (int side = 0; side < 2; ++side) {
+        const double zp = side ? -hh : hh;
+        const double da = P[2] - zp, db = Q[2] - zp;
+        if ((da < 0.0 && db > 0.0) || (da > 0.0 && db < 0.0)) {
+          const double tt = da / (da - db);
+          px[np] = P[0] + tt * (Q[0] - P[0]);
+          py[np] = P[1] + tt * (Q[1] - P[1]);
+          ++np;
+        }
+      }
+    }
+  if (np == 0) return 0;
+  int inside = 1;
+  for (int i = 0; i < np && inside; ++i) {
+    int found = 0;
+    for (int j = 0; j < np; ++j)
+      if (px[i] * py[j] - py[i] * px[j] < 0.0) {
+        found = 1;
+        break;
+      }
+    inside = found;
+  }
+  if (inside) return 1;
+  const double rr = c->radius * c->radius;
+  for (int i = 0; i < np; ++i)
+    for (int j = i; j < np; ++j)
+      if (seg_d2_origin(px[i], py[i], px[j], py[j]) <= rr) return 1;
+  return 0;
+}
+static int tilted_check_at(ko_coll *c, double x, double y, double yaw) {
+  const double res = c->res, inv = 1.0 / c->res;
+  const double d[3] = {x - (double)c->F.t[0], y - (double)c->F.t[1], 0.0 - (double)c->F.t[2]};
+  double cf[3];
+  for (int i = 0; i < 3; ++i)
+    cf[i] = (double)c->F.R[0][i] * d[0] + (double)c->F.R[1][i] * d[1] + (double)c->F.R[2][i] * d[2];
+  double rho;
+  if (c->shape == KO_SPHERE) rho = c->radius;
+  else if (c->shape == KO_BOX) {
+    const double a = (double)c->dims[0] / 2.0, b = (double)c->dims[1] / 2.0, cc = (double)c->dims[2] / 2.0;
+    rho = sqrt(a * a + b * b + cc * cc);
+  } else {
+    const double hh = c->height / 2.0;
+    rho = sqrt(c->radius * c->radius + hh * hh);
+  }
+  const double zlo = (double)c->tilt_kz * res, zhi = (double)(c->tilt_kz + 1) * res;
+  if (zlo - cf[2] > rho || cf[2] - zhi > rho) return 0;
+  const int32_t kx0 = (int32_t)floor((cf[0] - rho) * inv) - 1, kx1 = (int32_t)floor((cf[0] + rho) * inv) + 1;
+  const int32_t ky0 = (int32_t)floor((cf[1] - rho) * inv) - 1, ky1 = (int32_t)floor((cf[1] + rho) * inv) + 1;
+  const double cw = cos(yaw), sw = sin(yaw);
+  for (int32_t ky = ky0; ky <= ky1; ++ky)
+    for (int32_t kx = kx0; kx <= kx1; ++kx) {
+      if (!coll_find(c, kx, ky)) continue;
+      const double m[3] = {((double)kx + 0.5) * res, ((double)ky + 0.5) * res, ((double)c->tilt_kz + 0.5) * res};
+      if (tilted_cube_hit(c, m, cf, x, y, cw, sw)) return 1;
+    }
+  return 0;
+}
+
 /* shape-vs-occupied-columns test at world pose (x, y, yaw) */
 int ko_coll_check_at(ko_coll *c, double x, double y, double yaw) {
   if (c->n_cells == 0) return 0;
+  if (c->tilted) return tilted_check_at(c, x, y, yaw);
   const double res = c->res, inv = 1.0 / c->res;
   /* pose in F: p_F = R_F^T (p_w - t_F) */
   const double r00 = c->F.R[0][0], r01 = c->F.R[0][1];

@@ -431,28 +431,23 @@ def test_class_level_cycle_is_one_launch_and_shards_through_rccl():
     assert (n3, cycles3) == (n, cycles)
 
 
-def test_non_planar_sensor_mount_raises_at_the_class_level():
-    """The collision restatement keeps the octree upright: a laserscan sensor rotated out of
-    the plane is outside the parity domain.  It must surface as an exception of the controller call --
-    the C ABI's KC_ERR_UNSUPPORTED -- never as a silently different result; point-cloud input (octree in
-    the world frame, collision_check.h:119-131) works with any mount."""
+def test_non_planar_sensor_mount_at_the_class_level():
+    """A laserscan sensor rotated out of the plane (collision_check.cpp:61-68 accepts any quaternion): the
+    octree frame is tilted, the class-level cycle runs the exact 3-D tests of the split roll-out path and
+    follows the oracle's restatement step for step; point-cloud input (octree in the world frame,
+    collision_check.h:119-131) works with any mount as before."""
     half = 0.2                      # 0.4 rad about the y axis
     tilted = [0.0, math.sin(half), 0.0, math.cos(half)]
     cfg = DWAConfig(max_linear_samples=5, max_angular_samples=5, octree_resolution=0.1, prediction_horizon=10,
                     control_horizon=2, control_time_step=0.1, proximity_sensor_rotation_to_robot=np.array(tilted))
-    robot, gpu, _ = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.CYLINDER, [0.1, 0.4],
-                              LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0),
-                              AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0), cfg)
-    gpu.set_path(_P([(x, 0.0) for x in np.arange(0.0, 5.01, 0.5)]))
-    robot.state.x, robot.state.y, robot.state.yaw = 0.0, 0.0, 0.0
-    # kompass_core.control.DWA.loop_step logs the planner's exception and reports "no command" (the
-    # reference front-end does the same, control/dwa.py:316-322); the planner itself raises
-    assert gpu.loop_step(current_state=robot.state, laser_scan=LaserScanData()) is False
-    scan = LaserScanData()
-    with pytest.raises(Exception) as e:
-        gpu._planner.compute_velocity_commands(kompass_cpp.types.Velocity2D(0.0, 0.0, 0.0, 0.0),
-                                               kompass_cpp.types.LaserScan(list(scan.ranges), list(scan.angles)))
-    assert "planar" in str(e.value) or "rotation" in str(e.value)
+    robot, gpu, cpu = make_pair(RobotType.DIFFERENTIAL_DRIVE, RobotGeometry.Type.CYLINDER, [0.1, 0.4],
+                                LinearCtrlLimits(max_vel=1.0, max_acc=2.0, max_decel=2.0),
+                                AngularCtrlLimits(max_vel=2.0, max_acc=3.0, max_decel=3.0, max_steer=2.0), cfg)
+    pts = [(x, 0.0) for x in np.arange(0.0, 5.01, 0.5)]
+    ang = np.linspace(0.0, 2.0 * np.pi, 360, endpoint=False)
+    scan = LaserScanData(ranges=1.5 + 0.5 * np.cos(3 * ang), angles=ang, range_max=10.0)
+    end, n, cycles = lockstep(robot, gpu, cpu, pts, (0.0, 0.0, 0.0), scan=scan, max_controls=40)
+    assert cycles >= 10
     cloud = _round_obstacle(3.0, 0.35, 0.2)
     assert gpu.loop_step(current_state=robot.state, local_map=cloud) and gpu.has_result()
 
