@@ -173,6 +173,10 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "num_ctrl_points" (0) numCtrlPoints_ = control_horizon / time_step as size_t (:88: the config-object
  *                        constructor's definition; the explicit-argument constructor leaves it
  *                        uninitialised)
+ *   "obs_near"       (1) LaserScan input with finite ranges: consecutive beams are a polyline -- the
+ *                        obstacle term of long admissible lists goes through a near table of the scan
+ *                        (per cell of the reachable box: the beam chunks that can hold the nearest
+ *                        obstacle, a seed, a floor; obs_near_kernel) instead of the bucket ring search
  *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
  *   "early_launch"   (1) the roll-out kernel is queued before the host trig table exists
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host

@@ -130,7 +130,20 @@ struct DcArgs {
   float nx0, ny0, ninv;     // origin and 1 / cell edge (floats: the kernels index with float arithmetic,
                             // the slack for that is in the table)
   int nW, nH;
+  // Near table of the OBSTACLES of a laser scan (obs_near_kernel), or null.  Consecutive beams of a
+  // scan are a polyline: `ocs` consecutive obstacles form a chunk (at most 64 chunks) with a bounding
+  // box; per cell of a grid over the reachable box the table holds {mask lo, mask hi, seed, floor}:
+  // the chunks that can hold the obstacle nearest to ANY point of the cell, an obstacle nearest to the
+  // cell centre, and a lower bound of the distance of any point of the cell to the obstacle set.
+  const uint4 *onear;
+  float ox0, oy0, oinv;
+  int oW, oH;
+  const float *osx, *osy;   // [on] obstacle coordinates in SCAN order (what setPointScan computes)
+  const float *oaabb;       // [4][64] xmin | xmax | ymin | ymax of the chunks (empty chunks: +inf boxes)
+  int on, ocs, onch;
+  double ocap;              // max_obstacles_dist
 };
+
 
 #ifdef KC_PHASE_STAMPS
 #define KC_STAMP(slot)                                                     \
@@ -230,6 +243,16 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   const uint32_t r2 = __builtin_amdgcn_readlane(static_cast<int>(v), 32);
   const uint32_t r3 = __builtin_amdgcn_readlane(static_cast<int>(v), 48);
   return min(min(r0, r1), min(r2, r3));
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+  v |= dpp_u32<0xB1>(v);
+  v |= dpp_u32<0x4E>(v);
+  v |= dpp_u32<0x141>(v);
+  v |= dpp_u32<0x140>(v);
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 0)) |
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 16)) |
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 32)) |
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
 }
 // the same inside each aligned group of eight lanes (three DPP steps; every
 // lane of the group ends up with the group's minimum)
@@ -1152,7 +1175,59 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       }
     }
     if (st) KC_STAMP(11);
-    if (a.use_obs) {
+    if (a.use_obs && t.onear != nullptr) {
+      // Laser scan: the obstacles are a polyline in beam order, cut into <= 64 chunks with bounding boxes, and
+      // the near table of the scan names, per cell of the reachable box, the chunks that can hold the nearest
+      // obstacle of ANY point of the cell, an obstacle nearest to the cell centre (an attained upper bound) and
+      // a lower bound of the distance of the cell's points.  Only the minimum over the whole trajectory counts
+      // (trajectory.h:218-235): the seeds give a tight bound on it, lanes whose floor lies above that bound
+      // drop out, and the candidate chunks of the others are scanned one at a time by ALL lanes (a lane a
+      // trajectory point, a loop over the chunk's obstacles: every value formed is a true distance, so nobody
+      // needs masking and the minimum is the one of the full scan).
+      const float fx = (x - t.ox0) * t.oinv, fy = (y - t.oy0) * t.oinv;
+      const bool inside = fx >= 0.0f && fy >= 0.0f && fx < static_cast<float>(t.oW) && fy < static_cast<float>(t.oH);
+      uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);  // outside the table: every chunk, no seed
+      if (inside) e = t.onear[static_cast<int>(fy) * t.oW + static_cast<int>(fx)];
+      auto exact_dd = [&](int j) {
+        const double dx = static_cast<double>(t.osx[j] - x);
+        const double dy = static_cast<double>(t.osy[j] - y);
+        return dx * dx + dy * dy;
+      };
+      double best = DBL_MAX;
+      if (live && e.z != 0xFFFFFFFFu) best = exact_dd(static_cast<int>(e.z));
+      double shared = fmin(ubound2, wave_min_nonneg(best));
+      const double lbk = static_cast<double>(__uint_as_float(e.w));
+      uint32_t mlo = live ? e.x : 0u, mhi = live ? e.y : 0u;
+      bool cont = live && (mlo | mhi) != 0u && lbk < t.ocap && !(x != x) && !(y != y);
+      for (int half = 0; half < 2; ++half) {
+        // (re-evaluated per half: the bound only falls)
+        uint32_t U = wave_or_u32((cont && lbk * lbk < shared * (1.0 - 1e-6)) ? (half ? mhi : mlo) : 0u);
+        while (U) {
+          const int cb = __ffs(static_cast<int>(U)) - 1;
+          U &= U - 1u;
+          const int c = cb + 32 * half;
+          if (c >= t.onch) break;
+          // box of the chunk against this lane's point (float, 1e-4 of slack on the compared square)
+          const float bx0 = t.oaabb[c], bx1 = t.oaabb[64 + c], by0 = t.oaabb[128 + c], by1 = t.oaabb[192 + c];
+          const float gx = fmaxf(fmaxf(bx0 - x, x - bx1), 0.0f), gy = fmaxf(fmaxf(by0 - y, y - by1), 0.0f);
+          const double lb2 = static_cast<double>(gx * gx + gy * gy) * (1.0 - 1e-4);
+          const bool part = cont && (((half ? mhi : mlo) >> cb) & 1u) && lbk * lbk < shared * (1.0 - 1e-6) &&
+                            !(lb2 >= shared);
+          if (__ballot(part) == 0ull) continue;
+          const int j0 = c * t.ocs, j1 = min(j0 + t.ocs, t.on);
+          for (int jb = j0; jb < j1; jb += 4) {
+            double d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) d[u] = exact_dd(min(jb + u, j1 - 1));  // (a repeat of the last one changes nothing)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);    // (NaN distances never win)
+          }
+          shared = fmin(shared, wave_min_nonneg(best));
+        }
+      }
+      ubound2 = shared;  // (carried to the next tile of a long trajectory)
+      if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(shared)));
+    } else if (a.use_obs) {
       // query cell (clamped: a query outside the grid searches from the
       // border and the guarantee radius shrinks by its distance to the grid)
       const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;

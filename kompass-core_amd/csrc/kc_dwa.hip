@@ -32,6 +32,7 @@
 #include "kc_rollout_kernels.h"
 #include "kc_sensor_kernels.h"
 #include "kc_segment_kernels.h"
+#include "kc_onear_kernels.h"
 #include "kc_shard.h"
 #include "kc_tilt_dev.h"
 
@@ -276,6 +277,19 @@ struct kc_dwa {
   size_t x_rw = 0;
   long long xseq = 0;
   int64_t last_lat = -1;       // id in `lat` of the last winner when it lives on this context, else -1
+
+  // a laser scan as a polyline: obstacle coordinates in beam order + the boxes of its <= 64 chunks, and the
+  // near table of the obstacles over the reachable box (kc_onear_kernels.h; option "obs_near")
+  std::vector<float> h_oscan;            // x[n] | y[n] | boxes [4][64]
+  DevBuf<float> d_oscan;
+  bool oscan_valid = false;
+  size_t oscan_n = 0;
+  int oscan_cs = 0, oscan_nch = 0;
+  unsigned long long sensor_version = 0, onear_version = ~0ull;
+  DevBuf<uint4> d_onear;
+  float onear_x0 = 0.f, onear_y0 = 0.f, onear_g = 0.f;
+  bool onear_ok = false;                 // the table covers the running cycle
+  bool obs_near_opt = true;
 
   // non-planar sensor mount with LaserScan input: the octree frame is tilted (kc_tilt_dev.h)
   bool tilted = false;
@@ -1470,6 +1484,63 @@ int near_table_ahead(kc_dwa *c) {
   return KC_OK;
 }
 
+// The near table of the scan's obstacles over everything the cycle that starts at (x, y) can reach: kept while
+// the sensor data stays and the box lies inside the table, else built (one launch, stream-ordered in front of
+// the cost stage that reads it).
+int ensure_onear(kc_dwa *c, double x, double y) {
+  c->onear_ok = false;
+  if (!c->oscan_valid || c->near_side == 0 || !(c->w.obstacles_distance_weight > 0.0) || c->external) return KC_OK;
+  const double reach = cycle_reach(c);
+  if (!(reach > 0.0) || !std::isfinite(reach) || !std::isfinite(x) || !std::isfinite(y)) return KC_OK;
+  const double lo_x = x - reach, lo_y = y - reach, hi_x = x + reach, hi_y = y + reach;
+  const int N = c->near_side;
+  if (c->onear_version == c->sensor_version && c->onear_g > 0.f) {
+    const double t_lo_x = c->onear_x0, t_lo_y = c->onear_y0, side = static_cast<double>(c->onear_g) * N;
+    if (lo_x >= t_lo_x && lo_y >= t_lo_y && hi_x <= t_lo_x + side && hi_y <= t_lo_y + side) {
+      c->onear_ok = true;
+      return KC_OK;
+    }
+  }
+  const double ext = 2.0 * reach;
+  const double pad = 0.02 * ext + 1e-3;
+  c->onear_x0 = static_cast<float>(lo_x - pad);
+  c->onear_y0 = static_cast<float>(lo_y - pad);
+  const double side = std::max(hi_x + pad - c->onear_x0, hi_y + pad - c->onear_y0) * 1.0001;
+  c->onear_g = static_cast<float>(side / N);
+  if (!(c->onear_g > 0.f) || !std::isfinite(c->onear_g) || !std::isfinite(1.0f / c->onear_g)) return KC_OK;
+  KC_TRY(c->d_onear.reserve(static_cast<size_t>(N) * N));
+  ObsNearArgs oa{};
+  const size_t n = c->oscan_n;
+  oa.osx = c->d_oscan.p;
+  oa.osy = c->d_oscan.p + n;
+  oa.aabb = c->d_oscan.p + 2 * n;
+  oa.n = static_cast<int>(n);
+  oa.cs = c->oscan_cs;
+  oa.nch = c->oscan_nch;
+  oa.x0 = c->onear_x0;
+  oa.y0 = c->onear_y0;
+  oa.g = c->onear_g;
+  // the cost kernels take a point's cell from (x - x0) * (1 / g) in float
+  oa.slack = static_cast<float>(1e-5 * side + 1e-6 * (std::fabs(c->onear_x0) + std::fabs(c->onear_y0) + side));
+  oa.cap = c->max_obs_dist;
+  oa.W = oa.H = N;
+  oa.out = c->d_onear.p;
+  KC_TRY(c->timing.start("obs_near_kernel", c->stream));
+  {
+    const dim3 grid((N * N + kObsNearBlock / kObsNearLanes - 1) / (kObsNearBlock / kObsNearLanes));
+    const size_t lds = 2 * n * sizeof(float);
+    if (lds <= kObsNearLdsMax && lds <= c->lds_limit_hw)
+      hipLaunchKernelGGL(obs_near_kernel<true>, grid, dim3(kObsNearBlock), lds, c->stream, oa);
+    else
+      hipLaunchKernelGGL(obs_near_kernel<false>, grid, dim3(kObsNearBlock), 0, c->stream, oa);
+  }
+  KC_TRY(c->timing.stop(c->stream));
+  c->onear_version = c->sensor_version;
+  c->onear_ok = true;
+  c->update_busy = true;  // a queued kernel reads the scan tables: the next sensor update waits for it
+  return KC_OK;
+}
+
 // argument blocks of the cost stage (stand-alone kernels and the cycle tail)
 int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt) {
   const size_t P = c->P;
@@ -1517,6 +1588,21 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
     dt.ny0 = c->near_y0;
     dt.ninv = 1.0f / c->near_g;
     dt.nW = dt.nH = c->near_side;
+  }
+  if (c->onear_ok && ca.use_obs && c->oscan_valid) {
+    const size_t on = c->oscan_n;
+    dt.onear = c->d_onear.p;
+    dt.ox0 = c->onear_x0;
+    dt.oy0 = c->onear_y0;
+    dt.oinv = 1.0f / c->onear_g;
+    dt.oW = dt.oH = c->near_side;
+    dt.osx = c->d_oscan.p;
+    dt.osy = c->d_oscan.p + on;
+    dt.oaabb = c->d_oscan.p + 2 * on;
+    dt.on = static_cast<int>(on);
+    dt.ocs = c->oscan_cs;
+    dt.onch = c->oscan_nch;
+    dt.ocap = static_cast<double>(c->max_obs_dist);
   }
   ca.seg_len = c->seg_len;
   ca.ref_len = c->ref_len;
@@ -1572,7 +1658,11 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   // the wavefront-per-sample search of a roll-out's samples goes through the near table
   c->near_ok = false;
   c->near_wanted = !use_block && !c->external;
-  if (c->near_wanted) KC_TRY(ensure_near_table(c, c->last_start.x, c->last_start.y));
+  c->onear_ok = false;
+  if (c->near_wanted) {
+    KC_TRY(ensure_near_table(c, c->last_start.x, c->last_start.y));
+    KC_TRY(ensure_onear(c, c->last_start.x, c->last_start.y));
+  }
   // caller-provided samples: the box found when they were uploaded
   if (!use_block && c->external && c->ext_box_valid)
     KC_TRY(ensure_near_table_box(c, c->ext_box[0], c->ext_box[1], c->ext_box[2], c->ext_box[3], 0.0));
@@ -2295,6 +2385,8 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_cprow.release();
   c->h_wrow.release();
   c->h_slots.release();
+  c->d_oscan.release();
+  c->d_onear.release();
   c->d_freeze.release();
   c->d_first_hit.release();
   c->d_frz.release();
@@ -2366,6 +2458,9 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   } else if (n == "num_ctrl_points") {
     if (!(v >= 0.0 && v <= 1e9)) KC_FAIL(KC_ERR_RANGE, "num_ctrl_points: a count >= 0");
     c->num_ctrl_points = static_cast<size_t>(v);
+  } else if (n == "obs_near") {
+    c->obs_near_opt = on;
+    if (!on) c->oscan_valid = c->onear_ok = false;
   } else if (n == "lazy_dilate") c->lazy_dilate = on;
   else if (n == "early_launch") c->early_launch = on;
   else if (n == "sensor_on_host") c->device_sensor = !on;
@@ -2392,6 +2487,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "velocity_group") *v = c->velocity_group;
   else if (n == "velocity_beside") *v = c->velocity_beside;
   else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
+  else if (n == "obs_near") *v = c->obs_near_opt;
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "sensor_on_host") *v = !c->device_sensor;
   else if (n == "trig_copy") *v = !c->trig_direct;
@@ -2608,6 +2704,54 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   }
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;  // cost_evaluator.h:179
+  ++c->sensor_version;
+  c->oscan_valid = false;
+  c->onear_ok = false;
+  if (c->obs_near_opt && n >= 64 && n <= 65536) {
+    // the obstacles in beam order (CostEvaluator::setPointScan, cost_evaluator.h:174-193: sensor_tf_body *
+    // body_tf_world applied to (r cos a, r sin a, 0)) and the boxes of their chunks, for the near table of the
+    // scan; a non-finite range leaves the scan to the bucket search
+    bool finite = true;
+    for (size_t i = 0; i < n && finite; ++i) finite = std::isfinite(ranges[i]);
+    if (finite) {
+      const int cs = static_cast<int>((n + 63) / 64);
+      const int nch = static_cast<int>((n + cs - 1) / cs);
+      c->h_oscan.resize(2 * n + 256);
+      float *hx = c->h_oscan.data(), *hy = hx + n, *box = hy + n;
+      for (size_t i = 0; i < n; ++i) {
+        float o[3];
+        c->obs_tf.apply(c->scan_xyz[3 * i], c->scan_xyz[3 * i + 1], 0.0f, o);
+        hx[i] = o[0];
+        hy[i] = o[1];
+      }
+      const float inf = std::numeric_limits<float>::infinity();
+      for (int k = 0; k < 64; ++k) {
+        float x0 = inf, x1 = -inf, y0 = inf, y1 = -inf;
+        if (k < nch)
+          for (size_t j = static_cast<size_t>(k) * cs; j < std::min(n, static_cast<size_t>(k + 1) * cs); ++j) {
+            x0 = std::min(x0, hx[j]);
+            x1 = std::max(x1, hx[j]);
+            y0 = std::min(y0, hy[j]);
+            y1 = std::max(y1, hy[j]);
+          }
+        box[k] = x0;
+        box[64 + k] = x1;
+        box[128 + k] = y0;
+        box[192 + k] = y1;
+      }
+      KC_TRY(c->d_oscan.reserve(2 * n + 256));
+      KC_TRY(upload_table(c, c->d_oscan.p, hx, (2 * n + 256) * sizeof(float)));
+      if (!c->trig_direct) {
+        KC_HIP(hipStreamSynchronize(c->stream));  // (pageable source)
+      } else {
+        bar_flush(c);
+      }
+      c->oscan_valid = true;
+      c->oscan_n = n;
+      c->oscan_cs = cs;
+      c->oscan_nch = nch;
+    }
+  }
   bool done = false;
   if (!c->tilted) KC_TRY(sensor_update_device(c, c->scan_xyz.data(), n, &done));
   if (done) return KC_OK;
@@ -2632,6 +2776,9 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   // updateSensorData<std::vector<Path::Point>>(cloud, global_frame = true)
   c->frame = hm::Rigid3f::identity();
   c->tilted = false;
+  ++c->sensor_version;
+  c->oscan_valid = false;
+  c->onear_ok = false;
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->obs_tf = c->sensor_tf_body * body;
   c->raw_is_scan = false;
@@ -2672,6 +2819,9 @@ int kc_dwa_set_grid_device(kc_dwa *c, const kc_state *st, const int32_t *dev_gri
   KC_TRY(quiesce_for_update(c));
   c->frame = hm::Rigid3f::identity();
   c->tilted = false;
+  ++c->sensor_version;
+  c->oscan_valid = false;
+  c->onear_ok = false;
   const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
   c->obs_tf = c->sensor_tf_body * body;
   c->raw_is_scan = false;
@@ -3226,7 +3376,11 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     // near table when the last cycle had that many
     c->near_ok = false;
     c->near_wanted = c->last_nadm < 0 || c->last_nadm > 2ll * cyc_G;
-    if (c->near_wanted) KC_TRY(ensure_near_table(c, start->x, start->y));
+    c->onear_ok = false;
+    if (c->near_wanted) {
+      KC_TRY(ensure_near_table(c, start->x, start->y));
+      KC_TRY(ensure_onear(c, start->x, start->y));
+    }
     KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
   }
   // fused path: trig rows + poses (64 x P double2) and the window bits in LDS
