@@ -323,6 +323,7 @@ def controller_bench(args, rank, world, local_rank):
                 if scene == args.scene:
                     continue
                 out[key] = scene_leg(ctx, cfg, scene, inp, vx, vy, om, P, S, pose, args)
+            out["laserscan_room"] = laserscan_leg(ctx, cfg, inp, vx, vy, om, P, S, pose, args)
             ctx.set_points(inp["state"], inp["points"], inp["max_range"])
             out["extras"] = extras(ctx, inp, P, pose)
             # one REFERENCE cycle per step: fresh sensor data, window + lattice, tracked segment, cycle
@@ -588,6 +589,82 @@ def cpu_baseline_fresh(syn, inp, ctr, cur_vel, max_lin, max_ang, state, r, args,
         "gpu_matches_cpu_winner": parity,
         "cpu_winner": {"raw_index": int(oi), "cost": float(oc), "n_admissible": int(na)},
     }
+
+
+def laserscan_leg(ctx, cfg, inp, vx, vy, om, P, S, pose, args, beams=1440):
+    """The same lattice with LaserScan input (the reference test's own input form, tests/test_controllers.py:213):
+    a room-like scan of `beams` beams -- walls metres from every trajectory point, the octree in the sensor frame
+    (collision_check.h:99-117), the obstacle list from CostEvaluator::setPointScan(LaserScan)."""
+    import synthetic as syn
+
+    base = syn.CONFIGS[cfg]
+    ang = np.linspace(-np.pi, np.pi, beams, endpoint=False)
+    rng = 4.0 + 1.5 * np.cos(5 * ang)
+    ctx.set_scan(inp["state"], rng, ang, inp["max_range"])
+    n = len(vx)
+    for i in range(args.warmup):
+        r = ctx.cycle(pose(i), P)
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ts = time.perf_counter()
+        r = ctx.cycle(pose(i), P)
+        lat.append(time.perf_counter() - ts)
+    elapsed = time.perf_counter() - t0
+    ctx.timing_enable(True)
+    kernel_ms = {}
+    for i in range(min(args.steps, 500)):
+        ctx.cycle(pose(i), P)
+        for name, ms in ctx.timings():
+            if not name.startswith("host:"):
+                kernel_ms.setdefault(name, []).append(ms)
+    ctx.timing_enable(False)
+    fresh = []
+    for i in range(200):  # new scan every cycle (the table of the scan is rebuilt every time)
+        ts = time.perf_counter()
+        ctx.set_scan(inp["state"], rng + 0.01 * (i % 9), ang, inp["max_range"])
+        ctx.cycle(pose(i), P)
+        fresh.append(time.perf_counter() - ts)
+    ctx.set_scan(inp["state"], rng, ang, inp["max_range"])
+    r = ctx.cycle(pose(args.steps - 1), P)
+    leg = {
+        "metric": "trajectory-steps/s", "value": n * P * args.steps / elapsed, "unit": "trajectory-steps/s",
+        "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
+        "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
+        "set_scan_and_cycle_ms": float(np.median(fresh) * 1e3),
+        "config": {"workload": f"{cfg} lattice ({n} x {P}) with LaserScan input: {beams} beams, room-like ranges 2.5-5.5 m, "
+                               f"{int(r.n_admissible)} of {n} samples admissible", "beams": beams,
+                   "n_admissible": int(r.n_admissible)},
+        "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
+        "roofline": roofline_of(kernel_ms, n, P, base["map_side"], S, beams, "scan", cfg),
+    }
+    if not args.no_cpu:
+        from oracle import ko
+
+        rb = inp["robot"]
+        state = pose(args.steps - 1)
+        coll = ko.Collision(rb["shape"], rb["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"])
+        coll.update_state(*inp["state"][:3])
+        coll.update_scan(rng, ang)
+        ox, oy = ko.obstacles_from_scan((0, 0, 0), (0, 0, 0, 1), inp["state"], rng, ang)
+        ci = ko.CostInputs(inp["seg_xyz"], 0, inp["acc_at_seg"], inp["ref_len"], np.stack([ox, oy], 1),
+                           np.float32(inp["max_range"]) / np.float32(3.0), inp["acc_limits"], ko.make_weights(*inp["weights"]))
+        ncores = usable_cpus()
+        t0 = time.perf_counter()
+        oi, oc, na = ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx, vy, om, threads=ncores)
+        t_mt = time.perf_counter() - t0
+        stride = max(1, int(np.ceil(t_mt * ncores / 4.0)))
+        t0 = time.perf_counter()
+        ko.baseline_cycle(coll, ci, state, inp["dt"], P, vx[::stride], vy[::stride], om[::stride], threads=1)
+        t_1 = time.perf_counter() - t0
+        leg["cpu_baseline"] = {
+            "value": len(vx[::stride]) * P / t_1, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
+            "sample": f"1 cycle over every {stride}th of the {n} samples on 1 thread: {t_1 * 1e3:.0f} ms",
+            "all_cores": {"value": n * P / t_mt, "cores": ncores, "seconds": t_mt, "sample": "1 full cycle"},
+            "gpu_matches_cpu_winner": bool((oi >= 0) == bool(r.found) and (not r.found or (
+                oi == int(r.raw_index) and np.float32(oc) == np.float32(r.cost)))),
+            "cpu_winner": {"raw_index": int(oi), "cost": float(oc), "n_admissible": int(na)}}
+    return leg
 
 
 def extras(ctx, inp, P, pose):

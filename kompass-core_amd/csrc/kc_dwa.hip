@@ -290,6 +290,7 @@ struct kc_dwa {
   float onear_x0 = 0.f, onear_y0 = 0.f, onear_g = 0.f;
   bool onear_ok = false;                 // the table covers the running cycle
   bool obs_near_opt = true;
+  int onear_side = 128;                  // cells per side of that table (option "obs_near": 0 off, 16..512)
 
   // non-planar sensor mount with LaserScan input: the octree frame is tilted (kc_tilt_dev.h)
   bool tilted = false;
@@ -1489,11 +1490,11 @@ int near_table_ahead(kc_dwa *c) {
 // the cost stage that reads it).
 int ensure_onear(kc_dwa *c, double x, double y) {
   c->onear_ok = false;
-  if (!c->oscan_valid || c->near_side == 0 || !(c->w.obstacles_distance_weight > 0.0) || c->external) return KC_OK;
+  if (!c->oscan_valid || !(c->w.obstacles_distance_weight > 0.0) || c->external) return KC_OK;
   const double reach = cycle_reach(c);
   if (!(reach > 0.0) || !std::isfinite(reach) || !std::isfinite(x) || !std::isfinite(y)) return KC_OK;
   const double lo_x = x - reach, lo_y = y - reach, hi_x = x + reach, hi_y = y + reach;
-  const int N = c->near_side;
+  const int N = c->onear_side;
   if (c->onear_version == c->sensor_version && c->onear_g > 0.f) {
     const double t_lo_x = c->onear_x0, t_lo_y = c->onear_y0, side = static_cast<double>(c->onear_g) * N;
     if (lo_x >= t_lo_x && lo_y >= t_lo_y && hi_x <= t_lo_x + side && hi_y <= t_lo_y + side) {
@@ -1595,7 +1596,7 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
     dt.ox0 = c->onear_x0;
     dt.oy0 = c->onear_y0;
     dt.oinv = 1.0f / c->onear_g;
-    dt.oW = dt.oH = c->near_side;
+    dt.oW = dt.oH = c->onear_side;
     dt.osx = c->d_oscan.p;
     dt.osy = c->d_oscan.p + on;
     dt.oaabb = c->d_oscan.p + 2 * on;
@@ -2459,8 +2460,12 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     if (!(v >= 0.0 && v <= 1e9)) KC_FAIL(KC_ERR_RANGE, "num_ctrl_points: a count >= 0");
     c->num_ctrl_points = static_cast<size_t>(v);
   } else if (n == "obs_near") {
+    if (v != 0.0 && v != 1.0 && !(v >= 16.0 && v <= 512.0)) KC_FAIL(KC_ERR_RANGE, "obs_near: 0 (off), 1 (on) or 16..512 cells per side");
     c->obs_near_opt = on;
-    if (!on) c->oscan_valid = c->onear_ok = false;
+    if (v >= 16.0) c->onear_side = static_cast<int>(v);
+    c->onear_version = ~0ull;
+    c->onear_ok = false;
+    if (!on) c->oscan_valid = false;
   } else if (n == "lazy_dilate") c->lazy_dilate = on;
   else if (n == "early_launch") c->early_launch = on;
   else if (n == "sensor_on_host") c->device_sensor = !on;
@@ -2487,7 +2492,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "velocity_group") *v = c->velocity_group;
   else if (n == "velocity_beside") *v = c->velocity_beside;
   else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
-  else if (n == "obs_near") *v = c->obs_near_opt;
+  else if (n == "obs_near") *v = c->obs_near_opt ? c->onear_side : 0;
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "sensor_on_host") *v = !c->device_sensor;
   else if (n == "trig_copy") *v = !c->trig_direct;
