@@ -177,6 +177,9 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        obstacle term of long admissible lists goes through a near table of the scan
  *                        (per cell of the reachable box: the beam chunks that can hold the nearest
  *                        obstacle, a seed, a floor; obs_near_kernel) instead of the bucket ring search
+ *                        From the second cycle on kc_dwa_set_scan builds the table for the pose it
+ *                        is given inside the launch of the sensor tables; a cycle that starts
+ *                        elsewhere (or reaches further) builds its own
  *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
  *   "early_launch"   (1) the roll-out kernel is queued before the host trig table exists
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host
@@ -184,7 +187,8 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "force_split"    (0) roll-out, collision and compaction as separate kernels
  * kc_dwa_get_option also reads "last_cycle_single_launch", "last_cycle_samples",
  * "host_threads", "trig_rows" (rows of the host's cos / sin table: distinct omegas of
- * this context's share) and "shard_samples".
+ * this context's share), "shard_samples", and the counters "obs_near_rides" /
+ * "obs_near_builds" (near tables built inside a sensor launch / by a launch of their own).
  * Waits for the context's stream.  Process-wide defaults may be preset with the
  * environment variables listed in DESIGN.md (test hooks). */
 int kc_dwa_set_option(kc_dwa *ctx, const char *name, double value);

@@ -289,6 +289,11 @@ struct kc_dwa {
   DevBuf<uint4> d_onear;
   float onear_x0 = 0.f, onear_y0 = 0.f, onear_g = 0.f;
   bool onear_ok = false;                 // the table covers the running cycle
+  bool obs_near_ahead = true;            // test hook KC_OBS_NEAR_AHEAD=0: the cycle builds the table itself
+  bool scan_lds_ok = false;              // sensor_build_scan_kernel may use the large LDS window
+  long long onear_rides = 0, onear_builds = 0;  // tables built in the sensor launch / by a launch of their own
+  bool onear_ahead = false;              // kc_dwa_set_scan planned a table (onear_args) for the sensor build launch
+  ObsNearArgs onear_args{};
   bool obs_near_opt = true;
   int onear_side = 128;                  // cells per side of that table (option "obs_near": 0 off, 16..512)
 
@@ -1098,8 +1103,18 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   a.dc_enable = c->d_dc_enable.p;
   if (!big) {
     const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
+    const size_t olds = 2 * static_cast<size_t>(c->onear_args.n) * sizeof(float);
+    const bool ride = c->onear_ahead && c->scan_lds_ok && olds <= kObsNearLdsMax;
     KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
-    hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
+    if (ride) {
+      const int cells = c->onear_args.W * c->onear_args.H, per = kSensorBlock / kObsNearLanes;
+      hipLaunchKernelGGL(sensor_build_scan_kernel<true>, dim3(1 + (cells + per - 1) / per), dim3(kSensorBlock),
+                         std::max(lds, olds), c->stream, a, c->onear_args);
+      c->onear_version = c->sensor_version;
+      ++c->onear_rides;
+    } else {
+      hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
+    }
     KC_TRY(c->timing.stop(c->stream));
   } else {
     // scratch: [cell records n | ox n | oy n | histogram rows]
@@ -1488,29 +1503,21 @@ int near_table_ahead(kc_dwa *c) {
 // The near table of the scan's obstacles over everything the cycle that starts at (x, y) can reach: kept while
 // the sensor data stays and the box lies inside the table, else built (one launch, stream-ordered in front of
 // the cost stage that reads it).
-int ensure_onear(kc_dwa *c, double x, double y) {
-  c->onear_ok = false;
-  if (!c->oscan_valid || !(c->w.obstacles_distance_weight > 0.0) || c->external) return KC_OK;
-  const double reach = cycle_reach(c);
-  if (!(reach > 0.0) || !std::isfinite(reach) || !std::isfinite(x) || !std::isfinite(y)) return KC_OK;
+// geometry + argument block of a table over the box (x, y) +- reach; *ok = false: no table (degenerate box)
+int onear_plan(kc_dwa *c, double x, double y, double reach, ObsNearArgs &oa, bool *ok) {
+  *ok = false;
   const double lo_x = x - reach, lo_y = y - reach, hi_x = x + reach, hi_y = y + reach;
   const int N = c->onear_side;
-  if (c->onear_version == c->sensor_version && c->onear_g > 0.f) {
-    const double t_lo_x = c->onear_x0, t_lo_y = c->onear_y0, side = static_cast<double>(c->onear_g) * N;
-    if (lo_x >= t_lo_x && lo_y >= t_lo_y && hi_x <= t_lo_x + side && hi_y <= t_lo_y + side) {
-      c->onear_ok = true;
-      return KC_OK;
-    }
-  }
   const double ext = 2.0 * reach;
   const double pad = 0.02 * ext + 1e-3;
   c->onear_x0 = static_cast<float>(lo_x - pad);
   c->onear_y0 = static_cast<float>(lo_y - pad);
   const double side = std::max(hi_x + pad - c->onear_x0, hi_y + pad - c->onear_y0) * 1.0001;
   c->onear_g = static_cast<float>(side / N);
+  c->onear_version = ~0ull;
   if (!(c->onear_g > 0.f) || !std::isfinite(c->onear_g) || !std::isfinite(1.0f / c->onear_g)) return KC_OK;
   KC_TRY(c->d_onear.reserve(static_cast<size_t>(N) * N));
-  ObsNearArgs oa{};
+  oa = ObsNearArgs{};
   const size_t n = c->oscan_n;
   oa.osx = c->d_oscan.p;
   oa.osy = c->d_oscan.p + n;
@@ -1526,16 +1533,57 @@ int ensure_onear(kc_dwa *c, double x, double y) {
   oa.cap = c->max_obs_dist;
   oa.W = oa.H = N;
   oa.out = c->d_onear.p;
+  *ok = true;
+  return KC_OK;
+}
+
+bool onear_wanted(const kc_dwa *c) {
+  return c->oscan_valid && c->w.obstacles_distance_weight > 0.0 && !c->external;
+}
+
+// kc_dwa_set_scan knows the pose the next cycle starts from: the table over what the LAST cycle's lattice and
+// horizon reach from there (+ 15 %: the velocity window moves with the robot's speed) rides in the launch of
+// the sensor tables (sensor_build_scan_kernel).  A cycle the guess does not cover builds its own.
+int onear_plan_ahead(kc_dwa *c, double x, double y) {
+  c->onear_ahead = false;
+  if (!onear_wanted(c) || c->P < 2) return KC_OK;
+  const double reach = cycle_reach(c) * 1.15;
+  if (!(reach > 0.0) || !std::isfinite(reach) || !std::isfinite(x) || !std::isfinite(y)) return KC_OK;
+  bool ok = false;
+  KC_TRY(onear_plan(c, x, y, reach, c->onear_args, &ok));
+  c->onear_ahead = ok;
+  return KC_OK;
+}
+
+int ensure_onear(kc_dwa *c, double x, double y) {
+  c->onear_ok = false;
+  if (!onear_wanted(c)) return KC_OK;
+  const double reach = cycle_reach(c);
+  if (!(reach > 0.0) || !std::isfinite(reach) || !std::isfinite(x) || !std::isfinite(y)) return KC_OK;
+  const double lo_x = x - reach, lo_y = y - reach, hi_x = x + reach, hi_y = y + reach;
+  const int N = c->onear_side;
+  if (c->onear_version == c->sensor_version && c->onear_g > 0.f) {
+    const double t_lo_x = c->onear_x0, t_lo_y = c->onear_y0, side = static_cast<double>(c->onear_g) * N;
+    if (lo_x >= t_lo_x && lo_y >= t_lo_y && hi_x <= t_lo_x + side && hi_y <= t_lo_y + side) {
+      c->onear_ok = true;
+      return KC_OK;
+    }
+  }
+  ObsNearArgs oa{};
+  bool ok = false;
+  KC_TRY(onear_plan(c, x, y, reach, oa, &ok));
+  if (!ok) return KC_OK;
   KC_TRY(c->timing.start("obs_near_kernel", c->stream));
   {
     const dim3 grid((N * N + kObsNearBlock / kObsNearLanes - 1) / (kObsNearBlock / kObsNearLanes));
-    const size_t lds = 2 * n * sizeof(float);
+    const size_t lds = 2 * static_cast<size_t>(oa.n) * sizeof(float);
     if (lds <= kObsNearLdsMax && lds <= c->lds_limit_hw)
       hipLaunchKernelGGL(obs_near_kernel<true>, grid, dim3(kObsNearBlock), lds, c->stream, oa);
     else
       hipLaunchKernelGGL(obs_near_kernel<false>, grid, dim3(kObsNearBlock), 0, c->stream, oa);
   }
   KC_TRY(c->timing.stop(c->stream));
+  ++c->onear_builds;
   c->onear_version = c->sensor_version;
   c->onear_ok = true;
   c->update_busy = true;  // a queued kernel reads the scan tables: the next sensor update waits for it
@@ -2198,6 +2246,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (const char *e = std::getenv("KC_SENSOR_BIG_MIN")) c->sensor_big_min = std::min<size_t>(16384, std::strtoul(e, nullptr, 10));
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
+    if (const char *e = std::getenv("KC_OBS_NEAR_AHEAD"))
+      if (e[0] == '0') c->obs_near_ahead = false;
     if (const char *e = std::getenv("KC_LAZY_DILATE"))
       if (e[0] == '0') c->lazy_dilate = false;          // test hook: dilate_kernel inside every sensor update
     if (const char *e = std::getenv("KC_COST_DC"))
@@ -2211,6 +2261,10 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_build_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
     if (!c->sensor_lds_ok) (void)hipGetLastError();
+    c->scan_lds_ok = c->sensor_lds_ok &&
+                     hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_build_scan_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
+    if (!c->scan_lds_ok) (void)hipGetLastError();
     if (const char *e = std::getenv("KC_COST_KERNEL"))  // tuning/test hook: "block" | "wave"
       c->cost_kernel_force = e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0;
     if (const char *e = std::getenv("KC_TEST_LATE_FLAG_MS")) c->test_late_flag_ms = std::atoi(e);
@@ -2493,6 +2547,8 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "velocity_beside") *v = c->velocity_beside;
   else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
   else if (n == "obs_near") *v = c->obs_near_opt ? c->onear_side : 0;
+  else if (n == "obs_near_rides") *v = static_cast<double>(c->onear_rides);    // read-only
+  else if (n == "obs_near_builds") *v = static_cast<double>(c->onear_builds);  // read-only
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "sensor_on_host") *v = !c->device_sensor;
   else if (n == "trig_copy") *v = !c->trig_direct;
@@ -2758,7 +2814,13 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
     }
   }
   bool done = false;
-  if (!c->tilted) KC_TRY(sensor_update_device(c, c->scan_xyz.data(), n, &done));
+  c->onear_ahead = false;
+  if (!c->tilted) {
+    if (c->obs_near_ahead) KC_TRY(onear_plan_ahead(c, st->x, st->y));
+    const int rc = sensor_update_device(c, c->scan_xyz.data(), n, &done);
+    c->onear_ahead = false;
+    KC_TRY(rc);
+  }
   if (done) return KC_OK;
   build_host_lists(c, c->scan_xyz.data(), n);
   KC_TRY(upload_voxels(c));

@@ -32,14 +32,13 @@ constexpr int kObsNearBlock = 512;  // 64 cells per workgroup
 constexpr int kObsNearLanes = 8;
 constexpr size_t kObsNearLdsMax = 48 * 1024;
 
-template <bool kLds>
-__global__ __launch_bounds__(kObsNearBlock) void obs_near_kernel(ObsNearArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
+template <bool kLds, int kBlock>
+__device__ __forceinline__ void obs_near_body(const ObsNearArgs &a, int block, unsigned char *smem) {
   __shared__ float l_box[256];
   float *lx = reinterpret_cast<float *>(smem), *ly = lx + a.n;
-  for (int j = threadIdx.x; j < 256; j += kObsNearBlock) l_box[j] = a.aabb[j];
+  for (int j = threadIdx.x; j < 256; j += kBlock) l_box[j] = a.aabb[j];
   if (kLds)
-    for (int j = threadIdx.x; j < a.n; j += kObsNearBlock) {
+    for (int j = threadIdx.x; j < a.n; j += kBlock) {
       lx[j] = a.osx[j];
       ly[j] = a.osy[j];
     }
@@ -47,7 +46,7 @@ __global__ __launch_bounds__(kObsNearBlock) void obs_near_kernel(ObsNearArgs a) 
   const float *ox = kLds ? lx : a.osx, *oy = kLds ? ly : a.osy;
   constexpr int kL = kObsNearLanes, kPer = 64 / kL;
   const int sub = threadIdx.x & (kL - 1);
-  const int cell = blockIdx.x * (kObsNearBlock / kL) + threadIdx.x / kL;
+  const int cell = block * (kBlock / kL) + threadIdx.x / kL;
   const int ncell = a.W * a.H;
   const int cc = min(cell, ncell - 1);  // whole groups stay in step (DPP reductions)
   const int ix = cc % a.W, iy = cc / a.W;
@@ -132,6 +131,22 @@ __global__ __launch_bounds__(kObsNearBlock) void obs_near_kernel(ObsNearArgs a) 
     }
     a.out[cell] = make_uint4(lo, hi, seed, __float_as_uint(fl));
   }
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kObsNearBlock) void obs_near_kernel(ObsNearArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  obs_near_body<kLds, kObsNearBlock>(a, static_cast<int>(blockIdx.x), smem);
+}
+
+// A scan update that knows where the next cycle starts builds the table in the launch of the sensor tables:
+// workgroup 0 is sensor_build_kernel, the others take kSensorBlock / 8 cells each (nothing of theirs depends
+// on workgroup 0: the obstacles in beam order come from the host).  The cycle then finds the table in place.
+template <bool kLds>
+__global__ __launch_bounds__(kSensorBlock) void sensor_build_scan_kernel(SensorArgs a, ObsNearArgs o) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  if (blockIdx.x == 0) sensor_build_body(a, smem);
+  else obs_near_body<kLds, kSensorBlock>(o, static_cast<int>(blockIdx.x) - 1, smem);
 }
 
 }  // namespace kc

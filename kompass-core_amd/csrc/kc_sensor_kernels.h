@@ -47,8 +47,7 @@ __device__ __forceinline__ bool sensor_obstacle(const SensorArgs &a, float x, fl
   return true;
 }
 
-__global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void sensor_build_body(const SensorArgs &a, unsigned char *smem) {
   const int nw = a.gH * a.gwpr, ncell = a.W * a.H;
   uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);   // [nw]
   int *lstart = reinterpret_cast<int *>(lbits + nw);      // [ncell + 1]: counts, then starts
@@ -198,6 +197,11 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a
   }
   // ---- 5: the bitmap --------------------------------------------------------------
   for (int i = tid; i < nw; i += kSensorBlock) a.gbits[i] = lbits[i];
+}
+
+__global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  sensor_build_body(a, smem);
 }
 
 // ---------------------------------------------------------------------------

@@ -95,3 +95,34 @@ def test_the_table_follows_sensor_updates_and_poses():
         o2 = oracle_cycle(cur2, scan=(r, ang))
         assert_cycle_equal(o2, hip_cycle(kh, cur2, scan=(r, ang), ctx=ctx))
     ctx.close()
+
+
+def test_set_scan_builds_the_table_for_the_next_cycle():
+    """From the second cycle on the table rides in the launch of the sensor tables (sensor_build_scan_kernel,
+    counter "obs_near_rides"); a cycle whose pose is not the one set_scan saw builds its own
+    ("obs_near_builds").  Both give the oracle's costs."""
+    inp = syn.make_controller_inputs("cfg2", seed=4, scale=0.2, scene="open")
+    ctx = hip_context(kh, inp)
+    ctx.set_option("fused_cycle", 0)
+    ctx.set_option("cost_kernel", 2)
+    rng = np.random.default_rng(21)
+    rides0 = builds0 = 0
+    for step in range(6):
+        ang, r = scan_shape(["room", "box", "corridor"][step % 3], [1440, 720, 361][step % 3], rng)
+        st = (0.2 * step, 0.1 * step, 0.2 * step, 0.0)
+        cur = dict(inp, state=st, seg_xyz=inp["seg_xyz"] + np.float32([st[0], st[1], 0.0]), P=(2 * inp["P"]) // 3)
+        o = oracle_cycle(cur, scan=(r, ang))
+        assert_cycle_equal(o, hip_cycle(kh, cur, scan=(r, ang), ctx=ctx))
+        rides, builds = int(ctx.get_option("obs_near_rides")), int(ctx.get_option("obs_near_builds"))
+        if step == 0:
+            assert (rides, builds) == (0, 1)      # nothing known about the cycle yet
+        else:
+            assert (rides - rides0, builds - builds0) == (1, 0)
+        rides0, builds0 = rides, builds
+    # a longer horizon than the one the table was planned for: the cycle reaches beyond it and builds its own
+    cur = dict(cur, P=inp["P"])
+    o = oracle_cycle(cur, scan=(r, ang))
+    assert_cycle_equal(o, hip_cycle(kh, cur, scan=(r, ang), ctx=ctx))
+    assert int(ctx.get_option("obs_near_rides")) == rides0 + 1
+    assert int(ctx.get_option("obs_near_builds")) == builds0 + 1
+    ctx.close()
