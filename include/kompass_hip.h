@@ -180,6 +180,11 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        From the second cycle on kc_dwa_set_scan builds the table for the pose it
  *                        is given inside the launch of the sensor tables; a cycle that starts
  *                        elsewhere (or reaches further) builds its own
+ *   "obs_union"      (96) obstacle term of long admissible lists, point-cloud / costmap input: where a
+ *                        trajectory runs through occupied bucket cells, the obstacles of the ONE
+ *                        rectangle of cells that can hold the trajectory's nearest obstacle are
+ *                        broadcast to all of its points (obstacle_union_scan) instead of a ring walk
+ *                        per point; rectangles with more obstacles than this fall back.  0: off
  *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
  *   "early_launch"   (1) the roll-out kernel is queued before the host trig table exists
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host

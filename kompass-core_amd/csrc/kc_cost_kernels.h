@@ -142,6 +142,7 @@ struct DcArgs {
   const float *oaabb;       // [4][64] xmin | xmax | ymin | ymax of the chunks (empty chunks: +inf boxes)
   int on, ocs, onch;
   double ocap;              // max_obstacles_dist
+  int ounion;               // > 0: obstacle_union_scan for rectangles of at most this many obstacles
 };
 
 
@@ -992,6 +993,160 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
 }
 
 
+// ---- obstacle term of a sample near clutter: one scan of the union block ------------------
+// The private ring walks below run in lock-step: every lane pays for the longest walk of the
+// wavefront, and each walk re-reads cell runs that its neighbours read too.  Only the minimum
+// over the WHOLE trajectory counts (trajectory.h:218-235), so where the trajectory runs through
+// occupied cells the wavefront does this instead:
+//   (1) every point takes a seed, the first and last obstacle of the block of (2 s + 1)^2
+//       bucket cells around its own (s = the smallest skip value of the trajectory: at least
+//       one such block is non-empty): an ATTAINED upper bound B of the answer;
+//   (2) points whose empty neighbourhood already reaches beyond sqrt(B) drop out, the others
+//       need the obstacles within R = sqrt(B) (1 + 1e-4) of themselves: all of those lie in
+//       the bucket cells [cell(x - R), cell(x + R)] x [cell(y - R), cell(y + R)] (the cell map
+//       is the monotone one the sensor build sorts the obstacles with), and the union of these
+//       rectangles over the points is ONE rectangle of cells;
+//   (3) its obstacles (row runs of the cell-sorted list, a row per lane, flattened to one
+//       obstacle per lane and load) are broadcast one at a time to all lanes: every lane forms
+//       the exact distance of ITS point, in the arithmetic of the ring walks.
+// Every value formed is a true distance of a trajectory point, and the pair that attains the
+// minimum is inside the rectangle: the result is the minimum of the full scan.  A rectangle
+// with more than `limit` obstacles (walls of a dense scan, far clutter) returns false with B
+// left in *obest, and the ring walks / the cooperative pass take over.  Grids of at most
+// 64 x 64 cells (the host checks).  Returns wave-uniform.
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t wave_pk_min_u16(uint32_t v) {
+  v = pk_min_u16(v, dpp_u32<0xB1>(v));
+  v = pk_min_u16(v, dpp_u32<0x4E>(v));
+  v = pk_min_u16(v, dpp_u32<0x141>(v));
+  v = pk_min_u16(v, dpp_u32<0x140>(v));
+  const uint32_t r0 = __builtin_amdgcn_readlane(static_cast<int>(v), 0);
+  const uint32_t r1 = __builtin_amdgcn_readlane(static_cast<int>(v), 16);
+  const uint32_t r2 = __builtin_amdgcn_readlane(static_cast<int>(v), 32);
+  const uint32_t r3 = __builtin_amdgcn_readlane(static_cast<int>(v), 48);
+  const uint32_t a = min(min(r0 >> 16, r1 >> 16), min(r2 >> 16, r3 >> 16));
+  const uint32_t b = min(min(r0 & 0xFFFFu, r1 & 0xFFFFu), min(r2 & 0xFFFFu, r3 & 0xFFFFu));
+  return (a << 16) | b;
+}
+__device__ __forceinline__ uint32_t wave_add_u32(uint32_t v) {
+  v += dpp_u32<0xB1>(v);
+  v += dpp_u32<0x4E>(v);
+  v += dpp_u32<0x141>(v);
+  v += dpp_u32<0x140>(v);
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 0)) +
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 16)) +
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 32)) +
+         static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
+}
+
+__device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limit, const int *cells,
+                                                    const uint8_t *skip, const float *obx, const float *oby,
+                                                    float x, float y, bool live, int lane,
+                                                    unsigned long long *obest) {
+  const bool fin = live && __builtin_isfinite(x) && __builtin_isfinite(y);  // (the others never win a minimum)
+  if (__ballot(fin) == 0ull) return true;
+  const double xd = static_cast<double>(x), yd = static_cast<double>(y);
+  const double fx = (xd - b.gx0) * b.inv_g, fy = (yd - b.gy0) * b.inv_g;
+  double off = 0.0;  // distance (cells) of a point outside the grid to it
+  if (fx < 0.0) off = fmax(off, -fx);
+  if (fy < 0.0) off = fmax(off, -fy);
+  if (fx > b.W) off = fmax(off, fx - b.W);
+  if (fy > b.H) off = fmax(off, fy - b.H);
+  const int cx = fin ? min(max(static_cast<int>(floor(fx)), 0), b.W - 1) : 0;
+  const int cy = fin ? min(max(static_cast<int>(floor(fy)), 0), b.H - 1) : 0;
+  const uint32_t sk = fin ? static_cast<uint32_t>(skip[cy * b.W + cx]) : 255u;
+  const int s = static_cast<int>(wave_min_u32(sk));
+  if (s > 2) return false;  // nothing close to any point: long walks, the cooperative pass
+  auto exact_dd = [&](int j) {
+    const double dx = static_cast<double>(obx[j] - x);
+    const double dy = static_cast<double>(oby[j] - y);
+    return dx * dx + dy * dy;
+  };
+  // (1) seeds
+  double best = DBL_MAX;
+  for (int dy = -s; dy <= s; ++dy) {
+    const int row = cy + dy;
+    if (fin && row >= 0 && row < b.H) {
+      const int beg = cells[row * b.W + max(cx - s, 0)], end = cells[row * b.W + min(cx + s, b.W - 1) + 1];
+      if (beg < end) {
+        best = __builtin_fmin(exact_dd(beg), best);
+        best = __builtin_fmin(exact_dd(end - 1), best);
+      }
+    }
+  }
+  const double prev = __longlong_as_double(static_cast<long long>(*const_cast<volatile unsigned long long *>(obest)));
+  const double B = fmin(prev, wave_min_nonneg(best));
+  if (!(B < 1.0e300)) return false;
+  // (2) the points that can still lower B, the rectangle of cells they need
+  const double lb0 = (static_cast<double>(static_cast<int>(sk) - 1) - off) * b.g;  // nothing is closer than this
+  const double lbs = lb0 * (1.0 - 1e-6) - 1e-9;
+  const bool cont = fin && !(lb0 >= b.cap) && !(lbs > 0.0 && lbs * lbs >= B);
+  if (__ballot(cont) == 0ull) return true;
+  const double R = fmin(static_cast<double>(__builtin_sqrtf(static_cast<float>(B)) * 1.0001f) + 1e-9, b.cap * 1.001);
+  auto cell_of = [&](double v, double g0, int n) {
+    const double f = floor((v - g0) * b.inv_g);
+    return static_cast<uint32_t>(min(max(static_cast<int>(fmin(fmax(f, -1.0), 65.0)), 0), n - 1));
+  };
+  uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
+  if (cont) {
+    lo = (cell_of(xd - R, b.gx0, b.W) << 16) | cell_of(yd - R, b.gy0, b.H);
+    hi = ((63u - cell_of(xd + R, b.gx0, b.W)) << 16) | (63u - cell_of(yd + R, b.gy0, b.H));
+  }
+  lo = wave_pk_min_u16(lo);
+  hi = wave_pk_min_u16(hi);
+  const int x0 = static_cast<int>(lo >> 16), y0 = static_cast<int>(lo & 0xFFFFu);
+  const int x1 = 63 - static_cast<int>(hi >> 16), y1 = 63 - static_cast<int>(hi & 0xFFFFu);
+  // (3) its rows, one per lane
+  const int nr = y1 - y0 + 1;
+  int rb = 0;
+  uint32_t cnt = 0u;
+  if (lane < nr) {
+    rb = cells[(y0 + lane) * b.W + x0];
+    cnt = static_cast<uint32_t>(cells[(y0 + lane) * b.W + x1 + 1] - rb);
+  }
+  const uint32_t T = wave_add_u32(cnt);
+  if (T > static_cast<uint32_t>(limit)) {
+    if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(B)));
+    return false;
+  }
+  const unsigned long long rows = __ballot(cnt != 0u);
+  for (uint32_t base = 0u; base < T; base += 64u) {
+    // obstacle base + lane of the rectangle
+    const uint32_t i = base + static_cast<uint32_t>(lane);
+    int j = -1;
+    uint32_t acc = 0u;
+    for (unsigned long long rm = rows; rm;) {
+      const int r = __ffsll(static_cast<long long>(rm)) - 1;
+      rm &= rm - 1ull;
+      const uint32_t cr = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cnt), r));
+      const int br = __builtin_amdgcn_readlane(rb, r);
+      const uint32_t rel = i - acc;
+      if (rel < cr) j = br + static_cast<int>(rel);
+      acc += cr;
+    }
+    const float ox = j >= 0 ? obx[j] : 0.0f, oy = j >= 0 ? oby[j] : 0.0f;
+    const int m = static_cast<int>(min(T - base, 64u));
+    for (int u0 = 0; u0 < m; u0 += 4) {
+      double d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int u = min(u0 + k, m - 1);  // (a repeat of the last one changes nothing)
+        const double dx = static_cast<double>(lane_value(ox, u) - x);
+        const double dy = static_cast<double>(lane_value(oy, u) - y);
+        d[k] = dx * dx + dy * dy;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) best = __builtin_fmin(d[k], best);  // (NaN distances never win)
+    }
+  }
+  const double found = fmin(B, wave_min_nonneg(best));
+  if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(found)));
+  return true;
+}
+
 // The wavefront-per-sample evaluation of ONE sample (one lane per trajectory
 // point, tiles of 64 points): see the comment on top of this file.  `seg`
 // gives the (x, y, z^2) of a segment point and its accumulated length, `cap` /
@@ -1227,6 +1382,9 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       }
       ubound2 = shared;  // (carried to the next tile of a long trajectory)
       if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(shared)));
+    } else if (a.use_obs && t.ounion > 0 &&
+               obstacle_union_scan(b, t.ounion, cells, skip, obx, oby, x, y, live, lane, obest)) {
+      // (one scan of the union block did it)
     } else if (a.use_obs) {
       // query cell (clamped: a query outside the grid searches from the
       // border and the guarantee radius shrinks by its distance to the grid)

@@ -289,6 +289,7 @@ struct kc_dwa {
   DevBuf<uint4> d_onear;
   float onear_x0 = 0.f, onear_y0 = 0.f, onear_g = 0.f;
   bool onear_ok = false;                 // the table covers the running cycle
+  int obs_union = 96;                    // option "obs_union": obstacle_union_scan up to this many obstacles (0: off)
   bool obs_near_ahead = true;            // test hook KC_OBS_NEAR_AHEAD=0: the cycle builds the table itself
   bool scan_lds_ok = false;              // sensor_build_scan_kernel may use the large LDS window
   long long onear_rides = 0, onear_builds = 0;  // tables built in the sensor launch / by a launch of their own
@@ -1653,6 +1654,7 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
     dt.onch = c->oscan_nch;
     dt.ocap = static_cast<double>(c->max_obs_dist);
   }
+  dt.ounion = (c->bucket.W <= 64 && c->bucket.H <= 64) ? c->obs_union : 0;
   ca.seg_len = c->seg_len;
   ca.ref_len = c->ref_len;
   ca.b = c->bucket;
@@ -2246,6 +2248,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (const char *e = std::getenv("KC_SENSOR_BIG_MIN")) c->sensor_big_min = std::min<size_t>(16384, std::strtoul(e, nullptr, 10));
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
+    if (const char *e = std::getenv("KC_OBS_UNION")) c->obs_union = std::min(4096, std::max(0, std::atoi(e)));  // tuning hook
     if (const char *e = std::getenv("KC_OBS_NEAR_AHEAD"))
       if (e[0] == '0') c->obs_near_ahead = false;
     if (const char *e = std::getenv("KC_LAZY_DILATE"))
@@ -2513,6 +2516,9 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   } else if (n == "num_ctrl_points") {
     if (!(v >= 0.0 && v <= 1e9)) KC_FAIL(KC_ERR_RANGE, "num_ctrl_points: a count >= 0");
     c->num_ctrl_points = static_cast<size_t>(v);
+  } else if (n == "obs_union") {
+    if (!(v >= 0.0 && v <= 4096.0)) KC_FAIL(KC_ERR_RANGE, "obs_union %g outside [0, 4096]", v);
+    c->obs_union = static_cast<int>(v);
   } else if (n == "obs_near") {
     if (v != 0.0 && v != 1.0 && !(v >= 16.0 && v <= 512.0)) KC_FAIL(KC_ERR_RANGE, "obs_near: 0 (off), 1 (on) or 16..512 cells per side");
     c->obs_near_opt = on;
@@ -2547,6 +2553,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "velocity_beside") *v = c->velocity_beside;
   else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
   else if (n == "obs_near") *v = c->obs_near_opt ? c->onear_side : 0;
+  else if (n == "obs_union") *v = c->obs_union;
   else if (n == "obs_near_rides") *v = static_cast<double>(c->onear_rides);    // read-only
   else if (n == "obs_near_builds") *v = static_cast<double>(c->onear_builds);  // read-only
   else if (n == "early_launch") *v = c->early_launch;
