@@ -1048,52 +1048,58 @@ __device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limi
                                                     unsigned long long *obest) {
   const bool fin = live && __builtin_isfinite(x) && __builtin_isfinite(y);  // (the others never win a minimum)
   if (__ballot(fin) == 0ull) return true;
-  const double xd = static_cast<double>(x), yd = static_cast<double>(y);
-  const double fx = (xd - b.gx0) * b.inv_g, fy = (yd - b.gy0) * b.inv_g;
-  double off = 0.0;  // distance (cells) of a point outside the grid to it
-  if (fx < 0.0) off = fmax(off, -fx);
-  if (fy < 0.0) off = fmax(off, -fy);
-  if (fx > b.W) off = fmax(off, fx - b.W);
-  if (fy > b.H) off = fmax(off, fy - b.H);
-  const int cx = fin ? min(max(static_cast<int>(floor(fx)), 0), b.W - 1) : 0;
-  const int cy = fin ? min(max(static_cast<int>(floor(fy)), 0), b.H - 1) : 0;
-  const uint32_t sk = fin ? static_cast<uint32_t>(skip[cy * b.W + cx]) : 255u;
-  const int s = static_cast<int>(wave_min_u32(sk));
-  if (s > 2) return false;  // nothing close to any point: long walks, the cooperative pass
-  auto exact_dd = [&](int j) {
-    const double dx = static_cast<double>(obx[j] - x);
-    const double dy = static_cast<double>(oby[j] - y);
-    return dx * dx + dy * dy;
+  // Cell coordinates in double like the sensor build's cell map, then float: everything up to the exact
+  // distances of step (3) is a BOUND, kept conservative by explicit slack (the kernel is VALU-issue bound and a
+  // double operation costs two float ones).
+  const float fx = static_cast<float>((static_cast<double>(x) - b.gx0) * b.inv_g);
+  const float fy = static_cast<float>((static_cast<double>(y) - b.gy0) * b.inv_g);
+  const float Wf = static_cast<float>(b.W), Hf = static_cast<float>(b.H);
+  const float off = fmaxf(fmaxf(fmaxf(-fx, fx - Wf), fmaxf(-fy, fy - Hf)), 0.0f);  // cells outside the grid
+  const float ferr = (fabsf(fx) + fabsf(fy)) * 2.4e-7f + 1e-5f;                  // of fx, fy, off (cells)
+  const int cx = fin ? min(max(static_cast<int>(floorf(fx)), 0), b.W - 1) : 0;
+  const int cy = fin ? min(max(static_cast<int>(floorf(fy)), 0), b.H - 1) : 0;
+  const int sk = fin ? static_cast<int>(skip[cy * b.W + cx]) : 255;
+  const float gdn = static_cast<float>(b.g) * (1.0f - 2e-7f), gup = static_cast<float>(b.inv_g) * (1.0f + 2e-7f);
+  const float capf = static_cast<float>(b.cap) * (1.0f + 2e-7f);
+  // cells nearer (Chebyshev) than sk to (cx, cy) are empty: nothing is closer than this to the point, metres
+  const float lbm = (static_cast<float>(sk - 1) - off - ferr) * gdn;
+  const bool near = fin && !(lbm >= capf);  // (beyond max_obstacles_dist: costs nothing)
+  if (__ballot(near && sk >= 255) != 0ull) return false;  // (a saturated skip value inside the cap: the walks)
+  auto dd_f32 = [&](int j) {
+    const float dx = obx[j] - x, dy = oby[j] - y;
+    return __builtin_fmaf(dx, dx, dy * dy);
   };
-  // (1) seeds
-  double best = DBL_MAX;
-  for (int dy = -s; dy <= s; ++dy) {
-    const int row = cy + dy;
-    if (fin && row >= 0 && row < b.H) {
-      const int beg = cells[row * b.W + max(cx - s, 0)], end = cells[row * b.W + min(cx + s, b.W - 1) + 1];
-      if (beg < end) {
-        best = __builtin_fmin(exact_dd(beg), best);
-        best = __builtin_fmin(exact_dd(end - 1), best);
+  // (1) seeds: the smallest block around every point in which some point finds an obstacle
+  float sf = __builtin_inff();
+  int s = 0;
+  for (; s <= 2; ++s) {
+    for (int dy = -s; dy <= s; ++dy) {
+      const int row = cy + dy;
+      if (fin && row >= 0 && row < b.H) {
+        const int beg = cells[row * b.W + max(cx - s, 0)], end = cells[row * b.W + min(cx + s, b.W - 1) + 1];
+        if (beg < end) sf = fminf(sf, fminf(dd_f32(beg), dd_f32(end - 1)));  // (NaN never wins)
       }
     }
+    if (__ballot(sf < 3.0e38f) != 0ull) break;
   }
+  if (s > 2) return false;  // nothing close to any point: long walks, the cooperative pass
+  // B: a float ABOVE the exact squared distance of the best seed (and of an earlier tile's minimum)
   const double prev = __longlong_as_double(static_cast<long long>(*const_cast<volatile unsigned long long *>(obest)));
-  const double B = fmin(prev, wave_min_nonneg(best));
-  if (!(B < 1.0e300)) return false;
-  // (2) the points that can still lower B, the rectangle of cells they need
-  const double lb0 = (static_cast<double>(static_cast<int>(sk) - 1) - off) * b.g;  // nothing is closer than this
-  const double lbs = lb0 * (1.0 - 1e-6) - 1e-9;
-  const bool cont = fin && !(lb0 >= b.cap) && !(lbs > 0.0 && lbs * lbs >= B);
+  const float bseed = __uint_as_float(wave_min_u32(__float_as_uint(sf))) * 1.000002f;
+  const float bf = fminf(bseed, static_cast<float>(prev) * 1.000001f) + 1e-37f;
+  // (2) the points that can still lower it, the rectangle of cells they need
+  const bool cont = near && !(lbm > 0.0f && lbm * lbm * (1.0f - 1e-6f) > bf);
   if (__ballot(cont) == 0ull) return true;
-  const double R = fmin(static_cast<double>(__builtin_sqrtf(static_cast<float>(B)) * 1.0001f) + 1e-9, b.cap * 1.001);
-  auto cell_of = [&](double v, double g0, int n) {
-    const double f = floor((v - g0) * b.inv_g);
-    return static_cast<uint32_t>(min(max(static_cast<int>(fmin(fmax(f, -1.0), 65.0)), 0), n - 1));
-  };
+  const float Rg = fminf(__builtin_sqrtf(bf) * 1.0001f + 1e-9f, capf * 1.001f) * gup;  // radius, cells
   uint32_t lo = 0xFFFFFFFFu, hi = 0xFFFFFFFFu;
   if (cont) {
-    lo = (cell_of(xd - R, b.gx0, b.W) << 16) | cell_of(yd - R, b.gy0, b.H);
-    hi = ((63u - cell_of(xd + R, b.gx0, b.W)) << 16) | (63u - cell_of(yd + R, b.gy0, b.H));
+    const float e = Rg + ferr;
+    const uint32_t xl = static_cast<uint32_t>(min(max(static_cast<int>(floorf(fx - e)), 0), b.W - 1));
+    const uint32_t yl = static_cast<uint32_t>(min(max(static_cast<int>(floorf(fy - e)), 0), b.H - 1));
+    const uint32_t xh = static_cast<uint32_t>(min(max(static_cast<int>(floorf(fx + e)), 0), b.W - 1));
+    const uint32_t yh = static_cast<uint32_t>(min(max(static_cast<int>(floorf(fy + e)), 0), b.H - 1));
+    lo = (xl << 16) | yl;
+    hi = ((63u - xh) << 16) | (63u - yh);
   }
   lo = wave_pk_min_u16(lo);
   hi = wave_pk_min_u16(hi);
@@ -1107,12 +1113,9 @@ __device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limi
     rb = cells[(y0 + lane) * b.W + x0];
     cnt = static_cast<uint32_t>(cells[(y0 + lane) * b.W + x1 + 1] - rb);
   }
-  const uint32_t T = wave_add_u32(cnt);
-  if (T > static_cast<uint32_t>(limit)) {
-    if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(B)));
-    return false;
-  }
   const unsigned long long rows = __ballot(cnt != 0u);
+  double best = DBL_MAX;
+  uint32_t T = 0xFFFFFFFFu;  // obstacles in the rectangle: known after the first flattening
   for (uint32_t base = 0u; base < T; base += 64u) {
     // obstacle base + lane of the rectangle
     const uint32_t i = base + static_cast<uint32_t>(lane);
@@ -1127,23 +1130,35 @@ __device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limi
       if (rel < cr) j = br + static_cast<int>(rel);
       acc += cr;
     }
+    T = acc;
+    if (T > static_cast<uint32_t>(limit)) return false;
     const float ox = j >= 0 ? obx[j] : 0.0f, oy = j >= 0 ? oby[j] : 0.0f;
     const int m = static_cast<int>(min(T - base, 64u));
+    // A float filter in front of the exact distance: dx and dy are the float differences the exact form
+    // converts, their squares are exact in double, so the float sum of squares is within 3 ulp (float) of the
+    // exact value -- an obstacle whose float value lies above B cannot lower the minimum for ANY lane, and
+    // most of the rectangle is like that.  The best seed passes (it defines B) and lies in the rectangle.
     for (int u0 = 0; u0 < m; u0 += 4) {
-      double d[4];
+      float dxf[4], dyf[4];
+      bool any = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int u = min(u0 + k, m - 1);  // (a repeat of the last one changes nothing)
-        const double dx = static_cast<double>(lane_value(ox, u) - x);
-        const double dy = static_cast<double>(lane_value(oy, u) - y);
-        d[k] = dx * dx + dy * dy;
+        dxf[k] = lane_value(ox, u) - x;
+        dyf[k] = lane_value(oy, u) - y;
+        const float f = __builtin_fmaf(dxf[k], dxf[k], dyf[k] * dyf[k]);
+        any = any || !(f > bf);  // (NaN: evaluated exactly, where it never wins)
       }
+      if (__ballot(any) == 0ull) continue;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) best = __builtin_fmin(d[k], best);  // (NaN distances never win)
+      for (int k = 0; k < 4; ++k) {
+        const double dx = static_cast<double>(dxf[k]), dy = static_cast<double>(dyf[k]);
+        best = __builtin_fmin(dx * dx + dy * dy, best);  // (NaN distances never win)
+      }
     }
   }
-  const double found = fmin(B, wave_min_nonneg(best));
-  if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(found)));
+  const double found = wave_min_nonneg(best);
+  if (lane == 0 && found < DBL_MAX) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(found)));
   return true;
 }
 

@@ -23,7 +23,12 @@ for name, w in (("all", inp["weights"]), ("segment only", (1, 1, 0, 0, 0)), ("ob
     for i in range(300): r = ctx.cycle(pose(i), P)
     t = (time.perf_counter() - t0) / 300 * 1e6
     ctx.timing_enable(True)
-    ctx.cycle(pose(0), P)
-    k = {n: round(ms * 1e3, 1) for n, ms in ctx.timings() if not n.startswith("host:")}
+    acc = {}
+    for i in range(40):
+        ctx.cycle(pose(i), P)
+        for n, ms in ctx.timings():
+            if not n.startswith("host:"):
+                acc.setdefault(n, []).append(ms * 1e3)
+    k = {n: round(float(np.median(v)), 1) for n, v in acc.items()}
     print(f"{cfg} {scene} {name:15s} {t:7.1f} us/cycle  admissible {r.n_admissible}  {k}", flush=True)
     ctx.close()
