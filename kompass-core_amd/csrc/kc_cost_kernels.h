@@ -1680,11 +1680,105 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
   return total;
 }
 
+template <typename T>
+__device__ __forceinline__ void st_agent(T *p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- the record of a cycle: minimum of the per-workgroup keys, the reference's compacted index of the
+// winner (admissible samples in front of it), the record for the host (pinned memory, polled: no D2H copy,
+// no stream wait) and the re-arming of the working slots.  One workgroup: publish_kernel behind the cost
+// kernels, or the workgroup of sample_cost_kernel that arrives last (PubArgs::fold).
+struct PubArgs {
+  const long long *block_keys;
+  int nblocks;
+  const uint8_t *flags;
+  int n, first;
+  long long *result;
+  long long *host_pub;
+  long long seq;
+  int identity_n;  // > 0: the admissible count of a batch that had no list (CostArgs::identity_n)
+  int fold;        // sample_cost_kernel: 1 = its last workgroup publishes (no publish_kernel behind it)
+};
+template <int kPubBlock>
+__device__ __forceinline__ void publish_body(const PubArgs &a) {
+  __shared__ long long wkey[kPubBlock / 64];
+  __shared__ int wsum[kPubBlock / 64];
+  __shared__ long long s_fkey;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long k = KEY_NONE;
+  for (int b = threadIdx.x; b < a.nblocks; b += kPubBlock) {
+    const long long v = ld_agent(a.block_keys + b);  // (another workgroup of this kernel may have written it)
+    k = v < k ? v : k;
+  }
+  const long long na = a.identity_n > 0 ? a.identity_n : a.result[W_LIST];
+  const long long err = a.result[W_NADM];  // device error word (roll-out gave up waiting)
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_xor(k, off, 64);
+    k = o < k ? o : k;
+  }
+  if (lane == 0) wkey[wave] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long m = wkey[0];
+    for (int w = 1; w < kPubBlock / 64; ++w) m = wkey[w] < m ? wkey[w] : m;
+    s_fkey = m;
+  }
+  __syncthreads();
+  const long long fkey = s_fkey;
+  // the reference's index counts the admissible samples in front of the winner
+  int cnt = 0;
+  if (fkey != KEY_NONE) {
+    long long lim =
+        static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
+    if (lim > a.n) lim = a.n;
+    // the flags are 0 / 1 bytes: sixteen per load, eight loads in flight per thread (a 65536-sample
+    // lattice is 8 loads per thread; byte by byte this loop was 21 us of a 0.2 ms cycle)
+    const int full = static_cast<int>(lim >> 4);
+    const uint4 *f16 = reinterpret_cast<const uint4 *>(a.flags);
+#pragma unroll 8
+    for (int i = threadIdx.x; i < full; i += kPubBlock) {
+      const uint4 v = f16[i];
+      cnt += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
+             __popc(v.w & 0x01010101u);
+    }
+    for (long long i = (static_cast<long long>(full) << 4) + threadIdx.x; i < lim; i += kPubBlock)
+      cnt += a.flags[i] & 1;
+  }
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  if (lane == 0) wsum[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kPubBlock / 64; ++w) s += wsum[w];
+    if (fkey == KEY_NONE) s = -1;
+    const long long na_pub = err ? -1 : na;
+    if (a.host_pub) {
+      // zero-copy hand-off: the host polls the record.  No fence between the
+      // words: the fourth is a mixing checksum over the others (record_check,
+      // kc_internal.h), so a half-arrived record is never accepted.
+      const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
+      store_host_record(a.host_pub, fkey, w1, a.seq, 0);  // (no winner row in this record)
+    }
+    a.result[R_KEY] = fkey;
+    a.result[R_NADM] = na_pub;
+    a.result[R_COMPACT] = s;
+    a.result[W_KEY] = KEY_NONE;
+    a.result[W_NADM] = 0;
+    a.result[W_TICKET] = 0;
+    a.result[W_LIST] = 0;  // admissible-list counter of the next cycle
+  }
+}
+
 // kLds: the tracked segment (+ chunk spheres), the bucket cell table and the
 // skip table are copied into LDS once per workgroup; kObsLds: the obstacle
 // coordinates too.  Otherwise they are read in place.
 template <bool kLds, bool kObsLds>
-__global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcArgs t) {
+__global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcArgs t, PubArgs pub) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ long long s_key;
   __shared__ unsigned long long s_obest[kCostWaves];  // per sample: min squared obstacle distance (double bits)
@@ -1783,8 +1877,24 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   // ---- the workgroup's best key, for publish_kernel ----------------------------
   if (lane == 0 && wkey != KEY_NONE) atomicMin(&s_key, wkey);
   __syncthreads();
-  if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
+  if (!pub.fold) {
+    if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
+    KC_STAMP(4);
+    return;
+  }
+  // Arrival ticket: the workgroup that arrives last publishes the cycle (the workgroups finish microseconds
+  // apart -- the atomics do not meet -- and the record is out one dispatch + one kernel earlier).
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    st_agent(a.block_keys + blockIdx.x, s_key);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tk = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.result + W_TICKET), 1ull,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (tk == static_cast<unsigned long long>(gridDim.x) - 1ull) ? 1 : 0;
+  }
+  __syncthreads();
   KC_STAMP(4);
+  if (s_last) publish_body<kCostBlock>(pub);
 }
 
 // One workgroup, queued behind sample_cost_kernel: minimum of the per-block
@@ -1815,85 +1925,8 @@ __global__ __launch_bounds__(256) void velocity_finish_kernel(VelFinishArgs a) {
   if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
 }
 
-struct PubArgs {
-  const long long *block_keys;
-  int nblocks;
-  const uint8_t *flags;
-  int n, first;
-  long long *result;
-  long long *host_pub;
-  long long seq;
-  int identity_n;  // > 0: the admissible count of a batch that had no list (CostArgs::identity_n)
-};
 constexpr int kPubBlock = 512;
-__global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) {
-  __shared__ long long wkey[kPubBlock / 64];
-  __shared__ int wsum[kPubBlock / 64];
-  __shared__ long long s_fkey;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long k = KEY_NONE;
-  for (int b = threadIdx.x; b < a.nblocks; b += kPubBlock) {
-    const long long v = a.block_keys[b];
-    k = v < k ? v : k;
-  }
-  const long long na = a.identity_n > 0 ? a.identity_n : a.result[W_LIST];
-  const long long err = a.result[W_NADM];  // device error word (roll-out gave up waiting)
-  for (int off = 32; off > 0; off >>= 1) {
-    const long long o = __shfl_xor(k, off, 64);
-    k = o < k ? o : k;
-  }
-  if (lane == 0) wkey[wave] = k;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long m = wkey[0];
-    for (int w = 1; w < kPubBlock / 64; ++w) m = wkey[w] < m ? wkey[w] : m;
-    s_fkey = m;
-  }
-  __syncthreads();
-  const long long fkey = s_fkey;
-  // the reference's index counts the admissible samples in front of the winner
-  int cnt = 0;
-  if (fkey != KEY_NONE) {
-    long long lim =
-        static_cast<long long>(static_cast<uint32_t>(fkey & 0xFFFFFFFFll)) - a.first;
-    if (lim > a.n) lim = a.n;
-    // the flags are 0 / 1 bytes: sixteen per load, eight loads in flight per thread (a 65536-sample
-    // lattice is 8 loads per thread; byte by byte this loop was 21 us of a 0.2 ms cycle)
-    const int full = static_cast<int>(lim >> 4);
-    const uint4 *f16 = reinterpret_cast<const uint4 *>(a.flags);
-#pragma unroll 8
-    for (int i = threadIdx.x; i < full; i += kPubBlock) {
-      const uint4 v = f16[i];
-      cnt += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
-             __popc(v.w & 0x01010101u);
-    }
-    for (long long i = (static_cast<long long>(full) << 4) + threadIdx.x; i < lim; i += kPubBlock)
-      cnt += a.flags[i] & 1;
-  }
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
-  if (lane == 0) wsum[wave] = cnt;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < kPubBlock / 64; ++w) s += wsum[w];
-    if (fkey == KEY_NONE) s = -1;
-    const long long na_pub = err ? -1 : na;
-    if (a.host_pub) {
-      // zero-copy hand-off: the host polls the record.  No fence between the
-      // words: the fourth is a mixing checksum over the others (record_check,
-      // kc_internal.h), so a half-arrived record is never accepted.
-      const long long w1 = (na_pub << 32) | static_cast<long long>(static_cast<uint32_t>(s));
-      store_host_record(a.host_pub, fkey, w1, a.seq, 0);  // (no winner row in this record)
-    }
-    a.result[R_KEY] = fkey;
-    a.result[R_NADM] = na_pub;
-    a.result[R_COMPACT] = s;
-    a.result[W_KEY] = KEY_NONE;
-    a.result[W_NADM] = 0;
-    a.result[W_TICKET] = 0;
-    a.result[W_LIST] = 0;  // admissible-list counter of the next cycle
-  }
-}
+__global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) { publish_body<kPubBlock>(a); }
 
 // the (externally reduced) device record again into the pinned mirror
 __global__ void republish_kernel(const long long *result, long long *host_pub, long long seq) {

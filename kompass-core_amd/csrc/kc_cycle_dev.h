@@ -21,15 +21,6 @@ constexpr int kTeamMaxSurvivors = 4;  // one or two survivors: half the workgrou
                                       // trajectory point; three or four: a quarter each, four lanes per
                                       // point (one pass either way); more: one per wavefront
 
-template <typename T>
-__device__ __forceinline__ void st_agent(T *p, T v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // LDS layout of the cost tables behind tab_off (the host sizes it the same way:
 // cycle_table_bytes in kc_dwa.hip)
 struct CycleTabs {

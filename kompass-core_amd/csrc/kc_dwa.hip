@@ -120,6 +120,8 @@ struct kc_dwa {
   long long last_nadm = -1;             // admissible count of the previous cycle (kernel choice)
   int cost_kernel_force = 0;            // 1: workgroup-per-sample, 2: wavefront-per-sample (KC_COST_KERNEL)
   bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
+  bool fold_publish = true;             // test hook KC_FOLD_PUBLISH=0: publish_kernel behind every cost kernel
+  bool cost_obs_lds = true;             // tuning hook KC_COST_OBS_LDS=0: obstacle coordinates stay in global memory
   bool cost_lds_ok = false;             // sample_cost_kernel<true> may take kCostLdsBudget
   int fused_samples = 32, fused_block = 1024;
   int cycle_samples = 32;  // samples per workgroup of the single-launch cycle: 16 when 32 would leave half the CUs idle
@@ -1816,6 +1818,17 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     lds_tab += (ncell + 1) * sizeof(int) + ((ncell + 3) & ~size_t(3));
     lds_obs = 2 * static_cast<size_t>(ca.b.nobs) * sizeof(float);
   }
+  PubArgs pa{};
+  pa.block_keys = c->d_block_keys.p;
+  pa.flags = c->d_flags.p;
+  pa.n = static_cast<int>(n);
+  pa.first = static_cast<int>(first);
+  pa.result = c->d_result.p;
+  pa.host_pub = c->h_pub.p;
+  pa.seq = ++c->seq;
+  pa.identity_n = ca.identity_n;
+  // the long-list kernel publishes by itself (its last workgroup) unless the velocity sums finish behind it
+  pa.fold = (!use_block && !vel_beside && c->fold_publish) ? 1 : 0;
   KC_TRY(c->timing.start(use_block ? "sample_cost_block_kernel" : "sample_cost_kernel", s));
   if (use_block) {
     cost_blocks = static_cast<unsigned>(std::min<size_t>(n, 512));
@@ -1835,23 +1848,24 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   } else {
     // one workgroup per CU, sixteen samples (wavefronts) in flight in each
     cost_blocks = static_cast<unsigned>(std::min<size_t>(n, kCostGrid));
+    pa.nblocks = static_cast<int>(cost_blocks);
     if (ca.use_seg)
       lds_tab += (8 * static_cast<size_t>(seg_pairs_padded(ca.nch, ca.seg_chunk)) + 8 * static_cast<size_t>(ca.nch) +
                   12 * static_cast<size_t>(ca.nsup)) * sizeof(float);  // pair records, capsules, spheres
     const bool tab_lds = c->cost_lds_ok && lds_tab + 64 <= kCostLdsBudget;
-    const bool obs_lds = tab_lds && ca.use_obs && lds_tab + lds_obs + 64 <= kCostLdsBudget;
+    const bool obs_lds = tab_lds && ca.use_obs && lds_tab + lds_obs + 64 <= kCostLdsBudget && c->cost_obs_lds;
     if (c->debug_stamps && c->seq <= 2)
       std::fprintf(stderr, "[kc] cost kernel: tables=%zu obstacles=%zu nobs=%d grid=%dx%d S=%zu chunk=%d tab_lds=%d obs_lds=%d\n",
                    lds_tab, lds_obs, ca.b.nobs, ca.b.W, ca.b.H, S, ca.seg_chunk, int(tab_lds), int(obs_lds));
     if (obs_lds)
       hipLaunchKernelGGL((sample_cost_kernel<true, true>), dim3(cost_blocks), dim3(kCostBlock),
-                         lds_tab + lds_obs, s, ca, dt);
+                         lds_tab + lds_obs, s, ca, dt, pa);
     else if (tab_lds)
       hipLaunchKernelGGL((sample_cost_kernel<true, false>), dim3(cost_blocks), dim3(kCostBlock),
-                         lds_tab, s, ca, dt);
+                         lds_tab, s, ca, dt, pa);
     else
       hipLaunchKernelGGL((sample_cost_kernel<false, false>), dim3(cost_blocks), dim3(kCostBlock),
-                         0, s, ca, dt);
+                         0, s, ca, dt, pa);
   }
   KC_TRY(c->timing.stop(s));
   if (vel_beside) {
@@ -1864,18 +1878,9 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     vf.block_keys = c->d_block_keys.p;
     hipLaunchKernelGGL(velocity_finish_kernel, dim3(cost_blocks), dim3(256), 0, s, vf);
   }
-  {
-    PubArgs pa{};
-    pa.block_keys = c->d_block_keys.p;
+  c->pub_pending = true;
+  if (!pa.fold) {
     pa.nblocks = static_cast<int>(cost_blocks);
-    pa.flags = c->d_flags.p;
-    pa.n = static_cast<int>(n);
-    pa.first = static_cast<int>(first);
-    pa.result = c->d_result.p;
-    pa.host_pub = c->h_pub.p;
-    pa.seq = ++c->seq;
-    pa.identity_n = ca.identity_n;
-    c->pub_pending = true;
     KC_TRY(c->timing.start("publish_kernel", s));
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kPubBlock), 0, s, pa);
     KC_TRY(c->timing.stop(s));
@@ -2248,6 +2253,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (const char *e = std::getenv("KC_SENSOR_BIG_MIN")) c->sensor_big_min = std::min<size_t>(16384, std::strtoul(e, nullptr, 10));
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
+    if (const char *e = std::getenv("KC_FOLD_PUBLISH")) c->fold_publish = e[0] != '0';
+    if (const char *e = std::getenv("KC_COST_OBS_LDS")) c->cost_obs_lds = e[0] != '0';
     if (const char *e = std::getenv("KC_OBS_UNION")) c->obs_union = std::min(4096, std::max(0, std::atoi(e)));  // tuning hook
     if (const char *e = std::getenv("KC_OBS_NEAR_AHEAD"))
       if (e[0] == '0') c->obs_near_ahead = false;
