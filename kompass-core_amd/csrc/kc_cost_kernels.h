@@ -999,8 +999,8 @@ __global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(Cos
 // over the WHOLE trajectory counts (trajectory.h:218-235), so where the trajectory runs through
 // occupied cells the wavefront does this instead:
 //   (1) every point takes a seed, the first and last obstacle of the block of (2 s + 1)^2
-//       bucket cells around its own (s = the smallest skip value of the trajectory: at least
-//       one such block is non-empty): an ATTAINED upper bound B of the answer;
+//       bucket cells around its own (s <= 2 = the smallest skip value of the trajectory, found
+//       by ballots: at least one such block is non-empty): a bound B above an ATTAINED distance;
 //   (2) points whose empty neighbourhood already reaches beyond sqrt(B) drop out, the others
 //       need the obstacles within R = sqrt(B) (1 + 1e-4) of themselves: all of those lie in
 //       the bucket cells [cell(x - R), cell(x + R)] x [cell(y - R), cell(y + R)] (the cell map
@@ -1064,25 +1064,28 @@ __device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limi
   // cells nearer (Chebyshev) than sk to (cx, cy) are empty: nothing is closer than this to the point, metres
   const float lbm = (static_cast<float>(sk - 1) - off - ferr) * gdn;
   const bool near = fin && !(lbm >= capf);  // (beyond max_obstacles_dist: costs nothing)
+  if (__ballot(near) == 0ull) return true;
   if (__ballot(near && sk >= 255) != 0ull) return false;  // (a saturated skip value inside the cap: the walks)
   auto dd_f32 = [&](int j) {
     const float dx = obx[j] - x, dy = oby[j] - y;
     return __builtin_fmaf(dx, dx, dy * dy);
   };
   // (1) seeds: the smallest block around every point in which some point finds an obstacle
+  // (the block of (2 s + 1)^2 cells around a point holds an obstacle exactly when its skip value is <= s)
+  int s;
+  if (__ballot(fin && sk == 0) != 0ull) s = 0;
+  else if (__ballot(fin && sk <= 1) != 0ull) s = 1;
+  else if (__ballot(fin && sk <= 2) != 0ull) s = 2;
+  else return false;  // nothing close to any point: long walks, the cooperative pass
   float sf = __builtin_inff();
-  int s = 0;
-  for (; s <= 2; ++s) {
-    for (int dy = -s; dy <= s; ++dy) {
-      const int row = cy + dy;
-      if (fin && row >= 0 && row < b.H) {
-        const int beg = cells[row * b.W + max(cx - s, 0)], end = cells[row * b.W + min(cx + s, b.W - 1) + 1];
-        if (beg < end) sf = fminf(sf, fminf(dd_f32(beg), dd_f32(end - 1)));  // (NaN never wins)
-      }
+  for (int dy = -s; dy <= s; ++dy) {
+    const int row = cy + dy;
+    if (fin && row >= 0 && row < b.H) {
+      const int beg = cells[row * b.W + max(cx - s, 0)], end = cells[row * b.W + min(cx + s, b.W - 1) + 1];
+      if (beg < end) sf = fminf(sf, fminf(dd_f32(beg), dd_f32(end - 1)));  // (NaN never wins)
     }
-    if (__ballot(sf < 3.0e38f) != 0ull) break;
   }
-  if (s > 2) return false;  // nothing close to any point: long walks, the cooperative pass
+  if (__ballot(sf < 3.0e38f) == 0ull) return false;  // (cannot happen: the skip table said otherwise)
   // B: a float ABOVE the exact squared distance of the best seed (and of an earlier tile's minimum)
   const double prev = __longlong_as_double(static_cast<long long>(*const_cast<volatile unsigned long long *>(obest)));
   const float bseed = __uint_as_float(wave_min_u32(__float_as_uint(sf))) * 1.000002f;
