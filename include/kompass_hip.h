@@ -185,6 +185,10 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        rectangle of cells that can hold the trajectory's nearest obstacle are
  *                        broadcast to all of its points (obstacle_union_scan) instead of a ring walk
  *                        per point; rectangles with more obstacles than this fall back.  0: off
+ *   "cost_batch"     (1) the long-list cost kernel leaves the per-sample part (ordered sum, the end
+ *                        point's index, weighted total, key) to a pass over 64 samples at once, a lane a
+ *                        sample (sample_cost_batched_kernel), when the list fills several buffers per
+ *                        workgroup (>= 10240 expected); 2: for every list length; 0: off
  *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
  *   "early_launch"   (1) the roll-out kernel is queued before the host trig table exists
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host

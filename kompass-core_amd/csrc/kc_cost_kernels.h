@@ -1171,13 +1171,23 @@ __device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limi
 // `sup` the chunk capsules [8][nch] and super-chunk spheres [4][nsup], `pts`
 // the sample's float points; *obest is a 64-bit LDS word of this wavefront.
 // Returns the weighted total (wave-uniform).
-template <class Seg, class Pts>
+// kBatched (sample_cost_batched_kernel): the per-POINT part only -- every point's distance to the segment goes
+// to `bs.mind`, what the end point's goal term needs to `bs.xe ...`, the obstacle minimum to *obest -- and the
+// per-SAMPLE part (ordered sum, the end point's index, the weighted total) is left to batch_totals, which does
+// it for 64 samples at once, a lane a sample.
+struct BatchSlot {
+  float *mind;                 // [P] this sample's row
+  float *xe, *ye;              // end point
+  uint32_t *be;                // bits of its minimum squared distance
+  unsigned long long *cand;    // the chunks its search scanned
+};
+template <class Seg, class Pts, bool kBatched = false>
 __device__ __forceinline__ float wave_sample_total(const CostArgs &a, const DcArgs &t, bool use_dc,
                                                    const Seg &seg, const float *cap, const float *sup,
                                                    float sz_end, const int *cells, const uint8_t *skip,
                                                    const float *obx, const float *oby, const Pts pts,
                                                    int n, int lane, unsigned long long *obest,
-                                                   bool stamp) {
+                                                   bool stamp, const BatchSlot bs = BatchSlot{}) {
   const BucketDev &b = a.b;
 if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
   float sum = 0.0f;            // ordered path-cost sum, carried over the point tiles
@@ -1294,7 +1304,14 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       if (st) KC_STAMP(10);
       const float best = __uint_as_float(bestb);
       mind = kc::sqrt_rn(best);
-      if (p0 + 64 >= a.P) {
+      if (kBatched) {
+        if (pp == a.P - 1) {
+          *bs.xe = x;
+          *bs.ye = y;
+          *bs.be = bestb;
+          *bs.cand = cand0;
+        }
+      } else if (p0 + 64 >= a.P) {
         // The end point (lane a.P - 1 - p0 of this tile): goalCostFunc,
         // cost_evaluator.cpp:157-176.  Its nearest segment point = the LOWEST
         // index whose squared distance equals the minimum found above (the
@@ -1651,7 +1668,9 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
     }
     if (st) KC_STAMP(12);
     // ordered path-cost sum of this tile (pathCostFunc, cost_evaluator.cpp:111-141)
-    if (a.use_seg) {
+    if (kBatched) {
+      if (live && a.use_seg) bs.mind[pp] = mind;
+    } else if (a.use_seg) {
       // (idle lanes contribute +0.0f, which leaves the non-negative sum as it is:
       // 64 straight-line additions instead of a counted loop)
       const float mv = live ? mind : 0.0f;
@@ -1662,6 +1681,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       }
     }
   }
+  if (kBatched) return 0.0f;
   // ---- weighted total (uniform over the wavefront) ---------------------------
   float total = 0.0f;
   if (a.ref_len > 0.0f) {
@@ -1681,6 +1701,102 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
   // constant-velocity samples: both terms are exactly 0 and `total += w*0`
   // leaves total unchanged, so nothing to do when !have_vel.
   return total;
+}
+
+// ---- the per-sample part of 64 samples at once (sample_cost_batched_kernel) --------------------------------
+// One LDS buffer of the batched kernel: what wave_sample_total<kBatched> left for the samples of a group.
+struct BatchBuf {
+  unsigned long long *obest, *cand;  // [64]
+  float *xe, *ye;                    // [64]
+  uint32_t *be;                      // [64]
+  int *n;                            // [64] sample ids
+  float *mind;                       // [64][Pp], Pp odd: a lane a row, conflict-free columns
+};
+__host__ __device__ inline size_t batch_buf_bytes(int P) { return 2048 + 256 * static_cast<size_t>(P | 1); }
+__device__ __forceinline__ BatchBuf batch_buf_at(unsigned char *p) {
+  BatchBuf B;
+  B.obest = reinterpret_cast<unsigned long long *>(p);
+  B.cand = B.obest + 64;
+  B.xe = reinterpret_cast<float *>(B.cand + 64);
+  B.ye = B.xe + 64;
+  B.be = reinterpret_cast<uint32_t *>(B.ye + 64);
+  B.n = reinterpret_cast<int *>(B.be + 64);
+  B.mind = reinterpret_cast<float *>(B.n + 64);
+  return B;
+}
+// A lane a sample: the ordered sum of its row (the additions of pathCostFunc in the reference's order,
+// cost_evaluator.cpp:111-141 -- P of them for 64 samples where the wavefront-per-sample form spends 64 per
+// sample), the end point's nearest segment index (the lowest index among the minima of the chunks its search
+// scanned, goalCostFunc :157-176), the weighted total in the reference's accumulation order (:59-100), the
+// cost and the key.  Samples with caller-provided velocity profiles need their sums precomputed (vsum_*).
+template <class Seg>
+__device__ __forceinline__ long long batch_totals(const CostArgs &a, const Seg &seg, float sz_end, const BatchBuf &B,
+                                                  int size, int lane) {
+  if (lane >= size) return KEY_NONE;
+  const int Pp = a.P | 1;
+  const int n = B.n[lane];
+  float sum = 0.0f, goal = 0.0f, endc = 0.0f;
+  if (a.use_seg) {
+    const float *row = B.mind + lane * Pp;
+    {  // (eight loads in flight: the chain is the additions, not the LDS round trips)
+      int p = 0;
+      for (; p + 8 <= a.P; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = row[p + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum = sum + v[u];
+      }
+      for (; p < a.P; ++p) sum = sum + row[p];
+    }
+    const float xe = B.xe[lane], ye = B.ye[lane];
+    const uint32_t be = B.be[lane];
+    unsigned long long ce = B.cand[lane];
+    const bool flat = a.seg_flat != 0;
+    uint32_t arg = 0xFFFFFFFFu;
+    if (be < 0x7F7FFFFFu) {
+      const int hp = a.seg_chunk >> 1;
+      while (ce && arg == 0xFFFFFFFFu) {
+        const int c = __ffsll(static_cast<long long>(ce)) - 1;
+        ce &= ce - 1ull;
+        const int k0 = (c * a.seg_chunk) >> 1;
+        for (int k = k0; k < k0 + hp && 2 * k < a.S && arg == 0xFFFFFFFFu; ++k) {
+          const f32x2 d = pair_d2(seg, k, xe, ye, flat);
+          if (__float_as_uint(d.x) == be) arg = static_cast<uint32_t>(2 * k);
+          else if (__float_as_uint(d.y) == be) arg = static_cast<uint32_t>(2 * k + 1);
+        }
+      }
+    }
+    const int argi = arg == 0xFFFFFFFFu ? 0 : static_cast<int>(arg);
+    const float mind_e = row[a.P - 1];
+    const float arc = kc::div_rn(a.ref_len - seg.acc(argi), a.ref_len);
+    goal = arc + kc::div_rn(mind_e, a.ref_len);
+    // end-point term of pathCostFunc, cost_evaluator.cpp:131-136
+    const float2 qe = seg.xy1(a.S - 1);
+    const float dx = xe - qe.x, dy = ye - qe.y, dz = 0.0f - sz_end;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    endc = kc::div_rn(kc::sqrt_rn(xx + (yy + zz)), a.seg_len);
+  }
+  float total = 0.0f;
+  if (a.ref_len > 0.0f) {
+    if (a.w_goal > 0.0) total = accum(total, a.w_goal, goal);
+    if (a.w_path > 0.0) {
+      const float c = kc::div_rn(kc::div_rn(sum, static_cast<float>(a.P)) + endc, 2.0f);
+      total = accum(total, a.w_path, c);
+    }
+  }
+  if (a.O > 0 && a.w_obs > 0.0)
+    total = accum(total, a.w_obs, obstacle_cost_from(a, __longlong_as_double(static_cast<long long>(B.obest[lane]))));
+  if (a.have_vel && !a.defer_vel) {
+    const float div = static_cast<float>(3L * (a.P - 1));
+    if (a.w_smooth > 0.0) total = accum(total, a.w_smooth, kc::div_rn(a.vsum_smooth[n], div));
+    if (a.w_jerk > 0.0) total = accum(total, a.w_jerk, kc::div_rn(a.vsum_jerk[n], div));
+  } else if (!a.have_vel && a.frz_smooth) {
+    total = add_frozen_costs(a, n, total);
+  }
+  a.costs[n] = total;
+  if (total < FLT_MAX && !a.defer_vel) return key_pack(total, static_cast<uint32_t>(a.first + n));
+  return KEY_NONE;
 }
 
 template <typename T>
@@ -1887,6 +2003,133 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   }
   // Arrival ticket: the workgroup that arrives last publishes the cycle (the workgroups finish microseconds
   // apart -- the atomics do not meet -- and the record is out one dispatch + one kernel earlier).
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    st_agent(a.block_keys + blockIdx.x, s_key);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tk = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(a.result + W_TICKET), 1ull,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (tk == static_cast<unsigned long long>(gridDim.x) - 1ull) ? 1 : 0;
+  }
+  __syncthreads();
+  KC_STAMP(4);
+  if (s_last) publish_body<kCostBlock>(pub);
+}
+
+// sample_cost_kernel with the per-sample part batched (the long lists of the DWA cycle: no caller-provided
+// velocity profiles, or their sums precomputed).  A wavefront still takes one sample at a time for the
+// per-point work (segment search, obstacle term), but leaves the results in a slot of an LDS buffer of 64
+// samples; the wavefront that completes a buffer runs batch_totals on it -- a lane a sample -- while the others
+// go on with the next buffer (two buffers; a wavefront that would write into a buffer whose previous round has
+// not been consumed waits for it).  The per-sample tail of the wavefront-per-sample form -- 64 dependent adds,
+// the end point's index search, four correctly rounded divisions, the weighted total: ~310 of ~900 wave
+// instructions per sample -- becomes ~7.  No barrier between the groups.
+template <bool kObsLds>
+__global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArgs a, DcArgs t, PubArgs pub) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ long long s_key;
+  __shared__ int s_next;      // next sample slot of this workgroup
+  __shared__ int s_done[2];   // finished slots of the group that owns the buffer
+  __shared__ int s_freed[2];  // rounds of the buffer whose totals are out
+  const int lane = threadIdx.x & 63;
+  KC_STAMP(0);
+  const int na = a.identity_n > 0 ? a.identity_n : static_cast<int>(*a.adm_count);
+  KC_STAMP(1);
+  const BucketDev &b = a.b;
+  const int ncell = b.W * b.H;
+  const int npp = seg_pairs_padded(a.nch, a.seg_chunk);
+  const int seg_words = a.use_seg ? 8 * npp + 8 * a.nch + 12 * a.nsup : 0;
+  // LDS: two sample buffers | segment pair records + capsules + spheres | cell table | skip table | obstacles
+  const size_t bufb = batch_buf_bytes(a.P);
+  float *const l_seg = reinterpret_cast<float *>(smem + 2 * bufb);
+  int *const l_cells = reinterpret_cast<int *>(l_seg + seg_words);
+  uint8_t *const l_skip = reinterpret_cast<uint8_t *>(l_cells + (a.use_obs ? ncell + 1 : 0));
+  float *const l_obs = reinterpret_cast<float *>(l_skip + (a.use_obs ? ((ncell + 3) & ~3) : 0));
+  const int *const cells = l_cells;
+  const uint8_t *const skip = l_skip;
+  const float *const obx = kObsLds ? l_obs : b.bx;
+  const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
+  float4 *const l_xy = reinterpret_cast<float4 *>(l_seg);
+  float4 *const l_za = l_xy + npp;
+  const float *const cap = l_seg + 8 * npp;
+  const float *const sup = cap + 8 * a.nch;
+  const bool use_dc = t.dc != nullptr && *t.enable != 0;
+  const float sz_end = (a.use_seg && a.S > 0) ? a.sz[a.S - 1] : 0.0f;
+  if (threadIdx.x == 0) {
+    s_key = KEY_NONE;
+    s_next = 0;
+    s_done[0] = s_done[1] = 0;
+    s_freed[0] = s_freed[1] = 0;
+  }
+  if (na > 0) {
+    if (a.use_seg) {
+      for (int k = threadIdx.x; k < npp; k += kCostBlock)
+        seg_pair_from_rows(a.sx, a.sy, a.szz, a.acc_seg, a.S, k, l_xy[k], l_za[k]);
+      float *const wc = l_seg + 8 * npp;
+      const float *const gc = a.sx + seg_cap_offset(a.S);
+      for (int j = threadIdx.x; j < 8 * a.nch + 12 * a.nsup; j += kCostBlock) wc[j] = gc[j];
+    }
+    if (a.use_obs) {
+#pragma unroll 8
+      for (int j = threadIdx.x; j <= ncell; j += kCostBlock) l_cells[j] = b.cell_start[j];
+      const uint32_t *gs = reinterpret_cast<const uint32_t *>(b.skip);
+      uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
+      for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kCostBlock) ls[j] = gs[j];
+      if (kObsLds) {
+#pragma unroll 8
+        for (int j = threadIdx.x; j < 2 * b.nobs; j += kCostBlock) l_obs[j] = b.bx[j];  // bx | by contiguous
+      }
+    }
+  }
+  __syncthreads();
+  KC_STAMP(6);
+  // sample i of the list belongs to workgroup (i % grid); this workgroup has M of them, in groups of 64 slots
+  const int G = static_cast<int>(gridDim.x);
+  const int M = static_cast<int>(blockIdx.x) < na ? (na - static_cast<int>(blockIdx.x) + G - 1) / G : 0;
+  const SegPairs seg{l_xy, l_za};
+  long long wkey = KEY_NONE;
+  for (;;) {
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(&s_next, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= M) break;
+    const int g = slot >> 6, q = slot & 63, sel = g & 1, round = g >> 1;
+    const int i = slot * G + static_cast<int>(blockIdx.x);
+    const int n = a.identity_n > 0 ? i : a.adm_list[i];
+    const RowPts pts{a.px + (size_t)n * a.P, a.py + (size_t)n * a.P};
+    // (the totals of the group that had this buffer two groups ago are out)
+    while (__hip_atomic_load(&s_freed[sel], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < round)
+      __builtin_amdgcn_s_sleep(1);
+    const BatchBuf B = batch_buf_at(smem + sel * bufb);
+    if (lane == 0) B.n[q] = n;
+    const BatchSlot bs{B.mind + q * (a.P | 1), B.xe + q, B.ye + q, B.be + q, B.cand + q};
+    wave_sample_total<SegPairs, RowPts, true>(a, t, use_dc, seg, cap, sup, sz_end, cells, skip, obx, oby, pts, n, lane,
+                                              B.obest + q, false, bs);
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(&s_done[sel], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = __builtin_amdgcn_readfirstlane(old);
+    const int size = min(64, M - 64 * g);
+    if (old + 1 == size) {  // this wavefront completed the group: its totals
+      long long k = batch_totals(a, seg, sz_end, B, size, lane);
+      for (int off = 32; off > 0; off >>= 1) {
+        const long long o = __shfl_xor(k, off, 64);
+        k = o < k ? o : k;
+      }
+      wkey = k < wkey ? k : wkey;
+      if (lane == 0) {
+        __hip_atomic_store(&s_done[sel], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_freed[sel], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+  KC_STAMP(2);
+  if (lane == 0 && wkey != KEY_NONE) atomicMin(&s_key, wkey);
+  __syncthreads();
+  if (!pub.fold) {
+    if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
+    KC_STAMP(4);
+    return;
+  }
   __shared__ int s_last;
   if (threadIdx.x == 0) {
     st_agent(a.block_keys + blockIdx.x, s_key);

@@ -77,7 +77,8 @@ PATHS = {
     "single_launch_ticket": dict(fused_cycle=2, host_reduce=0),
     "single_launch_rows": dict(fused_cycle=2, write_paths=1),
     "three_kernels_block": dict(fused_cycle=0, cost_kernel=1),
-    "three_kernels_wave": dict(fused_cycle=0, cost_kernel=2),
+    "three_kernels_wave": dict(fused_cycle=0, cost_kernel=2, cost_batch=0),
+    "three_kernels_wave_batched": dict(fused_cycle=0, cost_kernel=2, cost_batch=2),
     "split": dict(force_split=1),
 }
 ALL5 = (1.0, 1.0, 1.0, 1.0, 1.0)
@@ -118,6 +119,6 @@ def test_frozen_samples_at_baseline_size(scene):
     inp = syn.make_controller_inputs("cfg2", seed=0, scene=scene)
     o = _oracle(inp, False, 2, ALL5)
     assert len(o["raw"]) > 4000
-    for opts in (dict(), dict(fused_cycle=0)):
+    for opts in (dict(), dict(fused_cycle=0), dict(fused_cycle=0, cost_kernel=2, cost_batch=2)):
         h = _run(inp, ALL5, 2, False, opts)
         _check(o, h, inp)

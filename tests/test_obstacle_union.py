@@ -57,10 +57,11 @@ def run(obs, px, py, w, unions, max_range=10.0):
                        (2.0, 0.0, 3.0), ko.make_weights(*w))
     oi, oc, ocosts = ko.min_trajectory_cost(ci, px, py, None)
     N, P = px.shape
-    for u in unions:
+    for k, u in enumerate(unions):
         ctx = kh.DwaContext(syn.CYLINDER, [0.1, 0.4], max_samples=N, max_points=P, max_obstacles=len(obs),
                             acc_limits=(2.0, 0.0, 3.0))
         ctx.set_option("cost_kernel", 2)   # the wavefront-per-sample kernel for every list length
+        ctx.set_option("cost_batch", 2 * (k & 1))   # ... with and without the batched per-sample part
         ctx.set_option("obs_union", u)
         ctx.set_weights(kh.make_weights(*w))
         ctx.set_tracked_segment(seg, acc, 4.0)
