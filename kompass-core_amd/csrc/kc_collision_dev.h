@@ -68,7 +68,9 @@ struct RollArgs {
   // work; the host then writes the table and this sequence word through the
   // BAR and the workgroups wait for it.  Null: the table is already there.
   const long long *trig_flag;
-  long long trig_seq;
+  long long trig_seq;       // the sequence word reads trig_seq + (stages of the table that are complete)
+  int trig_stage_rows;      // rows per stage: row r belongs to stage r / trig_stage_rows
+  int trig_stages;
   long long *dev_err;   // set when the wait gives up (host never delivered)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
   CollDev c;

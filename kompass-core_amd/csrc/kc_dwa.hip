@@ -116,6 +116,14 @@ struct kc_dwa {
   int test_late_flag_ms = 0;            // KC_TEST_LATE_FLAG_MS: delay the trig sequence word once
   bool early_launch = true;             // fused kernel queued before the trig table exists
   long long trig_seq = 0;
+  // staged hand-off of the trig table (early launch): the rows are produced in `trig_stages` stages of
+  // consecutive rows, every stage dealt over all workers; the worker that completes a stage publishes
+  // 16 seq + (stages done) in the sequence word, and a workgroup waits only for the stage of its highest row
+  std::atomic<int> trig_stage_rows_done[8];
+  std::atomic<long long> trig_flag_shadow{0};
+  bool trig_staged = true;              // test hook KC_TRIG_STAGES=0: one flag for the whole table
+  size_t trig_stage_table_min = 16384;  // entries of the table from which it is handed over in stages
+  int trig_stage_min = 6;               // tuning hook KC_TRIG_STAGE_MIN: rows per worker and stage, at least
   int seg_chunk = kSegChunkMin, seg_nch = 0, seg_nsup = 0;  // chunking of the tracked segment (cost kernel)
   long long last_nadm = -1;             // admissible count of the previous cycle (kernel choice)
   int cost_kernel_force = 0;            // 1: workgroup-per-sample, 2: wavefront-per-sample (KC_COST_KERNEL)
@@ -2280,6 +2288,8 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (const char *e = std::getenv("KC_SENSOR_BIG_MIN")) c->sensor_big_min = std::min<size_t>(16384, std::strtoul(e, nullptr, 10));
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
+    if (const char *e = std::getenv("KC_TRIG_STAGES")) c->trig_staged = e[0] != '0';
+    if (const char *e = std::getenv("KC_TRIG_STAGE_MIN")) c->trig_stage_min = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("KC_COST_BATCH")) {
       c->cost_batch = e[0] != '0';
       c->cost_batch_forced = e[0] == '2';
@@ -3421,7 +3431,58 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     ~PoolJoin() { WorkerPool::instance().wait(ticket); }
   } pool_join;
   c->hprof.mark(8);
-  if (trig_ahead) pool_join.ticket = WorkerPool::instance().begin(A, 2, trig_rows);
+  // Stages: up to 8, at least 16 rows each.  Values of the sequence word: base + stages done (base = 16 seq).
+  // Only where the roll-out runs in several rounds of workgroups (more than one workgroup of 32 samples per
+  // CU: the three-kernel cycle of a large lattice, whose workgroups take their samples in row order), and only
+  // as many stages as leave every worker a run of `trig_stage_min` rows per stage: short runs fragment the
+  // write-combined stores over the BAR (cfg2 with 8 stages of 1-2 rows per worker: +14 us per cycle).
+  const long long trig_base = (c->trig_seq + 1) * 16;
+  size_t n_stages = 1;
+  // ... and only for tables the workers need longer for than a round of workgroups takes (cfg3: 25 700 sincos,
+  // 21 us on 11 workers -- 157.9 -> 141.3 us per cycle; cfg5: 9 650, 9 us -- 154 -> 158 us with two stages)
+  if (c->trig_staged && c->test_late_flag_ms <= 0 && blocks_for(n, 32) > static_cast<unsigned>(c->num_cus) &&
+      A * P >= c->trig_stage_table_min) {
+    const size_t per = static_cast<size_t>(c->trig_stage_min) * static_cast<size_t>(std::max(1, WorkerPool::instance().workers()));
+    n_stages = std::min<size_t>(8, std::max<size_t>(1, A / std::max<size_t>(per, 1)));
+  }
+  const size_t stage_rows = (A + n_stages - 1) / n_stages;
+  n_stages = (A + stage_rows - 1) / stage_rows;
+  const bool staged = trig_ahead && n_stages > 1;
+  if (trig_ahead && !staged) {
+    ++c->trig_seq;
+    pool_join.ticket = WorkerPool::instance().begin(A, 2, trig_rows);
+  } else if (trig_ahead) {
+    ++c->trig_seq;  // (whatever launch follows: a word of this table must never pass for the next one's)
+    for (auto &d : c->trig_stage_rows_done) d.store(0, std::memory_order_relaxed);
+    c->trig_flag_shadow.store(trig_base, std::memory_order_relaxed);
+    volatile long long *flag = reinterpret_cast<volatile long long *>(c->d_result.p + R_TRIGSEQ);
+    kc_dwa *cc = c;
+    auto trig_staged_rows = [=](size_t q, size_t parts) {
+      for (size_t st = 0; st < n_stages; ++st) {
+        const size_t lo = st * stage_rows, len = std::min(stage_rows, A - lo);
+        const size_t h = (q + st) % parts;  // the shares rotate: nobody gets the long one of every stage
+        const size_t b0 = lo + len * h / parts, b1 = lo + len * (h + 1) / parts;
+        if (b0 < b1) trig_rows(b0, b1);  // (ends with sfence)
+        const int done = cc->trig_stage_rows_done[st].fetch_add(static_cast<int>(b1 - b0), std::memory_order_acq_rel) +
+                         static_cast<int>(b1 - b0);
+        if (staged && b0 < b1 && done == static_cast<int>(len)) {
+          // every row of stages 0 .. st is out of the cores (a worker finishes stage st - 1 first and its
+          // sfence precedes its fetch_add): publish, unless a later stage already has
+          const long long v = trig_base + static_cast<long long>(st) + 1;
+          long long cur = cc->trig_flag_shadow.load(std::memory_order_relaxed);
+          while (cur < v && !cc->trig_flag_shadow.compare_exchange_weak(cur, v, std::memory_order_acq_rel)) {
+          }
+          if (cur < v) {
+            *flag = v;
+#if defined(__x86_64__)
+            __builtin_ia32_sfence();
+#endif
+          }
+        }
+      }
+    };
+    pool_join.ticket = WorkerPool::instance().begin_parts(A, 2, trig_staged_rows);
+  }
   c->hprof.mark(9);
   RollArgs a{};
   KC_TRY(ensure_cycle_buffers(c, n, P));
@@ -3609,7 +3670,9 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     }
     if (early) {
       a.trig_flag = c->d_result.p + R_TRIGSEQ;
-      a.trig_seq = ++c->trig_seq;
+      a.trig_seq = trig_base;
+      a.trig_stage_rows = static_cast<int>(stage_rows);
+      a.trig_stages = static_cast<int>(n_stages);
       a.dev_err = c->d_result.p + W_NADM;
     }
     c->hprof.mark(1);
@@ -3649,7 +3712,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       }
       // the table is out of the cores (sfence in every worker); now the word
       // the workgroups are waiting for
-      *reinterpret_cast<volatile long long *>(c->d_result.p + R_TRIGSEQ) = a.trig_seq;
+      *reinterpret_cast<volatile long long *>(c->d_result.p + R_TRIGSEQ) = a.trig_seq + a.trig_stages;
 #if defined(__x86_64__)
       __builtin_ia32_sfence();
 #endif

@@ -80,6 +80,36 @@ class WorkerPool {
     t.self = self != 0;
     return t;
   }
+  // The same with the decomposition handed to the job: fn(q, parts) for q = 0 .. parts - 1 (a job that wants
+  // to publish partial results in a global order deals its work over the parts by itself).
+  template <typename F>
+  Ticket begin_parts(size_t n, size_t min_chunk, F fn) {
+    Ticket t;
+    if (n == 0) return t;
+    run_mu_.lock();
+    if (threads_.empty()) {
+      run_mu_.unlock();
+      fn(size_t(0), size_t(1));
+      return t;
+    }
+    const size_t self = threads_.size() <= 3 ? 1 : 0;
+    const size_t parts = std::min<size_t>(threads_.size() + self,
+                                          min_chunk ? std::max<size_t>(n / min_chunk, 1) : n);
+    job_fn_ = [fn, parts, self](size_t part) {
+      const size_t q = part - (self ? 0 : 1);
+      if (q < parts) fn(q, parts);
+    };
+    job_parts_ = parts + (self ? 0 : 1);
+    const uint64_t g = gen_.load(std::memory_order_relaxed) + 1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      gen_.store(g, std::memory_order_release);
+    }
+    if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+    t.gen = g;
+    t.self = self != 0;
+    return t;
+  }
   void wait(Ticket &t) {
     if (!t.gen) return;
     if (t.self) job_fn_(0);

@@ -314,11 +314,16 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     // wait for the host's table (system-scope loads: the word and the table
     // arrive over PCIe, behind this GPU's caches).  Bounded: ~50 ms.
     __shared__ int s_late;
+    __syncthreads();  // lrow
     if (tid == 0) {
       int late = 0;
+      // the stage of this workgroup's highest trig row (the three-kernel roll-out takes its samples in row
+      // order: a workgroup of the first round needs the first stages only)
+      int top = 0;
+      for (int k = 0; k < rows; ++k) top = max(top, lrow[k]);
+      const long long want = a.trig_seq + min(top / a.trig_stage_rows, a.trig_stages - 1) + 1;
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(a.trig_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) !=
-             a.trig_seq) {
+      while (__hip_atomic_load(a.trig_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {
           late = 1;
           break;
