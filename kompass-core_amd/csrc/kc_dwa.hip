@@ -1840,8 +1840,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
   pa.identity_n = ca.identity_n;
   // the long-list kernel publishes by itself (its last workgroup) unless the velocity sums finish behind it
   pa.fold = (!use_block && !vel_beside && c->fold_publish) ? 1 : 0;
-  KC_TRY(c->timing.start(use_block ? "sample_cost_block_kernel" : "sample_cost_kernel", s));
   if (use_block) {
+    KC_TRY(c->timing.start("sample_cost_block_kernel", s));
     cost_blocks = static_cast<unsigned>(std::min<size_t>(n, 512));
     size_t lds = (P * 3 * sizeof(float) + 15) & ~size_t(15);
     if (ca.use_seg) lds_tab += 5 * S * sizeof(float);
@@ -1879,6 +1879,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     if (c->debug_stamps && c->seq <= 2)
       std::fprintf(stderr, "[kc] cost kernel: tables=%zu obstacles=%zu nobs=%d grid=%dx%d S=%zu chunk=%d tab_lds=%d obs_lds=%d\n",
                    lds_tab, lds_obs, ca.b.nobs, ca.b.W, ca.b.H, S, ca.seg_chunk, int(tab_lds), int(obs_lds));
+    KC_TRY(c->timing.start(batched ? "sample_cost_batched_kernel" : "sample_cost_kernel", s));
     if (batched && obs_lds)
       hipLaunchKernelGGL((sample_cost_batched_kernel<true>), dim3(cost_blocks), dim3(kCostBlock),
                          lds_tab + lds_obs, s, ca, dt, pa);
