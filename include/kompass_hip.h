@@ -190,7 +190,9 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        sample (sample_cost_batched_kernel), when the list fills several buffers per
  *                        workgroup (>= 10240 expected); 2: for every list length; 0: off
  *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
- *   "early_launch"   (1) the roll-out kernel is queued before the host trig table exists
+ *   "device_trig"    (1) cos / sin(yaw_k) formed by the roll-out kernels themselves (below:
+ *                        kc_trig_selfcheck); 0: the host's libm table, written over the BAR
+ *   "early_launch"   (1) host trig table only: the roll-out kernel is queued before the table exists
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host
  *   "trig_copy"      (0) trig table through pinned memory + H2D copy instead of BAR stores
  *   "force_split"    (0) roll-out, collision and compaction as separate kernels
@@ -207,6 +209,19 @@ int kc_dwa_get_option(kc_dwa *ctx, const char *name, double *value);
  * step): 1..64, the calling thread included.  Default: from the CPUs the process
  * may use (cgroup quota / ranks on the node) or KC_HOST_THREADS. */
 int kc_set_host_threads(int n);
+/* Device trig (option "device_trig", default 1; csrc/kc_trig_exact.h): the roll-out kernels form
+ * yaw_k of their omega rows by repeated addition and evaluate glibc's `sincos` algorithm themselves
+ * (State::update, datatypes/path.h:24-30, calls cos / sin of the host libm per step; gcc folds the
+ * pair into `sincos`) -- every operation a correctly rounded IEEE double add / multiply in the
+ * library's order over its 440-entry table, so the bits are the host's.
+ * kc_trig_selfcheck compares the restatement with the INSTALLED sincos on a fixed argument set
+ * (run once when the first context asks; a difference switches device trig off for the process and
+ * the host table of rounds 1-3 is used); kc_trig_table fills cos_sin_out[k * n_rows + r] =
+ * {cos, sin}(yaw_k of row r), yaw_0 = yaw0, yaw_{k+1} = yaw_k + omega[r] * dt, on the current
+ * device (tests: against the host's sincos). */
+int kc_trig_selfcheck(int64_t *compared_out);
+int kc_trig_table(double yaw0, const double *omega, size_t n_rows, size_t n_steps, double dt,
+                  double *cos_sin_out);
 
 /* A1 on the host: TrajectorySampler::UpdateReachableVelocityRange
  * (trajectory_sampler.cpp:328-372) + the lattice loops (:181-220 / :256-272,

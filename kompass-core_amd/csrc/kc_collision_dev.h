@@ -72,6 +72,12 @@ struct RollArgs {
   int trig_stage_rows;      // rows per stage: row r belongs to stage r / trig_stage_rows
   int trig_stages;
   long long *dev_err;   // set when the wait gives up (host never delivered)
+  // Device trig (round 3, kc_trig_exact.h): no host table at all -- the fused kernel forms yaw_k of its own
+  // omega rows by repeated addition from yaw0 (path.h:30) and evaluates glibc's sincos algorithm itself; the
+  // split path's kernels read a table trig_table_kernel has filled the same way.
+  int trig_dev;             // 1: fused kernel computes its trig rows (trig_flag is null then)
+  double yaw0;
+  double2 *trig_out;        // box footprints: the rows also go here (the exact tests read yaw_k of a pose back)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
   CollDev c;
   // c.dil == 2: the first cycle after a sensor update dilates its window itself

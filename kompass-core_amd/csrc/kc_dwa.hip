@@ -114,6 +114,8 @@ struct kc_dwa {
   std::vector<int> cell_id, cell_cursor;  // bucketing scratch (reused)
   std::vector<uint8_t> skip_pad;
   int test_late_flag_ms = 0;            // KC_TEST_LATE_FLAG_MS: delay the trig sequence word once
+  bool device_trig = true;              // option "device_trig" / KC_DEVICE_TRIG: cos / sin(yaw_k) formed by the kernels
+                                        // (kc_trig_exact.h); off: the host's libm table over the BAR (rounds 1-3)
   bool early_launch = true;             // fused kernel queued before the trig table exists
   long long trig_seq = 0;
   // staged hand-off of the trig table (early launch): the rows are produced in `trig_stages` stages of
@@ -732,6 +734,54 @@ int upload_obstacles(kc_dwa *c, size_t n) {
   return KC_OK;
 }
 
+// kc_trig_exact.h against the installed libm, once per process: a fixed argument set over every branch of the
+// algorithm (tiny, Taylor, table, pi/2 - x, Cody-Waite with every quadrant) and yaw chains as the roll-out forms
+// them.  Any difference (another libm: a build with FMA contraction, a different algorithm) switches the device
+// trig off for the process -- the host table path is exact by construction.
+static const double kc_sincostab_host[440] = {KC_SINCOSTAB_VALUES};
+int trig_selfcheck_run(long *compared) {
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  auto next = [&st]() {  // splitmix64
+    unsigned long long z = (st += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto unit = [&next]() { return static_cast<double>(next() >> 11) * 0x1p-53; };
+  long n = 0, bad = 0;
+  auto chk = [&](double x) {
+    double s, c, rs, rc;
+    if (!trig::sincos_exact(x, &s, &c, kc_sincostab_host)) return;
+    ::sincos(x, &rs, &rc);
+    ++n;
+    if (std::memcmp(&s, &rs, 8) != 0 || std::memcmp(&c, &rc, 8) != 0) ++bad;
+  };
+  const double ranges[][2] = {{0.0, 1e-7}, {0.0, 0.13}, {0.12, 0.86}, {0.85, 2.43}, {2.42, 7.0}, {0.0, 100.0}, {100.0, 1.0e8}};
+  for (const auto &r : ranges)
+    for (int i = 0; i < 4000; ++i) {
+      const double x = r[0] + (r[1] - r[0]) * unit();
+      chk(x);
+      chk(-x);
+    }
+  for (int i = 0; i < 100; ++i) {
+    double yaw = -3.2 + 6.4 * unit();
+    const double w = (-3.0 + 6.0 * unit()) * 0.05;
+    for (int k = 0; k < 100; ++k) {
+      chk(yaw);
+      yaw += w;
+    }
+  }
+  for (int e = -1074; e < 27; e += 3) chk(std::ldexp(1.0 + unit(), e));
+  chk(0.0);
+  chk(-0.0);
+  if (compared) *compared = n;
+  return static_cast<int>(bad);
+}
+bool trig_selfcheck_ok() {
+  static const bool ok = trig_selfcheck_run(nullptr) == 0;
+  return ok;
+}
+
 // omega of every trig row on the device (drop_samples = false: the velocity step of a frozen profile)
 int upload_omega(kc_dwa *c) {
   const size_t A = c->lat.omega_values.size();
@@ -768,6 +818,7 @@ int upload_samples(kc_dwa *c) {
   KC_TRY(c->d_vyt.reserve(ny));
   KC_TRY(c->d_vidx.reserve(n));
   KC_TRY(c->d_row.reserve(n));
+  KC_TRY(c->d_omega.reserve(std::max<size_t>(lat.omega_values.size(), 1)));  // (the kernels' trig rows: omega of a row)
   std::vector<uint32_t> packed;
   if (!same) {
     packed.resize(n);
@@ -783,6 +834,7 @@ int upload_samples(kc_dwa *c) {
     }
     std::memcpy(c->d_vxt.p, lat.vx_values.data(), nx * sizeof(double));
     std::memcpy(c->d_vyt.p, lat.vy_values.data(), ny * sizeof(double));
+    std::memcpy(c->d_omega.p, lat.omega_values.data(), lat.omega_values.size() * sizeof(double));
     if (!same) {
       std::memcpy(c->d_vidx.p, packed.data(), n * sizeof(uint32_t));
       std::memcpy(c->d_row.p, lat.row.data(), n * sizeof(int32_t));
@@ -792,6 +844,8 @@ int upload_samples(kc_dwa *c) {
   } else {
     KC_HIP(hipMemcpyAsync(c->d_vxt.p, lat.vx_values.data(), nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
     KC_HIP(hipMemcpyAsync(c->d_vyt.p, lat.vy_values.data(), ny * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipMemcpyAsync(c->d_omega.p, lat.omega_values.data(), lat.omega_values.size() * sizeof(double),
+                          hipMemcpyHostToDevice, c->stream));
     if (!same) {
       KC_HIP(hipMemcpyAsync(c->d_vidx.p, packed.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
       KC_HIP(hipMemcpyAsync(c->d_row.p, lat.row.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -810,7 +864,6 @@ int upload_samples(kc_dwa *c) {
       c->up_iy.clear();
     }
   }
-  if (!c->drop_samples) KC_TRY(upload_omega(c));
   return KC_OK;
 }
 
@@ -2320,6 +2373,7 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (const char *e = std::getenv("KC_COST_KERNEL"))  // tuning/test hook: "block" | "wave"
       c->cost_kernel_force = e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0;
     if (const char *e = std::getenv("KC_TEST_LATE_FLAG_MS")) c->test_late_flag_ms = std::atoi(e);
+    if (const char *e = std::getenv("KC_DEVICE_TRIG")) c->device_trig = e[0] != '0';
     if (const char *e = std::getenv("KC_EARLY_LAUNCH"))
       c->early_launch = e[0] != '0';            // tuning/test hook
   }
@@ -2580,6 +2634,7 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     if (!on) c->oscan_valid = false;
   } else if (n == "lazy_dilate") c->lazy_dilate = on;
   else if (n == "early_launch") c->early_launch = on;
+  else if (n == "device_trig") c->device_trig = on;
   else if (n == "sensor_on_host") c->device_sensor = !on;
   else if (n == "trig_copy") c->trig_direct = c->large_bar && !on;
   else if (n == "force_split") {
@@ -2610,6 +2665,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "obs_near_rides") *v = static_cast<double>(c->onear_rides);    // read-only
   else if (n == "obs_near_builds") *v = static_cast<double>(c->onear_builds);  // read-only
   else if (n == "early_launch") *v = c->early_launch;
+  else if (n == "device_trig") *v = c->device_trig && trig_selfcheck_ok();
   else if (n == "sensor_on_host") *v = !c->device_sensor;
   else if (n == "trig_copy") *v = !c->trig_direct;
   else if (n == "force_split") *v = c->lds_limit == 0;
@@ -2627,6 +2683,35 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
 int kc_set_host_threads(int n) {
   if (n < 1 || n > 64) KC_FAIL(KC_ERR_RANGE, "host threads must be 1..64");
   WorkerPool::instance().resize(n);
+  return KC_OK;
+}
+
+int kc_trig_selfcheck(int64_t *compared_out) {
+  long n = 0;
+  const int bad = trig_selfcheck_run(&n);
+  if (compared_out) *compared_out = n;
+  if (bad) KC_FAIL(KC_ERR_STATE, "%d of %ld arguments: the restated sincos differs from the installed libm's", bad, n);
+  return KC_OK;
+}
+
+int kc_trig_table(double yaw0, const double *omega, size_t n_rows, size_t n_steps, double dt, double *cos_sin_out) {
+  if (!omega || !cos_sin_out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (n_rows == 0 || n_steps == 0) return KC_OK;
+  if (n_steps > 4096 || n_rows > (1u << 20)) KC_FAIL(KC_ERR_RANGE, "table of %zu x %zu entries", n_rows, n_steps);
+  double om_max = 0.0;
+  for (size_t i = 0; i < n_rows; ++i) om_max = std::max(om_max, std::fabs(omega[i]));
+  const double reach = std::fabs(yaw0) + om_max * std::fabs(dt) * static_cast<double>(n_steps);
+  if (!(reach < 1.0e8)) KC_FAIL(KC_ERR_RANGE, "yaw reaches %g: outside the table + Cody-Waite range of sincos", reach);
+  DevBuf<double> d_om;
+  DevBuf<double2> d_out;
+  KC_TRY(d_om.reserve(n_rows));
+  KC_TRY(d_out.reserve(n_rows * n_steps));
+  KC_HIP(hipMemcpy(d_om.p, omega, n_rows * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(trig_table_kernel, dim3(blocks_for(n_rows, kTrigRows)), dim3(kTrigBlock),
+                     static_cast<size_t>(kTrigRows) * n_steps * sizeof(double), nullptr, yaw0, d_om.p, dt,
+                     static_cast<int>(n_rows), static_cast<int>(n_steps), d_out.p);
+  KC_HIP(hipGetLastError());
+  KC_HIP(hipMemcpy(cos_sin_out, d_out.p, n_rows * n_steps * sizeof(double2), hipMemcpyDeviceToHost));
   return KC_OK;
 }
 
@@ -3426,6 +3511,18 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   };
   // The workers start on the table at once (BAR path: straight into d_trig) -- before this thread
   // has put the kernel arguments together, so that the table is complete when the kernel asks for it.
+  // Device trig (kc_trig_exact.h): the kernels form cos / sin(yaw_k) themselves -- no host table, no flag,
+  // no worker pool.  Only while every yaw_k stays inside the range the restated algorithm covers
+  // (|yaw| < 105414350; a bound on |yaw0| + P |omega| dt decides), and only when the restatement agreed
+  // with the installed libm when the library was loaded.
+  bool dev_trig = c->device_trig && trig_selfcheck_ok() && std::isfinite(yaw0);
+  if (dev_trig) {
+    double om_max = 0.0;
+    for (size_t i = 0; i < A; ++i) om_max = std::max(om_max, std::fabs(om_v[i]));
+    const double reach = std::fabs(yaw0) + om_max * dt * static_cast<double>(P);
+    dev_trig = std::isfinite(reach) && reach < 1.0e8;
+  }
+  if (dev_trig) trig_ready = true;  // (nothing for the host to produce)
   const bool trig_ahead = !trig_ready && c->trig_direct && c->early_launch && !c->timing.enabled;
   struct PoolJoin {  // an error return below must not leave this call's job running
     WorkerPool::Ticket ticket;
@@ -3499,6 +3596,10 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   a.vidx = c->d_vidx.p;
   a.row = c->d_row.p;
   a.trig = c->d_trig.p;
+  a.trig_dev = dev_trig ? 1 : 0;
+  a.yaw0 = yaw0;
+  a.trig_out = c->d_trig.p;
+  a.omega_values = c->d_omega.p;
   a.px = c->d_px.p;
   a.py = c->d_py.p;
   a.flags = c->d_flags.p;
@@ -3618,7 +3719,15 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     if (trig_ahead) WorkerPool::instance().wait(pool_join.ticket);  // (split path: the table first)
     else if (!trig_ready) WorkerPool::instance().parallel_for(A, 2, trig_rows);
     c->timing.mark("host:trig_table");
-    if (!c->trig_direct)
+    if (dev_trig) {
+      if (!fused) {  // the split path's kernels read a table: filled on the device, in stream order
+        KC_TRY(c->timing.start("trig_table_kernel", s));
+        hipLaunchKernelGGL(trig_table_kernel, dim3(blocks_for(A, kTrigRows)), dim3(kTrigBlock),
+                           static_cast<size_t>(kTrigRows) * P * sizeof(double), s, yaw0, c->d_omega.p, dt,
+                           static_cast<int>(A), static_cast<int>(P), c->d_trig.p);
+        KC_TRY(c->timing.stop(s));
+      }
+    } else if (!c->trig_direct)
       KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
                             hipMemcpyHostToDevice, s));
   }

@@ -2,7 +2,44 @@
 // fused roll-out + pose gate, pose-parallel collision pass.  Part of kc_dwa.hip.
 #pragma once
 
+#include "kc_sincostab.h"
+#include "kc_trig_exact.h"
+
 namespace kc {
+
+// sin / cos (k / 128) in double-double: what glibc's sincos reads (kc_trig_exact.h); 3.5 KB, L2-resident
+__device__ const double kc_sincostab_dev[440] = {KC_SINCOSTAB_VALUES};
+
+// ===========================================================================
+// K0: the (step x omega row) table of cos / sin(yaw_k) on the device, for the kernels of the split
+// path (rollout_kernel, collision_kernel, collision_tilted_kernel) -- what the host's libm produced
+// every cycle in rounds 1-3.  A workgroup takes 8 rows: one lane per row forms yaw_k by repeated
+// addition of omega * dt (path.h:30) into LDS, then every lane evaluates entries.
+// ===========================================================================
+constexpr int kTrigRows = 8, kTrigBlock = 256;
+__global__ __launch_bounds__(kTrigBlock) void trig_table_kernel(double yaw0, const double *__restrict__ omega,
+                                                                 double dt, int A, int P, double2 *__restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *lyaw = reinterpret_cast<double *>(smem);  // [kTrigRows][P]
+  const int tid = threadIdx.x, r0 = blockIdx.x * kTrigRows;
+  const int nr = min(kTrigRows, A - r0);
+  if (tid < nr) {
+    const double w = omega[r0 + tid] * dt;
+    double yaw = yaw0;
+    for (int k = 0; k < P; ++k) {
+      lyaw[tid * P + k] = yaw;
+      yaw += w;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < kTrigRows * P; i += kTrigBlock) {
+    const int r = i & (kTrigRows - 1), k = i >> 3;
+    if (r >= nr) continue;
+    double sn, cs;
+    trig::sincos_exact(lyaw[r * P + k], &sn, &cs, kc_sincostab_dev);
+    out[(size_t)k * A + r0 + r] = make_double2(cs, sn);
+  }
+}
 
 // ===========================================================================
 // K1a: roll-out.  One lane per sample: the recurrence x_{k+1} = x_k + (...) is
@@ -310,7 +347,93 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     ncand2 = 0;
   }
   KC_RSTAMP(1);
-  if (a.trig_flag) {
+  if (a.trig_dev) {
+    // ---- trig rows of this workgroup, computed here (kc_trig_exact.h) ----------------------------
+    // The samples of a workgroup share a few omega rows (build_perm deals them that way): one lane per
+    // DISTINCT row forms yaw_k by repeated addition (path.h:30), the (row, step) entries are evaluated
+    // by densely packed lanes into the leader's LDS row, then every sample forms its increments from
+    // its leader's entries -- followers first, the leaders in place behind a barrier.
+    __shared__ int llead[kFusedSamples];   // slots of the distinct rows
+    __shared__ int lfirst[kFusedSamples];  // slot -> the first slot with the same row
+    __shared__ int nlead;
+    const bool box = a.c.enabled && a.c.shape == KC_BOX;
+    __syncthreads();  // lrow
+    if (tid < 64) {
+      bool lead = false;
+      if (tid < rows) {
+        const int r = lrow[tid];
+        int f = tid;
+        for (int j = 0; j < tid; ++j)
+          if (lrow[j] == r) {
+            f = j;
+            break;
+          }
+        lfirst[tid] = f;
+        lead = f == tid;
+      }
+      const unsigned long long bal = __ballot(lead);
+      if (lead) llead[__popcll(bal & ((1ull << tid) - 1ull))] = tid;
+      if (tid == 0) nlead = __popcll(bal);
+      if (lead) {
+        const int r = lrow[tid];
+        const double w = a.omega_values[r] * a.dt;
+        double yaw = a.yaw0;
+        double2 *mine = lpos + tid * PP;
+        for (int k = 0; k < steps; ++k) {
+          mine[k].x = yaw;
+          yaw += w;
+        }
+        if (box) {  // yaw of the last pose: no LDS slot, straight to the table the exact tests read
+          double sn, cs;
+          trig::sincos_exact(yaw, &sn, &cs, kc_sincostab_dev);
+          a.trig_out[(size_t)steps * a.A + r] = make_double2(cs, sn);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int L = nlead;
+      int sh = 0;
+      while ((1 << sh) < L) ++sh;
+      const int tot = steps << sh;
+      for (int i = tid; i < tot; i += kFusedBlock) {
+        const int l = i & ((1 << sh) - 1), k = i >> sh;
+        if (l >= L) continue;
+        const int sl = llead[l];
+        double sn, cs;
+        trig::sincos_exact(lpos[sl * PP + k].x, &sn, &cs, kc_sincostab_dev);
+        lpos[sl * PP + k] = make_double2(cs, sn);
+        if (box) a.trig_out[(size_t)k * a.A + lrow[sl]] = make_double2(cs, sn);
+      }
+    }
+    __syncthreads();
+    KC_RSTAMP(2);
+    const int s = tid & (kFusedSamples - 1);
+    const bool mine = s < rows;
+    const int f = mine ? lfirst[s] : 0;
+    double vx = 0.0, vy = 0.0;
+    if (mine) {
+      const uint32_t vi = lvi[s];
+      vx = a.vxt[vi & 0xFFFFu];
+      vy = a.vyt[vi >> 16];
+    }
+    //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt   (datatypes/path.h:24-30)
+    if (mine && f != s)
+      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
+        const double2 cs = lpos[f * PP + k];
+        const double tx = vx * cs.x - vy * cs.y;
+        const double ty = vx * cs.y + vy * cs.x;
+        lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
+      }
+    __syncthreads();
+    if (mine && f == s)
+      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
+        const double2 cs = lpos[s * PP + k];
+        const double tx = vx * cs.x - vy * cs.y;
+        const double ty = vx * cs.y + vy * cs.x;
+        lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
+      }
+  } else if (a.trig_flag) {
     // wait for the host's table (system-scope loads: the word and the table
     // arrive over PCIe, behind this GPU's caches).  Bounded: ~50 ms.
     __shared__ int s_late;
@@ -536,6 +659,11 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
           const double *tg = reinterpret_cast<const double *>(a.trig);
           t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (a.trig_dev) {
+          // written by lanes of this workgroup in the trig phase (barriers in between); read at L2
+          const double *tg = reinterpret_cast<const double *>(a.trig);
+          t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
           t = a.trig[e];
         }

@@ -91,6 +91,8 @@ SIGNATURES = {
     "kc_dwa_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "kc_dwa_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "kc_set_host_threads": (C.c_int, [C.c_int]),
+    "kc_trig_selfcheck": (C.c_int, [C.POINTER(C.c_int64)]),
+    "kc_trig_table": (C.c_int, [C.c_double, _dp, _sz, _sz, C.c_double, _dp]),
     "kc_dwa_sample_window": (C.c_int, [_vp, C.c_int, C.POINTER(Limits), C.c_double, C.c_double, C.c_double,
                                        C.c_int, C.c_int, C.POINTER(_sz), _dp, _dp, _dp, _sz]),
     "kc_dwa_set_samples": (C.c_int, [_vp, _sz, _dp, _dp, _dp]),
@@ -212,6 +214,23 @@ def device_count() -> int:
 def set_host_threads(n: int):
     """Threads of the process-wide host pool behind the roll-out's libm trig table."""
     _check(lib().kc_set_host_threads(int(n)))
+
+
+def trig_selfcheck() -> int:
+    """The restated sincos (csrc/kc_trig_exact.h) against the installed libm on the library's fixed argument
+    set (host only); returns the number of arguments compared, raises when any differs."""
+    n = C.c_int64(0)
+    _check(lib().kc_trig_selfcheck(C.byref(n)))
+    return int(n.value)
+
+
+def trig_table(yaw0: float, omega, n_steps: int, dt: float):
+    """{cos, sin}(yaw_k) of every omega row, formed on the device: [n_steps, n_rows, 2] float64."""
+    om = np.ascontiguousarray(omega, dtype=np.float64)
+    out = np.empty((int(n_steps), len(om), 2), dtype=np.float64)
+    _check(lib().kc_trig_table(float(yaw0), om.ctypes.data_as(_dp), len(om), int(n_steps), float(dt),
+                               out.ctypes.data_as(_dp)))
+    return out
 
 
 def _f32(a):

@@ -348,8 +348,10 @@ def _path_scenario(name, scale, shape, dims, variant, seed=4):
     {"KC_FORCE_SPLIT": "1"},      # roll-out + host window bits + pose-parallel collision + compaction
     {"KC_COST_KERNEL": "wave"},   # wavefront-per-sample cost kernel for every list
     {"KC_COST_KERNEL": "block"},  # workgroup-per-sample cost kernel for every list
-    {"KC_TRIG_COPY": "1"},        # trig table through pinned memory + H2D copy, launch after it
-    {"KC_EARLY_LAUNCH": "0"},     # BAR table, but classic order
+    {"KC_DEVICE_TRIG": "0"},      # the host's libm trig table over the BAR, kernel queued ahead of it (rounds 1-3)
+    {"KC_DEVICE_TRIG": "0", "KC_TRIG_COPY": "1"},     # ... through pinned memory + H2D copy, launch after it
+    {"KC_DEVICE_TRIG": "0", "KC_EARLY_LAUNCH": "0"},  # ... BAR table, but classic order
+    {"KC_DEVICE_TRIG": "0", "KC_FORCE_SPLIT": "1"},
     {"KC_SENSOR_HOST": "1"},      # sensor update (voxel bitmap, buckets) built on the host
     {"KC_LAZY_DILATE": "0"},      # dilate_kernel inside every sensor update (no self-dilating first cycle)
     {"KC_COST_DC": "64"},         # far-obstacle searches bracketed by the cell-centre distance table
@@ -531,7 +533,7 @@ for opt, val in (("host_reduce", 0), ("fused_cycle", 0)):
                      .replace('r = ctx.cycle(st, inp["P"])', 'ctx.rollout(st, inp["P"]); ctx.evaluate(); r = ctx.fetch_result()')
     assert code_split != code
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
-                       env=dict(os.environ, KC_TEST_LATE_FLAG_MS="120"))
+                       env=dict(os.environ, KC_TEST_LATE_FLAG_MS="120", KC_DEVICE_TRIG="0"))
     assert p.returncode == 0, p.stderr[-600:]
     ref = hip_cycle(kh, syn.make_controller_inputs("cfg1", seed=2))
     lines = p.stdout.strip().splitlines()
@@ -542,7 +544,7 @@ for opt, val in (("host_reduce", 0), ("fused_cycle", 0)):
     assert lines[2] == f"THEN: host_reduce True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p.stdout
     assert lines[3] == f"THEN: fused_cycle True {ref['res']['raw_index']} {ref['res']['n_admissible']}", p.stdout
     p2 = subprocess.run([sys.executable, "-c", code_split], capture_output=True, text=True, timeout=120,
-                        env=dict(os.environ, KC_TEST_LATE_FLAG_MS="120"))
+                        env=dict(os.environ, KC_TEST_LATE_FLAG_MS="120", KC_DEVICE_TRIG="0"))
     assert p2.returncode == 0, p2.stderr[-600:]
     lines2 = p2.stdout.strip().splitlines()
     assert lines2[0] == "FIRST: no error", p2.stdout   # the roll-out call itself does not fail: the error word is set on the device

@@ -34,6 +34,7 @@ def _run(tmp_path, world, scenario, cfg, scale, seed, mode, late_rank=None):
         env["KC_HOST_THREADS"] = "2"
         if late_rank == r:
             env["KC_TEST_LATE_FLAG_MS"] = "120"
+            env["KC_DEVICE_TRIG"] = "0"   # (a late HOST table: the host-trig path)
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "_shm_worker.py"), str(r), str(world), name,
                                        str(tmp_path), scenario, cfg, str(scale), str(seed), str(mode)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))

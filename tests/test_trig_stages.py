@@ -43,7 +43,7 @@ print("OK")
 @pytest.mark.parametrize("env", [dict(), dict(KC_TRIG_STAGES="0"), dict(KC_TRIG_STAGE_MIN="1"), dict(KC_TRIG_STAGE_MIN="3", KC_HOST_THREADS="5"),
                                  dict(KC_HOST_THREADS="1")])
 def test_staged_table_cycles_match_the_oracle(env):
-    e = dict(os.environ, **env)
+    e = dict(os.environ, KC_DEVICE_TRIG="0", **env)   # (the host table is what is staged)
     p = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT)], env=e, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-3000:]
 
@@ -69,7 +69,7 @@ r = ctx.cycle(inp["state"], inp["P"])          # the context is usable at once
 print("THEN", r.n_admissible > 0)
 ctx.close()
 """ % dict(root=ROOT)
-    e = dict(os.environ, KC_TEST_LATE_FLAG_MS="120")
+    e = dict(os.environ, KC_TEST_LATE_FLAG_MS="120", KC_DEVICE_TRIG="0")
     p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     assert "ERR" in p.stdout and "gave up waiting" in p.stdout and "THEN True" in p.stdout, p.stdout
