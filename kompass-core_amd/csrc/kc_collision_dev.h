@@ -77,6 +77,7 @@ struct RollArgs {
   // split path's kernels read a table trig_table_kernel has filled the same way.
   int trig_dev;             // 1: fused kernel computes its trig rows (trig_flag is null then)
   double yaw0;
+  const double *sincostab;  // [440] the table sincos reads, in the context's device memory
   double2 *trig_out;        // box footprints: the rows also go here (the exact tests read yaw_k of a pose back)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
   CollDev c;

@@ -78,43 +78,45 @@ struct CycleTabRegs {
   bool ok;
 };
 template <int kBlock, class Tail>
-__device__ __forceinline__ void cycle_tables_load(const Tail &tail, int tid, CycleTabRegs<kBlock> &r) {
+__device__ __forceinline__ void cycle_tables_load(const Tail &tail, int tid, int nthreads, CycleTabRegs<kBlock> &r) {
+  // (threads 0 .. nthreads - 1 copy: the trig waves of a device-trig launch stay out of it)
   const CostArgs &c = tail.c;
   const int ncell = c.use_obs ? c.b.W * c.b.H : 0;
   const int capw = c.use_seg ? 8 * c.nch + 12 * c.nsup : 0;
   const int npp = c.use_seg ? seg_pairs_padded(c.nch, c.seg_chunk) : 0;
-  r.ok = npp <= kBlock && capw <= 2 * kBlock && ncell + 1 <= 5 * kBlock &&
-         (ncell + 3) / 4 <= 2 * kBlock;
-  if (!r.ok) return;
+  r.ok = npp <= nthreads && capw <= 2 * nthreads && ncell + 1 <= 5 * nthreads &&
+         (ncell + 3) / 4 <= 2 * nthreads;
+  if (!r.ok || tid >= nthreads) return;
   if (c.use_seg) {
     if (tid < npp) seg_pair_from_rows(c.sx, c.sy, c.szz, c.acc_seg, c.S, tid, r.sxy, r.sza);
     const float *gc = c.sx + seg_cap_offset(c.S);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = tid + u * kBlock;
+      const int j = tid + u * nthreads;
       if (j < capw) r.cap[u] = gc[j];
     }
   }
   if (c.use_obs) {
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
-      const int j = tid + u * kBlock;
+      const int j = tid + u * nthreads;
       if (j <= ncell) r.cells[u] = c.b.cell_start[j];
     }
     const uint32_t *gs = reinterpret_cast<const uint32_t *>(c.b.skip);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = tid + u * kBlock;
+      const int j = tid + u * nthreads;
       if (j < (ncell + 3) / 4) r.skip[u] = gs[j];
     }
   }
 }
 template <int kBlock, class Tail>
-__device__ __forceinline__ void cycle_tables_store(const Tail &tail, unsigned char *smem, int tid,
+__device__ __forceinline__ void cycle_tables_store(const Tail &tail, unsigned char *smem, int tid, int nthreads,
                                                    const CycleTabRegs<kBlock> &r) {
   const CostArgs &c = tail.c;
+  if (tid >= nthreads) return;
   if (!r.ok) {
-    cycle_fill_tables(tail, smem, tid, kBlock);
+    cycle_fill_tables(tail, smem, tid, nthreads);
     return;
   }
   const CycleTabs t = cycle_tabs(c, smem, tail.tab_off);
@@ -127,20 +129,20 @@ __device__ __forceinline__ void cycle_tables_store(const Tail &tail, unsigned ch
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = tid + u * kBlock;
+      const int j = tid + u * nthreads;
       if (j < capw) t.cap[j] = r.cap[u];
     }
   }
   if (c.use_obs) {
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
-      const int j = tid + u * kBlock;
+      const int j = tid + u * nthreads;
       if (j <= ncell) t.cells[j] = r.cells[u];
     }
     uint32_t *ls = reinterpret_cast<uint32_t *>(t.skip);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int j = tid + u * kBlock;
+      const int j = tid + u * nthreads;
       if (j < (ncell + 3) / 4) ls[j] = r.skip[u];
     }
   }

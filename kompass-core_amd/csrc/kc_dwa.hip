@@ -323,6 +323,7 @@ struct kc_dwa {
   DevBuf<int> d_freeze, d_first_hit;   // [n] first zero-velocity step of a frozen sample (0: not frozen) / split path scratch
   DevBuf<float> d_frz;                 // [2][n] smoothness | jerk sums of the frozen profiles
   DevBuf<double> d_omega;              // [A] omega of every trig row
+  DevBuf<double> d_sincostab;          // the 440 table values of kc_trig_exact.h beside the context's other tables
   bool freeze_valid = false;           // d_freeze describes the last roll-out
 };
 
@@ -2552,6 +2553,7 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_first_hit.release();
   c->d_frz.release();
   c->d_omega.release();
+  c->d_sincostab.release();
   c->d_gid.release();
   c->d_xs.release();
   c->d_xr.release();
@@ -3597,6 +3599,12 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   a.row = c->d_row.p;
   a.trig = c->d_trig.p;
   a.trig_dev = dev_trig ? 1 : 0;
+  if (dev_trig && !c->d_sincostab.p) {
+    KC_TRY(c->d_sincostab.reserve(440));
+    KC_HIP(hipMemcpyAsync(c->d_sincostab.p, kc_sincostab_host, sizeof(kc_sincostab_host), hipMemcpyHostToDevice, s));
+    KC_HIP(hipStreamSynchronize(s));
+  }
+  a.sincostab = c->d_sincostab.p;
   a.yaw0 = yaw0;
   a.trig_out = c->d_trig.p;
   a.omega_values = c->d_omega.p;

@@ -198,6 +198,16 @@ __global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
 // the workgroups with a skewed stride over the trig-row order (build_perm):
 // survivors cluster in a few omega rows, contiguous blocks of that order would
 // leave the cost phase to a few workgroups.
+// Device trig inside the fused kernel (kc_trig_exact.h).  The samples of a workgroup share a few omega rows and
+// rows are non-decreasing in slot order (build_perm: row-sorted order, dealt in runs): the first slot of a
+// run is its LEADER.  Phase A brings the 440-entry table sincos reads and the omega values into LDS with the
+// other tables (one more bulk load per thread: vector loads return in order, a table read from global memory
+// issued behind them would wait for all of them), wavefront 0 lists the leaders; behind the phase's barrier
+// a lane per (leader, step) forms yaw_k by repeated addition from yaw0 (path.h:30: the additions of the
+// steps in front of k, in the lane itself), evaluates sincos and leaves {cos, sin} in the leader's LDS
+// pose row; every sample then forms its increments from its leader's entries.
+constexpr int kTrigOmegaLds = 384;  // omega values kept in LDS (more rows: read from global memory)
+
 struct NoTail {};
 struct CycleTail {
   CostArgs c;
@@ -257,8 +267,28 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   }
   // Cycle: the cost tables' global loads are issued here and land in LDS at the end of the
   // phase; the window loads below are in flight at the same time.
+  __shared__ int lfirst[kFusedSamples];  // device trig: slot -> its leader (the first slot with the same trig row)
+  __shared__ int llead[kFusedSamples];   // ... the leaders, ascending
+  __shared__ int nlead;
+  __shared__ double ltab[440];           // ... sin / cos (k / 128): what sincos reads
+  __shared__ double lom[kTrigOmegaLds];  // ... omega of the trig rows
+  const bool box = a.c.enabled && a.c.shape == KC_BOX;
+  constexpr int kTabPer = (440 + kFusedBlock - 1) / kFusedBlock, kOmPer = (kTrigOmegaLds + kFusedBlock - 1) / kFusedBlock;
+  double tabv[kTabPer], omv[kOmPer];
+  if (a.trig_dev) {
+#pragma unroll
+    for (int u = 0; u < kTabPer; ++u) {
+      const int j = tid + u * kFusedBlock;
+      tabv[u] = j < 440 ? a.sincostab[j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kOmPer; ++u) {
+      const int j = tid + u * kFusedBlock;
+      omv[u] = (j < kTrigOmegaLds && j < a.A) ? a.omega_values[j] : 0.0;
+    }
+  }
   CycleTabRegs<kFusedBlock> tabregs;
-  if constexpr (kCycle) cycle_tables_load<kFusedBlock>(tail, tid, tabregs);
+  if constexpr (kCycle) cycle_tables_load<kFusedBlock>(tail, tid, kFusedBlock, tabregs);
   if (a.c.enabled && a.c.dil == 2) {
     // The dilated masks of this sensor update do not exist yet: the raw bits of
     // the window plus a halo of R rows and one word either way go to LDS, and
@@ -334,7 +364,29 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       }
     }
   }
-  if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, tabregs);
+  if (a.trig_dev) {
+#pragma unroll
+    for (int u = 0; u < kTabPer; ++u) {
+      const int j = tid + u * kFusedBlock;
+      if (j < 440) ltab[j] = tabv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kOmPer; ++u) {
+      const int j = tid + u * kFusedBlock;
+      if (j < kTrigOmegaLds) lom[j] = omv[u];
+    }
+  }
+  if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, kFusedBlock, tabregs);
+  if (a.trig_dev && tid < 64) {
+    // leaders: a slot whose row differs from the slot in front of it (rows come in runs)
+    const int prev = __shfl_up(my_row, 1, 64);
+    const bool lead = tid < rows && (tid == 0 || prev != my_row);
+    const unsigned long long bal = __ballot(lead);
+    const unsigned long long upto = bal & (~0ull >> (63 - tid));  // leaders at or in front of this slot
+    if (tid < rows) lfirst[tid] = 63 - __clzll(static_cast<long long>(upto));
+    if (lead) llead[__popcll(upto) - 1] = tid;
+    if (tid == 0) nlead = __popcll(bal);
+  }
   if (tid < kFusedSamples) {
     lhit[tid] = a.freeze ? 0x7FFFFFFF : 0;  // freeze mode: the FIRST colliding pose index of the sample (minimum)
     lperm[tid] = my_id;
@@ -348,62 +400,28 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   }
   KC_RSTAMP(1);
   if (a.trig_dev) {
-    // ---- trig rows of this workgroup, computed here (kc_trig_exact.h) ----------------------------
-    // The samples of a workgroup share a few omega rows (build_perm deals them that way): one lane per
-    // DISTINCT row forms yaw_k by repeated addition (path.h:30), the (row, step) entries are evaluated
-    // by densely packed lanes into the leader's LDS row, then every sample forms its increments from
-    // its leader's entries -- followers first, the leaders in place behind a barrier.
-    __shared__ int llead[kFusedSamples];   // slots of the distinct rows
-    __shared__ int lfirst[kFusedSamples];  // slot -> the first slot with the same row
-    __shared__ int nlead;
-    const bool box = a.c.enabled && a.c.shape == KC_BOX;
-    __syncthreads();  // lrow
-    if (tid < 64) {
-      bool lead = false;
-      if (tid < rows) {
-        const int r = lrow[tid];
-        int f = tid;
-        for (int j = 0; j < tid; ++j)
-          if (lrow[j] == r) {
-            f = j;
-            break;
-          }
-        lfirst[tid] = f;
-        lead = f == tid;
-      }
-      const unsigned long long bal = __ballot(lead);
-      if (lead) llead[__popcll(bal & ((1ull << tid) - 1ull))] = tid;
-      if (tid == 0) nlead = __popcll(bal);
-      if (lead) {
-        const int r = lrow[tid];
-        const double w = a.omega_values[r] * a.dt;
-        double yaw = a.yaw0;
-        double2 *mine = lpos + tid * PP;
-        for (int k = 0; k < steps; ++k) {
-          mine[k].x = yaw;
-          yaw += w;
-        }
-        if (box) {  // yaw of the last pose: no LDS slot, straight to the table the exact tests read
-          double sn, cs;
-          trig::sincos_exact(yaw, &sn, &cs, kc_sincostab_dev);
-          a.trig_out[(size_t)steps * a.A + r] = make_double2(cs, sn);
-        }
-      }
-    }
+    // {cos, sin}(yaw_k) of every distinct row into the LDS pose row of its leader, a lane per entry; then
+    // every sample forms its increments from its leader's entries -- followers first, the leaders in place
+    // behind a barrier
     __syncthreads();
     {
       const int L = nlead;
       int sh = 0;
       while ((1 << sh) < L) ++sh;
-      const int tot = steps << sh;
-      for (int i = tid; i < tot; i += kFusedBlock) {
+      const int ktop = steps + (box ? 1 : 0);  // (boxes: yaw of the last pose too, for the exact tests)
+      for (int i = tid; i < (ktop << sh); i += kFusedBlock) {
         const int l = i & ((1 << sh) - 1), k = i >> sh;
         if (l >= L) continue;
-        const int sl = llead[l];
+        const int sl = llead[l], r = lrow[sl];
+        const double w = (r < kTrigOmegaLds ? lom[r] : a.omega_values[r]) * a.dt;
+        double yaw = a.yaw0;
+        int q = 0;
+        for (; q + 4 <= k; q += 4) yaw = (((yaw + w) + w) + w) + w;
+        for (; q < k; ++q) yaw += w;
         double sn, cs;
-        trig::sincos_exact(lpos[sl * PP + k].x, &sn, &cs, kc_sincostab_dev);
-        lpos[sl * PP + k] = make_double2(cs, sn);
-        if (box) a.trig_out[(size_t)k * a.A + lrow[sl]] = make_double2(cs, sn);
+        trig::sincos_exact(yaw, &sn, &cs, static_cast<const double *>(ltab));
+        if (k < steps) lpos[sl * PP + k] = make_double2(cs, sn);
+        if (box) a.trig_out[(size_t)k * a.A + r] = make_double2(cs, sn);
       }
     }
     __syncthreads();

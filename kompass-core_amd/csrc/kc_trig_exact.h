@@ -87,55 +87,58 @@ KC_TRIG_HD double do_sin(double x, double dx, Tab tab) {
 }
 
 // s_sincos.c: __sincos.  Returns false outside the table + Cody-Waite range (NaN, inf, |x| >= 105414350).
+// The library's three argument ranges differ only in how they reach (a, da) with |a + da| < 0.86 and in which
+// of do_sin / do_cos gives which result with which sign; they are restated as ONE evaluation of the pair behind
+// selects (a wavefront whose lanes fall into different ranges runs the polynomials once, not three times).
 template <class Tab>
 KC_TRIG_HD bool sincos_exact(double x, double *sinx, double *cosx, Tab tab) {
   const uint32_t k = static_cast<uint32_t>(Bits::of(x) >> 32) & 0x7fffffffu;
-  if (k < 0x400368fdu) {
-    if (k < 0x3e400000u) {  // |x| < 2^-27
-      *sinx = x;
-      *cosx = 1.0;
-      return true;
-    }
-    if (k < 0x3feb6000u) {  // |x| < 0.855469
-      *sinx = do_sin(x, 0.0, tab);
-      *cosx = do_cos(x, 0.0, tab);
-      return true;
-    }
-    // |x| < 2.426265: through pi/2 - |x|
-    constexpr double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
-    const double y = hp0 - absd(x);
-    const double a = y + hp1;
-    const double da = (y - a) + hp1;
-    *sinx = __builtin_copysign(do_cos(a, da, tab), x);
-    *cosx = do_sin(a, da, tab);
-    return true;
-  }
-  if (k < 0x419921FBu) {  // |x| < 105414350: reduce_sincos
-    constexpr double hpinv = 0x1.45f306dc9c883p-1, toint = 0x1.8p52;
-    constexpr double mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27;
-    constexpr double pp3 = -0x1.cb3b398000000p-55, pp4 = -0x1.d747f23e32ed7p-83;
-    const double t = x * hpinv + toint;
-    const double xn = t - toint;
-    const double y = (x - xn * mp1) - xn * mp2;
-    const int n = static_cast<int>(static_cast<uint32_t>(Bits::of(t))) & 3;
-    double t1 = xn * pp3;
-    const double t2 = y - t1;
-    double db = (y - t2) - t1;
-    t1 = xn * pp4;
-    const double b = t2 - t1;
-    db += (t2 - b) - t1;
-    // do_sincos (a, da, n) and (a, da, n + 1)
-    const double sv = do_sin(b, db, tab), cv = do_cos(b, db, tab);
-    double s = (n & 1) ? cv : sv;
+  if (k >= 0x419921FBu) return false;
+  const bool direct = k < 0x3feb6000u;   // |x| < 0.855469: do_sin (x, 0), do_cos (x, 0)
+  const bool halfpi = k < 0x400368fdu;   // |x| < 2.426265: through pi/2 - |x|
+  // pi/2 - |x|
+  constexpr double hp0 = 0x1.921fb54442d18p+0, hp1 = 0x1.1a62633145c07p-54;
+  const double y2 = hp0 - absd(x);
+  const double a2 = y2 + hp1;
+  const double da2 = (y2 - a2) + hp1;
+  // reduce_sincos
+  constexpr double hpinv = 0x1.45f306dc9c883p-1, toint = 0x1.8p52;
+  constexpr double mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde973c000000p-27;
+  constexpr double pp3 = -0x1.cb3b398000000p-55, pp4 = -0x1.d747f23e32ed7p-83;
+  const double t = x * hpinv + toint;
+  const double xn = t - toint;
+  const double y = (x - xn * mp1) - xn * mp2;
+  const int n = static_cast<int>(static_cast<uint32_t>(Bits::of(t))) & 3;
+  double t1 = xn * pp3;
+  const double t2 = y - t1;
+  double db = (y - t2) - t1;
+  t1 = xn * pp4;
+  const double b = t2 - t1;
+  db += (t2 - b) - t1;
+  const double a = direct ? x : halfpi ? a2 : b;
+  const double da = direct ? 0.0 : halfpi ? da2 : db;
+  const double sv = do_sin(a, da, tab), cv = do_cos(a, da, tab);
+  double s, c;
+  if (direct) {
+    s = sv;
+    c = cv;
+  } else if (halfpi) {
+    s = __builtin_copysign(cv, x);
+    c = sv;
+  } else {  // do_sincos (a, da, n) and (a, da, n + 1)
+    s = (n & 1) ? cv : sv;
     if (n & 2) s = -s;
     const int m = n + 1;
-    double c = (m & 1) ? cv : sv;
+    c = (m & 1) ? cv : sv;
     if (m & 2) c = -c;
-    *sinx = s;
-    *cosx = c;
-    return true;
   }
-  return false;
+  if (k < 0x3e400000u) {  // |x| < 2^-27
+    s = x;
+    c = 1.0;
+  }
+  *sinx = s;
+  *cosx = c;
+  return true;
 }
 
 }  // namespace trig
