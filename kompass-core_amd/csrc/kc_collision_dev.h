@@ -135,7 +135,7 @@ __device__ __forceinline__ double sample_vy(const RollArgs &a, int local) { retu
 #define KC_RSTAMP(slot)                                                    \
   do {                                                                     \
     if (a.dbg && threadIdx.x == 0 && blockIdx.x < 512)                                    \
-      a.dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+      a.dbg[(size_t)blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define KC_RSTAMP(slot) do { } while (0)

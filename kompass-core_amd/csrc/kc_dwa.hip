@@ -2406,18 +2406,19 @@ void kc_dwa_destroy(kc_dwa *c) {
   }
   hipError_t e = hipSetDevice(c->prm.device);
   if (c->debug_stamps && c->d_dbg2.p) {
-    std::vector<unsigned long long> h(512 * 16);
+    std::vector<unsigned long long> h(512 * 32);
     e = hipDeviceSynchronize();
     e = hipMemcpy(h.data(), c->d_dbg2.p, h.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull;
-    for (int b = 0; b < 512; ++b) if (h[b * 16]) t0 = std::min(t0, h[b * 16]);
-    const char *nm[15] = {"start", "bits copied", "flag seen", "trig rows in LDS", "recurrence done", "poses checked", "flags out", "increments done", "costs done", "epilogue done", "pass 0 searched", "pass 0 barrier", "pass 0 total", "poses classified / ticket", "last: reduced"};
+    for (int b = 0; b < 512; ++b) if (h[b * 32]) t0 = std::min(t0, h[b * 32]);
+    const char *nm[20] = {"start", "phase A done", "trig entries in LDS", "increments in LDS", "recurrence done", "poses checked", "flags out", "increments done", "costs done", "epilogue done", "pass 0 searched", "pass 0 barrier", "pass 0 total", "poses classified / ticket", "last: reduced", "", "A: loads issued", "A: window stored", "A: sincos / omega stored", "A: cost tables stored"};
     std::fprintf(stderr, "[kc stamps] roll-out kernel, us since first block start (avg / max):\n");
-    for (int k = 0; k < 15; ++k) {
+    for (int k = 0; k < 20; ++k) {
+      if (k == 15) continue;
       double sm = 0, mx = 0; int nb = 0;
       for (int b = 0; b < 512; ++b) {
-        if (!h[b * 16] || !h[b * 16 + k]) continue;
-        const double us = (h[b * 16 + k] - t0) / 100.0;
+        if (!h[b * 32] || !h[b * 32 + k]) continue;
+        const double us = (h[b * 32 + k] - t0) / 100.0;
         sm += us; mx = std::max(mx, us); ++nb;
       }
       std::fprintf(stderr, "  %-18s %7.2f / %7.2f  (%d blocks)\n", nm[k], nb ? sm / nb : 0.0, mx, nb);
@@ -2425,8 +2426,8 @@ void kc_dwa_destroy(kc_dwa *c) {
     {
       double sm = 0, mx = 0; int nb = 0;
       for (int b = 0; b < 512; ++b) {
-        if (!h[b * 16]) continue;
-        sm += static_cast<double>(h[b * 16 + 15]); mx = std::max(mx, static_cast<double>(h[b * 16 + 15])); ++nb;
+        if (!h[b * 32]) continue;
+        sm += static_cast<double>(h[b * 32 + 15]); mx = std::max(mx, static_cast<double>(h[b * 32 + 15])); ++nb;
       }
       std::fprintf(stderr, "  undecided poses per workgroup (exact shell tests): %.1f / %.0f\n", nb ? sm / nb : 0.0, mx);
     }
@@ -3748,8 +3749,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     a.pvi = cycle ? c->d_cpvi.p : c->d_pvi.p;
 #ifdef KC_PHASE_STAMPS
     if (c->debug_stamps) {
-      KC_TRY(c->d_dbg2.reserve(512 * 16));
-      KC_HIP(hipMemsetAsync(c->d_dbg2.p, 0, 512 * 16 * 8, s));
+      KC_TRY(c->d_dbg2.reserve(512 * 32));
+      KC_HIP(hipMemsetAsync(c->d_dbg2.p, 0, 512 * 32 * 8, s));
       a.dbg = c->d_dbg2.p;
     }
 #endif

@@ -255,9 +255,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   const int steps = a.P - 1;
 
   KC_RSTAMP(0);
-  // ---- A: window bits + trig rows -----------------------------------------
-  // (the sample ids of this workgroup: loads issued here, used behind the table copies -- a wait
-  // for them in front would put wavefront 0 a memory round trip behind the others)
+  // ---- A: window bits, cost tables, trig rows ------------------------------------------------
+  // Host trig table: one round of loads (window, cost tables), the sample ids used behind the copies.
+  // Device trig: the SMALL loads first (sample ids, the table sincos reads, omega values), a barrier, then the
+  // bulk loads are issued and the trig entries are formed from LDS while they are in flight.
   int my_id = 0, my_row = 0;
   uint32_t my_vi = 0u;
   if (tid < rows) {
@@ -265,8 +266,6 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     my_row = a.prow[base + tid];
     my_vi = a.pvi[base + tid];
   }
-  // Cycle: the cost tables' global loads are issued here and land in LDS at the end of the
-  // phase; the window loads below are in flight at the same time.
   __shared__ int lfirst[kFusedSamples];  // device trig: slot -> its leader (the first slot with the same trig row)
   __shared__ int llead[kFusedSamples];   // ... the leaders, ascending
   __shared__ int nlead;
@@ -274,8 +273,32 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ double lom[kTrigOmegaLds];  // ... omega of the trig rows
   const bool box = a.c.enabled && a.c.shape == KC_BOX;
   constexpr int kTabPer = (440 + kFusedBlock - 1) / kFusedBlock, kOmPer = (kTrigOmegaLds + kFusedBlock - 1) / kFusedBlock;
-  double tabv[kTabPer], omv[kOmPer];
+  // the per-slot words of the workgroup (+ device trig: the leaders of the row runs)
+  auto slot_words = [&]() {
+    if (a.trig_dev && tid < 64) {
+      // leaders: a slot whose row differs from the slot in front of it (rows come in runs)
+      const int prev = __shfl_up(my_row, 1, 64);
+      const bool lead = tid < rows && (tid == 0 || prev != my_row);
+      const unsigned long long bal = __ballot(lead);
+      const unsigned long long upto = bal & (~0ull >> (63 - tid));  // leaders at or in front of this slot
+      if (tid < rows) lfirst[tid] = 63 - __clzll(static_cast<long long>(upto));
+      if (lead) llead[__popcll(upto) - 1] = tid;
+      if (tid == 0) nlead = __popcll(bal);
+    }
+    if (tid < kFusedSamples) {
+      lhit[tid] = a.freeze ? 0x7FFFFFFF : 0;  // freeze mode: the FIRST colliding pose index of the sample (minimum)
+      lperm[tid] = my_id;
+      lrow[tid] = my_row;
+      lvi[tid] = my_vi;
+      if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
+    }
+    if (tid == 0) {
+      ncand = 0;
+      ncand2 = 0;
+    }
+  };
   if (a.trig_dev) {
+    double tabv[kTabPer], omv[kOmPer];
 #pragma unroll
     for (int u = 0; u < kTabPer; ++u) {
       const int j = tid + u * kFusedBlock;
@@ -286,85 +309,6 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const int j = tid + u * kFusedBlock;
       omv[u] = (j < kTrigOmegaLds && j < a.A) ? a.omega_values[j] : 0.0;
     }
-  }
-  CycleTabRegs<kFusedBlock> tabregs;
-  if constexpr (kCycle) cycle_tables_load<kFusedBlock>(tail, tid, kFusedBlock, tabregs);
-  if (a.c.enabled && a.c.dil == 2) {
-    // The dilated masks of this sensor update do not exist yet: the raw bits of
-    // the window plus a halo of R rows and one word either way go to LDS, and
-    // the window words are dilated from there exactly as dilate_kernel does
-    // (rows outside the bitmap are skipped, words outside it are empty).
-    const int R = a.dilR;
-    const int hw = a.c.wpr + 2, hh = a.c.H + 2 * R;
-    const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;
-    for (int i = tid; i < hw * hh; i += kFusedBlock) {
-      const int hy = i / hw, hx = i - hy * hw;
-      const int gy = a.c.ky0 + hy - R - a.c.gky0, gw = w0 + hx - 1;
-      uint32_t v = 0u;
-      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) v = a.c.gbits[(size_t)gy * a.c.gwpr + gw];
-      lhalo[i] = v;
-    }
-    __syncthreads();
-    const signed char *win = a.diltab, *wout = a.diltab + kMaxDil + 1;
-    const int nwords = a.c.H * a.c.wpr;
-    for (int i = tid; i < nwords; i += kFusedBlock) {
-      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
-      uint32_t in_acc = 0u, out_acc = 0u;
-      for (int j = -R; j <= R; ++j) {
-        const int gy = a.c.ky0 + cy + j - a.c.gky0;
-        if (gy < 0 || gy >= a.c.gH) continue;
-        const uint32_t *row = lhalo + (cy + j + R) * hw + w;  // [w] = left, [w + 1] = mid, [w + 2] = right
-        const uint32_t left = row[0], mid = row[1], right = row[2];
-        if ((mid | left | right) == 0u) continue;
-        const int aj = j < 0 ? -j : j;
-        if (win[aj] >= 0) in_acc |= hdilate(left, mid, right, win[aj]);
-        if (wout[aj] >= 0) out_acc |= hdilate(left, mid, right, wout[aj]);
-      }
-      // (words of the window outside the bitmap stay empty, as in the copy below)
-      const int gy0 = a.c.ky0 + cy - a.c.gky0, gw0 = w0 + w;
-      const bool inside = gy0 >= 0 && gy0 < a.c.gH && gw0 >= 0 && gw0 < a.c.gwpr;
-      lbits[i] = lhalo[(cy + R) * hw + w + 1];
-      linner[i] = inside ? in_acc : 0u;
-      louter[i] = inside ? out_acc : 0u;
-    }
-  } else if (a.c.enabled) {
-    // window origin is word aligned with the sensor bitmap: whole-word copies (up to three
-    // words of each mask per thread held in registers: all loads first, then the stores)
-    const int nwords = a.c.H * a.c.wpr;
-    const int w0 = (a.c.kx0 - a.c.gkx0) >> 5;  // exact: difference is a multiple of 32
-    for (int i0 = 0; i0 < nwords; i0 += 3 * kFusedBlock) {
-      uint32_t v[3], vi[3], vo[3];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int i = i0 + tid + u * kFusedBlock;
-        v[u] = vi[u] = vo[u] = 0u;
-        if (i < nwords) {
-          const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
-          const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
-          if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
-            const size_t g = (size_t)gy * a.c.gwpr + gw;
-            v[u] = a.c.gbits[g];
-            if (a.c.dil) {
-              vi[u] = a.c.ginner[g];
-              vo[u] = a.c.gouter[g];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int i = i0 + tid + u * kFusedBlock;
-        if (i < nwords) {
-          lbits[i] = v[u];
-          if (a.c.dil) {
-            linner[i] = vi[u];
-            louter[i] = vo[u];
-          }
-        }
-      }
-    }
-  }
-  if (a.trig_dev) {
 #pragma unroll
     for (int u = 0; u < kTabPer; ++u) {
       const int j = tid + u * kFusedBlock;
@@ -375,66 +319,136 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const int j = tid + u * kFusedBlock;
       if (j < kTrigOmegaLds) lom[j] = omv[u];
     }
-  }
-  if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, kFusedBlock, tabregs);
-  if (a.trig_dev && tid < 64) {
-    // leaders: a slot whose row differs from the slot in front of it (rows come in runs)
-    const int prev = __shfl_up(my_row, 1, 64);
-    const bool lead = tid < rows && (tid == 0 || prev != my_row);
-    const unsigned long long bal = __ballot(lead);
-    const unsigned long long upto = bal & (~0ull >> (63 - tid));  // leaders at or in front of this slot
-    if (tid < rows) lfirst[tid] = 63 - __clzll(static_cast<long long>(upto));
-    if (lead) llead[__popcll(upto) - 1] = tid;
-    if (tid == 0) nlead = __popcll(bal);
-  }
-  if (tid < kFusedSamples) {
-    lhit[tid] = a.freeze ? 0x7FFFFFFF : 0;  // freeze mode: the FIRST colliding pose index of the sample (minimum)
-    lperm[tid] = my_id;
-    lrow[tid] = my_row;
-    lvi[tid] = my_vi;
-    if constexpr (kCycle) lpos[tid * PP + PP - 1] = make_double2(a.x0, a.y0);  // spare slot of the row: pose 0
-  }
-  if (tid == 0) {
-    ncand = 0;
-    ncand2 = 0;
-  }
-  KC_RSTAMP(1);
-  if (a.trig_dev) {
-    // {cos, sin}(yaw_k) of every distinct row into the LDS pose row of its leader, a lane per entry; then
-    // every sample forms its increments from its leader's entries -- followers first, the leaders in place
-    // behind a barrier
+    slot_words();
     __syncthreads();
-    {
-      const int L = nlead;
-      int sh = 0;
-      while ((1 << sh) < L) ++sh;
-      const int ktop = steps + (box ? 1 : 0);  // (boxes: yaw of the last pose too, for the exact tests)
-      for (int i = tid; i < (ktop << sh); i += kFusedBlock) {
-        const int l = i & ((1 << sh) - 1), k = i >> sh;
-        if (l >= L) continue;
-        const int sl = llead[l], r = lrow[sl];
-        const double w = (r < kTrigOmegaLds ? lom[r] : a.omega_values[r]) * a.dt;
-        double yaw = a.yaw0;
-        int q = 0;
-        for (; q + 4 <= k; q += 4) yaw = (((yaw + w) + w) + w) + w;
-        for (; q < k; ++q) yaw += w;
-        double sn, cs;
-        trig::sincos_exact(yaw, &sn, &cs, static_cast<const double *>(ltab));
-        if (k < steps) lpos[sl * PP + k] = make_double2(cs, sn);
-        if (box) a.trig_out[(size_t)k * a.A + r] = make_double2(cs, sn);
+  }
+  // the bulk loads: cost tables (cycle) and the first round of the window words, into registers
+  CycleTabRegs<kFusedBlock> tabregs;
+  if constexpr (kCycle) cycle_tables_load<kFusedBlock>(tail, tid, kFusedBlock, tabregs);
+  const bool win = a.c.enabled && a.c.dil != 2;
+  const int nwords = a.c.enabled ? a.c.H * a.c.wpr : 0;
+  const int w0 = a.c.enabled ? (a.c.kx0 - a.c.gkx0) >> 5 : 0;  // exact: difference is a multiple of 32
+  // window origin is word aligned with the sensor bitmap: whole-word copies (up to three
+  // words of each mask per thread held in registers: all loads first, then the stores)
+  auto win_load = [&](int i0, uint32_t(&v)[3], uint32_t(&vi)[3], uint32_t(&vo)[3]) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = i0 + tid + u * kFusedBlock;
+      v[u] = vi[u] = vo[u] = 0u;
+      if (i < nwords) {
+        const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
+        const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
+        if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
+          const size_t g = (size_t)gy * a.c.gwpr + gw;
+          v[u] = a.c.gbits[g];
+          if (a.c.dil) {
+            vi[u] = a.c.ginner[g];
+            vo[u] = a.c.gouter[g];
+          }
+        }
       }
     }
-    __syncthreads();
-    KC_RSTAMP(2);
-    const int s = tid & (kFusedSamples - 1);
-    const bool mine = s < rows;
-    const int f = mine ? lfirst[s] : 0;
-    double vx = 0.0, vy = 0.0;
+  };
+  auto win_store = [&](int i0, const uint32_t(&v)[3], const uint32_t(&vi)[3], const uint32_t(&vo)[3]) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = i0 + tid + u * kFusedBlock;
+      if (i < nwords) {
+        lbits[i] = v[u];
+        if (a.c.dil) {
+          linner[i] = vi[u];
+          louter[i] = vo[u];
+        }
+      }
+    }
+  };
+  uint32_t wv[3], wvi[3], wvo[3];
+  if (win) win_load(0, wv, wvi, wvo);
+  // device trig: the sample's velocity (for the increments) and {cos, sin}(yaw_k) of every distinct row into
+  // the LDS pose row of its leader, a lane per entry -- LDS and VALU only, under the loads just issued
+  const int s = tid & (kFusedSamples - 1);
+  const bool mine = s < rows;
+  double vx = 0.0, vy = 0.0;
+  if (a.trig_dev) {
     if (mine) {
       const uint32_t vi = lvi[s];
       vx = a.vxt[vi & 0xFFFFu];
       vy = a.vyt[vi >> 16];
     }
+    const int L = nlead;
+    int sh = 0;
+    while ((1 << sh) < L) ++sh;
+    const int ktop = steps + (box ? 1 : 0);  // (boxes: yaw of the last pose too, for the exact tests)
+    for (int i = tid; i < (ktop << sh); i += kFusedBlock) {
+      const int l = i & ((1 << sh) - 1), k = i >> sh;
+      if (l >= L) continue;
+      const int sl = llead[l], r = lrow[sl];
+      double om;
+      if (r < kTrigOmegaLds) om = lom[r];
+      else om = a.omega_values[r];
+      const double w = om * a.dt;
+      double yaw = a.yaw0;
+      int q = 0;
+      for (; q + 4 <= k; q += 4) yaw = (((yaw + w) + w) + w) + w;
+      for (; q < k; ++q) yaw += w;
+      double sn, cs;
+      trig::sincos_exact(yaw, &sn, &cs, static_cast<const double *>(ltab));
+      if (k < steps) lpos[sl * PP + k] = make_double2(cs, sn);
+      if (box) a.trig_out[(size_t)k * a.A + r] = make_double2(cs, sn);
+    }
+  }
+  if (a.c.enabled && a.c.dil == 2) {
+    // The dilated masks of this sensor update do not exist yet: the raw bits of
+    // the window plus a halo of R rows and one word either way go to LDS, and
+    // the window words are dilated from there exactly as dilate_kernel does
+    // (rows outside the bitmap are skipped, words outside it are empty).
+    const int R = a.dilR;
+    const int hw = a.c.wpr + 2, hh = a.c.H + 2 * R;
+    for (int i = tid; i < hw * hh; i += kFusedBlock) {
+      const int hy = i / hw, hx = i - hy * hw;
+      const int gy = a.c.ky0 + hy - R - a.c.gky0, gw = w0 + hx - 1;
+      uint32_t v = 0u;
+      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) v = a.c.gbits[(size_t)gy * a.c.gwpr + gw];
+      lhalo[i] = v;
+    }
+    __syncthreads();
+    const signed char *dwin = a.diltab, *dwout = a.diltab + kMaxDil + 1;
+    for (int i = tid; i < nwords; i += kFusedBlock) {
+      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
+      uint32_t in_acc = 0u, out_acc = 0u;
+      for (int j = -R; j <= R; ++j) {
+        const int gy = a.c.ky0 + cy + j - a.c.gky0;
+        if (gy < 0 || gy >= a.c.gH) continue;
+        const uint32_t *row = lhalo + (cy + j + R) * hw + w;  // [w] = left, [w + 1] = mid, [w + 2] = right
+        const uint32_t left = row[0], mid = row[1], right = row[2];
+        if ((mid | left | right) == 0u) continue;
+        const int aj = j < 0 ? -j : j;
+        if (dwin[aj] >= 0) in_acc |= hdilate(left, mid, right, dwin[aj]);
+        if (dwout[aj] >= 0) out_acc |= hdilate(left, mid, right, dwout[aj]);
+      }
+      // (words of the window outside the bitmap stay empty, as in the copy below)
+      const int gy0 = a.c.ky0 + cy - a.c.gky0, gw0 = w0 + w;
+      const bool inside = gy0 >= 0 && gy0 < a.c.gH && gw0 >= 0 && gw0 < a.c.gwpr;
+      lbits[i] = lhalo[(cy + R) * hw + w + 1];
+      linner[i] = inside ? in_acc : 0u;
+      louter[i] = inside ? out_acc : 0u;
+    }
+  } else if (win) {
+    win_store(0, wv, wvi, wvo);
+    for (int i0 = 3 * kFusedBlock; i0 < nwords; i0 += 3 * kFusedBlock) {
+      win_load(i0, wv, wvi, wvo);
+      win_store(i0, wv, wvi, wvo);
+    }
+  }
+  if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, kFusedBlock, tabregs);
+  if (!a.trig_dev) slot_words();
+  KC_RSTAMP(1);
+  if (a.trig_dev) {
+    // every sample forms its increments from its leader's entries -- followers first, the leaders in place
+    // behind a barrier
+    __syncthreads();
+    KC_RSTAMP(2);
+    const int f = mine ? lfirst[s] : 0;
     //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt   (datatypes/path.h:24-30)
     if (mine && f != s)
       for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
@@ -657,7 +671,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       nc = ncand2;
     }
 #ifdef KC_PHASE_STAMPS
-    if (a.dbg && tid == 0 && blockIdx.x < 512) a.dbg[(size_t)blockIdx.x * 16 + 15] = static_cast<unsigned long long>(nc);
+    if (a.dbg && tid == 0 && blockIdx.x < 512) a.dbg[(size_t)blockIdx.x * 32 + 15] = static_cast<unsigned long long>(nc);
 #endif
     // 2, 4 or 8 lanes per undecided pose when the queue is short enough for that (the rows of the
     // voxel window go round the lanes: each exact test is a chain of dependent LDS reads and f64
