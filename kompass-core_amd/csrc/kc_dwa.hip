@@ -114,6 +114,15 @@ struct kc_dwa {
   std::vector<int> cell_id, cell_cursor;  // bucketing scratch (reused)
   std::vector<uint8_t> skip_pad;
   int test_late_flag_ms = 0;            // KC_TEST_LATE_FLAG_MS: delay the trig sequence word once
+  // ... and a cycle that follows a sensor update finds its table made already: the sensor build launch carries
+  // a few workgroups that form it for the update's yaw, the current lattice and the last horizon (TrigJob)
+  bool trig_plan = false;               // kc_dwa_set_points / set_scan: a job may ride in this update's launch
+  double trig_plan_yaw = 0.0;
+  bool trig_ahead_valid = false;        // d_trig holds the table of (trig_ahead_yaw, trig_ahead_P, trig_ahead_lat)
+  double trig_ahead_yaw = 0.0;
+  size_t trig_ahead_P = 0;
+  unsigned long long trig_ahead_lat = 0, lat_version = 0;  // lattice uploads (upload_samples)
+  long long trig_rides = 0;             // get_option "trig_rides"
   bool device_trig = true;              // option "device_trig" / KC_DEVICE_TRIG: cos / sin(yaw_k) formed by the kernels
                                         // (kc_trig_exact.h); off: the host's libm table over the BAR (rounds 1-3)
   bool early_launch = true;             // fused kernel queued before the trig table exists
@@ -810,6 +819,7 @@ int upload_samples(kc_dwa *c) {
   const bool same = n == c->up_n && ((lat.signature != 0 && lat.signature == c->up_sig) ||
                                      (lat.signature == 0 && c->up_sig == 0 && c->uploaded_rows == lat.row &&
                                       c->up_ix == lat.ix && c->up_iy == lat.iy));
+  ++c->lat_version;
   c->shard_first = 0;
   c->shard_count = n;
   if (!same) c->perm_valid = false;  // (the orders also belong to one shard: perm_first / perm_count)
@@ -1059,6 +1069,40 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
 
 // the part behind the bounds; xyz == nullptr: the points are in d_raw already
 // (grid hand-off)
+// The trig job of a sensor update (SensorArgs::trig): only for a context that has run a cycle (the horizon), whose
+// lattice is on the device and whose yaw chain stays inside the range of kc_trig_exact.h.
+int plan_trig_job(kc_dwa *c, TrigJob &j) {
+  j = TrigJob{};
+  c->trig_ahead_valid = false;  // (whatever follows overwrites or outdates the table)
+  const size_t A = c->lat.omega_values.size(), P = c->P;
+  if (!c->trig_plan || !c->device_trig || !trig_selfcheck_ok() || A == 0 || P < 2 || !c->d_omega.p || c->d_omega.cap < A ||
+      !std::isfinite(c->trig_plan_yaw))
+    return KC_OK;
+  const double dt = static_cast<double>(static_cast<float>(c->prm.time_step));
+  double om_max = 0.0;
+  for (double v : c->lat.omega_values) om_max = std::max(om_max, std::fabs(v));
+  const double reach = std::fabs(c->trig_plan_yaw) + om_max * dt * static_cast<double>(P);
+  if (!(reach < 1.0e8)) return KC_OK;
+  KC_TRY(c->d_trig.reserve(A * P));
+  if (!c->d_sincostab.p) {
+    KC_TRY(c->d_sincostab.reserve(440));
+    KC_HIP(hipMemcpyAsync(c->d_sincostab.p, kc_sincostab_host, sizeof(kc_sincostab_host), hipMemcpyHostToDevice, c->stream));
+    KC_HIP(hipStreamSynchronize(c->stream));
+  }
+  j.yaw0 = c->trig_plan_yaw;
+  j.dt = dt;
+  j.omega = c->d_omega.p;
+  j.tab = c->d_sincostab.p;
+  j.out = c->d_trig.p;
+  j.A = static_cast<int>(A);
+  j.P = static_cast<int>(P);
+  j.nblk = static_cast<int>(std::min<size_t>(32, (A * P + kSensorBlock - 1) / kSensorBlock));
+  c->trig_ahead_yaw = c->trig_plan_yaw;
+  c->trig_ahead_P = P;
+  c->trig_ahead_lat = c->lat_version;
+  return KC_OK;
+}
+
 int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
                                  const float hi[3], bool *done, bool raw_copied) {
   *done = false;
@@ -1169,6 +1213,12 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   a.obs_z_zero = c->raw_is_scan ? 1 : 0;
   KC_TRY(c->d_dc_enable.reserve(1));
   a.dc_enable = c->d_dc_enable.p;
+  KC_TRY(plan_trig_job(c, a.trig));
+  const unsigned tj = static_cast<unsigned>(a.trig.nblk);
+  if (tj) {
+    c->trig_ahead_valid = true;
+    ++c->trig_rides;
+  }
   if (!big) {
     const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
     const size_t olds = 2 * static_cast<size_t>(c->onear_args.n) * sizeof(float);
@@ -1176,12 +1226,12 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
     if (ride) {
       const int cells = c->onear_args.W * c->onear_args.H, per = kSensorBlock / kObsNearLanes;
-      hipLaunchKernelGGL(sensor_build_scan_kernel<true>, dim3(1 + (cells + per - 1) / per), dim3(kSensorBlock),
+      hipLaunchKernelGGL(sensor_build_scan_kernel<true>, dim3(1 + (cells + per - 1) / per + tj), dim3(kSensorBlock),
                          std::max(lds, olds), c->stream, a, c->onear_args);
       c->onear_version = c->sensor_version;
       ++c->onear_rides;
     } else {
-      hipLaunchKernelGGL(sensor_build_kernel, dim3(1), dim3(kSensorBlock), lds, c->stream, a);
+      hipLaunchKernelGGL(sensor_build_kernel, dim3(1 + tj), dim3(kSensorBlock), lds, c->stream, a);
     }
     KC_TRY(c->timing.stop(c->stream));
   } else {
@@ -1204,7 +1254,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     }
 #endif
     KC_TRY(c->timing.start("sensor_points_kernel", c->stream));
-    hipLaunchKernelGGL(sensor_points_kernel, dim3(sb.rows), dim3(kSensorBlock), 0, c->stream, sb);
+    hipLaunchKernelGGL(sensor_points_kernel, dim3(sb.rows + tj), dim3(kSensorBlock), 0, c->stream, sb);
     KC_TRY(c->timing.stop(c->stream));
     KC_TRY(c->timing.start("sensor_place_kernel", c->stream));
     const unsigned pack_blocks = std::min(240u, blocks_for(nwords, kSensorBlock));  // pack-only workgroups behind the rows
@@ -2669,6 +2719,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "obs_near_builds") *v = static_cast<double>(c->onear_builds);  // read-only
   else if (n == "early_launch") *v = c->early_launch;
   else if (n == "device_trig") *v = c->device_trig && trig_selfcheck_ok();
+  else if (n == "trig_rides") *v = static_cast<double>(c->trig_rides);  // read-only
   else if (n == "sensor_on_host") *v = !c->device_sensor;
   else if (n == "trig_copy") *v = !c->trig_direct;
   else if (n == "force_split") *v = c->lds_limit == 0;
@@ -2965,7 +3016,10 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   c->onear_ahead = false;
   if (!c->tilted) {
     if (c->obs_near_ahead) KC_TRY(onear_plan_ahead(c, st->x, st->y));
+    c->trig_plan = true;  // (the launch of this update may carry the trig table of the cycle that follows)
+    c->trig_plan_yaw = st->yaw;
     const int rc = sensor_update_device(c, c->scan_xyz.data(), n, &done);
+    c->trig_plan = false;
     c->onear_ahead = false;
     KC_TRY(rc);
   }
@@ -3001,7 +3055,11 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
   c->max_obs_dist = max_range / 3.0f;
   c->host_lists_valid = true;
   bool done = false;
-  KC_TRY(sensor_update_device(c, xyz, n, &done));
+  c->trig_plan = true;  // (the launch of this update may carry the trig table of the cycle that follows)
+  c->trig_plan_yaw = st->yaw;
+  const int rc_dev = sensor_update_device(c, xyz, n, &done);
+  c->trig_plan = false;
+  KC_TRY(rc_dev);
   if (done) {
     if (c->debug_stamps)
       std::fprintf(stderr, "[kc] set_points (device build): sync %.1f | host part %.1f us\n",
@@ -3525,6 +3583,14 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     const double reach = std::fabs(yaw0) + om_max * dt * static_cast<double>(P);
     dev_trig = std::isfinite(reach) && reach < 1.0e8;
   }
+  // ... or the table is there already: formed inside the launch of the sensor update this cycle follows
+  // (plan_trig_job), for this yaw, this lattice and this horizon
+  bool table_ahead = false;
+  if (dev_trig && c->trig_ahead_valid) {
+    table_ahead = P == c->trig_ahead_P && c->lat_version == c->trig_ahead_lat && c->d_trig.cap >= A * P &&
+                  std::memcmp(&yaw0, &c->trig_ahead_yaw, sizeof(double)) == 0;
+  }
+  if (!table_ahead) c->trig_ahead_valid = false;  // (d_trig is about to be rewritten, or belongs to another pose)
   if (dev_trig) trig_ready = true;  // (nothing for the host to produce)
   const bool trig_ahead = !trig_ready && c->trig_direct && c->early_launch && !c->timing.enabled;
   struct PoolJoin {  // an error return below must not leave this call's job running
@@ -3599,7 +3665,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   a.vidx = c->d_vidx.p;
   a.row = c->d_row.p;
   a.trig = c->d_trig.p;
-  a.trig_dev = dev_trig ? 1 : 0;
+  a.trig_dev = (dev_trig && !table_ahead) ? 1 : 0;
   if (dev_trig && !c->d_sincostab.p) {
     KC_TRY(c->d_sincostab.reserve(440));
     KC_HIP(hipMemcpyAsync(c->d_sincostab.p, kc_sincostab_host, sizeof(kc_sincostab_host), hipMemcpyHostToDevice, s));
@@ -3729,7 +3795,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     else if (!trig_ready) WorkerPool::instance().parallel_for(A, 2, trig_rows);
     c->timing.mark("host:trig_table");
     if (dev_trig) {
-      if (!fused) {  // the split path's kernels read a table: filled on the device, in stream order
+      if (!fused && !table_ahead) {  // the split path's kernels read a table: filled on the device, in stream order
         KC_TRY(c->timing.start("trig_table_kernel", s));
         hipLaunchKernelGGL(trig_table_kernel, dim3(blocks_for(A, kTrigRows)), dim3(kTrigBlock),
                            static_cast<size_t>(kTrigRows) * P * sizeof(double), s, yaw0, c->d_omega.p, dt,

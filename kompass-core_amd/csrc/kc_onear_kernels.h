@@ -145,6 +145,10 @@ __global__ __launch_bounds__(kObsNearBlock) void obs_near_kernel(ObsNearArgs a) 
 template <bool kLds>
 __global__ __launch_bounds__(kSensorBlock) void sensor_build_scan_kernel(SensorArgs a, ObsNearArgs o) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (blockIdx.x >= gridDim.x - a.trig.nblk) {
+    trig_job_block<kSensorBlock>(a.trig, static_cast<int>(blockIdx.x - (gridDim.x - a.trig.nblk)));
+    return;
+  }
   if (blockIdx.x == 0) sensor_build_body(a, smem);
   else obs_near_body<kLds, kSensorBlock>(o, static_cast<int>(blockIdx.x) - 1, smem);
 }

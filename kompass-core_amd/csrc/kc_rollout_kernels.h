@@ -41,6 +41,33 @@ __global__ __launch_bounds__(kTrigBlock) void trig_table_kernel(double yaw0, con
   }
 }
 
+// The same table as a JOB that rides in another launch (the sensor build of a controller cycle with fresh
+// inputs: a few extra workgroups on CUs that launch leaves idle).  A lane per entry, yaw_k by the lane's own
+// repeated additions; consecutive lanes take consecutive rows of one step (coalesced stores).  `tab` is the
+// context's copy of the 440 table values in device memory.
+struct TrigJob {
+  double yaw0, dt;
+  const double *omega, *tab;
+  double2 *out;  // [P][A]
+  int A, P;
+  int nblk;      // workgroups of the carrying launch that belong to the job (the LAST nblk); 0: no job
+};
+template <int kBlock>
+__device__ __forceinline__ void trig_job_block(const TrigJob &j, int blk) {
+  const int total = j.A * j.P;
+  for (int i = blk * kBlock + static_cast<int>(threadIdx.x); i < total; i += j.nblk * kBlock) {
+    const int k = i / j.A, r = i - k * j.A;
+    const double w = j.omega[r] * j.dt;
+    double yaw = j.yaw0;
+    int q = 0;
+    for (; q + 4 <= k; q += 4) yaw = (((yaw + w) + w) + w) + w;
+    for (; q < k; ++q) yaw += w;
+    double sn, cs;
+    trig::sincos_exact(yaw, &sn, &cs, j.tab);
+    j.out[i] = make_double2(cs, sn);
+  }
+}
+
 // ===========================================================================
 // K1a: roll-out.  One lane per sample: the recurrence x_{k+1} = x_k + (...) is
 // serial in k and keeps the reference's addition order (path.h:24-30).  The

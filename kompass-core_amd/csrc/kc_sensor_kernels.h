@@ -12,6 +12,7 @@
 namespace kc {
 
 struct SensorArgs {
+  TrigJob trig;      // the cycle's cos / sin table, formed by the last trig.nblk workgroups of the launch
   const float *xyz;  // [n][3]
   int n;
   // voxel acceptance (add_voxel)
@@ -201,6 +202,10 @@ __device__ __forceinline__ void sensor_build_body(const SensorArgs &a, unsigned 
 
 __global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+  if (blockIdx.x >= gridDim.x - a.trig.nblk) {
+    trig_job_block<kSensorBlock>(a.trig, static_cast<int>(blockIdx.x - (gridDim.x - a.trig.nblk)));
+    return;
+  }
   sensor_build_body(a, smem);
 }
 
@@ -249,6 +254,10 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_points_kernel(SensorBigAr
   const SensorArgs &a = b.a;
   __shared__ __align__(16) int lhist[kHistRow];
   const int tid = threadIdx.x;
+  if (static_cast<int>(blockIdx.x) >= b.rows) {  // (the workgroups behind the rows: the trig job)
+    trig_job_block<kSensorBlock>(a.trig, static_cast<int>(blockIdx.x) - b.rows);
+    return;
+  }
   KC_SSTAMP(blockIdx.x, 0);
   reinterpret_cast<int4 *>(lhist)[tid] = make_int4(0, 0, 0, 0);
   __syncthreads();

@@ -110,3 +110,58 @@ def test_cycles_with_and_without_device_trig_equal_the_oracle(cfg, scale, scene,
             assert ctx.get_option("device_trig") == float(opts.get("device_trig", 1))
             assert_cycle_equal(o, hip_cycle(kh, cur, ctx=ctx))
             ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,scale,scan", [("cfg2", 0.5, False), ("cfg2", 1.0, False), ("cfg1", 1.0, False), ("cfg2", 0.5, True)])
+def test_table_riding_in_the_sensor_launch(cfg, scale, scan):
+    """A cycle that follows a sensor update finds its trig table formed inside that update's launch (same yaw,
+    lattice, horizon); a cycle at another yaw, or behind a new lattice, forms its own.  Every cycle equals the
+    oracle; `trig_rides` counts the launches that carried a table."""
+    import synthetic as syn
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import assert_cycle_equal, hip_context, hip_cycle, oracle_cycle
+
+    inp = syn.make_controller_inputs(cfg, seed=2, scale=scale, scene="mid")
+    sc = None
+    if scan:
+        ang = np.linspace(-np.pi, np.pi, 720, endpoint=False)
+        sc = (ang, 2.5 + 0.8 * np.sin(3 * ang))
+    ctx = hip_context(kh, inp)
+    rides = []
+    for i, yaw in enumerate((0.0, 0.4, 0.4, -2.2, 3.0)):
+        cur = dict(inp, state=(0.02 * i, -0.01 * i, yaw, 0.0))
+        o = oracle_cycle(cur, scan=sc) if scan else oracle_cycle(cur)
+        assert_cycle_equal(o, hip_cycle(kh, cur, scan=sc, ctx=ctx))     # set_points / set_scan, segment, samples, cycle
+        rides.append(ctx.get_option("trig_rides"))
+    assert rides[0] == 0 and rides[-1] >= 3, rides                       # (the first update knows no horizon yet)
+    # the update's yaw is not the cycle's: the kernel forms its own rows
+    st_a, st_b = (0.0, 0.0, 0.3, 0.0), (0.0, 0.0, -0.9, 0.0)
+    ctx.set_weights(kh.make_weights(*inp["weights"]))
+    if scan:
+        ctx.set_scan(st_a, sc[0], sc[1], inp["max_range"])
+    else:
+        ctx.set_points(st_a, inp["points"], inp["max_range"])
+    r = ctx.cycle(st_b, inp["P"])
+    ctx2 = hip_context(kh, inp)
+    ctx2.set_option("device_trig", 0)
+    ctx2.set_weights(kh.make_weights(*inp["weights"]))
+    if scan:
+        ctx2.set_scan(st_a, sc[0], sc[1], inp["max_range"])
+    else:
+        ctx2.set_points(st_a, inp["points"], inp["max_range"])
+    ctx2.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+    ctx2.set_samples(inp["vx"], inp["vy"], inp["omega"])
+    r2 = ctx2.cycle(st_b, inp["P"])
+    assert (r.found, r.index, r.raw_index, r.n_admissible) == (r2.found, r2.index, r2.raw_index, r2.n_admissible)
+    assert np.float32(r.cost) == np.float32(r2.cost)
+    # a new lattice between the update and the cycle
+    ctx.set_points(st_a, inp["points"], inp["max_range"]) if not scan else ctx.set_scan(st_a, sc[0], sc[1], inp["max_range"])
+    ctx.set_samples(inp["vx"] * 0.9, inp["vy"] * 0.9, inp["omega"] * 0.8)
+    ctx2.set_samples(inp["vx"] * 0.9, inp["vy"] * 0.9, inp["omega"] * 0.8)
+    ctx2.set_points(st_a, inp["points"], inp["max_range"]) if not scan else ctx2.set_scan(st_a, sc[0], sc[1], inp["max_range"])
+    r, r2 = ctx.cycle(st_a, inp["P"]), ctx2.cycle(st_a, inp["P"])
+    assert (r.found, r.index, r.raw_index, r.n_admissible) == (r2.found, r2.index, r2.raw_index, r2.n_admissible)
+    assert np.float32(r.cost) == np.float32(r2.cost)
+    ctx.close(); ctx2.close()
