@@ -294,6 +294,9 @@ def controller_bench(args, rank, world, local_rank):
                          "three kernels" + (" (--split)" if args.split else " (kc_dwa_cycle keeps them beyond one resident "
                                             "wave of workgroups and for small shards with many survivors)"),
                 "parallelism": f"sample-shard x{world}" if world > 1 else "single GPU",
+                "trig": ("device: the roll-out kernel evaluates glibc's sincos algorithm itself, bit-equal to the host libm "
+                         "(csrc/kc_trig_exact.h); no host table, no host threads in the cycle"
+                         if ctx.get_option("device_trig") else "host libm table over the BAR (KC_DEVICE_TRIG=0)"),
             },
             "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
             "latency_min_ms": float(np.min(lat) * 1e3), "latency_max_ms": float(np.max(lat) * 1e3),

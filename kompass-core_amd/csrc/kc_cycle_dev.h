@@ -416,8 +416,26 @@ __device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &ta
   }
   for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
   if (lane == 0) s_wcnt[wave] = cnt;
+  if (tail.xs) {
+    // the rank's words of the exchange record: its bitmap (the words this workgroup holds in registers)
+    uint32_t *region = reinterpret_cast<uint32_t *>(tail.xs + X_REGIONS + static_cast<size_t>(tail.xrank) * tail.xrw);
+#pragma unroll
+    for (int u = 0; u < kMaxWords; ++u) {
+      const unsigned w = tid + u * kBlock;
+      if (w < 2u * static_cast<unsigned>(tail.xrw)) region[w] = w >= nwords ? 0u : wreg[u];  // (a late cycle left no survivors: zeros)
+    }
+  }
   __syncthreads();
   KC_RSTAMP(14);
+  if (tid == 0 && tail.xs) {
+    long long key = fkey;
+    if (key != KEY_NONE && tail.xgid) {
+      const uint32_t lat = static_cast<uint32_t>(key & 0xFFFFFFFFll);
+      key = (key & ~0xFFFFFFFFll) | static_cast<long long>(static_cast<uint32_t>(tail.xgid[lat]));
+    }
+    tail.xs[X_KEY] = err ? KEY_NONE : key;
+    tail.xs[X_ERR] = err ? -1ll : 0ll;
+  }
   if (tid == 0) {
     int s = 0;
     for (int w = 0; w < kBlock / 64; ++w) s += s_wcnt[w];

@@ -28,12 +28,12 @@
 
 #include "kc_collision_dev.h"
 #include "kc_cost_kernels.h"
+#include "kc_shard.h"
 #include "kc_cycle_dev.h"
 #include "kc_rollout_kernels.h"
 #include "kc_sensor_kernels.h"
 #include "kc_segment_kernels.h"
 #include "kc_onear_kernels.h"
-#include "kc_shard.h"
 #include "kc_tilt_dev.h"
 
 // ===========================================================================
@@ -285,6 +285,9 @@ struct kc_dwa {
   PinBuf<long long> h_slots;   // [grid][4]
   std::vector<int32_t> h_dealt;     // host copy of the dealt order (compacted index of the winner)
   std::vector<uint64_t> slot_pending;   // scratch of fetch_slots
+  long long *xchg_send = nullptr;  // sharded call: the send record, this rank, words per rank (set by kc_dwa_cycle_sharded)
+  int xchg_rank = 0, xchg_rw = 0;
+  bool xchg_packed = false;        // ... and the cycle kernel of this call has written the rank's words itself
   bool sharded_call = false;   // kc_dwa_cycle_sharded: the cycle kernel leaves the host record to the
                                // hand-off behind the all-reduce
   long long rec_w4 = 0;        // row word of the record fetched last
@@ -3851,6 +3854,12 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       }
       tail.seq = ++c->seq;
       tail.c.block_keys = c->d_block_keys.p;
+      // sharded call: the last workgroup also writes this rank's words of the exchange record (no pack launch)
+      tail.xs = c->sharded_call ? c->xchg_send : nullptr;
+      tail.xgid = c->gid.empty() ? nullptr : c->d_gid.p;
+      tail.xrank = c->xchg_rank;
+      tail.xrw = c->xchg_rw;
+      c->xchg_packed = tail.xs != nullptr;
       a.dev_err = c->d_result.p + W_NADM;
     }
     if (early) {
@@ -4467,13 +4476,19 @@ int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P,
   // ---- this rank's cycle.  From here on the rank takes part in the exchange whatever happens:
   // a failure travels in the record's error word and fails the cycle on EVERY rank.
   c->sharded_call = true;
+  c->xchg_send = c->d_xs.p;
+  c->xchg_rank = rank;
+  c->xchg_rw = static_cast<int>(rw);
+  c->xchg_packed = false;
   int rc = rollout_impl(c, start, P, true);
   c->sharded_call = false;
   if (rc == KC_OK && !c->cycle_launched) rc = kc_dwa_evaluate(c);
   std::string why;
   if (rc != KC_OK) why = kc_last_error();
   c->pub_pending = false;  // (a sharded cycle hands its record over through the exchange, not h_pub)
-  if (rc == KC_OK) {
+  if (rc == KC_OK && c->cycle_launched && c->xchg_packed) {
+    // (the single-launch cycle's last workgroup has written this rank's words: cycle_epilogue)
+  } else if (rc == KC_OK) {
     PackArgs pa{};
     pa.result = c->d_result.p;
     pa.flags = c->d_flags.p;

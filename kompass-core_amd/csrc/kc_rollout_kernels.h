@@ -255,6 +255,12 @@ struct CycleTail {
   // from the dealt order it built itself).  No drain, no ticket, no round trip on
   // the device.  Null: the ticket epilogue (device record for the all-reduce).
   long long *host_slots;          // pinned: [grid][4]
+  // kc_dwa_cycle_sharded: the last workgroup writes this rank's part of the exchange record (kc_shard.h: best
+  // key with the GLOBAL raw index, error word, admissible bitmap by share-local id) -- what xchg_pack_kernel
+  // does behind the three-kernel cycle.  Null: no exchange.
+  long long *xs;
+  const int32_t *xgid;            // share-local lattice id -> global id (null: identity)
+  int xrank, xrw;
 };
 
 template <int kFusedSamples, int kFusedBlock, class Tail = NoTail>
