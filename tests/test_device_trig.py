@@ -83,6 +83,29 @@ def test_device_table_random_rows():
 
 
 @pytest.mark.gpu
+def test_device_table_quarter_million_entries():
+    """250 000 entries in one table (2 500 rows x 100 steps, yaw chains from -40 to 40 rad: every branch of the
+    algorithm, every quadrant of the reduction) against the host's sincos."""
+    rng = np.random.default_rng(11)
+    A, P, dt = 2500, 100, 0.05
+    omega = rng.uniform(-8.0, 8.0, size=A)
+    got = kh.trig_table(-0.37, omega, P, dt)
+    libm = ctypes.CDLL("libm.so.6")
+    libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    libm.sincos.restype = None
+    yaw = np.full(A, -0.37)
+    w = omega * dt                      # (elementwise IEEE products and sums: the kernel's chain)
+    want = np.empty((P, A, 2))
+    s, c = ctypes.c_double(), ctypes.c_double()
+    for k in range(P):
+        for r in range(A):
+            libm.sincos(float(yaw[r]), ctypes.byref(s), ctypes.byref(c))
+            want[k, r] = (c.value, s.value)
+        yaw = yaw + w
+    np.testing.assert_array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+@pytest.mark.gpu
 def test_table_outside_the_range_is_refused():
     with pytest.raises(Exception):
         kh.trig_table(2.0e8, [0.0], 4, 0.05)
