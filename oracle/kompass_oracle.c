@@ -961,7 +961,12 @@ static int rollout_one(ko_coll *coll, const ko_state *start, double dt_d,
   px[0] = (float)x;
   py[0] = (float)y;
   for (size_t i = 0; i + 1 < P; ++i) {
-    const double c = cos(yaw), s = sin(yaw);
+    /* path.h:24-30 writes cos(yaw), sin(yaw); the reference's gcc release build folds the pair into ONE
+       sincos call (as gcc -O2 does here) -- called explicitly so that the oracle does not depend on its own
+       optimisation level: glibc's sin() / cos() take FMA variants on an FMA CPU and differ from sincos in
+       the last bit of 0.14 % of arguments */
+    double c, s;
+    sincos(yaw, &s, &c);
     x += (vx * c - vy * s) * dt;
     y += (vx * s + vy * c) * dt;
     yaw += om * dt;
@@ -990,7 +995,12 @@ static int rollout_one_mode(ko_coll *coll, const ko_state *start, double dt_d, s
   int is_collision = 0;
   size_t last_free = P - 1;
   for (size_t i = 0; i + 1 < P; ++i) {
-    const double c = cos(yaw), s = sin(yaw);
+    /* path.h:24-30 writes cos(yaw), sin(yaw); the reference's gcc release build folds the pair into ONE
+       sincos call (as gcc -O2 does here) -- called explicitly so that the oracle does not depend on its own
+       optimisation level: glibc's sin() / cos() take FMA variants on an FMA CPU and differ from sincos in
+       the last bit of 0.14 % of arguments */
+    double c, s;
+    sincos(yaw, &s, &c);
     x += (vx * c - vy * s) * dt;
     y += (vx * s + vy * c) * dt;
     yaw += om * dt;
