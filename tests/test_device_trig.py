@@ -188,3 +188,28 @@ def test_table_riding_in_the_sensor_launch(cfg, scale, scan):
     assert (r.found, r.index, r.raw_index, r.n_admissible) == (r2.found, r2.index, r2.raw_index, r2.n_admissible)
     assert np.float32(r.cost) == np.float32(r2.cost)
     ctx.close(); ctx2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(), dict(fused_cycle=2), dict(fused_cycle=0), dict(force_split=1)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "default")
+def test_more_trig_rows_than_the_lds_table_holds(opts):
+    """450 distinct omegas: rows beyond the 384 the kernels keep in LDS are read from global memory; the riding
+    table of such a lattice (450 x 50 entries over 22 workgroups) as well."""
+    import synthetic as syn
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import assert_cycle_equal, hip_context, hip_cycle, oracle_cycle
+
+    inp = syn.make_controller_inputs("cfg2", seed=4, scale=0.5, scene="mid")
+    vx, vy, om = syn.lattice_nonholonomic(8, 450)
+    inp = dict(inp, vx=vx, vy=vy, omega=om)
+    ctx = hip_context(kh, inp)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    assert ctx.get_option("device_trig") == 1.0
+    for yaw in (0.1, -2.0, 0.1):
+        cur = dict(inp, state=(0.0, 0.0, yaw, 0.0))
+        assert_cycle_equal(oracle_cycle(cur), hip_cycle(kh, cur, ctx=ctx))
+    assert ctx.get_option("trig_rows") == 450
+    ctx.close()
