@@ -302,6 +302,9 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ int lfirst[kFusedSamples];  // device trig: slot -> its leader (the first slot with the same trig row)
   __shared__ int llead[kFusedSamples];   // ... the leaders, ascending
   __shared__ int nlead;
+  __shared__ int lrun[kFusedSamples];    // ... samples in the run of leader l
+  __shared__ int runs_short;             // ... every run has at most kRunMax samples: the entry lanes write the increments
+  constexpr int kRunMax = 4;
   __shared__ double ltab[440];           // ... sin / cos (k / 128): what sincos reads
   __shared__ double lom[kTrigOmegaLds];  // ... omega of the trig rows
   const bool box = a.c.enabled && a.c.shape == KC_BOX;
@@ -315,8 +318,17 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const unsigned long long bal = __ballot(lead);
       const unsigned long long upto = bal & (~0ull >> (63 - tid));  // leaders at or in front of this slot
       if (tid < rows) lfirst[tid] = 63 - __clzll(static_cast<long long>(upto));
-      if (lead) llead[__popcll(upto) - 1] = tid;
-      if (tid == 0) nlead = __popcll(bal);
+      const unsigned long long above = bal & ~(~0ull >> (63 - tid));  // leaders behind this slot
+      const int run = (above ? __ffsll(static_cast<long long>(above)) - 1 : rows) - tid;
+      if (lead) {
+        llead[__popcll(upto) - 1] = tid;
+        lrun[__popcll(upto) - 1] = run;
+      }
+      const unsigned long long longrun = __ballot(lead && run > kRunMax);
+      if (tid == 0) {
+        nlead = __popcll(bal);
+        runs_short = longrun == 0ull ? 1 : 0;
+      }
     }
     if (tid < kFusedSamples) {
       lhit[tid] = a.freeze ? 0x7FFFFFFF : 0;  // freeze mode: the FIRST colliding pose index of the sample (minimum)
@@ -402,8 +414,9 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   const int s = tid & (kFusedSamples - 1);
   const bool mine = s < rows;
   double vx = 0.0, vy = 0.0;
+  const bool direct_inc = a.trig_dev && runs_short != 0;  // (read behind the early barrier; uniform)
   if (a.trig_dev) {
-    if (mine) {
+    if (mine && !direct_inc) {
       const uint32_t vi = lvi[s];
       vx = a.vxt[vi & 0xFFFFu];
       vy = a.vyt[vi >> 16];
@@ -416,6 +429,19 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const int l = i & ((1 << sh) - 1), k = i >> sh;
       if (l >= L) continue;
       const int sl = llead[l], r = lrow[sl];
+      // short runs (the dealt order of the cycle: four samples per row): this lane also forms the increments of
+      // the run's samples from its entry -- their velocities are asked for now, used behind the sincos
+      const int run = direct_inc ? lrun[l] : 0;
+      double rvx[kRunMax], rvy[kRunMax];
+#pragma unroll
+      for (int u = 0; u < kRunMax; ++u) {
+        rvx[u] = rvy[u] = 0.0;
+        if (u < run) {
+          const uint32_t vi = lvi[sl + u];
+          rvx[u] = a.vxt[vi & 0xFFFFu];
+          rvy[u] = a.vyt[vi >> 16];
+        }
+      }
       double om;
       if (r < kTrigOmegaLds) om = lom[r];
       else om = a.omega_values[r];
@@ -426,7 +452,20 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       for (; q < k; ++q) yaw += w;
       double sn, cs;
       trig::sincos_exact(yaw, &sn, &cs, static_cast<const double *>(ltab));
-      if (k < steps) lpos[sl * PP + k] = make_double2(cs, sn);
+      if (k < steps) {
+        if (direct_inc) {
+          //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt   (datatypes/path.h:24-30)
+#pragma unroll
+          for (int u = 0; u < kRunMax; ++u)
+            if (u < run) {
+              const double tx = rvx[u] * cs - rvy[u] * sn;
+              const double ty = rvx[u] * sn + rvy[u] * cs;
+              lpos[(sl + u) * PP + k] = make_double2(tx * a.dt, ty * a.dt);
+            }
+        } else {
+          lpos[sl * PP + k] = make_double2(cs, sn);
+        }
+      }
       if (box) a.trig_out[(size_t)k * a.A + r] = make_double2(cs, sn);
     }
   }
@@ -476,7 +515,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, kFusedBlock, tabregs);
   if (!a.trig_dev) slot_words();
   KC_RSTAMP(1);
-  if (a.trig_dev) {
+  if (direct_inc) {
+    // (the entry lanes have written the increments: nothing to do in front of the serial sums)
+    KC_RSTAMP(2);
+  } else if (a.trig_dev) {
     // every sample forms its increments from its leader's entries -- followers first, the leaders in place
     // behind a barrier
     __syncthreads();
