@@ -247,30 +247,24 @@ __device__ __forceinline__ void cycle_epilogue_host(const RollArgs &a, const Tai
                                                     const double2 *best_row, int late, int tid) {
   const int P = a.P;
   const unsigned b = blockIdx.x;
-  __shared__ unsigned int s_rowx;
-  if (tid == 0) s_rowx = 0u;
-  __syncthreads();
+  // wavefront 0 alone (the row lies in LDS behind the barrier of the cost phase): row out, its check word by a
+  // wave reduction, the slot -- no barrier, no LDS atomic on the tail of the workgroup
+  if (tid >= 64) return;
   const bool have_row = best_slot >= 0 && tail.host_rows != nullptr;
+  unsigned int x = 0u;
   if (have_row) {
     uint32_t *dst = tail.host_rows + (size_t)b * 2 * P;
-    unsigned int x = 0u;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int k = tid + u * kBlock;
-      if (k < 2 * P) {
-        const int p = k < P ? k : k - P;
-        const double2 r = best_row[p == 0 ? (P | 1) - 1 : p - 1];  // pose 0 sits in the spare slot of the row
-        const uint32_t w = __float_as_uint(static_cast<float>(k < P ? r.x : r.y));
-        dst[k] = w;
-        x ^= w * (2u * static_cast<unsigned>(k) + 1u);
-      }
+    for (int k = tid; k < 2 * P; k += 64) {
+      const int p = k < P ? k : k - P;
+      const double2 r = best_row[p == 0 ? (P | 1) - 1 : p - 1];  // pose 0 sits in the spare slot of the row
+      const uint32_t w = __float_as_uint(static_cast<float>(k < P ? r.x : r.y));
+      dst[k] = w;
+      x ^= w * (2u * static_cast<unsigned>(k) + 1u);
     }
     for (int off = 32; off > 0; off >>= 1) x ^= __shfl_xor(x, off, 64);
-    if ((tid & 63) == 0 && x) atomicXor(&s_rowx, x);
-    __syncthreads();
   }
   if (tid == 0) {
-    const long long w1 = static_cast<long long>((mask & 0xFFFFFFFFull) | (static_cast<unsigned long long>(s_rowx) << 32));
+    const long long w1 = static_cast<long long>((mask & 0xFFFFFFFFull) | (static_cast<unsigned long long>(x) << 32));
     const long long w2 = tail.seq | (late ? (1ll << 62) : 0ll) | (have_row ? (1ll << 61) : 0ll);
     longlong2 *v = reinterpret_cast<longlong2 *>(tail.host_slots + 4 * b);
     longlong2 lo, hi;
