@@ -1381,11 +1381,31 @@ int build_perm(kc_dwa *c) {
           for (size_t i = 0; i < rows_per; ++i)
             for (size_t k = 0; k < 4; ++k) dealt.push_back(c->h_perm[(a + A * i) * L + b + B * k]);
     } else {
-      const size_t G = (n + cs - 1) / cs;
+      // Ragged rows (omni windows, shares dealt by row): quads again -- every row of the sorted order is cut
+      // into groups of (up to) four samples a quarter of the row apart, and the quads are dealt with the skewed
+      // stride (a workgroup takes its quads from cs / 4 regions of the sorted order: adjacent rows and adjacent
+      // speeds go to different workgroups, and the samples of a workgroup share cs / 4 trig rows or a few more
+      // instead of cs -- the rows its lanes have to form).  A workgroup is whatever cs consecutive
+      // entries of the flat list are: partial quads only shift the boundaries.
+      std::vector<int32_t> qstart, qstep, qcount;  // quad = h_perm[qstart + k * qstep], k < qcount
+      for (size_t i = 0; i < n;) {
+        size_t j = i;
+        while (j < n && row[c->h_perm[j]] == row[c->h_perm[i]]) ++j;
+        const size_t len = j - i, nq = (len + 3) / 4;
+        for (size_t q = 0; q < nq; ++q) {
+          qstart.push_back(static_cast<int32_t>(i + q));
+          qstep.push_back(static_cast<int32_t>(nq));
+          qcount.push_back(static_cast<int32_t>((len - q + nq - 1) / nq));  // elements q, q + nq, ... below len
+        }
+        i = j;
+      }
+      const size_t Q = qstart.size(), qper = cs / 4;
+      const size_t G = (Q + qper - 1) / qper;
       for (size_t g = 0; g < G; ++g)
-        for (size_t j = 0; j < cs; ++j) {
+        for (size_t j = 0; j < qper; ++j) {
           const size_t e = j * G + (g + 37 * j) % G;
-          if (e < n) dealt.push_back(c->h_perm[e]);
+          if (e >= Q) continue;
+          for (int32_t k = 0; k < qcount[e]; ++k) dealt.push_back(c->h_perm[static_cast<size_t>(qstart[e] + k * qstep[e])]);
         }
     }
   }
