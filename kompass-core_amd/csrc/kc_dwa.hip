@@ -2779,14 +2779,23 @@ int kc_trig_table(double yaw0, const double *omega, size_t n_rows, size_t n_step
   for (size_t i = 0; i < n_rows; ++i) om_max = std::max(om_max, std::fabs(omega[i]));
   const double reach = std::fabs(yaw0) + om_max * std::fabs(dt) * static_cast<double>(n_steps);
   if (!(reach < 1.0e8)) KC_FAIL(KC_ERR_RANGE, "yaw reaches %g: outside the table + Cody-Waite range of sincos", reach);
-  DevBuf<double> d_om;
+  DevBuf<double> d_om, d_tab;
   DevBuf<double2> d_out;
   KC_TRY(d_om.reserve(n_rows));
+  KC_TRY(d_tab.reserve(440));
   KC_TRY(d_out.reserve(n_rows * n_steps));
   KC_HIP(hipMemcpy(d_om.p, omega, n_rows * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(trig_table_kernel, dim3(blocks_for(n_rows, kTrigRows)), dim3(kTrigBlock),
-                     static_cast<size_t>(kTrigRows) * n_steps * sizeof(double), nullptr, yaw0, d_om.p, dt,
-                     static_cast<int>(n_rows), static_cast<int>(n_steps), d_out.p);
+  KC_HIP(hipMemcpy(d_tab.p, kc_sincostab_host, sizeof(kc_sincostab_host), hipMemcpyHostToDevice));
+  TrigJob tj{};
+  tj.yaw0 = yaw0;
+  tj.dt = dt;
+  tj.omega = d_om.p;
+  tj.tab = d_tab.p;
+  tj.out = d_out.p;
+  tj.A = static_cast<int>(n_rows);
+  tj.P = static_cast<int>(n_steps);
+  tj.nblk = static_cast<int>(std::min<size_t>(1024, blocks_for(n_rows * n_steps, kTrigBlock)));
+  hipLaunchKernelGGL(trig_table_kernel, dim3(tj.nblk), dim3(kTrigBlock), 0, nullptr, tj);
   KC_HIP(hipGetLastError());
   KC_HIP(hipMemcpy(cos_sin_out, d_out.p, n_rows * n_steps * sizeof(double2), hipMemcpyDeviceToHost));
   return KC_OK;
@@ -3820,9 +3829,16 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     if (dev_trig) {
       if (!fused && !table_ahead) {  // the split path's kernels read a table: filled on the device, in stream order
         KC_TRY(c->timing.start("trig_table_kernel", s));
-        hipLaunchKernelGGL(trig_table_kernel, dim3(blocks_for(A, kTrigRows)), dim3(kTrigBlock),
-                           static_cast<size_t>(kTrigRows) * P * sizeof(double), s, yaw0, c->d_omega.p, dt,
-                           static_cast<int>(A), static_cast<int>(P), c->d_trig.p);
+        TrigJob tj{};
+        tj.yaw0 = yaw0;
+        tj.dt = dt;
+        tj.omega = c->d_omega.p;
+        tj.tab = c->d_sincostab.p;
+        tj.out = c->d_trig.p;
+        tj.A = static_cast<int>(A);
+        tj.P = static_cast<int>(P);
+        tj.nblk = static_cast<int>(std::min<size_t>(1024, blocks_for(A * P, kTrigBlock)));
+        hipLaunchKernelGGL(trig_table_kernel, dim3(tj.nblk), dim3(kTrigBlock), 0, s, tj);
         KC_TRY(c->timing.stop(s));
       }
     } else if (!c->trig_direct)

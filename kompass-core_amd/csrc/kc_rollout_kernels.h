@@ -7,40 +7,11 @@
 
 namespace kc {
 
-// sin / cos (k / 128) in double-double: what glibc's sincos reads (kc_trig_exact.h); 3.5 KB, L2-resident
-__device__ const double kc_sincostab_dev[440] = {KC_SINCOSTAB_VALUES};
-
 // ===========================================================================
 // K0: the (step x omega row) table of cos / sin(yaw_k) on the device, for the kernels of the split
 // path (rollout_kernel, collision_kernel, collision_tilted_kernel) -- what the host's libm produced
-// every cycle in rounds 1-3.  A workgroup takes 8 rows: one lane per row forms yaw_k by repeated
-// addition of omega * dt (path.h:30) into LDS, then every lane evaluates entries.
+// every cycle in rounds 1-3 -- and as a job riding in another launch (below).
 // ===========================================================================
-constexpr int kTrigRows = 8, kTrigBlock = 256;
-__global__ __launch_bounds__(kTrigBlock) void trig_table_kernel(double yaw0, const double *__restrict__ omega,
-                                                                 double dt, int A, int P, double2 *__restrict__ out) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  double *lyaw = reinterpret_cast<double *>(smem);  // [kTrigRows][P]
-  const int tid = threadIdx.x, r0 = blockIdx.x * kTrigRows;
-  const int nr = min(kTrigRows, A - r0);
-  if (tid < nr) {
-    const double w = omega[r0 + tid] * dt;
-    double yaw = yaw0;
-    for (int k = 0; k < P; ++k) {
-      lyaw[tid * P + k] = yaw;
-      yaw += w;
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < kTrigRows * P; i += kTrigBlock) {
-    const int r = i & (kTrigRows - 1), k = i >> 3;
-    if (r >= nr) continue;
-    double sn, cs;
-    trig::sincos_exact(lyaw[r * P + k], &sn, &cs, kc_sincostab_dev);
-    out[(size_t)k * A + r0 + r] = make_double2(cs, sn);
-  }
-}
-
 // The same table as a JOB that rides in another launch (the sensor build of a controller cycle with fresh
 // inputs: a few extra workgroups on CUs that launch leaves idle).  A lane per entry, yaw_k by the lane's own
 // repeated additions; consecutive lanes take consecutive rows of one step (coalesced stores).  `tab` is the
@@ -66,6 +37,12 @@ __device__ __forceinline__ void trig_job_block(const TrigJob &j, int blk) {
     trig::sincos_exact(yaw, &sn, &cs, j.tab);
     j.out[i] = make_double2(cs, sn);
   }
+}
+
+// stand-alone: every workgroup of the launch belongs to the job (any horizon: no LDS)
+constexpr int kTrigBlock = 256;
+__global__ __launch_bounds__(kTrigBlock) void trig_table_kernel(TrigJob j) {
+  trig_job_block<kTrigBlock>(j, static_cast<int>(blockIdx.x));
 }
 
 // ===========================================================================

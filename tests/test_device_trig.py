@@ -63,6 +63,7 @@ def _libm_table(yaw0, omega, P, dt):
     (50.0, 3.0, 17, 200, 0.05),           # Cody-Waite reduction, every quadrant
     (-1.0e6, 40.0, 9, 300, 0.25),
     (99999000.0, 0.0, 3, 4, 0.05),        # just inside the range
+    (0.2, 1.0, 5, 1500, 0.01),            # a very long horizon (no LDS staging: any number of steps)
 ])
 def test_device_table_equals_host_sincos(yaw0, om_max, A, P, dt):
     omega = np.linspace(-om_max, om_max, A)
