@@ -598,31 +598,31 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   KC_RSTAMP(3);
   KC_RSTAMP(7);
   // ---- B: the serial sums ------------------------------------------------------
-  if (tid < rows) {
+  // (the x sums of the samples by wavefront 0, the y sums by wavefront 1: two independent chains per sample,
+  // half the LDS traffic and half the additions per wavefront)
+  if (tid < 128 && (tid & 63) < rows) {
     // sixteen increments per register chunk: one LDS latency per chunk instead
     // of one per step
     constexpr int kChunk = 16;
-    double x = a.x0, y = a.y0;
-    double2 *mine = lpos + tid * PP;
+    const int comp = tid >> 6;
+    double acc = comp ? a.y0 : a.x0;
+    double *mine = reinterpret_cast<double *>(lpos + (tid & 63) * PP) + comp;  // (.x or .y of the row's entries)
     int k = 0;
     for (; k + kChunk <= steps; k += kChunk) {
-      double2 v[kChunk];
+      double v[kChunk];
 #pragma unroll
-      for (int j = 0; j < kChunk; ++j) v[j] = mine[k + j];
+      for (int j = 0; j < kChunk; ++j) v[j] = mine[2 * (k + j)];
 #pragma unroll
       for (int j = 0; j < kChunk; ++j) {
-        x += v[j].x;
-        y += v[j].y;
-        v[j] = make_double2(x, y);  // pose k + j + 1
+        acc += v[j];
+        v[j] = acc;  // pose k + j + 1
       }
 #pragma unroll
-      for (int j = 0; j < kChunk; ++j) mine[k + j] = v[j];
+      for (int j = 0; j < kChunk; ++j) mine[2 * (k + j)] = v[j];
     }
     for (; k < steps; ++k) {
-      const double2 inc = mine[k];
-      x += inc.x;
-      y += inc.y;
-      mine[k] = make_double2(x, y);
+      acc += mine[2 * k];
+      mine[2 * k] = acc;
     }
   }
   __syncthreads();
