@@ -89,9 +89,13 @@ KC_TRIG_HD double do_sin(double x, double dx, Tab tab) {
 // s_sincos.c: __sincos.  Returns false outside the table + Cody-Waite range (NaN, inf, |x| >= 105414350).
 // The library's three argument ranges differ only in how they reach (a, da) with |a + da| < 0.86 and in which
 // of do_sin / do_cos gives which result with which sign; they are restated as ONE evaluation of the pair behind
-// selects (a wavefront whose lanes fall into different ranges runs the polynomials once, not three times).
-template <class Tab>
-KC_TRIG_HD bool sincos_exact(double x, double *sinx, double *cosx, Tab tab) {
+// selects (a wavefront whose lanes fall into different ranges runs the polynomials once, not three times) --
+// in three steps, so that two lanes can share an argument: sincos_reduce, do_sin | do_cos, sincos_finish.
+struct Reduced {
+  double a, da;  // the reduced argument
+  int mode;      // 0: tiny, 1: direct, 2: pi/2 - |x|, 4 + n: Cody-Waite with quadrant n
+};
+KC_TRIG_HD bool sincos_reduce(double x, Reduced *r) {
   const uint32_t k = static_cast<uint32_t>(Bits::of(x) >> 32) & 0x7fffffffu;
   if (k >= 0x419921FBu) return false;
   const bool direct = k < 0x3feb6000u;   // |x| < 0.855469: do_sin (x, 0), do_cos (x, 0)
@@ -115,29 +119,40 @@ KC_TRIG_HD bool sincos_exact(double x, double *sinx, double *cosx, Tab tab) {
   t1 = xn * pp4;
   const double b = t2 - t1;
   db += (t2 - b) - t1;
-  const double a = direct ? x : halfpi ? a2 : b;
-  const double da = direct ? 0.0 : halfpi ? da2 : db;
-  const double sv = do_sin(a, da, tab), cv = do_cos(a, da, tab);
+  r->a = direct ? x : halfpi ? a2 : b;
+  r->da = direct ? 0.0 : halfpi ? da2 : db;
+  r->mode = k < 0x3e400000u ? 0 : direct ? 1 : halfpi ? 2 : 4 + n;  // (|x| < 2^-27: sin = x, cos = 1)
+  return true;
+}
+// sv = do_sin (a, da), cv = do_cos (a, da)
+KC_TRIG_HD void sincos_finish(double x, int mode, double sv, double cv, double *sinx, double *cosx) {
   double s, c;
-  if (direct) {
+  if (mode == 1) {
     s = sv;
     c = cv;
-  } else if (halfpi) {
+  } else if (mode == 2) {
     s = __builtin_copysign(cv, x);
     c = sv;
   } else {  // do_sincos (a, da, n) and (a, da, n + 1)
+    const int n = mode & 3;
     s = (n & 1) ? cv : sv;
     if (n & 2) s = -s;
     const int m = n + 1;
     c = (m & 1) ? cv : sv;
     if (m & 2) c = -c;
   }
-  if (k < 0x3e400000u) {  // |x| < 2^-27
+  if (mode == 0) {
     s = x;
     c = 1.0;
   }
   *sinx = s;
   *cosx = c;
+}
+template <class Tab>
+KC_TRIG_HD bool sincos_exact(double x, double *sinx, double *cosx, Tab tab) {
+  Reduced r;
+  if (!sincos_reduce(x, &r)) return false;
+  sincos_finish(x, r.mode, do_sin(r.a, r.da, tab), do_cos(r.a, r.da, tab), sinx, cosx);
   return true;
 }
 
