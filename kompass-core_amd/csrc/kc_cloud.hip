@@ -116,12 +116,17 @@ __device__ __forceinline__ void cloud_point(const CloudArgs &a, unsigned long lo
   }
   int bin = static_cast<int>(fl);
   bin = min(bin, a.num_bins - 1);
-  const double dist = static_cast<double>(kc::sqrt_rn(range_sq));  // std::sqrt(float)
-  if (!(dist >= 0.0)) return;
-  const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(dist));
+  const float distf = kc::sqrt_rn(range_sq);  // std::sqrt(float)
+  if (!(distf >= 0.0f)) return;
   if (kLds) {
-    if (bits < lbins[bin]) atomicMin(&lbins[bin], bits);
+    // the minimum of the widened floats is the widened minimum: the workgroup keeps FLOAT bits (non-negative
+    // floats order like their bit patterns; half the LDS and half the row traffic), the merge widens once
+    // and applies max_range
+    uint32_t *l32 = reinterpret_cast<uint32_t *>(lbins);
+    const uint32_t b32 = __float_as_uint(distf);
+    if (b32 < l32[bin]) atomicMin(&l32[bin], b32);
   } else {
+    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(distf)));
     atomicMin(&a.bins[bin], bits);
   }
 }
@@ -137,7 +142,8 @@ template <bool kLds>
 __global__ __launch_bounds__(kCloudBlock) void cloud_bins_kernel(CloudArgs a) {
   extern __shared__ unsigned long long lbins[];
   if (kLds) {
-    for (int b = threadIdx.x; b < a.num_bins; b += kCloudBlock) lbins[b] = a.max_bits;
+    uint32_t *l32 = reinterpret_cast<uint32_t *>(lbins);
+    for (int b = threadIdx.x; b < a.num_bins; b += kCloudBlock) l32[b] = 0x7F800000u;  // +inf: no point yet
     __syncthreads();
   }
   const long long stride = static_cast<long long>(gridDim.x) * kCloudBlock;
@@ -174,8 +180,9 @@ __global__ __launch_bounds__(kCloudBlock) void cloud_bins_kernel(CloudArgs a) {
   }
   if (kLds) {
     __syncthreads();
-    unsigned long long *rowp = a.partial + static_cast<size_t>(blockIdx.x) * a.num_bins;
-    for (int b = threadIdx.x; b < a.num_bins; b += kCloudBlock) rowp[b] = lbins[b];
+    uint32_t *rowp = reinterpret_cast<uint32_t *>(a.partial) + static_cast<size_t>(blockIdx.x) * a.num_bins;
+    const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lbins);
+    for (int b = threadIdx.x; b < a.num_bins; b += kCloudBlock) rowp[b] = l32[b];
   }
 }
 
@@ -183,33 +190,45 @@ __global__ __launch_bounds__(kCloudBlock) void cloud_bins_kernel(CloudArgs a) {
 // ... and hands the result to the host: bins, edge-list count and (last
 // workgroup) the sequence number go straight into pinned host memory, which
 // the host polls instead of copying and waiting on the stream
-__global__ __launch_bounds__(1024) void cloud_merge_kernel(const unsigned long long *partial, int rows,
-                                                           int num_bins, unsigned long long *bins,
+constexpr int kMergeBins = 16;  // bins per workgroup of the merge: 64 row lanes each
+__global__ __launch_bounds__(1024) void cloud_merge_kernel(const uint32_t *partial, int rows, int num_bins,
+                                                           double max_range, unsigned long long *bins,
                                                            const unsigned int *count_now,
                                                            unsigned int *next_count, unsigned int *ticket,
                                                            unsigned long long *host_out, long long seq) {
-  // 64 bins per workgroup, 16 lanes per bin over the rows (eight loads in
-  // flight per lane), LDS minimum over the 16
-  __shared__ unsigned long long part[16][64];
-  const int bl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int b = blockIdx.x * 64 + bl;
-  unsigned long long m = ~0ull;
+  // 16 bins per workgroup (a 64-byte segment of every row), 64 lanes per bin over the rows -- every load of a
+  // lane in flight at once (512 rows: eight) --, the minimum over the lanes of a bin by two DPP-free shuffles
+  // inside the wavefront (4 row lanes x 16 bins) and an LDS pass over the 16 wavefronts
+  __shared__ uint32_t part[16][kMergeBins];
+  const int bl = threadIdx.x & (kMergeBins - 1), rg = threadIdx.x >> 4;  // rg: 0 .. 63
+  const int b = blockIdx.x * kMergeBins + bl;
+  uint32_t m = 0x7F800000u;
   if (b < num_bins) {
 #pragma unroll 8
-    for (int r = rg; r < rows; r += 16) {
-      const unsigned long long v = partial[static_cast<size_t>(r) * num_bins + b];
+    for (int r = rg; r < rows; r += 64) {
+      const uint32_t v = partial[static_cast<size_t>(r) * num_bins + b];
       m = v < m ? v : m;
     }
   }
-  part[rg][bl] = m;
+  {
+    const uint32_t o = static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), 16, 64));
+    m = o < m ? o : m;
+    const uint32_t o2 = static_cast<uint32_t>(__shfl_xor(static_cast<int>(m), 32, 64));
+    m = o2 < m ? o2 : m;
+  }
+  if ((threadIdx.x & 63) < kMergeBins) part[threadIdx.x >> 6][bl] = m;
   __syncthreads();
-  if (rg == 0 && b < num_bins) {
+  if (threadIdx.x < kMergeBins && b < num_bins) {
 #pragma unroll
     for (int k = 1; k < 16; ++k) m = part[k][bl] < m ? part[k][bl] : m;
-    bins[b] = m;
-    host_out[2 + b] = m;
+    // widen once; `distance < ranges[bin]` against the initial max_range (pointcloud.h:170-175)
+    const double d = static_cast<double>(__uint_as_float(m));
+    const double out = d < max_range ? d : max_range;
+    const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(out));
+    bins[b] = bits;
+    host_out[2 + b] = bits;
+    __threadfence_system();
   }
-  __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
     *ticket = 0u;
@@ -370,7 +389,7 @@ int kc_cloud_to_laserscan_typed(kc_cloud *c, const int8_t *data, size_t nbytes,
   KC_TRY(c->d_list.reserve(static_cast<size_t>(n_rec)));
   const bool in_lds = c->lds_ok && num_bins <= kCloudMaxLdsBins;
   const unsigned grid = static_cast<unsigned>(
-      std::min<long long>(512, (n_rec + kCloudBlock - 1) / kCloudBlock));
+      std::min<long long>(256, (n_rec + kCloudBlock - 1) / kCloudBlock));
   if (in_lds) KC_TRY(c->d_partial.reserve(static_cast<size_t>(grid) * num_bins));
   double max_r = max_range;
   CloudArgs a{};
@@ -411,7 +430,7 @@ int kc_cloud_to_laserscan_typed(kc_cloud *c, const int8_t *data, size_t nbytes,
   KC_TRY(c->timing.start("cloud_bins_kernel", s));
   if (in_lds)
     hipLaunchKernelGGL(cloud_bins_kernel<true>, dim3(grid), dim3(kCloudBlock),
-                       static_cast<size_t>(num_bins) * 8, s, a);
+                       static_cast<size_t>(num_bins) * 4, s, a);
   else
     hipLaunchKernelGGL(cloud_bins_kernel<false>, dim3(grid), dim3(kCloudBlock), 0, s, a);
   KC_TRY(c->timing.stop(s));
@@ -420,9 +439,9 @@ int kc_cloud_to_laserscan_typed(kc_cloud *c, const int8_t *data, size_t nbytes,
     KC_TRY(c->h_out.reserve(static_cast<size_t>(num_bins) + 2));
     const long long seq = ++c->seq;
     KC_TRY(c->timing.start("cloud_merge_kernel", s));
-    hipLaunchKernelGGL(cloud_merge_kernel, dim3((num_bins + 63) / 64), dim3(1024), 0, s,
-                       c->d_partial.p, static_cast<int>(grid), num_bins, c->d_bins.p, count_now,
-                       count_next, c->d_count.p + 2, c->h_out.p, seq);
+    hipLaunchKernelGGL(cloud_merge_kernel, dim3((num_bins + kMergeBins - 1) / kMergeBins), dim3(1024), 0, s,
+                       reinterpret_cast<const uint32_t *>(c->d_partial.p), static_cast<int>(grid), num_bins, max_range,
+                       c->d_bins.p, count_now, count_next, c->d_count.p + 2, c->h_out.p, seq);
     KC_TRY(c->timing.stop(s));
     KC_HIP(hipGetLastError());
     // poll the sequence word (bounded: then wait on the stream)
