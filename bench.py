@@ -42,6 +42,11 @@ from pathlib import Path
 # Nothing here needs a threaded BLAS.
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_v, "4")
+# dmabuf IPC: RCCL between rank processes on this pool fails with the legacy mode (hipIpcGetMemHandle).
+# Set here -- before torch or libkompass_hip.so is imported, i.e. before anything touches the GPU -- so that
+# ranks started by an EXTERNAL launcher (python -m torch.distributed.run ... bench.py --gpus N) have it too,
+# not only the children of launch_ranks().
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 
@@ -1206,6 +1211,7 @@ def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: N fresh rank processes (torch.distributed.run,
     rendezvous on 127.0.0.1) as CHILDREN of this process, which has not touched the GPU and never will;
     rank 0's JSON line is relayed, the launcher's return code is this script's."""
+    import signal
     import socket
     import subprocess
 
@@ -1218,19 +1224,48 @@ def launch_ranks(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this pool)
     env.setdefault("OMP_NUM_THREADS", "4")
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    # The ranks run in a process group of their own with a wall-clock limit: a rank that dies AFTER the
+    # rendezvous leaves its peers inside a collective that never completes -- the limit ends the whole group
+    # (fresh children only: nothing here re-executes a process that has touched the GPU) and the launcher
+    # returns non-zero instead of hanging the caller.
+    limit = float(os.environ.get("KC_BENCH_LAUNCH_LIMIT_S", "900"))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        stdout, _ = p.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)  # the group of the launcher we started, by its exact id
+            except ProcessLookupError:
+                break
+            try:
+                p.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        stdout = ""
+        try:
+            stdout = p.communicate(timeout=5)[0] or ""
+        except Exception:  # noqa: BLE001  (pipes of a killed group)
+            pass
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in (stdout or "").splitlines():
         if ln.startswith("{") and ln.rstrip().endswith("}"):
             line = ln
-    print(f"[bench] launcher pid {os.getpid()}: {n} ranks, rc {p.returncode}, "
+    rc = p.returncode if p.returncode is not None else 1
+    print(f"[bench] launcher pid {os.getpid()}: {n} ranks, rc {rc}{' (wall-clock limit: group terminated)' if timed_out else ''}, "
           f"launcher_loaded_hip_library={hip_library_loaded()}", file=sys.stderr, flush=True)
+    if timed_out:
+        print(f"[bench] the ranks did not finish within {limit:.0f} s", file=sys.stderr)
+        return 124
     if line is not None:
         print(line, flush=True)
-    elif p.returncode == 0:
+    elif rc == 0:
         print("[bench] the ranks printed no JSON line", file=sys.stderr)
         return 1
-    return p.returncode
+    return rc
 
 
 def dry_rank(args, rank, world, local_rank):
@@ -1240,6 +1275,10 @@ def dry_rank(args, rank, world, local_rank):
     if args.dry_fail_rank == rank:
         sys.exit(3)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if args.dry_die_after_rendezvous == rank:
+        os._exit(5)  # (no clean-up: the peers are left inside the next collective)
+    if args.dry_die_after_rendezvous >= 0:
+        time.sleep(3600)  # a peer that would wait for ever: only the launcher's limit ends it
     me = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "ppid": os.getppid(),
           "master": os.environ.get("MASTER_ADDR"), "hip_library_loaded": hip_library_loaded()}
     out = [None] * world
@@ -1273,6 +1312,8 @@ def main():
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, report their environment, do no GPU work (launcher test)")
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help="with --dry-launch: this rank exits with code 3")
+    ap.add_argument("--dry-die-after-rendezvous", type=int, default=-1,
+                    help="with --dry-launch: this rank dies behind the rendezvous, its peers wait for ever (launcher limit test)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()

@@ -798,20 +798,30 @@ __device__ __forceinline__ void velocity_sums_group(const VelSumArgs &a, float *
   const float *vx = a.vx + static_cast<size_t>(valid ? n : 0) * a.nv;
   const float *vy = a.vy + static_cast<size_t>(valid ? n : 0) * a.nv;
   const float *om = a.om + static_cast<size_t>(valid ? n : 0) * a.nv;
-  float r = 0.0f;
-  for (int k0 = k_first; k0 < a.nv; k0 += kLanes) {
+  // The quotients of a tile (f64 divisions, ~100 instructions, independent of the running sum) are formed one
+  // tile AHEAD of the additions that consume them and without a branch (steps beyond the row and axes without
+  // a limit read a valid entry and select +0.0, which leaves the non-negative sum as it is): one basic block,
+  // so the divisions of tile i + 1 fill the issue slots the dependent chain of tile i leaves empty.
+  auto quotients = [&](int k0, double &t0, double &t1, double &t2) {
     const int k = k0 + j;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    if (valid && k < a.nv) {
-      auto term = [&](const float *v, float lim) {
-        const float d = kJerk ? v[k] - 2 * v[k - 1] + v[k - 2] : v[k] - v[k - 1];
-        const double dd = static_cast<double>(d);
-        return (dd * dd) / static_cast<double>(lim);
-      };
-      if (a.acc0 > 0) t0 = term(vx, a.acc0);
-      if (a.acc1 > 0) t1 = term(vy, a.acc1);
-      if (a.acc2 > 0) t2 = term(om, a.acc2);
-    }
+    const bool in = valid && k < a.nv;
+    const int kk = in ? k : k_first;
+    auto term = [&](const float *v, float lim) {
+      const float d = kJerk ? v[kk] - 2 * v[kk - 1] + v[kk - 2] : v[kk] - v[kk - 1];
+      const double dd = static_cast<double>(d);
+      const double q = (dd * dd) / static_cast<double>(lim);
+      return (in && lim > 0) ? q : 0.0;
+    };
+    t0 = term(vx, a.acc0);
+    t1 = term(vy, a.acc1);
+    t2 = term(om, a.acc2);
+  };
+  float r = 0.0f;
+  double t0, t1, t2;
+  quotients(k_first, t0, t1, t2);
+  for (int k0 = k_first; k0 < a.nv; k0 += kLanes) {
+    double n0, n1, n2;
+    quotients(k0 + kLanes, n0, n1, n2);
 #pragma unroll
     for (int q = 0; q < kLanes; ++q) {
       const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(r), kRotate, 0xf, 0xf, true));
@@ -819,11 +829,15 @@ __device__ __forceinline__ void velocity_sums_group(const VelSumArgs &a, float *
       v = static_cast<float>(static_cast<double>(v) + t1);
       r = static_cast<float>(static_cast<double>(v) + t2);
     }
+    t0 = n0;
+    t1 = n1;
+    t2 = n2;
   }
   if (valid && j == kLanes - 1) out[n] = r;
 }
+constexpr int kVelBlock = 256;
 template <int kLanes>
-__global__ __launch_bounds__(256) void velocity_sums_kernel(VelSumArgs a) {
+__global__ __launch_bounds__(kVelBlock) void velocity_sums_kernel(VelSumArgs a) {
   if (blockIdx.y + a.first_kind == 0)
     velocity_sums_group<false, kLanes>(a, a.out[0]);
   else
@@ -1896,8 +1910,14 @@ __device__ __forceinline__ void publish_body(const PubArgs &a) {
 // kLds: the tracked segment (+ chunk spheres), the bucket cell table and the
 // skip table are copied into LDS once per workgroup; kObsLds: the obstacle
 // coordinates too.  Otherwise they are read in place.
-template <bool kLds, bool kObsLds>
-__global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcArgs t, PubArgs pub) {
+// kFold: the workgroup that arrives last publishes the cycle (PubArgs, publish_body).  The instance without it
+// is the one that runs BESIDE velocity_sums_kernel (caller-provided velocity profiles, run_evaluate): it is held
+// to 96 VGPRs (five wavefronts per SIMD's worth) so that its four wavefronts per SIMD leave 128 registers --
+// three wavefronts of the sums.  With the publish code inside, the kernel took 104 and left room for two: the
+// sums ran behind the cost kernel instead of beside it (CostEvaluator_5k_Trajs 0.198 -> 0.273 ms, round 3).
+template <bool kLds, bool kObsLds, bool kFold>
+__global__ __launch_bounds__(kCostBlock)
+__attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_cost_kernel(CostArgs a, DcArgs t, PubArgs pub) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ long long s_key;
   __shared__ unsigned long long s_obest[kCostWaves];  // per sample: min squared obstacle distance (double bits)
@@ -1996,7 +2016,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_kernel(CostArgs a, DcA
   // ---- the workgroup's best key, for publish_kernel ----------------------------
   if (lane == 0 && wkey != KEY_NONE) atomicMin(&s_key, wkey);
   __syncthreads();
-  if (!pub.fold) {
+  if (!kFold) {
     if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
     KC_STAMP(4);
     return;

@@ -297,6 +297,8 @@ struct kc_dwa {
   ShardLayout layout;
   hm::VelocityLattice full;    // KC_SHARD_ROWS: the full list (`lat` is this rank's share of it)
   std::vector<int32_t> gid;    // KC_SHARD_ROWS: id in `lat` -> global id (position in `full`)
+  bool rows_active = false;    // `lat` is this rank's KC_SHARD_ROWS share of `full` (the share -- and gid -- may be EMPTY:
+                               // more ranks than dealt rows; the state is this flag, never gid.empty())
   DevBuf<int32_t> d_gid;
   DevBuf<long long> d_xs, d_xr;      // send / reduced record
   PinBuf<long long> h_xvec, h_xrec;  // the reduced record and its 5-word hand-off record, written by the GPU
@@ -883,13 +885,15 @@ int upload_samples(kc_dwa *c) {
 
 // global id (position in the caller's full list) of sample `lat_id` of this context's list
 inline int64_t global_of(const kc_dwa *c, int64_t lat_id) {
-  return (c->gid.empty() || lat_id < 0) ? lat_id : static_cast<int64_t>(c->gid[static_cast<size_t>(lat_id)]);
+  if (!c->rows_active || lat_id < 0) return lat_id;
+  return static_cast<size_t>(lat_id) < c->gid.size() ? static_cast<int64_t>(c->gid[static_cast<size_t>(lat_id)]) : -1;
 }
 
 // c->lat holds the caller's FULL list: keep this rank's share under the shard rule and upload
 int apply_shard_rule(kc_dwa *c) {
   ShardLayout &L = c->layout;
   c->gid.clear();
+  c->rows_active = false;
   c->full.clear();
   if (L.mode < 0) return upload_samples(c);
   const size_t n = c->lat.size();
@@ -910,6 +914,7 @@ int apply_shard_rule(kc_dwa *c) {
   c->lat.clear();
   const std::vector<int32_t> &mine = L.gids[me];
   c->gid = mine;
+  c->rows_active = true;
   // this rank's rows, relabelled in ascending order of the full list's labels
   std::vector<int32_t> relabel(c->full.omega_values.size(), -1);
   for (int32_t g : mine) relabel[static_cast<size_t>(c->full.row[static_cast<size_t>(g)])] = 0;
@@ -939,7 +944,7 @@ int apply_shard_rule(kc_dwa *c) {
 }
 
 // the caller's full list (sample_window output, velocity look-ups by global id)
-inline const hm::VelocityLattice &full_list(const kc_dwa *c) { return c->gid.empty() ? c->lat : c->full; }
+inline const hm::VelocityLattice &full_list(const kc_dwa *c) { return c->rows_active ? c->full : c->lat; }
 
 // host lists of a global-frame point update (add_voxel per point, obstacle
 // coordinates through obs_tf): the sensor path of the host, and the lazy
@@ -1887,7 +1892,7 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
       va.out[0] = c->d_vsum.p;
       va.out[1] = c->d_vsum.p + n;
       va.first_kind = ca.w_smooth > 0.0 ? 0 : 1;
-      const dim3 grid(blocks_for(n, 4 * static_cast<size_t>(group)), kinds);  // four wavefronts per workgroup
+      const dim3 grid(blocks_for(n, (kVelBlock / 64) * static_cast<size_t>(group)), kinds);
       // Beside the wavefront-per-sample cost kernel on a second stream: these chains leave most issue slots
       // of their SIMDs idle, the segment searches fill them (not while kernels are being timed one by one)
       vel_beside = !use_block && !c->timing.enabled && c->velocity_beside;
@@ -1905,9 +1910,9 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
       vel_launch = [=]() -> int {
         KC_TRY(c->timing.start("velocity_sums_kernel", vs));
         if (group == 4)
-          hipLaunchKernelGGL(velocity_sums_kernel<16>, grid, dim3(256), 0, vs, va);
+          hipLaunchKernelGGL(velocity_sums_kernel<16>, grid, dim3(kVelBlock), 0, vs, va);
         else
-          hipLaunchKernelGGL(velocity_sums_kernel<4>, grid, dim3(256), 0, vs, va);
+          hipLaunchKernelGGL(velocity_sums_kernel<4>, grid, dim3(kVelBlock), 0, vs, va);
         KC_TRY(c->timing.stop(vs));
         return KC_OK;
       };
@@ -2013,15 +2018,20 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     else if (batched)
       hipLaunchKernelGGL((sample_cost_batched_kernel<false>), dim3(cost_blocks), dim3(kCostBlock),
                          lds_tab, s, ca, dt, pa);
-    else if (obs_lds)
-      hipLaunchKernelGGL((sample_cost_kernel<true, true>), dim3(cost_blocks), dim3(kCostBlock),
-                         lds_tab + lds_obs, s, ca, dt, pa);
-    else if (tab_lds)
-      hipLaunchKernelGGL((sample_cost_kernel<true, false>), dim3(cost_blocks), dim3(kCostBlock),
-                         lds_tab, s, ca, dt, pa);
-    else
-      hipLaunchKernelGGL((sample_cost_kernel<false, false>), dim3(cost_blocks), dim3(kCostBlock),
-                         0, s, ca, dt, pa);
+    else {
+      auto launch = [&](auto kernel, size_t lds) {
+        hipLaunchKernelGGL(kernel, dim3(cost_blocks), dim3(kCostBlock), lds, s, ca, dt, pa);
+      };
+      if (pa.fold) {
+        if (obs_lds) launch(sample_cost_kernel<true, true, true>, lds_tab + lds_obs);
+        else if (tab_lds) launch(sample_cost_kernel<true, false, true>, lds_tab);
+        else launch(sample_cost_kernel<false, false, true>, 0);
+      } else {
+        if (obs_lds) launch(sample_cost_kernel<true, true, false>, lds_tab + lds_obs);
+        else if (tab_lds) launch(sample_cost_kernel<true, false, false>, lds_tab);
+        else launch(sample_cost_kernel<false, false, false>, 0);
+      }
+    }
   }
   KC_TRY(c->timing.stop(s));
   if (vel_beside) {
@@ -2356,10 +2366,16 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     if (ok) c->lds_limit = 150 * 1024;
     c->lds_limit_hw = c->lds_limit;
     c->cost_lds_ok =
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, true>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(kCostLdsBudget)) == hipSuccess &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, false>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kCostLdsBudget)) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(kCostLdsBudget)) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_kernel<true, false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(kCostLdsBudget)) == hipSuccess &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(sample_cost_block_kernel<true, true>),
@@ -2817,7 +2833,7 @@ int kc_dwa_sample_window(kc_dwa *c, int ctr_type, const kc_limits *limits,
   if (max_lin < 1 || max_ang < 1)
     KC_FAIL(KC_ERR_RANGE, "sample counts must be >= 1");
   KC_TRY(use_device(c));
-  if (!c->gid.empty()) c->lat = std::move(c->full);  // the previous FULL window: its index pattern may carry over
+  if (c->rows_active) c->lat = std::move(c->full);  // the previous FULL window: its index pattern may carry over
   hm::build_window_lattice(ctr_type, *limits, cvx, cvy, com, c->prm.time_step,
                            max_lin, max_ang, c->lat);
   KC_TRY(apply_shard_rule(c));
@@ -2870,7 +2886,7 @@ int kc_dwa_set_samples(kc_dwa *c, size_t n, const double *vx, const double *vy,
 int kc_dwa_set_shard(kc_dwa *c, size_t first, size_t count) {
   if (!c) KC_FAIL(KC_ERR_INVALID, "null context");
   KC_TRY(use_device(c));
-  if (c->layout.mode == KC_SHARD_ROWS && !c->gid.empty()) {  // the full list again
+  if (c->rows_active) {  // the full list again
     c->lat = std::move(c->full);
     c->layout.mode = -1;
     KC_TRY(apply_shard_rule(c));
@@ -2889,7 +2905,7 @@ int kc_dwa_set_shard_rule(kc_dwa *c, int rank, int world, int mode) {
   if (mode >= 0 && mode != KC_SHARD_BLOCKS && mode != KC_SHARD_ROWS) KC_FAIL(KC_ERR_INVALID, "unknown shard mode %d", mode);
   if (mode >= 0 && (world < 1 || rank < 0 || rank >= world)) KC_FAIL(KC_ERR_RANGE, "rank %d outside world %d", rank, world);
   KC_TRY(use_device(c));
-  if (!c->gid.empty()) c->lat = std::move(c->full);  // the full list back in front of the rule
+  if (c->rows_active) c->lat = std::move(c->full);  // the full list back in front of the rule
   c->layout = ShardLayout{};
   c->layout.mode = mode < 0 ? -1 : mode;
   c->layout.rank = mode < 0 ? 0 : rank;
@@ -2950,7 +2966,7 @@ int kc_shard_merge(const int64_t *record, size_t words_per_rank, int world, int 
 int kc_dwa_owns_sample(kc_dwa *c, int64_t raw, int *owned) {
   if (!c || !owned) KC_FAIL(KC_ERR_INVALID, "null argument");
   int64_t lat_id = raw;
-  if (!c->gid.empty()) {
+  if (c->rows_active) {
     const auto it = std::lower_bound(c->gid.begin(), c->gid.end(), static_cast<int32_t>(std::min<int64_t>(std::max<int64_t>(raw, -1), INT32_MAX)));
     lat_id = (raw >= 0 && it != c->gid.end() && *it == raw) ? static_cast<int64_t>(it - c->gid.begin()) : -1;
   }
@@ -3892,7 +3908,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       tail.c.block_keys = c->d_block_keys.p;
       // sharded call: the last workgroup also writes this rank's words of the exchange record (no pack launch)
       tail.xs = c->sharded_call ? c->xchg_send : nullptr;
-      tail.xgid = c->gid.empty() ? nullptr : c->d_gid.p;
+      tail.xgid = c->rows_active ? c->d_gid.p : nullptr;
       tail.xrank = c->xchg_rank;
       tail.xrw = c->xchg_rw;
       c->xchg_packed = tail.xs != nullptr;
@@ -4361,7 +4377,7 @@ namespace {
 long long local_bound(const kc_dwa *c, int64_t raw) {
   if (raw <= 0) return 0;
   long long lat_lim;
-  if (c->gid.empty() || c->external)
+  if (!c->rows_active || c->external)
     lat_lim = raw;
   else
     lat_lim = std::lower_bound(c->gid.begin(), c->gid.end(), static_cast<int32_t>(std::min<int64_t>(raw, INT32_MAX))) -
@@ -4474,7 +4490,7 @@ int kc_dwa_allreduce_best(kc_dwa *c, kc_comm *m) {
                           "kc_dwa_rollout + kc_dwa_evaluate, for a device-resident record");
   if (kc::comm_device(m) != c->prm.device)
     KC_FAIL(KC_ERR_INVALID, "communicator on device %d, controller on device %d", kc::comm_device(m), c->prm.device);
-  if (!c->gid.empty())
+  if (c->rows_active)
     KC_FAIL(KC_ERR_STATE, "KC_SHARD_ROWS: the device record carries this rank's own numbering; use kc_dwa_cycle_sharded");
   KC_TRY(use_device(c));
   KC_TRY(kc::comm_allreduce_i64(m, c->d_result.p + R_KEY, c->d_result.p + R_KEY, 1, /*sum=*/false, c->stream));
@@ -4530,7 +4546,7 @@ int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P,
     pa.flags = c->d_flags.p;
     pa.n = static_cast<int>(c->n_roll);
     pa.first = static_cast<int>(c->shard_first);
-    pa.gid = c->gid.empty() ? nullptr : c->d_gid.p;
+    pa.gid = c->rows_active ? c->d_gid.p : nullptr;
     pa.xs = c->d_xs.p;
     pa.rank = rank;
     pa.rw = static_cast<int>(rw);

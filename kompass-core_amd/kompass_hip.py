@@ -14,7 +14,8 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libkompass_hip.so"
+# KOMPASS_HIP_LIB: another build of the same library (same-box A/B of two builds, tools/ab_libs.sh)
+LIB_PATH = Path(os.environ["KOMPASS_HIP_LIB"]) if os.environ.get("KOMPASS_HIP_LIB") else _HERE / "lib" / "libkompass_hip.so"
 
 ACKERMANN, DIFFERENTIAL_DRIVE, OMNI = 0, 1, 2
 CYLINDER, BOX, SPHERE = 0, 1, 2

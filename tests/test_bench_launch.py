@@ -60,3 +60,16 @@ def test_under_an_external_launcher_the_script_does_not_launch_again():
     assert p.returncode == 0, p.stderr[-800:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert len(out["ranks"]) == 2 and "launcher pid" not in p.stderr
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_dying_after_rendezvous_ends_the_launcher_within_its_limit():
+    """a rank that dies BEHIND the rendezvous leaves its peers waiting; the launcher's
+    wall-clock limit terminates the child process group and the script returns non-zero -- it does not hang."""
+    import time
+
+    t0 = time.time()
+    p = _bench("--gpus", "2", "--dry-launch", "--dry-die-after-rendezvous", "1", env={"KC_BENCH_LAUNCH_LIMIT_S": "25"})
+    assert p.returncode != 0
+    assert time.time() - t0 < 120
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

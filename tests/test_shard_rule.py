@@ -144,3 +144,48 @@ def test_world_of_one_through_rccl_with_a_rule():
                     np.testing.assert_array_equal(bx, o["px"][o["index"]])
                 ctx.close()
     comm.close()
+
+
+def test_a_rank_without_samples_still_serves_the_full_list():
+    """world greater than the number of dealt rows -- some rank's KC_SHARD_ROWS share is EMPTY.
+    That rank still reports the FULL window from kc_dwa_sample_window, answers velocity look-ups for any
+    global id, owns nothing, and the rule can be taken off again."""
+    inp = syn.make_controller_inputs("cfg1", seed=7)
+    vx = np.array([0.1, 0.2, 0.3, 0.1, 0.2], np.float64)
+    vy = np.zeros(5)
+    om = np.array([-0.2, 0.0, 0.2, -0.2, 0.0], np.float64)
+    world = 8
+    _, rows = np.unique(om + 0.0, return_inverse=True)
+    owner = kh.shard_plan(rows, world, kh.SHARD_ROWS)
+    empty = [r for r in range(world) if not (owner == r).any()]
+    assert empty
+    ctx = hip_context(kh, inp)
+    _prepare(ctx, inp)
+    for r in range(world):
+        ctx.set_shard_rule(r, world, kh.SHARD_ROWS)
+        ctx.set_samples(vx, vy, om)
+        mine = np.nonzero(owner == r)[0]
+        assert int(ctx.get_option("shard_samples")) == len(mine)
+        for g in range(5):
+            assert ctx.get_sample_velocity(g) == (vx[g], vy[g], om[g])
+            assert ctx.owns_sample(g) == (g in mine)
+        res = ctx.cycle(inp["state"], inp["P"])
+        assert res.n_samples == len(mine)
+        if r in empty:
+            assert not res.found and res.n_admissible == 0
+    # a window under the rule on a rank with nothing: the full count comes back
+    r = empty[0]
+    ctx.set_shard_rule(r, world, kh.SHARD_ROWS)
+    ctx.set_samples(vx, vy, om)
+    wvx, wvy, wom = ctx.sample_window(kh.DIFFERENTIAL_DRIVE, kh.make_limits(), (0.2, 0.0, 0.0), 2, 3)
+    n_full = len(wvx)
+    assert n_full > 0 and ctx.sample_window(kh.DIFFERENTIAL_DRIVE, kh.make_limits(), (0.2, 0.0, 0.0), 2, 3,
+                                            want_list=False) == n_full
+    _, wrows = np.unique(np.asarray(wom) + 0.0, return_inverse=True)
+    wowner = kh.shard_plan(wrows, world, kh.SHARD_ROWS)
+    assert int(ctx.get_option("shard_samples")) == int((wowner == r).sum())
+    assert ctx.get_sample_velocity(n_full - 1) == (wvx[-1], wvy[-1], wom[-1])
+    ctx.set_shard_rule(0, 1, -1)
+    ctx.set_samples(vx, vy, om)
+    assert int(ctx.get_option("shard_samples")) == 5
+    ctx.close()

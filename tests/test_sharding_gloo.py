@@ -98,3 +98,32 @@ def test_shard_plan_rules():
             # trig rows a rank needs: about 1 / w of them (+ the heavy ones)
             need = [len(set(rows[orow == r])) for r in range(w)]
             assert max(need) <= -(-int((~heavy).sum()) // w) + int(heavy.sum())
+
+
+def test_plan_and_merge_with_more_ranks_than_rows():
+    """with more ranks than dealt trig rows some ranks own NOTHING; the plan still gives every sample
+    one owner and the merge of an exchange record with empty shares names the winner in the FULL numbering."""
+    import kompass_hip as kh
+
+    rows = np.array([0, 1, 2, 0, 1], np.int32)       # 5 samples, 3 trig rows
+    world = 8
+    owner = kh.shard_plan(rows, world, kh.SHARD_ROWS)
+    counts = np.bincount(owner, minlength=world)
+    assert counts.sum() == len(rows) and (counts == 0).sum() >= world - len(rows)
+    rw = 1                                            # 64 share-local ids per rank
+    adm = np.array([1, 0, 1, 1, 1], bool)             # sample 1 hit something
+    costs = np.float32([0.7, 0.1, 0.5, 0.9, 0.5])     # winner: sample 2 (tie with 4: lowest index)
+    rec = np.full(2 + world * rw, np.iinfo(np.int64).max, np.int64)
+    rec[1] = 0
+    for r in range(world):
+        mine = np.nonzero(owner == r)[0]
+        bits = 0
+        for local, g in enumerate(mine):
+            if adm[g]:
+                bits |= 1 << local
+                rec[0] = min(rec[0], sharding.key_pack(costs[g], int(g)))
+        rec[2 + r * rw] = bits                         # an empty share contributes 0: nothing admissible
+    res = kh.shard_merge(rec, rw, world, kh.SHARD_ROWS, owner, len(rows))
+    assert res.found and res.raw_index == 2 and np.float32(res.cost) == np.float32(0.5)
+    assert res.n_admissible == int(adm.sum()) and res.index == 1   # admissible samples in front of 2: {0}
+    assert res.n_samples == len(rows)
