@@ -77,6 +77,21 @@ def pmc_traffic(kernel, scene="survey", cfg="cfg2"):
 GPU_SIMDS, GPU_CLOCK_HZ = 1024, 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz
 
 
+def profile_kernel_ms(stats_csv, kernel):
+    """Average duration (ms) of `kernel` in a committed rocprofv3 --stats summary, or None."""
+    import csv
+
+    short = {"cycle_kernel": "rollout_collide_kernel<32, 1024, kc::CycleTail>"}.get(kernel, kernel)
+    try:
+        with open(stats_csv) as f:
+            for row in csv.DictReader(f):
+                if short in row["Name"]:
+                    return float(row["AverageNs"]) * 1e-6
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def pmc_explain(kernel, scene, cfg, launch_ms):
     """What binds the kernel when HBM does not ('VALU utilisation + launch count as the explanatory
     figures'), from the newest committed SQ counter passes of this workload (profiles/*_<cfg>_<scene>_pmc_sq.json:
@@ -88,10 +103,16 @@ def pmc_explain(kernel, scene, cfg, launch_ms):
     out = {}
     files = sorted(glob.glob(str(ROOT / "profiles" / f"*_{cfg}_{scene}_pmc_sq.json")))
     rec = _json.load(open(files[-1])).get("kernels", {}).get(kernel) if files else None
-    if rec and rec.get("SQ_ACTIVE_INST_VALU") and launch_ms:
-        # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues VALU work: x 4 = SIMD cycles, over the
-        # SIMD cycles the launch lasted on the whole chip
-        out["valu_issue_frac"] = rec["SQ_ACTIVE_INST_VALU"] * 4.0 / (GPU_SIMDS * GPU_CLOCK_HZ * launch_ms * 1e-3)
+    if rec and rec.get("SQ_ACTIVE_INST_VALU"):
+        # Counter and duration from the SAME collection (one box): the kernel's average in the
+        # *_kernel_stats.csv that was written beside the counter file.  (Round 3 divided the committed counter by
+        # THIS run's launch time -- two different boxes of a pool that differ by 10 %.)
+        prof_ms = profile_kernel_ms(files[-1].replace("_pmc_sq.json", "_kernel_stats.csv"), kernel)
+        if prof_ms:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD issues VALU work: x 4 = SIMD cycles, over the
+            # SIMD cycles the launch lasted on the whole chip
+            out["valu_issue_frac"] = rec["SQ_ACTIVE_INST_VALU"] * 4.0 / (GPU_SIMDS * GPU_CLOCK_HZ * prof_ms * 1e-3)
+            out["valu_issue_frac_launch_ms"] = prof_ms
         if rec.get("SQ_INSTS_SALU") and rec.get("SQ_INSTS_VALU"):
             out["salu_per_valu"] = rec["SQ_INSTS_SALU"] / rec["SQ_INSTS_VALU"]
         if rec.get("SQ_LDS_BANK_CONFLICT") is not None and rec.get("SQ_ACTIVE_INST_LDS"):
@@ -99,6 +120,8 @@ def pmc_explain(kernel, scene, cfg, launch_ms):
         if rec.get("SQ_INSTS_VALU") and rec.get("SQ_WAVES"):
             out["valu_insts_per_wave"] = rec["SQ_INSTS_VALU"] / rec["SQ_WAVES"]
         out["counters_source"] = os.path.basename(files[-1])
+        out["counters_box"] = ("the box of the committed profile (counters and the launch time they are divided by come from "
+                               "the same collection); avg_launch_ms / achieved / frac above are THIS run's")
     files = sorted(glob.glob(str(ROOT / "profiles" / f"*_{cfg}_{scene}_phase_stamps.json")))
     if files:
         st = _json.load(open(files[-1]))
@@ -136,17 +159,16 @@ class Ranks:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(self.device)
-        if self.rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", self.device))
+        # gloo for the control plane on every run: the ONLY RCCL communicator of a rank is the one inside
+        # libkompass_hip.so that carries the cycle's all-reduce (no second communicator beside it)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier(self):
         self.dist.barrier()
         self.torch.cuda.synchronize()
 
     def max(self, *vals):
-        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device="cpu" if self.rehearsal else "cuda")
+        t = self.torch.tensor(list(vals), dtype=self.torch.float64, device="cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return [float(v) for v in t.tolist()]
 
@@ -159,6 +181,10 @@ class Ranks:
         """The library's communicator: RCCL (unique id from rank 0), or the shared-memory rehearsal transport."""
         if self.rehearsal:
             import uuid
+
+            if self.torch.cuda.device_count() >= self.world:  # (cannot happen: rehearsal means fewer GPUs than ranks)
+                raise SystemExit("the shared-memory transport is a rehearsal for boxes with fewer GPUs than ranks; "
+                                 "with a GPU per rank the exchange goes through RCCL")
 
             name = [uuid.uuid4().hex[:16] if self.rank == 0 else None]
             self.dist.broadcast_object_list(name, src=0)
@@ -268,8 +294,12 @@ def controller_bench(args, rank, world, local_rank):
 
     # ---- result of the last cycle (for the parity check below) -------------
     found, cost, raw = bool(last.found), float(last.cost), int(last.raw_index)
+    if use_dist:
+        # what the transport itself reports: ncclCommCount / ncclCommUserRank / ncclCommCuDevice (kc_comm_query)
+        q_n, q_rank, q_dev = comm.query()
     seen = ranks.gather({"rank": rank, "device": device, "pid": os.getpid(), "comm_world": comm.world,
-                         "transport": comm.transport, "winner": [found, cost, raw, int(last.index)]}) if use_dist else None
+                         "transport": comm.transport, "comm_count": q_n, "comm_user_rank": q_rank, "comm_device": q_dev,
+                         "winner": [found, cost, raw, int(last.index)]}) if use_dist else None
 
     out = None
     if rank == 0:
@@ -321,7 +351,10 @@ def controller_bench(args, rank, world, local_rank):
                 ("RCCL inside libkompass_hip.so" if comm.transport == "rccl" else
                  "REHEARSAL: the ranks share GPUs, host shared-memory transport instead of RCCL"))
             out["config"]["transport"] = comm.transport
-            out["n_ranks_seen"] = int(kh.lib().kc_comm_world(comm.h))
+            out["n_ranks_seen"] = int(q_n)  # ncclCommCount of the library's communicator (shm: ranks attached)
+            out["n_ranks_seen_source"] = "ncclCommCount" if comm.transport == "rccl" else "shm segment attach count"
+            if any(s_["comm_count"] != world or s_["comm_user_rank"] != s_["rank"] for s_ in seen):
+                raise SystemExit(f"the communicator disagrees with the launcher: {seen}")
             out["ranks"] = seen
             out["ranks_agree"] = all(s_["winner"] == seen[0]["winner"] for s_ in seen)
             out["winner"]["index"] = int(last.index)
@@ -336,6 +369,11 @@ def controller_bench(args, rank, world, local_rank):
             out["extras"] = extras(ctx, inp, P, pose)
             # one REFERENCE cycle per step: fresh sensor data, window + lattice, tracked segment, cycle
             out["fresh_inputs"] = fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args)
+            # ... which is the figure a robot pays (dwa.h:183-230: new sensor data every cycle): beside the headline
+            # at the top level, so that a record that keeps only the top-level fields keeps it
+            out["fresh_ms_per_step"] = out["fresh_inputs"]["ms_per_step"]
+            out["fresh_latency_p50_ms"] = out["fresh_inputs"]["latency_p50_ms"]
+            out["fresh_value"] = out["fresh_inputs"]["value"]
             # BASELINE configs[3] in the same record: 4096-beam scan -> 1000 x 1000 grid
             margs = argparse.Namespace(**vars(args))
             margs.steps, margs.warmup = min(args.steps, 500), min(args.warmup, 50)
@@ -533,7 +571,8 @@ def fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args):
                    "samples": n, "points": P, "n_admissible": int(r.n_admissible), "reference": "controllers/dwa.h:183-230"},
         "kernels_ms": {k: float(np.mean(v)) for k, v in kernel_ms.items()},
         "launches_per_step": len(kernel_ms),
-        "roofline": roofline_of({k: v for k, v in kernel_ms.items()}, n, P, base["map_side"], S, O, inp["scene"], cfg),
+        # (the counter passes of THIS leg: profiles/*_<cfg>_fresh_pmc_{hbm,sq}.json, collected with --fresh)
+        "roofline": roofline_of({k: v for k, v in kernel_ms.items()}, n, P, base["map_side"], S, O, "fresh", cfg),
         "winner": {"found": bool(r.found), "cost": float(r.cost), "raw_index": int(r.raw_index), "index": int(r.index)},
     }
     if not args.no_cpu:
@@ -834,11 +873,18 @@ def mapper_bench(args):
     for i in range(args.warmup):
         m.scan_to_grid_device(ang, scans[i % 8])
         m.sync()
+    lat, t_call = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ta = time.perf_counter()
         m.scan_to_grid_device(ang, scans[i % 8])
+        tb = time.perf_counter()
         m.sync()
+        tc = time.perf_counter()
+        lat.append(tc - ta)
+        t_call.append(tb - ta)
     el = time.perf_counter() - t0
+    lat_us, call_us = np.array(lat) * 1e6, np.array(t_call) * 1e6
     # same scans again with HIP events around every kernel (roofline leg; the
     # events stay out of `value`)
     m.timing_enable(True)
@@ -860,11 +906,21 @@ def mapper_bench(args):
     bytes_scan = 4 * H * W + 12 * n + 12 * ray_cells
     dom = max(kms, key=lambda k: np.mean(kms[k]))
     dom_ms = float(np.mean(kms[dom]))
+    kernels_sum_us = float(sum(np.mean(v) for v in kms.values()) * 1e3)
     return {
         "metric": "scans/s", "value": args.steps / el, "unit": "scans/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32 grid / f32 endpoints", "data": "synthetic",
         "config": {"workload": "cfg4: LocalMapper 4096 beams -> 1000x1000@0.05 grid, grid resident on device"},
+        "latency_p50_ms": float(np.percentile(lat_us, 50)) * 1e-3, "latency_min_ms": float(lat_us.min()) * 1e-3,
+        "latency_max_ms": float(lat_us.max()) * 1e-3,
+        # where a scan's wall time goes: the call (ranges over the BAR + the launches) returns, then kc_mapper_sync
+        # polls the word the last endpoints workgroup posts into pinned memory: kernels_sum is the kernels' own run
+        # time by HIP events, the rest of call + wait is launch / dispatch latency in front of and between them
+        # (BENCH_r03: 42 us per scan on the driver's box against 27 on the builder's with 24 us of kernels on both)
+        "host_phases_us": {"call_p50": float(np.percentile(call_us, 50)),
+                           "sync_wait_p50": float(np.percentile(lat_us - call_us, 50)),
+                           "kernels_sum": kernels_sum_us},
         "pcie_inclusive_scans_per_s": args.steps / el_host,
         "kernels_ms": {k: float(np.mean(v)) for k, v in kms.items()},
         "roofline": dict({"bound": "hbm", "kernel": dom, "achieved": bytes_scan / (dom_ms * 1e-3) / 1e9,

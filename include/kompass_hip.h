@@ -306,6 +306,11 @@ int kc_dwa_set_grid_from_mapper(kc_dwa *ctx, const kc_state *state, struct kc_ma
 int kc_dwa_set_tracked_segment(kc_dwa *ctx, const float *x, const float *y,
                                const float *z, const float *acc_at_seg,
                                size_t seg_size, float ref_path_length);
+/* the same segment from ONE array of points, xyz[j] = {x, y, z} of segment point j (a std::vector<Path::Point>
+ * / an (S, 3) float32 array where it lies, datatypes/path.h:14-21): the library de-interleaves while it fills
+ * its rows, the caller makes no column copies (they were 6 us of a 12 us call through the Python binding). */
+int kc_dwa_set_tracked_segment_xyz(kc_dwa *ctx, const float *xyz, const float *acc_at_seg,
+                                   size_t seg_size, float ref_path_length);
 
 /* SURVEY 8f rank 4, second half -- the reference path resident on the device.
  * kc_dwa_set_path: the whole (interpolated) path once per path: points, the
@@ -414,6 +419,11 @@ int kc_comm_rank(const kc_comm *comm);
 int kc_comm_world(const kc_comm *comm);
 enum { KC_COMM_RCCL = 0, KC_COMM_SHM = 1 };
 int kc_comm_transport(const kc_comm *comm);
+/* What the transport ITSELF reports (any pointer may be null): RCCL -- ncclCommCount, ncclCommUserRank,
+ * ncclCommCuDevice of the communicator (kc_comm_create fails when they disagree with its arguments); shared
+ * memory -- the number of ranks attached to the segment.  kc_comm_world / kc_comm_rank return the constructor's
+ * arguments.  The reference has no collective (cost_evaluator_gpu.cpp:55): nothing to cite. */
+int kc_comm_query(kc_comm *comm, int *n_ranks, int *user_rank, int *device);
 /* after kc_dwa_evaluate: ONE ncclAllReduce(1 x int64, ncclMin) of the packed key in
  * the device record, on the context's stream, and the hand-off of the reduced
  * record to the host (kc_dwa_fetch_result then returns the GLOBAL winner: found,

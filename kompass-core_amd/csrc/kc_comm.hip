@@ -43,6 +43,9 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                             hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // what the communicator itself reports
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;   // (kc_comm_query)
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
   std::string why;
 };
@@ -66,7 +69,11 @@ Rccl &rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+    r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(sym("ncclCommCuDevice"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString && r.CommCount &&
+           r.CommUserRank && r.CommCuDevice;
     if (!r.ok) r.why = "librccl.so lacks a required symbol";
   });
   return r;
@@ -207,6 +214,15 @@ int kc_comm_create(int rank, int world, const uint8_t id_in[KC_COMM_ID_BYTES], i
     delete m;
     return KC_ERR_HIP;
   }
+  // the communicator's own view has to agree with the arguments (a stale unique id, a rank started twice)
+  int cnt = -1, ur = -1, dev = -1;
+  if (rccl().CommCount(m->comm, &cnt) != ncclSuccess || rccl().CommUserRank(m->comm, &ur) != ncclSuccess ||
+      rccl().CommCuDevice(m->comm, &dev) != ncclSuccess || cnt != world || ur != rank || dev != device) {
+    set_error("RCCL communicator reports %d ranks / rank %d / device %d, asked for %d / %d / %d", cnt, ur, dev, world, rank, device);
+    (void)rccl().CommDestroy(m->comm);
+    delete m;
+    return KC_ERR_STATE;
+  }
   *out = m;
   return KC_OK;
 }
@@ -225,49 +241,61 @@ int kc_comm_create_shm(int rank, int world, const char *name, int device, kc_com
   m->shm_name = std::string("/kc_comm_") + name;
   if (const char *e = std::getenv("KC_SHM_TIMEOUT_MS")) m->shm_timeout_ms = std::max(100, std::atoi(e));
   m->shm_bytes = 4096 + sizeof(ShmRank) * static_cast<size_t>(world);
-  auto fail = [&](const char *what) {
-    set_error("shm transport: %s(%s) failed: %s", what, m->shm_name.c_str(), std::strerror(errno));
+  // sys: a system call failed (errno says why); otherwise a peer did not show up in time.  Rank 0 takes the
+  // name away on every failure path: a later communicator of the same name must not find this segment.
+  auto fail = [&](const char *what, bool sys) {
+    if (sys) set_error("shm transport: %s(%s) failed: %s", what, m->shm_name.c_str(), std::strerror(errno));
+    else set_error("shm transport: %s on %s timed out after %d ms", what, m->shm_name.c_str(), m->shm_timeout_ms);
     if (m->shm_base) munmap(m->shm_base, m->shm_bytes);
+    if (rank == 0) shm_unlink(m->shm_name.c_str());
     delete m;
     return KC_ERR_HIP;
   };
-  // rank 0 creates and sizes the segment (a fresh file is all zero: every flag 0), the others
-  // wait for its magic word
-  int fd = -1;
+  // rank 0 creates and sizes the segment (a fresh file is all zero: every flag 0) and stores the magic word;
+  // the others look the name up until they hold a segment that is (a) large enough, (b) carries the magic word
+  // and (c) is still waiting for ranks.  A segment whose ranks have all attached is a LEFT-OVER of an earlier
+  // communicator of this name (its rank 0 died between attach and unlink): never joined, looked up again.
   const auto t0 = std::chrono::steady_clock::now();
+  auto late = [&] { return std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(m->shm_timeout_ms); };
+  ShmHeader *h = nullptr;
   if (rank == 0) {
     shm_unlink(m->shm_name.c_str());
-    fd = shm_open(m->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0) return fail("shm_open");
+    const int fd = shm_open(m->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return fail("shm_open", true);
     if (ftruncate(fd, static_cast<off_t>(m->shm_bytes)) != 0) {
       close(fd);
-      return fail("ftruncate");
+      return fail("ftruncate", true);
     }
-  } else {
-    for (;;) {
-      fd = shm_open(m->shm_name.c_str(), O_RDWR, 0600);
-      struct stat st {};
-      if (fd >= 0 && fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) >= m->shm_bytes) break;
-      if (fd >= 0) close(fd);
-      fd = -1;
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(m->shm_timeout_ms)) return fail("shm_open");
-      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    m->shm_base = mmap(nullptr, m->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m->shm_base == MAP_FAILED) {
+      m->shm_base = nullptr;
+      return fail("mmap", true);
     }
-  }
-  m->shm_base = mmap(nullptr, m->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (m->shm_base == MAP_FAILED) {
-    m->shm_base = nullptr;
-    return fail("mmap");
-  }
-  ShmHeader *h = shm_header(m);
-  if (rank == 0) {
+    h = shm_header(m);
     h->world = world;
     h->magic.store(kShmMagic, std::memory_order_release);
   } else {
-    while (h->magic.load(std::memory_order_acquire) != kShmMagic) {
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(m->shm_timeout_ms)) return fail("handshake");
-      std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    for (;;) {
+      const int fd = shm_open(m->shm_name.c_str(), O_RDWR, 0600);
+      struct stat st {};
+      if (fd >= 0 && fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) >= m->shm_bytes) {
+        void *base = mmap(nullptr, m->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (base == MAP_FAILED) return fail("mmap", true);
+        ShmHeader *hh = static_cast<ShmHeader *>(base);
+        if (hh->magic.load(std::memory_order_acquire) == kShmMagic &&
+            hh->attached.load(std::memory_order_acquire) < hh->world) {
+          m->shm_base = base;
+          h = hh;
+          break;
+        }
+        munmap(base, m->shm_bytes);  // not sized / not signed yet, or stale
+      } else if (fd >= 0) {
+        close(fd);
+      }
+      if (late()) return fail("waiting for rank 0's segment", false);
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
     }
     if (h->world != world) {
       set_error("shm transport: segment %s was created for %lld ranks, not %d", m->shm_name.c_str(), h->world, world);
@@ -280,7 +308,7 @@ int kc_comm_create_shm(int rank, int world, const char *name, int device, kc_com
   // as long as a process maps it and cannot collide with a later communicator of the same name)
   h->attached.fetch_add(1, std::memory_order_acq_rel);
   while (h->attached.load(std::memory_order_acquire) < world) {
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(m->shm_timeout_ms)) return fail("attach");
+    if (late()) return fail("attach", false);
     std::this_thread::sleep_for(std::chrono::milliseconds(1));
   }
   if (rank == 0) shm_unlink(m->shm_name.c_str());
@@ -314,5 +342,26 @@ void kc_comm_destroy(kc_comm *m) {
 int kc_comm_rank(const kc_comm *m) { return m ? m->rank : -1; }
 int kc_comm_world(const kc_comm *m) { return m ? m->world : 0; }
 int kc_comm_transport(const kc_comm *m) { return m ? (m->shm ? KC_COMM_SHM : KC_COMM_RCCL) : -1; }
+
+// What the TRANSPORT reports, not what the constructor was told: ncclCommCount / ncclCommUserRank /
+// ncclCommCuDevice of the RCCL communicator; the attach count of the segment for the shared-memory transport.
+int kc_comm_query(kc_comm *m, int *n_ranks, int *user_rank, int *device) {
+  if (!m) KC_FAIL(KC_ERR_INVALID, "null communicator");
+  int cnt = 0, ur = 0, dev = 0;
+  if (m->shm) {
+    cnt = m->shm_base ? static_cast<int>(shm_header(m)->attached.load(std::memory_order_acquire)) : 0;
+    ur = m->rank;
+    dev = m->device;
+  } else {
+    if (!m->comm || !rccl().ok) KC_FAIL(KC_ERR_STATE, "no RCCL communicator");
+    KC_NCCL(rccl().CommCount(m->comm, &cnt));
+    KC_NCCL(rccl().CommUserRank(m->comm, &ur));
+    KC_NCCL(rccl().CommCuDevice(m->comm, &dev));
+  }
+  if (n_ranks) *n_ranks = cnt;
+  if (user_rank) *user_rank = ur;
+  if (device) *device = dev;
+  return KC_OK;
+}
 
 }  // extern "C"

@@ -73,9 +73,8 @@ struct kc_dwa {
   long long grid_seq = 0;
   hipEvent_t grid_ready = nullptr;  // mapper stream -> this stream
   bool device_sensor = true;            // KC_SENSOR_HOST=1 turns the device-side update off
-  size_t sensor_big_min = 4096;         // clouds beyond this take the multi-workgroup build (crossover measured with
-                                        // tools/sensor_update_time.py; KC_SENSOR_BIG_MIN for that measurement)
-  bool sensor_lds_ok = false;
+  bool sensor_fused_ok = false;         // sensor_fused_kernel may take kSensorFusedLds
+  bool sensor_two_launch = false;       // option: the two-launch build (clouds beyond kSensorFusedMax) for every size
   std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
   // occupancy bits of all accepted voxel columns over their bounding box
   PinBuf<uint32_t> h_gbits;
@@ -242,7 +241,7 @@ struct kc_dwa {
   DevBuf<uint8_t> d_skip;
   size_t n_bucketed = 0;
   DevBuf<float> d_dc;    // cell centre -> nearest obstacle (device sensor build only)
-  DevBuf<int> d_dc_enable;  // ... filled in or not (decided by sensor_build_kernel)
+  DevBuf<int> d_dc_enable;  // ... filled in or not (decided by the sensor build)
   bool have_dc = false;  // ... valid for the current buckets
   // Off by default: per sensor update the table costs about what it saves in the
   // one cycle that follows; it pays when several cycles share a sensor update.
@@ -320,7 +319,6 @@ struct kc_dwa {
   bool onear_ok = false;                 // the table covers the running cycle
   int obs_union = 96;                    // option "obs_union": obstacle_union_scan up to this many obstacles (0: off)
   bool obs_near_ahead = true;            // test hook KC_OBS_NEAR_AHEAD=0: the cycle builds the table itself
-  bool scan_lds_ok = false;              // sensor_build_scan_kernel may use the large LDS window
   long long onear_rides = 0, onear_builds = 0;  // tables built in the sensor launch / by a launch of their own
   bool onear_ahead = false;              // kc_dwa_set_scan planned a table (onear_args) for the sensor build launch
   ObsNearArgs onear_args{};
@@ -346,6 +344,8 @@ namespace {
 // largest point list the device-side sensor update takes (bucket grid of at most 64 x 64 cells:
 // about one obstacle per cell up to 4 k points, 64 per cell here); beyond: the host path, finer grid
 constexpr size_t kSensorDeviceMax = 262144;
+constexpr size_t kSensorFusedMax = 32768;       // points up to which the one-launch sensor build is used
+constexpr size_t kSensorFusedLds = 100 * 1024;  // dynamic LDS of sensor_fused_kernel (band rows; bucket tables + point ids)
 
 int use_device(const kc_dwa *c) {
   KC_HIP(hipSetDevice(c->prm.device));
@@ -996,7 +996,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
 int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   *done = false;
   c->raw_on_device = false;
-  if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
+  if (!c->device_sensor || !c->trig_direct || c->prm.shape == KC_SPHERE ||
       n == 0 || n > kSensorDeviceMax)
     return KC_OK;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -1114,7 +1114,7 @@ int plan_trig_job(kc_dwa *c, TrigJob &j) {
 int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
                                  const float hi[3], bool *done, bool raw_copied) {
   *done = false;
-  if (!c->device_sensor || !c->trig_direct || !c->sensor_lds_ok || c->prm.shape == KC_SPHERE ||
+  if (!c->device_sensor || !c->trig_direct || c->prm.shape == KC_SPHERE ||
       n == 0 || n > kSensorDeviceMax)
     return KC_OK;
   // bitmap: keys of the bounds (points beyond the 16-level octree are dropped
@@ -1133,7 +1133,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   }
   // one workgroup with everything in LDS, or (large clouds / bitmaps) the points
   // over many workgroups with device atomics
-  const bool big = n > c->sensor_big_min || nwords * sizeof(uint32_t) > 64 * 1024;
+  const bool big_only = c->sensor_two_launch;  // option "sensor_two_launch": the build for clouds beyond kSensorFusedMax, for any size (tests)
   // bucket grid: covers the image of the bounding box (an affine map takes the
   // box into the hull of its eight transformed corners)
   double blo[2] = {DBL_MAX, DBL_MAX}, bhi[2] = {-DBL_MAX, -DBL_MAX};
@@ -1170,13 +1170,6 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   KC_TRY(c->d_skip.reserve(ncell + 4));
   KC_TRY(c->d_bobs.reserve(2 * n));
   KC_TRY(c->d_raw.reserve(3 * n));
-  if (big) {
-    // byte map of the voxels: zero between updates (sensor_place_kernel clears what it packs)
-    const uint8_t *was = c->d_sensor_bytes.p;
-    KC_TRY(c->d_sensor_bytes.reserve(nwords * 32));
-    if (c->d_sensor_bytes.p != was)
-      KC_HIP(hipMemsetAsync(c->d_sensor_bytes.p, 0, c->d_sensor_bytes.cap, c->stream));
-  }
   // the raw points: host copy for the lazy lists, device copy through the BAR
   c->host_lists_valid = false;
   if (xyz) {
@@ -1227,22 +1220,55 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     c->trig_ahead_valid = true;
     ++c->trig_rides;
   }
-  if (!big) {
-    const size_t lds = nwords * 4 + (ncell + 1) * 4 + 8 + static_cast<size_t>(b.H) * 8 + 16;
+  // One launch, no hand-over between workgroups (sensor_fused_kernel): every workgroup reads all points and keeps
+  // its part -- bands of the bitmap with their dilations, slices of the bucket tables.  Beyond 32 k points (every
+  // workgroup reading every point stops being free) or with bands that do not fit LDS: the two-launch build.
+  const DilGeom dg = dil_geom(c);
+  const int dilR = c->have_dil ? dg.R : -1;
+  int nb = std::min(64, c->gH), band_rows = (c->gH + nb - 1) / nb;
+  // (LDS of a band: its rows + R rows of halo either side, and the two dilation accumulators of its own rows)
+  auto band_bytes = [&] { return (3 * static_cast<size_t>(band_rows) + 2 * static_cast<size_t>(std::max(dilR, 0))) * c->gwpr * 4; };
+  while (band_bytes() > kSensorFusedLds && band_rows > 1) {
+    band_rows = (band_rows + 1) / 2;
+  }
+  nb = (c->gH + band_rows - 1) / band_rows;
+  const bool fused = !big_only && c->sensor_fused_ok && n <= kSensorFusedMax && band_bytes() <= kSensorFusedLds && nb <= 1024;
+  bool masks_built = false;
+  if (fused) {
+    SensorFusedArgs f{};
+    f.a = a;
+    f.nb = nb;
+    f.kb = 8;
+    f.band_rows = band_rows;
+    f.R = dilR;
+    f.ginner = c->d_ginner.p;
+    f.gouter = c->d_gouter.p;
+    if (dilR >= 0) dil_tables(dg, f.win, f.wout);
+    size_t bucket_lds = (((ncell + 4) & ~size_t(3)) + ((ncell + 3) & ~size_t(3))) * 4 + 64 * 8;
+    f.ids_in_lds = bucket_lds + 2 * n + 16 <= kSensorFusedLds ? 1 : 0;  // (8 k points: 16 KB; else the second pass transforms all again)
+    if (f.ids_in_lds) bucket_lds += 2 * n;
+    size_t lds = std::max(band_bytes(), bucket_lds) + 16;
     const size_t olds = 2 * static_cast<size_t>(c->onear_args.n) * sizeof(float);
-    const bool ride = c->onear_ahead && c->scan_lds_ok && olds <= kObsNearLdsMax;
-    KC_TRY(c->timing.start("sensor_build_kernel", c->stream));
+    const bool ride = c->onear_ahead && olds <= kObsNearLdsMax;
     if (ride) {
       const int cells = c->onear_args.W * c->onear_args.H, per = kSensorBlock / kObsNearLanes;
-      hipLaunchKernelGGL(sensor_build_scan_kernel<true>, dim3(1 + (cells + per - 1) / per + tj), dim3(kSensorBlock),
-                         std::max(lds, olds), c->stream, a, c->onear_args);
+      f.o = c->onear_args;
+      f.o_blocks = (cells + per - 1) / per;
+      lds = std::max(lds, olds);
       c->onear_version = c->sensor_version;
       ++c->onear_rides;
-    } else {
-      hipLaunchKernelGGL(sensor_build_kernel, dim3(1 + tj), dim3(kSensorBlock), lds, c->stream, a);
     }
+    KC_TRY(c->timing.start("sensor_fused_kernel", c->stream));
+    hipLaunchKernelGGL(sensor_fused_kernel<true>, dim3(f.nb + f.kb + f.o_blocks + tj), dim3(kSensorBlock), lds, c->stream, f);
     KC_TRY(c->timing.stop(c->stream));
+    masks_built = true;
   } else {
+    {  // byte map of the voxels: zero between updates (sensor_place_kernel clears what it packs)
+      const uint8_t *was = c->d_sensor_bytes.p;
+      KC_TRY(c->d_sensor_bytes.reserve(nwords * 32));
+      if (c->d_sensor_bytes.p != was)
+        KC_HIP(hipMemsetAsync(c->d_sensor_bytes.p, 0, c->d_sensor_bytes.cap, c->stream));
+    }
     // scratch: [cell records n | ox n | oy n | histogram rows]
     SensorBigArgs sb{};
     sb.a = a;
@@ -1326,7 +1352,8 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     c->dc_H = da.Hd;
     c->have_dc = true;
   }
-  KC_TRY(defer_dilate(c));
+  if (masks_built) c->dil_lazy = false;  // (sensor_fused_kernel wrote both dilations beside the bitmap)
+  else KC_TRY(defer_dilate(c));
   c->have_gbits = true;
   b.skip = c->d_skip.p;
   b.cell_start = c->d_cells.p;
@@ -1689,7 +1716,7 @@ bool onear_wanted(const kc_dwa *c) {
 
 // kc_dwa_set_scan knows the pose the next cycle starts from: the table over what the LAST cycle's lattice and
 // horizon reach from there (+ 15 %: the velocity window moves with the robot's speed) rides in the launch of
-// the sensor tables (sensor_build_scan_kernel).  A cycle the guess does not cover builds its own.
+// the sensor tables (sensor_fused_kernel).  A cycle the guess does not cover builds its own.
 int onear_plan_ahead(kc_dwa *c, double x, double y) {
   c->onear_ahead = false;
   if (!onear_wanted(c) || c->P < 2) return KC_OK;
@@ -2429,7 +2456,6 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
     }
     if (const char *e = std::getenv("KC_TRIG_COPY"))
       if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
-    if (const char *e = std::getenv("KC_SENSOR_BIG_MIN")) c->sensor_big_min = std::min<size_t>(16384, std::strtoul(e, nullptr, 10));
     if (const char *e = std::getenv("KC_SENSOR_HOST"))
       if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
     if (const char *e = std::getenv("KC_TRIG_STAGES")) c->trig_staged = e[0] != '0';
@@ -2452,14 +2478,10 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
         c->no_dc = false;
       }
     }
-    c->sensor_lds_ok =
-        hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_build_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
-    if (!c->sensor_lds_ok) (void)hipGetLastError();
-    c->scan_lds_ok = c->sensor_lds_ok &&
-                     hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_build_scan_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) == hipSuccess;
-    if (!c->scan_lds_ok) (void)hipGetLastError();
+    c->sensor_fused_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_fused_kernel<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(kSensorFusedLds)) == hipSuccess;
+    if (!c->sensor_fused_ok) (void)hipGetLastError();
     if (const char *e = std::getenv("KC_COST_KERNEL"))  // tuning/test hook: "block" | "wave"
       c->cost_kernel_force = e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0;
     if (const char *e = std::getenv("KC_TEST_LATE_FLAG_MS")) c->test_late_flag_ms = std::atoi(e);
@@ -2725,6 +2747,7 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     c->onear_ok = false;
     if (!on) c->oscan_valid = false;
   } else if (n == "lazy_dilate") c->lazy_dilate = on;
+  else if (n == "sensor_two_launch") c->sensor_two_launch = on;
   else if (n == "early_launch") c->early_launch = on;
   else if (n == "device_trig") c->device_trig = on;
   else if (n == "sensor_on_host") c->device_sensor = !on;
@@ -2746,6 +2769,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "cost_kernel") *v = c->cost_kernel_force;
   else if (n == "cost_dc_cells") *v = c->no_dc ? 0.0 : c->dc_side;
   else if (n == "lazy_dilate") *v = c->lazy_dilate;
+  else if (n == "sensor_two_launch") *v = c->sensor_two_launch;
   else if (n == "near_table") *v = c->near_side;
   else if (n == "cycle_samples") *v = c->cycle_samples_opt;
   else if (n == "velocity_group") *v = c->velocity_group;
@@ -3234,10 +3258,11 @@ int kc_dwa_set_grid_from_mapper(kc_dwa *c, const kc_state *st, kc_mapper *m, flo
   return kc_dwa_set_grid_device(c, st, v.grid, v.H, v.W, v.res, v.c0, v.c1, max_range);
 }
 
-int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
-                               const float *z, const float *acc, size_t S,
-                               float ref_len) {
-  if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
+}  // extern "C"
+namespace {
+// x / y / z rows, or xyz = [S][3] interleaved points (Path::Point order) de-interleaved on the way into the rows
+int set_tracked_segment_impl(kc_dwa *c, const float *x, const float *y, const float *z, const float *xyz,
+                             const float *acc, size_t S, float ref_len) {
   static double dbg_sum[6] = {0};
   static long dbg_n = 0;
   const auto dbg0 = std::chrono::steady_clock::now();
@@ -3270,10 +3295,19 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
   if (c->seg_stage.size() < seg_words) c->seg_stage.resize(seg_words + seg_words / 4 + 16);
   float *h = c->seg_stage.data();
   // rows: whole-row copies (this call is on the host's critical path in front of every cycle launch)
-  std::memcpy(h, x, S * sizeof(float));
-  std::memcpy(h + S, y, S * sizeof(float));
-  if (z) std::memcpy(h + 2 * S, z, S * sizeof(float));
-  else std::memset(h + 2 * S, 0, S * sizeof(float));
+  if (xyz) {
+    float *hx = h, *hy = h + S, *hz0 = h + 2 * S;
+    for (size_t j = 0; j < S; ++j) {
+      hx[j] = xyz[3 * j];
+      hy[j] = xyz[3 * j + 1];
+      hz0[j] = xyz[3 * j + 2];
+    }
+  } else {
+    std::memcpy(h, x, S * sizeof(float));
+    std::memcpy(h + S, y, S * sizeof(float));
+    if (z) std::memcpy(h + 2 * S, z, S * sizeof(float));
+    else std::memset(h + 2 * S, 0, S * sizeof(float));
+  }
   std::memcpy(h + 4 * S, acc, S * sizeof(float));
   uint32_t zbits = 0u;
   {
@@ -3413,6 +3447,19 @@ int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y,
     std::fprintf(stderr, "[kc host] set_tracked_segment us: quiesce %.2f rows %.2f tables %.2f upload %.2f near %.2f\n",
                  dbg_sum[0] / dbg_n, dbg_sum[1] / dbg_n, dbg_sum[2] / dbg_n, dbg_sum[3] / dbg_n, dbg_sum[4] / dbg_n);
   return KC_OK;
+}
+}  // namespace
+extern "C" {
+
+int kc_dwa_set_tracked_segment(kc_dwa *c, const float *x, const float *y, const float *z, const float *acc, size_t S,
+                               float ref_len) {
+  if (!c || (S && (!x || !y || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
+  return set_tracked_segment_impl(c, x, y, z, nullptr, acc, S, ref_len);
+}
+
+int kc_dwa_set_tracked_segment_xyz(kc_dwa *c, const float *xyz, const float *acc, size_t S, float ref_len) {
+  if (!c || (S && (!xyz || !acc))) KC_FAIL(KC_ERR_INVALID, "null argument");
+  return set_tracked_segment_impl(c, nullptr, nullptr, nullptr, xyz, acc, S, ref_len);
 }
 
 // SURVEY 8f rank 4, second half: the interpolated reference path stays on the
@@ -3907,7 +3954,9 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       tail.seq = ++c->seq;
       tail.c.block_keys = c->d_block_keys.p;
       // sharded call: the last workgroup also writes this rank's words of the exchange record (no pack launch)
-      tail.xs = c->sharded_call ? c->xchg_send : nullptr;
+      // (cycle_epilogue holds kMaxWords x kBlock = 2048 32-bit words of the bitmap in registers: a wider region --
+      // a share beyond 65536 samples -- is packed by xchg_pack_kernel behind the cycle instead)
+      tail.xs = (c->sharded_call && 2 * static_cast<size_t>(c->xchg_rw) <= 2048) ? c->xchg_send : nullptr;
       tail.xgid = c->rows_active ? c->d_gid.p : nullptr;
       tail.xrank = c->xchg_rank;
       tail.xrw = c->xchg_rw;
@@ -4545,7 +4594,6 @@ int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P,
     pa.result = c->d_result.p;
     pa.flags = c->d_flags.p;
     pa.n = static_cast<int>(c->n_roll);
-    pa.first = static_cast<int>(c->shard_first);
     pa.gid = c->rows_active ? c->d_gid.p : nullptr;
     pa.xs = c->d_xs.p;
     pa.rank = rank;

@@ -139,18 +139,248 @@ __global__ __launch_bounds__(kObsNearBlock) void obs_near_kernel(ObsNearArgs a) 
   obs_near_body<kLds, kObsNearBlock>(a, static_cast<int>(blockIdx.x), smem);
 }
 
-// A scan update that knows where the next cycle starts builds the table in the launch of the sensor tables:
-// workgroup 0 is sensor_build_kernel, the others take kSensorBlock / 8 cells each (nothing of theirs depends
-// on workgroup 0: the obstacles in beam order come from the host).  The cycle then finds the table in place.
-template <bool kLds>
-__global__ __launch_bounds__(kSensorBlock) void sensor_build_scan_kernel(SensorArgs a, ObsNearArgs o) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  if (blockIdx.x >= gridDim.x - a.trig.nblk) {
-    trig_job_block<kSensorBlock>(a.trig, static_cast<int>(blockIdx.x - (gridDim.x - a.trig.nblk)));
-    return;
+// ---------------------------------------------------------------------------
+// The sensor update of a controller cycle in ONE launch with NO inter-workgroup dependency (round 4).
+// collision_check.h:91-136 (octree rebuild) + cost_evaluator.h:174-223 (setPointScan) produce, here: the
+// voxel bitmap, its two dilations, the obstacle buckets.  Rounds 1-3 built them with one workgroup (slow
+// beyond ~4 k points), or with two launches + a byte map + a histogram matrix in global memory, and left
+// the dilation to every workgroup of the cycle kernel (3.5 us of its phase A).  Every hand-over between
+// workgroups costs a launch boundary or a device-wide barrier (3-7 us on this chip); reading the point list
+// again costs next to nothing (105 KB at cfg2, L2-resident: the host has just written it).  So nobody hands
+// anything over -- every workgroup reads ALL points and keeps what falls into ITS part of the output:
+//   band workgroups    rows [y0, y1) of the bitmap: the points whose voxel row lies within R rows of the
+//                      band go into an LDS bitmap (LDS atomics), the band's rows leave as plain stores
+//                      together with their two dilations, formed from the LDS rows (R = dilation radius);
+//   bucket workgroups  each histograms ALL points over the <= 64 x 64 bucket grid and scans it (redundant:
+//                      2 us, instead of a hand-over), then writes ITS slice of the cell starts / skip table and
+//                      puts the points of ITS cell range into cell order (rank from an LDS counter: the owner
+//                      of a cell is the only one that ranks its points);
+//   riders             the near table of a scan polyline (obs_near_body) and the cycle's trig table (TrigJob).
+// No global atomics, no scratch buffers, no second launch, nothing for the cycle kernel to dilate.
+// Same per-point arithmetic as the kernels above (add_voxel / Rigid3f::apply / cell index).
+// ---------------------------------------------------------------------------
+struct SensorFusedArgs {
+  SensorArgs a;
+  ObsNearArgs o;         // the rider (o_blocks > 0)
+  int nb, kb, o_blocks;  // band workgroups | bucket workgroups | near-table workgroups (| a.trig.nblk trig workgroups)
+  int band_rows;         // rows per band
+  int ids_in_lds;        // bucket workgroups keep the cell id of every point in LDS between their two passes
+  int R;                 // dilation radius in rows; < 0: no masks (spheres without a gap bound, huge robots)
+  uint32_t *ginner, *gouter;
+  signed char win[kMaxDil + 1], wout[kMaxDil + 1];
+};
+
+__device__ __forceinline__ bool sensor_voxel_cell(const SensorArgs &a, float x, float y, float z, int &cx, int &cy) {
+  // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
+  const double fx = floor(a.inv_res * static_cast<double>(x));
+  const double fy = floor(a.inv_res * static_cast<double>(y));
+  const double fz = floor(a.inv_res * static_cast<double>(z));
+  if (!(fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0)) return false;
+  const int kz = static_cast<int>(fz);
+  const double zlo = static_cast<double>(kz) * a.res;
+  const double zhi = static_cast<double>(kz + 1) * a.res;
+  if (!(zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height)) return false;
+  cx = static_cast<int>(fx) - a.gkx0;
+  cy = static_cast<int>(fy) - a.gky0;
+  return cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr;
+}
+
+// every point of the list, eight loads in flight per thread: f(i, x, y, z)
+template <class F>
+__device__ __forceinline__ void sensor_for_points(const SensorArgs &a, F &&f) {
+  const int tid = threadIdx.x;
+  for (int i0 = 0; i0 < a.n; i0 += 8 * kSensorBlock) {
+    float qx[8], qy[8], qz[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kSensorBlock + tid;
+      const int j = i < a.n ? i : 0;  // idle slots shadow point 0, used for nothing
+      qx[u] = a.xyz[3 * j];
+      qy[u] = a.xyz[3 * j + 1];
+      qz[u] = a.xyz[3 * j + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * kSensorBlock + tid;
+      if (i < a.n) f(i, qx[u], qy[u], qz[u]);
+    }
   }
-  if (blockIdx.x == 0) sensor_build_body(a, smem);
-  else obs_near_body<kLds, kSensorBlock>(o, static_cast<int>(blockIdx.x) - 1, smem);
+}
+
+__device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int band, unsigned char *smem) {
+  const SensorArgs &a = s.a;
+  const int tid = threadIdx.x;
+  const int R = s.R > 0 ? s.R : 0;
+  const int y0 = band * s.band_rows, y1 = min(y0 + s.band_rows, a.gH);
+  if (y0 >= y1) return;
+  const int lo = y0 - R, nrows = (y1 - y0) + 2 * R;
+  uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);  // [nrows][gwpr], row 0 = bitmap row `lo`
+  for (int i = tid; i < nrows * a.gwpr; i += kSensorBlock) lbits[i] = 0u;
+  __syncthreads();
+  sensor_for_points(a, [&](int, float x, float y, float z) {
+    int cx, cy;
+    if (sensor_voxel_cell(a, x, y, z, cx, cy)) {
+      const int r = cy - lo;
+      if (r >= 0 && r < nrows) atomicOr(&lbits[r * a.gwpr + (cx >> 5)], 1u << (cx & 31));
+    }
+  });
+  __syncthreads();
+  // The band's rows leave as they are; their two dilations are formed from the LDS rows around them (rows outside
+  // the bitmap hold no bit: sensor_voxel_cell admits none there).  A task per (row offset j, output word): the
+  // (2 R + 1) x words tasks of a band go round ALL lanes (a thread per output word left 7/8 of the workgroup idle
+  // behind a loop of (2 R + 1) x two run widths), the contributions meet in two LDS accumulators.
+  const int nout = (y1 - y0) * a.gwpr;
+  uint32_t *lin = lbits + nrows * a.gwpr, *lout = lin + nout;
+  if (s.R >= 0) {
+    for (int t = tid; t < 2 * nout; t += kSensorBlock) lin[t] = 0u;
+    __syncthreads();
+    const int total = nout * (2 * R + 1);
+    for (int t = tid; t < total; t += kSensorBlock) {
+      const int jj = t / nout, o = t - jj * nout;  // (the row offset is the slow index: a wavefront reads one LDS row)
+      const int yr = o / a.gwpr, w = o - yr * a.gwpr;
+      const uint32_t *row = lbits + (yr + jj) * a.gwpr;  // row offset j = jj - R of output row yr (LDS row yr + R)
+      const uint32_t mid = row[w];
+      const uint32_t left = w > 0 ? row[w - 1] : 0u;
+      const uint32_t right = w + 1 < a.gwpr ? row[w + 1] : 0u;
+      if ((mid | left | right) == 0u) continue;
+      const int aj = jj < R ? R - jj : jj - R;
+      if (s.win[aj] >= 0) atomicOr(&lin[o], hdilate(left, mid, right, s.win[aj]));
+      if (s.wout[aj] >= 0) atomicOr(&lout[o], hdilate(left, mid, right, s.wout[aj]));
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < nout; t += kSensorBlock) {
+    const int yr = t / a.gwpr, w = t - yr * a.gwpr;
+    const size_t g = static_cast<size_t>(y0 + yr) * a.gwpr + w;
+    a.gbits[g] = lbits[(yr + R) * a.gwpr + w];
+    if (s.R >= 0) {
+      s.ginner[g] = lin[t];
+      s.gouter[g] = lout[t];
+    }
+  }
+}
+
+__device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int me, unsigned char *smem) {
+  const SensorArgs &a = s.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncell = a.W * a.H;
+  int *lstart = reinterpret_cast<int *>(smem);                 // [ncell + 1] (+ pad): slot k + 1 = count, then start, of cell k
+  int *lpos = lstart + ((ncell + 1 + 3) & ~3);                 // [ncell] next free position of a cell of MY range
+  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(lpos + ((ncell + 3) & ~3));  // [64]
+  // [n] cell id of every point (0xFFFF: not an obstacle), kept from the counting pass: the placing pass reloads and
+  // transforms only the points of this workgroup's cell range (an eighth of them)
+  uint16_t *lid = s.ids_in_lds ? reinterpret_cast<uint16_t *>(lmask + 64) : nullptr;
+  __shared__ int wave_tot[kSensorBlock / 64];
+  __shared__ int s_nonempty;
+  for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = 0;
+  if (tid == 0) s_nonempty = 0;
+  __syncthreads();
+  // ---- 1: counts of ALL points ----------------------------------------------------------------------
+  sensor_for_points(a, [&](int i, float x, float y, float z) {
+    float ox, oy;
+    int id;
+    const bool ob = sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id);
+    if (ob) atomicAdd(&lstart[id + 1], 1);
+    if (lid) lid[i] = ob ? static_cast<uint16_t>(id) : static_cast<uint16_t>(0xFFFF);
+  });
+  __syncthreads();
+  // ---- 2: starts: in-place inclusive scan of the ncell + 1 slots (consecutive slots per thread, <= 8: the
+  // host keeps the grid at 64 x 64; wave scan of the thread totals)
+  {
+    const int N = ncell + 1;
+    const int per = (N + kSensorBlock - 1) / kSensorBlock;
+    const int k0 = tid * per;
+    int v[8];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = k0 + k;
+      if (k < per && idx < N) sum += lstart[idx];
+      v[k] = sum;
+    }
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += u;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_tot[w];
+    const int offset = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = k0 + k;
+      if (k < per && idx < N) lstart[idx] = offset + v[k];
+    }
+  }
+  __syncthreads();
+  // ---- 3: my slice of what the cost kernels read: cell starts, skip table (Chebyshev distance to the nearest
+  // non-empty cell, from one 64-bit mask per grid row), dc_enable -- 64 cells per wavefront, the wavefronts of
+  // the bucket workgroups interleaved
+  for (int y = wave; y < a.H; y += kSensorBlock / 64) {
+    const bool ne = lane < a.W && lstart[y * a.W + lane + 1] > lstart[y * a.W + lane];
+    const unsigned long long m = __ballot(ne);
+    if (lane == 0) {
+      lmask[y] = m;
+      if (me == 0) atomicAdd(&s_nonempty, __popcll(m));
+    }
+  }
+  const int c0 = static_cast<int>(static_cast<long long>(ncell) * me / s.kb);
+  const int c1 = static_cast<int>(static_cast<long long>(ncell) * (me + 1) / s.kb);
+  for (int k = c0 + tid; k < c1; k += kSensorBlock) lpos[k] = lstart[k];
+  __syncthreads();
+  if (me == 0 && tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
+  if (me == 0 && tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
+  for (int k = (wave * s.kb + me) * 64 + lane; k <= ncell; k += s.kb * kSensorBlock) {
+    a.cell_start[k] = lstart[k];
+    if (k == ncell) break;
+    const int y = k / a.W, x = k - y * a.W;
+    unsigned long long acc = lmask[y];
+    int r = 0;
+    const int rmax = max(a.W, a.H);
+    for (;;) {
+      const int x0 = max(x - r, 0), x1 = min(x + r, a.W - 1);
+      const unsigned long long win = (x1 - x0 == 63) ? ~0ull : (((1ull << (x1 - x0 + 1)) - 1ull) << x0);
+      if (acc & win) break;
+      ++r;
+      if (r > rmax || r >= 255) {
+        r = 255;
+        break;
+      }
+      if (y - r >= 0) acc |= lmask[y - r];
+      if (y + r < a.H) acc |= lmask[y + r];
+    }
+    a.skip[k] = static_cast<uint8_t>(r);
+  }
+  // ---- 4: the points of my cell range into cell order ------------------------------------------------
+  auto place = [&](float x, float y, float z) {
+    float ox, oy;
+    int id;
+    if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id) && id >= c0 && id < c1) {
+      const int pos = atomicAdd(&lpos[id], 1);
+      a.bx[pos] = ox;
+      a.by[pos] = oy;
+    }
+  };
+  if (lid) {
+    for (int i = tid; i < a.n; i += kSensorBlock) {
+      const int id = lid[i];
+      if (id >= c0 && id < c1) place(a.xyz[3 * i], a.xyz[3 * i + 1], a.xyz[3 * i + 2]);  // (0xFFFF is in no range)
+    }
+  } else {
+    sensor_for_points(a, [&](int, float x, float y, float z) { place(x, y, z); });
+  }
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kSensorBlock) void sensor_fused_kernel(SensorFusedArgs s) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int b = static_cast<int>(blockIdx.x);
+  if (b < s.nb) sensor_band_body(s, b, smem);
+  else if (b < s.nb + s.kb) sensor_bucket_body(s, b - s.nb, smem);
+  else if (b < s.nb + s.kb + s.o_blocks) obs_near_body<kLds, kSensorBlock>(s.o, b - s.nb - s.kb, smem);
+  else trig_job_block<kSensorBlock>(s.a.trig, b - s.nb - s.kb - s.o_blocks);
 }
 
 }  // namespace kc

@@ -154,11 +154,19 @@ struct DilArgs {
   int H, wpr, R;
   signed char win[kMaxDil + 1], wout[kMaxDil + 1];
 };
+// bits of the middle word within w (<= 31) of a set bit of the 96-bit string left | mid | right: the OR of the
+// shifts 0..w towards higher x (high word of mid:left) and towards lower x (low word of right:mid), by doubling --
+// a value that holds the shifts 0..c, OR-ed with itself shifted by s <= c + 1, holds 0..c + s
 __device__ __forceinline__ uint32_t hdilate(uint32_t left, uint32_t mid, uint32_t right, int w) {
-  uint32_t acc = mid;
-  for (int s = 1; s <= w; ++s)
-    acc |= (mid << s) | (left >> (32 - s)) | (mid >> s) | (right << (32 - s));
-  return acc;
+  unsigned long long up = (static_cast<unsigned long long>(mid) << 32) | left;
+  unsigned long long dn = (static_cast<unsigned long long>(right) << 32) | mid;
+  for (int cover = 0; cover < w;) {
+    const int s = min(cover + 1, w - cover);
+    up |= up << s;
+    dn |= dn >> s;
+    cover += s;
+  }
+  return static_cast<uint32_t>(up >> 32) | static_cast<uint32_t>(dn);
 }
 __global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
   const int t = blockIdx.x * 256 + threadIdx.x;

@@ -1,12 +1,11 @@
 // Sensor update on the device (A4 + A8 inputs): world-frame points -> occupancy
 // bitmap of the accepted voxel columns + obstacle buckets (cell table, skip
 // table, coordinates in cell order), everything the roll-out and cost kernels
-// read.  One workgroup: at costmap sizes (<= 16k points, bitmap <= 64 KB) the
-// whole structure fits its LDS, so every scatter is an LDS atomic and the
-// results leave as plain coalesced stores.  Same arithmetic as the host path
-// (add_voxel / Rigid3f::apply / cell index); the order of the points inside a
-// bucket is arbitrary on both paths (only minima are taken over them).
-// Part of kc_dwa.hip.
+// read.  Up to 32 k points: ONE launch without any hand-over between workgroups
+// (sensor_fused_kernel, kc_onear_kernels.h); beyond: the two launches below.  Same
+// arithmetic as the host path (add_voxel / Rigid3f::apply / cell index); the order
+// of the points inside a bucket is arbitrary on every path (only minima are taken
+// over them).  Part of kc_dwa.hip.
 #pragma once
 
 namespace kc {
@@ -48,170 +47,9 @@ __device__ __forceinline__ bool sensor_obstacle(const SensorArgs &a, float x, fl
   return true;
 }
 
-__device__ __forceinline__ void sensor_build_body(const SensorArgs &a, unsigned char *smem) {
-  const int nw = a.gH * a.gwpr, ncell = a.W * a.H;
-  uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);   // [nw]
-  int *lstart = reinterpret_cast<int *>(lbits + nw);      // [ncell + 1]: counts, then starts
-  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(
-      smem + ((static_cast<size_t>(nw) * 4 + static_cast<size_t>(ncell + 1) * 4 + 7) & ~size_t(7)));  // [H]
-  __shared__ int wave_tot[kSensorBlock / 64];
-  __shared__ int s_nonempty;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < nw; i += kSensorBlock) lbits[i] = 0u;
-  for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = 0;
-  if (tid == 0) s_nonempty = 0;
-  __syncthreads();
-  // ---- 1: voxel bits + bucket counts ----------------------------------------
-  // A thread keeps the records of its points (<= 16: the host sends at most
-  // 16 k points here) in registers until the scatter of step 4 -- transformed
-  // coordinates and (cell id | rank in the cell << 12) -- and loads the raw
-  // points eight at a time, so that their latencies overlap.
-  constexpr int kPer = 16;
-  float rox[kPer], roy[kPer];
-  int rcell[kPer];
-#pragma unroll
-  for (int h = 0; h < kPer / 8; ++h) {
-    float qx[8], qy[8], qz[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = tid + (h * 8 + u) * kSensorBlock;
-      const int j = i < a.n ? i : 0;  // idle slots shadow point 0, used for nothing
-      qx[u] = a.xyz[3 * j];
-      qy[u] = a.xyz[3 * j + 1];
-      qz[u] = a.xyz[3 * j + 2];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = h * 8 + u;
-      const int i = tid + k * kSensorBlock;
-      rcell[k] = -1;
-      rox[k] = roy[k] = 0.0f;
-      if (i >= a.n) continue;
-      const float x = qx[u], y = qy[u], z = qz[u];
-      // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
-      const double fx = floor(a.inv_res * static_cast<double>(x));
-      const double fy = floor(a.inv_res * static_cast<double>(y));
-      const double fz = floor(a.inv_res * static_cast<double>(z));
-      if (fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0) {
-        const int kz = static_cast<int>(fz);
-        const double zlo = static_cast<double>(kz) * a.res;
-        const double zhi = static_cast<double>(kz + 1) * a.res;
-        if (zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height) {
-          const int cx = static_cast<int>(fx) - a.gkx0, cy = static_cast<int>(fy) - a.gky0;
-          if (cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr)
-            atomicOr(&lbits[cy * a.gwpr + (cx >> 5)], 1u << (cx & 31));
-        }
-      }
-      float ox, oy;
-      int id;
-      if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id)) {
-        rox[k] = ox;
-        roy[k] = oy;
-        rcell[k] = id | (atomicAdd(&lstart[id + 1], 1) << 12);  // id < 4096 cells, rank < 16384
-      }
-    }
-  }
-  __syncthreads();
-  // ---- 2: cell starts.  The count of cell k sits in slot k + 1 (slot 0 is 0), so
-  // an in-place inclusive scan of the ncell + 1 slots is the exclusive scan of
-  // the counts, total in the last slot.  Consecutive slots per thread (<= 8:
-  // the host keeps the grid at 64 x 64), wave scan of the thread totals.
-  {
-    const int N = ncell + 1;
-    const int per = (N + kSensorBlock - 1) / kSensorBlock;
-    const int k0 = tid * per;
-    int v[8];
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int idx = k0 + k;
-      if (k < per && idx < N) sum += lstart[idx];
-      v[k] = sum;
-    }
-    int incl = sum;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int u = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += u;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wave_tot[w];
-    const int offset = base + incl - sum;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int idx = k0 + k;
-      if (k < per && idx < N) {
-        const int s = offset + v[k];
-        lstart[idx] = s;
-      }
-    }
-  }
-  __syncthreads();
-  for (int k = tid; k <= ncell; k += kSensorBlock) a.cell_start[k] = lstart[k];
-  // ---- 3: skip table = Chebyshev distance to the nearest non-empty cell.  A row
-  // of the grid (<= 64 cells) is one 64-bit mask of its non-empty cells; the
-  // distance of cell (x, y) is the smallest r for which the rows y-r..y+r hold
-  // a set bit in columns x-r..x+r.
-  {
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int y = wave; y < a.H; y += kSensorBlock / 64) {
-      const bool ne = lane < a.W && lstart[y * a.W + lane + 1] > lstart[y * a.W + lane];
-      const unsigned long long m = __ballot(ne);
-      if (lane == 0) {
-        lmask[y] = m;
-        atomicAdd(&s_nonempty, __popcll(m));
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
-  for (int k = tid; k < ncell; k += kSensorBlock) {
-    const int y = k / a.W, x = k - y * a.W;
-    unsigned long long acc = lmask[y];
-    int r = 0;
-    const int rmax = max(a.W, a.H);
-    for (;;) {
-      const int x0 = max(x - r, 0), x1 = min(x + r, a.W - 1);
-      const unsigned long long win = (x1 - x0 == 63) ? ~0ull : (((1ull << (x1 - x0 + 1)) - 1ull) << x0);
-      if (acc & win) break;
-      ++r;
-      if (r > rmax || r >= 255) {
-        r = 255;
-        break;
-      }
-      if (y - r >= 0) acc |= lmask[y - r];
-      if (y + r < a.H) acc |= lmask[y + r];
-    }
-    a.skip[k] = static_cast<uint8_t>(r);
-  }
-  if (tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
-  // ---- 4: scatter the coordinates into their cells (start + rank) --------------
-#pragma unroll
-  for (int k = 0; k < kPer; ++k) {
-    if (rcell[k] >= 0) {
-      const int pos = lstart[rcell[k] & 4095] + (rcell[k] >> 12);
-      a.bx[pos] = rox[k];
-      a.by[pos] = roy[k];
-    }
-  }
-  // ---- 5: the bitmap --------------------------------------------------------------
-  for (int i = tid; i < nw; i += kSensorBlock) a.gbits[i] = lbits[i];
-}
-
-__global__ __launch_bounds__(kSensorBlock) void sensor_build_kernel(SensorArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  if (blockIdx.x >= gridDim.x - a.trig.nblk) {
-    trig_job_block<kSensorBlock>(a.trig, static_cast<int>(blockIdx.x - (gridDim.x - a.trig.nblk)));
-    return;
-  }
-  sensor_build_body(a, smem);
-}
-
 // ---------------------------------------------------------------------------
-// The same structure for LARGE clouds (more than 16 k points, or a voxel bitmap
-// beyond 64 KB: a 1000 x 1000 costmap has ~28 k occupied cells), two launches and
+// The same structure for LARGE clouds (more than 32 k points, or bitmap bands beyond
+// the LDS budget of the one-launch build), two launches and
 // NO global atomics: device-scope atomics execute at the memory side on this
 // chip (55 k of them took 13 us, and 18 us with sixteen counters per cache line
 // queueing behind each other).

@@ -156,7 +156,7 @@ inline void merge_exchange(const ShardLayout &L, const long long *X, size_t rw, 
 struct PackArgs {
   const long long *result;  // device record of the cycle (R_KEY, R_NADM)
   const uint8_t *flags;     // [n] admissible flags by shard-local id
-  int n, first;             // shard size, first local-lattice id of the shard
+  int n;                    // shard size (the flags are indexed by shard-local id)
   const int32_t *gid;       // local-lattice id -> global id (null: identity)
   long long *xs;            // send record
   int rank, rw;
@@ -165,7 +165,7 @@ struct PackArgs {
 __global__ __launch_bounds__(1024) void xchg_pack_kernel(PackArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long *region = a.xs + X_REGIONS + static_cast<size_t>(a.rank) * a.rw;
-  for (int j = wave; j < a.rw; j += 16) {
+  for (int j = wave; j < a.rw; j += static_cast<int>(blockDim.x >> 6)) {
     const int i = j * 64 + lane;
     const bool f = i < a.n && a.flags[i] != 0;
     const unsigned long long bal = __ballot(f);

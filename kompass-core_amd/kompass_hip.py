@@ -110,6 +110,7 @@ SIGNATURES = {
                                          C.c_float]),
     "kc_dwa_set_grid_from_mapper": (C.c_int, [_vp, C.POINTER(State), _vp, C.c_float]),
     "kc_dwa_set_tracked_segment": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _sz, C.c_float]),
+    "kc_dwa_set_tracked_segment_xyz": (C.c_int, [_vp, _fp, _fp, _sz, C.c_float]),
     "kc_dwa_rollout": (C.c_int, [_vp, C.POINTER(State), _sz]),
     "kc_dwa_check_poses": (C.c_int, [_vp, _dp, _dp, _dp, _sz, C.POINTER(C.c_uint8)]),
     "kc_dwa_evaluate": (C.c_int, [_vp]),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "kc_comm_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.POINTER(_vp)]),
     "kc_comm_create_shm": (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "kc_comm_transport": (C.c_int, [_vp]),
+    "kc_comm_query": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "kc_comm_destroy": (None, [_vp]),
     "kc_comm_rank": (C.c_int, [_vp]),
     "kc_comm_world": (C.c_int, [_vp]),
@@ -196,7 +198,35 @@ def lib():
         f.restype = res
         f.argtypes = args
     _lib = L
+    _bind_fast(L)
     return L
+
+
+# The four calls of a controller cycle with fresh inputs (window, points, segment, cycle) sit on the critical
+# path in front of the cycle kernel's launch: a second prototype of each takes plain ADDRESSES (c_void_p from an
+# int: no ctypes pointer objects per call), the wrappers below reuse one State / Result per context and hand
+# float32 C-contiguous arrays over where they lie.
+_fast = {}
+
+
+def _bind_fast(L):
+    vp, i, d, f, z = C.c_void_p, C.c_int, C.c_double, C.c_float, C.c_size_t
+    protos = {
+        "kc_dwa_set_points": (vp, vp, vp, z, f),
+        "kc_dwa_set_tracked_segment": (vp, vp, vp, vp, vp, z, f),
+        "kc_dwa_set_tracked_segment_xyz": (vp, vp, vp, z, f),
+        "kc_dwa_cycle": (vp, vp, z, vp),
+        "kc_dwa_sample_window": (vp, i, vp, d, d, d, i, i, vp, vp, vp, vp, z),
+    }
+    for name, args in protos.items():
+        _fast[name] = C.CFUNCTYPE(C.c_int, *args)((name, L))
+
+
+def _addr32(a):
+    """(float32 C-contiguous array, its address): `a` itself when it already is one."""
+    if not (type(a) is np.ndarray and a.dtype == np.float32 and a.flags.c_contiguous):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.__array_interface__["data"][0]
 
 
 def _check(rc):
@@ -309,6 +339,13 @@ class Comm:
     def transport(self) -> str:
         return "shm" if lib().kc_comm_transport(self.h) == COMM_SHM else "rccl"
 
+    def query(self):
+        """(n_ranks, user_rank, device) as the transport itself reports them (RCCL: ncclCommCount /
+        ncclCommUserRank / ncclCommCuDevice)."""
+        n, r, d = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(lib().kc_comm_query(self.h, C.byref(n), C.byref(r), C.byref(d)))
+        return n.value, r.value, d.value
+
     def close(self):
         if getattr(self, "h", None) and self.h.value:
             lib().kc_comm_destroy(self.h)
@@ -346,6 +383,10 @@ class DwaContext:
         self.h = _vp()
         _check(lib().kc_dwa_create(C.byref(p), C.byref(self.h)))
         self._P = 0
+        self._st = State()                      # reused by the per-cycle calls
+        self._st_addr = C.addressof(self._st)
+        self._n = _sz(0)
+        self._n_addr = C.addressof(self._n)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -386,9 +427,11 @@ class DwaContext:
                                               _pd(om), cap))
             k = n.value
             return vx[:k].copy(), vy[:k].copy(), om[:k].copy()
-        _check(lib().kc_dwa_sample_window(self.h, ctr_type, C.byref(limits), cur_vel[0], cur_vel[1],
-                                          cur_vel[2], max_lin, max_ang, C.byref(n), None, None, None, 0))
-        return n.value
+        rc = _fast["kc_dwa_sample_window"](self.h, ctr_type, C.addressof(limits), cur_vel[0], cur_vel[1], cur_vel[2],
+                                           max_lin, max_ang, self._n_addr, None, None, None, 0)
+        if rc != KC_OK:
+            _check(rc)
+        return self._n.value
 
     def set_samples(self, vx, vy, omega):
         vx, vy, omega = _f64(vx), _f64(vy), _f64(omega)
@@ -411,10 +454,16 @@ class DwaContext:
         st = State(*state)
         _check(lib().kc_dwa_set_scan(self.h, C.byref(st), _pd(r), _pd(a), len(r), float(max_sensor_range)))
 
+    def _state(self, state):
+        st = self._st
+        st.x, st.y, st.yaw, st.speed = state
+        return self._st_addr
+
     def set_points(self, state, xyz, max_sensor_range=10.0):
-        p = _f32(xyz).reshape(-1, 3)
-        st = State(*state)
-        _check(lib().kc_dwa_set_points(self.h, C.byref(st), _pf(p), len(p), float(max_sensor_range)))
+        p, addr = _addr32(xyz)
+        rc = _fast["kc_dwa_set_points"](self.h, self._state(state), addr, p.size // 3, max_sensor_range)
+        if rc != KC_OK:
+            _check(rc)
 
     def set_grid_device(self, state, dev_grid_ptr, grid_height, grid_width, resolution, central=None,
                         max_sensor_range=10.0):
@@ -445,16 +494,23 @@ class DwaContext:
         _check(lib().kc_dwa_set_tracked_window(self.h, int(start), int(size)))
 
     def set_tracked_segment(self, seg_xyz, acc_at_seg, ref_path_length):
-        seg = _f32(seg_xyz).reshape(-1, 3)
-        self.set_tracked_segment_columns(seg[:, 0], seg[:, 1], seg[:, 2], acc_at_seg, ref_path_length)
+        """Segment points as ONE (S, 3) array (kc_dwa_set_tracked_segment_xyz: no column copies here)."""
+        seg, a_seg = _addr32(seg_xyz)
+        acc, a_acc = _addr32(acc_at_seg)
+        n = seg.size // 3
+        assert acc.size == n
+        rc = _fast["kc_dwa_set_tracked_segment_xyz"](self.h, a_seg, a_acc, n, float(np.float32(ref_path_length)))
+        if rc != KC_OK:
+            _check(rc)
 
     def set_tracked_segment_columns(self, x, y, z, acc_at_seg, ref_path_length):
         """The same from separate x / y / z arrays (what the C ABI takes: contiguous float32 arrays are passed
         where they lie, without the column copies of set_tracked_segment)."""
-        x, y, z, acc = _f32(x), _f32(y), _f32(z), _f32(acc_at_seg)
+        (x, ax), (y, ay), (z, az), (acc, aa) = _addr32(x), _addr32(y), _addr32(z), _addr32(acc_at_seg)
         assert len(acc) == len(x)
-        _check(lib().kc_dwa_set_tracked_segment(self.h, _pf(x), _pf(y), _pf(z), _pf(acc), len(x),
-                                                float(np.float32(ref_path_length))))
+        rc = _fast["kc_dwa_set_tracked_segment"](self.h, ax, ay, az, aa, len(x), float(np.float32(ref_path_length)))
+        if rc != KC_OK:
+            _check(rc)
 
     # -- cycle --------------------------------------------------------------
     def rollout(self, state, P):
@@ -478,10 +534,11 @@ class DwaContext:
         return r
 
     def cycle(self, state, P) -> Result:
-        st = State(*state)
         self._P = int(P)
         r = Result()
-        _check(lib().kc_dwa_cycle(self.h, C.byref(st), int(P), C.byref(r)))
+        rc = _fast["kc_dwa_cycle"](self.h, self._state(state), self._P, C.addressof(r))
+        if rc != KC_OK:
+            _check(rc)
         return r
 
     def get_best(self):

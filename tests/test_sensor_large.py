@@ -1,7 +1,7 @@
-"""Sensor updates of LARGE clouds on the device (two-launch build: more than
-4 k points or a voxel bitmap beyond 64 KB; VERDICT r1 item 5, reference step
-collision_check.h:91-136 + cost_evaluator.h:174-223): the cycle that follows
-must equal the oracle's and the one after a host-built update, bit for bit."""
+"""Sensor updates of LARGE clouds on the device (one launch without hand-overs up to 32 k
+points -- sensor_fused_kernel --, the two-launch build beyond and as option `sensor_two_launch`;
+VERDICT r1 item 5, reference step collision_check.h:91-136 + cost_evaluator.h:174-223): the
+cycle that follows must equal the oracle's and the one after a host-built update, bit for bit."""
 import numpy as np
 import pytest
 
@@ -37,16 +37,20 @@ def test_large_cloud_device_build_equals_host_build_and_oracle(kind):
     o = oracle_cycle_mt(inp)
     assert 0 < len(o["raw"])
     dev = hip_context(kh, inp)
+    two = hip_context(kh, inp)
+    two.set_option("sensor_two_launch", 1)
     host = hip_context(kh, inp)
     host.set_option("sensor_on_host", 1)
     assert_cycle_equal(o, hip_cycle(kh, inp, ctx=dev))
+    assert_cycle_equal(o, hip_cycle(kh, inp, ctx=two))
     assert_cycle_equal(o, hip_cycle(kh, inp, ctx=host))
     # a second update + cycle on the same contexts (buffers reused, bitmap re-zeroed)
     inp2 = dict(inp, points=inp["points"][::2].copy(), state=(0.0, 0.0, 0.0, 0.0))
     o2 = oracle_cycle_mt(inp2)
     assert_cycle_equal(o2, hip_cycle(kh, inp2, ctx=dev))
+    assert_cycle_equal(o2, hip_cycle(kh, inp2, ctx=two))
     assert_cycle_equal(o2, hip_cycle(kh, inp2, ctx=host))
-    dev.close(); host.close()
+    dev.close(); two.close(); host.close()
 
 
 def _same(a, b):
