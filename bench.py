@@ -525,15 +525,25 @@ def fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args):
     sacc = np.ascontiguousarray(inp["acc_at_seg"], np.float32)
     pts = np.ascontiguousarray(inp["points"], np.float32)
 
-    def step(i):
+    def step4(i):  # the four entries one by one (what rounds 1-3 timed)
         st = pose(i)
         ctx.sample_window(base["ctr"], lim, cur(i), max_lin, max_ang, want_list=False)
         ctx.set_points(st, pts, inp["max_range"])
         ctx.set_tracked_segment_columns(sx, sy, sz, sacc, inp["ref_len"])
         return ctx.cycle(st, P)
 
+    def step(i):   # the same cycle through ONE entry (kc_dwa_find_best_path = DWA::findBestPath, dwa.h:183-230)
+        return ctx.find_best_path(pose(i), P, window=(base["ctr"], lim, cur(i), max_lin, max_ang), points=pts,
+                                  max_sensor_range=inp["max_range"], segment=(seg, sacc, inp["ref_len"]))
+
     n = int(ctx.sample_window(base["ctr"], lim, cur(0), max_lin, max_ang, want_list=False))
     steps, warm = min(args.steps, 1000), min(args.warmup, 100)
+    for i in range(warm):
+        step4(i)
+    t4 = time.perf_counter()
+    for i in range(steps):
+        r4 = step4(i)
+    four_calls_ms = 1e3 * (time.perf_counter() - t4) / steps
     for i in range(warm):
         step(i)
     lat = []
@@ -564,6 +574,10 @@ def fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args):
         "metric": "trajectory-steps/s", "value": n * P * steps / elapsed, "unit": "trajectory-steps/s",
         "ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warm,
         "latency_p50_ms": float(np.percentile(np.array(lat) * 1e3, 50)),
+        "entry": "kc_dwa_find_best_path (one C-ABI call per cycle: window + points + segment + cycle)",
+        "four_calls_ms_per_step": four_calls_ms,
+        "four_calls_same_winner": bool((r4.found, r4.raw_index, r4.index, r4.n_admissible) ==
+                                       (r.found, r.raw_index, r.index, r.n_admissible) and np.float32(r4.cost) == np.float32(r.cost)),
         "config": {"workload": f"{cfg}, one reference controller cycle per step: kc_dwa_sample_window (max_linear_samples "
                                f"{max_lin}, max_angular_samples {max_ang}: {n} samples) + kc_dwa_set_points ({O} points: "
                                f"voxel set + obstacle list) + kc_dwa_set_tracked_segment ({S} points) + kc_dwa_cycle "

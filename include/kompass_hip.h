@@ -346,6 +346,37 @@ int kc_dwa_fetch_result(kc_dwa *ctx, kc_result *out);
 int kc_dwa_cycle(kc_dwa *ctx, const kc_state *start, size_t num_points,
                  kc_result *out);
 
+/* ONE reference controller cycle in one call -- DWA::findBestPath (controllers/dwa.h:183-230): a new dynamic
+ * window and lattice (trajectory_sampler.cpp:328-372), this cycle's sensor data (collision_check.h:91-136,
+ * cost_evaluator.h:174-223), the tracked segment (dwa.cpp:208-233), roll-out + costs + argmin (dwa.h:215-229).
+ * Exactly kc_dwa_sample_window + kc_dwa_set_points | kc_dwa_set_scan + kc_dwa_set_tracked_segment[_xyz] +
+ * kc_dwa_cycle in that order, same state, same results; what it saves is the caller's per-call cost (a binding
+ * crossing per entry: 4 x ~1.5 us through ctypes) on the host chain in front of the cycle kernel's launch.
+ * Any part with a null / zero input is skipped and keeps what the context holds (limits NULL: the current sample
+ * list; no points and no scan: the current sensor data; seg_size 0: the current segment). */
+typedef struct kc_step_inputs {
+  /* window: kc_dwa_sample_window(ctr_type, limits, cur_*, max_*); limits NULL: skip */
+  int ctr_type;
+  const kc_limits *limits;
+  double cur_vx, cur_vy, cur_omega;
+  int max_linear_samples, max_angular_samples;
+  /* sensor data: points_xyz [n_points][3] (kc_dwa_set_points), else scan_ranges / scan_angles [n_beams]
+   * (kc_dwa_set_scan); both NULL: skip */
+  const float *points_xyz;
+  size_t n_points;
+  const double *scan_ranges, *scan_angles;
+  size_t n_beams;
+  float max_sensor_range;
+  /* tracked segment: seg_xyz [seg_size][3] (kc_dwa_set_tracked_segment_xyz), else seg_x / seg_y / seg_z
+   * (kc_dwa_set_tracked_segment); seg_size 0: skip */
+  const float *seg_xyz, *seg_x, *seg_y, *seg_z, *acc_at_seg;
+  size_t seg_size;
+  float ref_path_length;
+  /* kc_dwa_cycle(state, num_points) */
+  size_t num_points;
+} kc_step_inputs;
+int kc_dwa_find_best_path(kc_dwa *ctx, const kc_state *state, const kc_step_inputs *in, kc_result *out);
+
 /* winner row: TrajectorySamples2D::getIndex (trajectory.h:556-562).  path_* are
  * num_points floats, vel_* are num_points-1 floats; any pointer may be NULL */
 int kc_dwa_get_best(kc_dwa *ctx, float *path_x, float *path_y, float *vel_vx,

@@ -20,10 +20,12 @@
 #include "kc_hostmath.h"
 #include "kc_internal.h"
 #include "kc_pool.h"
+#include "kc_seg_tables.h"
 
 #include <type_traits>
 #if defined(__SSE2__)
 #include <emmintrin.h>
+#include <immintrin.h>
 #endif
 
 #include "kc_collision_dev.h"
@@ -73,6 +75,7 @@ struct kc_dwa {
   long long grid_seq = 0;
   hipEvent_t grid_ready = nullptr;  // mapper stream -> this stream
   bool device_sensor = true;            // KC_SENSOR_HOST=1 turns the device-side update off
+  long sensor_stamp_calls = 0;
   bool sensor_fused_ok = false;         // sensor_fused_kernel may take kSensorFusedLds
   bool sensor_two_launch = false;       // option: the two-launch build (clouds beyond kSensorFusedMax) for every size
   std::vector<double> vox_ddz;          // sphere: z gap per accepted voxel
@@ -993,6 +996,57 @@ inline bool any_voxel(const kc_dwa *c) {
 int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
                                  const float hi[3], bool *done, bool raw_copied = false);
 
+#if defined(__x86_64__)
+inline bool cpu_has_avx512f() {
+  static const bool v = __builtin_cpu_supports("avx512f");
+  return v;
+}
+// The head of the bounds + copy pass of sensor_update_device with 64-byte vectors: floats [0, 48 k) of src are
+// stored to dst (non-temporal: dst is device memory behind the BAR) and folded into min / max accumulators laid
+// out like the 16-byte loop's (acc[0|1][m]: the SSE vector m = 0..2 of the 12-float period); *ok = false when a
+// value is not finite.  Returns the number of floats done (a multiple of 48: the loop that follows continues in
+// phase).
+__attribute__((target("avx512f"))) size_t bounds_copy_avx512(const float *src, float *dst, size_t total, float acc[2][3][4],
+                                                             bool *ok) {
+  const __m512 big = _mm512_set1_ps(FLT_MAX);
+  __m512 mn[3] = {big, big, big}, mx[3] = {_mm512_sub_ps(_mm512_setzero_ps(), big), _mm512_sub_ps(_mm512_setzero_ps(), big),
+                                           _mm512_sub_ps(_mm512_setzero_ps(), big)};
+  __mmask16 bad = 0;
+  size_t i = 0;
+  for (; i + 48 <= total; i += 48) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const __m512 v = _mm512_loadu_ps(src + i + 16 * q);
+      _mm512_stream_ps(dst + i + 16 * q, v);
+      mn[q] = _mm512_min_ps(mn[q], v);
+      mx[q] = _mm512_max_ps(mx[q], v);
+      const __m512 d = _mm512_sub_ps(v, v);
+      bad |= _mm512_cmp_ps_mask(d, d, _CMP_UNORD_Q);
+    }
+  }
+  // 64-byte vector q, 16-byte lane l = SSE vector (4 q + l) of the stream: period 3
+  for (int m = 0; m < 3; ++m)
+    for (int k = 0; k < 4; ++k) {
+      acc[0][m][k] = FLT_MAX;
+      acc[1][m][k] = -FLT_MAX;
+    }
+  alignas(64) float lo[16], hi[16];
+  for (int q = 0; q < 3; ++q) {
+    _mm512_store_ps(lo, mn[q]);
+    _mm512_store_ps(hi, mx[q]);
+    for (int l = 0; l < 4; ++l) {
+      const int m = (4 * q + l) % 3;
+      for (int k = 0; k < 4; ++k) {
+        acc[0][m][k] = std::min(acc[0][m][k], lo[4 * l + k]);
+        acc[1][m][k] = std::max(acc[1][m][k], hi[4 * l + k]);
+      }
+    }
+  }
+  *ok = bad == 0;
+  return i;
+}
+#endif
+
 int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   *done = false;
   c->raw_on_device = false;
@@ -1008,7 +1062,7 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   // any non-finite coordinate (v - v != 0) sends the whole list to the loop below.
   // The same pass stores the points to their device buffer through the BAR
   // (write-combining stores): one trip over the list instead of two.
-  KC_TRY(c->d_raw.reserve(3 * n));
+  KC_TRY(c->d_raw.reserve(3 * n + 16));
   {
     float *dst = c->d_raw.p;
     typedef float v4 __attribute__((vector_size(16)));
@@ -1018,6 +1072,17 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
     v4i ok = {-1, -1, -1, -1};
     const size_t total = 3 * n;
     size_t i = 0;
+    if (total >= 96 && cpu_has_avx512f()) {
+      // 48 floats (16 points) per step as three 64-byte vectors: a write-combining store per cache line
+      float acc[2][3][4];
+      bool ok512 = true;
+      i = bounds_copy_avx512(xyz, dst, total, acc, &ok512);
+      for (int q = 0; q < 3; ++q) {
+        std::memcpy(&mn[q], acc[0][q], sizeof(v4));
+        std::memcpy(&mx[q], acc[1][q], sizeof(v4));
+      }
+      if (!ok512) ok = v4i{0, 0, 0, 0};
+    }
     for (; i + 12 <= total; i += 12) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -1169,7 +1234,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   KC_TRY(c->d_cells.reserve(ncell + 1));
   KC_TRY(c->d_skip.reserve(ncell + 4));
   KC_TRY(c->d_bobs.reserve(2 * n));
-  KC_TRY(c->d_raw.reserve(3 * n));
+  KC_TRY(c->d_raw.reserve(3 * n + 16));
   // the raw points: host copy for the lazy lists, device copy through the BAR
   c->host_lists_valid = false;
   if (xyz) {
@@ -1240,13 +1305,31 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     f.nb = nb;
     f.kb = 8;
     f.band_rows = band_rows;
+    f.roles = 15;
+    if (const char *e = std::getenv("KC_SENSOR_ROLES")) f.roles = std::atoi(e);
+    if (const char *e = std::getenv("KC_SENSOR_KB")) f.kb = std::atoi(e);
+    if (const char *e = std::getenv("KC_SENSOR_NB")) { f.nb = std::atoi(e); band_rows = (c->gH + f.nb - 1) / f.nb; f.band_rows = band_rows; f.nb = (c->gH + band_rows - 1) / band_rows; }
     f.R = dilR;
     f.ginner = c->d_ginner.p;
     f.gouter = c->d_gouter.p;
     if (dilR >= 0) dil_tables(dg, f.win, f.wout);
-    size_t bucket_lds = (((ncell + 4) & ~size_t(3)) + ((ncell + 3) & ~size_t(3))) * 4 + 64 * 8;
-    f.ids_in_lds = bucket_lds + 2 * n + 16 <= kSensorFusedLds ? 1 : 0;  // (8 k points: 16 KB; else the second pass transforms all again)
-    if (f.ids_in_lds) bucket_lds += 2 * n;
+    // bucket workgroup: cell slots + row masks + (lists of more than one trip) a position per cell
+    const size_t bucket_lds = ((ncell + 4) & ~size_t(3)) * 4 + 64 * 8 + ((ncell + 3) & ~size_t(3)) * 4;
+    // float estimate of the cell index (sensor_obstacle_fast): its distance from the double expression
+    {
+      const double span = std::max(std::fabs(b.gx0), std::fabs(b.gy0)) + 64.0 * b.g;  // largest |coordinate| inside the grid
+      const double ulp = span * 1.2e-7;                                                  // float spacing there
+      const double err = (2.0 * ulp) * b.inv_g + 66.0 * 2.4e-7;                          // origin + difference, scaled; product rounding
+      f.gx0f = static_cast<float>(b.gx0);
+      f.gy0f = static_cast<float>(b.gy0);
+      f.inv_gf = static_cast<float>(b.inv_g);
+      f.id_eps = static_cast<float>(std::min(0.5, 8.0 * err));
+    }
+    // a band's y interval (sensor_band_body's first filter): keys gky0 + rows, padded by a voxel and the float rounding of y
+    f.band_y0 = static_cast<float>(static_cast<double>(c->gky0) * c->res);
+    f.band_dy = static_cast<float>(static_cast<double>(band_rows) * c->res);
+    f.band_pad = static_cast<float>((static_cast<double>(std::max(dilR, 0)) + 2.0) * c->res +
+                                    1e-5 * (std::fabs(static_cast<double>(c->gky0)) + c->gH) * c->res);
     size_t lds = std::max(band_bytes(), bucket_lds) + 16;
     const size_t olds = 2 * static_cast<size_t>(c->onear_args.n) * sizeof(float);
     const bool ride = c->onear_ahead && olds <= kObsNearLdsMax;
@@ -1258,9 +1341,42 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
       c->onear_version = c->sensor_version;
       ++c->onear_rides;
     }
+#ifdef KC_PHASE_STAMPS
+    if (c->debug_stamps) {
+      KC_TRY(c->d_dbg.reserve(512 * 16));
+      KC_HIP(hipMemsetAsync(c->d_dbg.p, 0, 512 * 16 * 8, c->stream));
+      f.dbg = c->d_dbg.p;
+    }
+#endif
     KC_TRY(c->timing.start("sensor_fused_kernel", c->stream));
     hipLaunchKernelGGL(sensor_fused_kernel<true>, dim3(f.nb + f.kb + f.o_blocks + tj), dim3(kSensorBlock), lds, c->stream, f);
     KC_TRY(c->timing.stop(c->stream));
+#ifdef KC_PHASE_STAMPS
+    if (f.dbg && (++c->sensor_stamp_calls % 100) == 50) {
+      const int G = std::min(512, f.nb + f.kb);
+      std::vector<unsigned long long> h(static_cast<size_t>(G) * 16);
+      KC_HIP(hipStreamSynchronize(c->stream));
+      KC_HIP(hipMemcpy(h.data(), c->d_dbg.p, h.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull;
+      for (int r = 0; r < G; ++r) if (h[r * 16]) t0 = std::min(t0, h[r * 16]);
+      auto dump = [&](const char *what, int r0, int r1, const char *const *nm, int cnt) {
+        std::fprintf(stderr, "[kc stamps] sensor_fused_kernel %s, us since the first workgroup (avg / max):\n", what);
+        for (int k = 0; k < cnt; ++k) {
+          double sm = 0, mx = 0; int m = 0;
+          for (int r = r0; r < r1; ++r) {
+            if (!h[r * 16 + k]) continue;
+            const double us = (h[r * 16 + k] - t0) / 100.0;
+            sm += us; mx = std::max(mx, us); ++m;
+          }
+          if (m) std::fprintf(stderr, "  %-18s %6.2f / %6.2f\n", nm[k], sm / m, mx);
+        }
+      };
+      static const char *bn[5] = {"start", "lds zero", "points", "dilated", "rows out"};
+      static const char *kn[7] = {"start", "lds zero", "counted", "scanned", "masks + pos", "slice out", "placed"};
+      dump("bands", 0, std::min(G, f.nb), bn, 5);
+      dump("buckets", f.nb, G, kn, 7);
+    }
+#endif
     masks_built = true;
   } else {
     {  // byte map of the voxels: zero between updates (sensor_place_kernel clears what it packs)
@@ -3175,7 +3291,7 @@ int kc_dwa_set_grid_device(kc_dwa *c, const kc_state *st, const int32_t *dev_gri
   c->max_obs_dist = max_range / 3.0f;
   c->host_lists_valid = true;
   const size_t cells = static_cast<size_t>(H) * W;
-  KC_TRY(c->d_raw.reserve(3 * cells));
+  KC_TRY(c->d_raw.reserve(3 * cells + 16));
   KC_TRY(c->h_gridrec.reserve(8));
   if (!c->d_gridcnt.p) {
     KC_TRY(c->d_gridcnt.reserve(5 * kGridCntStride));
@@ -3333,14 +3449,13 @@ int set_tracked_segment_impl(kc_dwa *c, const float *x, const float *y, const fl
     p[1] = h[S + j];
     p[2] = h[2 * S + j];
   };
+  const segtab::Span span{h, h + S, h + 2 * S};
   {
     float *cap = h + seg_cap_offset(static_cast<int>(S));
     // capsule of the points [j0, j1): chord A -> B of the first and last point as the kernels see it
     // (float A, float AB, float 1/|AB|^2) + the largest deviation of the points from it, rounded up
     auto capsule = [&](size_t j0, size_t j1, float *out, size_t k) {  // record k of `out` (struct Capsule)
-      bool finite = true;
-      for (size_t j = j0; j < j1; ++j)
-        finite = finite && std::isfinite(h[j]) && std::isfinite(h[S + j]) && std::isfinite(h[2 * S + j]);
+      const bool finite = segtab::finite_span(span, j0, j1);
       double A[3], B[3];
       pt(j0, A);
       pt(j1 - 1, B);
@@ -3350,16 +3465,7 @@ int set_tracked_segment_impl(kc_dwa *c, const float *x, const float *y, const fl
                         static_cast<double>(ab[2]) * ab[2];
       const float inv = (finite && l2 > 0.0 && std::isfinite(1.0 / l2)) ? static_cast<float>(1.0 / l2) : 0.0f;
       double eps = 0.0, mag = 0.0;
-      for (size_t j = j0; j < j1 && finite; ++j) {
-        double P[3];
-        pt(j, P);
-        const double q[3] = {P[0] - A[0], P[1] - A[1], P[2] - A[2]};
-        double t = (q[0] * ab[0] + q[1] * ab[1] + q[2] * ab[2]) * static_cast<double>(inv);
-        t = std::min(std::max(t, 0.0), 1.0);
-        const double e[3] = {q[0] - t * ab[0], q[1] - t * ab[1], q[2] - t * ab[2]};
-        eps = std::max(eps, e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);  // squared: one sqrt per chunk
-        mag = std::max(mag, std::fabs(P[0]) + std::fabs(P[1]) + std::fabs(P[2]));
-      }
+      if (finite) segtab::capsule_span(span, j0, j1, A, ab, inv, eps, mag);  // (kc_seg_tables.h: four points at a time)
       eps = std::sqrt(eps);  // sqrt is monotonic and correctly rounded: max of the roots
       float *rec = out + 8 * k;
       rec[0] = static_cast<float>(A[0]);
@@ -3380,16 +3486,8 @@ int set_tracked_segment_impl(kc_dwa *c, const float *x, const float *y, const fl
     auto sphere = [&](size_t s) {
       const size_t j0 = s * 8 * chunk, j1 = std::min(j0 + 8 * chunk, S);
       double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-      bool finite = true;
-      for (size_t j = j0; j < j1; ++j) {
-        double P[3];
-        pt(j, P);
-        for (int q = 0; q < 3; ++q) {
-          finite = finite && std::isfinite(P[q]);
-          lo[q] = std::min(lo[q], P[q]);
-          hi[q] = std::max(hi[q], P[q]);
-        }
-      }
+      const bool finite = segtab::finite_span(span, j0, j1);
+      if (finite) segtab::box_span(span, j0, j1, lo, hi);
       if (!finite) {  // never skipped
         sup[s] = sup[nsup + s] = sup[2 * nsup + s] = 0.0f;
         sup[3 * nsup + s] = kInf;
@@ -3400,13 +3498,7 @@ int set_tracked_segment_impl(kc_dwa *c, const float *x, const float *y, const fl
       const float fc[3] = {static_cast<float>(0.5 * (lo[0] + hi[0])),
                            static_cast<float>(0.5 * (lo[1] + hi[1])),
                            static_cast<float>(0.5 * (lo[2] + hi[2]))};
-      double r = 0.0;
-      for (size_t j = j0; j < j1; ++j) {
-        double P[3];
-        pt(j, P);
-        const double dx = P[0] - fc[0], dy = P[1] - fc[1], dz = P[2] - fc[2];
-        r = std::max(r, dx * dx + dy * dy + dz * dz);
-      }
+      double r = segtab::radius2_span(span, j0, j1, fc);
       r = std::sqrt(r);
       const double mag = std::fabs(fc[0]) + std::fabs(fc[1]) + std::fabs(fc[2]) + r;
       sup[s] = fc[0];
@@ -3414,15 +3506,7 @@ int set_tracked_segment_impl(kc_dwa *c, const float *x, const float *y, const fl
       sup[2 * nsup + s] = fc[2];
       sup[3 * nsup + s] = up(r * (1.0 + 1e-6) + 1e-6 * mag + 1e-30);
     };
-    auto length = [&]() {  // View::totalSegmentLength, path.h:85-91
-      float len = 0.0f;
-      for (size_t j = 0; j + 1 < S; ++j) {
-        const float dx = h[j] - h[j + 1], dy = h[S + j] - h[S + j + 1],
-                    dz = h[2 * S + j] - h[2 * S + j + 1];
-        len += std::sqrt(hm::add3(dx * dx, dy * dy, dz * dz));
-      }
-      seg_len_out = len;
-    };
+    auto length = [&]() { seg_len_out = segtab::length(span, S); };  // View::totalSegmentLength, path.h:85-91
     const size_t ntasks = nch + 2 * nsup + 1;
     auto run_task = [&](size_t t) {
       if (t < nch) capsule(t * chunk, std::min(t * chunk + chunk, S), cap, t);
@@ -4194,6 +4278,22 @@ int kc_dwa_cycle(kc_dwa *c, const kc_state *start, size_t P, kc_result *out) {
   c->hprof.mark(7);
   c->hprof.close();
   return rc;
+}
+
+int kc_dwa_find_best_path(kc_dwa *c, const kc_state *st, const kc_step_inputs *in, kc_result *out) {
+  if (!c || !st || !in || !out) KC_FAIL(KC_ERR_INVALID, "null argument");
+  if (in->limits)
+    KC_TRY(kc_dwa_sample_window(c, in->ctr_type, in->limits, in->cur_vx, in->cur_vy, in->cur_omega, in->max_linear_samples,
+                                in->max_angular_samples, nullptr, nullptr, nullptr, nullptr, 0));
+  if (in->points_xyz)
+    KC_TRY(kc_dwa_set_points(c, st, in->points_xyz, in->n_points, in->max_sensor_range));
+  else if (in->scan_ranges && in->scan_angles)
+    KC_TRY(kc_dwa_set_scan(c, st, in->scan_ranges, in->scan_angles, in->n_beams, in->max_sensor_range));
+  if (in->seg_size) {
+    if (in->seg_xyz) KC_TRY(kc_dwa_set_tracked_segment_xyz(c, in->seg_xyz, in->acc_at_seg, in->seg_size, in->ref_path_length));
+    else KC_TRY(kc_dwa_set_tracked_segment(c, in->seg_x, in->seg_y, in->seg_z, in->acc_at_seg, in->seg_size, in->ref_path_length));
+  }
+  return kc_dwa_cycle(c, st, in->num_points, out);
 }
 
 int kc_dwa_get_best(kc_dwa *c, float *path_x, float *path_y, float *vvx,

@@ -164,11 +164,24 @@ struct SensorFusedArgs {
   ObsNearArgs o;         // the rider (o_blocks > 0)
   int nb, kb, o_blocks;  // band workgroups | bucket workgroups | near-table workgroups (| a.trig.nblk trig workgroups)
   int band_rows;         // rows per band
-  int ids_in_lds;        // bucket workgroups keep the cell id of every point in LDS between their two passes
+  float gx0f, gy0f, inv_gf, id_eps;  // sensor_obstacle_fast (id_eps >= 0.5: always the double expression)
+  float band_y0, band_dy;            // band b can only hold points with y in band_y0 + b band_dy + [-band_pad, band_dy + band_pad)
+  float band_pad;
+  int roles;             // (measurement hook)
+  unsigned long long *dbg;  // KC_PHASE_STAMPS builds: [workgroup][16] s_memrealtime stamps, or null
   int R;                 // dilation radius in rows; < 0: no masks (spheres without a gap bound, huge robots)
   uint32_t *ginner, *gouter;
   signed char win[kMaxDil + 1], wout[kMaxDil + 1];
 };
+
+#ifdef KC_PHASE_STAMPS
+#define KC_FSTAMP(slot)                                                                                   \
+  do {                                                                                                    \
+    if (s.dbg && threadIdx.x == 0) s.dbg[blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();    \
+  } while (0)
+#else
+#define KC_FSTAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool sensor_voxel_cell(const SensorArgs &a, float x, float y, float z, int &cx, int &cy) {
   // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
@@ -185,26 +198,68 @@ __device__ __forceinline__ bool sensor_voxel_cell(const SensorArgs &a, float x, 
   return cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr;
 }
 
-// every point of the list, eight loads in flight per thread: f(i, x, y, z)
-template <class F>
-__device__ __forceinline__ void sensor_for_points(const SensorArgs &a, F &&f) {
+// A thread takes FOUR consecutive points at a time: 48 bytes = three aligned 16-byte loads (the list is [n][3]
+// floats; 12-byte loads a point apiece kept the CU's address unit busy for ~2 us per pass of a 8.8 k-point list --
+// every workgroup reads every point --, and a second trip doubled it).  Three such groups in flight per thread:
+// lists up to 12 k points are ONE memory round trip per pass.  pre() runs once, behind the first trip's loads
+// and in front of their first use: what a pass has to set up (LDS zeroing + barrier) hides under the round trip.
+// The list is padded to a multiple of four points (host: d_raw), the pad is never handed to f.
+constexpr int kSensorGroups = 3;                                      // groups of four points per thread and trip
+constexpr int kSensorOneTrip = 4 * kSensorGroups * kSensorBlock;     // points of a list that is one trip
+template <class Pre, class F>
+__device__ __forceinline__ void sensor_for_points(const SensorArgs &a, Pre &&pre, F &&f) {
+  constexpr int kGroups = kSensorGroups;
   const int tid = threadIdx.x;
-  for (int i0 = 0; i0 < a.n; i0 += 8 * kSensorBlock) {
-    float qx[8], qy[8], qz[8];
+  const float4 *v = reinterpret_cast<const float4 *>(a.xyz);
+  const int ngroups = (a.n + 3) >> 2;
+  for (int g0 = 0; g0 < ngroups; g0 += kGroups * kSensorBlock) {
+    float4 q[kGroups][3];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * kSensorBlock + tid;
-      const int j = i < a.n ? i : 0;  // idle slots shadow point 0, used for nothing
-      qx[u] = a.xyz[3 * j];
-      qy[u] = a.xyz[3 * j + 1];
-      qz[u] = a.xyz[3 * j + 2];
+    for (int u = 0; u < kGroups; ++u) {
+      const int g = g0 + u * kSensorBlock + tid;
+      const int gg = g < ngroups ? g : 0;  // idle slots shadow group 0, used for nothing
+      q[u][0] = v[3 * gg];
+      q[u][1] = v[3 * gg + 1];
+      q[u][2] = v[3 * gg + 2];
     }
+    if (g0 == 0) pre();
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * kSensorBlock + tid;
-      if (i < a.n) f(i, qx[u], qy[u], qz[u]);
+    for (int u = 0; u < kGroups; ++u) {
+      const int g = g0 + u * kSensorBlock + tid;
+      if (g >= ngroups) continue;
+      const int i = 4 * g;  // (slot 4 u + p: a compile-time constant in the first trip, for per-thread records)
+      f(4 * u, i, q[u][0].x, q[u][0].y, q[u][0].z);
+      if (i + 1 < a.n) f(4 * u + 1, i + 1, q[u][0].w, q[u][1].x, q[u][1].y);
+      if (i + 2 < a.n) f(4 * u + 2, i + 2, q[u][1].z, q[u][1].w, q[u][2].x);
+      if (i + 3 < a.n) f(4 * u + 3, i + 3, q[u][2].y, q[u][2].z, q[u][2].w);
     }
   }
+  if (a.n <= 0) pre();
+}
+
+// The obstacle of a point and its bucket, as sensor_obstacle -- the cell index from a FLOAT estimate where that is
+// safe: the estimate is within id_eps cells of the double expression (host: float rounding of the origin, of the
+// difference and of 1 / g), so away from a cell edge by more than that both truncate to the same cell; the few
+// points nearer to an edge take the double expression itself.  (f64 conversions run at a quarter of the f32
+// rate: they were half of the counting pass of a bucket workgroup, which sees EVERY point.)
+__device__ __forceinline__ bool sensor_obstacle_fast(const SensorFusedArgs &s, float x, float y, float z, float &ox,
+                                                     float &oy, int &id) {
+  const SensorArgs &a = s.a;
+  ox = a.t[0] + (a.R[0][0] * x + (a.R[0][1] * y + a.R[0][2] * z));
+  oy = a.t[1] + (a.R[1][0] * x + (a.R[1][1] * y + a.R[1][2] * z));
+  if (!isfinite(ox) || !isfinite(oy)) return false;
+  const float ex = (ox - s.gx0f) * s.inv_gf, ey = (oy - s.gy0f) * s.inv_gf;
+  int cx = static_cast<int>(ex), cy = static_cast<int>(ey);
+  const float dx = ex - static_cast<float>(cx), dy = ey - static_cast<float>(cy);  // (|.| < 1: truncation)
+  const float e = s.id_eps, e1 = 1.0f - s.id_eps;
+  if (!(fabsf(dx) > e && fabsf(dx) < e1 && fabsf(dy) > e && fabsf(dy) < e1) || !(fabsf(ex) < 1.0e6f && fabsf(ey) < 1.0e6f)) {
+    cx = static_cast<int>((static_cast<double>(ox) - a.gx0) * a.inv_g);
+    cy = static_cast<int>((static_cast<double>(oy) - a.gy0) * a.inv_g);
+  }
+  cx = min(max(cx, 0), a.W - 1);
+  cy = min(max(cy, 0), a.H - 1);
+  id = cy * a.W + cx;
+  return true;
 }
 
 __device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int band, unsigned char *smem) {
@@ -215,9 +270,17 @@ __device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int b
   if (y0 >= y1) return;
   const int lo = y0 - R, nrows = (y1 - y0) + 2 * R;
   uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);  // [nrows][gwpr], row 0 = bitmap row `lo`
-  for (int i = tid; i < nrows * a.gwpr; i += kSensorBlock) lbits[i] = 0u;
-  __syncthreads();
-  sensor_for_points(a, [&](int, float x, float y, float z) {
+  KC_FSTAMP(0);
+  // (a band and its halo hold a few per cent of the points: two float compares -- the band's y interval, padded by a
+  // voxel for the rounding of the key -- send the others away before any f64 work)
+  const float ylo = s.band_y0 + static_cast<float>(band) * s.band_dy - s.band_pad;
+  const float yhi = s.band_y0 + static_cast<float>(band + 1) * s.band_dy + s.band_pad;
+  sensor_for_points(a, [&] {
+    for (int i = tid; i < nrows * a.gwpr; i += kSensorBlock) lbits[i] = 0u;
+    __syncthreads();
+    KC_FSTAMP(1);
+  }, [&](int, int, float x, float y, float z) {
+    if (!(y >= ylo && y <= yhi)) return;
     int cx, cy;
     if (sensor_voxel_cell(a, x, y, z, cx, cy)) {
       const int r = cy - lo;
@@ -225,6 +288,7 @@ __device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int b
     }
   });
   __syncthreads();
+  KC_FSTAMP(2);
   // The band's rows leave as they are; their two dilations are formed from the LDS rows around them (rows outside
   // the bitmap hold no bit: sensor_voxel_cell admits none there).  A task per (row offset j, output word): the
   // (2 R + 1) x words tasks of a band go round ALL lanes (a thread per output word left 7/8 of the workgroup idle
@@ -249,6 +313,7 @@ __device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int b
     }
     __syncthreads();
   }
+  KC_FSTAMP(3);
   for (int t = tid; t < nout; t += kSensorBlock) {
     const int yr = t / a.gwpr, w = t - yr * a.gwpr;
     const size_t g = static_cast<size_t>(y0 + yr) * a.gwpr + w;
@@ -258,6 +323,7 @@ __device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int b
       s.gouter[g] = lout[t];
     }
   }
+  KC_FSTAMP(4);
 }
 
 __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int me, unsigned char *smem) {
@@ -265,27 +331,52 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncell = a.W * a.H;
   int *lstart = reinterpret_cast<int *>(smem);                 // [ncell + 1] (+ pad): slot k + 1 = count, then start, of cell k
-  int *lpos = lstart + ((ncell + 1 + 3) & ~3);                 // [ncell] next free position of a cell of MY range
-  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(lpos + ((ncell + 3) & ~3));  // [64]
-  // [n] cell id of every point (0xFFFF: not an obstacle), kept from the counting pass: the placing pass reloads and
-  // transforms only the points of this workgroup's cell range (an eighth of them)
-  uint16_t *lid = s.ids_in_lds ? reinterpret_cast<uint16_t *>(lmask + 64) : nullptr;
+  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(lstart + ((ncell + 1 + 3) & ~3));  // [64]
+  // A list of one trip (<= 12 k points): every thread keeps {cell | rank << 12, obstacle x, y} of its <= 12 points
+  // in registers from the counting pass -- this workgroup counts ALL points, so the rank it hands out is the rank
+  // in the whole list -- and the placing pass is a table read and two stores for the points of its cell range: no
+  // second read of the list, no second atomic.  Longer lists: [ncell] next free position of a cell of my range,
+  // and the placing pass reads and transforms every point again.
+  const bool one_trip = a.n <= kSensorOneTrip;
+  int *lpos = reinterpret_cast<int *>(lmask + 64);
+  int rec[4 * kSensorGroups];
+  float rox[4 * kSensorGroups], roy[4 * kSensorGroups];
+#pragma unroll
+  for (int k = 0; k < 4 * kSensorGroups; ++k) rec[k] = -1;
   __shared__ int wave_tot[kSensorBlock / 64];
   __shared__ int s_nonempty;
-  for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = 0;
-  if (tid == 0) s_nonempty = 0;
-  __syncthreads();
+  KC_FSTAMP(0);
   // ---- 1: counts of ALL points ----------------------------------------------------------------------
-  sensor_for_points(a, [&](int i, float x, float y, float z) {
+  sensor_for_points(a, [&] {
+    for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = 0;
+    if (tid == 0) s_nonempty = 0;
+    __syncthreads();
+    KC_FSTAMP(1);
+  }, [&](int slot, int i, float x, float y, float z) {
     float ox, oy;
     int id;
-    const bool ob = sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id);
-    if (ob) atomicAdd(&lstart[id + 1], 1);
-    if (lid) lid[i] = ob ? static_cast<uint16_t>(id) : static_cast<uint16_t>(0xFFFF);
+    if (!sensor_obstacle_fast(s, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id)) return;
+    const int rank = atomicAdd(&lstart[id + 1], 1);
+    if (i < kSensorOneTrip) {  // (first trip: `slot` is a constant after unrolling -- the arrays stay in registers)
+      rec[slot] = id | (rank << 12);  // id < 4096 cells, rank < 32 k
+      rox[slot] = ox;
+      roy[slot] = oy;
+    }
   });
   __syncthreads();
-  // ---- 2: starts: in-place inclusive scan of the ncell + 1 slots (consecutive slots per thread, <= 8: the
-  // host keeps the grid at 64 x 64; wave scan of the thread totals)
+  KC_FSTAMP(2);
+  // ---- 2: row masks of the non-empty cells (from the COUNTS: slot k + 1 = points of cell k; read-only, like
+  // the first half of the scan below -- no barrier of their own), then the starts: in-place inclusive scan of
+  // the ncell + 1 slots (consecutive slots per thread, <= 8: the host keeps the grid at 64 x 64; wave scan of
+  // the thread totals)
+  for (int y = wave; y < a.H; y += kSensorBlock / 64) {
+    const bool ne = lane < a.W && lstart[y * a.W + lane + 1] > 0;
+    const unsigned long long m = __ballot(ne);
+    if (lane == 0) {
+      lmask[y] = m;
+      if (me == 0) atomicAdd(&s_nonempty, __popcll(m));
+    }
+  }
   {
     const int N = ncell + 1;
     const int per = (N + kSensorBlock - 1) / kSensorBlock;
@@ -315,21 +406,17 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
     }
   }
   __syncthreads();
+  KC_FSTAMP(3);
   // ---- 3: my slice of what the cost kernels read: cell starts, skip table (Chebyshev distance to the nearest
   // non-empty cell, from one 64-bit mask per grid row), dc_enable -- 64 cells per wavefront, the wavefronts of
   // the bucket workgroups interleaved
-  for (int y = wave; y < a.H; y += kSensorBlock / 64) {
-    const bool ne = lane < a.W && lstart[y * a.W + lane + 1] > lstart[y * a.W + lane];
-    const unsigned long long m = __ballot(ne);
-    if (lane == 0) {
-      lmask[y] = m;
-      if (me == 0) atomicAdd(&s_nonempty, __popcll(m));
-    }
-  }
   const int c0 = static_cast<int>(static_cast<long long>(ncell) * me / s.kb);
   const int c1 = static_cast<int>(static_cast<long long>(ncell) * (me + 1) / s.kb);
-  for (int k = c0 + tid; k < c1; k += kSensorBlock) lpos[k] = lstart[k];
-  __syncthreads();
+  if (!one_trip) {
+    for (int k = c0 + tid; k < c1; k += kSensorBlock) lpos[k] = lstart[k];
+    __syncthreads();
+  }
+  KC_FSTAMP(4);
   if (me == 0 && tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
   if (me == 0 && tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
   for (int k = (wave * s.kb + me) * 64 + lane; k <= ncell; k += s.kb * kSensorBlock) {
@@ -353,34 +440,40 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
     }
     a.skip[k] = static_cast<uint8_t>(r);
   }
+  KC_FSTAMP(5);
   // ---- 4: the points of my cell range into cell order ------------------------------------------------
-  auto place = [&](float x, float y, float z) {
-    float ox, oy;
-    int id;
-    if (sensor_obstacle(a, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id) && id >= c0 && id < c1) {
-      const int pos = atomicAdd(&lpos[id], 1);
-      a.bx[pos] = ox;
-      a.by[pos] = oy;
-    }
-  };
-  if (lid) {
-    for (int i = tid; i < a.n; i += kSensorBlock) {
-      const int id = lid[i];
-      if (id >= c0 && id < c1) place(a.xyz[3 * i], a.xyz[3 * i + 1], a.xyz[3 * i + 2]);  // (0xFFFF is in no range)
+  if (one_trip) {
+#pragma unroll
+    for (int k = 0; k < 4 * kSensorGroups; ++k) {
+      const int id = rec[k] & 4095;
+      if (rec[k] >= 0 && id >= c0 && id < c1) {
+        const int pos = lstart[id] + (rec[k] >> 12);
+        a.bx[pos] = rox[k];
+        a.by[pos] = roy[k];
+      }
     }
   } else {
-    sensor_for_points(a, [&](int, float x, float y, float z) { place(x, y, z); });
+    sensor_for_points(a, [] {}, [&](int, int, float x, float y, float z) {
+      float ox, oy;
+      int id;
+      if (sensor_obstacle_fast(s, x, y, a.obs_z_zero ? 0.0f : z, ox, oy, id) && id >= c0 && id < c1) {
+        const int pos = atomicAdd(&lpos[id], 1);
+        a.bx[pos] = ox;
+        a.by[pos] = oy;
+      }
+    });
   }
+  KC_FSTAMP(6);
 }
 
 template <bool kLds>
 __global__ __launch_bounds__(kSensorBlock) void sensor_fused_kernel(SensorFusedArgs s) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = static_cast<int>(blockIdx.x);
-  if (b < s.nb) sensor_band_body(s, b, smem);
-  else if (b < s.nb + s.kb) sensor_bucket_body(s, b - s.nb, smem);
-  else if (b < s.nb + s.kb + s.o_blocks) obs_near_body<kLds, kSensorBlock>(s.o, b - s.nb - s.kb, smem);
-  else trig_job_block<kSensorBlock>(s.a.trig, b - s.nb - s.kb - s.o_blocks);
+  if (b < s.nb) { if (s.roles & 1) sensor_band_body(s, b, smem); }
+  else if (b < s.nb + s.kb) { if (s.roles & 2) sensor_bucket_body(s, b - s.nb, smem); }
+  else if (b < s.nb + s.kb + s.o_blocks) { if (s.roles & 4) obs_near_body<kLds, kSensorBlock>(s.o, b - s.nb - s.kb, smem); }
+  else if (s.roles & 8) trig_job_block<kSensorBlock>(s.a.trig, b - s.nb - s.kb - s.o_blocks);
 }
 
 }  // namespace kc

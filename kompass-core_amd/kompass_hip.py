@@ -63,6 +63,19 @@ class DwaParams(C.Structure):
     ]
 
 
+class StepInputs(C.Structure):
+    """kc_step_inputs: one reference controller cycle (kc_dwa_find_best_path)."""
+    _fields_ = [
+        ("ctr_type", C.c_int), ("limits", C.c_void_p), ("cur_vx", C.c_double), ("cur_vy", C.c_double),
+        ("cur_omega", C.c_double), ("max_linear_samples", C.c_int), ("max_angular_samples", C.c_int),
+        ("points_xyz", C.c_void_p), ("n_points", C.c_size_t), ("scan_ranges", C.c_void_p), ("scan_angles", C.c_void_p),
+        ("n_beams", C.c_size_t), ("max_sensor_range", C.c_float),
+        ("seg_xyz", C.c_void_p), ("seg_x", C.c_void_p), ("seg_y", C.c_void_p), ("seg_z", C.c_void_p),
+        ("acc_at_seg", C.c_void_p), ("seg_size", C.c_size_t), ("ref_path_length", C.c_float),
+        ("num_points", C.c_size_t),
+    ]
+
+
 class Result(C.Structure):
     _fields_ = [
         ("found", C.c_int), ("cost", C.c_float), ("index", C.c_int64),
@@ -116,6 +129,7 @@ SIGNATURES = {
     "kc_dwa_evaluate": (C.c_int, [_vp]),
     "kc_dwa_fetch_result": (C.c_int, [_vp, C.POINTER(Result)]),
     "kc_dwa_cycle": (C.c_int, [_vp, C.POINTER(State), _sz, C.POINTER(Result)]),
+    "kc_dwa_find_best_path": (C.c_int, [_vp, C.POINTER(State), C.POINTER(StepInputs), C.POINTER(Result)]),
     "kc_dwa_get_best": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _fp]),
     "kc_dwa_get_sample_velocity": (C.c_int, [_vp, C.c_int64, _dp, _dp, _dp]),
     "kc_dwa_get_samples": (C.c_int, [_vp, _fp, _fp, _ip, _fp, _sz, C.POINTER(_sz)]),
@@ -216,6 +230,7 @@ def _bind_fast(L):
         "kc_dwa_set_tracked_segment": (vp, vp, vp, vp, vp, z, f),
         "kc_dwa_set_tracked_segment_xyz": (vp, vp, vp, z, f),
         "kc_dwa_cycle": (vp, vp, z, vp),
+        "kc_dwa_find_best_path": (vp, vp, vp, vp),
         "kc_dwa_sample_window": (vp, i, vp, d, d, d, i, i, vp, vp, vp, vp, z),
     }
     for name, args in protos.items():
@@ -387,6 +402,7 @@ class DwaContext:
         self._st_addr = C.addressof(self._st)
         self._n = _sz(0)
         self._n_addr = C.addressof(self._n)
+        self._step = None
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -537,6 +553,67 @@ class DwaContext:
         self._P = int(P)
         r = Result()
         rc = _fast["kc_dwa_cycle"](self.h, self._state(state), self._P, C.addressof(r))
+        if rc != KC_OK:
+            _check(rc)
+        return r
+
+    def find_best_path(self, state, P, *, window=None, points=None, scan=None, max_sensor_range=10.0,
+                       segment=None) -> Result:
+        """One reference controller cycle in ONE call (kc_dwa_find_best_path = DWA::findBestPath, dwa.h:183-230):
+        window = (ctr_type, Limits, (vx, vy, omega), max_linear_samples, max_angular_samples), points = (n, 3)
+        float32 array or scan = (ranges, angles) float64 arrays, segment = (seg_xyz (S, 3) float32, acc_at_seg,
+        ref_path_length).  An omitted part keeps what the context holds.  The arrays of the previous call are
+        recognised by identity (same objects: their addresses are reused)."""
+        si = self._step
+        if si is None:
+            si = self._step = StepInputs()
+            self._step_addr = C.addressof(si)
+            self._step_keep = [None] * 6   # the arrays whose addresses sit in the structure (kept alive)
+        keep = self._step_keep
+        if window is not None:
+            ctr, lim, cur, ml, ma = window
+            if keep[5] is not lim:
+                keep[5] = lim
+                si.limits = C.addressof(lim)
+            si.ctr_type, si.max_linear_samples, si.max_angular_samples = ctr, ml, ma
+            si.cur_vx, si.cur_vy, si.cur_omega = cur
+        else:
+            si.limits = None
+            keep[5] = None
+        if points is not None:
+            if keep[0] is not points:
+                p, addr = _addr32(points)
+                keep[0] = points if p is points else None  # (a converted copy lives only for this call)
+                self._step_tmp = p
+                si.points_xyz, si.n_points = addr, p.size // 3
+                si.scan_ranges = si.scan_angles = None
+        elif scan is not None:
+            r, ang = _f64(scan[0]), _f64(scan[1])
+            self._step_tmp = (r, ang)
+            keep[0] = None
+            si.points_xyz = None
+            si.scan_ranges, si.scan_angles, si.n_beams = r.ctypes.data, ang.ctypes.data, len(r)
+        else:
+            si.points_xyz = si.scan_ranges = si.scan_angles = None
+            keep[0] = None
+        si.max_sensor_range = max_sensor_range
+        if segment is not None:
+            seg, acc, ref_len = segment
+            if keep[1] is not seg or keep[2] is not acc:
+                s2, a_seg = _addr32(seg)
+                a2, a_acc = _addr32(acc)
+                keep[1] = seg if s2 is seg else None
+                keep[2] = acc if a2 is acc else None
+                self._step_tmp2 = (s2, a2)
+                si.seg_xyz, si.acc_at_seg, si.seg_size = a_seg, a_acc, s2.size // 3
+                si.seg_x = si.seg_y = si.seg_z = None
+            si.ref_path_length = ref_len
+        else:
+            si.seg_size = 0
+            keep[1] = keep[2] = None
+        self._P = si.num_points = int(P)
+        r = Result()
+        rc = _fast["kc_dwa_find_best_path"](self.h, self._state(state), self._step_addr, C.addressof(r))
         if rc != KC_OK:
             _check(rc)
         return r

@@ -242,3 +242,47 @@ def test_room_like_scans_far_walls_dense_rows(beams):
                 ctx.set_option(k, v)
             assert_cycle_equal(o, hip_cycle(kh, cur, scan=(rng, ang), ctx=ctx))
             ctx.close()
+
+
+def test_find_best_path_is_the_four_entries_in_one_call():
+    """kc_dwa_find_best_path (DWA::findBestPath, dwa.h:183-230) = kc_dwa_sample_window + kc_dwa_set_points |
+    kc_dwa_set_scan + kc_dwa_set_tracked_segment + kc_dwa_cycle: same record, same winner row, same as the
+    oracle; parts left out keep the context's state."""
+    from oracle import ko
+
+    inp = syn.make_controller_inputs("cfg2", seed=3, scale=0.3)
+    lim = kh.make_limits(syn.LIMITS["vx"], syn.LIMITS["vy"], syn.LIMITS["omega"])
+    pts = np.ascontiguousarray(inp["points"], np.float32)
+    seg = np.ascontiguousarray(inp["seg_xyz"], np.float32)
+    acc = np.ascontiguousarray(inp["acc_at_seg"], np.float32)
+    one, four = hip_context(kh, inp), hip_context(kh, inp)
+    for c in (one, four):
+        c.set_weights(kh.make_weights(*inp["weights"]))
+    P = inp["P"]
+    for i in range(6):
+        st = (0.02 * i, -0.01 * i, 0.03 * i, 0.0)
+        cur = (0.4 + 0.01 * i, 0.0, 0.02 * (i - 2))
+        a = one.find_best_path(st, P, window=(syn.DIFFERENTIAL_DRIVE, lim, cur, 21, 15), points=pts,
+                               max_sensor_range=inp["max_range"], segment=(seg, acc, inp["ref_len"]))
+        wvx, wvy, wom = four.sample_window(syn.DIFFERENTIAL_DRIVE, lim, cur, 21, 15)
+        four.set_points(st, pts, inp["max_range"])
+        four.set_tracked_segment(seg, acc, inp["ref_len"])
+        b = four.cycle(st, P)
+        assert (a.found, a.index, a.raw_index, a.n_admissible, a.n_samples) == (b.found, b.index, b.raw_index, b.n_admissible, b.n_samples)
+        assert np.float32(a.cost) == np.float32(b.cost)
+        if a.found:
+            np.testing.assert_array_equal(one.get_best()[0], four.get_best()[0])
+        o = oracle_cycle(dict(inp, vx=wvx, vy=wvy, omega=wom, state=st))
+        assert a.n_admissible == len(o["raw"]) and a.index == o["index"]
+        if a.found:
+            assert np.float32(a.cost) == np.float32(o["cost"])
+    # parts left out: the context keeps its window / sensor data / segment
+    c2 = one.find_best_path(st, P)
+    assert (c2.found, c2.index, c2.raw_index, c2.n_admissible) == (a.found, a.index, a.raw_index, a.n_admissible)
+    # a scan instead of points
+    ang, rng = syn.dense_scan(360)
+    s1 = one.find_best_path(st, P, scan=(rng, ang), max_sensor_range=inp["max_range"])
+    four.set_scan(st, rng, ang, inp["max_range"])
+    s2 = four.cycle(st, P)
+    assert (s1.found, s1.index, s1.raw_index, s1.n_admissible) == (s2.found, s2.index, s2.raw_index, s2.n_admissible)
+    one.close(); four.close()
