@@ -259,6 +259,12 @@ def controller_bench(args, rank, world, local_rank):
         if use_dist:
             ranks.barrier()
 
+    if args.scan and not use_dist:  # profiling passes of the laserscan_room leg: that leg alone, as the top-level line
+        leg = laserscan_leg(ctx, cfg, inp, vx, vy, om, P, S, pose, args)
+        leg.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f64 roll-out / f32 costs", "data": "synthetic"})
+        ctx.close()
+        return leg
     if args.fresh and not use_dist:
         leg = fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args)
         leg.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -1372,6 +1378,8 @@ def main():
     ap.add_argument("--split", action="store_true", help="three-kernel cycle instead of the single launch")
     ap.add_argument("--fresh", action="store_true",
                     help="only the fresh_inputs leg (one reference cycle per step), as the top-level line (profiling passes)")
+    ap.add_argument("--scan", action="store_true",
+                    help="only the laserscan_room leg (LaserScan input, 1440 beams), as the top-level line (profiling passes)")
     ap.add_argument("--only-headline", action="store_true",
                     help="no mid_density / open_space / extras legs (profiling passes: one scene per process)")
     ap.add_argument("--mapper", action="store_true", help="bench the LocalMapper (cfg4) instead")

@@ -163,9 +163,6 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        (otherwise rows are produced on demand by kc_dwa_get_samples)
  *   "cost_kernel"    (0) stand-alone cost stage: 0 chosen from the admissible count
  *                        of the previous cycle, 1 workgroup per sample, 2 wavefront per sample
- *   "cost_dc_cells"  (0) n = 8..512: cell-centre distance table of n cells along the
- *                        longer side for the far-obstacle searches (pays when several
- *                        cycles share one sensor update); 0: off
  *   "drop_samples"   (1) TrajectorySampler::setSampleDroppingMode (trajectory_sampler.cpp:103-105).  0: a
  *                        sample that collides at loop step i with last_free_index = i - 1 beyond
  *                        "num_ctrl_points" is KEPT (:157-168): path points i + 1 .. P - 1 repeat point
@@ -189,19 +186,18 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        point's index, weighted total, key) to a pass over 64 samples at once, a lane a
  *                        sample (sample_cost_batched_kernel), when the list fills several buffers per
  *                        workgroup (>= 10240 expected); 2: for every list length; 0: off
- *   "lazy_dilate"    (1) the first roll-out after a sensor update dilates its own window
  *   "device_trig"    (1) cos / sin(yaw_k) formed by the roll-out kernels themselves (below:
- *                        kc_trig_selfcheck); 0: the host's libm table, written over the BAR
- *   "early_launch"   (1) host trig table only: the roll-out kernel is queued before the table exists
- *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host
- *   "trig_copy"      (0) trig table through pinned memory + H2D copy instead of BAR stores
+ *                        kc_trig_selfcheck); 0: the FALLBACK -- the host's libm table, complete before the
+ *                        launch (no kernel ever waits for the host)
+ *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host (spheres always are)
+ *   "sensor_two_launch" (0) the sensor build of clouds beyond 32 k points (two launches) for every size
  *   "force_split"    (0) roll-out, collision and compaction as separate kernels
  * kc_dwa_get_option also reads "last_cycle_single_launch", "last_cycle_samples",
  * "host_threads", "trig_rows" (rows of the host's cos / sin table: distinct omegas of
  * this context's share), "shard_samples", and the counters "obs_near_rides" /
  * "obs_near_builds" (near tables built inside a sensor launch / by a launch of their own).
- * Waits for the context's stream.  Process-wide defaults may be preset with the
- * environment variables listed in DESIGN.md (test hooks). */
+ * Waits for the context's stream.  Nothing that selects a path is read from the environment (round 4); the
+ * variables that remain are diagnostics (Switches). */
 int kc_dwa_set_option(kc_dwa *ctx, const char *name, double value);
 int kc_dwa_get_option(kc_dwa *ctx, const char *name, double *value);
 /* threads of the process-wide host pool that evaluates the libm trig table of a

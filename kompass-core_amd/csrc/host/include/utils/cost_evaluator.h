@@ -78,11 +78,8 @@ class CostEvaluator {
   // communicator: this context's shard of the lattice + one 8-byte all-reduce
   // (kc_dwa_cycle_sharded); the winner's path is then re-rolled on the host from
   // its velocity (same arithmetic, same libm) when another rank owns it.
-  //
-  // Retry contract: the early-launched kernel waits at most 50 ms for the host's
-  // trig table; a host descheduled for longer makes that ONE cycle fail
-  // (KC_ERR_HIP, "gave up waiting"), the context is usable again at once.  This
-  // call repeats such a cycle once before it throws std::runtime_error.
+  // No kernel of a cycle waits for the host (device trig; the host's libm table -- fallback -- is complete
+  // before the launch): a failing cycle throws std::runtime_error, there is nothing to repeat.
   TrajSearchResult cycleOnDevice(const Path::Path *reference_path, const Path::Path::View &tracked_segment,
                                  size_t numPointsPerTrajectory, const Path::State &pose, double time_step,
                                  const std::function<Velocity2D(size_t)> &sampleVelocity, size_t n_generated,

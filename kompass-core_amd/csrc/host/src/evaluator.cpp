@@ -220,14 +220,7 @@ TrajSearchResult CostEvaluator::cycleOnDevice(const Path::Path *ref, const Path:
   // rule, kc_dwa_sample_window applied it)
   (void)n_generated;
   kc_result r;
-  auto run = [&]() { return comm ? kc_dwa_cycle_sharded(ctx_.get(), comm, &st, P, &r) : kc_dwa_cycle(ctx_.get(), &st, P, &r); };
-  int rc = run();
-  // The retry contract (see the header): once.  With a communicator the error is collective -- the
-  // exchange record carries an error word, so EVERY rank sees "gave up waiting" for the same cycle and
-  // every rank repeats it: the ranks stay paired (a lone retry used to put one rank a
-  // collective out of step).
-  if (rc == KC_ERR_HIP && std::string(kc_last_error()).find("gave up waiting") != std::string::npos)
-    rc = run();
+  const int rc = comm ? kc_dwa_cycle_sharded(ctx_.get(), comm, &st, P, &r) : kc_dwa_cycle(ctx_.get(), &st, P, &r);
   hip::check(rc);
   sensorDataResident = false;
   if (!customTrajCostsPtrs_.empty()) {

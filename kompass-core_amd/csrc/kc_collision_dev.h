@@ -63,29 +63,16 @@ struct RollArgs {
   uint8_t *flags;       // [n] admissible
   int *adm_list;        // admissible local sample ids, appended (any order)
   long long *adm_count; // device counter (re-armed by the cost kernel)
-  // early launch (fused kernel only): the kernel is queued BEFORE the host has
-  // produced the trig table, so launch + dispatch latency overlap the libm
-  // work; the host then writes the table and this sequence word through the
-  // BAR and the workgroups wait for it.  Null: the table is already there.
-  const long long *trig_flag;
-  long long trig_seq;       // the sequence word reads trig_seq + (stages of the table that are complete)
-  int trig_stage_rows;      // rows per stage: row r belongs to stage r / trig_stage_rows
-  int trig_stages;
-  long long *dev_err;   // set when the wait gives up (host never delivered)
+  long long *dev_err;   // device error word of the cycle record (no kernel sets it at present; the epilogues carry it)
   // Device trig (round 3, kc_trig_exact.h): no host table at all -- the fused kernel forms yaw_k of its own
   // omega rows by repeated addition from yaw0 (path.h:30) and evaluates glibc's sincos algorithm itself; the
   // split path's kernels read a table trig_table_kernel has filled the same way.
-  int trig_dev;             // 1: fused kernel computes its trig rows (trig_flag is null then)
+  int trig_dev;             // 1: fused kernel computes its trig rows; 0: it reads `trig`
   double yaw0;
   const double *sincostab;  // [440] the table sincos reads, in the context's device memory
   double2 *trig_out;        // box footprints: the rows also go here (the exact tests read yaw_k of a pose back)
   unsigned long long *dbg;  // diagnostic build only (KC_DEBUG_STAMPS)
   CollDev c;
-  // c.dil == 2: the first cycle after a sensor update dilates its window itself
-  // (dilate_kernel then runs behind that cycle, for the following ones): run
-  // half-widths of the two discs per row offset, win[0..R] | wout[0..R], and R
-  const signed char *diltab;
-  int dilR;
   // drop_samples_ == false (trajectory_sampler.cpp:157-168): a sample whose first collision comes at loop
   // step i with last_free_index = i - 1 > num_ctrl stays admissible -- path points i + 1 .. P - 1 repeat point
   // i - 1, velocities i .. P - 2 are zero.  Needs the FIRST colliding pose of a sample, not just any.

@@ -116,12 +116,6 @@ struct CostArgs {
 // second argument of the long-list kernel only (the layout of CostArgs is left
 // alone: the workgroup-per-sample kernel is sensitive to it)
 struct DcArgs {
-  const float *dc;          // [H][W] distance from a cell centre to the nearest obstacle (+inf
-                            // beyond cap + a cell), a grid of its own from the bucket origin; or
-                            // null (cell_dist_kernel, kc_sensor_kernels.h)
-  double inv_g, h;          // 1 / cell edge, half a cell diagonal
-  int W, H;
-  const int *enable;        // device flag of the sensor build: table filled in or not
   // Near table of the tracked segment (segment_near_kernel, kc_segment_kernels.h), or null: for
   // every cell of a grid over the reachable box, the range of chunks that can hold the nearest
   // segment point of ANY point of the cell, and the index of the point nearest to its centre:
@@ -1196,7 +1190,7 @@ struct BatchSlot {
   unsigned long long *cand;    // the chunks its search scanned
 };
 template <class Seg, class Pts, bool kBatched = false>
-__device__ __forceinline__ float wave_sample_total(const CostArgs &a, const DcArgs &t, bool use_dc,
+__device__ __forceinline__ float wave_sample_total(const CostArgs &a, const DcArgs &t,
                                                    const Seg &seg, const float *cap, const float *sup,
                                                    float sz_end, const int *cells, const uint8_t *skip,
                                                    const float *obx, const float *oby, const Pts pts,
@@ -1459,22 +1453,8 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       // lanes with an empty neighbourhood wait for the cooperative pass below
       bool far = active && sk >= kCoopMinSkip && sk < 255;
       if (far) active = false;
-      // bracket of this point's distance from the centre table (off == 0: the
-      // point lies in its cell): within half a cell diagonal of the centre's
       double lb0 = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
       double ubp = DBL_MAX;
-      if (far && use_dc && off == 0.0) {
-        const int ix = min(max(static_cast<int>((static_cast<double>(x) - b.gx0) * t.inv_g), 0), t.W - 1);
-        const int iy = min(max(static_cast<int>((static_cast<double>(y) - b.gy0) * t.inv_g), 0), t.H - 1);
-        const float dcv = t.dc[iy * t.W + ix];
-        if (dcv > 3.0e38f) {
-          far = false;  // farther than the cap: costs nothing
-        } else {
-          const double hh = t.h + 1e-4 + static_cast<double>(dcv) * 1e-6;
-          lb0 = fmax(lb0, static_cast<double>(dcv) - hh);
-          ubp = static_cast<double>(dcv) + hh;
-        }
-      }
       while (__ballot(active)) {
         if (active) {
           const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
@@ -1948,7 +1928,6 @@ __attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_c
   float4 *const l_za = l_xy + npp;
   const float *const cap = kLds ? l_seg + 8 * npp : a.sx + seg_cap_offset(a.S);  // [nch] capsule records
   const float *const sup = cap + 8 * a.nch;                          // [4][nsup]
-  const bool use_dc = t.dc != nullptr && *t.enable != 0;
   const float sz_end = (a.use_seg && a.S > 0) ? a.sz[a.S - 1] : 0.0f;  // z of the last segment point (end term)
   if (threadIdx.x == 0) {
     s_key = KEY_NONE;
@@ -2000,10 +1979,10 @@ __attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_c
 #endif
     float total;
     if (kLds)
-      total = wave_sample_total(a, t, use_dc, SegPairs{l_xy, l_za}, cap, sup, sz_end, cells, skip, obx, oby, pts,
+      total = wave_sample_total(a, t, SegPairs{l_xy, l_za}, cap, sup, sz_end, cells, skip, obx, oby, pts,
                                 n, lane, &s_obest[wave], stamp);
     else
-      total = wave_sample_total(a, t, use_dc, SegRows{a.sx, a.sy, a.szz, a.acc_seg, a.S}, cap, sup, sz_end,
+      total = wave_sample_total(a, t, SegRows{a.sx, a.sy, a.szz, a.acc_seg, a.S}, cap, sup, sz_end,
                                 cells, skip, obx, oby, pts, n, lane, &s_obest[wave], stamp);
     if (lane == 0) a.costs[n] = total;
     if (stamp) KC_STAMP(3);
@@ -2073,7 +2052,6 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArg
   float4 *const l_za = l_xy + npp;
   const float *const cap = l_seg + 8 * npp;
   const float *const sup = cap + 8 * a.nch;
-  const bool use_dc = t.dc != nullptr && *t.enable != 0;
   const float sz_end = (a.use_seg && a.S > 0) ? a.sz[a.S - 1] : 0.0f;
   if (threadIdx.x == 0) {
     s_key = KEY_NONE;
@@ -2123,7 +2101,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArg
     const BatchBuf B = batch_buf_at(smem + sel * bufb);
     if (lane == 0) B.n[q] = n;
     const BatchSlot bs{B.mind + q * (a.P | 1), B.xe + q, B.ye + q, B.be + q, B.cand + q};
-    wave_sample_total<SegPairs, RowPts, true>(a, t, use_dc, seg, cap, sup, sz_end, cells, skip, obx, oby, pts, n, lane,
+    wave_sample_total<SegPairs, RowPts, true>(a, t, seg, cap, sup, sz_end, cells, skip, obx, oby, pts, n, lane,
                                               B.obest + q, false, bs);
     int old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(&s_done[sel], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -207,7 +207,6 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
     KC_RSTAMP(12);
   } else {
     __syncthreads();  // s_next, s_key
-    const bool use_dc = tail.t.dc != nullptr && *tail.t.enable != 0;
     const float *cap = t.cap, *sup = t.cap + 8 * c.nch;
     long long wkey = KEY_NONE;
     for (;;) {
@@ -218,7 +217,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
       const int s = lsurv[q];
       const int n = lperm[s];
       const PosePts pts{lpos + s * PP, PP - 1};
-      const float total = wave_sample_total(c, tail.t, use_dc, seg, cap, sup, sz_end, t.cells, t.skip,
+      const float total = wave_sample_total(c, tail.t, seg, cap, sup, sz_end, t.cells, t.skip,
                                             c.b.bx, c.b.by, pts, n, lane, &s_ob[wave], false);
       if (lane == 0) c.costs[n] = total;
       if (total < FLT_MAX) {
@@ -244,7 +243,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
 template <int kBlock, class Tail>
 __device__ __forceinline__ void cycle_epilogue_host(const RollArgs &a, const Tail &tail, long long key,
                                                     unsigned long long mask, int best_slot,
-                                                    const double2 *best_row, int late, int tid) {
+                                                    const double2 *best_row, int tid) {
   const int P = a.P;
   const unsigned b = blockIdx.x;
   // wavefront 0 alone (the row lies in LDS behind the barrier of the cost phase): row out, its check word by a
@@ -265,7 +264,7 @@ __device__ __forceinline__ void cycle_epilogue_host(const RollArgs &a, const Tai
   }
   if (tid == 0) {
     const long long w1 = static_cast<long long>((mask & 0xFFFFFFFFull) | (static_cast<unsigned long long>(x) << 32));
-    const long long w2 = tail.seq | (late ? (1ll << 62) : 0ll) | (have_row ? (1ll << 61) : 0ll);
+    const long long w2 = tail.seq | (have_row ? (1ll << 61) : 0ll);
     longlong2 *v = reinterpret_cast<longlong2 *>(tail.host_slots + 4 * b);
     longlong2 lo, hi;
     lo.x = key;
@@ -416,7 +415,7 @@ __device__ __forceinline__ void cycle_epilogue(const RollArgs &a, const Tail &ta
 #pragma unroll
     for (int u = 0; u < kMaxWords; ++u) {
       const unsigned w = tid + u * kBlock;
-      if (w < 2u * static_cast<unsigned>(tail.xrw)) region[w] = w >= nwords ? 0u : wreg[u];  // (a late cycle left no survivors: zeros)
+      if (w < 2u * static_cast<unsigned>(tail.xrw)) region[w] = w >= nwords ? 0u : wreg[u];
     }
   }
   __syncthreads();

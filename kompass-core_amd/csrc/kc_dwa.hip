@@ -94,11 +94,6 @@ struct kc_dwa {
   size_t lds_limit = 64 * 1024;         // dynamic LDS the fused kernel may use
   DevBuf<long long> d_block_keys;       // per-workgroup best keys of the cost kernel
   DevBuf<uint32_t> d_ginner, d_gouter;  // dilated sensor bitmaps
-  DevBuf<signed char> d_diltab;         // disc run tables for the roll-out that dilates its own window
-  int dil_R = 0;
-  bool dil_lazy = false;                // the masks of the current bitmap are not built yet
-  int dil_uses = 0;                     // roll-outs that dilated their own window since the update
-  bool lazy_dilate = true;              // KC_LAZY_DILATE=0: dilate_kernel inside every sensor update
   bool have_dil = false;
   DevBuf<unsigned long long> d_dbg2;    // roll-out kernel stamps (diagnostic)
   DevBuf<int32_t> d_prow;               // trig rows in d_perm order (velocities are read through d_perm)
@@ -115,7 +110,6 @@ struct kc_dwa {
   bool seg_busy = false;     // ... a kernel that writes the tracked-segment table (resident-path window)
   std::vector<int> cell_id, cell_cursor;  // bucketing scratch (reused)
   std::vector<uint8_t> skip_pad;
-  int test_late_flag_ms = 0;            // KC_TEST_LATE_FLAG_MS: delay the trig sequence word once
   // ... and a cycle that follows a sensor update finds its table made already: the sensor build launch carries
   // a few workgroups that form it for the update's yaw, the current lattice and the last horizon (TrigJob)
   bool trig_plan = false;               // kc_dwa_set_points / set_scan: a job may ride in this update's launch
@@ -127,16 +121,6 @@ struct kc_dwa {
   long long trig_rides = 0;             // get_option "trig_rides"
   bool device_trig = true;              // option "device_trig" / KC_DEVICE_TRIG: cos / sin(yaw_k) formed by the kernels
                                         // (kc_trig_exact.h); off: the host's libm table over the BAR (rounds 1-3)
-  bool early_launch = true;             // fused kernel queued before the trig table exists
-  long long trig_seq = 0;
-  // staged hand-off of the trig table (early launch): the rows are produced in `trig_stages` stages of
-  // consecutive rows, every stage dealt over all workers; the worker that completes a stage publishes
-  // 16 seq + (stages done) in the sequence word, and a workgroup waits only for the stage of its highest row
-  std::atomic<int> trig_stage_rows_done[8];
-  std::atomic<long long> trig_flag_shadow{0};
-  bool trig_staged = true;              // test hook KC_TRIG_STAGES=0: one flag for the whole table
-  size_t trig_stage_table_min = 16384;  // entries of the table from which it is handed over in stages
-  int trig_stage_min = 6;               // tuning hook KC_TRIG_STAGE_MIN: rows per worker and stage, at least
   int seg_chunk = kSegChunkMin, seg_nch = 0, seg_nsup = 0;  // chunking of the tracked segment (cost kernel)
   long long last_nadm = -1;             // admissible count of the previous cycle (kernel choice)
   int cost_kernel_force = 0;            // 1: workgroup-per-sample, 2: wavefront-per-sample (KC_COST_KERNEL)
@@ -243,15 +227,6 @@ struct kc_dwa {
   PinBuf<uint8_t> h_skip;  // Chebyshev distance to the nearest non-empty cell
   DevBuf<uint8_t> d_skip;
   size_t n_bucketed = 0;
-  DevBuf<float> d_dc;    // cell centre -> nearest obstacle (device sensor build only)
-  DevBuf<int> d_dc_enable;  // ... filled in or not (decided by the sensor build)
-  bool have_dc = false;  // ... valid for the current buckets
-  // Off by default: per sensor update the table costs about what it saves in the
-  // one cycle that follows; it pays when several cycles share a sensor update.
-  bool no_dc = true;     // KC_COST_DC=<cells along the longer side of the table> turns it on
-  int dc_side = 64;
-  double dc_inv_g = 0, dc_h = 0;
-  int dc_W = 0, dc_H = 0;
 
   DevBuf<long long> d_result;  // key, n_adm, compact index, scratch
   PinBuf<long long> h_result;
@@ -491,7 +466,6 @@ void dil_tables(const DilGeom &dg, signed char win[kMaxDil + 1], signed char wou
 
 // the two dilated masks from the bitmap in d_gbits
 int launch_dilate(kc_dwa *c) {
-  c->dil_lazy = false;
   if (!c->have_dil) return KC_OK;
   const DilGeom dg = dil_geom(c);
   const size_t nwords = static_cast<size_t>(c->gH) * c->gwpr;
@@ -509,25 +483,6 @@ int launch_dilate(kc_dwa *c) {
   KC_TRY(c->timing.stop(c->stream));
   KC_HIP(hipGetLastError());
   c->update_busy = true;
-  return KC_OK;
-}
-
-// A sensor update does not queue dilate_kernel itself: the first roll-out that
-// follows dilates its own window in LDS (RollArgs::diltab); the kernel runs
-// only if a second cycle comes on the same data.  This writes the table the
-// roll-out reads and marks the masks as not built yet.
-int defer_dilate(kc_dwa *c) {
-  if (!c->have_dil || !c->lazy_dilate || !c->trig_direct) return launch_dilate(c);
-  const DilGeom dg = dil_geom(c);
-  signed char tab[2 * (kMaxDil + 1)];
-  dil_tables(dg, tab, tab + kMaxDil + 1);
-  KC_TRY(c->d_diltab.reserve(sizeof(tab)));
-  std::memcpy(c->d_diltab.p, tab, sizeof(tab));  // over the BAR, like the other per-update tables
-  c->bar_dirty = true;
-  bar_flush(c);
-  c->dil_R = dg.R;
-  c->dil_lazy = true;
-  c->dil_uses = 0;
   return KC_OK;
 }
 
@@ -558,7 +513,6 @@ void dil_tables(const DilGeom &dg, signed char win[kMaxDil + 1], signed char wou
 // reachable window out of it)
 int upload_voxels(kc_dwa *c) {
   c->have_gbits = false;
-  c->dil_lazy = false;
   const size_t nv = c->vox_kx.size();
   if (nv == 0) return KC_OK;
   int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN;
@@ -611,7 +565,7 @@ int upload_voxels(kc_dwa *c) {
   }
   if (!c->trig_direct) c->update_busy = true;
   bar_flush(c);  // the kernels behind it read the bitmap
-  KC_TRY(defer_dilate(c));
+  KC_TRY(launch_dilate(c));
   c->have_gbits = true;
   return KC_OK;
 }
@@ -622,7 +576,6 @@ int upload_voxels(kc_dwa *c) {
 int upload_obstacles(kc_dwa *c, size_t n) {
   c->O = n;
   c->n_bucketed = 0;
-  c->have_dc = false;  // the centre table belongs to the device-side build
   if (n == 0) return KC_OK;
   const float *ox = c->h_obs.p, *oy = c->h_obs.p + n;
   double lox = DBL_MAX, loy = DBL_MAX, hix = -DBL_MAX, hiy = -DBL_MAX;
@@ -1193,8 +1146,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   const size_t nwords = fits ? static_cast<size_t>(c->gH) * c->gwpr : 0;
   if (!fits) {
     c->have_gbits = false;
-    c->dil_lazy = false;
-    return KC_OK;
+      return KC_OK;
   }
   // one workgroup with everything in LDS, or (large clouds / bitmaps) the points
   // over many workgroups with device atomics
@@ -1277,8 +1229,6 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   a.bx = c->d_bobs.p;
   a.by = c->d_bobs.p + n;
   a.obs_z_zero = c->raw_is_scan ? 1 : 0;
-  KC_TRY(c->d_dc_enable.reserve(1));
-  a.dc_enable = c->d_dc_enable.p;
   KC_TRY(plan_trig_job(c, a.trig));
   const unsigned tj = static_cast<unsigned>(a.trig.nblk);
   if (tj) {
@@ -1305,10 +1255,6 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     f.nb = nb;
     f.kb = 8;
     f.band_rows = band_rows;
-    f.roles = 15;
-    if (const char *e = std::getenv("KC_SENSOR_ROLES")) f.roles = std::atoi(e);
-    if (const char *e = std::getenv("KC_SENSOR_KB")) f.kb = std::atoi(e);
-    if (const char *e = std::getenv("KC_SENSOR_NB")) { f.nb = std::atoi(e); band_rows = (c->gH + f.nb - 1) / f.nb; f.band_rows = band_rows; f.nb = (c->gH + band_rows - 1) / band_rows; }
     f.R = dilR;
     f.ginner = c->d_ginner.p;
     f.gouter = c->d_gouter.p;
@@ -1434,42 +1380,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   }
   KC_HIP(hipGetLastError());
   c->update_busy = true;
-  c->have_dc = false;
-  if (!c->no_dc) {
-    // centre-distance table for the far searches of the cost kernels: a grid of
-    // its own (dc_side cells along the longer side) over the bucket extent
-    CellDistArgs da{};
-    const double ex = b.W * b.g, ey = b.H * b.g;
-    da.gx0 = b.gx0;
-    da.gy0 = b.gy0;
-    da.gd = std::max(ex, ey) / c->dc_side;
-    da.Wd = std::min(c->dc_side + 1, static_cast<int>(std::ceil(ex / da.gd * (1.0 + 1e-9))) + 1);
-    da.Hd = std::min(c->dc_side + 1, static_cast<int>(std::ceil(ey / da.gd * (1.0 + 1e-9))) + 1);
-    const size_t nd = static_cast<size_t>(da.Wd) * da.Hd;
-    KC_TRY(c->d_dc.reserve(nd));
-    da.dc = c->d_dc.p;
-    da.g = b.g;
-    da.inv_g = b.inv_g;
-    da.cap = b.cap;
-    da.W = b.W;
-    da.H = b.H;
-    da.cell_start = c->d_cells.p;
-    da.skip = c->d_skip.p;
-    da.bx = c->d_bobs.p;
-    da.by = c->d_bobs.p + n;
-    da.enable = c->d_dc_enable.p;
-    KC_TRY(c->timing.start("cell_dist_kernel", c->stream));
-    hipLaunchKernelGGL(cell_dist_kernel, dim3(blocks_for(nd, 4)), dim3(256), 0, c->stream, da);
-    KC_TRY(c->timing.stop(c->stream));
-    KC_HIP(hipGetLastError());
-    c->dc_inv_g = 1.0 / da.gd;
-    c->dc_h = da.gd * 0.70710678118654757;
-    c->dc_W = da.Wd;
-    c->dc_H = da.Hd;
-    c->have_dc = true;
-  }
-  if (masks_built) c->dil_lazy = false;  // (sensor_fused_kernel wrote both dilations beside the bitmap)
-  else KC_TRY(defer_dilate(c));
+  if (!masks_built) KC_TRY(launch_dilate(c));  // (sensor_fused_kernel writes both dilations beside the bitmap)
   c->have_gbits = true;
   b.skip = c->d_skip.p;
   b.cell_start = c->d_cells.p;
@@ -1643,7 +1554,7 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
     }
     cd.ginner = c->d_ginner.p;
     cd.gouter = c->d_gouter.p;
-    cd.dil = c->have_dil ? (c->dil_lazy ? 2 : 1) : 0;
+    cd.dil = c->have_dil ? 1 : 0;
     cd.gkx0 = c->gkx0;
     cd.gky0 = c->gky0;
     cd.gH = c->gH;
@@ -1914,12 +1825,6 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
   ca.nsup = c->seg_nsup;
   ca.seg_flat = c->seg_flat ? 1 : 0;
   dt = DcArgs{};
-  dt.dc = c->have_dc ? c->d_dc.p : nullptr;
-  dt.inv_g = c->dc_inv_g;
-  dt.h = c->dc_h;
-  dt.W = c->dc_W;
-  dt.H = c->dc_H;
-  dt.enable = c->d_dc_enable.p;
   if (c->near_ok && ca.use_seg) {
     dt.near = c->d_near.p;
     dt.nx0 = c->near_x0;
@@ -2223,7 +2128,6 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
   long long fkey = KEY_NONE;
   unsigned bw = 0;
   long long na = 0;
-  bool late = false;
   for (long sweeps = 0; remaining; ++sweeps) {
     for (size_t w = 0; w < pend.size(); ++w) {
       for (uint64_t m = pend[w]; m;) {
@@ -2238,7 +2142,6 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
           bw = g;
         }
         na += __builtin_popcountll(static_cast<unsigned long long>(w1) & 0xFFFFFFFFull);
-        late = late || ((w2 >> 62) & 1);
       }
     }
     if (remaining && (sweeps & 255) == 255 &&
@@ -2254,7 +2157,6 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
   c->update_busy = false;
   c->seg_busy = false;
   c->timing.mark("host:wait_result");
-  if (late) KC_FAIL(KC_ERR_HIP, "roll-out kernel gave up waiting for the host's trig table");
   kc_result r{};
   r.n_admissible = na;
   c->last_nadm = na;
@@ -2360,7 +2262,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
   kc_result r{};
   const long long key = c->h_result.p[0];
   if (c->h_result.p[1] < 0)
-    KC_FAIL(KC_ERR_HIP, "roll-out kernel gave up waiting for the host's trig table");
+    KC_FAIL(KC_ERR_HIP, "the cycle's device error word is set");
   r.n_admissible = c->h_result.p[1];
   c->last_nadm = r.n_admissible;
   r.n_samples = static_cast<int64_t>(n);
@@ -2537,14 +2439,6 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kCostLdsBudget)) == hipSuccess;
     if (!c->cost_batch_ok) (void)hipGetLastError();
   }
-  if (const char *e = std::getenv("KC_FUSED_CFG")) {  // tuning hook: "samples,threads"
-    int sa = 0, th = 0;
-    if (std::sscanf(e, "%d,%d", &sa, &th) == 2) {
-      c->fused_samples = sa;
-      c->fused_block = th;
-      c->fused_shape_fixed = true;
-    }
-  }
   {
     int large_bar = 0;
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, p->device) != hipSuccess) {
@@ -2560,57 +2454,15 @@ int kc_dwa_create(const kc_dwa_params *p, kc_dwa **out) {
       else
         (void)hipGetLastError();
     }
-    if (const char *e = std::getenv("KC_FUSED_CYCLE"))
-      {  // process default; option "fused_cycle" per context
-        if (e[0] == '0') c->cycle_fused = false;
-        if (e[0] == '2') c->cycle_forced = true;
-      }
+    // Process-wide defaults from the environment: diagnostics only (everything that selects a path is a
+    // per-context option, kc_dwa_set_option).
     if (const char *e = std::getenv("KC_DEBUG_HOST")) c->hprof.on = e[0] == '1';
-    if (const char *e = std::getenv("KC_NEAR_TABLE")) {  // process default of option "near_table"
-      const int v = std::atoi(e);
-      if (v == 0 || (v >= 16 && v <= 512)) c->near_side = v;
-    }
-    if (const char *e = std::getenv("KC_TRIG_COPY"))
-      if (e[0] == '1') c->trig_direct = false;  // test hook: exercise the staged copy
-    if (const char *e = std::getenv("KC_SENSOR_HOST"))
-      if (e[0] == '1') c->device_sensor = false;        // test hook: host-side sensor update
-    if (const char *e = std::getenv("KC_TRIG_STAGES")) c->trig_staged = e[0] != '0';
-    if (const char *e = std::getenv("KC_TRIG_STAGE_MIN")) c->trig_stage_min = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("KC_COST_BATCH")) {
-      c->cost_batch = e[0] != '0';
-      c->cost_batch_forced = e[0] == '2';
-    }
-    if (const char *e = std::getenv("KC_FOLD_PUBLISH")) c->fold_publish = e[0] != '0';
-    if (const char *e = std::getenv("KC_COST_OBS_LDS")) c->cost_obs_lds = e[0] != '0';
-    if (const char *e = std::getenv("KC_OBS_UNION")) c->obs_union = std::min(4096, std::max(0, std::atoi(e)));  // tuning hook
-    if (const char *e = std::getenv("KC_OBS_NEAR_AHEAD"))
-      if (e[0] == '0') c->obs_near_ahead = false;
-    if (const char *e = std::getenv("KC_LAZY_DILATE"))
-      if (e[0] == '0') c->lazy_dilate = false;          // test hook: dilate_kernel inside every sensor update
-    if (const char *e = std::getenv("KC_COST_DC"))
-    {
-      if (std::atoi(e) >= 8 && std::atoi(e) <= 512) {
-        c->dc_side = std::atoi(e);
-        c->no_dc = false;
-      }
-    }
     c->sensor_fused_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(sensor_fused_kernel<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(kSensorFusedLds)) == hipSuccess;
     if (!c->sensor_fused_ok) (void)hipGetLastError();
-    if (const char *e = std::getenv("KC_COST_KERNEL"))  // tuning/test hook: "block" | "wave"
-      c->cost_kernel_force = e[0] == 'b' ? 1 : e[0] == 'w' ? 2 : 0;
-    if (const char *e = std::getenv("KC_TEST_LATE_FLAG_MS")) c->test_late_flag_ms = std::atoi(e);
-    if (const char *e = std::getenv("KC_DEVICE_TRIG")) c->device_trig = e[0] != '0';
-    if (const char *e = std::getenv("KC_EARLY_LAUNCH"))
-      c->early_launch = e[0] != '0';            // tuning/test hook
   }
   if (const char *e = std::getenv("KC_DEBUG_STAMPS")) c->debug_stamps = e[0] == '1';
-  if (const char *e = std::getenv("KC_FORCE_SPLIT"))
-    if (e[0] == '1') {  // test hook: exercise the split / in-place paths
-      c->lds_limit = 0;
-      c->cost_lds_ok = false;
-    }
   hipLaunchKernelGGL(init_result_kernel, dim3(1), dim3(1), 0, c->stream,
                      c->d_result.p);
   if (hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -2722,8 +2574,6 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_sensor_tmp.release();
   c->d_sensor_bytes.release();
   c->d_vsum.release();
-  c->d_dc.release();
-  c->d_dc_enable.release();
   c->d_gridcnt.release();
   c->h_gridrec.release();
   if (c->aux_stream) {
@@ -2762,7 +2612,6 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_block_keys.release();
   c->d_gbits.release();
   c->d_ginner.release();
-  c->d_diltab.release();
   c->d_gouter.release();
   c->d_adm.release();
   c->d_pos.release();
@@ -2825,11 +2674,6 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   else if (n == "cost_kernel") {
     if (!(v == 0.0 || v == 1.0 || v == 2.0)) KC_FAIL(KC_ERR_RANGE, "cost_kernel: 0 auto, 1 workgroup per sample, 2 wavefront per sample");
     c->cost_kernel_force = static_cast<int>(v);
-  } else if (n == "cost_dc_cells") {
-    if (v != 0.0 && !(v >= 8.0 && v <= 512.0)) KC_FAIL(KC_ERR_RANGE, "cost_dc_cells: 0 (off) or 8..512");
-    c->no_dc = v == 0.0;
-    if (!c->no_dc) c->dc_side = static_cast<int>(v);
-    c->have_dc = false;  // built by the next sensor update
   } else if (n == "cycle_samples") {
     if (!(v == 0.0 || v == 16.0 || v == 32.0)) KC_FAIL(KC_ERR_RANGE, "cycle_samples: 0 (by shard size), 16 or 32");
     c->cycle_samples_opt = static_cast<int>(v);
@@ -2862,12 +2706,9 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     c->onear_version = ~0ull;
     c->onear_ok = false;
     if (!on) c->oscan_valid = false;
-  } else if (n == "lazy_dilate") c->lazy_dilate = on;
-  else if (n == "sensor_two_launch") c->sensor_two_launch = on;
-  else if (n == "early_launch") c->early_launch = on;
+  } else if (n == "sensor_two_launch") c->sensor_two_launch = on;
   else if (n == "device_trig") c->device_trig = on;
   else if (n == "sensor_on_host") c->device_sensor = !on;
-  else if (n == "trig_copy") c->trig_direct = c->large_bar && !on;
   else if (n == "force_split") {
     c->lds_limit = on ? 0 : c->lds_limit_hw;
     c->cost_lds_ok = on ? false : c->cost_lds_hw;
@@ -2883,8 +2724,6 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "write_paths") *v = c->write_paths;
   else if (n == "host_reduce") *v = c->host_reduce;
   else if (n == "cost_kernel") *v = c->cost_kernel_force;
-  else if (n == "cost_dc_cells") *v = c->no_dc ? 0.0 : c->dc_side;
-  else if (n == "lazy_dilate") *v = c->lazy_dilate;
   else if (n == "sensor_two_launch") *v = c->sensor_two_launch;
   else if (n == "near_table") *v = c->near_side;
   else if (n == "cycle_samples") *v = c->cycle_samples_opt;
@@ -2896,11 +2735,9 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "obs_union") *v = c->obs_union;
   else if (n == "obs_near_rides") *v = static_cast<double>(c->onear_rides);    // read-only
   else if (n == "obs_near_builds") *v = static_cast<double>(c->onear_builds);  // read-only
-  else if (n == "early_launch") *v = c->early_launch;
   else if (n == "device_trig") *v = c->device_trig && trig_selfcheck_ok();
   else if (n == "trig_rides") *v = static_cast<double>(c->trig_rides);  // read-only
   else if (n == "sensor_on_host") *v = !c->device_sensor;
-  else if (n == "trig_copy") *v = !c->trig_direct;
   else if (n == "force_split") *v = c->lds_limit == 0;
   else if (n == "last_cycle_single_launch") *v = c->cycle_launched;  // read-only
   else if (n == "host_threads") *v = WorkerPool::instance().workers() + 1;  // read-only here: kc_set_host_threads
@@ -3216,8 +3053,7 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   KC_TRY(upload_voxels(c));
   if (c->tilted) {
     c->have_dil = false;
-    c->dil_lazy = false;
-    if (!c->vox_kx.empty() && !c->have_gbits)
+      if (!c->vox_kx.empty() && !c->have_gbits)
       KC_FAIL(KC_ERR_UNSUPPORTED, "tilted sensor frame: the scan's voxel columns span more than 8192 cells");
   }
   return upload_obstacles(c, n);
@@ -3749,12 +3585,11 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     __builtin_ia32_sfence();  // write-combined stores leave the core before "done"
 #endif
   };
-  // The workers start on the table at once (BAR path: straight into d_trig) -- before this thread
-  // has put the kernel arguments together, so that the table is complete when the kernel asks for it.
-  // Device trig (kc_trig_exact.h): the kernels form cos / sin(yaw_k) themselves -- no host table, no flag,
-  // no worker pool.  Only while every yaw_k stays inside the range the restated algorithm covers
-  // (|yaw| < 105414350; a bound on |yaw0| + P |omega| dt decides), and only when the restatement agreed
-  // with the installed libm when the library was loaded.
+  // Device trig (kc_trig_exact.h): the kernels form cos / sin(yaw_k) themselves -- no host table at all.  Only
+  // while every yaw_k stays inside the range the restated algorithm covers (|yaw| < 105414350; a bound on
+  // |yaw0| + P |omega| dt decides), and only when the restatement agreed with the installed libm when the
+  // library was loaded.  Otherwise -- the FALLBACK -- the host fills the table with its libm (the worker pool of
+  // kc_set_host_threads shares the rows), in front of the launch: no kernel ever waits for the host.
   bool dev_trig = c->device_trig && trig_selfcheck_ok() && std::isfinite(yaw0);
   if (dev_trig) {
     double om_max = 0.0;
@@ -3770,65 +3605,13 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
                   std::memcmp(&yaw0, &c->trig_ahead_yaw, sizeof(double)) == 0;
   }
   if (!table_ahead) c->trig_ahead_valid = false;  // (d_trig is about to be rewritten, or belongs to another pose)
-  if (dev_trig) trig_ready = true;  // (nothing for the host to produce)
-  const bool trig_ahead = !trig_ready && c->trig_direct && c->early_launch && !c->timing.enabled;
-  struct PoolJoin {  // an error return below must not leave this call's job running
-    WorkerPool::Ticket ticket;
-    ~PoolJoin() { WorkerPool::instance().wait(ticket); }
-  } pool_join;
-  c->hprof.mark(8);
-  // Stages: up to 8, at least 16 rows each.  Values of the sequence word: base + stages done (base = 16 seq).
-  // Only where the roll-out runs in several rounds of workgroups (more than one workgroup of 32 samples per
-  // CU: the three-kernel cycle of a large lattice, whose workgroups take their samples in row order), and only
-  // as many stages as leave every worker a run of `trig_stage_min` rows per stage: short runs fragment the
-  // write-combined stores over the BAR (cfg2 with 8 stages of 1-2 rows per worker: +14 us per cycle).
-  const long long trig_base = (c->trig_seq + 1) * 16;
-  size_t n_stages = 1;
-  // ... and only for tables the workers need longer for than a round of workgroups takes (cfg3: 25 700 sincos,
-  // 21 us on 11 workers -- 157.9 -> 141.3 us per cycle; cfg5: 9 650, 9 us -- 154 -> 158 us with two stages)
-  if (c->trig_staged && c->test_late_flag_ms <= 0 && blocks_for(n, 32) > static_cast<unsigned>(c->num_cus) &&
-      A * P >= c->trig_stage_table_min) {
-    const size_t per = static_cast<size_t>(c->trig_stage_min) * static_cast<size_t>(std::max(1, WorkerPool::instance().workers()));
-    n_stages = std::min<size_t>(8, std::max<size_t>(1, A / std::max<size_t>(per, 1)));
+  if (!dev_trig && !trig_ready) {
+    WorkerPool::instance().parallel_for(A, 2, trig_rows);
+    c->timing.mark("host:trig_table");
+    if (!c->trig_direct)
+      KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2), hipMemcpyHostToDevice, s));
   }
-  const size_t stage_rows = (A + n_stages - 1) / n_stages;
-  n_stages = (A + stage_rows - 1) / stage_rows;
-  const bool staged = trig_ahead && n_stages > 1;
-  if (trig_ahead && !staged) {
-    ++c->trig_seq;
-    pool_join.ticket = WorkerPool::instance().begin(A, 2, trig_rows);
-  } else if (trig_ahead) {
-    ++c->trig_seq;  // (whatever launch follows: a word of this table must never pass for the next one's)
-    for (auto &d : c->trig_stage_rows_done) d.store(0, std::memory_order_relaxed);
-    c->trig_flag_shadow.store(trig_base, std::memory_order_relaxed);
-    volatile long long *flag = reinterpret_cast<volatile long long *>(c->d_result.p + R_TRIGSEQ);
-    kc_dwa *cc = c;
-    auto trig_staged_rows = [=](size_t q, size_t parts) {
-      for (size_t st = 0; st < n_stages; ++st) {
-        const size_t lo = st * stage_rows, len = std::min(stage_rows, A - lo);
-        const size_t h = (q + st) % parts;  // the shares rotate: nobody gets the long one of every stage
-        const size_t b0 = lo + len * h / parts, b1 = lo + len * (h + 1) / parts;
-        if (b0 < b1) trig_rows(b0, b1);  // (ends with sfence)
-        const int done = cc->trig_stage_rows_done[st].fetch_add(static_cast<int>(b1 - b0), std::memory_order_acq_rel) +
-                         static_cast<int>(b1 - b0);
-        if (staged && b0 < b1 && done == static_cast<int>(len)) {
-          // every row of stages 0 .. st is out of the cores (a worker finishes stage st - 1 first and its
-          // sfence precedes its fetch_add): publish, unless a later stage already has
-          const long long v = trig_base + static_cast<long long>(st) + 1;
-          long long cur = cc->trig_flag_shadow.load(std::memory_order_relaxed);
-          while (cur < v && !cc->trig_flag_shadow.compare_exchange_weak(cur, v, std::memory_order_acq_rel)) {
-          }
-          if (cur < v) {
-            *flag = v;
-#if defined(__x86_64__)
-            __builtin_ia32_sfence();
-#endif
-          }
-        }
-      }
-    };
-    pool_join.ticket = WorkerPool::instance().begin_parts(A, 2, trig_staged_rows);
-  }
+  trig_ready = true;
   c->hprof.mark(9);
   RollArgs a{};
   KC_TRY(ensure_cycle_buffers(c, n, P));
@@ -3927,70 +3710,29 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   size_t bits_bytes =
       (a.c.enabled ? static_cast<size_t>(a.c.H) * a.c.wpr * 4 * (a.c.dil ? 3 : 1) : 0) +
       static_cast<size_t>(fs) * P * sizeof(int);  // + queue of undecided poses
-  if (a.c.enabled && a.c.dil == 2) {
-    // The first cycle on new sensor data dilates its own window from the raw
-    // bits + halo (a controller that gets new data every cycle never runs
-    // dilate_kernel at all); a second cycle on the same data builds the masks
-    // once, and so does a window that does not fit with its halo.
-    const size_t halo = static_cast<size_t>(a.c.H + 2 * c->dil_R) * (a.c.wpr + 2) * 4;
-    // (a single-launch cycle whose cost tables fit only without the halo keeps the
-    // tables: one dilate_kernel costs less than two more launches)
-    const size_t cyc_tab = cycle ? cycle_table_bytes(tail.c) + 2048 : 0;
-    const bool cyc_fits = cycle && pos_bytes + bits_bytes + cyc_tab + 512 <= c->lds_limit;
-    if (c->dil_uses++ == 0 && c->prm.shape != KC_SPHERE &&
-        pos_bytes + bits_bytes + halo + (cyc_fits ? cyc_tab : 0) + 512 <= c->lds_limit) {
-      bits_bytes += halo;
-      a.diltab = c->d_diltab.p;
-      a.dilR = c->dil_R;
-    } else {
-      KC_TRY(launch_dilate(c));
-      a.c.dil = 1;
-    }
-  } else if (c->dil_lazy && !a.c.enabled) {
-    // nothing within reach this cycle: the masks are still owed to the next one
-  }
   const bool fused = sphere_ok && !c->tilted && (!a.c.enabled || c->have_gbits) &&
                      pos_bytes + bits_bytes + 512 <= c->lds_limit;
   const size_t tab_off = (pos_bytes + bits_bytes + 15) & ~size_t(15);
   cycle = cycle && fused && tab_off + cycle_table_bytes(tail.c) + 2048 <= c->lds_limit;
   if (want_cycle && !cycle && fused && (fs != c->fused_samples || fb != plain_fb))
   {
-    // sized for the cycle shape: start over for the plain one (the table this call's workers are
-    // writing stays valid: same pose, same rows)
-    const bool had = trig_ahead || trig_ready;
-    if (trig_ahead) WorkerPool::instance().wait(pool_join.ticket);
-    return rollout_impl(c, start, P, false, had);
+    // sized for the cycle shape: start over for the plain one (a host-built table stays valid: same pose, same rows)
+    return rollout_impl(c, start, P, false, true);
   }
   c->need_compact = !fused || cycle;
-  // early launch: queue the fused kernel first and let launch + dispatch
-  // latency run under the host's libm work (needs the BAR path for the table
-  // and its sequence word; not while kernels are being timed, the wait would
-  // be charged to the kernel)
-  const bool early = fused && trig_ahead;
-  if (early) {
-    // the workers produce the table while this thread queues the kernel
-  } else {
-    if (trig_ahead) WorkerPool::instance().wait(pool_join.ticket);  // (split path: the table first)
-    else if (!trig_ready) WorkerPool::instance().parallel_for(A, 2, trig_rows);
-    c->timing.mark("host:trig_table");
-    if (dev_trig) {
-      if (!fused && !table_ahead) {  // the split path's kernels read a table: filled on the device, in stream order
-        KC_TRY(c->timing.start("trig_table_kernel", s));
-        TrigJob tj{};
-        tj.yaw0 = yaw0;
-        tj.dt = dt;
-        tj.omega = c->d_omega.p;
-        tj.tab = c->d_sincostab.p;
-        tj.out = c->d_trig.p;
-        tj.A = static_cast<int>(A);
-        tj.P = static_cast<int>(P);
-        tj.nblk = static_cast<int>(std::min<size_t>(1024, blocks_for(A * P, kTrigBlock)));
-        hipLaunchKernelGGL(trig_table_kernel, dim3(tj.nblk), dim3(kTrigBlock), 0, s, tj);
-        KC_TRY(c->timing.stop(s));
-      }
-    } else if (!c->trig_direct)
-      KC_HIP(hipMemcpyAsync(c->d_trig.p, c->h_trig.p, A * P * sizeof(double2),
-                            hipMemcpyHostToDevice, s));
+  if (dev_trig && !fused && !table_ahead) {  // the split path's kernels read a table: filled on the device, in stream order
+    KC_TRY(c->timing.start("trig_table_kernel", s));
+    TrigJob tj{};
+    tj.yaw0 = yaw0;
+    tj.dt = dt;
+    tj.omega = c->d_omega.p;
+    tj.tab = c->d_sincostab.p;
+    tj.out = c->d_trig.p;
+    tj.A = static_cast<int>(A);
+    tj.P = static_cast<int>(P);
+    tj.nblk = static_cast<int>(std::min<size_t>(1024, blocks_for(A * P, kTrigBlock)));
+    hipLaunchKernelGGL(trig_table_kernel, dim3(tj.nblk), dim3(kTrigBlock), 0, s, tj);
+    KC_TRY(c->timing.stop(s));
   }
   if (fused) {
     if (!c->perm_valid || c->perm_first != c->shard_first || c->perm_count != c->shard_count ||
@@ -4007,7 +3749,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     }
 #endif
     if (c->list_dirty)  // previous roll-out was never evaluated: re-arm the list (and the error word a
-                        // roll-out that gave up waiting may have left)
+                        // failed cycle may have left)
       KC_HIP(hipMemsetAsync(c->d_result.p + W_NADM, 0, 3 * sizeof(long long), s));
     c->list_dirty = !cycle;
     a.c.lds = 1;
@@ -4047,13 +3789,6 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       c->xchg_packed = tail.xs != nullptr;
       a.dev_err = c->d_result.p + W_NADM;
     }
-    if (early) {
-      a.trig_flag = c->d_result.p + R_TRIGSEQ;
-      a.trig_seq = trig_base;
-      a.trig_stage_rows = static_cast<int>(stage_rows);
-      a.trig_stages = static_cast<int>(n_stages);
-      a.dev_err = c->d_result.p + W_NADM;
-    }
     c->hprof.mark(1);
     KC_TRY(c->timing.start(cycle ? "cycle_kernel" : "rollout_collide_kernel", s));
     const dim3 grid(blocks_for(n, fs)), block(fb);
@@ -4082,21 +3817,6 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     }
     c->timing.mark("host:launch_rollout");
     c->hprof.mark(2);
-    if (early) {
-      WorkerPool::instance().wait(pool_join.ticket);
-      c->hprof.mark(3);
-      if (c->test_late_flag_ms > 0) {  // test hook: a host that does not deliver in time
-        std::this_thread::sleep_for(std::chrono::milliseconds(c->test_late_flag_ms));
-        c->test_late_flag_ms = 0;      // once
-      }
-      // the table is out of the cores (sfence in every worker); now the word
-      // the workgroups are waiting for
-      *reinterpret_cast<volatile long long *>(c->d_result.p + R_TRIGSEQ) = a.trig_seq + a.trig_stages;
-#if defined(__x86_64__)
-      __builtin_ia32_sfence();
-#endif
-      c->hprof.mark(4);
-    }
   } else {
     // split path (sphere, very long horizons, windows beyond LDS): roll-out
     // first, window bits built on the host while it runs, then the pose-
@@ -4574,7 +4294,7 @@ int fetch_xchg(kc_dwa *c, const ShardLayout &L, size_t rw, kc_result *out) {
       if (static_cast<long long>(sum) == w0) break;
     }
     if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-      // a peer may be late by its own bounded wait (50 ms) and more: wait for the stream, which ends behind
+      // a peer may be late: wait for the stream, which ends behind
       // the all-reduce and the hand-off kernel; a record that still does not add up then is an error
       if (synced) KC_FAIL(KC_ERR_HIP, "the reduced exchange record never arrived intact");
       KC_HIP(hipStreamSynchronize(c->stream));
@@ -4595,8 +4315,7 @@ int fetch_xchg(kc_dwa *c, const ShardLayout &L, size_t rw, kc_result *out) {
   if (failed) {
     c->have_last = false;
     if (xv[X_ERR] == -1)
-      KC_FAIL(KC_ERR_HIP, "sharded cycle: a rank's roll-out kernel gave up waiting for the host's trig table "
-                          "(every rank fails this cycle)");
+      KC_FAIL(KC_ERR_HIP, "sharded cycle: a rank's device error word is set (every rank fails this cycle)");
     KC_FAIL(KC_ERR_HIP, "sharded cycle: a rank failed before the exchange (every rank fails this cycle)");
   }
   if (r.found) {

@@ -167,7 +167,6 @@ struct SensorFusedArgs {
   float gx0f, gy0f, inv_gf, id_eps;  // sensor_obstacle_fast (id_eps >= 0.5: always the double expression)
   float band_y0, band_dy;            // band b can only hold points with y in band_y0 + b band_dy + [-band_pad, band_dy + band_pad)
   float band_pad;
-  int roles;             // (measurement hook)
   unsigned long long *dbg;  // KC_PHASE_STAMPS builds: [workgroup][16] s_memrealtime stamps, or null
   int R;                 // dilation radius in rows; < 0: no masks (spheres without a gap bound, huge robots)
   uint32_t *ginner, *gouter;
@@ -344,12 +343,10 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
 #pragma unroll
   for (int k = 0; k < 4 * kSensorGroups; ++k) rec[k] = -1;
   __shared__ int wave_tot[kSensorBlock / 64];
-  __shared__ int s_nonempty;
   KC_FSTAMP(0);
   // ---- 1: counts of ALL points ----------------------------------------------------------------------
   sensor_for_points(a, [&] {
     for (int i = tid; i <= ncell; i += kSensorBlock) lstart[i] = 0;
-    if (tid == 0) s_nonempty = 0;
     __syncthreads();
     KC_FSTAMP(1);
   }, [&](int slot, int i, float x, float y, float z) {
@@ -372,10 +369,7 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
   for (int y = wave; y < a.H; y += kSensorBlock / 64) {
     const bool ne = lane < a.W && lstart[y * a.W + lane + 1] > 0;
     const unsigned long long m = __ballot(ne);
-    if (lane == 0) {
-      lmask[y] = m;
-      if (me == 0) atomicAdd(&s_nonempty, __popcll(m));
-    }
+    if (lane == 0) lmask[y] = m;
   }
   {
     const int N = ncell + 1;
@@ -408,7 +402,7 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
   __syncthreads();
   KC_FSTAMP(3);
   // ---- 3: my slice of what the cost kernels read: cell starts, skip table (Chebyshev distance to the nearest
-  // non-empty cell, from one 64-bit mask per grid row), dc_enable -- 64 cells per wavefront, the wavefronts of
+  // non-empty cell, from one 64-bit mask per grid row) -- 64 cells per wavefront, the wavefronts of
   // the bucket workgroups interleaved
   const int c0 = static_cast<int>(static_cast<long long>(ncell) * me / s.kb);
   const int c1 = static_cast<int>(static_cast<long long>(ncell) * (me + 1) / s.kb);
@@ -417,7 +411,6 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
     __syncthreads();
   }
   KC_FSTAMP(4);
-  if (me == 0 && tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
   if (me == 0 && tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
   for (int k = (wave * s.kb + me) * 64 + lane; k <= ncell; k += s.kb * kSensorBlock) {
     a.cell_start[k] = lstart[k];
@@ -470,10 +463,10 @@ template <bool kLds>
 __global__ __launch_bounds__(kSensorBlock) void sensor_fused_kernel(SensorFusedArgs s) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = static_cast<int>(blockIdx.x);
-  if (b < s.nb) { if (s.roles & 1) sensor_band_body(s, b, smem); }
-  else if (b < s.nb + s.kb) { if (s.roles & 2) sensor_bucket_body(s, b - s.nb, smem); }
-  else if (b < s.nb + s.kb + s.o_blocks) { if (s.roles & 4) obs_near_body<kLds, kSensorBlock>(s.o, b - s.nb - s.kb, smem); }
-  else if (s.roles & 8) trig_job_block<kSensorBlock>(s.a.trig, b - s.nb - s.kb - s.o_blocks);
+  if (b < s.nb) sensor_band_body(s, b, smem);
+  else if (b < s.nb + s.kb) sensor_bucket_body(s, b - s.nb, smem);
+  else if (b < s.nb + s.kb + s.o_blocks) obs_near_body<kLds, kSensorBlock>(s.o, b - s.nb - s.kb, smem);
+  else trig_job_block<kSensorBlock>(s.a.trig, b - s.nb - s.kb - s.o_blocks);
 }
 
 }  // namespace kc

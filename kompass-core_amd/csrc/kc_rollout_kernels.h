@@ -260,7 +260,6 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   uint32_t *linner = lbits + nwin;                 // a.c.dil only
   uint32_t *louter = linner + (a.c.dil ? nwin : 0);
   int *lcand = reinterpret_cast<int *>(louter + (a.c.dil ? nwin : 0));  // [samples * P]
-  uint32_t *lhalo = reinterpret_cast<uint32_t *>(lcand + kFusedSamples * a.P);  // a.c.dil == 2 only
   __shared__ int ncand, ncand2;
   __shared__ int lhit[kFusedSamples];
   __shared__ int lperm[kFusedSamples];  // local sample id of slot s
@@ -274,7 +273,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
 
   KC_RSTAMP(0);
   // ---- A: window bits, cost tables, trig rows ------------------------------------------------
-  // Host trig table: one round of loads (window, cost tables), the sample ids used behind the copies.
+  // A table that is there already (formed in the sensor update's launch, or -- fallback -- by the host): one round
+  // of loads (window, cost tables), the sample ids used behind the copies.
   // Device trig: the SMALL loads first (sample ids, the table sincos reads, omega values), a barrier, then the
   // bulk loads are issued and the trig entries are formed from LDS while they are in flight.
   int my_id = 0, my_row = 0;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   // the bulk loads: cost tables (cycle) and the first round of the window words, into registers
   CycleTabRegs<kFusedBlock> tabregs;
   if constexpr (kCycle) cycle_tables_load<kFusedBlock>(tail, tid, kFusedBlock, tabregs);
-  const bool win = a.c.enabled && a.c.dil != 2;
+  const bool win = a.c.enabled != 0;
   const int nwords = a.c.enabled ? a.c.H * a.c.wpr : 0;
   const int w0 = a.c.enabled ? (a.c.kx0 - a.c.gkx0) >> 5 : 0;  // exact: difference is a multiple of 32
   // window origin is word aligned with the sensor bitmap: whole-word copies (up to three
@@ -454,43 +454,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       if (box) a.trig_out[(size_t)k * a.A + r] = make_double2(cs, sn);
     }
   }
-  if (a.c.enabled && a.c.dil == 2) {
-    // The dilated masks of this sensor update do not exist yet: the raw bits of
-    // the window plus a halo of R rows and one word either way go to LDS, and
-    // the window words are dilated from there exactly as dilate_kernel does
-    // (rows outside the bitmap are skipped, words outside it are empty).
-    const int R = a.dilR;
-    const int hw = a.c.wpr + 2, hh = a.c.H + 2 * R;
-    for (int i = tid; i < hw * hh; i += kFusedBlock) {
-      const int hy = i / hw, hx = i - hy * hw;
-      const int gy = a.c.ky0 + hy - R - a.c.gky0, gw = w0 + hx - 1;
-      uint32_t v = 0u;
-      if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) v = a.c.gbits[(size_t)gy * a.c.gwpr + gw];
-      lhalo[i] = v;
-    }
-    __syncthreads();
-    const signed char *dwin = a.diltab, *dwout = a.diltab + kMaxDil + 1;
-    for (int i = tid; i < nwords; i += kFusedBlock) {
-      const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
-      uint32_t in_acc = 0u, out_acc = 0u;
-      for (int j = -R; j <= R; ++j) {
-        const int gy = a.c.ky0 + cy + j - a.c.gky0;
-        if (gy < 0 || gy >= a.c.gH) continue;
-        const uint32_t *row = lhalo + (cy + j + R) * hw + w;  // [w] = left, [w + 1] = mid, [w + 2] = right
-        const uint32_t left = row[0], mid = row[1], right = row[2];
-        if ((mid | left | right) == 0u) continue;
-        const int aj = j < 0 ? -j : j;
-        if (dwin[aj] >= 0) in_acc |= hdilate(left, mid, right, dwin[aj]);
-        if (dwout[aj] >= 0) out_acc |= hdilate(left, mid, right, dwout[aj]);
-      }
-      // (words of the window outside the bitmap stay empty, as in the copy below)
-      const int gy0 = a.c.ky0 + cy - a.c.gky0, gw0 = w0 + w;
-      const bool inside = gy0 >= 0 && gy0 < a.c.gH && gw0 >= 0 && gw0 < a.c.gwpr;
-      lbits[i] = lhalo[(cy + R) * hw + w + 1];
-      linner[i] = inside ? in_acc : 0u;
-      louter[i] = inside ? out_acc : 0u;
-    }
-  } else if (win) {
+  if (win) {
     win_store(0, wv, wvi, wvo);
     for (int i0 = 3 * kFusedBlock; i0 < nwords; i0 += 3 * kFusedBlock) {
       win_load(i0, wv, wvi, wvo);
@@ -525,68 +489,6 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
         const double ty = vx * cs.y + vy * cs.x;
         lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
       }
-  } else if (a.trig_flag) {
-    // wait for the host's table (system-scope loads: the word and the table
-    // arrive over PCIe, behind this GPU's caches).  Bounded: ~50 ms.
-    __shared__ int s_late;
-    __syncthreads();  // lrow
-    if (tid == 0) {
-      int late = 0;
-      // the stage of this workgroup's highest trig row (the three-kernel roll-out takes its samples in row
-      // order: a workgroup of the first round needs the first stages only)
-      int top = 0;
-      for (int k = 0; k < rows; ++k) top = max(top, lrow[k]);
-      const long long want = a.trig_seq + min(top / a.trig_stage_rows, a.trig_stages - 1) + 1;
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(a.trig_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 5000000ull) {
-          late = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-      }
-      s_late = late;
-    }
-    __syncthreads();
-    KC_RSTAMP(2);
-    if (s_late) {  // give the cycle up: nothing admissible, error word set
-      if (tid < rows) a.flags[lperm[tid]] = 0;
-      if constexpr (kCycle) {
-        if (tail.host_slots) {
-          // the slot's own late bit carries the error: the device error word stays untouched (nothing on
-          // this path would re-arm it, and a later ticket / three-kernel cycle would inherit it)
-          cycle_epilogue_host<kFusedBlock>(a, tail, KEY_NONE, 0ull, -1, lpos, 1, tid);
-        } else {
-          // the ticket is still taken: the last workgroup publishes the error and re-arms the word
-          if (tid == 0)
-            atomicOr(reinterpret_cast<unsigned long long *>(a.dev_err), 1ull);
-          cycle_epilogue<kFusedBlock>(a, tail, KEY_NONE, 0, -1, lpos, lperm, lperm, tid);
-        }
-      } else {
-        if (tid == 0) *a.dev_err = 1;
-      }
-      return;
-    }
-    // trig entries of this thread's (sample, step) pairs and the sample's velocity (read through
-    // the dealt view: velocities change every cycle, the order does not) -> increments
-    //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt   (datatypes/path.h:24-30)
-    // straight into LDS; only the additions -- whose order fixes the rounding -- run as a serial
-    // chain per sample below.
-    const int s = tid & (kFusedSamples - 1);
-    if (s < rows) {
-      const int r = lrow[s];
-      const uint32_t vi = lvi[s];
-      const double vx = a.vxt[vi & 0xFFFFu], vy = a.vyt[vi >> 16];
-      const double *tg = reinterpret_cast<const double *>(a.trig);
-      for (int k = tid / kFusedSamples; k < steps; k += kFusedBlock / kFusedSamples) {
-        const size_t e = ((size_t)k * a.A + r) * 2;
-        const double cs = __hip_atomic_load(tg + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const double sn = __hip_atomic_load(tg + e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const double tx = vx * cs - vy * sn;
-        const double ty = vx * sn + vy * cs;
-        lpos[s * PP + k] = make_double2(tx * a.dt, ty * a.dt);
-      }
-    }
   } else {
     __syncthreads();  // lrow, lperm
     const int s = tid & (kFusedSamples - 1);
@@ -747,11 +649,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       if (a.c.shape == KC_BOX) {
         const size_t e = (size_t)k * a.A + lrow[s];  // yaw_k
         double2 t;
-        if (a.trig_flag) {
-          const double *tg = reinterpret_cast<const double *>(a.trig);
-          t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          t.y = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if (a.trig_dev) {
+        if (a.trig_dev) {
           // written by lanes of this workgroup in the trig phase (barriers in between); read at L2
           const double *tg = reinterpret_cast<const double *>(a.trig);
           t.x = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -848,7 +746,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     KC_RSTAMP(8);
     if (tail.host_slots)
       cycle_epilogue_host<kFusedBlock>(a, tail, key, lmask, best_slot,
-                                       lpos + (best_slot < 0 ? 0 : best_slot) * PP, 0, tid);
+                                       lpos + (best_slot < 0 ? 0 : best_slot) * PP, tid);
     else
       cycle_epilogue<kFusedBlock>(a, tail, key, nsurv, best_slot, lpos + (best_slot < 0 ? 0 : best_slot) * PP,
                                   lperm, lsurv, tid);

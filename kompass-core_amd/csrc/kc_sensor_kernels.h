@@ -26,9 +26,6 @@ struct SensorArgs {
   uint8_t *skip;             // [W*H] (+ padding written by the host)
   float *bx, *by;            // cell-ordered coordinates
   int obs_z_zero;            // laserscan: the obstacle of a point is taken at z = 0
-  int *dc_enable;            // out: 1 when fewer than a third of the bucket cells hold a point (the
-                             // centre-distance table pays only where trajectory points have empty
-                             // neighbourhoods), else 0: cell_dist_kernel and the cost kernels skip it
 };
 
 constexpr int kSensorBlock = 1024;
@@ -156,7 +153,6 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
   __shared__ __align__(16) int lbase[kHistRow];       // points of the cell in the workgroups before this one
   __shared__ unsigned long long lmask[64];
   __shared__ int wave_tot[kSensorBlock / 64];
-  __shared__ int s_nonempty;
   const int tid = threadIdx.x;
   const int me = blockIdx.x;
   // ---- byte map -> bitmap, bytes cleared behind: the workgroups beyond the rows do only this -------------
@@ -219,7 +215,6 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
     }
     if (tid == 0) {
       lstart[0] = 0;
-      s_nonempty = 0;
     }
     lstart[4 * tid + 1] = acc.x;
     lstart[4 * tid + 2] = acc.y;
@@ -271,12 +266,10 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
       const unsigned long long m = __ballot(ne);
       if (lane == 0) {
         lmask[y] = m;
-        if (me == 0) atomicAdd(&s_nonempty, __popcll(m));
       }
     }
     __syncthreads();
     KC_SSTAMP(me, 7);
-    if (me == 0 && tid == 0) *a.dc_enable = (3 * s_nonempty < ncell) ? 1 : 0;
     if (me == 0 && tid < 4) a.skip[ncell + tid] = 255;  // word padding the cost kernels copy
     const int nb = b.rows;
     for (int k = (wave * nb + me) * 64 + lane; k <= ncell; k += nb * kSensorBlock) {
@@ -320,90 +313,6 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
     a.by[pos] = b.toy[i];
   }
   KC_SSTAMP(me, 9);
-}
-
-// ---- distance table for the far-obstacle searches of the cost kernels ---------------
-// A uniform grid of its own over the obstacles' bounding box: for every cell the
-// distance from the cell CENTRE to the nearest obstacle.  A point p of that cell
-// is within half a cell diagonal h of the centre, so its distance to the
-// obstacle set lies in [dc - h, dc + h] (1-Lipschitz): the cost kernels bracket
-// every far trajectory point with one table read and evaluate exactly only the
-// few points that can hold the trajectory minimum.  Exact where it is below
-// cap + gd (ring search over the obstacle buckets, rows over the lanes, from
-// the first ring that can hold a point), +inf beyond: such points cost nothing.
-// One wavefront per cell.
-struct CellDistArgs {
-  double gx0, gy0, gd;     // table origin (= bucket origin) and cell edge
-  int Wd, Hd;
-  float *dc;               // [Wd*Hd]
-  double g, inv_g, cap;    // obstacle buckets
-  int W, H;
-  const int *cell_start;
-  const uint8_t *skip;
-  const float *bx, *by;
-  const int *enable;       // written by sensor_build_kernel
-};
-
-__global__ __launch_bounds__(256) void cell_dist_kernel(CellDistArgs a) {
-  if (*a.enable == 0) return;  // dense obstacle field: the table would not be used
-  const int lane = threadIdx.x & 63;
-  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (k >= a.Wd * a.Hd) return;
-  const int cyd = k / a.Wd, cxd = k - cyd * a.Wd;
-  const double qx = a.gx0 + (static_cast<double>(cxd) + 0.5) * a.gd;
-  const double qy = a.gy0 + (static_cast<double>(cyd) + 0.5) * a.gd;
-  // bucket cell of the centre (the table may overhang the bucket grid by a cell)
-  const double fx = (qx - a.gx0) * a.inv_g, fy = (qy - a.gy0) * a.inv_g;
-  double off = 0.0;
-  if (fx > a.W) off = fmax(off, fx - a.W);
-  if (fy > a.H) off = fmax(off, fy - a.H);
-  const int cx = min(max(static_cast<int>(floor(fx)), 0), a.W - 1);
-  const int cy = min(max(static_cast<int>(floor(fy)), 0), a.H - 1);
-  const int sk = static_cast<int>(a.skip[cy * a.W + cx]);
-  const double limit = a.cap + a.gd;
-  const int mmax = max(a.W, a.H);
-  float out = __builtin_inff();
-  if (sk < 255 && (static_cast<double>(sk - 1) - off) * a.g < limit) {
-    int pm = sk - 1, m = max(1, sk);
-    double found = DBL_MAX;
-    bool exact = false;
-    for (;;) {
-      const int y0 = max(cy - m, 0), y1 = min(cy + m, a.H - 1);
-      const int x0 = max(cx - m, 0), x1 = min(cx + m, a.W - 1);
-      double part = DBL_MAX;
-      for (int row = y0 + lane; row <= y1; row += 64) {
-        const bool inner = pm >= 0 && row >= cy - pm && row <= cy + pm;
-        int beg = a.cell_start[row * a.W + x0];
-        int end = inner ? a.cell_start[row * a.W + max(cx - pm, x0)] : a.cell_start[row * a.W + x1 + 1];
-        for (int pass = 0; pass < 2; ++pass) {
-          for (int j = beg; j < end; ++j) {
-            const double dx = static_cast<double>(a.bx[j]) - qx;
-            const double dy = static_cast<double>(a.by[j]) - qy;
-            const double dd = dx * dx + dy * dy;
-            part = dd < part ? dd : part;
-          }
-          if (!inner) break;
-          beg = a.cell_start[row * a.W + min(cx + pm, x1) + 1];
-          end = a.cell_start[row * a.W + x1 + 1];
-        }
-      }
-      const double stage = wave_min_nonneg(part);
-      found = stage < found ? stage : found;
-      // every obstacle closer than (m - off) g to the centre was visited
-      const double reach = (static_cast<double>(m) - off) * a.g;
-      if ((reach > 0.0 && found < reach * reach) || m >= mmax) {
-        exact = found < DBL_MAX;
-        break;
-      }
-      if (reach >= limit) break;
-      const double need = found < DBL_MAX ? sqrt(found) : limit;
-      const double mm = ceil(fmin(need, limit) * a.inv_g + off) + 1.0;
-      pm = m;
-      m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-    }
-    if (exact) out = static_cast<float>(sqrt(found));
-  }
-  if (lane == 0) a.dc[k] = out;
 }
 
 // ---- occupancy grid -> point list on the device ------------

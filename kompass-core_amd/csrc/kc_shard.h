@@ -6,9 +6,8 @@
 //   X[0]                      packed key of the rank's best sample, GLOBAL raw index
 //                             (KEY_NONE: nothing admissible) -- the minimum over the ranks is
 //                             LowestCost::combine (datatypes/trajectory.h:630-636)
-//   X[1]                      0; -1 when this rank's roll-out gave up waiting for the host's
-//                             trig table (a cycle the caller may repeat -- on every rank);
-//                             -2 when the rank failed before the exchange.  The minimum makes
+//   X[1]                      0; -1 when this rank's device error word is set; -2 when the rank
+//                             failed before the exchange.  The minimum makes
 //                             the failure collective: every rank fails the SAME cycle and none
 //                             is a collective out of step
 //   X[2 + r*rw ... + rw)      rank r's admissible bitmap by shard-local sample id (bit i of

@@ -84,9 +84,9 @@ def test_many_cycles_moving_pose_both_paths_agree():
 
 
 @pytest.mark.parametrize("opts", [dict(fused_cycle=2), dict(fused_cycle=2, cycle_samples=16), dict(fused_cycle=2, cycle_samples=32),
-                                  dict(fused_cycle=2, cycle_samples=16, host_reduce=0), dict(near_table=0, fused_cycle=2), dict(host_reduce=0), dict(cost_kernel=1), dict(cost_kernel=2), dict(force_split=1), dict(device_trig=0), dict(device_trig=0, trig_copy=1),
-                                  dict(device_trig=0, early_launch=0), dict(device_trig=0, force_split=1), dict(device_trig=0, fused_cycle=2, cycle_samples=16), dict(sensor_on_host=1), dict(lazy_dilate=0), dict(sensor_two_launch=1), dict(sensor_two_launch=1, lazy_dilate=0),
-                                  dict(cost_dc_cells=64), dict(fused_cycle=0, cost_kernel=2, cost_dc_cells=128)],
+                                  dict(fused_cycle=2, cycle_samples=16, host_reduce=0), dict(near_table=0, fused_cycle=2), dict(host_reduce=0), dict(cost_kernel=1), dict(cost_kernel=2), dict(force_split=1), dict(device_trig=0),
+                                  dict(device_trig=0, force_split=1), dict(device_trig=0, fused_cycle=2, cycle_samples=16), dict(sensor_on_host=1), dict(sensor_two_launch=1),
+                                  dict(fused_cycle=0, cost_kernel=2)],
                          ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()))
 def test_options_per_context_give_identical_results(opts):
     """Every switch of kc_dwa_set_option, set on ONE context of a process that
@@ -161,8 +161,8 @@ def test_two_threads_with_differently_configured_contexts():
 
     inps = [_path_scenario(*_PATH_SCENARIOS[1]), _path_scenario(*_PATH_SCENARIOS[5])]
     want = [oracle_cycle(i) for i in inps]
-    configs = [(dict(fused_cycle=2), dict(force_split=1)), (dict(fused_cycle=2, host_reduce=0), dict(device_trig=0, trig_copy=1)),
-               (dict(), dict(fused_cycle=0, device_trig=0, early_launch=0)), (dict(device_trig=0), dict())]
+    configs = [(dict(fused_cycle=2), dict(force_split=1)), (dict(fused_cycle=2, host_reduce=0), dict(device_trig=0)),
+               (dict(), dict(fused_cycle=0, device_trig=0)), (dict(device_trig=0), dict())]
     for opts_a, opts_b in configs:
         ctxs = [_prepared(inps[0], **opts_a), _prepared(inps[1], **opts_b)]
         ctxs[1].timing_enable(True)

@@ -1,7 +1,7 @@
 """CPU: the process-wide host worker pool (csrc/kc_pool.h) hammered from several caller
 threads while a third resizes it -- what two controller contexts on two threads and
-kc_set_host_threads do (wait() must only ever join / release the caller's own
-job).  Plain build, and under ThreadSanitizer when the toolchain has it."""
+kc_set_host_threads do in the host-trig fallback.  Plain build, and under ThreadSanitizer when the
+toolchain has it."""
 import shutil
 import subprocess
 from pathlib import Path
@@ -24,7 +24,7 @@ def _build(tmp_path, name, flags):
 def test_pool_two_callers_and_a_resizer(tmp_path):
     exe, err = _build(tmp_path, "pool_stress", ["-O2"])
     assert exe is not None, err
-    p = subprocess.run([str(exe), "100000", "3"], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([str(exe), "20000", "3"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert " 0 bad" in p.stdout
 

@@ -1,18 +1,28 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/profile_round.sh TAG
-# bench (with cpu_baseline), rocprofv3 kernel stats of the same command, PMC HBM passes -> gpurun_out/TAG_*
+# usage (on the GPU box, from the repo root): tools/profile_round.sh TAG [quick]
+# The default bench line, then rocprofv3 evidence (tools/pmc_collect.py: kernel stats + separate counter
+# passes) for every workload the bench JSON prices: cfg2 on the three scenes, the fresh-input reference cycle
+# (sensor build pair + window + segment + cycle), cfg4 mapper, cfg3 / cfg5 mid (three-kernel cycle:
+# sample_cost_kernel), the reference's cost workload (velocity_sums_kernel); phase clocks of the cycle kernel.
 set -e
-TAG=${1:-r01_b}
-export TMPDIR=/tmp
-O=gpurun_out
-python bench.py > $O/${TAG}_cfg2_bench.json 2> $O/${TAG}_cfg2_bench.err
-tail -c 600 $O/${TAG}_cfg2_bench.json; echo
-python bench.py --mapper --no-cpu > $O/${TAG}_cfg4_mapper_bench.json 2> $O/${TAG}_cfg4_mapper_bench.err || true
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o ${TAG} -- python3 bench.py --no-cpu > $O/${TAG}_stats.log 2>&1
-find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_cfg2_kernel_stats.csv
-head -8 $O/${TAG}_cfg2_kernel_stats.csv
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/${TAG}_pmc_$ctr -o ${TAG}_$ctr -- python3 bench.py --steps 50 --warmup 5 --no-cpu > $O/${TAG}_pmc_$ctr.log 2>&1 || echo "pmc $ctr failed"
-  find $O/${TAG}_pmc_$ctr -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $O/${TAG}_cfg2_pmc_$ctr.csv || true
+TAG=${1:-r04_a}
+O=gpurun_out/$TAG
+mkdir -p $O
+python bench.py > $O/cfg2_bench.json 2> $O/cfg2_bench.err || { tail -5 $O/cfg2_bench.err; exit 1; }
+tail -c 400 $O/cfg2_bench.json; echo
+C="--only-headline --no-cpu --steps 200 --warmup 20"
+for scene in survey mid open; do
+  python3 tools/pmc_collect.py $O cfg2_$scene -- $C --scene $scene
 done
-ls -la $O | grep ${TAG}
+python3 tools/pmc_collect.py $O cfg2_fresh -- --fresh --no-cpu --steps 200 --warmup 20
+python3 tools/pmc_collect.py $O cfg2_scan -- --scan --no-cpu --steps 200 --warmup 20
+if [ "$2" != "quick" ]; then
+  python3 tools/pmc_collect.py $O cfg4_mapper -- --mapper --no-cpu --steps 200 --warmup 20
+  python3 tools/pmc_collect.py $O cfg3_mid -- $C --config cfg3 --scene mid
+  python3 tools/pmc_collect.py $O cfg5_mid -- $C --config cfg5 --scene mid
+  python3 tools/pmc_collect.py $O cost5k -- --ref cost5k --no-cpu --steps 50 --warmup 5
+fi
+for scene in survey mid open; do
+  python3 tools/stamps_json.py cfg2 $scene $O/cfg2_${scene}_phase_stamps.json || true
+done
+ls $O
