@@ -277,6 +277,12 @@ int kc_dwa_set_scan(kc_dwa *ctx, const kc_state *state, const double *ranges,
                     const double *angles, size_t n, float max_sensor_range);
 int kc_dwa_set_points(kc_dwa *ctx, const kc_state *state, const float *xyz,
                       size_t n, float max_sensor_range);
+/* the same with the list in the SENSOR frame -- updateSensorData(cloud, global_frame = false),
+ * collision_check.h:119-131: the octree frame is body->tf * sensor_tf_body (as for a laser scan), the obstacle
+ * list of the cost term is the same (setPointScan(cloud), cost_evaluator.h:205-223).  Mounts that are not a
+ * rotation about z: KC_ERR_UNSUPPORTED for point lists (laser scans take any mount). */
+int kc_dwa_set_points_sensor_frame(kc_dwa *ctx, const kc_state *state, const float *xyz, size_t n,
+                                   float max_sensor_range);
 
 /* SURVEY 8f rank 4 -- occupancy grid -> obstacle set without the host round
  * trip (the reference goes grid -> host -> point list -> DWA, control/dwa.py:
@@ -465,11 +471,20 @@ int kc_dwa_allreduce_best(kc_dwa *ctx, kc_comm *comm);
  * n_admissible / n_samples over all ranks.  Collective: every rank of the
  * communicator calls it with the same start / num_points, after
  * kc_dwa_set_shard_rule(rank, world, ...) (a world of one may use kc_dwa_set_shard).
- * Errors are collective too: when any rank fails (its roll-out gave up waiting for
- * the host's trig table, or a call failed before the exchange) EVERY rank returns an
- * error for this cycle and all of them have taken part in exactly one all-reduce, so
- * the next cycle pairs up again. */
+ * Errors are collective too: when any rank fails (a call failed before the exchange,
+ * or its device error word is set) EVERY rank returns an error for this cycle and all
+ * of them have taken part in exactly one all-reduce, so the next cycle pairs up again. */
 int kc_dwa_cycle_sharded(kc_dwa *ctx, kc_comm *comm, const kc_state *start, size_t num_points,
+                         kc_result *out);
+/* The same exchange for a cycle whose LAST cost terms the host has added -- custom cost callbacks of a sharded
+ * DWA ("evaluated on host over gathered paths"; cost_evaluator.cpp:96-100: customTrajCostsPtrs_
+ * after the built-in terms, total += weight * cost in float-from-double).  Every rank runs kc_dwa_cycle on its
+ * share, reads its admissible rows (kc_dwa_get_samples: GLOBAL raw indices, device totals), adds the callbacks
+ * in registration order and hands its own best {found, cost, raw_index} in; the record that is all-reduced is
+ * kc_dwa_cycle_sharded's (this key, the error word, the admissible bitmap of the cycle just run), the result the
+ * same on every rank.  status != 0: this rank failed before -- it still takes part and every rank fails the
+ * cycle.  Collective. */
+int kc_dwa_exchange_best(kc_dwa *ctx, kc_comm *comm, int status, int found, float cost, int64_t raw_index,
                          kc_result *out);
 /* the winner's index in the reference's admissible-only numbering: admissible
  * samples in front of it on every shard, one ncclAllReduce(1 x int64, ncclSum).

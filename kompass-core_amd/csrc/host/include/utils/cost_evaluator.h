@@ -114,8 +114,8 @@ class CostEvaluator {
  private:
   void uploadSegment(const Path::Path *reference_path,
                      const Path::Path::View &tracked_segment);
-  TrajSearchResult finishWithCustomCosts(const Path::Path *reference_path,
-                                         size_t P);
+  // (raw_out: the GLOBAL raw index of the returned sample -- what a sharded cycle hands into its exchange)
+  TrajSearchResult finishWithCustomCosts(const Path::Path *reference_path, size_t P, int64_t *raw_out = nullptr);
   std::unique_ptr<TrajectoryCostsWeights> costWeights;
   hip::DwaHandle ctx_;
   unsigned long long residentSerial_ = 0;  // Path::serial() of the path resident on the device

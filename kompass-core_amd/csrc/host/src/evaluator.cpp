@@ -133,7 +133,7 @@ void CostEvaluator::uploadSegment(const Path::Path *ref, const Path::Path::View 
 // callbacks in registration order with the reference's float += double*float
 // rounding, and take the (first) minimum on the host -- the structure of the
 // reference's own GPU build (cost_evaluator_gpu.cpp:344-383)
-TrajSearchResult CostEvaluator::finishWithCustomCosts(const Path::Path *ref, size_t P) {
+TrajSearchResult CostEvaluator::finishWithCustomCosts(const Path::Path *ref, size_t P, int64_t *raw_out) {
   size_t rows = 0;
   hip::check(kc_dwa_get_samples(ctx_.get(), nullptr, nullptr, nullptr, nullptr, 0, &rows));
   TrajSearchResult out;
@@ -160,6 +160,7 @@ TrajSearchResult CostEvaluator::finishWithCustomCosts(const Path::Path *ref, siz
   if (!found) return out;
   out.isTrajFound = true;
   out.trajCost = best;
+  if (raw_out) *raw_out = raw[arg];
   out.trajectory = Trajectory2D(P);
   for (size_t i = 0; i < P; ++i) out.trajectory.path.add(i, px[arg * P + i], py[arg * P + i], 0.0f);
   double vx = 0.0, vy = 0.0, om = 0.0;
@@ -220,13 +221,32 @@ TrajSearchResult CostEvaluator::cycleOnDevice(const Path::Path *ref, const Path:
   // rule, kc_dwa_sample_window applied it)
   (void)n_generated;
   kc_result r;
-  const int rc = comm ? kc_dwa_cycle_sharded(ctx_.get(), comm, &st, P, &r) : kc_dwa_cycle(ctx_.get(), &st, P, &r);
+  TrajSearchResult mine_best;   // sharded + custom costs: this rank's own best, with its path
+  int64_t mine_raw = -1;
+  int rc;
+  if (comm && !customTrajCostsPtrs_.empty()) {
+    // SURVEY 8e row 2 / cost_evaluator.cpp:96-100: every rank scores its share on the device, adds the callbacks
+    // to the totals of its own admissible rows on the host (registration order, the reference's rounding) and
+    // hands its best into the same single exchange a plain sharded cycle runs.  Whatever fails here, the rank
+    // still takes part in the exchange (status != 0): the failure is every rank's, of the same cycle.
+    int status = kc_dwa_cycle(ctx_.get(), &st, P, &r);
+    std::string why = status != KC_OK ? kc_last_error() : "";
+    if (status == KC_OK) {
+      try {
+        mine_best = finishWithCustomCosts(ref, P, &mine_raw);
+      } catch (const std::exception &e) {
+        status = KC_ERR_STATE;
+        why = e.what();
+      }
+    }
+    rc = kc_dwa_exchange_best(ctx_.get(), comm, status, mine_best.isTrajFound ? 1 : 0, mine_best.trajCost, mine_raw, &r);
+    if (status != KC_OK) throw std::runtime_error("sharded cycle with custom costs: " + why);
+  } else {
+    rc = comm ? kc_dwa_cycle_sharded(ctx_.get(), comm, &st, P, &r) : kc_dwa_cycle(ctx_.get(), &st, P, &r);
+  }
   hip::check(rc);
   sensorDataResident = false;
-  if (!customTrajCostsPtrs_.empty()) {
-    if (comm) throw std::runtime_error("custom cost callbacks are host-side and serial: not with a sharded DWA");
-    return finishWithCustomCosts(ref, P);
-  }
+  if (!customTrajCostsPtrs_.empty() && !comm) return finishWithCustomCosts(ref, P);
   TrajSearchResult out;
   out.trajectory = Trajectory2D(P);
   if (!r.found) return out;
@@ -234,6 +254,7 @@ TrajSearchResult CostEvaluator::cycleOnDevice(const Path::Path *ref, const Path:
   out.trajCost = r.cost;
   int mine = 1;
   if (comm) hip::check(kc_dwa_owns_sample(ctx_.get(), r.raw_index, &mine));
+  if (mine && comm && !customTrajCostsPtrs_.empty() && mine_raw == r.raw_index) return mine_best;
   if (mine)
     hip::check(kc_dwa_get_best(ctx_.get(), out.trajectory.path.x.data(), out.trajectory.path.y.data(),
                                out.trajectory.velocities.vx.data(), out.trajectory.velocities.vy.data(),

@@ -87,21 +87,15 @@ void CollisionChecker::updateSensorData(const Control::LaserScan &scan, const bo
 }
 void CollisionChecker::updateSensorData(const std::vector<Path::Point> &cloud,
                                         const bool global_frame) {
-  if (!global_frame)
-    throw std::runtime_error(
-        "CollisionChecker: sensor-frame point lists are not supported by this "
-        "build (the controllers always pass global_frame = true)");
   // Path::Point is three packed floats: the list goes to the device as it lies
   static_assert(sizeof(Path::Point) == 3 * sizeof(float), "Path::Point must be packed (x, y, z)");
-  updateSensorData(Control::PointCloudView{cloud.empty() ? nullptr : cloud.data()->data(), cloud.size()}, true);
+  updateSensorData(Control::PointCloudView{cloud.empty() ? nullptr : cloud.data()->data(), cloud.size()}, global_frame);
 }
+// (collision_check.h:119-131: world-frame lists -- what the controllers pass -- or sensor-frame lists)
 void CollisionChecker::updateSensorData(const Control::PointCloudView &cloud, const bool global_frame) {
-  if (!global_frame)
-    throw std::runtime_error(
-        "CollisionChecker: sensor-frame point lists are not supported by this "
-        "build (the controllers always pass global_frame = true)");
   const kc_state st = toKc(state_);
-  hip::check(kc_dwa_set_points(ctx_.get(), &st, cloud.xyz, cloud.n, maxSensorRange));
+  hip::check(global_frame ? kc_dwa_set_points(ctx_.get(), &st, cloud.xyz, cloud.n, maxSensorRange)
+                          : kc_dwa_set_points_sensor_frame(ctx_.get(), &st, cloud.xyz, cloud.n, maxSensorRange));
 }
 void CollisionChecker::updateSensorData(const Mapping::LocalMapper &mapper, const bool) {
   const kc_state st = toKc(state_);

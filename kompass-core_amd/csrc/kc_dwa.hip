@@ -306,6 +306,12 @@ struct kc_dwa {
   // non-planar sensor mount with LaserScan input: the octree frame is tilted (kc_tilt_dev.h)
   bool tilted = false;
   int tilt_kz = 0;             // the scan's voxel layer in the octree frame
+  // A tilted scan whose voxel columns span more than 8192 cells (fine octrees, long ranges) keeps the columns
+  // within kTiltCrop cells of the robot's own column: nothing farther can be reached by a roll-out (checked
+  // per cycle against the horizon: rollout_impl), so dropping it changes no collision result.
+  bool tilt_cropped = false;
+  int tilt_cx = 0, tilt_cy = 0;  // the robot's column at the update (octree keys)
+  double tilt_body_x = 0, tilt_body_y = 0;  // the pose of that update
 
   // drop_samples_ == false (trajectory_sampler.cpp:157-168; option "drop_samples" = 0)
   bool drop_samples = true;
@@ -322,6 +328,7 @@ namespace {
 // largest point list the device-side sensor update takes (bucket grid of at most 64 x 64 cells:
 // about one obstacle per cell up to 4 k points, 64 per cell here); beyond: the host path, finer grid
 constexpr size_t kSensorDeviceMax = 262144;
+constexpr int kTiltCrop = 4000;                // half side of the kept window of a cropped tilted scan, in voxel columns
 constexpr size_t kSensorFusedMax = 32768;       // points up to which the one-launch sensor build is used
 constexpr size_t kSensorFusedLds = 100 * 1024;  // dynamic LDS of sensor_fused_kernel (band rows; bucket tables + point ids)
 
@@ -513,14 +520,45 @@ void dil_tables(const DilGeom &dg, signed char win[kMaxDil + 1], signed char wou
 // reachable window out of it)
 int upload_voxels(kc_dwa *c) {
   c->have_gbits = false;
-  const size_t nv = c->vox_kx.size();
+  size_t nv = c->vox_kx.size();
+  c->tilt_cropped = false;
   if (nv == 0) return KC_OK;
   int lox = INT32_MAX, loy = INT32_MAX, hix = INT32_MIN, hiy = INT32_MIN;
-  for (size_t i = 0; i < nv; ++i) {
-    lox = std::min(lox, c->vox_kx[i]);
-    hix = std::max(hix, c->vox_kx[i]);
-    loy = std::min(loy, c->vox_ky[i]);
-    hiy = std::max(hiy, c->vox_ky[i]);
+  auto bounds = [&] {
+    lox = loy = INT32_MAX;
+    hix = hiy = INT32_MIN;
+    for (size_t i = 0; i < nv; ++i) {
+      lox = std::min(lox, c->vox_kx[i]);
+      hix = std::max(hix, c->vox_kx[i]);
+      loy = std::min(loy, c->vox_ky[i]);
+      hiy = std::max(hiy, c->vox_ky[i]);
+    }
+  };
+  bounds();
+  if (c->tilted && (static_cast<long>(hix) - lox + 1 > 8192 || static_cast<long>(hiy) - loy + 1 > 8192)) {
+    // the robot's own column: the body origin in octree coordinates, F^-1 (x, y, 0) = R^T ((x, y, 0) - t)
+    const hm::Rigid3f &F = c->frame;
+    const double d[3] = {c->tilt_body_x - static_cast<double>(F.t[0]), c->tilt_body_y - static_cast<double>(F.t[1]),
+                         0.0 - static_cast<double>(F.t[2])};
+    const double ox = F.R[0][0] * d[0] + F.R[1][0] * d[1] + F.R[2][0] * d[2];
+    const double oy = F.R[0][1] * d[0] + F.R[1][1] * d[1] + F.R[2][1] * d[2];
+    c->tilt_cx = static_cast<int>(std::floor(ox * c->inv_res));
+    c->tilt_cy = static_cast<int>(std::floor(oy * c->inv_res));
+    size_t w = 0;
+    for (size_t i = 0; i < nv; ++i)
+      if (std::abs(c->vox_kx[i] - c->tilt_cx) <= kTiltCrop && std::abs(c->vox_ky[i] - c->tilt_cy) <= kTiltCrop) {
+        c->vox_kx[w] = c->vox_kx[i];
+        c->vox_ky[w] = c->vox_ky[i];
+        if (c->vox_ddz.size() == nv) c->vox_ddz[w] = c->vox_ddz[i];
+        ++w;
+      }
+    c->vox_kx.resize(w);
+    c->vox_ky.resize(w);
+    if (c->vox_ddz.size() == nv) c->vox_ddz.resize(w);
+    nv = w;
+    c->tilt_cropped = true;
+    if (nv == 0) return KC_OK;
+    bounds();
   }
   c->sphere_ddz_max = -1.0;
   if (c->prm.shape == KC_SPHERE && c->vox_ddz.size() == nv)
@@ -2964,6 +3002,8 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   // a mount that is not a rotation about z tilts the octree against the upright robot shape: exact
   // 3-D tests on the split roll-out path (kc_tilt_dev.h), host-built voxel columns, no dilated masks
   c->tilted = !c->frame.planar();
+  c->tilt_body_x = st->x;
+  c->tilt_body_y = st->y;
   const float hz = static_cast<float>(
       -static_cast<double>(c->sensor_tf_body.t[2]) / 2.0);
   // CostEvaluator::setPointScan(LaserScan): sensor_tf_body * body_tf_world
@@ -3053,27 +3093,33 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   KC_TRY(upload_voxels(c));
   if (c->tilted) {
     c->have_dil = false;
-      if (!c->vox_kx.empty() && !c->have_gbits)
+    if (!c->vox_kx.empty() && !c->have_gbits)  // (cannot happen: a wider span was cropped to the reachable window above)
       KC_FAIL(KC_ERR_UNSUPPORTED, "tilted sensor frame: the scan's voxel columns span more than 8192 cells");
   }
   return upload_obstacles(c, n);
 }
 
-int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
-                      float max_range) {
+}  // extern "C"
+namespace {
+// updateSensorData<std::vector<Path::Point>>(cloud, global_frame), collision_check.h:119-131: the octree of a
+// world-frame list lies in the world frame (identity); that of a SENSOR-frame list in body->tf * sensor_tf_body,
+// like a laser scan's (the voxel keys are taken from the points as they are; the poses go into that frame).
+int set_points_impl(kc_dwa *c, const kc_state *st, const float *xyz, size_t n, float max_range, bool global_frame) {
   if (!c || !st || (n && !xyz)) KC_FAIL(KC_ERR_INVALID, "null argument");
   KC_TRY(use_device(c));
   const auto dbg_t0 = std::chrono::steady_clock::now();
   KC_TRY(quiesce_for_update(c));
   const auto dbg_t1 = std::chrono::steady_clock::now();
-  // updateSensorData<std::vector<Path::Point>>(cloud, global_frame = true)
-  c->frame = hm::Rigid3f::identity();
+  const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
+  c->frame = global_frame ? hm::Rigid3f::identity() : body * c->sensor_tf_body;
   c->tilted = false;
+  if (!c->frame.planar())
+    KC_FAIL(KC_ERR_UNSUPPORTED, "a sensor-frame point list under a sensor mount that is not a rotation about z (several "
+                                "voxel layers in a tilted octree frame) is not restated; laser scans are");
   ++c->sensor_version;
   c->oscan_valid = false;
   c->onear_ok = false;
-  const hm::Rigid3f body = hm::Rigid3f::from_pose2d(st->x, st->y, st->yaw);
-  c->obs_tf = c->sensor_tf_body * body;
+  c->obs_tf = c->sensor_tf_body * body;  // setPointScan(cloud): the same whatever frame the octree takes
   c->raw_is_scan = false;
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;
@@ -3103,6 +3149,16 @@ int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n,
                  us(dbg_t0, dbg_t1), us(dbg_t1, dbg_t2), us(dbg_t2, dbg_t3), us(dbg_t3, dbg_t4));
   }
   return rc;
+}
+}  // namespace
+extern "C" {
+
+int kc_dwa_set_points(kc_dwa *c, const kc_state *st, const float *xyz, size_t n, float max_range) {
+  return set_points_impl(c, st, xyz, n, max_range, true);
+}
+
+int kc_dwa_set_points_sensor_frame(kc_dwa *c, const kc_state *st, const float *xyz, size_t n, float max_range) {
+  return set_points_impl(c, st, xyz, n, max_range, false);
 }
 
 // the mapper's grid feeds the controller without leaving the
@@ -3842,6 +3898,14 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       // tilted octree frame: every pose against the voxel columns within its reach, exact 3-D tests
       TiltArgs ta{};
       KC_TRY(tilt_params(c, ta.c));
+      if (c->tilt_cropped) {
+        // the cropped window (upload_voxels) must hold every column a pose of this roll-out can touch: the start's
+        // distance from the update's pose + the horizon's reach + the robot's bounding radius, in columns
+        const double far = std::hypot(start->x - c->tilt_body_x, start->y - c->tilt_body_y) + cycle_reach(c) + ta.c.rho;
+        if (!(far * c->inv_res + 4.0 < static_cast<double>(kTiltCrop)))
+          KC_FAIL(KC_ERR_UNSUPPORTED, "tilted sensor frame: the roll-out reaches %.0f voxel columns from the pose of the scan, "
+                                      "beyond the %d kept of a scan that spans more than 8192", far * c->inv_res, kTiltCrop);
+      }
       ta.pos = c->d_pos.p;
       ta.trig = c->d_trig.p;
       ta.row = c->d_row.p;
@@ -3926,6 +3990,13 @@ int kc_dwa_check_poses(kc_dwa *c, const double *x, const double *y,
     }
     TiltDev td;
     KC_TRY(tilt_params(c, td));
+    if (c->tilt_cropped) {  // (see rollout_impl: every pose inside the kept window of the cropped scan)
+      double far = 0.0;
+      for (size_t i = 0; i < n; ++i) far = std::max(far, std::hypot(x[i] - c->tilt_body_x, y[i] - c->tilt_body_y));
+      if (!((far + td.rho) * c->inv_res + 4.0 < static_cast<double>(kTiltCrop)))
+        KC_FAIL(KC_ERR_UNSUPPORTED, "tilted sensor frame: a pose lies %.0f voxel columns from the pose of the scan, beyond the "
+                                    "%d kept of a scan that spans more than 8192", far * c->inv_res, kTiltCrop);
+    }
     KC_TRY(c->h_trig.reserve(2 * n));
     KC_TRY(c->d_trig.reserve(2 * n));
     for (size_t i = 0; i < n; ++i) {
@@ -4365,6 +4436,36 @@ int kc_dwa_allreduce_best(kc_dwa *c, kc_comm *m) {
   return kc_dwa_publish_result(c);
 }
 
+}  // extern "C"
+namespace {
+// the part of a sharded cycle behind this rank's words of the send record: the ONE all-reduce, the hand-off of the
+// reduced record to the host, the merge.  rc / why: this rank's own failure so far (it has taken part all the same).
+int finish_exchange(kc_dwa *c, kc_comm *m, const ShardLayout &L, size_t rw, int rc, const std::string &why, kc_result *out) {
+  const size_t len = X_REGIONS + static_cast<size_t>(kc::comm_world(m)) * rw;
+  hipStream_t s = c->stream;
+  int trc = c->timing.start("all_reduce", s);
+  const int rc_x = kc::comm_allreduce_i64(m, c->d_xs.p, c->d_xr.p, len, /*sum=*/false, s);
+  if (trc == KC_OK) trc = c->timing.stop(s);
+  if (rc_x != KC_OK) {
+    if (rc != KC_OK) set_error("%s", why.c_str());
+    return rc != KC_OK ? rc : rc_x;
+  }
+  hipLaunchKernelGGL(xchg_publish_kernel, dim3(1), dim3(256), 0, s, c->d_xr.p, static_cast<int>(len), c->h_xvec.p,
+                     c->h_xrec.p, ++c->xseq);
+  c->drained = false;
+  kc_result r{};
+  const int rc_f = fetch_xchg(c, L, rw, &r);
+  if (rc != KC_OK) {  // this rank's own failure is the more specific message
+    set_error("%s", why.c_str());
+    return rc;
+  }
+  KC_TRY(rc_f);
+  if (out) *out = r;
+  return KC_OK;
+}
+}  // namespace
+extern "C" {
+
 int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P, kc_result *out) {
   if (!c || !m) KC_FAIL(KC_ERR_INVALID, "null argument");
   const int world = kc::comm_world(m), rank = kc::comm_rank(m);
@@ -4391,7 +4492,6 @@ int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P,
   KC_TRY(use_device(c));
   const size_t rw = std::max<size_t>((L->max_count() + 63) / 64, 1);
   KC_TRY(ensure_xchg(c, world, rank, rw));
-  const size_t len = X_REGIONS + static_cast<size_t>(world) * rw;
   hipStream_t s = c->stream;
   // ---- this rank's cycle.  From here on the rank takes part in the exchange whatever happens:
   // a failure travels in the record's error word and fails the cycle on EVERY rank.
@@ -4424,25 +4524,58 @@ int kc_dwa_cycle_sharded(kc_dwa *c, kc_comm *m, const kc_state *start, size_t P,
     (void)hipGetLastError();
     hipLaunchKernelGGL(xchg_fail_kernel, dim3(1), dim3(256), 0, s, c->d_xs.p, rank, static_cast<int>(rw));
   }
-  int trc = c->timing.start("all_reduce", s);
-  const int rc_x = kc::comm_allreduce_i64(m, c->d_xs.p, c->d_xr.p, len, /*sum=*/false, s);
-  if (trc == KC_OK) trc = c->timing.stop(s);
-  if (rc_x != KC_OK) {
-    if (rc != KC_OK) set_error("%s", why.c_str());
-    return rc != KC_OK ? rc : rc_x;
+  return finish_exchange(c, m, *L, rw, rc, why, out);
+}
+
+// The exchange of a cycle whose LAST cost terms were added on the host (custom cost callbacks of a sharded DWA:
+// cost_evaluator.cpp:96-100 -- every rank adds the callbacks to the device totals of its own admissible rows, in
+// the reference's order, and knows its own best): the same record as kc_dwa_cycle_sharded -- this rank's key
+// {cost, GLOBAL raw index} as handed in, the error word, its admissible bitmap from the flags of the cycle it has
+// just run (kc_dwa_cycle on its share) -- through the same single all-reduce and the same merge.  status != 0:
+// this rank failed somewhere before; it still takes part, and the cycle fails on every rank.
+int kc_dwa_exchange_best(kc_dwa *c, kc_comm *m, int status, int found, float cost, int64_t raw_index, kc_result *out) {
+  if (!c || !m) KC_FAIL(KC_ERR_INVALID, "null argument");
+  const int world = kc::comm_world(m), rank = kc::comm_rank(m);
+  if (kc::comm_device(m) != c->prm.device)
+    KC_FAIL(KC_ERR_INVALID, "communicator on device %d, controller on device %d", kc::comm_device(m), c->prm.device);
+  ShardLayout implicit;
+  const ShardLayout *L = &c->layout;
+  if (c->layout.mode < 0) {
+    if (world > 1) KC_FAIL(KC_ERR_STATE, "an exchange over %d ranks needs kc_dwa_set_shard_rule", world);
+    implicit.mode = KC_SHARD_BLOCKS;
+    implicit.first = {c->shard_first};
+    implicit.count = {c->shard_count};
+    implicit.n_total = c->shard_count;
+    L = &implicit;
+  } else if (c->layout.world != world || c->layout.rank != rank) {
+    KC_FAIL(KC_ERR_INVALID, "shard rule is for rank %d of %d, the communicator is rank %d of %d", c->layout.rank,
+            c->layout.world, rank, world);
   }
-  hipLaunchKernelGGL(xchg_publish_kernel, dim3(1), dim3(256), 0, s, c->d_xr.p, static_cast<int>(len), c->h_xvec.p,
-                     c->h_xrec.p, ++c->xseq);
-  c->drained = false;
-  kc_result r{};
-  const int rc_f = fetch_xchg(c, *L, rw, &r);
-  if (rc != KC_OK) {  // this rank's own failure is the more specific message
-    set_error("%s", why.c_str());
-    return rc;
+  KC_TRY(use_device(c));
+  const size_t rw = std::max<size_t>((L->max_count() + 63) / 64, 1);
+  KC_TRY(ensure_xchg(c, world, rank, rw));
+  hipStream_t s = c->stream;
+  int rc = KC_OK;
+  std::string why;
+  if (status != 0 || !c->rolled) {
+    rc = KC_ERR_STATE;
+    why = status != 0 ? "this rank failed before the exchange" : "no cycle has run on this rank's share";
+    hipLaunchKernelGGL(xchg_fail_kernel, dim3(1), dim3(256), 0, s, c->d_xs.p, rank, static_cast<int>(rw));
+  } else {
+    PackArgs pa{};
+    pa.result = c->d_result.p;
+    pa.flags = c->d_flags.p;
+    pa.n = static_cast<int>(c->n_roll);
+    pa.gid = nullptr;
+    pa.xs = c->d_xs.p;
+    pa.rank = rank;
+    pa.rw = static_cast<int>(rw);
+    pa.host_key = 1;
+    pa.key = found ? key_pack(cost, static_cast<uint32_t>(raw_index)) : KEY_NONE;
+    hipLaunchKernelGGL(xchg_pack_kernel, dim3(1), dim3(1024), 0, s, pa);
   }
-  KC_TRY(rc_f);
-  if (out) *out = r;
-  return KC_OK;
+  c->pub_pending = false;
+  return finish_exchange(c, m, *L, rw, rc, why, out);
 }
 
 int kc_dwa_global_index(kc_dwa *c, kc_comm *m, int64_t raw, int64_t *index_out) {

@@ -159,6 +159,8 @@ struct PackArgs {
   const int32_t *gid;       // local-lattice id -> global id (null: identity)
   long long *xs;            // send record
   int rank, rw;
+  int host_key;             // 1: the key comes from the host (kc_dwa_exchange_best: host-side costs were added to the
+  long long key;            //    device totals), already with the GLOBAL raw index; the device record is not read
 };
 // one workgroup: this rank's words of the send record from the cycle's device record + flags
 __global__ __launch_bounds__(1024) void xchg_pack_kernel(PackArgs a) {
@@ -170,7 +172,10 @@ __global__ __launch_bounds__(1024) void xchg_pack_kernel(PackArgs a) {
     const unsigned long long bal = __ballot(f);
     if (lane == 0) region[j] = static_cast<long long>(bal);
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && a.host_key) {
+    a.xs[X_KEY] = a.key;
+    a.xs[X_ERR] = 0ll;
+  } else if (threadIdx.x == 0) {
     long long key = a.result[R_KEY];
     const bool err = a.result[R_NADM] < 0;
     if (key != KEY_NONE && a.gid) {

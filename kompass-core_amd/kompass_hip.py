@@ -117,6 +117,7 @@ SIGNATURES = {
     "kc_dwa_owns_sample": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int)]),
     "kc_dwa_set_scan": (C.c_int, [_vp, C.POINTER(State), _dp, _dp, _sz, C.c_float]),
     "kc_dwa_set_points": (C.c_int, [_vp, C.POINTER(State), _fp, _sz, C.c_float]),
+    "kc_dwa_set_points_sensor_frame": (C.c_int, [_vp, C.POINTER(State), _fp, _sz, C.c_float]),
     "kc_dwa_set_path": (C.c_int, [_vp, _fp, _fp, _fp, _fp, _sz, C.c_float]),
     "kc_dwa_set_tracked_window": (C.c_int, [_vp, _sz, _sz]),
     "kc_dwa_set_grid_device": (C.c_int, [_vp, C.POINTER(State), _vp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
@@ -150,6 +151,7 @@ SIGNATURES = {
     "kc_comm_world": (C.c_int, [_vp]),
     "kc_dwa_allreduce_best": (C.c_int, [_vp, _vp]),
     "kc_dwa_cycle_sharded": (C.c_int, [_vp, _vp, C.POINTER(State), _sz, C.POINTER(Result)]),
+    "kc_dwa_exchange_best": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_float, C.c_int64, C.POINTER(Result)]),
     "kc_dwa_global_index": (C.c_int, [_vp, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "kc_key_cost": (C.c_float, [C.c_int64]),
     "kc_key_index": (C.c_int64, [C.c_int64]),
@@ -475,9 +477,14 @@ class DwaContext:
         st.x, st.y, st.yaw, st.speed = state
         return self._st_addr
 
-    def set_points(self, state, xyz, max_sensor_range=10.0):
+    def set_points(self, state, xyz, max_sensor_range=10.0, global_frame=True):
+        """updateSensorData(cloud, global_frame): world-frame points, or (global_frame=False) sensor-frame points."""
         p, addr = _addr32(xyz)
-        rc = _fast["kc_dwa_set_points"](self.h, self._state(state), addr, p.size // 3, max_sensor_range)
+        if global_frame:
+            rc = _fast["kc_dwa_set_points"](self.h, self._state(state), addr, p.size // 3, max_sensor_range)
+        else:
+            st = State(*state)
+            rc = lib().kc_dwa_set_points_sensor_frame(self.h, C.byref(st), _pf(p), p.size // 3, float(max_sensor_range))
         if rc != KC_OK:
             _check(rc)
 
@@ -686,6 +693,14 @@ class DwaContext:
         self._P = int(P)
         r = Result()
         _check(lib().kc_dwa_cycle_sharded(self.h, comm.h, C.byref(st), int(P), C.byref(r)))
+        return r
+
+    def exchange_best(self, comm: "Comm", found, cost, raw_index, status=0) -> Result:
+        """The exchange of a sharded cycle whose last cost terms the HOST added (custom cost callbacks): this
+        rank's own best {found, cost, global raw index} in, the global result out (kc_dwa_exchange_best)."""
+        r = Result()
+        _check(lib().kc_dwa_exchange_best(self.h, comm.h, int(status), int(bool(found)), float(np.float32(cost)),
+                                          int(raw_index), C.byref(r)))
         return r
 
     def global_index(self, comm: "Comm", raw_index) -> int:

@@ -14,6 +14,11 @@ import kompass_hip as kh  # noqa: E402
 import synthetic as syn  # noqa: E402
 
 
+def custom_cost(raw):
+    """The host callback of the `custom` scenario: a float32 cost per GLOBAL sample id."""
+    return np.float32(((raw * 2654435761) % 1000) / 1000.0)
+
+
 def poses(inp, k):
     x, y, yaw, sp = inp["state"]
     return (x + 0.01 * k, y - 0.005 * k, yaw + 0.02 * ((k % 5) - 2), sp)
@@ -44,7 +49,25 @@ def main():
         if scenario == "prefail" and k == 1 and rank == world - 1:
             p_call = P + 1  # beyond max_points: this rank fails BEFORE the exchange
         try:
-            r = ctx.cycle_sharded(comm, st, p_call)
+            if scenario == "custom":
+                # custom cost callbacks of a sharded DWA (cost_evaluator.cpp:96-100): the cycle of this rank's
+                # share, the callback added on the host to the device totals of its own admissible rows in the
+                # reference's rounding (float = (double) total + w * (double) c), its own first minimum into the
+                # exchange (kc_dwa_exchange_best)
+                status = 0
+                found, best, braw = False, np.float32(np.finfo(np.float32).max), -1
+                try:
+                    ctx.cycle(st, p_call)
+                    _, _, raw, costs = ctx.get_samples(with_costs=True, with_paths=False)
+                    for g, c in zip(raw, costs):
+                        t = np.float32(np.float64(c) + 2.5 * np.float64(custom_cost(int(g))))
+                        if t < best:
+                            found, best, braw = True, t, int(g)
+                except (RuntimeError, IndexError, ValueError):
+                    status = 1
+                r = ctx.exchange_best(comm, found, best, braw, status=status)
+            else:
+                r = ctx.cycle_sharded(comm, st, p_call)
             rec = dict(ok=True, found=bool(r.found), cost=float(r.cost), raw=int(r.raw_index), index=int(r.index),
                        n_admissible=int(r.n_admissible), n_samples=int(r.n_samples),
                        owns=bool(r.found and ctx.owns_sample(r.raw_index)))

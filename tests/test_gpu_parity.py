@@ -496,3 +496,54 @@ def test_mapper_scan_sequences_on_one_context(H, W):
         got = m.scan_to_grid(ang, rng)
         assert np.array_equal(got, want), (case, n, int((got != want).sum()))
     m.close()
+
+
+@pytest.mark.parametrize("shape,dims", [(syn.CYLINDER, [0.1, 0.4]), (syn.BOX, [0.5, 0.3, 0.6])], ids=["cylinder", "box"])
+@pytest.mark.parametrize("opts", [dict(), dict(sensor_on_host=1), dict(sensor_two_launch=1), dict(force_split=1)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "default")
+def test_sensor_frame_point_list(shape, dims, opts):
+    """updateSensorData(cloud, global_frame = false), collision_check.h:119-131 -- the list is in
+    the SENSOR frame, the octree frame is body->tf * sensor_tf_body (a mount rotated about z and shifted); the
+    obstacle list of the cost term is the same as for a world-frame list.  Every device path against the oracle's
+    restatement (ko_coll_update_points(..., 0)); a mount that is not a rotation about z is refused."""
+    import math
+
+    inp = syn.make_controller_inputs("cfg2", seed=9, scale=0.25)
+    inp["robot"] = dict(shape=shape, dims=dims)
+    spos, srot = (0.12, -0.05, 0.15), (0.0, 0.0, math.sin(0.2), math.cos(0.2))
+    st = (0.3, -0.2, 0.25, 0.0)
+    pts = np.ascontiguousarray(inp["points"], np.float32)
+    rb = inp["robot"]
+    coll = ko.Collision(rb["shape"], rb["dims"], spos, srot, inp["octree_res"])
+    coll.update_state(st[0], st[1], st[2])
+    coll.update_points(pts, False)
+    ox, oy = ko.obstacles_from_points(spos, srot, st, pts)
+    px, py, raw, _ = ko.rollout(coll, st, inp["dt"], inp["P"], inp["vx"], inp["vy"], inp["omega"])
+    ci = ko.CostInputs(inp["seg_xyz"], 0, inp["acc_at_seg"], inp["ref_len"], np.stack([ox, oy], axis=1),
+                       np.float32(inp["max_range"]) / np.float32(3.0), inp["acc_limits"], ko.make_weights(*inp["weights"]))
+    assert 0 < len(px) < len(inp["vx"])
+    idx, cost, costs = ko.min_trajectory_cost(ci, px, py, None)
+    # the world-frame reading of the same numbers is a different scene: the test would not notice a frame mix-up otherwise
+    coll_w = ko.Collision(rb["shape"], rb["dims"], spos, srot, inp["octree_res"])
+    coll_w.update_state(st[0], st[1], st[2])
+    coll_w.update_points(pts, True)
+    assert not np.array_equal(ko.rollout(coll_w, st, inp["dt"], inp["P"], inp["vx"], inp["vy"], inp["omega"])[2], raw)
+    ctx = hip_context(kh, inp, spos, srot)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    ctx.set_weights(kh.make_weights(*inp["weights"]))
+    ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
+    ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
+    for rep in range(2):
+        ctx.set_points(st, pts, inp["max_range"], global_frame=False)
+        r = ctx.cycle(st, inp["P"])
+        hx, hy, hraw, hcosts = ctx.get_samples(with_costs=True)
+        np.testing.assert_array_equal(hraw, raw)
+        np.testing.assert_array_equal(hx.view(np.uint32), px.view(np.uint32))
+        np.testing.assert_array_equal(hcosts.view(np.uint32), costs.view(np.uint32))
+        assert r.found and r.index == idx and np.float32(r.cost) == np.float32(cost)
+    ctx.close()
+    tilted = hip_context(kh, inp, spos, (0.0, math.sin(0.2), 0.0, math.cos(0.2)))
+    with pytest.raises(Exception):
+        tilted.set_points(st, pts, inp["max_range"], global_frame=False)
+    tilted.close()

@@ -23,7 +23,7 @@ from helpers import oracle_cycle  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
-from _shm_worker import poses  # noqa: E402
+from _shm_worker import custom_cost, poses  # noqa: E402
 
 
 def _run(tmp_path, world, scenario, cfg, scale, seed, mode):
@@ -86,6 +86,33 @@ def test_ranks_agree_with_the_unsharded_oracle(tmp_path, world, cfg, scale, seed
                 owners += 1
                 np.testing.assert_array_equal(np.float32(got[r][k]["best_x"]), o["px"][o["index"]])
         assert owners == (1 if o["index"] >= 0 else 0)   # exactly one rank holds the winner's row
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,cfg,scale,seed,mode", [(2, "cfg2", 0.25, 41, kh.SHARD_ROWS), (3, "cfg1", 1.0, 42, kh.SHARD_BLOCKS)])
+def test_custom_costs_with_a_sharded_controller(tmp_path, world, cfg, scale, seed, mode):
+    """VERDICT r3 item 6 / SURVEY 8e row 2: custom cost callbacks are host-side; with a sharded DWA every rank adds
+    them to the device totals of its own admissible rows and the ranks exchange their bests
+    (kc_dwa_exchange_best).  Every rank must return what ONE process gets that adds the callback to the oracle's
+    per-sample totals (cost_evaluator.cpp:96-100: float = (double) total + weight * (double) cost, first strict
+    minimum in generation order)."""
+    got = _run(tmp_path, world, "custom", cfg, scale, seed, mode)
+    ora = _oracles(cfg, scale, seed)
+    n_total = len(syn.make_controller_inputs(cfg, seed=seed, scale=scale)["vx"])
+    for k, o in enumerate(ora):
+        best, arg = np.float32(np.finfo(np.float32).max), -1
+        for i, (g, c) in enumerate(zip(o["raw"], o["costs"])):
+            t = np.float32(np.float64(c) + 2.5 * np.float64(custom_cost(int(g))))
+            if t < best:
+                best, arg = t, i
+        for r in range(world):
+            rec = got[r][k]
+            assert rec["ok"], rec
+            assert rec["n_admissible"] == len(o["raw"]) and rec["n_samples"] == n_total
+            assert rec["found"] == (arg >= 0)
+            if arg >= 0:
+                assert rec["raw"] == int(o["raw"][arg]) and rec["index"] == arg
+                assert np.float32(rec["cost"]) == best
 
 
 @pytest.mark.timeout(600)

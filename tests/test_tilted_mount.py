@@ -104,3 +104,35 @@ def test_closed_form_cases_pin_the_tilted_tests():
             ctx.set_scan((0, 0, 0, 0), np.array([r]), np.array([0.0]), 10.0)
             assert bool(ctx.check_poses([0.0], [0.0], [0.0])[0]) == expect
             ctx.close()
+
+
+def test_a_tilted_scan_wider_than_8192_columns():
+    """a fine octree and long ranges put the voxel columns of a tilted scan more than 8192
+    cells apart (round 3: KC_ERR_UNSUPPORTED).  The columns beyond 4000 cells of the robot are unreachable for any
+    roll-out and are dropped; cycle and pose checks equal the oracle's, which keeps them all."""
+    res = 0.01
+    srot, spos = quat((0, 1, 0), 0.35), (0.05, 0.0, 0.1)
+    inp = syn.make_controller_inputs("cfg1", seed=8)
+    inp["octree_res"] = res
+    inp["robot"] = dict(shape=syn.CYLINDER, dims=[0.15, 0.4])
+    ang = np.linspace(0, 2 * math.pi, 1200, endpoint=False)
+    rng = np.random.default_rng(4)
+    ranges = 0.7 + 1.4 * rng.random(1200)
+    ranges[::9] = 55.0 + 4.0 * rng.random(len(ranges[::9]))      # far returns: +-59 m at 1 cm = 11 800 columns
+    o = oracle_cycle(inp, scan=(ranges, ang), sensor_pos=spos, sensor_rot=srot)
+    assert 0 < len(o["raw"]) < len(inp["vx"])
+    h = hip_cycle(kh, inp, scan=(ranges, ang), sensor_pos=spos, sensor_rot=srot)
+    assert_cycle_equal(o, h)
+    ctx = h["ctx"]
+    st = inp["state"]
+    coll = ko.Collision(syn.CYLINDER, [0.15, 0.4], spos, srot, res)
+    coll.update_state(*st[:3])
+    coll.update_scan(ranges, ang)
+    x = st[0] + rng.uniform(-2.0, 2.0, 1500)
+    y = st[1] + rng.uniform(-2.0, 2.0, 1500)
+    yaw = rng.uniform(-math.pi, math.pi, 1500)
+    want = np.array([coll.check_at(x[i], y[i], yaw[i]) for i in range(1500)], np.uint8)
+    assert 0 < want.sum() < 1500
+    np.testing.assert_array_equal(ctx.check_poses(x, y, yaw), want)
+    with pytest.raises(Exception):       # a pose 45 m away: outside what the cropped window can answer for
+        ctx.check_poses([st[0] + 45.0], [st[1]], [0.0])
