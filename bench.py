@@ -431,13 +431,28 @@ def strong_leg(kh, syn, sharding, cfg, rank, world, device, comm, args, ranks):
     el = time.perf_counter() - t0
     el, p50 = ranks.max(el, float(np.percentile(np.array(lat) * 1e3, 50)))
     single = int(ctx.get_option("last_cycle_single_launch"))
-    shares = ranks.gather({"samples": count, "trig_rows": trig_rows, "single_launch": single,
+    # the same cycles with HIP events around every kernel and around the all-reduce (out of `value`)
+    ctx.timing_enable(True)
+    kms = {}
+    for i in range(min(steps, 50)):
+        ctx.cycle_sharded(comm, pose(i), P)
+        for name, ms in ctx.timings():
+            if not name.startswith("host:"):
+                kms.setdefault(name, []).append(ms)
+    ctx.timing_enable(False)
+    kernels_ms = {k: float(np.mean(v)) for k, v in kms.items()}
+    shares = ranks.gather({"samples": count, "trig_rows": trig_rows, "single_launch": single, "kernels_ms": kernels_ms,
                            "winner": [bool(r.found), float(r.cost), int(r.raw_index), int(r.index), int(r.n_admissible)]})
     ctx.close()
     return {"scaling": "strong", "workload": f"{cfg}: {n_total} samples x {P} steps in all, dealt by trig row, scene 'mid'",
             "value": n_total * P * steps / el, "unit": "trajectory-steps/s", "ms_per_step": 1e3 * el / steps,
             "latency_p50_ms": p50, "steps": steps, "n_gpus": world, "n_admissible_global": int(r.n_admissible),
             "samples_per_rank": [s_["samples"] for s_ in shares], "trig_rows_per_rank": [s_["trig_rows"] for s_ in shares],
+            # the ONE collective of a cycle: int64 x (2 + world x words per rank), ncclMin; its time by HIP events on the
+            # launch stream of every rank (launch gaps included), the slowest rank's
+            "exchange_record_bytes": 8 * (2 + world * ((max(s_["samples"] for s_ in shares) + 63) // 64)),
+            "all_reduce_ms_max": max(s_["kernels_ms"].get("all_reduce", 0.0) for s_ in shares),
+            "kernels_ms_rank0": shares[0]["kernels_ms"],
             "single_launch_per_rank": [s_["single_launch"] for s_ in shares],
             "ranks_agree": all(s_["winner"] == shares[0]["winner"] for s_ in shares),
             "winner": {"found": bool(r.found), "cost": float(r.cost), "raw_index": int(r.raw_index), "index": int(r.index)}}
