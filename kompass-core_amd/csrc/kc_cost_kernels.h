@@ -2147,6 +2147,7 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArg
 // stream wait) and the re-arming of the working slots.  A kernel boundary
 // instead of a device-wide "last block" ticket: hundreds of same-address
 // atomics cost more than the dispatch of this kernel.
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(256) void velocity_finish_kernel(VelFinishArgs a) {
   __shared__ long long s_key;
   if (threadIdx.x == 0) s_key = KEY_NONE;
@@ -2168,17 +2169,22 @@ __global__ __launch_bounds__(256) void velocity_finish_kernel(VelFinishArgs a) {
   __syncthreads();
   if (threadIdx.x == 0) a.block_keys[blockIdx.x] = s_key;
 }
+#endif  // KC_TU_CYCLE
 
 constexpr int kPubBlock = 512;
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(kPubBlock) void publish_kernel(PubArgs a) { publish_body<kPubBlock>(a); }
+#endif  // KC_TU_CYCLE
 
 // the (externally reduced) device record again into the pinned mirror
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ void republish_kernel(const long long *result, long long *host_pub, long long seq) {
   const long long key = result[R_KEY];
   const long long w1 = (result[R_NADM] << 32) |
                        static_cast<long long>(static_cast<uint32_t>(result[R_COMPACT]));
   store_host_record(host_pub, key, w1, seq, 0);
 }
+#endif  // KC_TU_CYCLE
 
 // ordered compaction of the admissible flags (one workgroup): adm_list[i] =
 // i-th admissible local sample id, *adm_count = how many.  Used by the split
@@ -2187,6 +2193,7 @@ __global__ void republish_kernel(const long long *result, long long *host_pub, l
 // up front: one memory latency), a block-wide scan gives the offsets.
 constexpr int kCompactMaxPer = 64;  // 1024 threads x 64 = 65536 samples
 
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(1024) void compact_kernel(
     const uint8_t *__restrict__ flags, int n, int *__restrict__ adm_list,
     long long *__restrict__ adm_count) {
@@ -2220,9 +2227,11 @@ __global__ __launch_bounds__(1024) void compact_kernel(
   }
   if (threadIdx.x == 0) *adm_count = tot;
 }
+#endif  // KC_TU_CYCLE
 
 // admissible samples in front of a raw index (multi-GPU: rebuilds the
 // reference's compacted index across shards).  One workgroup.
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(1024) void count_before_kernel(
     const uint8_t *__restrict__ flags, int n, int first, long long target_raw,
     long long *result, int slot) {
@@ -2240,8 +2249,10 @@ __global__ __launch_bounds__(1024) void count_before_kernel(
     result[slot] = s;
   }
 }
+#endif  // KC_TU_CYCLE
 
 // arms the result record (context creation, and the empty-batch case)
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ void init_result_kernel(long long *result) {
   result[R_KEY] = KEY_NONE;
   result[R_NADM] = 0;
@@ -2254,6 +2265,7 @@ __global__ void init_result_kernel(long long *result) {
   result[R_SCRATCH] = 0;
   result[R_TRIGSEQ] = 0;
 }
+#endif  // KC_TU_CYCLE
 
 // Bounding box of caller-provided sample points (kc_cost_upload): min / max of the finite x and y as
 // order-preserving unsigned keys (atomicMin / atomicMax), out = {min x, min y, max x, max y}, armed by
@@ -2262,6 +2274,7 @@ __device__ __forceinline__ unsigned int float_order_key(float v) {
   const unsigned int b = __float_as_uint(v);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(256) void bbox_kernel(const float *px, const float *py, size_t count, unsigned int *out) {
   unsigned int lo_x = 0xFFFFFFFFu, lo_y = 0xFFFFFFFFu, hi_x = 0u, hi_y = 0u, bad = 0u;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
@@ -2291,10 +2304,13 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float *px, const float 
     if (bad) atomicOr(out + 4, 1u);
   }
 }
+#endif  // KC_TU_CYCLE
 
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ void fill_u8_kernel(uint8_t *p, int n, uint8_t v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
 }
+#endif  // KC_TU_CYCLE
 
 }  // namespace kc

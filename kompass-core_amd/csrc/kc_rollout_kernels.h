@@ -41,9 +41,11 @@ __device__ __forceinline__ void trig_job_block(const TrigJob &j, int blk) {
 
 // stand-alone: every workgroup of the launch belongs to the job (any horizon: no LDS)
 constexpr int kTrigBlock = 256;
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(kTrigBlock) void trig_table_kernel(TrigJob j) {
   trig_job_block<kTrigBlock>(j, static_cast<int>(blockIdx.x));
 }
+#endif  // KC_TU_CYCLE
 
 // ===========================================================================
 // K1a: roll-out.  One lane per sample: the recurrence x_{k+1} = x_k + (...) is
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(kTrigBlock) void trig_table_kernel(TrigJob j) {
 // ===========================================================================
 constexpr int kRollBlock = 64;
 
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int P1 = a.P | 1;  // odd row pitch: conflict-free column writes
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(RollArgs a) {
     }
   }
 }
+#endif  // KC_TU_CYCLE
 
 // ---------------------------------------------------------------------------
 // Dilated occupancy masks (once per sensor update).  For a pose in cell c and
@@ -168,6 +172,7 @@ __device__ __forceinline__ uint32_t hdilate(uint32_t left, uint32_t mid, uint32_
   }
   return static_cast<uint32_t>(up >> 32) | static_cast<uint32_t>(dn);
 }
+#ifdef KC_TU_SENSOR  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= a.H * a.wpr) return;
@@ -188,6 +193,7 @@ __global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
   a.inner[t] = in_acc;
   a.outer[t] = out_acc;
 }
+#endif  // KC_TU_SENSOR
 
 // ===========================================================================
 // K1 (fused): roll-out + collision gate of 32 samples per workgroup, no global
@@ -763,6 +769,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
 // ===========================================================================
 constexpr int kCollBlock = 256;
 
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t *lbits = reinterpret_cast<uint32_t *>(smem);
@@ -790,10 +797,12 @@ __global__ __launch_bounds__(kCollBlock) void collision_kernel(RollArgs a) {
     if (a.first_hit) atomicMin(&a.first_hit[n], k);  // drop_samples = false: which pose collides FIRST decides
   }
 }
+#endif  // KC_TU_CYCLE
 
 // split path, drop_samples = false: from the first colliding pose of every sample decide what
 // trajectory_sampler.cpp:157-168 decides, freeze the float rows of the kept samples (the row already holds the
 // float of the point it repeats) and leave the frozen profile's smoothness / jerk sums.  One lane per sample.
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(256) void freeze_fixup_kernel(RollArgs a) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= a.n) return;
@@ -820,9 +829,11 @@ __global__ __launch_bounds__(256) void freeze_fixup_kernel(RollArgs a) {
   a.frz_smooth[n] = fs;
   a.frz_jerk[n] = fj;
 }
+#endif  // KC_TU_CYCLE
 
 // batch pose check (CollisionChecker::checkCollisions for arbitrary poses):
 // occupancy bits read from global memory, cos/sin(yaw) from the host table
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
                                   const double2 *__restrict__ cs, int n,
                                   uint8_t *__restrict__ hit) {
@@ -838,5 +849,6 @@ __global__ void pose_check_kernel(CollDev c, const double2 *__restrict__ pos,
   }
   hit[i] = h ? 1 : 0;
 }
+#endif  // KC_TU_CYCLE
 
 }  // namespace kc

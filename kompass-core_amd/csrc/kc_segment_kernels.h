@@ -39,6 +39,7 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   return v;
 }
 
+#ifdef KC_TU_SENSOR  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowArgs a) {
   const int S = a.S, nch = a.nch, nsup = a.nsup;
   float *h = a.seg;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(kSegWinBlock) void segment_window_kernel(SegWindowA
     }
   }
 }
+#endif  // KC_TU_SENSOR
 
 // ---------------------------------------------------------------------------
 // Near table of the tracked segment (DcArgs::near): a grid of W x H cells of

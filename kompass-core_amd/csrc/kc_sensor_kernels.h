@@ -85,6 +85,7 @@ struct SensorBigArgs {
 #define KC_SSTAMP(row, slot) do { } while (0)
 #endif
 
+#ifdef KC_TU_SENSOR  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(kSensorBlock) void sensor_points_kernel(SensorBigArgs b) {
   const SensorArgs &a = b.a;
   __shared__ __align__(16) int lhist[kHistRow];
@@ -145,7 +146,9 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_points_kernel(SensorBigAr
   reinterpret_cast<int4 *>(b.hist + static_cast<size_t>(blockIdx.x) * kHistRow)[tid] = reinterpret_cast<int4 *>(lhist)[tid];
   KC_SSTAMP(blockIdx.x, 3);
 }
+#endif  // KC_TU_SENSOR
 
+#ifdef KC_TU_SENSOR  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArgs b) {
   const SensorArgs &a = b.a;
   const int ncell = a.W * a.H;
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(kSensorBlock) void sensor_place_kernel(SensorBigArg
   }
   KC_SSTAMP(me, 9);
 }
+#endif  // KC_TU_SENSOR
 
 // ---- occupancy grid -> point list on the device ------------
 // One thread per cell of a column-major int32 grid (LocalMapper layout, cell
@@ -332,6 +336,7 @@ struct GridPtsArgs {
 };
 constexpr int kGridCntStride = 16;
 
+#ifdef KC_TU_SENSOR  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(256) void grid_points_kernel(GridPtsArgs a) {
   // hits are counted and bounded per workgroup in LDS first: one slot range and
   // four bound updates per workgroup that holds a hit (same-address global
@@ -385,9 +390,11 @@ __global__ __launch_bounds__(256) void grid_points_kernel(GridPtsArgs a) {
     a.xyz[3 * slot + 2] = 0.0f;
   }
 }
+#endif  // KC_TU_SENSOR
 
 // one thread behind it (the kernel boundary has made the counters visible):
 // count + bounds into pinned host memory, counters re-armed
+#ifdef KC_TU_SENSOR  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ void grid_points_publish_kernel(unsigned int *cnt, long long *host, long long seq) {
   int *b = reinterpret_cast<int *>(cnt);
   host[1] = cnt[0];
@@ -403,5 +410,6 @@ __global__ void grid_points_publish_kernel(unsigned int *cnt, long long *host, l
   __threadfence_system();
   *reinterpret_cast<volatile long long *>(host) = seq;
 }
+#endif  // KC_TU_SENSOR
 
 }  // namespace kc

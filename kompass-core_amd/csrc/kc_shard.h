@@ -163,6 +163,7 @@ struct PackArgs {
   long long key;            //    device totals), already with the GLOBAL raw index; the device record is not read
 };
 // one workgroup: this rank's words of the send record from the cycle's device record + flags
+#ifdef KC_TU_SHARD  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(1024) void xchg_pack_kernel(PackArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long *region = a.xs + X_REGIONS + static_cast<size_t>(a.rank) * a.rw;
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(1024) void xchg_pack_kernel(PackArgs a) {
     a.xs[X_ERR] = err ? -1ll : 0ll;
   }
 }
+#endif  // KC_TU_SHARD
 // this rank failed before the exchange: it still takes part, with the error word set
+#ifdef KC_TU_SHARD  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ void xchg_fail_kernel(long long *xs, int rank, int rw) {
   for (int j = threadIdx.x; j < rw; j += blockDim.x) xs[X_REGIONS + static_cast<size_t>(rank) * rw + j] = 0;
   if (threadIdx.x == 0) {
@@ -194,12 +197,14 @@ __global__ void xchg_fail_kernel(long long *xs, int rank, int rw) {
     xs[X_ERR] = -2ll;
   }
 }
+#endif  // KC_TU_SHARD
 
 __host__ __device__ inline unsigned long long xchg_word_mix(long long w, unsigned i) {
   return rec_mix(static_cast<unsigned long long>(w) + 0x9E3779B97F4A7C15ull * (static_cast<unsigned long long>(i) + 1ull));
 }
 // the reduced record into pinned host memory (plain stores) + a 5-word record {checksum of the
 // words, length, sequence} the host polls; the words are accepted when their checksum adds up
+#ifdef KC_TU_SHARD  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(256) void xchg_publish_kernel(const long long *xr, int len, long long *host_vec,
                                                            long long *host_rec, long long seq) {
   __shared__ unsigned long long wsum[4];
@@ -217,5 +222,6 @@ __global__ __launch_bounds__(256) void xchg_publish_kernel(const long long *xr, 
     store_host_record(host_rec, static_cast<long long>(t), static_cast<long long>(len), seq, 0);
   }
 }
+#endif  // KC_TU_SHARD
 
 }  // namespace kc

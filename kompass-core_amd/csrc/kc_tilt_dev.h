@@ -176,6 +176,7 @@ struct TiltArgs {
 };
 
 // split path, tilted octree: one lane per pose (trajectory_sampler.cpp:147-152: any colliding pose drops the sample)
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ __launch_bounds__(256) void collision_tilted_kernel(TiltArgs a) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= (long)a.n * (a.P - 1)) return;
@@ -193,13 +194,16 @@ __global__ __launch_bounds__(256) void collision_tilted_kernel(TiltArgs a) {
     if (a.first_hit) atomicMin(&a.first_hit[n], k);
   }
 }
+#endif  // KC_TU_CYCLE
 
 // batch pose check (CollisionChecker::checkCollisions) against a tilted octree
+#ifdef KC_TU_CYCLE  // (a non-template kernel is defined in ONE translation unit: kc_dwa_ctx.h)
 __global__ void pose_check_tilted_kernel(TiltDev c, const double2 *__restrict__ pos, const double2 *__restrict__ cs,
                                          int n, uint8_t *__restrict__ hit) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   hit[i] = tilt_hit(c, c.gbits, pos[i].x, pos[i].y, cs[i].x, cs[i].y) ? 1 : 0;
 }
+#endif  // KC_TU_CYCLE
 
 }  // namespace kc
