@@ -127,6 +127,7 @@ inline ShmRank *shm_rank(kc_comm *m, int r) {
   return reinterpret_cast<ShmRank *>(static_cast<char *>(m->shm_base) + 4096) + r;
 }
 
+#ifndef KC_WITHOUT_REHEARSAL_TRANSPORT  // (make HIPFLAGS_EXTRA=-DKC_WITHOUT_REHEARSAL_TRANSPORT: a product build without it)
 // host-side all-reduce over the segment: every rank publishes its record under the next sequence
 // number, waits for the same number from every peer, reduces.  Two slots by sequence parity: a
 // rank that is one exchange ahead writes the other slot; it cannot be two ahead, because the
@@ -166,6 +167,11 @@ int shm_allreduce(kc_comm *m, const long long *send_dev, long long *recv_dev, si
   KC_HIP(hipMemcpyAsync(recv_dev, out, count * sizeof(long long), hipMemcpyHostToDevice, stream));
   return KC_OK;
 }
+#else
+int shm_allreduce(kc_comm *, const long long *, long long *, size_t, bool, hipStream_t) {
+  KC_FAIL(KC_ERR_UNSUPPORTED, "this build has no rehearsal transport");
+}
+#endif
 }  // namespace
 
 namespace kc {
@@ -228,6 +234,11 @@ int kc_comm_create(int rank, int world, const uint8_t id_in[KC_COMM_ID_BYTES], i
 }
 
 int kc_comm_create_shm(int rank, int world, const char *name, int device, kc_comm **out) {
+#ifdef KC_WITHOUT_REHEARSAL_TRANSPORT
+  (void)rank; (void)world; (void)name; (void)device;
+  if (out) *out = nullptr;
+  KC_FAIL(KC_ERR_UNSUPPORTED, "built with KC_WITHOUT_REHEARSAL_TRANSPORT: ranks exchange through RCCL only");
+#else
   if (!name || !out) KC_FAIL(KC_ERR_INVALID, "null argument");
   *out = nullptr;
   if (world < 1 || world > 64 || rank < 0 || rank >= world)
@@ -322,6 +333,7 @@ int kc_comm_create_shm(int rank, int world, const char *name, int device, kc_com
   }
   *out = m;
   return KC_OK;
+#endif
 }
 
 void kc_comm_destroy(kc_comm *m) {
