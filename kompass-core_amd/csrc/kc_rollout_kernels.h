@@ -296,7 +296,11 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   __shared__ int lrun[kFusedSamples];    // ... samples in the run of leader l
   __shared__ int runs_short;             // ... every run has at most kRunMax samples: the entry lanes write the increments
   constexpr int kRunMax = 4;
-  __shared__ double ltab[440];           // ... sin / cos (k / 128): what sincos reads
+  __shared__ double ltab[440];           // ... sin / cos (k / 128): what sincos reads, as FOUR ROWS of 110 (sn | ssn |
+                                         // cs | ccs): the lanes of a wavefront look up different k -- entries of four
+                                         // doubles side by side put every lane on one of 8 bank groups (LDS conflict
+                                         // share of the kernel 0.11 -> 0.29 when the table came into LDS, r3), rows of
+                                         // 110 doubles spread them over 32
   __shared__ double lom[kTrigOmegaLds];  // ... omega of the trig rows
   const bool box = a.c.enabled && a.c.shape == KC_BOX;
   constexpr int kTabPer = (440 + kFusedBlock - 1) / kFusedBlock, kOmPer = (kTrigOmegaLds + kFusedBlock - 1) / kFusedBlock;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
 #pragma unroll
     for (int u = 0; u < kTabPer; ++u) {
       const int j = tid + u * kFusedBlock;
-      if (j < 440) ltab[j] = tabv[u];
+      if (j < 440) ltab[(j & 3) * 110 + (j >> 2)] = tabv[u];
     }
 #pragma unroll
     for (int u = 0; u < kOmPer; ++u) {
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       for (; q + 4 <= k; q += 4) yaw = (((yaw + w) + w) + w) + w;
       for (; q < k; ++q) yaw += w;
       double sn, cs;
-      trig::sincos_exact(yaw, &sn, &cs, static_cast<const double *>(ltab));
+      trig::sincos_exact(yaw, &sn, &cs, trig::TabRows{ltab});
       if (k < steps) {
         if (direct_inc) {
           //   x += (vx*cos - vy*sin) * dt;  y += (vx*sin + vy*cos) * dt   (datatypes/path.h:24-30)

@@ -42,6 +42,13 @@ struct Bits {
 
 KC_TRIG_HD double absd(double x) { return __builtin_fabs(x); }
 
+// The table as do_sin / do_cos index it -- tab[4 i + c], c = 0..3: sn, ssn, cs, ccs of entry i -- held as four
+// rows of 110 (an LDS copy whose lanes look up different entries: see rollout_collide_kernel)
+struct TabRows {
+  const double *p;
+  KC_TRIG_HD double operator[](int k) const { return p[(k & 3) * 110 + (k >> 2)]; }
+};
+
 // do_sin / do_cos of s_sin.c: x + dx is the argument (|x + dx| < 0.86), tab = sincostab
 template <class Tab>
 KC_TRIG_HD double do_cos(double x, double dx, Tab tab) {
