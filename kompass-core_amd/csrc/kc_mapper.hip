@@ -856,8 +856,8 @@ int kc_mapper_create(int H, int W, float res, const float pos[3], float orient,
     large_bar = 0;
   }
   m->direct = large_bar != 0;
-  if (const char *e = std::getenv("KC_TRIG_COPY"))
-    if (e[0] == '1') m->direct = false;  // test hook: staged copies
+  if (const char *e = std::getenv("KC_MAPPER_STAGED"))
+    if (e[0] == '1') m->direct = false;  // test hook: the copies of a device without a large BAR
   if (const char *e = std::getenv("KC_MAPPER_TILES"))
     if (e[0] >= '0' && e[0] <= '3') m->tile_mode = e[0] - '0';
   *out = m;

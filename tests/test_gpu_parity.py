@@ -240,8 +240,11 @@ def test_mapper_parity(H, W, res, pos, orient, n, scale, tiles, monkeypatch):
     m.close()
 
 
-def test_mapper_fixture_scan():
-    """The reference's own 360-beam fixture (tests/resources/mapping/laserscan_data.json)."""
+@pytest.mark.parametrize("staged", ["0", "1"])
+def test_mapper_fixture_scan(staged, monkeypatch):
+    """The reference's own 360-beam fixture (tests/resources/mapping/laserscan_data.json); staged = the copies a
+    device without a large BAR gets (KC_MAPPER_STAGED, read when the context is made)."""
+    monkeypatch.setenv("KC_MAPPER_STAGED", staged)
     data = json.loads((Path(__file__).parent / "golden" / "laserscan_data.json").read_text())
     rng = np.array(data["ranges"], dtype=np.float64)
     ang = data["angle_min"] + np.arange(len(rng)) * data["angle_increment"]

@@ -1,5 +1,5 @@
 """python tools/run_cycles.py cfg scene w_path,w_goal,w_obs,w_smooth,w_jerk [cycles]: plain cycles of one scene (for
-rocprofv3 counter passes; switches via KC_FUSED_CYCLE / KC_COST_KERNEL)."""
+rocprofv3 counter passes)."""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "kompass-core_amd"))
