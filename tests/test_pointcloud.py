@@ -255,6 +255,91 @@ def test_oracle_typed_fields_decode_like_load_and_cast_val(ftype):
     assert (r < 50.0).sum() > 20
 
 
+def _libm_atan2f():
+    import ctypes
+    import ctypes.util
+    f = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6").atan2f
+    f.restype, f.argtypes = ctypes.c_float, [ctypes.c_float, ctypes.c_float]
+    return f
+
+
+_atan2f = _libm_atan2f()
+
+
+def _load_and_cast_bytes(buf, off, ftype):
+    """load_and_cast_val (utils/pointcloud.h:49-87) restated from the bytes up: the field's bytes are gathered one by
+    one from `off` (any alignment), assembled little-endian into the field's type, `static_cast<float>` of that."""
+    size = np.dtype(FIELD_DTYPES[ftype]).itemsize
+    raw = bytes(int(buf[off + i]) & 0xFF for i in range(size))
+    if ftype in (1, 3, 5):
+        return np.float32(int.from_bytes(raw, "little", signed=True))
+    if ftype in (2, 4, 6):
+        return np.float32(int.from_bytes(raw, "little", signed=False))
+    import struct
+    with np.errstate(over="ignore"):
+        return np.float32(struct.unpack("<f" if ftype == 7 else "<d", raw)[0])
+
+
+def _scan_from_bytes(buf, nbytes, step, n, offs, ftype, max_range, min_z, max_z, num_bins):
+    """pointCloudToLaserScanFromRaw (pointcloud.h:205-259) in plain Python over `_load_and_cast_bytes`; a record whose
+    furthest field would read past `nbytes` is skipped (:139-146, with the field's own size)."""
+    size = np.dtype(FIELD_DTYPES[ftype]).itemsize
+    out = np.full(num_bins, float(max_range))
+    for k in range(n):
+        start = k * step
+        if start + max(offs) + size > nbytes:
+            continue
+        x, y, z = (_load_and_cast_bytes(buf, start + o, ftype) for o in offs)
+        with np.errstate(over="ignore", invalid="ignore"):
+            r2 = np.float32(np.float32(x * x) + np.float32(y * y))
+        if float(r2) < 1e-6 or float(z) < min_z or (max_z >= 0.0 and float(z) > max_z):
+            continue
+        if not (np.isfinite(x) and np.isfinite(y)):
+            continue
+        ang = float(_atan2f(float(y), float(x)))   # std::atan2(float, float) = libm's atan2f (numpy's own float32
+        #                                            arctan2 is 1 ulp off at x == y, which moves points across bins)
+        if ang < 0.0:
+            ang += 2.0 * np.pi
+        b = min(int((ang / (2.0 * np.pi)) * num_bins), num_bins - 1)
+        d = float(np.sqrt(r2))
+        if d < out[b]:
+            out[b] = d
+    return out
+
+
+@pytest.mark.parametrize("ftype", sorted(FIELD_DTYPES))
+@pytest.mark.parametrize("lead", [0, 1, 3])
+def test_oracle_typed_decode_byte_by_byte(ftype, lead):
+    """the C oracle's typed decode against a restatement from the bytes up, per datatype: unaligned field
+    offsets (lead 1 and 3), extreme values (integers beyond 2^24 that round in the cast, UINT32 above 2^31, doubles
+    that overflow float, NaN / inf), and a buffer that ends INSIDE the last record's z field.
+    Parity of the non-FLOAT32 decode itself stays unpinned: the reference holds no fixture for it and uses
+    load_and_cast_val only inside its device kernels."""
+    dt = np.dtype(FIELD_DTYPES[ftype])
+    rng = np.random.default_rng(100 * ftype + lead)
+    n = 120
+    xyz = np.column_stack([rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), rng.uniform(0, 2, n)])
+    data, step, offs, vals = typed_cloud(xyz, ftype, pad=int(rng.integers(0, 4)), lead=lead)
+    data = data.copy()
+    rec = data.view(np.uint8).reshape(n, step)
+    if dt.kind in "iu":
+        info = np.iinfo(dt)
+        extremes = np.array([[info.max, info.min, 1], [info.min, info.max, 0], [info.max - 1, 3, 1],
+                             [16777217 % (int(info.max) + 1), 5, 1]], dtype=np.int64).astype(dt)
+    else:
+        big = 1e300 if ftype == 8 else 3e38
+        extremes = np.array([[big, 1.0, 1.0], [np.nan, 1.0, 1.0], [2.0, np.inf, 1.0], [-0.0, 1e-4, 1.0]], dtype=dt)
+    rec[:4, lead:lead + 3 * dt.itemsize] = extremes.view(np.uint8).reshape(4, -1)
+    nbytes = data.size - step + offs[2] + dt.itemsize - 1      # the last record's z field lacks its last byte
+    want = _scan_from_bytes(data, nbytes, step, n, offs, ftype, 60.0, -1.0, -1.0, 72)
+    got = ko.pointcloud_to_laserscan(data[:nbytes], step, n * step, 1, n, *offs, 60.0, -1.0, -1.0, num_bins=72,
+                                     field_type=ftype)
+    np.testing.assert_array_equal(got, want)
+    full = ko.pointcloud_to_laserscan(data, step, n * step, 1, n, *offs, 60.0, -1.0, -1.0, num_bins=72, field_type=ftype)
+    np.testing.assert_array_equal(full, _scan_from_bytes(data, data.size, step, n, offs, ftype, 60.0, -1.0, -1.0, 72))
+    assert (want < 60.0).sum() > 10
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("ftype", sorted(FIELD_DTYPES))
 def test_hip_typed_fields_match_oracle(ftype):
