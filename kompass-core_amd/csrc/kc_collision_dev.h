@@ -13,6 +13,7 @@ struct CollDev {
   int lds;          // stage the occupancy bits in LDS
   int kx0, ky0;     // window origin (voxel keys, octree frame)
   int W, H, wpr;    // window size in cells, 32-bit words per row
+  uint32_t wpr_magic;  // ceil(2^32 / wpr) (wpr > 1): word index / wpr == __umulhi(index, wpr_magic) for every index < 2^24
   double r00, r01, r10, r11;  // octree-frame rotation (float values widened)
   double tx, ty;              // octree-frame origin in the world
   double res, inv;            // voxel edge, 1/res (octomap resolution_factor)
@@ -51,6 +52,7 @@ struct RollArgs {
   // the sample list: value tables of the axes + per sample (index into vxt) | (index into vyt) << 16
   // (hm::VelocityLattice: a new window rewrites the small tables only)
   const double *vxt, *vyt;
+  int nvx, nvy;     // their lengths
   const uint32_t *vidx;
   const int32_t *row;
   const int32_t *perm;  // fused kernel: local sample ids ordered by omega row, so that the
@@ -114,6 +116,52 @@ __host__ __device__ inline void frozen_velocity_sums(float fvx, float fvy, float
 
 __device__ __forceinline__ double sample_vx(const RollArgs &a, int local) { return a.vxt[a.vidx[a.first + local] & 0xFFFFu]; }
 __device__ __forceinline__ double sample_vy(const RollArgs &a, int local) { return a.vyt[a.vidx[a.first + local] >> 16]; }
+
+// Kernel arguments of the large kernels (the cycle kernel: 1.3 KB = 21 cache lines) reach a wavefront through
+// scalar loads from the kernarg segment, and the compiler reloads them lazily -- one s_load + s_waitcnt per
+// struct member, in a row, each the first touch of its line (round 4 phase clocks: 3 us between two barriers of the
+// cycle kernel's phase A with nothing in it but 25 such pairs).  kernarg_touch asks for EVERY line of the segment
+// at once when the wavefront starts -- one scalar round trip; the lazy reloads then hit the scalar cache.
+// Lines beyond the segment are clamped to its last line (the segment may end a page).
+// The kernel then reads its arguments THROUGH the pointer the touch hands back (an opaque value to the compiler, so no
+// argument load can be placed in front of the touch; constant address space, so the loads stay scalar and may be
+// moved and merged like kernarg loads): `const auto &ka = *kernargs_touched<Args...>()`.
+template <class A, class B>
+struct KernargPair {  // the kernarg segment of a kernel (A, B): members in order, each at its own alignment
+  A a;
+  B b;
+};
+template <class A, class B, class C>
+struct KernargTriple {
+  A a;
+  B b;
+  C c;
+};
+template <class KA>
+__device__ __forceinline__ const KA *kernargs_touched() {
+  constexpr int kLines = (static_cast<int>(sizeof(KA)) + 63) / 64;
+  static_assert(kLines >= 1 && kLines <= 24, "kernargs_touched: up to 1536 bytes");
+  unsigned long long ka = reinterpret_cast<unsigned long long>(__builtin_amdgcn_kernarg_segment_ptr());
+  // (every load names the same destination: the values are never used, and the wait sits in the same block,
+  // so the register cannot be handed to anything else while a load is in flight)
+  unsigned int t;
+#define KC_KA_OFF(i) "i"(((i) < kLines ? (i) : kLines - 1) * 64)
+#define KC_KA_L(n) "s_load_dword %0, %1, %" #n "\n\t"
+  asm volatile(KC_KA_L(2) KC_KA_L(3) KC_KA_L(4) KC_KA_L(5) KC_KA_L(6) KC_KA_L(7) KC_KA_L(8) KC_KA_L(9) KC_KA_L(10)
+               KC_KA_L(11) KC_KA_L(12) KC_KA_L(13) KC_KA_L(14) KC_KA_L(15) KC_KA_L(16) KC_KA_L(17) KC_KA_L(18)
+               KC_KA_L(19) KC_KA_L(20) KC_KA_L(21) KC_KA_L(22) KC_KA_L(23) KC_KA_L(24) KC_KA_L(25)
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(t), "+s"(ka)
+               : KC_KA_OFF(0), KC_KA_OFF(1), KC_KA_OFF(2), KC_KA_OFF(3), KC_KA_OFF(4), KC_KA_OFF(5), KC_KA_OFF(6),
+                 KC_KA_OFF(7), KC_KA_OFF(8), KC_KA_OFF(9), KC_KA_OFF(10), KC_KA_OFF(11), KC_KA_OFF(12), KC_KA_OFF(13),
+                 KC_KA_OFF(14), KC_KA_OFF(15), KC_KA_OFF(16), KC_KA_OFF(17), KC_KA_OFF(18), KC_KA_OFF(19), KC_KA_OFF(20),
+                 KC_KA_OFF(21), KC_KA_OFF(22), KC_KA_OFF(23)
+               : "memory");
+#undef KC_KA_L
+#undef KC_KA_OFF
+  typedef const KA __attribute__((address_space(4))) *ConstPtr;
+  return (const KA *)reinterpret_cast<ConstPtr>(ka);
+}
 
 // Phase clocks for kernel tuning: compiled in only with -DKC_PHASE_STAMPS (the
 // product build carries none of it); KC_DEBUG_STAMPS=1 then dumps them when the

@@ -1897,7 +1897,11 @@ __device__ __forceinline__ void publish_body(const PubArgs &a) {
 // sums ran behind the cost kernel instead of beside it (CostEvaluator_5k_Trajs 0.198 -> 0.273 ms, round 3).
 template <bool kLds, bool kObsLds, bool kFold>
 __global__ __launch_bounds__(kCostBlock)
-__attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_cost_kernel(CostArgs a, DcArgs t, PubArgs pub) {
+__attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_cost_kernel(CostArgs a_, DcArgs t_, PubArgs pub_) {
+  const KernargTriple<CostArgs, DcArgs, PubArgs> *ka_ = kernargs_touched<KernargTriple<CostArgs, DcArgs, PubArgs>>();
+  const CostArgs &a = ka_->a;  // (the arguments as read behind the touch of every kernarg line)
+  const DcArgs &t = ka_->b;
+  const PubArgs &pub = ka_->c;
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ long long s_key;
   __shared__ unsigned long long s_obest[kCostWaves];  // per sample: min squared obstacle distance (double bits)
@@ -2024,7 +2028,11 @@ __attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_c
 // the end point's index search, four correctly rounded divisions, the weighted total: ~310 of ~900 wave
 // instructions per sample -- becomes ~7.  No barrier between the groups.
 template <bool kObsLds>
-__global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArgs a, DcArgs t, PubArgs pub) {
+__global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArgs a_, DcArgs t_, PubArgs pub_) {
+  const KernargTriple<CostArgs, DcArgs, PubArgs> *ka_ = kernargs_touched<KernargTriple<CostArgs, DcArgs, PubArgs>>();
+  const CostArgs &a = ka_->a;  // (the arguments as read behind the touch of every kernarg line)
+  const DcArgs &t = ka_->b;
+  const PubArgs &pub = ka_->c;
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ long long s_key;
   __shared__ int s_next;      // next sample slot of this workgroup

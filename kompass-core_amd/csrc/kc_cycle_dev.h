@@ -22,12 +22,12 @@ constexpr int kTeamMaxSurvivors = 4;  // one or two survivors: half the workgrou
                                       // point (one pass either way); more: one per wavefront
 
 // LDS layout of the cost tables behind tab_off (the host sizes it the same way:
-// cycle_table_bytes in kc_dwa.hip)
+// cycle_table_bytes in kc_dwa_cycle.hip); every table starts on a 16-byte boundary
 struct CycleTabs {
   float4 *xy, *za;  // [seg_pairs_padded] pair records of the segment points (struct SegPairs)
   float *cap;       // [8][nch] capsules, then [4][nsup] spheres, then [8][nsup] super-chunk capsules
-  int *cells;       // [ncell + 1]
-  uint8_t *skip;    // [ncell padded to 4]
+  int *cells;       // [ncell + 1], padded to 4
+  uint8_t *skip;    // [ncell], padded to 16
   float *mind;      // [4][P] team scratch
 };
 __device__ __forceinline__ CycleTabs cycle_tabs(const CostArgs &c, unsigned char *smem, unsigned tab_off) {
@@ -37,12 +37,13 @@ __device__ __forceinline__ CycleTabs cycle_tabs(const CostArgs &c, unsigned char
   t.xy = reinterpret_cast<float4 *>(smem + tab_off);
   t.za = t.xy + npp;
   t.cap = reinterpret_cast<float *>(t.za + npp);
-  t.cells = reinterpret_cast<int *>(t.cap + (c.use_seg ? 8 * c.nch + 12 * c.nsup : 0));
-  t.skip = reinterpret_cast<uint8_t *>(t.cells + (c.use_obs ? ncell + 1 : 0));
-  t.mind = reinterpret_cast<float *>(t.skip + (c.use_obs ? ((ncell + 3) & ~3) : 0));
+  t.cells = reinterpret_cast<int *>(t.cap + (c.use_seg ? (8 * c.nch + 12 * c.nsup + 3) & ~3 : 0));
+  t.skip = reinterpret_cast<uint8_t *>(t.cells + (c.use_obs ? (ncell + 1 + 3) & ~3 : 0));
+  t.mind = reinterpret_cast<float *>(t.skip + (c.use_obs ? ((ncell + 15) & ~15) : 0));
   return t;
 }
 
+// the plain copy loops (tables beyond what CycleTabRegs holds)
 template <class Tail>
 __device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned char *smem, int tid, int nthreads) {
   const CostArgs &c = tail.c;
@@ -55,38 +56,38 @@ __device__ __forceinline__ void cycle_fill_tables(const Tail &tail, unsigned cha
   }
   if (c.use_obs) {
     const int ncell = c.b.W * c.b.H;
-#pragma unroll 4
-    for (int j = tid; j <= ncell; j += nthreads) t.cells[j] = c.b.cell_start[j];
-    // the skip table is padded to a multiple of 4 bytes on the host
-    const uint32_t *gs = reinterpret_cast<const uint32_t *>(c.b.skip);
-    uint32_t *ls = reinterpret_cast<uint32_t *>(t.skip);
-    for (int j = tid; j < (ncell + 3) / 4; j += nthreads) ls[j] = gs[j];
+    // (both tables are allocated with room for the last vector: kc_dwa_sensor.hip)
+    const int4 *gcell = reinterpret_cast<const int4 *>(c.b.cell_start);
+    int4 *lcell = reinterpret_cast<int4 *>(t.cells);
+    for (int j = tid; j < (ncell + 1 + 3) / 4; j += nthreads) lcell[j] = gcell[j];
+    const uint4 *gs = reinterpret_cast<const uint4 *>(c.b.skip);
+    uint4 *ls = reinterpret_cast<uint4 *>(t.skip);
+    for (int j = tid; j < (ncell + 15) / 16; j += nthreads) ls[j] = gs[j];
   }
 }
 
 // The same in two halves -- every global load first (into registers), the LDS
-// stores later -- so that the caller can put its other phase-A loads (window
-// bits) in between and pay ONE memory latency for all of them instead of one
-// per copy loop.  Capacity: one segment pair, two capsule words, five cell
-// words and two skip words per thread; `ok` false: the plain loops above.
+// stores later -- so that ONE memory latency is paid for all of them instead of one
+// per copy loop.  Capacity: one segment pair, two capsule words, two vectors of four
+// cell words and one of sixteen skip bytes per thread; `ok` false: the plain loops above.
+// The threads that copy are the caller's choice (tid 0 .. nthreads - 1).
+typedef int CycleV4i __attribute__((ext_vector_type(4)));  // (native vectors: the registers of a thread, never memory)
 template <int kBlock>
 struct CycleTabRegs {
   float4 sxy, sza;
   float cap[2];
-  int cells[5];
-  uint32_t skip[2];
+  CycleV4i cells[2];
+  CycleV4i skip;
   bool ok;
 };
 template <int kBlock, class Tail>
 __device__ __forceinline__ void cycle_tables_load(const Tail &tail, int tid, int nthreads, CycleTabRegs<kBlock> &r) {
-  // (threads 0 .. nthreads - 1 copy: the trig waves of a device-trig launch stay out of it)
   const CostArgs &c = tail.c;
   const int ncell = c.use_obs ? c.b.W * c.b.H : 0;
   const int capw = c.use_seg ? 8 * c.nch + 12 * c.nsup : 0;
   const int npp = c.use_seg ? seg_pairs_padded(c.nch, c.seg_chunk) : 0;
-  r.ok = npp <= nthreads && capw <= 2 * nthreads && ncell + 1 <= 5 * nthreads &&
-         (ncell + 3) / 4 <= 2 * nthreads;
-  if (!r.ok || tid >= nthreads) return;
+  r.ok = npp <= nthreads && capw <= 2 * nthreads && (ncell + 1 + 3) / 4 <= 2 * nthreads && (ncell + 15) / 16 <= nthreads;
+  if (!r.ok) return;
   if (c.use_seg) {
     if (tid < npp) seg_pair_from_rows(c.sx, c.sy, c.szz, c.acc_seg, c.S, tid, r.sxy, r.sza);
     const float *gc = c.sx + seg_cap_offset(c.S);
@@ -97,24 +98,21 @@ __device__ __forceinline__ void cycle_tables_load(const Tail &tail, int tid, int
     }
   }
   if (c.use_obs) {
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int j = tid + u * nthreads;
-      if (j <= ncell) r.cells[u] = c.b.cell_start[j];
-    }
-    const uint32_t *gs = reinterpret_cast<const uint32_t *>(c.b.skip);
+    const CycleV4i *gcell = reinterpret_cast<const CycleV4i *>(c.b.cell_start);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int j = tid + u * nthreads;
-      if (j < (ncell + 3) / 4) r.skip[u] = gs[j];
+      r.cells[u] = CycleV4i{0, 0, 0, 0};
+      if (j < (ncell + 1 + 3) / 4) r.cells[u] = gcell[j];
     }
+    r.skip = CycleV4i{0, 0, 0, 0};
+    if (tid < (ncell + 15) / 16) r.skip = reinterpret_cast<const CycleV4i *>(c.b.skip)[tid];
   }
 }
 template <int kBlock, class Tail>
 __device__ __forceinline__ void cycle_tables_store(const Tail &tail, unsigned char *smem, int tid, int nthreads,
                                                    const CycleTabRegs<kBlock> &r) {
   const CostArgs &c = tail.c;
-  if (tid >= nthreads) return;
   if (!r.ok) {
     cycle_fill_tables(tail, smem, tid, nthreads);
     return;
@@ -134,17 +132,13 @@ __device__ __forceinline__ void cycle_tables_store(const Tail &tail, unsigned ch
     }
   }
   if (c.use_obs) {
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int j = tid + u * nthreads;
-      if (j <= ncell) t.cells[j] = r.cells[u];
-    }
-    uint32_t *ls = reinterpret_cast<uint32_t *>(t.skip);
+    CycleV4i *lcell = reinterpret_cast<CycleV4i *>(t.cells);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int j = tid + u * nthreads;
-      if (j < (ncell + 3) / 4) ls[j] = r.skip[u];
+      if (j < (ncell + 1 + 3) / 4) lcell[j] = r.cells[u];
     }
+    if (tid < (ncell + 15) / 16) reinterpret_cast<CycleV4i *>(t.skip)[tid] = r.skip;
   }
 }
 

@@ -419,9 +419,9 @@ void kc_dwa_destroy(kc_dwa *c) {
     e = hipMemcpy(h.data(), c->d_dbg2.p, h.size() * 8, hipMemcpyDeviceToHost);
     unsigned long long t0 = ~0ull;
     for (int b = 0; b < 512; ++b) if (h[b * 32]) t0 = std::min(t0, h[b * 32]);
-    const char *nm[20] = {"start", "phase A done", "trig entries in LDS", "increments in LDS", "recurrence done", "poses checked", "flags out", "increments done", "costs done", "epilogue done", "pass 0 searched", "pass 0 barrier", "pass 0 total", "poses classified / ticket", "last: reduced", "", "A: loads issued", "A: window stored", "A: sincos / omega stored", "A: cost tables stored"};
+    const char *nm[22] = {"start", "phase A done", "trig entries in LDS", "increments in LDS", "recurrence done", "poses checked", "flags out", "increments done", "costs done", "epilogue done", "pass 0 searched", "pass 0 barrier", "pass 0 total", "poses classified / ticket", "last: reduced", "", "A: small tables in LDS", "A: bulk loads issued", "A: trig entries formed", "A: window stored", "A: table loads issued", ""};
     std::fprintf(stderr, "[kc stamps] roll-out kernel, us since first block start (avg / max):\n");
-    for (int k = 0; k < 20; ++k) {
+    for (int k = 0; k < 22; ++k) {
       if (k == 15) continue;
       double sm = 0, mx = 0; int nb = 0;
       for (int b = 0; b < 512; ++b) {

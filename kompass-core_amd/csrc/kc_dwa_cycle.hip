@@ -70,6 +70,7 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
     cd.gwpr = c->gwpr;
   }
   cd.wpr = (cd.W + 31) / 32;
+  cd.wpr_magic = cd.wpr > 1 ? 0xFFFFFFFFu / static_cast<uint32_t>(cd.wpr) + 1u : 0u;
   cd.enabled = 1;
   return KC_OK;
 }
@@ -665,10 +666,10 @@ size_t cycle_table_bytes(const CostArgs &ca) {
   size_t b = 0;
   if (ca.use_seg)
     b += 32 * static_cast<size_t>(seg_pairs_padded(ca.nch, ca.seg_chunk)) +
-         4 * (8 * static_cast<size_t>(ca.nch) + 12 * static_cast<size_t>(ca.nsup));
+         4 * ((8 * static_cast<size_t>(ca.nch) + 12 * static_cast<size_t>(ca.nsup) + 3) & ~size_t(3));
   if (ca.use_obs) {
     const size_t ncell = static_cast<size_t>(ca.b.W) * ca.b.H;
-    b += 4 * (ncell + 1) + ((ncell + 3) & ~size_t(3));
+    b += 4 * ((ncell + 1 + 3) & ~size_t(3)) + ((ncell + 15) & ~size_t(15));  // (16-byte rows: copied as vectors)
   }
   return b + 4 * static_cast<size_t>(ca.P) * 4;
 }
@@ -809,6 +810,8 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   a.dt = dt;
   a.vxt = c->d_vxt.p;
   a.vyt = c->d_vyt.p;
+  a.nvx = static_cast<int>(c->lat.vx_values.size());
+  a.nvy = static_cast<int>(c->lat.vy_values.size());
   a.vidx = c->d_vidx.p;
   a.row = c->d_row.p;
   a.trig = c->d_trig.p;

@@ -258,13 +258,13 @@ int upload_obstacles(kc_dwa *c, size_t n) {
     b.g = 1.0;
     b.inv_g = 1.0;
     KC_TRY(c->h_cells.reserve(2));
-    KC_TRY(c->d_cells.reserve(2));
+    KC_TRY(c->d_cells.reserve(8));
     c->h_cells.p[0] = c->h_cells.p[1] = 0;
     KC_HIP(hipMemcpyAsync(c->d_cells.p, c->h_cells.p, 2 * sizeof(int),
                           hipMemcpyHostToDevice, c->stream));
     KC_TRY(c->d_bobs.reserve(2));
     KC_TRY(c->h_skip.reserve(4));
-    KC_TRY(c->d_skip.reserve(4));
+    KC_TRY(c->d_skip.reserve(16));
     std::memset(c->h_skip.p, 255, 4);
     KC_HIP(hipMemcpyAsync(c->d_skip.p, c->h_skip.p, 4, hipMemcpyHostToDevice, c->stream));
     b.skip = c->d_skip.p;
@@ -290,7 +290,7 @@ int upload_obstacles(kc_dwa *c, size_t n) {
   b.H = std::min(kMaxSide, static_cast<int>((hiy - loy) * b.inv_g) + 1);
   const size_t ncell = static_cast<size_t>(b.W) * b.H;
   KC_TRY(c->h_cells.reserve(ncell + 1));
-  KC_TRY(c->d_cells.reserve(ncell + 1));
+  KC_TRY(c->d_cells.reserve(ncell + 4));   // (+ the tail of the cycle kernel's 16-byte copies)
   KC_TRY(c->h_bobs.reserve(2 * nf));
   KC_TRY(c->d_bobs.reserve(2 * nf));
   int *cs = c->h_cells.p;
@@ -325,7 +325,7 @@ int upload_obstacles(kc_dwa *c, size_t n) {
   // with the 8-neighbourhood are exact for the Chebyshev metric); a border of
   // 255 around the table keeps the inner loops free of range tests
   KC_TRY(c->h_skip.reserve(ncell + 4));
-  KC_TRY(c->d_skip.reserve(ncell + 4));
+  KC_TRY(c->d_skip.reserve(ncell + 16));
   {
     const int W = b.W, H = b.H, Wp = W + 2;
     c->skip_pad.assign(static_cast<size_t>(Wp) * (H + 2), 255);
@@ -639,8 +639,8 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   b.W = std::min(side, static_cast<int>((bhi[0] - blo[0]) * b.inv_g) + 1);
   b.H = std::min(side, static_cast<int>((bhi[1] - blo[1]) * b.inv_g) + 1);
   const size_t ncell = static_cast<size_t>(b.W) * b.H;
-  KC_TRY(c->d_cells.reserve(ncell + 1));
-  KC_TRY(c->d_skip.reserve(ncell + 4));
+  KC_TRY(c->d_cells.reserve(ncell + 4));   // (+ the tail of the cycle kernel's 16-byte copies)
+  KC_TRY(c->d_skip.reserve(ncell + 16));
   KC_TRY(c->d_bobs.reserve(2 * n));
   KC_TRY(c->d_raw.reserve(3 * n + 16));
   // the raw points: host copy for the lazy lists, device copy through the BAR

@@ -460,7 +460,8 @@ __device__ __forceinline__ void sensor_bucket_body(const SensorFusedArgs &s, int
 }
 
 template <bool kLds>
-__global__ __launch_bounds__(kSensorBlock) void sensor_fused_kernel(SensorFusedArgs s) {
+__global__ __launch_bounds__(kSensorBlock) void sensor_fused_kernel(SensorFusedArgs s_) {
+  const SensorFusedArgs &s = *kernargs_touched<SensorFusedArgs>();  // (every kernarg line asked for at once)
   extern __shared__ __align__(16) unsigned char smem[];
   const int b = static_cast<int>(blockIdx.x);
   if (b < s.nb) sensor_band_body(s, b, smem);

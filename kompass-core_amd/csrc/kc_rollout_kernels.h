@@ -255,8 +255,12 @@ struct CycleTail {
 };
 
 template <int kFusedSamples, int kFusedBlock, class Tail = NoTail>
-__global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a, Tail tail) {
+__global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a_, Tail tail_) {
   constexpr bool kCycle = !std::is_same<Tail, NoTail>::value;
+  // (the arguments as read behind the touch of every kernarg line: see kernargs_touched)
+  const KernargPair<RollArgs, Tail> *ka_ = kCycle ? kernargs_touched<KernargPair<RollArgs, Tail>>() : nullptr;
+  const RollArgs &a = kCycle ? ka_->a : a_;
+  const Tail &tail = kCycle ? ka_->b : tail_;
   extern __shared__ __align__(16) unsigned char smem[];
   const int PP = a.P | 1;  // pitch of a sample's row in 16-byte slots
   double2 *lpos = reinterpret_cast<double2 *>(smem);
@@ -302,6 +306,8 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
                                          // share of the kernel 0.11 -> 0.29 when the table came into LDS, r3), rows of
                                          // 110 doubles spread them over 32
   __shared__ double lom[kTrigOmegaLds];  // ... omega of the trig rows
+  constexpr int kVxLds = 128, kVyLds = 64;
+  __shared__ double lvx[kVxLds], lvy[kVyLds];  // ... the value tables of the x / y axes (the head of longer ones)
   const bool box = a.c.enabled && a.c.shape == KC_BOX;
   constexpr int kTabPer = (440 + kFusedBlock - 1) / kFusedBlock, kOmPer = (kTrigOmegaLds + kFusedBlock - 1) / kFusedBlock;
   // the per-slot words of the workgroup (+ device trig: the leaders of the row runs)
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
     }
   };
   if (a.trig_dev) {
-    double tabv[kTabPer], omv[kOmPer];
+    double tabv[kTabPer], omv[kOmPer], vxv = 0.0, vyv = 0.0;
 #pragma unroll
     for (int u = 0; u < kTabPer; ++u) {
       const int j = tid + u * kFusedBlock;
@@ -349,6 +355,10 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const int j = tid + u * kFusedBlock;
       omv[u] = (j < kTrigOmegaLds && j < a.A) ? a.omega_values[j] : 0.0;
     }
+    // (the value tables of the axes from the far end of the workgroup: the lanes in front hold sample ids)
+    const int jv = kFusedBlock - 1 - tid;
+    if (jv < kVxLds && jv < a.nvx) vxv = a.vxt[jv];
+    if (jv >= kVxLds && jv < kVxLds + kVyLds && jv - kVxLds < a.nvy) vyv = a.vyt[jv - kVxLds];
 #pragma unroll
     for (int u = 0; u < kTabPer; ++u) {
       const int j = tid + u * kFusedBlock;
@@ -359,12 +369,24 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const int j = tid + u * kFusedBlock;
       if (j < kTrigOmegaLds) lom[j] = omv[u];
     }
+    if (jv < kVxLds) lvx[jv] = vxv;
+    else if (jv < kVxLds + kVyLds) lvy[jv - kVxLds] = vyv;
     slot_words();
     __syncthreads();
   }
-  // the bulk loads: cost tables (cycle) and the first round of the window words, into registers
-  CycleTabRegs<kFusedBlock> tabregs;
-  if constexpr (kCycle) cycle_tables_load<kFusedBlock>(tail, tid, kFusedBlock, tabregs);
+  KC_RSTAMP(16);
+  // Behind the barrier the wavefronts split the rest of the phase (device trig): the ones that own trig entries
+  // -- a lane per (leader, step), the first waves of the workgroup -- form them from LDS alone; the waves behind
+  // them fetch the cost tables of the cycle's last phase meanwhile (loads, the wait, the LDS stores).  Everybody
+  // brings in the window words (issued first: vector loads return in order, and the window is what phase C
+  // needs).  Without device trig every thread copies.
+  const int L = a.trig_dev ? nlead : 0;
+  int sh = 0;
+  while ((1 << sh) < L) ++sh;
+  const int ktop = steps + (box ? 1 : 0);  // (boxes: yaw of the last pose too, for the exact tests)
+  const int nentry = a.trig_dev ? (ktop << sh) : 0;
+  // first thread of the table copy: behind the entry lanes, but at least a quarter of the workgroup copies
+  const int tab_t0 = min((nentry + 63) & ~63, kFusedBlock - kFusedBlock / 4);
   const bool win = a.c.enabled != 0;
   const int nwords = a.c.enabled ? a.c.H * a.c.wpr : 0;
   const int w0 = a.c.enabled ? (a.c.kx0 - a.c.gkx0) >> 5 : 0;  // exact: difference is a multiple of 32
@@ -376,7 +398,9 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const int i = i0 + tid + u * kFusedBlock;
       v[u] = vi[u] = vo[u] = 0u;
       if (i < nwords) {
-        const int cy = i / a.c.wpr, w = i - cy * a.c.wpr;
+        // i / wpr by the host's reciprocal (CollDev::wpr_magic)
+        const int cy = a.c.wpr > 1 ? static_cast<int>(__umulhi(static_cast<uint32_t>(i), a.c.wpr_magic)) : i;
+        const int w = i - cy * a.c.wpr;
         const int gy = a.c.ky0 + cy - a.c.gky0, gw = w0 + w;
         if (gy >= 0 && gy < a.c.gH && gw >= 0 && gw < a.c.gwpr) {
           const size_t g = (size_t)gy * a.c.gwpr + gw;
@@ -404,28 +428,47 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
   };
   uint32_t wv[3], wvi[3], wvo[3];
   if (win) win_load(0, wv, wvi, wvo);
+  KC_RSTAMP(17);
+  if constexpr (kCycle)
+    if (tid >= tab_t0) {
+      CycleTabRegs<kFusedBlock> tabregs;
+      cycle_tables_load<kFusedBlock>(tail, tid - tab_t0, kFusedBlock - tab_t0, tabregs);
+      cycle_tables_store<kFusedBlock>(tail, smem, tid - tab_t0, kFusedBlock - tab_t0, tabregs);
+    }
+  KC_RSTAMP(20);
   // device trig: the sample's velocity (for the increments) and {cos, sin}(yaw_k) of every distinct row into
-  // the LDS pose row of its leader, a lane per entry -- LDS and VALU only, under the loads just issued
+  // the LDS pose row of its leader, a lane per entry -- LDS and VALU only
   const int s = tid & (kFusedSamples - 1);
   const bool mine = s < rows;
   double vx = 0.0, vy = 0.0;
   const bool direct_inc = a.trig_dev && runs_short != 0;  // (read behind the early barrier; uniform)
+  // (the LDS copy is read unconditionally and a value beyond it replaces the result: `c ? lds[j] : global[j]` would
+  // select between the two ADDRESSES and load once through a flat pointer -- a load that counts as a vector load and
+  // waits, in order, behind every window word still in flight)
+  auto axis_vx = [&](uint32_t vi) {
+    const int j = static_cast<int>(vi & 0xFFFFu);
+    double v = lvx[j & (kVxLds - 1)];
+    if (j >= kVxLds) v = *static_cast<const volatile double *>(a.vxt + j);  // (volatile: never merged with the LDS read)
+    return v;
+  };
+  auto axis_vy = [&](uint32_t vi) {
+    const int j = static_cast<int>(vi >> 16);
+    double v = lvy[j & (kVyLds - 1)];
+    if (j >= kVyLds) v = *static_cast<const volatile double *>(a.vyt + j);
+    return v;
+  };
   if (a.trig_dev) {
     if (mine && !direct_inc) {
       const uint32_t vi = lvi[s];
-      vx = a.vxt[vi & 0xFFFFu];
-      vy = a.vyt[vi >> 16];
+      vx = axis_vx(vi);
+      vy = axis_vy(vi);
     }
-    const int L = nlead;
-    int sh = 0;
-    while ((1 << sh) < L) ++sh;
-    const int ktop = steps + (box ? 1 : 0);  // (boxes: yaw of the last pose too, for the exact tests)
-    for (int i = tid; i < (ktop << sh); i += kFusedBlock) {
+    for (int i = tid; i < nentry; i += kFusedBlock) {
       const int l = i & ((1 << sh) - 1), k = i >> sh;
       if (l >= L) continue;
       const int sl = llead[l], r = lrow[sl];
       // short runs (the dealt order of the cycle: four samples per row): this lane also forms the increments of
-      // the run's samples from its entry -- their velocities are asked for now, used behind the sincos
+      // the run's samples from its entry
       const int run = direct_inc ? lrun[l] : 0;
       double rvx[kRunMax], rvy[kRunMax];
 #pragma unroll
@@ -433,13 +476,12 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
         rvx[u] = rvy[u] = 0.0;
         if (u < run) {
           const uint32_t vi = lvi[sl + u];
-          rvx[u] = a.vxt[vi & 0xFFFFu];
-          rvy[u] = a.vyt[vi >> 16];
+          rvx[u] = axis_vx(vi);
+          rvy[u] = axis_vy(vi);
         }
       }
-      double om;
-      if (r < kTrigOmegaLds) om = lom[r];
-      else om = a.omega_values[r];
+      double om = lom[min(r, kTrigOmegaLds - 1)];
+      if (r >= kTrigOmegaLds) om = *static_cast<const volatile double *>(a.omega_values + r);
       const double w = om * a.dt;
       double yaw = a.yaw0;
       int q = 0;
@@ -464,6 +506,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       if (box) a.trig_out[(size_t)k * a.A + r] = make_double2(cs, sn);
     }
   }
+  KC_RSTAMP(18);
   if (win) {
     win_store(0, wv, wvi, wvo);
     for (int i0 = 3 * kFusedBlock; i0 < nwords; i0 += 3 * kFusedBlock) {
@@ -471,7 +514,7 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       win_store(i0, wv, wvi, wvo);
     }
   }
-  if constexpr (kCycle) cycle_tables_store<kFusedBlock>(tail, smem, tid, kFusedBlock, tabregs);
+  KC_RSTAMP(19);
   if (!a.trig_dev) slot_words();
   KC_RSTAMP(1);
   if (direct_inc) {

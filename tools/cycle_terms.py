@@ -13,7 +13,8 @@ ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 
 ctx.set_points(inp["state"], inp["points"], inp["max_range"])
 ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
 ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
-for w in ((1, 1, 1, 0, 0), (1, 1, 0, 0, 0), (0, 0, 1, 0, 0), (1, 0, 0, 0, 0), (0, 1, 0, 0, 0)):
+print('default weights', inp['weights'])
+for w in (tuple(inp['weights']), (1, 1, 1, 0, 0), (1, 1, 0, 0, 0), (0, 0, 1, 0, 0), (1, 0, 0, 0, 0), (0, 1, 0, 0, 0), (0, 0, 0, 1, 1), (0, 0, 0, 1, 0)):
     ctx.set_weights(kh.make_weights(*[float(v) for v in w]))
     for i in range(100): r = ctx.cycle((0.0, 0.0, 1e-3 * (i % 7 - 3), 0.0), P)
     t0 = time.perf_counter()
