@@ -903,7 +903,8 @@ __device__ __forceinline__ float team_sample_total(const CostArgs &a, int n, int
 }
 
 template <bool kLds, bool kObsLds>
-__global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(CostArgs a) {
+__global__ __launch_bounds__(kBlkCostBlock, 4) void sample_cost_block_kernel(CostArgs a_) {
+  const CostArgs &a = *kernargs_touched<CostArgs>();  // (the arguments as read behind the touch of every kernarg line)
   extern __shared__ __align__(16) unsigned char smem[];
   float *s_mind = reinterpret_cast<float *>(smem);               // [P]
   float *s_px = s_mind + a.P;                                    // [P]

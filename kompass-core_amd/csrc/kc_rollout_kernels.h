@@ -258,9 +258,9 @@ template <int kFusedSamples, int kFusedBlock, class Tail = NoTail>
 __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a_, Tail tail_) {
   constexpr bool kCycle = !std::is_same<Tail, NoTail>::value;
   // (the arguments as read behind the touch of every kernarg line: see kernargs_touched)
-  const KernargPair<RollArgs, Tail> *ka_ = kCycle ? kernargs_touched<KernargPair<RollArgs, Tail>>() : nullptr;
-  const RollArgs &a = kCycle ? ka_->a : a_;
-  const Tail &tail = kCycle ? ka_->b : tail_;
+  const KernargPair<RollArgs, Tail> *ka_ = kernargs_touched<KernargPair<RollArgs, Tail>>();
+  const RollArgs &a = ka_->a;
+  const Tail &tail = kCycle ? ka_->b : tail_;  // (NoTail is empty: nothing to read)
   extern __shared__ __align__(16) unsigned char smem[];
   const int PP = a.P | 1;  // pitch of a sample's row in 16-byte slots
   double2 *lpos = reinterpret_cast<double2 *>(smem);
@@ -469,16 +469,17 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
       const int sl = llead[l], r = lrow[sl];
       // short runs (the dealt order of the cycle: four samples per row): this lane also forms the increments of
       // the run's samples from its entry
+      // (every read unconditional -- slots beyond the run are read and not used: four LDS reads in flight, then
+      // eight, instead of a wait per sample)
       const int run = direct_inc ? lrun[l] : 0;
+      uint32_t rvi[kRunMax];
+#pragma unroll
+      for (int u = 0; u < kRunMax; ++u) rvi[u] = lvi[min(sl + u, kFusedSamples - 1)];
       double rvx[kRunMax], rvy[kRunMax];
 #pragma unroll
       for (int u = 0; u < kRunMax; ++u) {
-        rvx[u] = rvy[u] = 0.0;
-        if (u < run) {
-          const uint32_t vi = lvi[sl + u];
-          rvx[u] = axis_vx(vi);
-          rvy[u] = axis_vy(vi);
-        }
+        rvx[u] = axis_vx(rvi[u]);
+        rvy[u] = axis_vy(rvi[u]);
       }
       double om = lom[min(r, kTrigOmegaLds - 1)];
       if (r >= kTrigOmegaLds) om = *static_cast<const volatile double *>(a.omega_values + r);
