@@ -218,12 +218,18 @@ __global__ __launch_bounds__(256) void dilate_kernel(DilArgs a) {
 // leave the cost phase to a few workgroups.
 // Device trig inside the fused kernel (kc_trig_exact.h).  The samples of a workgroup share a few omega rows and
 // rows are non-decreasing in slot order (build_perm: row-sorted order, dealt in runs): the first slot of a
-// run is its LEADER.  Phase A brings the 440-entry table sincos reads and the omega values into LDS with the
-// other tables (one more bulk load per thread: vector loads return in order, a table read from global memory
-// issued behind them would wait for all of them), wavefront 0 lists the leaders; behind the phase's barrier
-// a lane per (leader, step) forms yaw_k by repeated addition from yaw0 (path.h:30: the additions of the
-// steps in front of k, in the lane itself), evaluates sincos and leaves {cos, sin} in the leader's LDS
-// pose row; every sample then forms its increments from its leader's entries.
+// run is its LEADER.  Phase A, round 4:
+//   (0) every kernarg line is asked for at once and the arguments are read through the pointer that block hands
+//       back (kernargs_touched, kc_collision_dev.h: scalar reloads at the use sites instead of SGPR spills -- the
+//       kernel is VALU-issue bound inside its phases, and a spilled scalar is a vector instruction);
+//   (1) the SMALL loads: sample ids, the 440-entry table sincos reads, the omega values, the value tables of the
+//       x / y axes -> LDS; wavefront 0 lists the leaders; barrier;
+//   (2) everybody issues its window words; then by wavefront role: the waves that own trig entries -- a lane per
+//       (leader, step) -- form yaw_k by repeated addition from yaw0 (path.h:30: the additions of the steps in
+//       front of k, in the lane itself), evaluate sincos and leave the increments of the run's samples (short
+//       runs) or {cos, sin} in the leader's LDS pose row, from LDS alone; the waves behind them fetch the cost
+//       tables of the cycle's last phase meanwhile (16-byte copies);
+//   (3) the window words go to LDS; barrier.
 constexpr int kTrigOmegaLds = 384;  // omega values kept in LDS (more rows: read from global memory)
 
 struct NoTail {};
