@@ -135,6 +135,9 @@ struct DcArgs {
   const float *osx, *osy;   // [on] obstacle coordinates in SCAN order (what setPointScan computes)
   const float *oaabb;       // [4][64] xmin | xmax | ymin | ymax of the chunks (empty chunks: +inf boxes)
   int on, ocs, onch;
+  // long scans (chunks of 32 obstacles and more): every chunk in four quarters of `oscs` obstacles with boxes of
+  // their own, [4][256] behind the chunk boxes (quarter q of chunk c: entry 4 c + q); 0: no quarters
+  int oscs;
   double ocap;              // max_obstacles_dist
   int ounion;               // > 0: obstacle_union_scan for rectangles of at most this many obstacles
 };
@@ -1414,6 +1417,30 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
                             !(lb2 >= shared);
           if (__ballot(part) == 0ull) continue;
           const int j0 = c * t.ocs, j1 = min(j0 + t.ocs, t.on);
+          if (t.oscs > 0) {
+            // a quarter of the chunk at a time: the same test against the quarter's own box, the bound refreshed
+            // behind every quarter that was scanned (a 4096-beam scan has chunks of 64 obstacles: most of a chunk
+            // the table names lies beyond what a neighbouring quarter has already found)
+            const float *sb = t.oaabb + 256;
+            for (int q = 0; q < 4; ++q) {
+              const int s0 = j0 + q * t.oscs, s1 = min(s0 + t.oscs, j1);
+              if (s0 >= s1) break;
+              const int e4 = 4 * c + q;
+              const float qx0 = sb[e4], qx1 = sb[256 + e4], qy0 = sb[512 + e4], qy1 = sb[768 + e4];
+              const float hx = fmaxf(fmaxf(qx0 - x, x - qx1), 0.0f), hy = fmaxf(fmaxf(qy0 - y, y - qy1), 0.0f);
+              const double lq2 = static_cast<double>(hx * hx + hy * hy) * (1.0 - 1e-4);
+              if (__ballot(part && !(lq2 >= shared)) == 0ull) continue;
+              for (int jb = s0; jb < s1; jb += 4) {
+                double d[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) d[u] = exact_dd(min(jb + u, s1 - 1));
+#pragma unroll
+                for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);
+              }
+              shared = fmin(shared, wave_min_nonneg(best));
+            }
+            continue;
+          }
           for (int jb = j0; jb < j1; jb += 4) {
             double d[4];
 #pragma unroll

@@ -25,6 +25,7 @@
 #include "kc_internal.h"
 #include "kc_pool.h"
 #include "kc_seg_tables.h"
+#include "kc_scan_tables.h"
 
 #include <type_traits>
 #if defined(__SSE2__)
@@ -65,7 +66,7 @@ struct kc_dwa {
   std::vector<float> raw_xyz;           // input of the last device-side sensor update
   bool raw_is_scan = false;             // ... laserscan points: obstacles are taken at z = 0
   std::vector<double> scan_angles;      // angles of the last laserscan + their cos/sin (a lidar's
-  std::vector<double2> scan_cs;         // angle table does not change between scans)
+  std::vector<double> scan_cos, scan_sin;  // angle table does not change between scans)
   std::vector<float> scan_xyz;          // sensor-frame points of the last laserscan
   DevBuf<float> d_raw;
   DevBuf<uint32_t> d_sensor_tmp;        // scratch of the multi-workgroup sensor build
@@ -295,6 +296,7 @@ struct kc_dwa {
   bool oscan_valid = false;
   size_t oscan_n = 0;
   int oscan_cs = 0, oscan_nch = 0;
+  int oscan_scs = 0;                     // obstacles per quarter of a chunk (long scans: quarter boxes behind the chunk boxes), else 0
   unsigned long long sensor_version = 0, onear_version = ~0ull;
   DevBuf<uint4> d_onear;
   float onear_x0 = 0.f, onear_y0 = 0.f, onear_g = 0.f;

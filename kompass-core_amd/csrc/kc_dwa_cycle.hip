@@ -188,6 +188,7 @@ int build_cost_args(kc_dwa *c, size_t n, size_t first, CostArgs &ca, DcArgs &dt)
     dt.on = static_cast<int>(on);
     dt.ocs = c->oscan_cs;
     dt.onch = c->oscan_nch;
+    dt.oscs = c->oscan_scs;
     dt.ocap = static_cast<double>(c->max_obs_dist);
   }
   dt.ounion = (c->bucket.W <= 64 && c->bucket.H <= 64) ? c->obs_union : 0;

@@ -1041,63 +1041,66 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   if (c->scan_angles.size() != n ||
       (n && std::memcmp(c->scan_angles.data(), angles, n * sizeof(double)) != 0)) {
     c->scan_angles.assign(angles, angles + n);
-    c->scan_cs.resize(n);
-    for (size_t i = 0; i < n; ++i) c->scan_cs[i] = make_double2(std::cos(angles[i]), std::sin(angles[i]));
+    c->scan_cos.resize(n);
+    c->scan_sin.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      c->scan_cos[i] = std::cos(angles[i]);
+      c->scan_sin[i] = std::sin(angles[i]);
+    }
   }
   // sensor-frame points: voxels at z = hz (collision_check.h:110-115; a
   // non-finite range gives non-finite coordinates, which add_voxel drops),
-  // obstacles from the same x, y at z = 0 (cost path: no filter)
+  // obstacles from the same x, y at z = 0 (cost path: no filter) -- one pass over the beams, four at a time
+  // (kc_scan_tables.h): points, the obstacles in beam order (CostEvaluator::setPointScan, cost_evaluator.h:174-193:
+  // sensor_tf_body * body_tf_world applied to (r cos a, r sin a, 0)), "every range finite"
   c->scan_xyz.resize(3 * n);
-  for (size_t i = 0; i < n; ++i) {
-    const double r = ranges[i];
-    c->scan_xyz[3 * i] = static_cast<float>(r * c->scan_cs[i].x);
-    c->scan_xyz[3 * i + 1] = static_cast<float>(r * c->scan_cs[i].y);
-    c->scan_xyz[3 * i + 2] = hz;
-  }
+  c->h_oscan.resize(2 * n + 256 + 1024);
+  float *hx = c->h_oscan.data(), *hy = hx + n, *box = hy + n, *sub = box + 256;
+  const scantab::Place place{c->obs_tf.R[0][0], c->obs_tf.R[0][1], c->obs_tf.R[0][2] * 0.0f, c->obs_tf.t[0],
+                             c->obs_tf.R[1][0], c->obs_tf.R[1][1], c->obs_tf.R[1][2] * 0.0f, c->obs_tf.t[1]};
+  const bool finite = scantab::points(ranges, c->scan_cos.data(), c->scan_sin.data(), n, hz, place, c->scan_xyz.data(), hx, hy);
   c->have_sensor = true;
   c->max_obs_dist = max_range / 3.0f;  // cost_evaluator.h:179
   ++c->sensor_version;
   c->oscan_valid = false;
   c->onear_ok = false;
   if (c->obs_near_opt && n >= 64 && n <= 65536) {
-    // the obstacles in beam order (CostEvaluator::setPointScan, cost_evaluator.h:174-193: sensor_tf_body *
-    // body_tf_world applied to (r cos a, r sin a, 0)) and the boxes of their chunks, for the near table of the
-    // scan; a non-finite range leaves the scan to the bucket search
-    bool finite = true;
-    for (size_t i = 0; i < n && finite; ++i) finite = std::isfinite(ranges[i]);
+    // the boxes of the chunks of the scan polyline, for the near table of the scan; a non-finite range leaves the
+    // scan to the bucket search
     if (finite) {
       const int cs = static_cast<int>((n + 63) / 64);
       const int nch = static_cast<int>((n + cs - 1) / cs);
-      c->h_oscan.resize(2 * n + 256);
-      float *hx = c->h_oscan.data(), *hy = hx + n, *box = hy + n;
-      for (size_t i = 0; i < n; ++i) {
-        float o[3];
-        c->obs_tf.apply(c->scan_xyz[3 * i], c->scan_xyz[3 * i + 1], 0.0f, o);
-        hx[i] = o[0];
-        hy[i] = o[1];
-      }
-      const float inf = std::numeric_limits<float>::infinity();
+      // chunks of 32 obstacles and more also get the boxes of their four quarters (wave_sample_total prunes by them)
+      const int scs = cs >= 32 ? (cs + 3) / 4 : 0;
+      auto put = [](float *out, int stride, int k, const scantab::Box &b) {
+        out[k] = b.x0;
+        out[stride + k] = b.x1;
+        out[2 * stride + k] = b.y0;
+        out[3 * stride + k] = b.y1;
+      };
       for (int k = 0; k < 64; ++k) {
-        float x0 = inf, x1 = -inf, y0 = inf, y1 = -inf;
-        if (k < nch)
-          for (size_t j = static_cast<size_t>(k) * cs; j < std::min(n, static_cast<size_t>(k + 1) * cs); ++j) {
-            x0 = std::min(x0, hx[j]);
-            x1 = std::max(x1, hx[j]);
-            y0 = std::min(y0, hy[j]);
-            y1 = std::max(y1, hy[j]);
+        const size_t j0 = std::min(n, static_cast<size_t>(k) * cs), j1 = std::min(n, static_cast<size_t>(k + 1) * cs);
+        if (scs > 0) {
+          scantab::Box whole = scantab::box_empty();
+          for (int q = 0; q < 4; ++q) {
+            const size_t q0 = std::min(j1, j0 + static_cast<size_t>(q) * scs), q1 = std::min(j1, q0 + static_cast<size_t>(scs));
+            const scantab::Box b = (k < nch) ? scantab::box_of(hx, hy, q0, q1) : scantab::box_empty();
+            put(sub, 256, 4 * k + q, b);
+            whole = scantab::box_join(whole, b);
           }
-        box[k] = x0;
-        box[64 + k] = x1;
-        box[128 + k] = y0;
-        box[192 + k] = y1;
+          put(box, 64, k, whole);
+        } else {
+          put(box, 64, k, (k < nch) ? scantab::box_of(hx, hy, j0, j1) : scantab::box_empty());
+        }
       }
-      KC_TRY(c->d_oscan.reserve(2 * n + 256));
-      KC_TRY(upload_table(c, c->d_oscan.p, hx, (2 * n + 256) * sizeof(float)));
+      KC_TRY(c->d_oscan.reserve(2 * n + 256 + 1024));
+      KC_TRY(upload_table(c, c->d_oscan.p, hx, (2 * n + 256 + (scs > 0 ? 1024 : 0)) * sizeof(float)));
       if (!c->trig_direct) {
         KC_HIP(hipStreamSynchronize(c->stream));  // (pageable source)
       } else {
         bar_flush(c);
       }
+      c->oscan_scs = scs;
       c->oscan_valid = true;
       c->oscan_n = n;
       c->oscan_cs = cs;
