@@ -439,6 +439,21 @@ void kc_dwa_destroy(kc_dwa *c) {
       }
       std::fprintf(stderr, "  undecided poses per workgroup (exact shell tests): %.1f / %.0f\n", nb ? sm / nb : 0.0, mx);
     }
+    {
+      // when the workgroups end (slot 9) and how long their cost phase takes (slot 8 - slot 6), in 1 us bins
+      int end_hist[64] = {0}, cost_hist[64] = {0};
+      for (int b = 0; b < 512; ++b) {
+        if (!h[b * 32] || !h[b * 32 + 9] || !h[b * 32 + 8] || !h[b * 32 + 6]) continue;
+        const int e = static_cast<int>((h[b * 32 + 9] - t0) / 100), d = static_cast<int>((h[b * 32 + 8] - h[b * 32 + 6]) / 100);
+        ++end_hist[std::min(std::max(e, 0), 63)];
+        ++cost_hist[std::min(std::max(d, 0), 63)];
+      }
+      std::fprintf(stderr, "  workgroups by end of epilogue (us):");
+      for (int i = 0; i < 64; ++i) if (end_hist[i]) std::fprintf(stderr, " %d:%d", i, end_hist[i]);
+      std::fprintf(stderr, "\n  workgroups by duration of the cost phase (us):");
+      for (int i = 0; i < 64; ++i) if (cost_hist[i]) std::fprintf(stderr, " %d:%d", i, cost_hist[i]);
+      std::fprintf(stderr, "\n");
+    }
   }
   if (c->debug_stamps && c->d_dbg.p) {  // diagnostic dump of the last cycle
     std::vector<unsigned long long> h(512 * 16);
