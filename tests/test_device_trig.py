@@ -214,3 +214,26 @@ def test_more_trig_rows_than_the_lds_table_holds(opts):
         assert_cycle_equal(oracle_cycle(cur), hip_cycle(kh, cur, ctx=ctx))
     assert ctx.get_option("trig_rows") == 450
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(), dict(fused_cycle=0)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "default")
+def test_more_axis_values_than_the_lds_tables_hold(opts):
+    """An omni lattice with 150 vx and 70 vy values: the cycle kernel keeps the first 128 / 64 values of the axes in LDS
+    (round 4) and reads the rest from global memory."""
+    import synthetic as syn
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import assert_cycle_equal, hip_context, hip_cycle, oracle_cycle
+
+    inp = syn.make_controller_inputs("cfg5", seed=9, scale=0.1, scene="mid")
+    vx, vy, om = syn.lattice_omni(150, 70, 5)
+    inp = dict(inp, vx=vx, vy=vy, omega=om)
+    ctx = hip_context(kh, inp)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    for yaw in (0.3, -1.1):
+        cur = dict(inp, state=(0.0, 0.0, yaw, 0.0))
+        assert_cycle_equal(oracle_cycle(cur), hip_cycle(kh, cur, ctx=ctx))
+    ctx.close()
