@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstddef>
+#include <cstring>
 #include <vector>
 
 #include "kompass_hip.h"
@@ -202,7 +203,12 @@ inline void build_window_lattice(int ctr_type, const kc_limits &L, double cvx,
   const double res_om = std::max((max_om - min_om) / (ang_n - 1), 0.001);
 
   // the axes, by the reference's repeated addition (trajectory_sampler.cpp:207-217, 256-272)
-  std::vector<double> xs, ys, oms;
+  // (per-thread scratch: this runs once per controller cycle, and three growing vectors were 25 allocations --
+  // more than half of the call)
+  thread_local std::vector<double> xs, ys, oms;
+  xs.clear();
+  ys.clear();
+  oms.clear();
   for (double v = min_vx; v <= max_vx; v += res_x) xs.push_back(v);
   if (ctr_type == KC_OMNI)
     for (double w = min_vy; w <= max_vy; w += res_y) ys.push_back(w);
@@ -225,30 +231,54 @@ inline void build_window_lattice(int ctr_type, const kc_limits &L, double cvx,
   // value tables: vx_values = the x axis; vy_values = [0.0, the y axis]; omega_values = the omega axis
   // [+ 0.0 as the row of the (vx, vy, 0) omni samples]
   if (!same) {
-    out.clear();
-    if (xs.size() > 65535 || ys.size() + 1 > 65535) return;  // (limits far above any sample budget)
+    out.signature = 0;
+    if (xs.size() > 65535 || ys.size() + 1 > 65535) {  // (limits far above any sample budget)
+      out.clear();
+      return;
+    }
   }
-  out.vx_values = xs;
+  out.vx_values.assign(xs.begin(), xs.end());
   out.vy_values.assign(1, 0.0);
   out.vy_values.insert(out.vy_values.end(), ys.begin(), ys.end());
-  out.omega_values = oms;
+  out.omega_values.assign(oms.begin(), oms.end());
   if (ctr_type == KC_OMNI) out.omega_values.push_back(0.0);
   if (same) return;
   out.signature = sig;
   const int32_t zero_row = static_cast<int32_t>(n_om);  // omni only
-  auto push_omega_row = [&](size_t i) {  // (v, 0, every omega) with |v| >= kMinVel: no sample of it is all-zero
-    const size_t at = out.row.size(), to = at + n_om;
-    out.ix.resize(to, static_cast<uint16_t>(i));
-    out.iy.resize(to, 0);
-    out.row.resize(to);
-    for (size_t r = 0; r < n_om; ++r) out.row[at + r] = static_cast<int32_t>(r);
-  };
+  // (sized once, filled by plain loops: this runs whenever an axis value crosses |v| = kMinVel or an axis
+  // gains / loses a value -- most cycles of a robot whose velocity moves)
+  size_t total = 0;
+  for (size_t i = 0; i < xs.size(); ++i) {
+    if (ctr_type == KC_OMNI)
+      for (size_t j = 0; j < ys.size(); ++j) total += !(small(xs[i]) && small(ys[j]));
+    if (!small(xs[i])) total += n_om;
+  }
+  out.ix.resize(total);
+  out.iy.resize(total);
+  out.row.resize(total);
+  uint16_t *pix = out.ix.data(), *piy = out.iy.data();
+  int32_t *prow = out.row.data();
+  size_t at = 0, first_block = static_cast<size_t>(-1);
   for (size_t i = 0; i < xs.size(); ++i) {
     if (ctr_type == KC_OMNI)
       for (size_t j = 0; j < ys.size(); ++j)
-        if (!(small(xs[i]) && small(ys[j])))  // (omega = 0 is small)
-          out.push(static_cast<uint16_t>(i), static_cast<uint16_t>(j + 1), zero_row);
-    if (!small(xs[i])) push_omega_row(i);
+        if (!(small(xs[i]) && small(ys[j]))) {  // (omega = 0 is small)
+          pix[at] = static_cast<uint16_t>(i);
+          piy[at] = static_cast<uint16_t>(j + 1);
+          prow[at] = zero_row;
+          ++at;
+        }
+    if (!small(xs[i])) {  // (v, 0, every omega) with |v| >= kMinVel: no sample of it is all-zero
+      std::fill_n(pix + at, n_om, static_cast<uint16_t>(i));
+      std::fill_n(piy + at, n_om, static_cast<uint16_t>(0));
+      if (first_block == static_cast<size_t>(-1)) {
+        for (size_t r = 0; r < n_om; ++r) prow[at + r] = static_cast<int32_t>(r);
+        first_block = at;
+      } else {
+        std::memcpy(prow + at, prow + first_block, n_om * sizeof(int32_t));
+      }
+      at += n_om;
+    }
   }
 }
 
