@@ -68,6 +68,75 @@ int upload_omega(kc_dwa *c) {
   return KC_OK;
 }
 
+// The tables of the active pattern change places with those of a kept one (signature + size), or -- a pattern not
+// seen lately -- with the least recently used slot, whose buffers the caller then overwrites.  true: the device
+// holds the tables of (sig, n) now.  Pointers only: nothing is written, nothing queued reads these tables between
+// cycles (the sensor kernels do not).
+static bool swap_in_pattern(kc_dwa *c, uint64_t sig, size_t n) {
+  // (40 bytes of device memory a sample and pattern: 128 MB of them at most, 16 to 256 patterns)
+  const size_t kKept = std::min<size_t>(256, std::max<size_t>(16, (size_t(128) << 20) / (40 * std::max<size_t>(n, 1))));
+  auto exchange = [&](kc_dwa::PatternTables &t) {
+    std::swap(t.vidx, c->d_vidx);
+    std::swap(t.row, c->d_row);
+    std::swap(t.perm, c->d_perm);
+    std::swap(t.prow, c->d_prow);
+    std::swap(t.pvi, c->d_pvi);
+    std::swap(t.cperm, c->d_cperm);
+    std::swap(t.cprow, c->d_cprow);
+    std::swap(t.cpvi, c->d_cpvi);
+    std::swap(t.h_perm, c->h_perm);
+    std::swap(t.h_dealt, c->h_dealt);
+    std::swap(t.rows, c->uploaded_rows);
+    std::swap(t.perm_valid, c->perm_valid);
+    std::swap(t.perm_plain_dev, c->perm_plain_dev);
+    std::swap(t.perm_dealt_dev, c->perm_dealt_dev);
+    std::swap(t.perm_first, c->perm_first);
+    std::swap(t.perm_count, c->perm_count);
+    std::swap(t.perm_cs, c->perm_cs);
+    std::swap(t.sig, c->up_sig);
+    std::swap(t.n, c->up_n);
+  };
+  ++c->pattern_clock;
+  const bool active_keeps = c->up_sig != 0 && c->up_n > 0;  // (lists without a signature are not kept)
+  for (auto &t : c->patterns)
+    if (t.sig == sig && t.n == n) {
+      if (!active_keeps) {  // nothing worth keeping comes back: the slot's tables move in, the slot empties
+        exchange(t);
+        t.sig = 0;
+        t.n = 0;
+        t.perm_valid = t.perm_plain_dev = t.perm_dealt_dev = false;
+      } else {
+        exchange(t);
+      }
+      t.stamp = c->pattern_clock;
+      c->up_ix.clear();
+      c->up_iy.clear();
+      ++c->pattern_hits;
+      return true;
+    }
+  if (!active_keeps) return false;
+  // keep the active tables: an empty slot, a new slot, or the one unused for longest
+  kc_dwa::PatternTables *slot = nullptr;
+  for (auto &t : c->patterns)
+    if (t.sig == 0) slot = &t;
+  if (!slot && c->patterns.size() < kKept) {
+    c->patterns.emplace_back();
+    slot = &c->patterns.back();
+  }
+  if (!slot) {
+    slot = &c->patterns[0];
+    for (auto &t : c->patterns)
+      if (t.stamp < slot->stamp) slot = &t;
+  }
+  exchange(*slot);
+  slot->stamp = c->pattern_clock;
+  // (what came back is a stale or empty set of buffers: the caller rebuilds into it)
+  c->up_sig = 0;
+  c->up_n = 0;
+  c->perm_valid = c->perm_plain_dev = c->perm_dealt_dev = false;
+  return false;
+}
+
 int upload_samples(kc_dwa *c) {
   const hm::VelocityLattice &lat = c->lat;
   const size_t n = lat.size();
@@ -82,13 +151,15 @@ int upload_samples(kc_dwa *c) {
   // A controller draws a new window every cycle: the velocities change, the pattern -- which sample
   // takes which axis value, which samples share an omega -- rarely does.  The index arrays on the device
   // and the orders the kernels walk the list in depend on that pattern only.
-  const bool same = n == c->up_n && ((lat.signature != 0 && lat.signature == c->up_sig) ||
-                                     (lat.signature == 0 && c->up_sig == 0 && c->uploaded_rows == lat.row &&
-                                      c->up_ix == lat.ix && c->up_iy == lat.iy));
+  const bool same_active = n == c->up_n && ((lat.signature != 0 && lat.signature == c->up_sig) ||
+                                            (lat.signature == 0 && c->up_sig == 0 && c->uploaded_rows == lat.row &&
+                                             c->up_ix == lat.ix && c->up_iy == lat.iy));
   ++c->lat_version;
   c->shard_first = 0;
   c->shard_count = n;
-  if (!same) c->perm_valid = false;  // (the orders also belong to one shard: perm_first / perm_count)
+  bool same = same_active;
+  if (!same && n > 0 && lat.signature != 0) same = swap_in_pattern(c, lat.signature, n);
+  if (!same) c->perm_valid = c->perm_plain_dev = c->perm_dealt_dev = false;  // (the orders also belong to one shard)
   if (n == 0) return KC_OK;
   const size_t nx = lat.vx_values.size(), ny = lat.vy_values.size();
   KC_TRY(c->d_vxt.reserve(nx));
@@ -107,6 +178,7 @@ int upload_samples(kc_dwa *c) {
     if (!c->drained) {
       KC_HIP(hipStreamSynchronize(c->stream));
       c->drained = true;
+      c->perm_busy = false;
       c->update_busy = false;
     }
     std::memcpy(c->d_vxt.p, lat.vx_values.data(), nx * sizeof(double));
@@ -211,79 +283,102 @@ int apply_shard_rule(kc_dwa *c) {
 // gate cluster (a few adjacent omega rows, the low speeds of each), and a
 // workgroup costs its own survivors, so a cluster of any shape has to land on
 // many workgroups instead of a few (see below).
-int build_perm(kc_dwa *c) {
+int build_perm(kc_dwa *c, bool want_dealt) {
   const size_t n = c->shard_count, first = c->shard_first;
+  const bool host_ok = c->perm_valid && c->perm_first == first && c->perm_count == n && c->perm_cs == c->cycle_samples;
+  if (!host_ok) c->perm_plain_dev = c->perm_dealt_dev = false;
   c->perm_valid = true;
   c->perm_first = first;
   c->perm_count = n;
   if (n == 0) return KC_OK;
-  c->h_perm.resize(n);
-  for (size_t i = 0; i < n; ++i) c->h_perm[i] = static_cast<int32_t>(i);
-  const int32_t *row = c->lat.row.data() + first;
-  std::stable_sort(c->h_perm.begin(), c->h_perm.end(),
-                   [row](int32_t x, int32_t y) { return row[x] < row[y]; });
   std::vector<int32_t> &dealt = c->h_dealt;
-  dealt.clear();
-  dealt.reserve(n);
-  {
-    // Rectangular lattice (R trig rows of L samples each -- the non-holonomic
-    // window is one): a workgroup takes 8 rows, R/8 apart, and 4 samples of each,
-    // L/4 apart.  Survivors cluster in adjacent rows and adjacent speeds, so at
-    // most a couple land in one workgroup, and a workgroup reads 8 rows of the
-    // trig table instead of 32.  Anything else (omni windows, ragged shards): the
-    // skewed stride, one sample per row.
-    size_t R = 0, L = 0;
-    bool rect = true;
-    for (size_t i = 0; i < n && rect;) {
-      size_t j = i;
-      while (j < n && row[c->h_perm[j]] == row[c->h_perm[i]]) ++j;
-      if (R == 0) L = j - i;
-      rect = (j - i) == L;
-      ++R;
-      i = j;
+  if (!host_ok) {
+    c->h_perm.resize(n);
+    const int32_t *row = c->lat.row.data() + first;
+    {
+      // the shard's samples ordered by trig row, ties in list order: a counting sort (rows are small integers; this
+      // runs whenever the window's pattern is new, which a robot crossing v = 0 makes a frequent event)
+      int32_t rmax = 0;
+      for (size_t i = 0; i < n; ++i) rmax = std::max(rmax, row[i]);
+      std::vector<int32_t> &start = c->perm_scratch;
+      start.assign(static_cast<size_t>(rmax) + 2, 0);
+      for (size_t i = 0; i < n; ++i) ++start[static_cast<size_t>(row[i]) + 1];
+      for (size_t r = 1; r < start.size(); ++r) start[r] += start[r - 1];
+      for (size_t i = 0; i < n; ++i) c->h_perm[static_cast<size_t>(start[static_cast<size_t>(row[i])]++)] = static_cast<int32_t>(i);
     }
-    const size_t cs = static_cast<size_t>(c->cycle_samples);  // 32: 8 rows x 4 samples, 16: 4 x 4
-    const size_t rows_per = cs / 4;
-    rect = rect && R * L == n && R % rows_per == 0 && L % 4 == 0;
-    if (rect) {
-      const size_t A = R / rows_per, B = L / 4;
-      for (size_t a = 0; a < A; ++a)
-        for (size_t b = 0; b < B; ++b)
-          for (size_t i = 0; i < rows_per; ++i)
-            for (size_t k = 0; k < 4; ++k) dealt.push_back(c->h_perm[(a + A * i) * L + b + B * k]);
-    } else {
-      // Ragged rows (omni windows, shares dealt by row): quads again -- every row of the sorted order is cut
-      // into groups of (up to) four samples a quarter of the row apart, and the quads are dealt with the skewed
-      // stride (a workgroup takes its quads from cs / 4 regions of the sorted order: adjacent rows and adjacent
-      // speeds go to different workgroups, and the samples of a workgroup share cs / 4 trig rows or a few more
-      // instead of cs -- the rows its lanes have to form).  A workgroup is whatever cs consecutive
-      // entries of the flat list are: partial quads only shift the boundaries.
-      std::vector<int32_t> qstart, qstep, qcount;  // quad = h_perm[qstart + k * qstep], k < qcount
-      for (size_t i = 0; i < n;) {
+    dealt.clear();
+    dealt.reserve(n);
+    {
+      // Rectangular lattice (R trig rows of L samples each -- the non-holonomic
+      // window is one): a workgroup takes 8 rows, R/8 apart, and 4 samples of each,
+      // L/4 apart.  Survivors cluster in adjacent rows and adjacent speeds, so at
+      // most a couple land in one workgroup, and a workgroup reads 8 rows of the
+      // trig table instead of 32.  Anything else (omni windows, ragged shards): the
+      // skewed stride, one sample per row.
+      size_t R = 0, L = 0;
+      bool rect = true;
+      for (size_t i = 0; i < n && rect;) {
         size_t j = i;
         while (j < n && row[c->h_perm[j]] == row[c->h_perm[i]]) ++j;
-        const size_t len = j - i, nq = (len + 3) / 4;
-        for (size_t q = 0; q < nq; ++q) {
-          qstart.push_back(static_cast<int32_t>(i + q));
-          qstep.push_back(static_cast<int32_t>(nq));
-          qcount.push_back(static_cast<int32_t>((len - q + nq - 1) / nq));  // elements q, q + nq, ... below len
-        }
+        if (R == 0) L = j - i;
+        rect = (j - i) == L;
+        ++R;
         i = j;
       }
-      const size_t Q = qstart.size(), qper = cs / 4;
-      const size_t G = (Q + qper - 1) / qper;
-      for (size_t g = 0; g < G; ++g)
-        for (size_t j = 0; j < qper; ++j) {
-          const size_t e = j * G + (g + 37 * j) % G;
-          if (e >= Q) continue;
-          for (int32_t k = 0; k < qcount[e]; ++k) dealt.push_back(c->h_perm[static_cast<size_t>(qstart[e] + k * qstep[e])]);
+      const size_t cs = static_cast<size_t>(c->cycle_samples);  // 32: 8 rows x 4 samples, 16: 4 x 4
+      const size_t rows_per = cs / 4;
+      rect = rect && R * L == n && R % rows_per == 0 && L % 4 == 0;
+      if (rect) {
+        const size_t A = R / rows_per, B = L / 4;
+        for (size_t a = 0; a < A; ++a)
+          for (size_t b = 0; b < B; ++b)
+            for (size_t i = 0; i < rows_per; ++i)
+              for (size_t k = 0; k < 4; ++k) dealt.push_back(c->h_perm[(a + A * i) * L + b + B * k]);
+      } else {
+        // Ragged rows (omni windows, shares dealt by row): quads again -- every row of the sorted order is cut
+        // into groups of (up to) four samples a quarter of the row apart, and the quads are dealt with the skewed
+        // stride (a workgroup takes its quads from cs / 4 regions of the sorted order: adjacent rows and adjacent
+        // speeds go to different workgroups, and the samples of a workgroup share cs / 4 trig rows or a few more
+        // instead of cs -- the rows its lanes have to form).  A workgroup is whatever cs consecutive
+        // entries of the flat list are: partial quads only shift the boundaries.
+        std::vector<int32_t> qstart, qstep, qcount;  // quad = h_perm[qstart + k * qstep], k < qcount
+        for (size_t i = 0; i < n;) {
+          size_t j = i;
+          while (j < n && row[c->h_perm[j]] == row[c->h_perm[i]]) ++j;
+          const size_t len = j - i, nq = (len + 3) / 4;
+          for (size_t q = 0; q < nq; ++q) {
+            qstart.push_back(static_cast<int32_t>(i + q));
+            qstep.push_back(static_cast<int32_t>(nq));
+            qcount.push_back(static_cast<int32_t>((len - q + nq - 1) / nq));  // elements q, q + nq, ... below len
+          }
+          i = j;
         }
+        const size_t Q = qstart.size(), qper = cs / 4;
+        const size_t G = (Q + qper - 1) / qper;
+        for (size_t g = 0; g < G; ++g)
+          for (size_t j = 0; j < qper; ++j) {
+            const size_t e = j * G + (g + 37 * j) % G;
+            if (e >= Q) continue;
+            for (int32_t k = 0; k < qcount[e]; ++k) dealt.push_back(c->h_perm[static_cast<size_t>(qstart[e] + k * qstep[e])]);
+          }
+      }
     }
-  }
+  }  // (host orders)
   c->perm_cs = c->cycle_samples;
-  std::vector<int32_t> prow(n);
-  std::vector<uint32_t> pvi(n);
-  for (int pass = 0; pass < 2; ++pass) {
+  if (want_dealt ? c->perm_dealt_dev : c->perm_plain_dev) return KC_OK;
+  std::vector<int32_t> &prow = c->perm_prow;
+  std::vector<uint32_t> &pvi = c->perm_pvi;
+  prow.resize(n);
+  pvi.resize(n);
+  if (c->trig_direct && c->perm_busy) {  // (stores through the BAR below: no queued roll-out may still read the old orders;
+    KC_HIP(hipStreamSynchronize(c->stream));  // a sensor update in flight does not touch them and is not waited for)
+    c->drained = true;
+    c->perm_busy = false;
+    c->update_busy = false;
+  }
+  // only the order the launch at hand walks goes to the device (the single-launch cycle: the dealt one): 12 bytes
+  // a sample over the BAR, on the host's critical path whenever the window's pattern is new
+  for (int pass = want_dealt ? 1 : 0; pass < (want_dealt ? 2 : 1); ++pass) {
     const std::vector<int32_t> &order = pass == 0 ? c->h_perm : dealt;
     DevBuf<int32_t> &dperm = pass == 0 ? c->d_perm : c->d_cperm;
     DevBuf<int32_t> &drow = pass == 0 ? c->d_prow : c->d_cprow;
@@ -296,11 +391,22 @@ int build_perm(kc_dwa *c) {
       prow[i] = c->lat.row[g];
       pvi[i] = static_cast<uint32_t>(c->lat.ix[g]) | (static_cast<uint32_t>(c->lat.iy[g]) << 16);
     }
-    KC_HIP(hipMemcpyAsync(dperm.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    KC_HIP(hipMemcpyAsync(drow.p, prow.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    KC_HIP(hipMemcpyAsync(dvi.p, pvi.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
+    if (c->trig_direct) {
+      // straight into device memory over the BAR (upload_samples does the same with the index tables): the orders are
+      // read by roll-out kernels only, and the cycle that asks for them has seen the previous cycle's record
+      KC_TRY(upload_table(c, dperm.p, order.data(), n * sizeof(int32_t)));
+      KC_TRY(upload_table(c, drow.p, prow.data(), n * sizeof(int32_t)));
+      KC_TRY(upload_table(c, dvi.p, pvi.data(), n * sizeof(uint32_t)));
+    } else {
+      KC_HIP(hipMemcpyAsync(dperm.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+      KC_HIP(hipMemcpyAsync(drow.p, prow.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+      KC_HIP(hipMemcpyAsync(dvi.p, pvi.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      KC_HIP(hipStreamSynchronize(c->stream));  // pageable sources
+    }
   }
+  if (c->trig_direct) bar_flush(c);
+  (want_dealt ? c->perm_dealt_dev : c->perm_plain_dev) = true;
+  if (!host_ok) ++c->pattern_builds;
   return KC_OK;
 }
 
@@ -566,6 +672,17 @@ void kc_dwa_destroy(kc_dwa *c) {
   c->d_adm_bits.release();
   c->d_cperm.release();
   c->d_cprow.release();
+  for (auto &t : c->patterns) {
+    t.vidx.release();
+    t.pvi.release();
+    t.cpvi.release();
+    t.row.release();
+    t.perm.release();
+    t.prow.release();
+    t.cperm.release();
+    t.cprow.release();
+  }
+  c->patterns.clear();
   c->h_wrow.release();
   c->h_slots.release();
   c->d_oscan.release();
@@ -605,6 +722,7 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   // whatever is queued was built under the old settings
   KC_HIP(hipStreamSynchronize(c->stream));
   c->drained = true;
+  c->perm_busy = false;
   c->update_busy = false;
   const std::string n(name);
   const bool on = v != 0.0;
@@ -688,6 +806,8 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "drop_samples") *v = c->drop_samples;
   else if (n == "num_ctrl_points") *v = static_cast<double>(c->num_ctrl_points);
   else if (n == "trig_rows") *v = static_cast<double>(c->lat.omega_values.size());  // read-only: rows of the host's cos / sin table
+  else if (n == "pattern_hits") *v = static_cast<double>(c->pattern_hits);      // read-only: window patterns found on the device
+  else if (n == "pattern_builds") *v = static_cast<double>(c->pattern_builds);  // read-only: walking orders built (build_perm)
   else if (n == "shard_samples") *v = static_cast<double>(c->shard_count);          // read-only: samples this context rolls out
   else
     KC_FAIL(KC_ERR_INVALID, "unknown option '%s'", name);

@@ -106,6 +106,10 @@ struct kc_dwa {
   DevBuf<uint32_t> d_pvi, d_cpvi;       // value indices in those two orders
   DevBuf<int32_t> d_perm;               // shard-local sample ids ordered by trig row
   std::vector<int32_t> h_perm;
+  std::vector<int32_t> perm_scratch;    // (counting sort of build_perm)
+  std::vector<int32_t> perm_prow;       // (its staging rows)
+  std::vector<uint32_t> perm_pvi;
+  bool perm_plain_dev = false, perm_dealt_dev = false;  // which of the two orders the device holds (perm_valid: the host does)
   std::vector<int32_t> uploaded_rows;   // trig-row pattern the orders on the device were built for
   size_t perm_first = 0, perm_count = 0;  // ... and the shard
   double inv_res = 0.0;      // 1.0 / res (octomap resolution_factor)
@@ -154,6 +158,25 @@ struct kc_dwa {
   double vmax_lin = 0.0;      // max hypot(vx, vy) over the list
   DevBuf<double> d_vxt, d_vyt;   // value tables of the axes (rewritten by every new window)
   DevBuf<uint32_t> d_vidx;       // [n] (index into d_vxt) | (index into d_vyt) << 16: rewritten when the pattern changes
+  // The index tables and the two walking orders of a window lattice belong to its PATTERN (which sample takes which
+  // axis value; lattice signature).  A robot whose velocity moves changes pattern in every second cycle -- an axis
+  // gains or loses a value, a value crosses |v| = kMinVel -- between a handful of patterns: the tables of the last
+  // few stay on the device and a change back is a swap of pointers (tools/window_sweep.py: 380 us per change
+  // before, the sort + six pageable copies of build_perm).
+  struct PatternTables {
+    uint64_t sig = 0;
+    size_t n = 0;
+    uint64_t stamp = 0;  // last use
+    DevBuf<uint32_t> vidx, pvi, cpvi;
+    DevBuf<int32_t> row, perm, prow, cperm, cprow;
+    std::vector<int32_t> h_perm, h_dealt, rows;
+    bool perm_valid = false, perm_plain_dev = false, perm_dealt_dev = false;
+    size_t perm_first = 0, perm_count = 0;
+    int perm_cs = 0;
+  };
+  std::vector<PatternTables> patterns;  // (inactive ones; the active pattern lives in the members above / below)
+  uint64_t pattern_clock = 0;
+  long pattern_hits = 0, pattern_builds = 0;
   DevBuf<int32_t> d_row;
   uint64_t up_sig = 0;           // signature / size of the pattern on the device
   size_t up_n = 0;
@@ -238,6 +261,7 @@ struct kc_dwa {
   PinBuf<long long> h_pub;     // {key, n_adm, compact, seq} written by the GPU
   long long seq = 0;           // last cycle sequence handed to finalize
   bool pub_pending = false;
+  bool perm_busy = false;  // a queued roll-out reads the walking orders (d_perm ...): cleared with `drained`
   bool drained = false;  // the host saw the last cost kernel's record: every earlier
                          // command of the stream has finished with the staging buffers
   PinBuf<float> h_row;         // winner row staging
@@ -380,6 +404,7 @@ inline int quiesce_for_update(kc_dwa *c, bool sensor_tables = true) {
     c->update_busy = false;
     c->seg_busy = false;
     c->drained = true;
+    c->perm_busy = false;
   }
   return KC_OK;
 }
@@ -409,7 +434,7 @@ int ensure_sincostab(kc_dwa *c);   // the 440 table values of kc_trig_exact.h in
 int upload_omega(kc_dwa *c);
 int upload_samples(kc_dwa *c);
 int apply_shard_rule(kc_dwa *c);
-int build_perm(kc_dwa *c);
+int build_perm(kc_dwa *c, bool want_dealt);
 // sensor data, tracked segment, near tables
 void build_host_lists(kc_dwa *c, const float *xyz, size_t n);
 int ensure_host_lists(kc_dwa *c);

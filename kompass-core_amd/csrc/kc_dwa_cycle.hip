@@ -498,6 +498,7 @@ int fetch_slots(kc_dwa *c, kc_result *out, size_t n) {
   c->hprof.mark(6);
   c->slots_pending = false;
   c->drained = true;        // every workgroup is past its last table read
+  c->perm_busy = false;
   c->update_busy = false;
   c->seg_busy = false;
   c->timing.mark("host:wait_result");
@@ -587,6 +588,7 @@ int fetch(kc_dwa *c, kc_result *out, size_t n) {
         c->h_result.p[2] = static_cast<long long>(static_cast<int32_t>(w1 & 0xFFFFFFFFll));
         got = true;
         c->drained = true;
+        c->perm_busy = false;
         c->update_busy = false;  // queued in front of the cycle whose record just arrived
         c->seg_busy = false;
         break;
@@ -920,12 +922,13 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     KC_TRY(c->timing.stop(s));
   }
   if (fused) {
-    if (!c->perm_valid || c->perm_first != c->shard_first || c->perm_count != c->shard_count ||
-        (cycle && c->perm_cs != cs))
-      KC_TRY(build_perm(c));
+    if (!c->perm_valid || c->perm_first != c->shard_first || c->perm_count != c->shard_count || c->perm_cs != cs ||
+        !(cycle ? c->perm_dealt_dev : c->perm_plain_dev))
+      KC_TRY(build_perm(c, cycle));
     a.perm = cycle ? c->d_cperm.p : c->d_perm.p;
     a.prow = cycle ? c->d_cprow.p : c->d_prow.p;
     a.pvi = cycle ? c->d_cpvi.p : c->d_pvi.p;
+    c->perm_busy = true;  // (until the host has seen this cycle's record)
 #ifdef KC_PHASE_STAMPS
     if (c->debug_stamps) {
       KC_TRY(c->d_dbg2.reserve(512 * 32));
@@ -1361,6 +1364,7 @@ int kc_cost_upload(kc_dwa *c, const float *paths_x, const float *paths_y, const 
   hipStream_t s = c->stream;
   KC_HIP(hipStreamSynchronize(s));
   c->drained = true;
+  c->perm_busy = false;
   c->update_busy = false;
   c->P = P;
   c->n_roll = n;

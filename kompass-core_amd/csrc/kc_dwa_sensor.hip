@@ -1470,6 +1470,7 @@ int kc_dwa_set_path(kc_dwa *c, const float *x, const float *y, const float *z, c
   KC_HIP(hipStreamSynchronize(c->stream));
   c->update_busy = false;
   c->drained = true;
+  c->perm_busy = false;
   c->path_n = n;
   c->path_len = total_length;
   c->path_edge.assign(n > 1 ? n - 1 : 0, 0.0f);
@@ -1520,6 +1521,7 @@ int kc_dwa_set_tracked_window(kc_dwa *c, size_t start, size_t S) {
     KC_HIP(hipStreamSynchronize(c->stream));
     c->update_busy = false;
     c->drained = true;
+    c->perm_busy = false;
     KC_TRY(c->d_seg.reserve(seg_words));
     KC_TRY(c->h_seg.reserve(seg_words));
   }

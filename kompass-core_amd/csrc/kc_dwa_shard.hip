@@ -64,6 +64,7 @@ int fetch_xchg(kc_dwa *c, const ShardLayout &L, size_t rw, kc_result *out) {
   }
   c->pub_pending = false;
   c->drained = true;
+  c->perm_busy = false;
   c->update_busy = false;
   c->seg_busy = false;
   c->timing.mark("host:wait_result");

@@ -286,3 +286,49 @@ def test_find_best_path_is_the_four_entries_in_one_call():
     s2 = four.cycle(st, P)
     assert (s1.found, s1.index, s1.raw_index, s1.n_admissible) == (s2.found, s2.index, s2.raw_index, s2.n_admissible)
     one.close(); four.close()
+
+
+@pytest.mark.gpu
+def test_a_moving_window_finds_its_patterns_on_the_device():
+    """A robot whose velocity wanders changes the PATTERN of its window lattice (an axis gains or loses a value, a value
+    crosses |v| = kMinVel) between a handful of patterns: every cycle equals a fresh context's, and a pattern seen
+    before comes back by a swap of device tables instead of a rebuild (counters pattern_hits / pattern_builds)."""
+    import synthetic as syn
+
+    inp = syn.make_controller_inputs("cfg2", seed=2, scale=0.25, scene="mid")
+    lim = kh.make_limits(syn.LIMITS["vx"], syn.LIMITS["vy"], syn.LIMITS["omega"])
+    ctr = syn.CONFIGS["cfg2"]["ctr"]
+    P = inp["P"]
+    seg = np.asarray(inp["seg_xyz"], np.float32)
+    sacc = np.ascontiguousarray(inp["acc_at_seg"], np.float32)
+    pts = np.ascontiguousarray(inp["points"], np.float32)
+
+    def make():
+        rb = inp["robot"]
+        c = kh.DwaContext(rb["shape"], rb["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"], inp["dt"], max_samples=4096,
+                          max_points=P, max_segment=len(seg), max_obstacles=len(pts), acc_limits=inp["acc_limits"])
+        c.set_weights(kh.make_weights(*inp["weights"]))
+        return c
+
+    ctx = make()
+    rng = np.random.default_rng(5)
+    vels = [(float(v), 0.0, float(o)) for v, o in zip(rng.uniform(-0.1, 1.0, 6), rng.uniform(-0.8, 0.8, 6))]
+    walk = [vels[int(k)] for k in rng.integers(0, len(vels), 60)]
+    counts = set()
+    for i, cur in enumerate(walk):
+        st = (0.0, 0.0, 0.01 * (i % 5), 0.0)
+        r = ctx.find_best_path(st, P, window=(ctr, lim, cur, 31, 31), points=pts, max_sensor_range=inp["max_range"],
+                               segment=(seg, sacc, inp["ref_len"]))
+        counts.add(int(r.n_samples))
+        ref = make()   # the same cycle on a context that has never seen another window
+        q = ref.find_best_path(st, P, window=(ctr, lim, cur, 31, 31), points=pts, max_sensor_range=inp["max_range"],
+                               segment=(seg, sacc, inp["ref_len"]))
+        assert (r.found, r.index, r.raw_index, r.n_admissible, r.n_samples) == (q.found, q.index, q.raw_index, q.n_admissible, q.n_samples)
+        assert np.float32(r.cost) == np.float32(q.cost)
+        if r.found:
+            np.testing.assert_array_equal(np.array(ctx.get_best()[0]), np.array(ref.get_best()[0]))
+        ref.close()
+    assert len(counts) > 1, "the walk was meant to change the pattern"
+    builds, hits = ctx.get_option("pattern_builds"), ctx.get_option("pattern_hits")
+    assert builds <= len(vels) + 1 and hits >= 1, (builds, hits, counts)
+    ctx.close()
