@@ -613,7 +613,36 @@ def fresh_inputs_leg(kh, syn, ctx, cfg, inp, pose, args):
     if not args.no_cpu:
         leg["cpu_baseline"] = cpu_baseline_fresh(syn, inp, base["ctr"], cur(last_i), max_lin, max_ang, pose(last_i), r, args,
                                                  max(3.0, args.cpu_seconds / 2))
+    leg["moving_window"] = moving_window_block(ctx, base, lim, max_lin, max_ang, pose, P, pts, seg, sacc, inp, min(steps, 1500))
+    ctx.sample_window(base["ctr"], lim, cur(last_i), max_lin, max_ang, want_list=False)
     return leg
+
+
+def moving_window_block(ctx, base, lim, max_lin, max_ang, pose, P, pts, seg, sacc, inp, steps):
+    """The same reference cycle with a velocity that WANDERS (a bounded random walk: what a closed loop's own commands do
+    to it).  The loop above moves its window among values that keep the lattice's index pattern; a robot changes pattern
+    in every second cycle (an axis gains or loses a value, a value crosses |v| = kMinVel), and a new pattern costs the
+    host a rebuild of the roll-out's walking orders.  Not `value`: a second reading of the
+    same path."""
+    rng = np.random.default_rng(1)
+    vx, om, lat, counts = 0.3, 0.0, [], []
+    h0, b0 = ctx.get_option("pattern_hits"), ctx.get_option("pattern_builds")
+    for i in range(steps + 100):
+        vx = float(np.clip(vx + rng.normal(0, 0.02), -0.2, 1.0))
+        om = float(np.clip(om + rng.normal(0, 0.05), -1.0, 1.0))
+        ts = time.perf_counter()
+        r = ctx.find_best_path(pose(i), P, window=(base["ctr"], lim, (vx, 0.0, om), max_lin, max_ang), points=pts,
+                               max_sensor_range=inp["max_range"], segment=(seg, sacc, inp["ref_len"]))
+        if i >= 100:
+            lat.append(time.perf_counter() - ts)
+            counts.append(int(r.n_samples))
+    lat = np.array(lat) * 1e3
+    return {"what": "kc_dwa_find_best_path under a bounded random walk of the current velocity (sigma 0.02 m/s, 0.05 rad/s per cycle)",
+            "steps": steps, "ms_per_step": float(lat.mean()), "latency_p50_ms": float(np.percentile(lat, 50)),
+            "latency_p90_ms": float(np.percentile(lat, 90)), "latency_p99_ms": float(np.percentile(lat, 99)),
+            "sample_count_changes": int(np.sum(np.diff(counts) != 0)),
+            "patterns_found_on_device": int(ctx.get_option("pattern_hits") - h0),
+            "patterns_built": int(ctx.get_option("pattern_builds") - b0)}
 
 
 def cpu_baseline_fresh(syn, inp, ctr, cur_vel, max_lin, max_ang, state, r, args, seconds):
