@@ -445,7 +445,7 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
                                                    const float *obx, const float *oby, const Pts pts,
                                                    int tid, float *s_mind, float *s_goal, float *s_end,
                                                    unsigned long long *s_obest, const float *cap = nullptr,
-                                                   const float *sup = nullptr) {
+                                                   const float *sup = nullptr, bool skip_obs = false) {
   const BucketDev &b = a.b;
   const int sub = tid & (kL - 1);
   for (int p0 = 0; p0 < a.P; p0 += kTeam / kL) {
@@ -496,7 +496,7 @@ __device__ __forceinline__ void team_sample_search(const CostArgs &a, const Seg 
         }
       }
     }
-    if (a.use_obs) {
+    if (a.use_obs && !skip_obs) {  // (skip_obs: a wavefront of the team forms the term, wave_obstacle_term)
       // query cell (clamped: a query outside the grid searches from the
       // border and the guarantee radius shrinks by its distance to the grid)
       const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
@@ -1177,6 +1177,328 @@ __device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limi
   return true;
 }
 
+// The obstacle term of ONE tile of a sample by a wavefront, a lane a trajectory point (x, y; `live` false: an idle lane
+// shadowing a point): the minimum squared distance to the obstacles goes into *obest (armed with DBL_MAX by the
+// caller), by the scan's near table, one scan of the union rectangle of bucket cells, or the ring walk.  ubound2 carries
+// a bound from tile to tile of a long trajectory.  Part of wave_sample_total; the teams of the cycle kernel call it
+// too (cycle_costs: their own block walk a point apiece runs four lanes a point and as many trips as its longest row).
+__device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcArgs &t, const int *cells, const uint8_t *skip,
+                                                   const float *obx, const float *oby, float x, float y, bool live, int lane,
+                                                   unsigned long long *obest, double &ubound2) {
+  const BucketDev &b = a.b;
+  if (a.use_obs && t.onear != nullptr) {
+    // Laser scan: the obstacles are a polyline in beam order, cut into <= 64 chunks with bounding boxes, and
+    // the near table of the scan names, per cell of the reachable box, the chunks that can hold the nearest
+    // obstacle of ANY point of the cell, an obstacle nearest to the cell centre (an attained upper bound) and
+    // a lower bound of the distance of the cell's points.  Only the minimum over the whole trajectory counts
+    // (trajectory.h:218-235): the seeds give a tight bound on it, lanes whose floor lies above that bound
+    // drop out, and the candidate chunks of the others are scanned one at a time by ALL lanes (a lane a
+    // trajectory point, a loop over the chunk's obstacles: every value formed is a true distance, so nobody
+    // needs masking and the minimum is the one of the full scan).
+    const float fx = (x - t.ox0) * t.oinv, fy = (y - t.oy0) * t.oinv;
+    const bool inside = fx >= 0.0f && fy >= 0.0f && fx < static_cast<float>(t.oW) && fy < static_cast<float>(t.oH);
+    uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);  // outside the table: every chunk, no seed
+    if (inside) e = t.onear[static_cast<int>(fy) * t.oW + static_cast<int>(fx)];
+    auto exact_dd = [&](int j) {
+      const double dx = static_cast<double>(t.osx[j] - x);
+      const double dy = static_cast<double>(t.osy[j] - y);
+      return dx * dx + dy * dy;
+    };
+    double best = DBL_MAX;
+    if (live && e.z != 0xFFFFFFFFu) best = exact_dd(static_cast<int>(e.z));
+    double shared = fmin(ubound2, wave_min_nonneg(best));
+    const double lbk = static_cast<double>(__uint_as_float(e.w));
+    uint32_t mlo = live ? e.x : 0u, mhi = live ? e.y : 0u;
+    bool cont = live && (mlo | mhi) != 0u && lbk < t.ocap && !(x != x) && !(y != y);
+    for (int half = 0; half < 2; ++half) {
+      // (re-evaluated per half: the bound only falls)
+      uint32_t U = wave_or_u32((cont && lbk * lbk < shared * (1.0 - 1e-6)) ? (half ? mhi : mlo) : 0u);
+      while (U) {
+        const int cb = __ffs(static_cast<int>(U)) - 1;
+        U &= U - 1u;
+        const int c = cb + 32 * half;
+        if (c >= t.onch) break;
+        // box of the chunk against this lane's point (float, 1e-4 of slack on the compared square)
+        const float bx0 = t.oaabb[c], bx1 = t.oaabb[64 + c], by0 = t.oaabb[128 + c], by1 = t.oaabb[192 + c];
+        const float gx = fmaxf(fmaxf(bx0 - x, x - bx1), 0.0f), gy = fmaxf(fmaxf(by0 - y, y - by1), 0.0f);
+        const double lb2 = static_cast<double>(gx * gx + gy * gy) * (1.0 - 1e-4);
+        const bool part = cont && (((half ? mhi : mlo) >> cb) & 1u) && lbk * lbk < shared * (1.0 - 1e-6) &&
+                          !(lb2 >= shared);
+        if (__ballot(part) == 0ull) continue;
+        const int j0 = c * t.ocs, j1 = min(j0 + t.ocs, t.on);
+        if (t.oscs > 0) {
+          // a quarter of the chunk at a time: the same test against the quarter's own box, the bound refreshed
+          // behind every quarter that was scanned (a 4096-beam scan has chunks of 64 obstacles: most of a chunk
+          // the table names lies beyond what a neighbouring quarter has already found)
+          const float *sb = t.oaabb + 256;
+          for (int q = 0; q < 4; ++q) {
+            const int s0 = j0 + q * t.oscs, s1 = min(s0 + t.oscs, j1);
+            if (s0 >= s1) break;
+            const int e4 = 4 * c + q;
+            const float qx0 = sb[e4], qx1 = sb[256 + e4], qy0 = sb[512 + e4], qy1 = sb[768 + e4];
+            const float hx = fmaxf(fmaxf(qx0 - x, x - qx1), 0.0f), hy = fmaxf(fmaxf(qy0 - y, y - qy1), 0.0f);
+            const double lq2 = static_cast<double>(hx * hx + hy * hy) * (1.0 - 1e-4);
+            if (__ballot(part && !(lq2 >= shared)) == 0ull) continue;
+            for (int jb = s0; jb < s1; jb += 4) {
+              double d[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) d[u] = exact_dd(min(jb + u, s1 - 1));
+#pragma unroll
+              for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);
+            }
+            shared = fmin(shared, wave_min_nonneg(best));
+          }
+          continue;
+        }
+        for (int jb = j0; jb < j1; jb += 4) {
+          double d[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) d[u] = exact_dd(min(jb + u, j1 - 1));  // (a repeat of the last one changes nothing)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);    // (NaN distances never win)
+        }
+        shared = fmin(shared, wave_min_nonneg(best));
+      }
+    }
+    ubound2 = shared;  // (carried to the next tile of a long trajectory)
+    if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(shared)));
+  } else if (a.use_obs && t.ounion > 0 &&
+             obstacle_union_scan(b, t.ounion, cells, skip, obx, oby, x, y, live, lane, obest)) {
+    // (one scan of the union block did it)
+  } else if (a.use_obs) {
+    // query cell (clamped: a query outside the grid searches from the
+    // border and the guarantee radius shrinks by its distance to the grid)
+    const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
+    const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
+    int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
+    double off = 0.0;
+    if (fx < 0.0) off = fmax(off, -fx);
+    if (fy < 0.0) off = fmax(off, -fy);
+    if (fx > b.W) off = fmax(off, fx - b.W);
+    if (fy > b.H) off = fmax(off, fy - b.H);
+    cx = min(max(cx, 0), b.W - 1);
+    cy = min(max(cy, 0), b.H - 1);
+    const int mmax = max(b.W, b.H);
+    const int sk = static_cast<int>(skip[cy * b.W + cx]);
+    // cells closer (Chebyshev) than sk are empty: the first ring is sk, and
+    // nothing is closer than (sk - 1 - off) cells
+    int pm = sk - 1;           // half-width of the block known to be empty / visited
+    int m = max(1, sk);
+    double best = DBL_MAX;
+    bool active = live && !(isnan(fx) || isnan(fy));
+    if ((static_cast<double>(pm) - off) * b.g >= b.cap) active = false;  // all of it costs 0
+    // lanes with an empty neighbourhood wait for the cooperative pass below
+    bool far = active && sk >= kCoopMinSkip && sk < 255;
+    if (far) active = false;
+    double lb0 = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
+    double ubp = DBL_MAX;
+    while (__ballot(active)) {
+      if (active) {
+        const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
+        const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
+        for (int row = y0; row <= y1; ++row) {
+          // rows inside the visited block only add the two side runs
+          const bool inner = pm >= 0 && row >= cy - pm && row <= cy + pm;
+          int beg = cells[row * b.W + x0];
+          int end = inner ? cells[row * b.W + max(cx - pm, x0)]
+                          : cells[row * b.W + x1 + 1];
+          for (int pass = 0; pass < 2; ++pass) {
+            // (a run of a thinned scene holds one or two obstacles: a first batch of two, fours behind it)
+            if (beg < end) {
+              const int j1 = min(beg + 1, end - 1);
+              const float ox0 = obx[beg], oy0 = oby[beg], ox1 = obx[j1], oy1 = oby[j1];
+              const double dx0 = static_cast<double>(ox0 - x), dy0 = static_cast<double>(oy0 - y);
+              const double dx1 = static_cast<double>(ox1 - x), dy1 = static_cast<double>(oy1 - y);
+              const double d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
+              best = __builtin_fmin(d0, best);  // (NaN distances never win either way)
+              best = __builtin_fmin(d1, best);
+            }
+            for (int jb = beg + 2; jb < end; jb += 4) {
+              float ox[4], oy[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int j = min(jb + u, end - 1);  // repeats of the last one change nothing
+                ox[u] = obx[j];
+                oy[u] = oby[j];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const double dx = static_cast<double>(ox[u] - x);
+                const double dy = static_cast<double>(oy[u] - y);
+                const double dd = dx * dx + dy * dy;
+                best = __builtin_fmin(dd, best);
+              }
+            }
+            if (!inner) break;
+            beg = cells[row * b.W + min(cx + pm, x1) + 1];
+            end = cells[row * b.W + x1 + 1];
+          }
+        }
+        atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(best)));
+      }
+      // (all lanes: the LDS queue of a wavefront is in order, the read sees every lane's minimum)
+      const double shared = __longlong_as_double(static_cast<long long>(
+          *const_cast<volatile unsigned long long *>(obest)));
+      if (active) {
+        // every obstacle closer than `reach` (true distance) was visited
+        const double reach = (static_cast<double>(m) - off) * b.g;
+        bool done = m >= mmax;  // whole grid visited
+        if (reach > 0.0) {
+          const double r2 = reach * reach * (1.0 - 1e-6);
+          if (shared < r2) done = true;
+          if (reach >= b.cap) done = true;
+        }
+        if (done) {
+          active = false;
+        } else {
+          // next half-width: enough cells to cover sqrt(shared) (+ guard),
+          // or the cap radius when nothing has been found yet (any
+          // over-estimate only visits more cells: float sqrt is enough)
+          const double need =
+              shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
+                               : b.cap;
+          const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
+          pm = m;
+          m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
+        }
+      }
+    }
+    // Far obstacles (points with an empty neighbourhood of kCoopMinSkip
+    // cells): a private ring walk per lane is long and mostly wasted,
+    // because only the trajectory minimum counts and the distance to the
+    // obstacle set is 1-Lipschitz along the trajectory.  After the near
+    // points have left their distances in the shared bound, the wavefront
+    // evaluates the far points one at a time TOGETHER (ring rows over the
+    // lanes), always the one with the smallest lower bound, and every exact
+    // distance raises the lower bounds of the others by the triangle
+    // inequality; points whose bound exceeds the best distance found are
+    // never evaluated.  The values that survive are exact, so the minimum
+    // is the one of the full scan.
+    if (__ballot(far)) {
+      // lower bound of this lane's distance (cells nearer than sk are empty;
+      // the centre table when there is one)
+      double lbk = lb0;
+      {
+        // the smallest upper bound bounds the trajectory minimum: points whose
+        // lower bound lies above it are never evaluated
+        const double u = wave_min_nonneg(far ? ubp : DBL_MAX);
+        if (u < 1.0e150) ubound2 = fmin(ubound2, u * u);
+      }
+      for (int guard = 0; guard < 64; ++guard) {
+        const double ub2 = fmin(ubound2, __longlong_as_double(static_cast<long long>(
+            *const_cast<volatile unsigned long long *>(obest))));
+        // lanes that can still lower the minimum
+        const bool cont = far && lbk * lbk < ub2 * (1.0 - 1e-6) && lbk < b.cap;
+        const unsigned long long cm = __ballot(cont);
+        if (cm == 0ull) break;
+        // the one with the smallest lower bound (float key, ties by lane)
+        const uint32_t key = cont ? __float_as_uint(static_cast<float>(lbk)) : 0xFFFFFFFFu;
+        const uint32_t kmin = wave_min_u32(key);
+        const int q = __ffsll(static_cast<long long>(__ballot(cont && key == kmin))) - 1;
+        const float xq = lane_value(x, q), yq = lane_value(y, q);
+        const int cxq = __builtin_amdgcn_readlane(cx, q), cyq = __builtin_amdgcn_readlane(cy, q);
+        const int skq = __builtin_amdgcn_readlane(sk, q);
+        const double offq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(off), q),
+                                             __builtin_amdgcn_readlane(__double2loint(off), q));
+        // exact search for (xq, yq): ring rows over the lanes; with a bound on
+        // the answer the first block is already the one that proves it
+        int pmq = skq - 1, mq = max(1, skq);
+        if (ub2 < 1.0e300) {
+          const double need0 = static_cast<double>(__builtin_sqrtf(static_cast<float>(ub2)) * 1.0001f);
+          const double mm0 = ceil(fmin(need0, b.cap * 1.001) * b.inv_g + offq) + 1.0;
+          mq = max(mq, static_cast<int>(fmin(mm0, static_cast<double>(mmax))));
+        }
+        double found = DBL_MAX;   // wave-uniform after every stage
+        double proven = 0.0;      // everything closer than this was visited
+        for (;;) {
+          const int y0 = max(cyq - mq, 0), y1 = min(cyq + mq, b.H - 1);
+          const int x0 = max(cxq - mq, 0), x1 = min(cxq + mq, b.W - 1);
+          double part = DBL_MAX;
+          auto eval = [&](int j) {
+            const double dx = static_cast<double>(obx[j] - xq);
+            const double dy = static_cast<double>(oby[j] - yq);
+            const double dd = dx * dx + dy * dy;
+            part = dd < part ? dd : part;
+          };
+          for (int row0 = y0; row0 <= y1; row0 += 64) {
+            // the (up to two) runs of this lane's row: [b1, e1) and, in rows of the visited square, [b2, e2)
+            const int row = row0 + lane;
+            int b1 = 0, e1 = 0, b2 = 0, e2 = 0;
+            if (row <= y1) {
+              const bool inner = pmq >= 0 && row >= cyq - pmq && row <= cyq + pmq;
+              if (!inner) {
+                b1 = cells[row * b.W + x0];
+                e1 = cells[row * b.W + x1 + 1];
+              } else {  // rows of the visited square: the two side runs
+                const int lb_ = min(x1, cxq - pmq - 1), ra = max(x0, cxq + pmq + 1);
+                if (x0 <= lb_) {
+                  b1 = cells[row * b.W + x0];
+                  e1 = cells[row * b.W + lb_ + 1];
+                }
+                if (ra <= x1) {
+                  b2 = cells[row * b.W + ra];
+                  e2 = cells[row * b.W + x1 + 1];
+                }
+              }
+            }
+            // A wall seen by a dense scan puts hundreds of points into one row of the block (a room, 1440 /
+            // 4096 beams: 216 / 440 us per cfg2-sized cycle with one lane per row): runs beyond kLongRun points
+            // are walked by the whole wavefront (107 / 111 us), the others by their lane alone (sparse clutter:
+            // runs of one to five points; a lower threshold costs the mid-density costmap scene 10 us)
+            constexpr int kLongRun = 16;
+            const bool long1 = e1 - b1 > kLongRun, long2 = e2 - b2 > kLongRun;
+            if (!long1)
+              for (int j = b1; j < e1; ++j) eval(j);
+            if (!long2)
+              for (int j = b2; j < e2; ++j) eval(j);
+            for (int pass = 0; pass < 2; ++pass) {
+              unsigned long long lm = __ballot(pass == 0 ? long1 : long2);
+              while (lm) {
+                const int r = __ffsll(static_cast<long long>(lm)) - 1;
+                lm &= lm - 1ull;
+                const int rb = __builtin_amdgcn_readlane(pass == 0 ? b1 : b2, r);
+                const int re = __builtin_amdgcn_readlane(pass == 0 ? e1 : e2, r);
+                for (int j = rb + lane; j < re; j += 64) eval(j);
+              }
+            }
+          }
+          const double stage = wave_min_nonneg(part);
+          found = stage < found ? stage : found;
+          const double sh = found < ub2 ? found : ub2;
+          const double reach = (static_cast<double>(mq) - offq) * b.g;
+          bool done = mq >= mmax;
+          if (reach > 0.0) {
+            proven = reach;
+            if (sh < reach * reach * (1.0 - 1e-6)) done = true;
+            if (reach >= b.cap) done = true;
+          }
+          if (done) break;
+          const double need = sh < DBL_MAX
+                                  ? static_cast<double>(__builtin_sqrtf(static_cast<float>(sh)) * 1.0001f)
+                                  : b.cap;
+          const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + offq) + 1.0;
+          pmq = mq;
+          mq = max(mq + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
+        }
+        if (lane == 0)
+          atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(found)));
+        // what is now known about the distance of point q: it is `found` when
+        // that lies inside the proven radius, at least the proven radius
+        // otherwise (the whole grid visited: nothing else exists)
+        double dq = kc::dsqrt_rn(found);
+        if (!(found < proven * proven) && mq < mmax) dq = proven;
+        if (lane == q) far = false;
+        // triangle inequality: d(p) >= d(q) - |p - q| (slack for the rounding)
+        const double ddx = static_cast<double>(x) - static_cast<double>(xq);
+        const double ddy = static_cast<double>(y) - static_cast<double>(yq);
+        const double sep = kc::dsqrt_rn(ddx * ddx + ddy * ddy);
+        const double lb = dq * (1.0 - 1e-6) - sep * (1.0 + 1e-6) - 1e-9;
+        lbk = lb > lbk ? lb : lbk;
+      }
+    }
+  }
+}
+
 // The wavefront-per-sample evaluation of ONE sample (one lane per trajectory
 // point, tiles of 64 points): see the comment on top of this file.  `seg`
 // gives the (x, y, z^2) of a segment point and its accumulated length, `cap` /
@@ -1200,8 +1522,7 @@ __device__ __forceinline__ float wave_sample_total(const CostArgs &a, const DcAr
                                                    const float *obx, const float *oby, const Pts pts,
                                                    int n, int lane, unsigned long long *obest,
                                                    bool stamp, const BatchSlot bs = BatchSlot{}) {
-  const BucketDev &b = a.b;
-if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
+  if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL_MAX));
   float sum = 0.0f;            // ordered path-cost sum, carried over the point tiles
   float goal = 0.0f, endc = 0.0f;
   double ubound2 = DBL_MAX;    // square of an upper bound of the sample's obstacle distance (not attained)
@@ -1377,317 +1698,7 @@ if (lane == 0) *obest = static_cast<unsigned long long>(__double_as_longlong(DBL
       }
     }
     if (st) KC_STAMP(11);
-    if (a.use_obs && t.onear != nullptr) {
-      // Laser scan: the obstacles are a polyline in beam order, cut into <= 64 chunks with bounding boxes, and
-      // the near table of the scan names, per cell of the reachable box, the chunks that can hold the nearest
-      // obstacle of ANY point of the cell, an obstacle nearest to the cell centre (an attained upper bound) and
-      // a lower bound of the distance of the cell's points.  Only the minimum over the whole trajectory counts
-      // (trajectory.h:218-235): the seeds give a tight bound on it, lanes whose floor lies above that bound
-      // drop out, and the candidate chunks of the others are scanned one at a time by ALL lanes (a lane a
-      // trajectory point, a loop over the chunk's obstacles: every value formed is a true distance, so nobody
-      // needs masking and the minimum is the one of the full scan).
-      const float fx = (x - t.ox0) * t.oinv, fy = (y - t.oy0) * t.oinv;
-      const bool inside = fx >= 0.0f && fy >= 0.0f && fx < static_cast<float>(t.oW) && fy < static_cast<float>(t.oH);
-      uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);  // outside the table: every chunk, no seed
-      if (inside) e = t.onear[static_cast<int>(fy) * t.oW + static_cast<int>(fx)];
-      auto exact_dd = [&](int j) {
-        const double dx = static_cast<double>(t.osx[j] - x);
-        const double dy = static_cast<double>(t.osy[j] - y);
-        return dx * dx + dy * dy;
-      };
-      double best = DBL_MAX;
-      if (live && e.z != 0xFFFFFFFFu) best = exact_dd(static_cast<int>(e.z));
-      double shared = fmin(ubound2, wave_min_nonneg(best));
-      const double lbk = static_cast<double>(__uint_as_float(e.w));
-      uint32_t mlo = live ? e.x : 0u, mhi = live ? e.y : 0u;
-      bool cont = live && (mlo | mhi) != 0u && lbk < t.ocap && !(x != x) && !(y != y);
-      for (int half = 0; half < 2; ++half) {
-        // (re-evaluated per half: the bound only falls)
-        uint32_t U = wave_or_u32((cont && lbk * lbk < shared * (1.0 - 1e-6)) ? (half ? mhi : mlo) : 0u);
-        while (U) {
-          const int cb = __ffs(static_cast<int>(U)) - 1;
-          U &= U - 1u;
-          const int c = cb + 32 * half;
-          if (c >= t.onch) break;
-          // box of the chunk against this lane's point (float, 1e-4 of slack on the compared square)
-          const float bx0 = t.oaabb[c], bx1 = t.oaabb[64 + c], by0 = t.oaabb[128 + c], by1 = t.oaabb[192 + c];
-          const float gx = fmaxf(fmaxf(bx0 - x, x - bx1), 0.0f), gy = fmaxf(fmaxf(by0 - y, y - by1), 0.0f);
-          const double lb2 = static_cast<double>(gx * gx + gy * gy) * (1.0 - 1e-4);
-          const bool part = cont && (((half ? mhi : mlo) >> cb) & 1u) && lbk * lbk < shared * (1.0 - 1e-6) &&
-                            !(lb2 >= shared);
-          if (__ballot(part) == 0ull) continue;
-          const int j0 = c * t.ocs, j1 = min(j0 + t.ocs, t.on);
-          if (t.oscs > 0) {
-            // a quarter of the chunk at a time: the same test against the quarter's own box, the bound refreshed
-            // behind every quarter that was scanned (a 4096-beam scan has chunks of 64 obstacles: most of a chunk
-            // the table names lies beyond what a neighbouring quarter has already found)
-            const float *sb = t.oaabb + 256;
-            for (int q = 0; q < 4; ++q) {
-              const int s0 = j0 + q * t.oscs, s1 = min(s0 + t.oscs, j1);
-              if (s0 >= s1) break;
-              const int e4 = 4 * c + q;
-              const float qx0 = sb[e4], qx1 = sb[256 + e4], qy0 = sb[512 + e4], qy1 = sb[768 + e4];
-              const float hx = fmaxf(fmaxf(qx0 - x, x - qx1), 0.0f), hy = fmaxf(fmaxf(qy0 - y, y - qy1), 0.0f);
-              const double lq2 = static_cast<double>(hx * hx + hy * hy) * (1.0 - 1e-4);
-              if (__ballot(part && !(lq2 >= shared)) == 0ull) continue;
-              for (int jb = s0; jb < s1; jb += 4) {
-                double d[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) d[u] = exact_dd(min(jb + u, s1 - 1));
-#pragma unroll
-                for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);
-              }
-              shared = fmin(shared, wave_min_nonneg(best));
-            }
-            continue;
-          }
-          for (int jb = j0; jb < j1; jb += 4) {
-            double d[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) d[u] = exact_dd(min(jb + u, j1 - 1));  // (a repeat of the last one changes nothing)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);    // (NaN distances never win)
-          }
-          shared = fmin(shared, wave_min_nonneg(best));
-        }
-      }
-      ubound2 = shared;  // (carried to the next tile of a long trajectory)
-      if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(shared)));
-    } else if (a.use_obs && t.ounion > 0 &&
-               obstacle_union_scan(b, t.ounion, cells, skip, obx, oby, x, y, live, lane, obest)) {
-      // (one scan of the union block did it)
-    } else if (a.use_obs) {
-      // query cell (clamped: a query outside the grid searches from the
-      // border and the guarantee radius shrinks by its distance to the grid)
-      const double fx = (static_cast<double>(x) - b.gx0) * b.inv_g;
-      const double fy = (static_cast<double>(y) - b.gy0) * b.inv_g;
-      int cx = static_cast<int>(floor(fx)), cy = static_cast<int>(floor(fy));
-      double off = 0.0;
-      if (fx < 0.0) off = fmax(off, -fx);
-      if (fy < 0.0) off = fmax(off, -fy);
-      if (fx > b.W) off = fmax(off, fx - b.W);
-      if (fy > b.H) off = fmax(off, fy - b.H);
-      cx = min(max(cx, 0), b.W - 1);
-      cy = min(max(cy, 0), b.H - 1);
-      const int mmax = max(b.W, b.H);
-      const int sk = static_cast<int>(skip[cy * b.W + cx]);
-      // cells closer (Chebyshev) than sk are empty: the first ring is sk, and
-      // nothing is closer than (sk - 1 - off) cells
-      int pm = sk - 1;           // half-width of the block known to be empty / visited
-      int m = max(1, sk);
-      double best = DBL_MAX;
-      bool active = live && !(isnan(fx) || isnan(fy));
-      if ((static_cast<double>(pm) - off) * b.g >= b.cap) active = false;  // all of it costs 0
-      // lanes with an empty neighbourhood wait for the cooperative pass below
-      bool far = active && sk >= kCoopMinSkip && sk < 255;
-      if (far) active = false;
-      double lb0 = fmax((static_cast<double>(pm) - off) * b.g, 0.0);
-      double ubp = DBL_MAX;
-      while (__ballot(active)) {
-        if (active) {
-          const int y0 = max(cy - m, 0), y1 = min(cy + m, b.H - 1);
-          const int x0 = max(cx - m, 0), x1 = min(cx + m, b.W - 1);
-          for (int row = y0; row <= y1; ++row) {
-            // rows inside the visited block only add the two side runs
-            const bool inner = pm >= 0 && row >= cy - pm && row <= cy + pm;
-            int beg = cells[row * b.W + x0];
-            int end = inner ? cells[row * b.W + max(cx - pm, x0)]
-                            : cells[row * b.W + x1 + 1];
-            for (int pass = 0; pass < 2; ++pass) {
-              // (a run of a thinned scene holds one or two obstacles: a first batch of two, fours behind it)
-              if (beg < end) {
-                const int j1 = min(beg + 1, end - 1);
-                const float ox0 = obx[beg], oy0 = oby[beg], ox1 = obx[j1], oy1 = oby[j1];
-                const double dx0 = static_cast<double>(ox0 - x), dy0 = static_cast<double>(oy0 - y);
-                const double dx1 = static_cast<double>(ox1 - x), dy1 = static_cast<double>(oy1 - y);
-                const double d0 = dx0 * dx0 + dy0 * dy0, d1 = dx1 * dx1 + dy1 * dy1;
-                best = __builtin_fmin(d0, best);  // (NaN distances never win either way)
-                best = __builtin_fmin(d1, best);
-              }
-              for (int jb = beg + 2; jb < end; jb += 4) {
-                float ox[4], oy[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  const int j = min(jb + u, end - 1);  // repeats of the last one change nothing
-                  ox[u] = obx[j];
-                  oy[u] = oby[j];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  const double dx = static_cast<double>(ox[u] - x);
-                  const double dy = static_cast<double>(oy[u] - y);
-                  const double dd = dx * dx + dy * dy;
-                  best = __builtin_fmin(dd, best);
-                }
-              }
-              if (!inner) break;
-              beg = cells[row * b.W + min(cx + pm, x1) + 1];
-              end = cells[row * b.W + x1 + 1];
-            }
-          }
-          atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(best)));
-        }
-        // (all lanes: the LDS queue of a wavefront is in order, the read sees every lane's minimum)
-        const double shared = __longlong_as_double(static_cast<long long>(
-            *const_cast<volatile unsigned long long *>(obest)));
-        if (active) {
-          // every obstacle closer than `reach` (true distance) was visited
-          const double reach = (static_cast<double>(m) - off) * b.g;
-          bool done = m >= mmax;  // whole grid visited
-          if (reach > 0.0) {
-            const double r2 = reach * reach * (1.0 - 1e-6);
-            if (shared < r2) done = true;
-            if (reach >= b.cap) done = true;
-          }
-          if (done) {
-            active = false;
-          } else {
-            // next half-width: enough cells to cover sqrt(shared) (+ guard),
-            // or the cap radius when nothing has been found yet (any
-            // over-estimate only visits more cells: float sqrt is enough)
-            const double need =
-                shared < DBL_MAX ? static_cast<double>(__builtin_sqrtf(static_cast<float>(shared)) * 1.0001f)
-                                 : b.cap;
-            const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + off) + 1.0;
-            pm = m;
-            m = max(m + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-          }
-        }
-      }
-      // Far obstacles (points with an empty neighbourhood of kCoopMinSkip
-      // cells): a private ring walk per lane is long and mostly wasted,
-      // because only the trajectory minimum counts and the distance to the
-      // obstacle set is 1-Lipschitz along the trajectory.  After the near
-      // points have left their distances in the shared bound, the wavefront
-      // evaluates the far points one at a time TOGETHER (ring rows over the
-      // lanes), always the one with the smallest lower bound, and every exact
-      // distance raises the lower bounds of the others by the triangle
-      // inequality; points whose bound exceeds the best distance found are
-      // never evaluated.  The values that survive are exact, so the minimum
-      // is the one of the full scan.
-      if (__ballot(far)) {
-        // lower bound of this lane's distance (cells nearer than sk are empty;
-        // the centre table when there is one)
-        double lbk = lb0;
-        {
-          // the smallest upper bound bounds the trajectory minimum: points whose
-          // lower bound lies above it are never evaluated
-          const double u = wave_min_nonneg(far ? ubp : DBL_MAX);
-          if (u < 1.0e150) ubound2 = fmin(ubound2, u * u);
-        }
-        for (int guard = 0; guard < 64; ++guard) {
-          const double ub2 = fmin(ubound2, __longlong_as_double(static_cast<long long>(
-              *const_cast<volatile unsigned long long *>(obest))));
-          // lanes that can still lower the minimum
-          const bool cont = far && lbk * lbk < ub2 * (1.0 - 1e-6) && lbk < b.cap;
-          const unsigned long long cm = __ballot(cont);
-          if (cm == 0ull) break;
-          // the one with the smallest lower bound (float key, ties by lane)
-          const uint32_t key = cont ? __float_as_uint(static_cast<float>(lbk)) : 0xFFFFFFFFu;
-          const uint32_t kmin = wave_min_u32(key);
-          const int q = __ffsll(static_cast<long long>(__ballot(cont && key == kmin))) - 1;
-          const float xq = lane_value(x, q), yq = lane_value(y, q);
-          const int cxq = __builtin_amdgcn_readlane(cx, q), cyq = __builtin_amdgcn_readlane(cy, q);
-          const int skq = __builtin_amdgcn_readlane(sk, q);
-          const double offq = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(off), q),
-                                               __builtin_amdgcn_readlane(__double2loint(off), q));
-          // exact search for (xq, yq): ring rows over the lanes; with a bound on
-          // the answer the first block is already the one that proves it
-          int pmq = skq - 1, mq = max(1, skq);
-          if (ub2 < 1.0e300) {
-            const double need0 = static_cast<double>(__builtin_sqrtf(static_cast<float>(ub2)) * 1.0001f);
-            const double mm0 = ceil(fmin(need0, b.cap * 1.001) * b.inv_g + offq) + 1.0;
-            mq = max(mq, static_cast<int>(fmin(mm0, static_cast<double>(mmax))));
-          }
-          double found = DBL_MAX;   // wave-uniform after every stage
-          double proven = 0.0;      // everything closer than this was visited
-          for (;;) {
-            const int y0 = max(cyq - mq, 0), y1 = min(cyq + mq, b.H - 1);
-            const int x0 = max(cxq - mq, 0), x1 = min(cxq + mq, b.W - 1);
-            double part = DBL_MAX;
-            auto eval = [&](int j) {
-              const double dx = static_cast<double>(obx[j] - xq);
-              const double dy = static_cast<double>(oby[j] - yq);
-              const double dd = dx * dx + dy * dy;
-              part = dd < part ? dd : part;
-            };
-            for (int row0 = y0; row0 <= y1; row0 += 64) {
-              // the (up to two) runs of this lane's row: [b1, e1) and, in rows of the visited square, [b2, e2)
-              const int row = row0 + lane;
-              int b1 = 0, e1 = 0, b2 = 0, e2 = 0;
-              if (row <= y1) {
-                const bool inner = pmq >= 0 && row >= cyq - pmq && row <= cyq + pmq;
-                if (!inner) {
-                  b1 = cells[row * b.W + x0];
-                  e1 = cells[row * b.W + x1 + 1];
-                } else {  // rows of the visited square: the two side runs
-                  const int lb_ = min(x1, cxq - pmq - 1), ra = max(x0, cxq + pmq + 1);
-                  if (x0 <= lb_) {
-                    b1 = cells[row * b.W + x0];
-                    e1 = cells[row * b.W + lb_ + 1];
-                  }
-                  if (ra <= x1) {
-                    b2 = cells[row * b.W + ra];
-                    e2 = cells[row * b.W + x1 + 1];
-                  }
-                }
-              }
-              // A wall seen by a dense scan puts hundreds of points into one row of the block (a room, 1440 /
-              // 4096 beams: 216 / 440 us per cfg2-sized cycle with one lane per row): runs beyond kLongRun points
-              // are walked by the whole wavefront (107 / 111 us), the others by their lane alone (sparse clutter:
-              // runs of one to five points; a lower threshold costs the mid-density costmap scene 10 us)
-              constexpr int kLongRun = 16;
-              const bool long1 = e1 - b1 > kLongRun, long2 = e2 - b2 > kLongRun;
-              if (!long1)
-                for (int j = b1; j < e1; ++j) eval(j);
-              if (!long2)
-                for (int j = b2; j < e2; ++j) eval(j);
-              for (int pass = 0; pass < 2; ++pass) {
-                unsigned long long lm = __ballot(pass == 0 ? long1 : long2);
-                while (lm) {
-                  const int r = __ffsll(static_cast<long long>(lm)) - 1;
-                  lm &= lm - 1ull;
-                  const int rb = __builtin_amdgcn_readlane(pass == 0 ? b1 : b2, r);
-                  const int re = __builtin_amdgcn_readlane(pass == 0 ? e1 : e2, r);
-                  for (int j = rb + lane; j < re; j += 64) eval(j);
-                }
-              }
-            }
-            const double stage = wave_min_nonneg(part);
-            found = stage < found ? stage : found;
-            const double sh = found < ub2 ? found : ub2;
-            const double reach = (static_cast<double>(mq) - offq) * b.g;
-            bool done = mq >= mmax;
-            if (reach > 0.0) {
-              proven = reach;
-              if (sh < reach * reach * (1.0 - 1e-6)) done = true;
-              if (reach >= b.cap) done = true;
-            }
-            if (done) break;
-            const double need = sh < DBL_MAX
-                                    ? static_cast<double>(__builtin_sqrtf(static_cast<float>(sh)) * 1.0001f)
-                                    : b.cap;
-            const double mm = ceil(fmin(need, b.cap * 1.001) * b.inv_g + offq) + 1.0;
-            pmq = mq;
-            mq = max(mq + 1, static_cast<int>(fmin(mm, static_cast<double>(mmax))));
-          }
-          if (lane == 0)
-            atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(found)));
-          // what is now known about the distance of point q: it is `found` when
-          // that lies inside the proven radius, at least the proven radius
-          // otherwise (the whole grid visited: nothing else exists)
-          double dq = kc::dsqrt_rn(found);
-          if (!(found < proven * proven) && mq < mmax) dq = proven;
-          if (lane == q) far = false;
-          // triangle inequality: d(p) >= d(q) - |p - q| (slack for the rounding)
-          const double ddx = static_cast<double>(x) - static_cast<double>(xq);
-          const double ddy = static_cast<double>(y) - static_cast<double>(yq);
-          const double sep = kc::dsqrt_rn(ddx * ddx + ddy * ddy);
-          const double lb = dq * (1.0 - 1e-6) - sep * (1.0 + 1e-6) - 1e-9;
-          lbk = lb > lbk ? lb : lbk;
-        }
-      }
-    }
+    wave_obstacle_term(a, t, cells, skip, obx, oby, x, y, live, lane, obest, ubound2);
     if (st) KC_STAMP(12);
     // ordered path-cost sum of this tile (pathCostFunc, cost_evaluator.cpp:111-141)
     if (kBatched) {

@@ -166,7 +166,8 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
     s_bslot = -1;
   }
   const SegPairs seg{t.xy, t.za};
-  if (R <= kTeamMaxSurvivors) {
+  const bool teams = R <= tail.team_max;
+  if (teams) {
     // every survivor at once: R teams (two halves or four quarters of the workgroup)
     const bool quarters = R > 2;
     const int team = quarters ? kBlock / 4 : kBlock / 2;
@@ -176,15 +177,31 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
     __syncthreads();  // (also s_key)
     const int s = active ? lsurv[h] : 0;
     const PosePts pts{lpos + s * PP, PP - 1};
-    if (active) {
+    // The obstacle term of a team's sample is formed by the team's LAST wavefront, a lane a point, the way the
+    // wavefront-per-sample path forms it (wave_obstacle_term: near table of a scan / one scan of the union rectangle /
+    // cooperative ring walk) -- beside the segment search of the other wavefronts when that wavefront holds no point of it
+    // (halves: 400 of 512 lanes search), behind its share otherwise (quarters).  The block walk a point apiece that the
+    // teams ran before took as many trips as the longest row of any point of a wavefront: quarters were 16 us late in
+    // clutter (cfg2, 38-step horizon).  Trajectories of more than 64 points keep the walk.
+    const bool wave_obs = c.use_obs && c.P <= 64;
+    const int lanes_per = quarters ? 4 : 8;
+    const bool last_wave = tt >= team - 64;
+    const bool holds_points = (team - 64) / lanes_per < c.P;  // (uniform: the last wavefront's first point slot)
+    if (active && !(wave_obs && last_wave && !holds_points)) {
       if (quarters)
         team_sample_search<kBlock / 4, SegPairs, PosePts, 4>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
                                                             t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h],
-                                                            t.cap, t.cap + 8 * c.nch);
+                                                            t.cap, t.cap + 8 * c.nch, wave_obs);
       else
         team_sample_search<kBlock / 2, SegPairs, PosePts, 8>(c, seg, sz_end, t.cells, t.skip, c.b.bx, c.b.by, pts, tt,
                                                             t.mind + h * c.P, &s_goal[h], &s_end[h], &s_ob[h],
-                                                            t.cap, t.cap + 8 * c.nch);
+                                                            t.cap, t.cap + 8 * c.nch, wave_obs);
+    }
+    if (active && wave_obs && last_wave) {
+      const bool live = lane < c.P;
+      const int p = live ? lane : c.P - 1;
+      double ubound2 = DBL_MAX;
+      wave_obstacle_term(c, tail.t, t.cells, t.skip, c.b.bx, c.b.by, pts.x(p), pts.y(p), live, lane, &s_ob[h], ubound2);
     }
     KC_RSTAMP(10);
     __syncthreads();

@@ -732,6 +732,7 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
     c->cycle_forced = v == 2.0;
   }
   else if (n == "write_paths") c->write_paths = on;
+  else if (n == "team_max") c->team_max = std::min(4, std::max(0, static_cast<int>(v)));
   else if (n == "host_reduce") c->host_reduce = on;
   else if (n == "cost_kernel") {
     if (!(v == 0.0 || v == 1.0 || v == 2.0)) KC_FAIL(KC_ERR_RANGE, "cost_kernel: 0 auto, 1 workgroup per sample, 2 wavefront per sample");
@@ -784,6 +785,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   const std::string n(name);
   if (n == "fused_cycle") *v = c->cycle_fused ? (c->cycle_forced ? 2.0 : 1.0) : 0.0;
   else if (n == "write_paths") *v = c->write_paths;
+  else if (n == "team_max") *v = c->team_max;
   else if (n == "host_reduce") *v = c->host_reduce;
   else if (n == "cost_kernel") *v = c->cost_kernel_force;
   else if (n == "sensor_two_launch") *v = c->sensor_two_launch;

@@ -261,6 +261,7 @@ struct kc_dwa {
   PinBuf<long long> h_pub;     // {key, n_adm, compact, seq} written by the GPU
   long long seq = 0;           // last cycle sequence handed to finalize
   bool pub_pending = false;
+  int team_max = 4;        // option "team_max" (0..4): workgroups of the cycle kernel with that many survivors cost them by teams
   bool perm_busy = false;  // a queued roll-out reads the walking orders (d_perm ...): cleared with `drained`
   bool drained = false;  // the host saw the last cost kernel's record: every earlier
                          // command of the stream has finished with the staging buffers

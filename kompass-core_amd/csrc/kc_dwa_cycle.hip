@@ -954,6 +954,7 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
       KC_TRY(c->h_wrow.reserve(static_cast<size_t>(G) * 2 * P));
       tail.tab_off = static_cast<unsigned>(tab_off);
       tail.write_paths = c->write_paths ? 1 : 0;
+      tail.team_max = c->team_max;
       tail.block_keys = c->d_block_keys.p;
       tail.adm_bits = c->d_adm_bits.p;
       tail.result = c->d_result.p;

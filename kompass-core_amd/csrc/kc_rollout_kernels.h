@@ -238,6 +238,7 @@ struct CycleTail {
   DcArgs t;
   unsigned tab_off;               // byte offset of the cost tables in dynamic LDS (16-aligned)
   int write_paths;                // also store the float rows (debugging samples)
+  int team_max;                   // survivors of a workgroup up to which they are costed by teams (<= kTeamMaxSurvivors)
   long long *block_keys;          // [grid][2] best key + row check word per workgroup (sc1 stores / loads)
   uint32_t *adm_bits;             // [n / 32 + 1] admissible samples by local id (agent-scope atomic OR;
                                   // zero at launch, cleared again by the last workgroup)

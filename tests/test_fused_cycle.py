@@ -332,3 +332,31 @@ def test_a_moving_window_finds_its_patterns_on_the_device():
     builds, hits = ctx.get_option("pattern_builds"), ctx.get_option("pattern_hits")
     assert builds <= len(vels) + 1 and hits >= 1, (builds, hits, counts)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [44, 38, 31])
+def test_shorter_horizons_through_the_teams(P):
+    """cfg2 on the clutter scene with a shortened horizon: 700 .. 2000 samples survive, three or four a workgroup -- the
+    workgroups that cost their survivors by QUARTERS, whose obstacle term the team's last wavefront now forms
+    (wave_obstacle_term; round 4: the block walk a point apiece made those workgroups 16 us late).  Full size, every
+    cost against the threaded oracle."""
+    import synthetic as syn
+    from helpers import oracle_cycle_mt
+
+    inp = syn.make_controller_inputs("cfg2", seed=0, scene="survey")
+    inp = dict(inp, P=P)
+    o = oracle_cycle_mt(inp)
+    ctx = hip_context(kh, inp)
+    h = hip_cycle(kh, inp, ctx=ctx)
+    assert h["res"]["n_admissible"] == len(o["raw"]) and 500 < len(o["raw"]) < 3000
+    np.testing.assert_array_equal(h["raw"], o["raw"])
+    np.testing.assert_array_equal(h["costs"].view(np.uint32), o["costs"].view(np.uint32))
+    assert h["res"]["found"] and h["res"]["index"] == o["index"]
+    for tm in (2, 0):   # halves only / a wavefront a sample: the same record
+        ctx.set_option("team_max", tm)
+        r = ctx.cycle(inp["state"], P)
+        assert ctx.get_option("last_cycle_single_launch") == 1.0
+        assert (r.found, r.index, r.raw_index, r.n_admissible) == (True, h["res"]["index"], h["res"]["raw_index"], h["res"]["n_admissible"])
+        assert np.float32(r.cost) == np.float32(h["res"]["cost"])
+    ctx.close()

@@ -11,6 +11,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 scene = sys.argv[2] if len(sys.argv) > 2 else "survey"
 inp = syn.make_controller_inputs(cfg, seed=0, scene=scene)
 P, S = inp["P"], len(inp["seg_xyz"])
+Pc = int(os.environ.get("KC_TOOL_P", P))   # (a shorter horizon for this run: more samples survive)
 ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"], inp["dt"],
                     max_samples=len(inp["vx"]), max_points=P, max_segment=S, max_obstacles=len(inp["points"]),
                     acc_limits=inp["acc_limits"])
@@ -20,6 +21,6 @@ ctx.set_points(inp["state"], inp["points"], inp["max_range"])
 ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
 ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
 for i in range(20):
-    res = ctx.cycle((0.0, 0.0, 1e-3 * (i % 7 - 3), 0.0), P)
+    res = ctx.cycle((0.0, 0.0, 1e-3 * (i % 7 - 3), 0.0), Pc)
 print(cfg, scene, "admissible", res.n_admissible, "single launch", ctx.get_option("last_cycle_single_launch"), flush=True)
 ctx.close()
