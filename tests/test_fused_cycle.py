@@ -360,3 +360,30 @@ def test_shorter_horizons_through_the_teams(P):
         assert (r.found, r.index, r.raw_index, r.n_admissible) == (True, h["res"]["index"], h["res"]["raw_index"], h["res"]["n_admissible"])
         assert np.float32(r.cost) == np.float32(h["res"]["cost"])
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p_occ,scale", [(0.0003, 1.0), (0.001, 0.5), (0.0001, 0.5)])
+def test_sparse_scenes_every_cost_against_the_oracle(p_occ, scale):
+    """A few obstacles metres away from every trajectory: no point of a sample has an occupied cell within two cells, the
+    case the union-rectangle scan used to hand to the ring walks (round 4: 73 us a cycle; its seed block now grows to the
+    smallest skip value of the sample).  Every admissible sample's cost, the winner, bit for bit."""
+    import synthetic as syn
+    from helpers import oracle_cycle_mt
+
+    inp = syn.make_controller_inputs("cfg2", seed=0, scale=scale, scene="survey")
+    inp = dict(inp, points=syn.costmap_points(syn.CONFIGS["cfg2"]["map_side"], 0.05, 3, p_occ=p_occ, free_radius=1.0))
+    o = oracle_cycle_mt(inp)
+    ctx = hip_context(kh, inp)
+    h = hip_cycle(kh, inp, ctx=ctx)
+    assert h["res"]["n_admissible"] == len(o["raw"]) and len(o["raw"]) > 0.8 * len(inp["vx"])
+    np.testing.assert_array_equal(h["raw"], o["raw"])
+    np.testing.assert_array_equal(h["costs"].view(np.uint32), o["costs"].view(np.uint32))
+    assert h["res"]["found"] and h["res"]["index"] == o["index"]
+    for opt in (dict(fused_cycle=0), dict(obs_union=0)):   # the three-kernel cycle; the walks alone
+        for k, v in opt.items():
+            ctx.set_option(k, v)
+        r = ctx.cycle(inp["state"], inp["P"])
+        assert (r.found, r.index, r.raw_index, r.n_admissible) == (True, h["res"]["index"], h["res"]["raw_index"], h["res"]["n_admissible"])
+        assert np.float32(r.cost) == np.float32(h["res"]["cost"])
+    ctx.close()
