@@ -444,7 +444,7 @@ void sensor_kernel_limits(kc_dwa *c);  // dynamic-LDS limit of sensor_fused_kern
 int ensure_near_table_box(kc_dwa *c, double lo_x, double lo_y, double hi_x, double hi_y, double margin);
 int ensure_near_table(kc_dwa *c, double x, double y, double margin = 0.0);
 int near_table_ahead(kc_dwa *c);
-int ensure_onear(kc_dwa *c, double x, double y);
+int ensure_onear(kc_dwa *c, double x, double y, bool build = true);
 // cycle
 double cycle_reach(const kc_dwa *c);
 int ensure_cycle_buffers(kc_dwa *c, size_t n, size_t P);

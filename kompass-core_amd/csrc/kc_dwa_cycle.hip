@@ -883,6 +883,10 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
     if (c->near_wanted) {
       KC_TRY(ensure_near_table(c, start->x, start->y));
       KC_TRY(ensure_onear(c, start->x, start->y));
+    } else {
+      // few survivors: the scan's near table only if it is there already (the teams' last wavefronts use it: a tiny room
+      // puts the whole scan into the union rectangle of a sample, 35 us for 44 survivors without the table)
+      KC_TRY(ensure_onear(c, start->x, start->y, false));
     }
     KC_TRY(build_cost_args(c, n, c->shard_first, tail.c, tail.t));
   }

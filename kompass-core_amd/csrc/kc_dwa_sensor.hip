@@ -981,7 +981,7 @@ int onear_plan_ahead(kc_dwa *c, double x, double y) {
   return KC_OK;
 }
 
-int ensure_onear(kc_dwa *c, double x, double y) {
+int ensure_onear(kc_dwa *c, double x, double y, bool build) {
   c->onear_ok = false;
   if (!onear_wanted(c)) return KC_OK;
   const double reach = cycle_reach(c);
@@ -995,6 +995,8 @@ int ensure_onear(kc_dwa *c, double x, double y) {
       return KC_OK;
     }
   }
+  if (!build) return KC_OK;  // (a cycle with a handful of survivors takes the table when it is there -- it rode in the sensor
+                             // launch -- and does not pay a launch for it)
   ObsNearArgs oa{};
   bool ok = false;
   KC_TRY(onear_plan(c, x, y, reach, oa, &ok));
