@@ -56,8 +56,12 @@ constexpr size_t kCostLdsBudget = 150 * 1024;
 constexpr int kSegChunkMin = 16;
 constexpr int kCoopMinSkip = 3;   // empty cells around every point from which the obstacle search
                                   // of a sample is done point by point by the whole wavefront
-constexpr long long kBlockKernelMaxAdm = 512;   // longest list the workgroup-per-sample kernel gets (one
-                                                // resident round of workgroups; measured crossover ~650)  // segment points per bounding sphere (at most 64 chunks)
+// Longest list the workgroup-per-sample kernel gets by itself.  Round 2 measured a crossover near 650 samples; since then
+// the wavefront-per-sample kernel got the near table, the union-rectangle scan and the folded publish, and round 4's
+// density sweep finds it ahead at every list length (cfg3: 0 / 123 / 489 admissible: 10.4 / 24.2 / 25.7 us against
+// 7.3 + 6.5 / 27.7 + 6.6 / 36.7 + 6.6 with the publish kernel the block kernel needs; cfg2's three-kernel cycle at 393:
+// 18.9 against 16.4 + 6.6).  The block kernel stays behind option cost_kernel = 1.
+constexpr long long kBlockKernelMaxAdm = -1;
 
 struct BucketDev {
   int W, H;            // cells
