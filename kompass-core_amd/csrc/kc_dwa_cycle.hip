@@ -868,12 +868,14 @@ int rollout_impl(kc_dwa *c, const kc_state *start, size_t P, bool want_cycle, bo
   if (blocks_for(n, static_cast<unsigned>(cs)) > 2048u) cs = 32;
   c->cycle_samples = cs;
   const unsigned cyc_G = blocks_for(n, static_cast<unsigned>(cs));
+  // (Rounds 2-3 sent small lattices with many survivors to the stand-alone cost kernels -- "they spread the survivors
+  // over all CUs".  Round 4's lattice sweep, 110 .. 2025 samples, half or all of them admissible: the single launch is
+  // 3 us ahead everywhere -- the second launch costs more than the spreading gains.  One resident round of workgroups is
+  // the only condition left.)
   const bool cyc_wave = cyc_G <= static_cast<unsigned>(c->num_cus);
-  const bool cyc_few = c->last_nadm < 0 || c->last_nadm <= 4ll * cyc_G;
-  const bool cyc_full = 2 * cyc_G >= static_cast<unsigned>(c->num_cus);
   const bool sphere_ok = c->prm.shape != KC_SPHERE || (c->have_gbits && c->gz_valid);  // (fused path)
   bool cycle = want_cycle && c->cycle_fused && sphere_ok && n <= 1024u * kCompactMaxPer &&
-               (c->cycle_forced || (cyc_wave && (cyc_few || cyc_full)));
+               (c->cycle_forced || cyc_wave);
   if (cycle) {
     // workgroups with more than a handful of survivors search wavefront-per-sample: through the
     // near table when the last cycle had that many
