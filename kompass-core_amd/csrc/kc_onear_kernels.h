@@ -74,6 +74,22 @@ __device__ __forceinline__ void obs_near_body(const ObsNearArgs &a, int block, u
     }
   }
   ub = group_min_u32<kL>(ub);
+  const float h = a.g * 0.70710679f * 1.0001f + a.slack;
+  {
+    // Every chunk's box beyond max_obstacles_dist + h of the centre: the cell costs nothing, whatever its nearest
+    // obstacle is -- no scan.  (Round 4: a room wider than the cap around the robot is nothing but such cells, and the
+    // scans of step (2) -- every chunk of a round wall is as near as every other -- made the sensor launch that carries
+    // this table 31 us instead of 12.)
+    float lmin = __builtin_inff();
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) lmin = fminf(lmin, fmaxf(lb[u], 0.0f));  // (a NaN box: lb = -inf -> 0: never early)
+    const float lall = __uint_as_float(group_min_u32<kL>(__float_as_uint(lmin)));
+    const float fl0 = (lall - h) * 0.9999f - 4e-7f * mag;
+    if (fl0 >= a.cap) {
+      if (sub == 0 && cell < ncell) a.out[cell] = make_uint4(0u, 0u, 0xFFFFFFFFu, __float_as_uint(fl0));
+      return;
+    }
+  }
   const float uthr = __builtin_sqrtf(__uint_as_float(ub)) * 1.0001f;
   // (2) the chunks that may hold something as close as that are scanned by the whole group: m and a seed
   uint32_t qlo = 0u, qhi = 0u;
@@ -103,7 +119,6 @@ __device__ __forceinline__ void obs_near_body(const ObsNearArgs &a, int block, u
   const uint32_t mg = group_min_u32<kL>(mb);
   const uint32_t jg = group_min_u32<kL>(mb == mg ? jb : 0xFFFFFFFFu);
   // (3) the chunks within m + 2 h, the floor of the cell
-  const float h = a.g * 0.70710679f * 1.0001f + a.slack;
   const float m = __builtin_sqrtf(__uint_as_float(mg));  // (+inf-ish when nothing is finite)
   const float R = m * 1.0001f + 2.0f * h;
   uint32_t lo = 0u, hi = 0u;
