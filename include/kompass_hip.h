@@ -161,8 +161,8 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        workgroup (what kc_dwa_cycle_sharded always uses)
  *   "write_paths"    (0) the single-launch cycle also stores every float row
  *                        (otherwise rows are produced on demand by kc_dwa_get_samples)
- *   "cost_kernel"    (0) stand-alone cost stage: 0 chosen from the admissible count
- *                        of the previous cycle, 1 workgroup per sample, 2 wavefront per sample
+ *   "cost_kernel"    (0) stand-alone cost stage: 0 = 2 (round 4: the wavefront-per-sample kernel is ahead at
+ *                        every list length), 1 workgroup per sample, 2 wavefront per sample
  *   "drop_samples"   (1) TrajectorySampler::setSampleDroppingMode (trajectory_sampler.cpp:103-105).  0: a
  *                        sample that collides at loop step i with last_free_index = i - 1 beyond
  *                        "num_ctrl_points" is KEPT (:157-168): path points i + 1 .. P - 1 repeat point
@@ -192,10 +192,15 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host (spheres always are)
  *   "sensor_two_launch" (0) the sensor build of clouds beyond 32 k points (two launches) for every size
  *   "force_split"    (0) roll-out, collision and compaction as separate kernels
+ *   "team_max"       (4) workgroups of the single-launch cycle with up to this many survivors cost them by teams
+ *                        (halves / quarters of the workgroup, eight / four lanes a trajectory point); more: a
+ *                        wavefront a sample.  0: always a wavefront a sample
  * kc_dwa_get_option also reads "last_cycle_single_launch", "last_cycle_samples",
  * "host_threads", "trig_rows" (rows of the host's cos / sin table: distinct omegas of
  * this context's share), "shard_samples", and the counters "obs_near_rides" /
- * "obs_near_builds" (near tables built inside a sensor launch / by a launch of their own).
+ * "obs_near_builds" (near tables built inside a sensor launch / by a launch of their own),
+ * "pattern_hits" / "pattern_builds" (index patterns of a window lattice found on the device /
+ * walking orders built for a new one).
  * Waits for the context's stream.  Nothing that selects a path is read from the environment (round 4); the
  * variables that remain are diagnostics (Switches). */
 int kc_dwa_set_option(kc_dwa *ctx, const char *name, double value);
