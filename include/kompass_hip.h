@@ -189,7 +189,7 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "device_trig"    (1) cos / sin(yaw_k) formed by the roll-out kernels themselves (below:
  *                        kc_trig_selfcheck); 0: the FALLBACK -- the host's libm table, complete before the
  *                        launch (no kernel ever waits for the host)
- *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host (spheres always are)
+ *   "sensor_on_host" (0) voxel bitmap / obstacle buckets built on the host (spheres beyond 32 k points or 32 z layers are)
  *   "sensor_two_launch" (0) the sensor build of clouds beyond 32 k points (two launches) for every size
  *   "force_split"    (0) roll-out, collision and compaction as separate kernels
  *   "team_max"       (4) workgroups of the single-launch cycle with up to this many survivors cost them by teams

@@ -201,9 +201,19 @@ int upload_voxels(kc_dwa *c) {
   c->gz_valid = false;
   if (c->prm.shape == KC_SPHERE) {
     // z gaps of the accepted voxels: one value per voxel layer within the sphere's height
-    std::vector<double> lut(c->vox_ddz.begin(), c->vox_ddz.end());
+    // (the gaps are a function of the voxel LAYER: a handful of distinct values among thousands of voxels -- collected
+    // by a scan against the values seen so far, sorted afterwards; sorting every voxel's gap was most of a sphere's
+    // sensor update)
+    std::vector<double> lut;
+    for (double g : c->vox_ddz) {
+      bool seen = false;
+      for (double v : lut) seen = seen || v == g;
+      if (!seen) {
+        lut.push_back(g);
+        if (lut.size() > 255) break;
+      }
+    }
     std::sort(lut.begin(), lut.end());
-    lut.erase(std::unique(lut.begin(), lut.end()), lut.end());
     if (lut.size() <= 255) {
       const size_t gW = static_cast<size_t>(c->gwpr) * 32, ncell = gW * c->gH;
       KC_TRY(c->h_gz.reserve(ncell));
@@ -463,9 +473,9 @@ __attribute__((target("avx512f"))) size_t bounds_copy_avx512(const float *src, f
 int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
   *done = false;
   c->raw_on_device = false;
-  if (!c->device_sensor || !c->trig_direct || c->prm.shape == KC_SPHERE ||
-      n == 0 || n > kSensorDeviceMax)
+  if (!c->device_sensor || !c->trig_direct || n == 0 || n > kSensorDeviceMax)
     return KC_OK;
+  if (c->prm.shape == KC_SPHERE && (c->sensor_two_launch || n > kSensorFusedMax || !c->sensor_fused_ok)) return KC_OK;
   float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   size_t nfin = 0;
   bool bounded = false, raw_copied = false;
@@ -588,8 +598,7 @@ int plan_trig_job(kc_dwa *c, TrigJob &j) {
 int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const float lo[3],
                                  const float hi[3], bool *done, bool raw_copied) {
   *done = false;
-  if (!c->device_sensor || !c->trig_direct || c->prm.shape == KC_SPHERE ||
-      n == 0 || n > kSensorDeviceMax)
+  if (!c->device_sensor || !c->trig_direct || n == 0 || n > kSensorDeviceMax)
     return KC_OK;
   // bitmap: keys of the bounds (points beyond the 16-level octree are dropped
   // by add_voxel anyway)
@@ -597,12 +606,60 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     const double f = std::floor(c->inv_res * static_cast<double>(v));
     return static_cast<int>(std::min(std::max(f, -32768.0), 32767.0));
   };
+  // Spheres (round 4; the host build took 120 us of a 176 us cycle): a voxel's z gap to the sphere's centre is a function
+  // of its LAYER, so add_voxel's rule is evaluated here once per layer the cloud's z range can hold -- accepted layers,
+  // their gaps in ascending order (the LUT of the exact tests), the code of every layer -- and the one-launch build keeps
+  // the smallest code of every voxel column (sensor_band_body).  The gap bound of the dilated masks is the largest gap of
+  // those layers: at least the largest gap present, so "certain hits" stay certain.  More than 32 layers, more than
+  // 32 k points, bands beyond LDS: the host build.
+  const bool sphere = c->prm.shape == KC_SPHERE;
+  int sph_kz0 = 0, sph_nkz = 0;
+  unsigned char sph_code[36] = {0};
+  std::vector<double> sph_lut;
+  if (sphere) {
+    if (c->sensor_two_launch || n > kSensorFusedMax || !c->sensor_fused_ok) return KC_OK;
+    const int k0 = key(lo[2]), k1 = key(hi[2]);
+    if (k1 - k0 + 1 > 36) return KC_OK;
+    const double zc = -static_cast<double>(c->frame.t[2]);
+    double gap[36];
+    double gmax = -1.0;
+    for (int kz = k0; kz <= k1; ++kz) {  // add_voxel, the sphere branch
+      const double zlo = static_cast<double>(kz) * c->res, zhi = static_cast<double>(kz + 1) * c->res;
+      double ddz = 0.0;
+      if (zlo - zc > ddz) ddz = zlo - zc;
+      if (zc - zhi > ddz) ddz = zc - zhi;
+      gap[kz - k0] = ddz > c->radius ? -1.0 : ddz;
+      if (gap[kz - k0] >= 0.0) {
+        gmax = std::max(gmax, ddz);
+        bool seen = false;
+        for (double v : sph_lut) seen = seen || v == ddz;
+        if (!seen) sph_lut.push_back(ddz);
+      }
+    }
+    std::sort(sph_lut.begin(), sph_lut.end());
+    if (sph_lut.size() > 32) return KC_OK;
+    for (int kz = k0; kz <= k1; ++kz)
+      if (gap[kz - k0] >= 0.0)
+        sph_code[kz - k0] = static_cast<unsigned char>(std::lower_bound(sph_lut.begin(), sph_lut.end(), gap[kz - k0]) - sph_lut.begin() + 1);
+    sph_kz0 = k0;
+    sph_nkz = k1 - k0 + 1;
+    c->sphere_ddz_max = gmax;  // (dil_geom: -1 = no layer of the cloud can touch the sphere: no masks, no voxels)
+  }
   bool fits = false;
   KC_TRY(bitmap_extent(c, key(lo[0]), key(lo[1]), key(hi[0]), key(hi[1]), &fits));
   const size_t nwords = fits ? static_cast<size_t>(c->gH) * c->gwpr : 0;
   if (!fits) {
     c->have_gbits = false;
       return KC_OK;
+  }
+  if (sphere) {
+    // (decided before anything is written: a sphere either takes the one-launch build or the host's)
+    const DilGeom dg0 = dil_geom(c);
+    const int dilR0 = c->have_dil ? dg0.R : -1;
+    int nb0 = std::min(64, c->gH), rows0 = (c->gH + nb0 - 1) / nb0;
+    auto bytes0 = [&] { return (3 * static_cast<size_t>(rows0) + 2 * static_cast<size_t>(std::max(dilR0, 0)) + 32 * static_cast<size_t>(rows0)) * c->gwpr * 4; };
+    while (bytes0() > kSensorFusedLds && rows0 > 1) rows0 = (rows0 + 1) / 2;
+    if (bytes0() > kSensorFusedLds || (c->gH + rows0 - 1) / rows0 > 1024) return KC_OK;
   }
   // one workgroup with everything in LDS, or (large clouds / bitmaps) the points
   // over many workgroups with device atomics
@@ -685,6 +742,10 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   a.bx = c->d_bobs.p;
   a.by = c->d_bobs.p + n;
   a.obs_z_zero = c->raw_is_scan ? 1 : 0;
+  a.sphere = sphere ? 1 : 0;
+  a.kz0 = sph_kz0;
+  a.nkz = sph_nkz;
+  std::memcpy(a.zcode, sph_code, sizeof(a.zcode));
   KC_TRY(plan_trig_job(c, a.trig));
   const unsigned tj = static_cast<unsigned>(a.trig.nblk);
   if (tj) {
@@ -698,7 +759,9 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   const int dilR = c->have_dil ? dg.R : -1;
   int nb = std::min(64, c->gH), band_rows = (c->gH + nb - 1) / nb;
   // (LDS of a band: its rows + R rows of halo either side, and the two dilation accumulators of its own rows)
-  auto band_bytes = [&] { return (3 * static_cast<size_t>(band_rows) + 2 * static_cast<size_t>(std::max(dilR, 0))) * c->gwpr * 4; };
+  auto band_bytes = [&] {
+    return (3 * static_cast<size_t>(band_rows) + 2 * static_cast<size_t>(std::max(dilR, 0)) + (sphere ? 32 * static_cast<size_t>(band_rows) : 0)) * c->gwpr * 4;
+  };
   while (band_bytes() > kSensorFusedLds && band_rows > 1) {
     band_rows = (band_rows + 1) / 2;
   }
@@ -715,6 +778,19 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     f.ginner = c->d_ginner.p;
     f.gouter = c->d_gouter.p;
     if (dilR >= 0) dil_tables(dg, f.win, f.wout);
+    c->gz_valid = false;
+    if (sphere) {
+      const size_t gcells = static_cast<size_t>(c->gwpr) * 32 * c->gH;
+      KC_TRY(c->d_gz.reserve(gcells));
+      KC_TRY(c->h_zlut.reserve(256));
+      KC_TRY(c->d_zlut.reserve(256));
+      for (size_t k = 0; k < sph_lut.size(); ++k) c->h_zlut.p[k] = sph_lut[k];
+      if (!sph_lut.empty()) KC_TRY(upload_table(c, c->d_zlut.p, c->h_zlut.p, sph_lut.size() * sizeof(double)));
+      bar_flush(c);
+      c->sphere_layers = sph_lut.size();
+      c->gz_valid = !sph_lut.empty();
+      f.gz = c->d_gz.p;
+    }
     // bucket workgroup: cell slots + row masks + (lists of more than one trip) a position per cell
     const size_t bucket_lds = ((ncell + 4) & ~size_t(3)) * 4 + 64 * 8 + ((ncell + 3) & ~size_t(3)) * 4;
     // float estimate of the cell index (sensor_obstacle_fast): its distance from the double expression
@@ -781,6 +857,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
 #endif
     masks_built = true;
   } else {
+    if (sphere) KC_FAIL(KC_ERR_STATE, "sphere: the one-launch sensor build was decided above");  // (cannot happen)
     {  // byte map of the voxels: zero between updates (sensor_place_kernel clears what it packs)
       const uint8_t *was = c->d_sensor_bytes.p;
       KC_TRY(c->d_sensor_bytes.reserve(nwords * 32));

@@ -186,6 +186,7 @@ struct SensorFusedArgs {
   int R;                 // dilation radius in rows; < 0: no masks (spheres without a gap bound, huge robots)
   uint32_t *ginner, *gouter;
   signed char win[kMaxDil + 1], wout[kMaxDil + 1];
+  uint8_t *gz;           // spheres: [gH][gwpr * 32] smallest layer code of a voxel column (0: none), else null
 };
 
 #ifdef KC_PHASE_STAMPS
@@ -197,16 +198,25 @@ struct SensorFusedArgs {
 #define KC_FSTAMP(slot) do { } while (0)
 #endif
 
-__device__ __forceinline__ bool sensor_voxel_cell(const SensorArgs &a, float x, float y, float z, int &cx, int &cy) {
-  // add_voxel: keys, octree range, z interval of the robot (cylinder / box)
+__device__ __forceinline__ bool sensor_voxel_cell(const SensorArgs &a, float x, float y, float z, int &cx, int &cy,
+                                                  int *code = nullptr) {
+  // add_voxel: keys, octree range, z interval of the robot (cylinder / box) or the layer table of a sphere
   const double fx = floor(a.inv_res * static_cast<double>(x));
   const double fy = floor(a.inv_res * static_cast<double>(y));
   const double fz = floor(a.inv_res * static_cast<double>(z));
   if (!(fabs(fx) < 32768.0 && fabs(fy) < 32768.0 && fabs(fz) < 32768.0)) return false;
   const int kz = static_cast<int>(fz);
-  const double zlo = static_cast<double>(kz) * a.res;
-  const double zhi = static_cast<double>(kz + 1) * a.res;
-  if (!(zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height)) return false;
+  if (a.sphere) {
+    const int q = kz - a.kz0;
+    if (q < 0 || q >= a.nkz) return false;
+    const int cd = a.zcode[q];
+    if (cd == 0) return false;
+    if (code) *code = cd;
+  } else {
+    const double zlo = static_cast<double>(kz) * a.res;
+    const double zhi = static_cast<double>(kz + 1) * a.res;
+    if (!(zlo <= a.zc + a.half_height && zhi >= a.zc - a.half_height)) return false;
+  }
   cx = static_cast<int>(fx) - a.gkx0;
   cy = static_cast<int>(fy) - a.gky0;
   return cx >= 0 && cy >= 0 && cy < a.gH && (cx >> 5) < a.gwpr;
@@ -289,16 +299,25 @@ __device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int b
   // voxel for the rounding of the key -- send the others away before any f64 work)
   const float ylo = s.band_y0 + static_cast<float>(band) * s.band_dy - s.band_pad;
   const float yhi = s.band_y0 + static_cast<float>(band + 1) * s.band_dy + s.band_pad;
+  // (spheres: the layer codes seen in every column of the band's OWN rows, a word of code bits a column, behind the
+  // bitmap rows and the two dilation accumulators)
+  const int nown = (y1 - y0) * a.gwpr;
+  const int gW = a.gwpr * 32;
+  uint32_t *lcode = lbits + nrows * a.gwpr + 2 * nown;
+  const bool zcodes = s.gz != nullptr;
   sensor_for_points(a, [&] {
     for (int i = tid; i < nrows * a.gwpr; i += kSensorBlock) lbits[i] = 0u;
+    if (zcodes)
+      for (int i = tid; i < (y1 - y0) * gW; i += kSensorBlock) lcode[i] = 0u;
     __syncthreads();
     KC_FSTAMP(1);
   }, [&](int, int, float x, float y, float z) {
     if (!(y >= ylo && y <= yhi)) return;
-    int cx, cy;
-    if (sensor_voxel_cell(a, x, y, z, cx, cy)) {
+    int cx, cy, code = 0;
+    if (sensor_voxel_cell(a, x, y, z, cx, cy, &code)) {
       const int r = cy - lo;
       if (r >= 0 && r < nrows) atomicOr(&lbits[r * a.gwpr + (cx >> 5)], 1u << (cx & 31));
+      if (zcodes && r >= R && r < R + (y1 - y0)) atomicOr(&lcode[(r - R) * gW + cx], 1u << (code - 1));
     }
   });
   __syncthreads();
@@ -337,6 +356,11 @@ __device__ __forceinline__ void sensor_band_body(const SensorFusedArgs &s, int b
       s.gouter[g] = lout[t];
     }
   }
+  if (zcodes)  // the smallest code of a column = its smallest z gap (the LUT ascends)
+    for (int t = tid; t < (y1 - y0) * gW; t += kSensorBlock) {
+      const uint32_t m = lcode[t];
+      s.gz[static_cast<size_t>(y0) * gW + t] = m ? static_cast<uint8_t>(__ffs(static_cast<int>(m))) : static_cast<uint8_t>(0);
+    }
   KC_FSTAMP(4);
 }
 

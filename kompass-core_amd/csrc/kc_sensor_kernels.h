@@ -26,6 +26,11 @@ struct SensorArgs {
   uint8_t *skip;             // [W*H] (+ padding written by the host)
   float *bx, *by;            // cell-ordered coordinates
   int obs_z_zero;            // laserscan: the obstacle of a point is taken at z = 0
+  // spheres (sensor_fused_kernel only): a voxel is accepted by its LAYER -- zcode[kz - kz0] != 0, the host evaluates
+  // add_voxel's gap rule once per layer -- and the code is the rank of the layer's z gap among the layers the cloud's
+  // z range can hold (d_zlut: ascending gaps); a column keeps its smallest code (d_gz, one byte a column)
+  int sphere, kz0, nkz;
+  unsigned char zcode[36];
 };
 
 constexpr int kSensorBlock = 1024;

@@ -387,3 +387,29 @@ def test_sparse_scenes_every_cost_against_the_oracle(p_occ, scale):
         assert (r.found, r.index, r.raw_index, r.n_admissible) == (True, h["res"]["index"], h["res"]["raw_index"], h["res"]["n_admissible"])
         assert np.float32(r.cost) == np.float32(h["res"]["cost"])
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor_z", [0.0, 0.18, -0.12])
+def test_sphere_sensor_update_on_the_device(sensor_z):
+    """Round 4: a sphere's sensor update runs in the one-launch device build (voxel acceptance by layer, the smallest
+    layer code of every column, the gap LUT of the layers the cloud's z range can hold).  Clouds over several heights and
+    sizes, the sensor above / below the sphere's centre: the oracle's admissible set, costs and winner, and the
+    host-built update's record."""
+    inp = syn.make_controller_inputs("cfg2", seed=5, scale=0.25, scene="mid")
+    inp["robot"] = dict(shape=syn.SPHERE, dims=[0.22])
+    rng = np.random.default_rng(int(100 * abs(sensor_z)) + 3)
+    dev = hip_context(kh, inp, sensor_pos=(0, 0, sensor_z))
+    host = hip_context(kh, inp, sensor_pos=(0, 0, sensor_z))
+    host.set_option("sensor_on_host", 1)
+    for n in (7, 900, 5000):
+        pts = np.asarray(inp["points"], np.float32)[rng.choice(len(inp["points"]), n, replace=False)].copy()
+        pts[:, 2] = rng.choice([-0.35, -0.1, 0.0, 0.07, 0.2, 0.45], n)
+        cur = dict(inp, points=pts)
+        o = oracle_cycle(cur, sensor_pos=(0, 0, sensor_z))
+        h = hip_cycle(kh, cur, sensor_pos=(0, 0, sensor_z), ctx=dev)
+        assert_cycle_equal(o, h)
+        g = hip_cycle(kh, cur, sensor_pos=(0, 0, sensor_z), ctx=host)
+        assert (h["res"]["found"], h["res"]["index"], h["res"]["n_admissible"]) == (g["res"]["found"], g["res"]["index"], g["res"]["n_admissible"])
+    dev.close()
+    host.close()

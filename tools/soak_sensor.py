@@ -1,7 +1,7 @@
 """Soak of the device-side sensor update: random clouds (1 .. 60 k points, random extent / origin / z layers /
 non-finite points, occasionally a tiny cloud or an empty one) on ONE context, each followed by a cycle; a second
 context builds every update on the host (`sensor_on_host`).  Any difference in the admissible set, the costs or the
-winner stops the run.  python tools/soak_sensor.py [iterations] [seed]"""
+winner stops the run.  python tools/soak_sensor.py [iterations] [seed] [cylinder|box|sphere]"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [os.path.join(ROOT, "kompass-core_amd"), os.path.join(ROOT, "tests"), ROOT]
@@ -11,11 +11,14 @@ import kompass_hip as kh, synthetic as syn
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 inp = syn.make_controller_inputs("cfg2", seed=3, scale=0.25)
+shape = sys.argv[3] if len(sys.argv) > 3 else "cylinder"
+inp["robot"] = {"cylinder": inp["robot"], "box": dict(shape=syn.BOX, dims=[0.3, 0.2, 0.4]), "sphere": dict(shape=syn.SPHERE, dims=[0.22])}[shape]
+sensor_z = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 P, S = inp["P"], len(inp["seg_xyz"])
 
 
 def ctx(host):
-    c = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"], inp["dt"],
+    c = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, sensor_z), (0, 0, 0, 1), inp["octree_res"], inp["dt"],
                       max_samples=len(inp["vx"]), max_points=P, max_segment=S, max_obstacles=70000,
                       acc_limits=inp["acc_limits"])
     c.set_option("sensor_on_host", 1 if host else 0)
