@@ -1343,7 +1343,7 @@ int kc_dwa_set_grid_device(kc_dwa *c, const kc_state *st, const int32_t *dev_gri
   bool done = false;
   KC_TRY(sensor_update_device_bounded(c, nullptr, n, lo, hi, &done));
   if (done) return KC_OK;
-  // large maps / spheres: the host path, on the (small) list instead of the grid
+  // large maps: the host path, on the (small) list instead of the grid
   c->raw_xyz.resize(3 * n);
   KC_HIP(hipMemcpyAsync(c->raw_xyz.data(), c->d_raw.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost,
                         c->stream));

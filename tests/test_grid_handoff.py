@@ -101,7 +101,7 @@ def test_mapper_to_controller_on_device(name, scale, side, res, beams, rscale):
     (kh.CYLINDER, [0.1, 0.4], 0.004),     # device build
     (kh.BOX, [0.3, 0.2, 0.4], 0.004),
     (kh.CYLINDER, [0.1, 0.4], 0.12),      # > 16 k occupied cells: host lists from the device list
-    (kh.SPHERE, [0.15], 0.004),           # spheres always take the host lists
+    (kh.SPHERE, [0.15], 0.004),           # spheres: the layer codes of the device build (one layer here)
 ])
 def test_foreign_grid_on_device(shape, dims, density):
     """kc_dwa_set_grid_device on a grid this library did not produce (a torch tensor)."""
