@@ -4,7 +4,8 @@ pathCostFunc (cost_evaluator.cpp:111-141), the end point's nearest segment index
 total in the reference's accumulation order (:59-100) and the key.  Same additions in the same order, same first
 minimum: every cost and the selected index bit-equal to the oracle, for trajectory lengths around the tile size,
 curved / non-planar segments, precomputed velocity sums, several buffers per workgroup (the double-buffer hand-off)
-and the default rule (long lists only)."""
+and the default rule (long lists only); few / clustered / dense obstacles (ring walks, the cooperative far pass, the
+union rectangle), a LaserScan (the scan's near table) and list lengths that leave a short last group."""
 import numpy as np
 import pytest
 
@@ -126,3 +127,57 @@ def test_three_kernel_cycle_with_the_batched_kernel(scene):
     np.testing.assert_array_equal(h["costs"].view(np.uint32), o["costs"].view(np.uint32))
     assert h["res"]["index"] == o["index"]
     ctx.close()
+
+
+@pytest.mark.parametrize("P,N", [(50, 1000), (50, 64 * 7 + 1), (100, 777), (20, 2111), (7, 3000)])
+@pytest.mark.parametrize("obstacles", ["few", "cluster", "dense"])
+def test_batched_kernel_obstacle_paths(P, N, obstacles):
+    """Every branch of the obstacle term under the batched kernel: a handful of far obstacles (skip values beyond the
+    union scan: ring walks + the cooperative pass), one cluster (near for some samples, far for others), dense clutter
+    (the union rectangle); list lengths with a short last group."""
+    rng = np.random.default_rng(P * 1000 + N)
+    S = 160
+    px, py = _paths(N, P, rng)
+    seg, acc = syn.arc_segment(S, radius=6.0, spacing=0.04)
+    if obstacles == "few":
+        obs = (rng.random((5, 3)) * 14 - 7).astype(np.float32)
+    elif obstacles == "cluster":
+        obs = (np.float32([1.5, -1.0, 0.0]) + 0.3 * rng.standard_normal((400, 3))).astype(np.float32)
+    else:
+        obs = (rng.random((3000, 3)) * 10 - 5).astype(np.float32)
+    w = (0.5, 1.0, 3.0, 0.0, 0.0)
+    ox, oy = ko.obstacles_from_points((0, 0, 0), (0, 0, 0, 1), STATE, obs)
+    ci = ko.CostInputs(seg, 0, acc, 6.4, np.stack([ox, oy], 1), np.float32(10.0) / np.float32(3.0), (2.0, 0.0, 3.0),
+                       ko.make_weights(*w))
+    oi, oc, ocosts = ko.min_trajectory_cost(ci, px, py, None)
+    for batch in (2, 0):
+        ctx = kh.DwaContext(syn.CYLINDER, [0.1, 0.4], max_samples=N, max_points=P, max_segment=S, max_obstacles=len(obs),
+                            acc_limits=(2.0, 0.0, 3.0))
+        ctx.set_option("cost_kernel", 2)
+        ctx.set_option("cost_batch", batch)
+        ctx.set_weights(kh.make_weights(*w))
+        ctx.set_tracked_segment(seg, acc, 6.4)
+        ctx.set_points(STATE, obs, 10.0)
+        for _ in range(2):
+            r, hcosts = ctx.cost_evaluate(px, py, None)
+            np.testing.assert_array_equal(hcosts.view(np.uint32), ocosts.view(np.uint32), err_msg=f"cost_batch={batch}")
+            assert r.found and r.index == oi and np.float32(r.cost) == np.float32(oc)
+        ctx.close()
+
+
+@pytest.mark.parametrize("beams", [360, 1440])
+def test_batched_kernel_with_a_laserscan(beams):
+    """The scan's near table under the batched kernel (three-kernel cycle, batched kernel forced / off)."""
+    from helpers import oracle_cycle
+    inp = syn.make_controller_inputs("cfg2", seed=4, scale=0.3, scene="open")
+    ang = np.linspace(-np.pi, np.pi, beams, endpoint=False)
+    rng = 3.0 + 1.2 * np.cos(5 * ang) + 0.3 * np.sin(17 * ang)
+    cur = dict(inp, state=(0.4, -0.3, 0.5, 0.0))
+    o = oracle_cycle(cur, scan=(rng, ang))
+    assert len(o["raw"]) > 100
+    for batch in (2, 0):
+        ctx = hip_context(kh, cur)
+        for k, v in dict(fused_cycle=0, cost_kernel=2, cost_batch=batch).items():
+            ctx.set_option(k, v)
+        assert_cycle_equal(o, hip_cycle(kh, cur, scan=(rng, ang), ctx=ctx))
+        ctx.close()
