@@ -1212,13 +1212,20 @@ __device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcAr
     };
     double best = DBL_MAX;
     if (live && e.z != 0xFFFFFFFFu) best = exact_dd(static_cast<int>(e.z));
-    double shared = fmin(ubound2, wave_min_nonneg(best));
-    const double lbk = static_cast<double>(__uint_as_float(e.w));
+    // The bound the lanes share is only ever COMPARED with: a float above the sample's minimum so far (a wave
+    // minimum of 32-bit keys and float tests, where the exact double took a 64-bit reduction behind every quarter
+    // scanned and double products per chunk: the reductions were as long as the scans); the exact minimum is
+    // formed once, at the end.
+    auto above = [](double v) { return static_cast<float>(v) * 1.0000003f + 1e-37f; };  // >= v (+inf stays)
+    auto wave_min_f32 = [](float v) { return __uint_as_float(wave_min_u32(__float_as_uint(v))); };  // v >= 0
+    float shared = fminf(above(ubound2), wave_min_f32(above(best)));
+    const float lbk = __uint_as_float(e.w);
+    const float lbk2 = lbk * lbk * (1.0f - 1e-6f);  // (below lbk^2: dropping a lane needs lbk^2 >= the bound for certain)
     uint32_t mlo = live ? e.x : 0u, mhi = live ? e.y : 0u;
-    bool cont = live && (mlo | mhi) != 0u && lbk < t.ocap && !(x != x) && !(y != y);
+    bool cont = live && (mlo | mhi) != 0u && static_cast<double>(lbk) < t.ocap && !(x != x) && !(y != y);
     for (int half = 0; half < 2; ++half) {
       // (re-evaluated per half: the bound only falls)
-      uint32_t U = wave_or_u32((cont && lbk * lbk < shared * (1.0 - 1e-6)) ? (half ? mhi : mlo) : 0u);
+      uint32_t U = wave_or_u32((cont && lbk2 < shared) ? (half ? mhi : mlo) : 0u);
       while (U) {
         const int cb = __ffs(static_cast<int>(U)) - 1;
         U &= U - 1u;
@@ -1227,9 +1234,8 @@ __device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcAr
         // box of the chunk against this lane's point (float, 1e-4 of slack on the compared square)
         const float bx0 = t.oaabb[c], bx1 = t.oaabb[64 + c], by0 = t.oaabb[128 + c], by1 = t.oaabb[192 + c];
         const float gx = fmaxf(fmaxf(bx0 - x, x - bx1), 0.0f), gy = fmaxf(fmaxf(by0 - y, y - by1), 0.0f);
-        const double lb2 = static_cast<double>(gx * gx + gy * gy) * (1.0 - 1e-4);
-        const bool part = cont && (((half ? mhi : mlo) >> cb) & 1u) && lbk * lbk < shared * (1.0 - 1e-6) &&
-                          !(lb2 >= shared);
+        const float lb2 = (gx * gx + gy * gy) * (1.0f - 1e-4f);
+        const bool part = cont && (((half ? mhi : mlo) >> cb) & 1u) && lbk2 < shared && !(lb2 >= shared);
         if (__ballot(part) == 0ull) continue;
         const int j0 = c * t.ocs, j1 = min(j0 + t.ocs, t.on);
         if (t.oscs > 0) {
@@ -1243,7 +1249,7 @@ __device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcAr
             const int e4 = 4 * c + q;
             const float qx0 = sb[e4], qx1 = sb[256 + e4], qy0 = sb[512 + e4], qy1 = sb[768 + e4];
             const float hx = fmaxf(fmaxf(qx0 - x, x - qx1), 0.0f), hy = fmaxf(fmaxf(qy0 - y, y - qy1), 0.0f);
-            const double lq2 = static_cast<double>(hx * hx + hy * hy) * (1.0 - 1e-4);
+            const float lq2 = (hx * hx + hy * hy) * (1.0f - 1e-4f);
             if (__ballot(part && !(lq2 >= shared)) == 0ull) continue;
             for (int jb = s0; jb < s1; jb += 4) {
               double d[4];
@@ -1252,7 +1258,7 @@ __device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcAr
 #pragma unroll
               for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);
             }
-            shared = fmin(shared, wave_min_nonneg(best));
+            shared = fminf(shared, wave_min_f32(above(best)));
           }
           continue;
         }
@@ -1263,11 +1269,11 @@ __device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcAr
 #pragma unroll
           for (int u = 0; u < 4; ++u) best = __builtin_fmin(d[u], best);    // (NaN distances never win)
         }
-        shared = fmin(shared, wave_min_nonneg(best));
+        shared = fminf(shared, wave_min_f32(above(best)));
       }
     }
-    ubound2 = shared;  // (carried to the next tile of a long trajectory)
-    if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(shared)));
+    ubound2 = fmin(ubound2, wave_min_nonneg(best));  // (exact; carried to the next tile of a long trajectory)
+    if (lane == 0) atomicMin(obest, static_cast<unsigned long long>(__double_as_longlong(ubound2)));
   } else if (a.use_obs && t.ounion > 0 &&
              obstacle_union_scan(b, t.ounion, cells, skip, obx, oby, x, y, live, lane, obest)) {
     // (one scan of the union block did it)

@@ -1,19 +1,25 @@
-"""Cycle time of one config / scene by cost term: python tools/cycle_terms.py cfg2 mid [option=value ...]"""
+"""Cycle time of one config / scene by cost term: python tools/cycle_terms.py cfg2 mid [option=value ...]
+(scene "scan": bench.py's laserscan_room leg -- 1440 beams, ranges 4 + 1.5 cos 5a; "scanN": N beams)"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "kompass-core_amd"))
 import numpy as np
 import kompass_hip as kh, synthetic as syn
 cfg, scene = sys.argv[1], sys.argv[2]
-inp = syn.make_controller_inputs(cfg, seed=0, scene=scene)
+beams = int(scene[4:] or 1440) if scene.startswith("scan") else 0
+inp = syn.make_controller_inputs(cfg, seed=0, scene="survey" if beams else scene)
 P, S = inp["P"], len(inp["seg_xyz"])
 ctx = kh.DwaContext(inp["robot"]["shape"], inp["robot"]["dims"], (0, 0, 0), (0, 0, 0, 1), inp["octree_res"], inp["dt"],
-                    max_samples=len(inp["vx"]), max_points=P, max_segment=S, max_obstacles=len(inp["points"]),
+                    max_samples=len(inp["vx"]), max_points=P, max_segment=S, max_obstacles=max(len(inp["points"]), beams, 16),
                     acc_limits=inp["acc_limits"])
 for kv in sys.argv[3:]:
     ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 ctx.timing_enable(True)
-ctx.set_points(inp["state"], inp["points"], inp["max_range"])
+if beams:
+    ang = np.linspace(-np.pi, np.pi, beams, endpoint=False)
+    ctx.set_scan(inp["state"], 4.0 + 1.5 * np.cos(5 * ang), ang, inp["max_range"])
+else:
+    ctx.set_points(inp["state"], inp["points"], inp["max_range"])
 ctx.set_tracked_segment(inp["seg_xyz"], inp["acc_at_seg"], inp["ref_len"])
 ctx.set_samples(inp["vx"], inp["vy"], inp["omega"])
 print('default weights', inp['weights'])
