@@ -161,6 +161,8 @@ struct DcArgs {
 // ax ay abx aby | 1/|ab|^2 eps az abz  -- a planar segment needs the first six only.  In the
 // tracked-segment table they start at a 16-byte boundary behind the five rows.
 __host__ __device__ inline int seg_cap_offset(int S) { return (5 * S + 3) & ~3; }
+// floats of a scan block (DcArgs::osx): x | y of the scan's obstacles, the chunk boxes [4][64], the quarter boxes [4][256]
+__host__ __device__ inline int scan_block_floats(int on, int oscs) { return 2 * on + 256 + (oscs > 0 ? 1024 : 0); }
 struct Capsule {
   float ax, ay, abx, aby, inv, eps, az, abz;
 };
@@ -1058,6 +1060,7 @@ __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v) {
          static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 48));
 }
 
+constexpr int kScanTransposeCost = 5;  // (3 and 8 measured: 105.5 / 108.8 us of cfg5's cost kernel with a scan against 104.4)  // scan near table: a chunk of n obstacles is taken a lane an obstacle for up to n / 5 points
 constexpr int kUnionSeedMax = 24;  // largest seed block of obstacle_union_scan, cells of half-width
 __device__ __forceinline__ bool obstacle_union_scan(const BucketDev &b, int limit, const int *cells,
                                                     const uint8_t *skip, const float *obx, const float *oby,
@@ -1201,13 +1204,16 @@ __device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcAr
     // drop out, and the candidate chunks of the others are scanned one at a time by ALL lanes (a lane a
     // trajectory point, a loop over the chunk's obstacles: every value formed is a true distance, so nobody
     // needs masking and the minimum is the one of the full scan).
+    // (with a scan, obx / oby are the caller's view of the scan block -- x | y in scan order | chunk boxes, DcArgs::osx:
+    // in LDS in the stand-alone cost kernels, where every chunk scanned was a chain of round trips to L2)
+    const float *const oaabb = obx + 2 * t.on;
     const float fx = (x - t.ox0) * t.oinv, fy = (y - t.oy0) * t.oinv;
     const bool inside = fx >= 0.0f && fy >= 0.0f && fx < static_cast<float>(t.oW) && fy < static_cast<float>(t.oH);
     uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);  // outside the table: every chunk, no seed
     if (inside) e = t.onear[static_cast<int>(fy) * t.oW + static_cast<int>(fx)];
     auto exact_dd = [&](int j) {
-      const double dx = static_cast<double>(t.osx[j] - x);
-      const double dy = static_cast<double>(t.osy[j] - y);
+      const double dx = static_cast<double>(obx[j] - x);
+      const double dy = static_cast<double>(oby[j] - y);
       return dx * dx + dy * dy;
     };
     double best = DBL_MAX;
@@ -1232,17 +1238,37 @@ __device__ __forceinline__ void wave_obstacle_term(const CostArgs &a, const DcAr
         const int c = cb + 32 * half;
         if (c >= t.onch) break;
         // box of the chunk against this lane's point (float, 1e-4 of slack on the compared square)
-        const float bx0 = t.oaabb[c], bx1 = t.oaabb[64 + c], by0 = t.oaabb[128 + c], by1 = t.oaabb[192 + c];
+        const float bx0 = oaabb[c], bx1 = oaabb[64 + c], by0 = oaabb[128 + c], by1 = oaabb[192 + c];
         const float gx = fmaxf(fmaxf(bx0 - x, x - bx1), 0.0f), gy = fmaxf(fmaxf(by0 - y, y - by1), 0.0f);
         const float lb2 = (gx * gx + gy * gy) * (1.0f - 1e-4f);
         const bool part = cont && (((half ? mhi : mlo) >> cb) & 1u) && lbk2 < shared && !(lb2 >= shared);
-        if (__ballot(part) == 0ull) continue;
+        const unsigned long long pm = __ballot(part);
+        if (pm == 0ull) continue;
         const int j0 = c * t.ocs, j1 = min(j0 + t.ocs, t.on);
+        if (__popcll(pm) * kScanTransposeCost <= j1 - j0) {
+          // Few points want this chunk (two of fifty on average in a room: the others' floors lie above the
+          // bound): one of them at a time with a LANE AN OBSTACLE -- one pass and one reduction per point
+          // instead of every lane walking the whole chunk for the sake of two.  Same differences, same products.
+          for (unsigned long long m = pm; m; m &= m - 1ull) {
+            const int L = __ffsll(static_cast<long long>(m)) - 1;
+            const float xq = lane_value(x, L), yq = lane_value(y, L);
+            double d = DBL_MAX;
+            for (int j = j0 + lane; j < j1; j += 64) {
+              const double dx = static_cast<double>(obx[j] - xq);
+              const double dy = static_cast<double>(oby[j] - yq);
+              d = __builtin_fmin(dx * dx + dy * dy, d);  // (NaN distances never win)
+            }
+            const double mn = wave_min_nonneg(d);
+            if (lane == L) best = __builtin_fmin(mn, best);
+          }
+          shared = fminf(shared, wave_min_f32(above(best)));
+          continue;
+        }
         if (t.oscs > 0) {
           // a quarter of the chunk at a time: the same test against the quarter's own box, the bound refreshed
           // behind every quarter that was scanned (a 4096-beam scan has chunks of 64 obstacles: most of a chunk
           // the table names lies beyond what a neighbouring quarter has already found)
-          const float *sb = t.oaabb + 256;
+          const float *sb = oaabb + 256;
           for (int q = 0; q < 4; ++q) {
             const int s0 = j0 + q * t.oscs, s1 = min(s0 + t.oscs, j1);
             if (s0 >= s1) break;
@@ -1975,8 +2001,9 @@ __attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_c
   float *const l_obs = reinterpret_cast<float *>(l_skip + (a.use_obs ? ((ncell + 3) & ~3) : 0));
   const int *const cells = kLds ? l_cells : b.cell_start;
   const uint8_t *const skip = kLds ? l_skip : b.skip;
-  const float *const obx = kObsLds ? l_obs : b.bx;
-  const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
+  const bool scan = t.onear != nullptr;  // (the obstacle term reads the scan block, not the buckets' arrays)
+  const float *const obx = kObsLds ? l_obs : (scan ? t.osx : b.bx);
+  const float *const oby = kObsLds ? l_obs + (scan ? t.on : b.nobs) : (scan ? t.osy : b.by);
   // In LDS the segment points are pair records (struct SegPairs): one 16-byte read per TWO points
   // instead of three reads from three rows per point; the capsules and spheres follow
   float4 *const l_xy = reinterpret_cast<float4 *>(l_seg);
@@ -2004,8 +2031,10 @@ __attribute__((amdgpu_waves_per_eu(kFold ? 4 : 5, kFold ? 4 : 5))) void sample_c
       uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
       for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kCostBlock) ls[j] = gs[j];
       if (kObsLds) {
+        const float *const src = scan ? t.osx : b.bx;  // bx | by contiguous; osx | osy | chunk boxes
+        const int cnt = scan ? scan_block_floats(t.on, t.oscs) : 2 * b.nobs;
 #pragma unroll 8
-        for (int j = threadIdx.x; j < 2 * b.nobs; j += kCostBlock) l_obs[j] = b.bx[j];  // bx | by contiguous
+        for (int j = threadIdx.x; j < cnt; j += kCostBlock) l_obs[j] = src[j];
       }
     }
   }
@@ -2105,8 +2134,9 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArg
   float *const l_obs = reinterpret_cast<float *>(l_skip + (a.use_obs ? ((ncell + 3) & ~3) : 0));
   const int *const cells = l_cells;
   const uint8_t *const skip = l_skip;
-  const float *const obx = kObsLds ? l_obs : b.bx;
-  const float *const oby = kObsLds ? l_obs + b.nobs : b.by;
+  const bool scan = t.onear != nullptr;  // (the obstacle term reads the scan block, not the buckets' arrays)
+  const float *const obx = kObsLds ? l_obs : (scan ? t.osx : b.bx);
+  const float *const oby = kObsLds ? l_obs + (scan ? t.on : b.nobs) : (scan ? t.osy : b.by);
   float4 *const l_xy = reinterpret_cast<float4 *>(l_seg);
   float4 *const l_za = l_xy + npp;
   const float *const cap = l_seg + 8 * npp;
@@ -2133,8 +2163,10 @@ __global__ __launch_bounds__(kCostBlock) void sample_cost_batched_kernel(CostArg
       uint32_t *ls = reinterpret_cast<uint32_t *>(l_skip);
       for (int j = threadIdx.x; j < (ncell + 3) / 4; j += kCostBlock) ls[j] = gs[j];
       if (kObsLds) {
+        const float *const src = scan ? t.osx : b.bx;  // bx | by contiguous; osx | osy | chunk boxes
+        const int cnt = scan ? scan_block_floats(t.on, t.oscs) : 2 * b.nobs;
 #pragma unroll 8
-        for (int j = threadIdx.x; j < 2 * b.nobs; j += kCostBlock) l_obs[j] = b.bx[j];  // bx | by contiguous
+        for (int j = threadIdx.x; j < cnt; j += kCostBlock) l_obs[j] = src[j];
       }
     }
   }

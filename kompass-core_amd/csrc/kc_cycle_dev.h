@@ -166,6 +166,9 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
     s_bslot = -1;
   }
   const SegPairs seg{t.xy, t.za};
+  // what the wavefront obstacle term reads: the scan block when there is a scan's near table, the buckets' arrays otherwise
+  const float *const wobx = tail.t.onear != nullptr ? tail.t.osx : c.b.bx;
+  const float *const woby = tail.t.onear != nullptr ? tail.t.osy : c.b.by;
   const bool teams = R <= tail.team_max;
   if (teams) {
     // every survivor at once: R teams (two halves or four quarters of the workgroup)
@@ -201,7 +204,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
       const bool live = lane < c.P;
       const int p = live ? lane : c.P - 1;
       double ubound2 = DBL_MAX;
-      wave_obstacle_term(c, tail.t, t.cells, t.skip, c.b.bx, c.b.by, pts.x(p), pts.y(p), live, lane, &s_ob[h], ubound2);
+      wave_obstacle_term(c, tail.t, t.cells, t.skip, wobx, woby, pts.x(p), pts.y(p), live, lane, &s_ob[h], ubound2);
     }
     KC_RSTAMP(10);
     __syncthreads();
@@ -229,7 +232,7 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
       const int n = lperm[s];
       const PosePts pts{lpos + s * PP, PP - 1};
       const float total = wave_sample_total(c, tail.t, seg, cap, sup, sz_end, t.cells, t.skip,
-                                            c.b.bx, c.b.by, pts, n, lane, &s_ob[wave], false);
+                                            wobx, woby, pts, n, lane, &s_ob[wave], false);
       if (lane == 0) c.costs[n] = total;
       if (total < FLT_MAX) {
         const long long k = key_pack(total, static_cast<uint32_t>(c.first + n));

@@ -352,6 +352,8 @@ int run_evaluate(kc_dwa *c, size_t n, size_t first) {
     const size_t ncell = static_cast<size_t>(ca.b.W) * ca.b.H;
     lds_tab += (ncell + 1) * sizeof(int) + ((ncell + 3) & ~size_t(3));
     lds_obs = 2 * static_cast<size_t>(ca.b.nobs) * sizeof(float);
+    // (with a scan's near table the wavefront kernels keep the scan block there instead: x | y | chunk boxes)
+    if (dt.onear) lds_obs = std::max(lds_obs, static_cast<size_t>(scan_block_floats(dt.on, dt.oscs)) * sizeof(float));
   }
   PubArgs pa{};
   pa.block_keys = c->d_block_keys.p;
