@@ -49,14 +49,14 @@ class Controller {
                                   double maxVel, double timeStep) const;
 
  protected:
-  // NOTE (reference quirk Q1): DWA never fills these two, so they keep the
-  // value-initialised type (ACKERMANN) and the default limits (1.0 / 1.0).
-  Control::ControlType ctrType;
-  Control::ControlLimitsParams ctrlimitsParams;
-  Control::Velocity2D currentVel;
-  Path::State currentState;
-  Control::Velocity2D currentCtr;
-  int maxNumThreads;
+  // NOTE (reference quirk Q1): DWA never fills the first two, so they keep the value-initialised type (ACKERMANN) and
+  // the default limits (1.0 / 1.0) -- getLinearVelocityCmdX and friends clamp with them.
+  Control::ControlType drive_;
+  Control::ControlLimitsParams limits_;
+  Path::State pose_;               // where the robot is (setCurrentState)
+  Control::Velocity2D velocity_;   // how it moves (setCurrentVelocity)
+  Control::Velocity2D last_command_;
+  int host_threads_;
   ControllerParameters config;
 };
 

@@ -29,7 +29,7 @@ class DWA : public Follower {
       const std::vector<float> robotDimensions,
       const Eigen::Vector3f &sensor_position_body,
       const Eigen::Vector4f &sensor_rotation_body, const double octreeRes,
-      CostEvaluator::TrajectoryCostsWeights costWeights, const int maxNumThreads = 1);
+      CostEvaluator::TrajectoryCostsWeights costWeights, const int host_threads_ = 1);
 
   DWA(TrajectorySampler::TrajectorySamplerParameters config,
       ControlLimitsParams controlLimits, ControlType controlType,
@@ -37,7 +37,7 @@ class DWA : public Follower {
       const std::vector<float> robotDimensions,
       const Eigen::Vector3f &sensor_position_body,
       const Eigen::Vector4f &sensor_rotation_body,
-      CostEvaluator::TrajectoryCostsWeights costWeights, const int maxNumThreads = 1);
+      CostEvaluator::TrajectoryCostsWeights costWeights, const int host_threads_ = 1);
   ~DWA() = default;
 
   void configure(ControlLimitsParams controlLimits, ControlType controlType,
@@ -48,7 +48,7 @@ class DWA : public Follower {
                  const Eigen::Vector3f &sensor_position_body,
                  const Eigen::Vector4f &sensor_rotation_body, const double octreeRes,
                  CostEvaluator::TrajectoryCostsWeights costWeights,
-                 const int maxNumThreads = 1);
+                 const int host_threads_ = 1);
   void configure(TrajectorySampler::TrajectorySamplerParameters config,
                  ControlLimitsParams controlLimits, ControlType controlType,
                  const CollisionChecker::ShapeType robotShapeType,
@@ -56,7 +56,7 @@ class DWA : public Follower {
                  const Eigen::Vector3f &sensor_position_body,
                  const Eigen::Vector4f &sensor_rotation_body,
                  CostEvaluator::TrajectoryCostsWeights costWeights,
-                 const int maxNumThreads = 1);
+                 const int host_threads_ = 1);
 
   void resetOctreeResolution(const double octreeRes);
   void setSensorMaxRange(const float max_range);
@@ -70,7 +70,7 @@ class DWA : public Follower {
     if (r.isTrajFound) {
       out.status = Controller::Result::Status::COMMAND_FOUND;
       out.velocity_command = r.trajectory.velocities.getFront();
-      latest_velocity_command_ = out.velocity_command;
+      command_ = out.velocity_command;
     } else {
       out.status = Controller::Result::Status::NO_COMMAND_POSSIBLE;
     }
@@ -80,7 +80,7 @@ class DWA : public Follower {
   template <typename T>
   TrajSearchResult computeVelocityCommandsSet(const Velocity2D &global_vel, const T &scan_points) {
     TrajSearchResult r = findBestPath(global_vel, scan_points);
-    if (r.isTrajFound) latest_velocity_command_ = r.trajectory.velocities.getFront();
+    if (r.isTrajFound) command_ = r.trajectory.velocities.getFront();
     return r;
   }
 
@@ -114,9 +114,9 @@ class DWA : public Follower {
   template <typename T>
   void debugVelocitySearch(const Velocity2D &global_vel, const T &scan_points, const bool &drop_samples) {
     requirePath();
-    determineTarget();
+    aimAtTarget();
     trajSampler->setSampleDroppingMode(drop_samples);
-    debuggingSamples_ = trajSampler->generateTrajectories(global_vel, currentState, scan_points);
+    debuggingSamples_ = trajSampler->generateTrajectories(global_vel, pose_, scan_points);
   }
 
  protected:
@@ -126,13 +126,13 @@ class DWA : public Follower {
   template <typename T>
   TrajSearchResult findBestPath(const Velocity2D &global_vel, const T &scan_points) {
     requirePath();
-    determineTarget();
-    if (rotate_in_place &&
-        std::abs(currentTrackedTarget_->heading_error) > goal_orientation_tolerance * 10.0) {
+    aimAtTarget();
+    if (knob_.turn_in_place &&
+        std::abs(on_.target->heading_error) > knob_.goal_yaw * 10.0) {
       LOG_DEBUG("Rotating In Place ...");
       auto trajectory = trajSampler->generateSingleSampleFromVel(Velocity2D(
           0.0, 0.0,
-          -currentTrackedTarget_->heading_error * ctrlimitsParams.omegaParams.maxOmega / M_PI));
+          -on_.target->heading_error * limits_.omegaParams.maxOmega / M_PI));
       return TrajSearchResult{trajectory, true, 0.0};
     }
     const auto T0 = std::chrono::steady_clock::now();
@@ -140,7 +140,7 @@ class DWA : public Follower {
     const auto T1 = std::chrono::steady_clock::now();
     // lattice + sensor data of this cycle onto the device ...
     const size_t generated =
-        trajSampler->prepareOnDevice(global_vel, currentState, scan_points, maxLocalRange_);
+        trajSampler->prepareOnDevice(global_vel, pose_, scan_points, maxLocalRange_);
     const auto T2 = std::chrono::steady_clock::now();
     if (generated == 0) return TrajSearchResult{Trajectory2D(), false, 0.0};
     // ... then ONE device cycle: roll-out + collision gate + costs + argmin against the
@@ -150,7 +150,7 @@ class DWA : public Follower {
     const auto T3 = std::chrono::steady_clock::now();
     TrajectorySampler *smp = trajSampler.get();
     auto rr = trajCostEvaluator->cycleOnDevice(
-        currentPath.get(), tracked, trajSampler->numPointsPerTrajectory, currentState, trajSampler->timeStep(),
+        on_.path.get(), tracked, trajSampler->numPointsPerTrajectory, pose_, trajSampler->timeStep(),
         [smp](size_t raw) { return smp->sampleVelocity(raw); }, generated, comm_.get());
     const auto T4 = std::chrono::steady_clock::now();
     static const bool dbg = std::getenv("KC_DEBUG_CLASS") != nullptr;
@@ -163,7 +163,7 @@ class DWA : public Follower {
 
  private:
   double max_forward_distance_ = 0.0;
-  int maxNumThreads;
+  int host_threads_;
   std::shared_ptr<kc_comm> comm_;
   void adoptComm(kc_comm *raw, int mode) {
     comm_ = std::shared_ptr<kc_comm>(raw, [](kc_comm *c) { kc_comm_destroy(c); });
@@ -174,7 +174,7 @@ class DWA : public Follower {
   float maxLocalRange_ = 10.0;
 
   void requirePath() const {
-    if (!currentPath)
+    if (!on_.path)
       throw std::invalid_argument(
           "Pointer to global path is NULL. Cannot use DWA local planner "
           "without setting a global path");

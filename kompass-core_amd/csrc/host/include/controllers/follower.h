@@ -55,57 +55,57 @@ class Follower : public Controller {
   Target getTrackedTarget() const;
 
   double getLinearVelocityCmdX() const {
-    return std::max(std::min(latest_velocity_command_.vx(), ctrlimitsParams.velXParams.maxVel),
-                    -ctrlimitsParams.velXParams.maxVel);
+    return std::max(std::min(command_.vx(), limits_.velXParams.maxVel),
+                    -limits_.velXParams.maxVel);
   }
   double getLinearVelocityCmdY() const {
-    return std::max(std::min(latest_velocity_command_.vy(), ctrlimitsParams.velYParams.maxVel),
-                    -ctrlimitsParams.velYParams.maxVel);
+    return std::max(std::min(command_.vy(), limits_.velYParams.maxVel),
+                    -limits_.velYParams.maxVel);
   }
   double getAngularVelocityCmd() const {
-    return std::max(std::min(latest_velocity_command_.omega(), ctrlimitsParams.omegaParams.maxOmega),
-                    -ctrlimitsParams.omegaParams.maxOmega);
+    return std::max(std::min(command_.omega(), limits_.omegaParams.maxOmega),
+                    -limits_.omegaParams.maxOmega);
   }
-  double getSteeringAngleCmd() const { return latest_velocity_command_.steer_ang(); }
-  double getPathLength() const { return currentPath->totalPathLength(); }
+  double getSteeringAngleCmd() const { return command_.steer_ang(); }
+  double getPathLength() const { return on_.path->totalPathLength(); }
   bool hasPath() const {
-    if (!currentPath || !path_processing_) return false;
-    return currentPath->totalPathLength() > 0.0;
+    if (!on_.path || !on_.ready) return false;
+    return on_.path->totalPathLength() > 0.0;
   }
   const Path::Path getCurrentPath() const;
 
  protected:
-  double speed_reg_curvature{0.0}, speed_reg_rotation{0.0};
-  std::unique_ptr<Path::Path> currentPath = nullptr;
-  std::unique_ptr<Path::PathPosition> closestPosition = std::make_unique<Path::PathPosition>();
-  double goal_dist_tolerance{0.0}, goal_orientation_tolerance{0.0};
-  double loosing_goal_distance{0.0}, curvature_horizon_tolerance_{1.0};
-  bool rotate_in_place{false};
-  double lookahead_distance{0.0};
-  bool enable_reverse_driving{false};
-  double path_segment_length_{0.0}, min_speed_regulation_factor{0.0};
-  double max_point_interpolation_distance_{0.0};
-  size_t max_segment_size_;
-  Path::InterpolationType interpolationType = Path::InterpolationType::LINEAR;
+  // What setParams reads out of the parameter set, once per change
+  struct Knobs {
+    double slow_in_curves{0.0}, slow_in_turns{0.0}, slowest{0.0};  // speed regulation
+    double goal_radius{0.0}, goal_yaw{0.0}, lost_radius{0.0};       // goal tests
+    double horizon_tolerance{1.0}, lookahead{0.0};
+    double segment_length{0.0}, point_spacing{0.0};                 // how a new path is cut / interpolated
+    bool turn_in_place{false}, reverse{false};
+  } knob_;
+  // The path being followed and the robot's place on it (rewritten by locateOnPath / aimAtTarget every cycle)
+  struct Place {
+    std::unique_ptr<Path::Path> path;
+    std::unique_ptr<Path::PathPosition> nearest = std::make_unique<Path::PathPosition>();
+    std::unique_ptr<Target> target = std::make_unique<Target>();
+    Path::InterpolationType spline = Path::InterpolationType::LINEAR;
+    bool ready{false};                       // a path was set and cut into segments
+    size_t segment{0}, last_segment{0}, longest_segment{0};
+    double along{0.0};                       // position inside `segment`, 0 .. 1
+    double goal_distance{std::numeric_limits<double>::max()};
+    double goal_yaw_error{std::numeric_limits<double>::max()};
+    bool at_goal{false}, at_yaw{false};
+  } on_;
+  Control::Velocity2D command_{0.0, 0.0, 0.0};  // what the last cycle decided
   FollowerParameters config = FollowerParameters();
 
-  Path::PathPosition findClosestPathPoint();
-  void determineTarget();
-
-  bool path_processing_{false};
-  std::unique_ptr<Target> currentTrackedTarget_ = std::make_unique<Target>();
-  size_t current_segment_index_{0};
-  double current_position_in_segment_{0.0};
-  size_t max_segment_index_{0};
-  double goal_distance_{std::numeric_limits<double>::max()};
-  double goal_orientation_{std::numeric_limits<double>::max()};
-  Control::Velocity2D latest_velocity_command_{0.0, 0.0, 0.0};
-  bool reached_goal_{false}, reached_yaw_{false};
+  Path::PathPosition locateOnPath();
+  void aimAtTarget();
 
  private:
-  size_t findClosestSegmentIndex(size_t left, size_t right);
-  Path::PathPosition findClosestPointOnSegment(size_t segment_index);
-  size_t getMaxSegmentSize() const;
+  size_t nearestSegment(size_t left, size_t right);
+  Path::PathPosition nearestOnSegment(size_t segment_index);
+  size_t longestSegment() const;
 };
 
 }  // namespace Control

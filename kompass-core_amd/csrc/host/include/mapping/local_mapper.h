@@ -62,22 +62,22 @@ class LocalMapper {
   void setPreviousGridProb(const Eigen::MatrixXf *prob);
 
  protected:
-  const int m_gridHeight, m_gridWidth;
-  const float m_resolution, m_laserscanOrientation, m_rangeMax;
-  const int m_maxPointsPerLine;
-  const Eigen::Vector3f m_laserscanPosition;
-  const int m_scanSize;
-  const float m_maxHeight, m_minHeight;
-  float m_angleStep = 0.0f;
+  const int rows_, cols_;
+  const float cell_, sensor_yaw_, range_cap_;
+  const int line_cap_;
+  const Eigen::Vector3f sensor_at_;
+  const int bins_;
+  const float z_hi_, z_lo_;
+  float bin_step_ = 0.0f;
   // inverse sensor model, defaults of the first ctor (local_mapper.h:22-24)
-  float m_pPrior = 0.5f, m_pEmpty = 0.4f, m_pOccupied = 0.6f, m_rangeSure = 1.0f, m_wallSize = 0.2f;
+  float p_prior_ = 0.5f, p_free_ = 0.4f, p_hit_ = 0.6f, sure_range_ = 1.0f, wall_ = 0.2f;
   // pointcloud mode (local_mapper.h:38-56): angles i * 2 pi / scanSize
-  std::vector<double> initializedAngles, initializedRanges;
-  Eigen::MatrixXi gridData;
-  Eigen::MatrixXf gridDataProb, previousGridDataProb;
+  std::vector<double> bin_angles_, bin_ranges_;
+  Eigen::MatrixXi cells_;
+  Eigen::MatrixXf belief_, prior_belief_;
   hip::MapperHandle ctx_;
-  bool bayesEnabled_ = false;
-  void enableBayes();
+  bool bayes_on_ = false;
+  void turnOnBayes();
 };
 
 }  // namespace Mapping

@@ -20,45 +20,40 @@ class CollisionChecker {
  public:
   enum class ShapeType { CYLINDER, BOX, SPHERE };
 
-  CollisionChecker(const ShapeType robot_shape_type,
-                   const std::vector<float> &robot_dimensions,
-                   const Eigen::Vector3f &sensor_position_body,
-                   const Eigen::Quaternionf &sensor_rotation_body,
-                   const double octree_resolution = 0.01);
+  // body shape + where the sensor sits on it; `voxel` = edge of the occupancy voxels (the reference's octree resolution)
+  CollisionChecker(const ShapeType shape, const std::vector<float> &dims, const Eigen::Vector3f &sensor_at,
+                   const Eigen::Quaternionf &sensor_facing, const double voxel = 0.01);
   // shares the device context of a sampler / controller
-  CollisionChecker(hip::DwaHandle ctx, ShapeType shape,
-                   const std::vector<float> &dims, double octree_resolution);
+  CollisionChecker(hip::DwaHandle ctx, ShapeType shape, const std::vector<float> &dims, double voxel);
   ~CollisionChecker() = default;
 
-  void resetOctreeResolution(const double resolution);
-  void updateState(const Path::State current_state);
+  void resetOctreeResolution(const double voxel);
+  void updateState(const Path::State pose);
   void updateState(const double x, const double y, const double yaw);
 
   // LaserScan (sensor frame) or point list (world frame when global_frame)
   void updateSensorData(const Control::LaserScan &scan, const bool global_frame = true);
   void updateSensorData(const std::vector<Path::Point> &cloud, const bool global_frame = true);
   void updateSensorData(const Control::PointCloudView &cloud, const bool global_frame = true);
-  // the OCCUPIED cells of the mapper's device-resident grid as the point list
-  // (no host round trip)
+  // the OCCUPIED cells of the mapper's device-resident grid as the point list (no host round trip)
   void updateSensorData(const Mapping::LocalMapper &mapper, const bool global_frame = true);
 
   bool checkCollisions();
-  bool checkCollisions(const Path::State current_state);
-  bool checkCollisions(const std::vector<double> &ranges,
-                       const std::vector<double> &angles, double height = 0.1);
+  bool checkCollisions(const Path::State pose);
+  bool checkCollisions(const std::vector<double> &ranges, const std::vector<double> &angles, double height = 0.1);
   // batch form used by TrajectorySampler::checkStatesFeasibility
-  std::vector<bool> checkCollisions(const std::vector<Path::State> &states);
+  std::vector<bool> checkCollisions(const std::vector<Path::State> &poses);
   float getRadius() const;
   const hip::DwaHandle &context() const { return ctx_; }
   float maxSensorRange = 10.0f;  // forwarded to the obstacle-cost side
 
  protected:
-  double robotHeight_{1.0}, robotRadius_{0.0};
+  double body_height_{1.0}, body_radius_{0.0};
 
  private:
   hip::DwaHandle ctx_;
-  Path::State state_;
-  double octree_resolution_{0.01};
+  Path::State pose_;
+  double voxel_{0.01};
 };
 
 }  // namespace Kompass

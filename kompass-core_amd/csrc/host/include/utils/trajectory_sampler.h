@@ -86,8 +86,8 @@ class TrajectorySampler {
   template <typename T>
   bool checkStatesFeasibility(const std::vector<Path::State> &states,
                               const T &sensor_points) {
-    collChecker->updateSensorData(sensor_points);
-    for (bool hit : collChecker->checkCollisions(states))
+    checker_->updateSensorData(sensor_points);
+    for (bool hit : checker_->checkCollisions(states))
       if (hit) return true;
     return false;
   }
@@ -111,12 +111,12 @@ class TrajectorySampler {
   template <typename T>
   size_t prepareOnDevice(const Velocity2D &current_vel, const Path::State &pose, const T &sensor_points,
                          float max_sensor_range) {
-    collChecker->maxSensorRange = max_sensor_range;
+    checker_->maxSensorRange = max_sensor_range;
     // the lattice first: its upload needs an idle stream (the list is written over the BAR under the
     // kernels' feet otherwise) -- behind the sensor update it would wait for the device-side sensor build
     const size_t n = sampleWindow(current_vel, /*host_copy=*/false);
-    collChecker->updateState(pose);
-    collChecker->updateSensorData(sensor_points);
+    checker_->updateState(pose);
+    checker_->updateSensorData(sensor_points);
     return n;
   }
   // velocity triple of generated sample `raw` of the last window (host copy of the lattice)
@@ -127,14 +127,14 @@ class TrajectorySampler {
   }
   double timeStep() const { return time_step_; }
   const hip::DwaHandle &context() const { return ctx_; }
-  ControlType controlType() const { return ctrType; }
-  const ControlLimitsParams &limits() const { return ctrlimits; }
+  ControlType controlType() const { return drive_; }
+  const ControlLimitsParams &limits() const { return limits_; }
 
  protected:
-  ControlType ctrType;
-  ControlLimitsParams ctrlimits;
-  std::unique_ptr<CollisionChecker> collChecker;
-  int maxNumThreads;
+  ControlType drive_;
+  ControlLimitsParams limits_;
+  std::unique_ptr<CollisionChecker> checker_;
+  int host_threads_;
 
  private:
   void init(const CollisionChecker::ShapeType shape,

@@ -307,10 +307,10 @@ TrajSearchResult CostEvaluator::getMinTrajectoryCostOnDevice(const Path::Path *r
 DWA::DWA(ControlLimitsParams lim, ControlType type, double dt, double predictionHorizon,
          double controlHorizon, int maxLin, int maxAng, const CollisionChecker::ShapeType shape,
          const std::vector<float> dims, const Eigen::Vector3f &spos, const Eigen::Vector4f &srot,
-         const double octreeRes, CostEvaluator::TrajectoryCostsWeights w, const int maxNumThreads)
+         const double octreeRes, CostEvaluator::TrajectoryCostsWeights w, const int host_threads_)
     : Follower() {
   configure(lim, type, dt, predictionHorizon, controlHorizon, maxLin, maxAng, shape, dims, spos,
-            srot, octreeRes, w, maxNumThreads);
+            srot, octreeRes, w, host_threads_);
   max_forward_distance_ =
       (type == ControlType::OMNI ? std::max(lim.velXParams.maxVel, lim.velYParams.maxVel)
                                  : lim.velXParams.maxVel) *
@@ -321,9 +321,9 @@ DWA::DWA(ControlLimitsParams lim, ControlType type, double dt, double prediction
 DWA::DWA(TrajectorySampler::TrajectorySamplerParameters config, ControlLimitsParams lim,
          ControlType type, const CollisionChecker::ShapeType shape, const std::vector<float> dims,
          const Eigen::Vector3f &spos, const Eigen::Vector4f &srot,
-         CostEvaluator::TrajectoryCostsWeights w, const int maxNumThreads)
+         CostEvaluator::TrajectoryCostsWeights w, const int host_threads_)
     : Follower() {
-  configure(config, lim, type, shape, dims, spos, srot, w, maxNumThreads);
+  configure(config, lim, type, shape, dims, spos, srot, w, host_threads_);
   const double horizon = config.getParameter<double>("control_horizon");
   max_forward_distance_ =
       (type == ControlType::OMNI ? std::max(lim.velXParams.maxVel, lim.velYParams.maxVel)
@@ -345,25 +345,25 @@ void DWA::configure(ControlLimitsParams lim, ControlType type, double dt, double
                     double controlHorizon, int maxLin, int maxAng,
                     const CollisionChecker::ShapeType shape, const std::vector<float> dims,
                     const Eigen::Vector3f &spos, const Eigen::Vector4f &srot, const double octreeRes,
-                    CostEvaluator::TrajectoryCostsWeights w, const int maxNumThreads) {
+                    CostEvaluator::TrajectoryCostsWeights w, const int host_threads_) {
   trajSampler = std::make_unique<TrajectorySampler>(lim, type, dt, predictionHorizon, controlHorizon,
                                                     maxLin, maxAng, shape, dims, spos,
-                                                    Eigen::Quaternionf(srot), octreeRes, maxNumThreads);
+                                                    Eigen::Quaternionf(srot), octreeRes, host_threads_);
   // sampler and evaluator share one device context: the rolled-out samples
   // never leave HBM between the two stages
   trajCostEvaluator = std::make_unique<CostEvaluator>(w, trajSampler->context());
-  this->maxNumThreads = maxNumThreads;
+  this->host_threads_ = host_threads_;
 }
 
 void DWA::configure(TrajectorySampler::TrajectorySamplerParameters config, ControlLimitsParams lim,
                     ControlType type, const CollisionChecker::ShapeType shape,
                     const std::vector<float> dims, const Eigen::Vector3f &spos,
                     const Eigen::Vector4f &srot, CostEvaluator::TrajectoryCostsWeights w,
-                    const int maxNumThreads) {
+                    const int host_threads_) {
   trajSampler = std::make_unique<TrajectorySampler>(config, lim, type, shape, dims, spos,
-                                                    Eigen::Quaternionf(srot), maxNumThreads);
+                                                    Eigen::Quaternionf(srot), host_threads_);
   trajCostEvaluator = std::make_unique<CostEvaluator>(w, trajSampler->context());
-  this->maxNumThreads = maxNumThreads;
+  this->host_threads_ = host_threads_;
 }
 
 void DWA::resetOctreeResolution(const double r) { trajSampler->resetOctreeResolution(r); }
@@ -372,28 +372,28 @@ void DWA::addCustomCost(double weight, CostEvaluator::CustomCostFunction f) {
   trajCostEvaluator->addCustomCost(weight, std::move(f));
 }
 void DWA::setCurrentState(const Path::State &s) {
-  currentState = s;
+  pose_ = s;
   trajSampler->updateState(s);
 }
 
 void DWA::adaptPredictionHorizonToCurvature() {
   const double base = trajSampler->getBasePredictionHorizon();
-  const double v_max = ctrlimitsParams.velXParams.maxVel;  // see Controller (Q1)
-  if (!currentPath || v_max < 1e-3 || max_point_interpolation_distance_ <= 0.0) {
+  const double v_max = limits_.velXParams.maxVel;  // see Controller (Q1)
+  if (!on_.path || v_max < 1e-3 || knob_.point_spacing <= 0.0) {
     trajSampler->setPredictionHorizon(base);
     max_forward_distance_ = base * v_max;
     return;
   }
-  const size_t last = currentPath->getSize() - 1;
-  const size_t first = std::min(closestPosition->index, last);
-  const size_t peek = static_cast<size_t>(std::ceil(base * v_max / max_point_interpolation_distance_));
+  const size_t last = on_.path->getSize() - 1;
+  const size_t first = std::min(on_.nearest->index, last);
+  const size_t peek = static_cast<size_t>(std::ceil(base * v_max / knob_.point_spacing));
   const size_t end = std::min(first + peek, last);
   float kappa = 0.0f;
   for (size_t i = first; i <= end; ++i)
-    kappa = std::max(kappa, std::abs(static_cast<float>(currentPath->getCurvature(i))));
+    kappa = std::max(kappa, std::abs(static_cast<float>(on_.path->getCurvature(i))));
   double horizon = base;
-  if (kappa > curvature_horizon_tolerance_) {
-    const double cap = std::sqrt(8.0 * curvature_horizon_tolerance_ / kappa) / v_max;
+  if (kappa > knob_.horizon_tolerance) {
+    const double cap = std::sqrt(8.0 * knob_.horizon_tolerance / kappa) / v_max;
     horizon = std::min(base, cap);
     LOG_DEBUG("Using Adaptive Horizon: ", horizon);
   }
@@ -402,14 +402,14 @@ void DWA::adaptPredictionHorizonToCurvature() {
 }
 
 Path::Path::View DWA::findTrackedPathSegment() {
-  const size_t last = currentPath->getSize() - 1;
-  const size_t first = std::min(closestPosition->index, last);
-  size_t look = max_segment_size_;
-  if (max_point_interpolation_distance_ > 0.0)
-    look = std::max(max_segment_size_,
+  const size_t last = on_.path->getSize() - 1;
+  const size_t first = std::min(on_.nearest->index, last);
+  size_t look = on_.longest_segment;
+  if (knob_.point_spacing > 0.0)
+    look = std::max(on_.longest_segment,
                     static_cast<size_t>(std::ceil(max_forward_distance_ /
-                                                  max_point_interpolation_distance_)) + 1);
-  return currentPath->getPart(first, std::min(first + look, last));
+                                                  knob_.point_spacing)) + 1);
+  return on_.path->getPart(first, std::min(first + look, last));
 }
 
 std::tuple<MatrixXfR, MatrixXfR> DWA::getDebuggingSamples() const {

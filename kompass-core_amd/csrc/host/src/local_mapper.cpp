@@ -24,18 +24,18 @@ LocalMapper::LocalMapper(const int H, const int W, const float res, const Eigen:
                          const float orient, const bool isPointCloud, const int scanSize,
                          const float angleStep, const float maxHeight, const float minHeight, const float rangeMax,
                          const int maxPointsPerLine, const int)
-    : m_gridHeight(H), m_gridWidth(W), m_resolution(res), m_laserscanOrientation(orient),
-      m_rangeMax(rangeMax), m_maxPointsPerLine(maxPointsPerLine), m_laserscanPosition(pos),
-      m_scanSize(scanSize), m_maxHeight(maxHeight), m_minHeight(minHeight), gridData(H, W),
+    : rows_(H), cols_(W), cell_(res), sensor_yaw_(orient),
+      range_cap_(rangeMax), line_cap_(maxPointsPerLine), sensor_at_(pos),
+      bins_(scanSize), z_hi_(maxHeight), z_lo_(minHeight), cells_(H, W),
       ctx_(makeMapper(H, W, res, pos, orient, scanSize)) {
-  m_angleStep = angleStep;
+  bin_step_ = angleStep;
   if (isPointCloud) {
     // local_mapper.h:38-56: the angle step is derived from the scan size so
     // that binning and ray casting see the same grid
     const double derived_step = (2.0 * M_PI) / static_cast<double>(scanSize);
-    initializedAngles.resize(std::max(scanSize, 0));
-    initializedRanges.resize(std::max(scanSize, 0));
-    for (int i = 0; i < scanSize; ++i) initializedAngles[i] = i * derived_step;
+    bin_angles_.resize(std::max(scanSize, 0));
+    bin_ranges_.resize(std::max(scanSize, 0));
+    for (int i = 0; i < scanSize; ++i) bin_angles_[i] = i * derived_step;
   }
 }
 
@@ -50,26 +50,26 @@ LocalMapper::LocalMapper(const int H, const int W, const float res, const Eigen:
                          const int maxPointsPerLine, const int maxNumThreads)
     : LocalMapper(H, W, res, pos, orient, isPointCloud, scanSize, angleStep, maxHeight, minHeight,
                   rangeMax, maxPointsPerLine, maxNumThreads) {
-  m_pPrior = pPrior;
-  m_pOccupied = pOccupied;
-  m_pEmpty = pEmpty;
-  m_rangeSure = rangeSure;
-  m_wallSize = wallSize;
+  p_prior_ = pPrior;
+  p_hit_ = pOccupied;
+  p_free_ = pEmpty;
+  sure_range_ = rangeSure;
+  wall_ = wallSize;
 }
 
-void LocalMapper::enableBayes() {
-  if (bayesEnabled_) return;
-  const kc_bayes_params p{m_pPrior, m_pOccupied, m_pEmpty, m_rangeSure, m_rangeMax, m_wallSize};
+void LocalMapper::turnOnBayes() {
+  if (bayes_on_) return;
+  const kc_bayes_params p{p_prior_, p_hit_, p_free_, sure_range_, range_cap_, wall_};
   hip::check(kc_mapper_enable_bayes(ctx_.get(), &p));
-  gridDataProb = Eigen::MatrixXf(m_gridHeight, m_gridWidth);
-  bayesEnabled_ = true;
+  belief_ = Eigen::MatrixXf(rows_, cols_);
+  bayes_on_ = true;
 }
 
 Eigen::MatrixXi &LocalMapper::scanToGrid(const std::vector<double> &angles,
                                          const std::vector<double> &ranges) {
   const size_t n = std::min(angles.size(), ranges.size());
-  hip::check(kc_mapper_scan_to_grid(ctx_.get(), angles.data(), ranges.data(), n, gridData.data()));
-  return gridData;
+  hip::check(kc_mapper_scan_to_grid(ctx_.get(), angles.data(), ranges.data(), n, cells_.data()));
+  return cells_;
 }
 
 void LocalMapper::scanToGridOnDevice(const std::vector<double> &angles,
@@ -82,23 +82,23 @@ void LocalMapper::scanToGridOnDevice(const std::vector<double> &angles,
 Eigen::MatrixXi &LocalMapper::scanToGrid(const std::vector<int8_t> &data, int point_step,
                                          int row_step, int height, int width, float x_offset,
                                          float y_offset, float z_offset) {
-  if (initializedAngles.empty())
+  if (bin_angles_.empty())
     throw std::runtime_error("LocalMapper::scanToGrid(raw point cloud): not constructed with is_pointcloud");
   pointCloudToLaserScanFromRaw(data, point_step, row_step, height, width, static_cast<int>(x_offset),
-                               static_cast<int>(y_offset), static_cast<int>(z_offset), m_rangeMax,
-                               m_minHeight, m_maxHeight, m_scanSize, initializedRanges);
-  return scanToGrid(initializedAngles, initializedRanges);
+                               static_cast<int>(y_offset), static_cast<int>(z_offset), range_cap_,
+                               z_lo_, z_hi_, bins_, bin_ranges_);
+  return scanToGrid(bin_angles_, bin_ranges_);
 }
 
 // local_mapper.cpp:222-241 (single-thread order: the last beam that crosses a
 // cell decides its probability)
 std::tuple<Eigen::MatrixXi &, Eigen::MatrixXf &>
 LocalMapper::scanToGridBaysian(const std::vector<double> &angles, const std::vector<double> &ranges) {
-  enableBayes();
+  turnOnBayes();
   const size_t n = std::min(angles.size(), ranges.size());
-  hip::check(kc_mapper_scan_to_grid_bayes(ctx_.get(), angles.data(), ranges.data(), n, gridData.data(),
-                                          gridDataProb.data()));
-  return std::tie(gridData, gridDataProb);
+  hip::check(kc_mapper_scan_to_grid_bayes(ctx_.get(), angles.data(), ranges.data(), n, cells_.data(),
+                                          belief_.data()));
+  return std::tie(cells_, belief_);
 }
 
 // local_mapper.cpp:253-269
@@ -108,8 +108,8 @@ LocalMapper::scanToGridBaysian(const std::vector<int8_t> &data, int point_step, 
                                float z_offset) {
   std::vector<double> angles, ranges;
   pointCloudToLaserScanFromRaw(data, point_step, row_step, height, width, static_cast<int>(x_offset),
-                               static_cast<int>(y_offset), static_cast<int>(z_offset), m_rangeMax,
-                               m_minHeight, m_maxHeight, m_angleStep, ranges, angles);
+                               static_cast<int>(y_offset), static_cast<int>(z_offset), range_cap_,
+                               z_lo_, z_hi_, bin_step_, ranges, angles);
   return scanToGridBaysian(angles, ranges);
 }
 
@@ -117,21 +117,21 @@ LocalMapper::scanToGridBaysian(const std::vector<int8_t> &data, int point_step, 
 // the device
 void LocalMapper::getPreviousGridInCurrentPose(const Eigen::Vector2f &currentPositionInPreviousPose,
                                                double currentOrientationInPreviousPose) {
-  enableBayes();
+  turnOnBayes();
   const float p[2] = {currentPositionInPreviousPose(0), currentPositionInPreviousPose(1)};
   hip::check(kc_mapper_warp_previous(ctx_.get(), p, currentOrientationInPreviousPose));
 }
 
 Eigen::MatrixXf &LocalMapper::previousGridProb() {
-  enableBayes();
-  previousGridDataProb = Eigen::MatrixXf(m_gridHeight, m_gridWidth);
-  hip::check(kc_mapper_get_previous_prob(ctx_.get(), previousGridDataProb.data()));
-  return previousGridDataProb;
+  turnOnBayes();
+  prior_belief_ = Eigen::MatrixXf(rows_, cols_);
+  hip::check(kc_mapper_get_previous_prob(ctx_.get(), prior_belief_.data()));
+  return prior_belief_;
 }
 
 void LocalMapper::setPreviousGridProb(const Eigen::MatrixXf *prob) {
-  enableBayes();
-  if (prob && (prob->rows() != m_gridHeight || prob->cols() != m_gridWidth))
+  turnOnBayes();
+  if (prob && (prob->rows() != rows_ || prob->cols() != cols_))
     throw std::invalid_argument("LocalMapper::setPreviousGridProb: grid must be grid_height x grid_width");
   hip::check(kc_mapper_set_previous_prob(ctx_.get(), prob ? prob->data() : nullptr));
 }

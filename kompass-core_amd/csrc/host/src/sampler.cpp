@@ -59,29 +59,29 @@ kc_state toKc(const Path::State &s) { return kc_state{s.x, s.y, s.yaw, s.speed};
 CollisionChecker::CollisionChecker(const ShapeType shape, const std::vector<float> &dims,
                                    const Eigen::Vector3f &spos,
                                    const Eigen::Quaternionf &srot, const double res)
-    : octree_resolution_(res) {
-  shapeExtents(shape, dims, robotRadius_, robotHeight_);
+    : voxel_(res) {
+  shapeExtents(shape, dims, body_radius_, body_height_);
   ctx_ = hip::makeDwa(baseParams(shape, dims, spos, srot, res));
 }
 CollisionChecker::CollisionChecker(hip::DwaHandle ctx, ShapeType shape,
                                    const std::vector<float> &dims, double res)
-    : ctx_(std::move(ctx)), octree_resolution_(res) {
-  shapeExtents(shape, dims, robotRadius_, robotHeight_);
+    : ctx_(std::move(ctx)), voxel_(res) {
+  shapeExtents(shape, dims, body_radius_, body_height_);
 }
 
 void CollisionChecker::resetOctreeResolution(const double r) {
-  if (r != octree_resolution_) {
-    octree_resolution_ = r;
+  if (r != voxel_) {
+    voxel_ = r;
     hip::check(kc_dwa_set_resolution(ctx_.get(), r));
   }
 }
-float CollisionChecker::getRadius() const { return static_cast<float>(robotRadius_); }
-void CollisionChecker::updateState(const Path::State s) { state_ = s; }
+float CollisionChecker::getRadius() const { return static_cast<float>(body_radius_); }
+void CollisionChecker::updateState(const Path::State s) { pose_ = s; }
 void CollisionChecker::updateState(const double x, const double y, const double yaw) {
-  state_ = Path::State(x, y, yaw);
+  pose_ = Path::State(x, y, yaw);
 }
 void CollisionChecker::updateSensorData(const Control::LaserScan &scan, const bool) {
-  const kc_state st = toKc(state_);
+  const kc_state st = toKc(pose_);
   hip::check(kc_dwa_set_scan(ctx_.get(), &st, scan.ranges.data(), scan.angles.data(),
                              std::min(scan.ranges.size(), scan.angles.size()), maxSensorRange));
 }
@@ -93,12 +93,12 @@ void CollisionChecker::updateSensorData(const std::vector<Path::Point> &cloud,
 }
 // (collision_check.h:119-131: world-frame lists -- what the controllers pass -- or sensor-frame lists)
 void CollisionChecker::updateSensorData(const Control::PointCloudView &cloud, const bool global_frame) {
-  const kc_state st = toKc(state_);
+  const kc_state st = toKc(pose_);
   hip::check(global_frame ? kc_dwa_set_points(ctx_.get(), &st, cloud.xyz, cloud.n, maxSensorRange)
                           : kc_dwa_set_points_sensor_frame(ctx_.get(), &st, cloud.xyz, cloud.n, maxSensorRange));
 }
 void CollisionChecker::updateSensorData(const Mapping::LocalMapper &mapper, const bool) {
-  const kc_state st = toKc(state_);
+  const kc_state st = toKc(pose_);
   hip::check(kc_dwa_set_grid_from_mapper(ctx_.get(), &st, mapper.hipContext(), maxSensorRange));
 }
 std::vector<bool> CollisionChecker::checkCollisions(const std::vector<Path::State> &states) {
@@ -116,7 +116,7 @@ std::vector<bool> CollisionChecker::checkCollisions(const std::vector<Path::Stat
 bool CollisionChecker::checkCollisions(const Path::State s) {
   return checkCollisions(std::vector<Path::State>{s})[0];
 }
-bool CollisionChecker::checkCollisions() { return checkCollisions(state_); }
+bool CollisionChecker::checkCollisions() { return checkCollisions(pose_); }
 bool CollisionChecker::checkCollisions(const std::vector<double> &ranges,
                                        const std::vector<double> &angles, double) {
   updateSensorData(Control::LaserScan(ranges, angles));
@@ -132,14 +132,14 @@ TrajectorySampler::TrajectorySampler(
     int maxAngularSamples, const CollisionChecker::ShapeType robotShapeType,
     const std::vector<float> robotDimensions, const Eigen::Vector3f &spos,
     const Eigen::Quaternionf &srot, const double octreeRes, const int maxNumThreads) {
-  ctrlimits = controlLimits;
-  ctrType = controlType;
+  limits_ = controlLimits;
+  drive_ = controlType;
   time_step_ = timeStep;
   max_time_ = base_max_time_ = predictionHorizon;
   control_time_ = controlHorizon;
   lin_samples_max_ = maxLinearSamples;
   ang_samples_max_raw_ = maxAngularSamples;
-  this->maxNumThreads = maxNumThreads;
+  host_threads_ = maxNumThreads;
   init(robotShapeType, robotDimensions, spos, srot, octreeRes);
 }
 
@@ -148,14 +148,14 @@ TrajectorySampler::TrajectorySampler(
     ControlType controlType, const CollisionChecker::ShapeType robotShapeType,
     const std::vector<float> robotDimensions, const Eigen::Vector3f &spos,
     const Eigen::Quaternionf &srot, const int maxNumThreads) {
-  ctrlimits = controlLimits;
-  ctrType = controlType;
+  limits_ = controlLimits;
+  drive_ = controlType;
   time_step_ = config.getParameter<double>("time_step");
   max_time_ = base_max_time_ = config.getParameter<double>("prediction_horizon");
   control_time_ = config.getParameter<double>("control_horizon");
   lin_samples_max_ = config.getParameter<int>("max_linear_samples");
   ang_samples_max_raw_ = config.getParameter<int>("max_angular_samples");
-  this->maxNumThreads = maxNumThreads;
+  host_threads_ = maxNumThreads;
   drop_samples_ = config.getParameter<bool>("drop_samples");
   init(robotShapeType, robotDimensions, spos, srot,
        config.getParameter<double>("octree_map_resolution"));
@@ -167,22 +167,22 @@ void TrajectorySampler::init(const CollisionChecker::ShapeType shape,
                              const Eigen::Quaternionf &srot, double octreeRes) {
   const int ang = ang_samples_max_raw_ + 1 - (ang_samples_max_raw_ % 2);
   numPointsPerTrajectory = getNumPointsPerTrajectory(time_step_, max_time_);
-  numTrajectories = getNumTrajectories(ctrType, lin_samples_max_, ang);
+  numTrajectories = getNumTrajectories(drive_, lin_samples_max_, ang);
   kc_dwa_params p = baseParams(shape, dims, spos, srot, octreeRes);
   p.time_step = time_step_;
   p.max_samples = numTrajectories + 8;
   p.max_points = std::max<size_t>(numPointsPerTrajectory, 2);
   p.max_segment = 512;
-  p.acc_limits[0] = static_cast<float>(ctrlimits.velXParams.maxAcceleration);
-  p.acc_limits[1] = static_cast<float>(ctrlimits.velYParams.maxAcceleration);
-  p.acc_limits[2] = static_cast<float>(ctrlimits.omegaParams.maxAcceleration);
+  p.acc_limits[0] = static_cast<float>(limits_.velXParams.maxAcceleration);
+  p.acc_limits[1] = static_cast<float>(limits_.velYParams.maxAcceleration);
+  p.acc_limits[2] = static_cast<float>(limits_.omegaParams.maxAcceleration);
   ctx_ = hip::makeDwa(p);
-  collChecker = std::make_unique<CollisionChecker>(ctx_, shape, dims, octreeRes);
-  if (ctrType != ControlType::OMNI)  // trajectory_sampler.cpp:51-54
-    ctrlimits.velYParams = LinearVelocityControlParams(0.0, 0.0, 0.0);
+  checker_ = std::make_unique<CollisionChecker>(ctx_, shape, dims, octreeRes);
+  if (drive_ != ControlType::OMNI)  // trajectory_sampler.cpp:51-54
+    limits_.velYParams = LinearVelocityControlParams(0.0, 0.0, 0.0);
 }
 
-void TrajectorySampler::updateState(const Path::State &s) { collChecker->updateState(s); }
+void TrajectorySampler::updateState(const Path::State &s) { checker_->updateState(s); }
 void TrajectorySampler::setSampleDroppingMode(const bool drop) {
   // trajectory_sampler.cpp:103-105 / :157-168.  numCtrlPoints_ is control_horizon / time_step as size_t (:88,
   // the config-object constructor; the explicit-argument constructor of the reference leaves the member
@@ -193,9 +193,9 @@ void TrajectorySampler::setSampleDroppingMode(const bool drop) {
   hip::check(kc_dwa_set_option(ctx_.get(), "drop_samples", drop ? 1.0 : 0.0));
 }
 void TrajectorySampler::resetOctreeResolution(const double r) {
-  collChecker->resetOctreeResolution(r);
+  checker_->resetOctreeResolution(r);
 }
-float TrajectorySampler::getRobotRadius() const { return collChecker->getRadius(); }
+float TrajectorySampler::getRobotRadius() const { return checker_->getRadius(); }
 
 void TrajectorySampler::setPredictionHorizon(double horizon) {
   const double min_h = 2.0 * time_step_;
@@ -214,23 +214,23 @@ size_t TrajectorySampler::launch(const Velocity2D &vel, const Path::State &pose)
 
 size_t TrajectorySampler::sampleWindow(const Velocity2D &vel, bool host_copy) {
   kc_limits L;
-  L.vx_max = ctrlimits.velXParams.maxVel;
-  L.vx_acc = ctrlimits.velXParams.maxAcceleration;
-  L.vx_dec = ctrlimits.velXParams.maxDeceleration;
-  L.vy_max = ctrlimits.velYParams.maxVel;
-  L.vy_acc = ctrlimits.velYParams.maxAcceleration;
-  L.vy_dec = ctrlimits.velYParams.maxDeceleration;
-  L.omega_max_angle = ctrlimits.omegaParams.maxAngle;
-  L.omega_max = ctrlimits.omegaParams.maxOmega;
-  L.omega_acc = ctrlimits.omegaParams.maxAcceleration;
-  L.omega_dec = ctrlimits.omegaParams.maxDeceleration;
+  L.vx_max = limits_.velXParams.maxVel;
+  L.vx_acc = limits_.velXParams.maxAcceleration;
+  L.vx_dec = limits_.velXParams.maxDeceleration;
+  L.vy_max = limits_.velYParams.maxVel;
+  L.vy_acc = limits_.velYParams.maxAcceleration;
+  L.vy_dec = limits_.velYParams.maxDeceleration;
+  L.omega_max_angle = limits_.omegaParams.maxAngle;
+  L.omega_max = limits_.omegaParams.maxOmega;
+  L.omega_acc = limits_.omegaParams.maxAcceleration;
+  L.omega_dec = limits_.omegaParams.maxDeceleration;
   size_t n = 0;
   if (host_copy) {  // collect() reads the lattice back sample by sample; the device cycle does not
     last_vx_.resize(numTrajectories + 8);
     last_vy_.resize(numTrajectories + 8);
     last_omega_.resize(numTrajectories + 8);
   }
-  hip::check(kc_dwa_sample_window(ctx_.get(), static_cast<int>(ctrType), &L, vel.vx(), vel.vy(),
+  hip::check(kc_dwa_sample_window(ctx_.get(), static_cast<int>(drive_), &L, vel.vx(), vel.vy(),
                                   vel.omega(), lin_samples_max_, ang_samples_max_raw_, &n,
                                   host_copy ? last_vx_.data() : nullptr, host_copy ? last_vy_.data() : nullptr,
                                   host_copy ? last_omega_.data() : nullptr, host_copy ? last_vx_.size() : 0));
@@ -239,24 +239,24 @@ size_t TrajectorySampler::sampleWindow(const Velocity2D &vel, bool host_copy) {
 
 size_t TrajectorySampler::rolloutOnDevice(const Velocity2D &vel, const Path::State &pose,
                                           const LaserScan &scan, float max_range) {
-  collChecker->maxSensorRange = max_range;
-  collChecker->updateState(pose);
-  collChecker->updateSensorData(scan);
+  checker_->maxSensorRange = max_range;
+  checker_->updateState(pose);
+  checker_->updateSensorData(scan);
   return launch(vel, pose);
 }
 size_t TrajectorySampler::rolloutOnDevice(const Velocity2D &vel, const Path::State &pose,
                                           const std::vector<Path::Point> &cloud, float max_range) {
-  collChecker->maxSensorRange = max_range;
-  collChecker->updateState(pose);
-  collChecker->updateSensorData(cloud);
+  checker_->maxSensorRange = max_range;
+  checker_->updateState(pose);
+  checker_->updateSensorData(cloud);
   return launch(vel, pose);
 }
 
 size_t TrajectorySampler::rolloutOnDevice(const Velocity2D &vel, const Path::State &pose,
                                           const Mapping::LocalMapper &mapper, float max_range) {
-  collChecker->maxSensorRange = max_range;
-  collChecker->updateState(pose);
-  collChecker->updateSensorData(mapper);
+  checker_->maxSensorRange = max_range;
+  checker_->updateState(pose);
+  checker_->updateSensorData(mapper);
   return launch(vel, pose);
 }
 
@@ -292,20 +292,20 @@ std::unique_ptr<TrajectorySamples2D> TrajectorySampler::collect() {
 std::unique_ptr<TrajectorySamples2D>
 TrajectorySampler::generateTrajectories(const Velocity2D &vel, const Path::State &pose,
                                         const LaserScan &scan) {
-  rolloutOnDevice(vel, pose, scan, collChecker->maxSensorRange);
+  rolloutOnDevice(vel, pose, scan, checker_->maxSensorRange);
   return collect();
 }
 std::unique_ptr<TrajectorySamples2D>
 TrajectorySampler::generateTrajectories(const Velocity2D &vel, const Path::State &pose,
                                         const std::vector<Path::Point> &cloud) {
-  rolloutOnDevice(vel, pose, cloud, collChecker->maxSensorRange);
+  rolloutOnDevice(vel, pose, cloud, checker_->maxSensorRange);
   return collect();
 }
 
 std::unique_ptr<TrajectorySamples2D>
 TrajectorySampler::generateTrajectories(const Velocity2D &vel, const Path::State &pose,
                                         const Mapping::LocalMapper &mapper) {
-  rolloutOnDevice(vel, pose, mapper, collChecker->maxSensorRange);
+  rolloutOnDevice(vel, pose, mapper, checker_->maxSensorRange);
   return collect();
 }
 
@@ -316,7 +316,7 @@ Trajectory2D TrajectorySampler::generateSingleSampleFromVel(const Velocity2D &ve
   Path::State s = pose;
   Trajectory2D t(numPointsPerTrajectory);
   t.path.add(0, s.x, s.y);
-  const bool rotate_then_move = ctrType == ControlType::DIFFERENTIAL_DRIVE;
+  const bool rotate_then_move = drive_ == ControlType::DIFFERENTIAL_DRIVE;
   for (size_t i = 0; i + 1 < numPointsPerTrajectory; ++i) {
     if (rotate_then_move && std::abs(vel.vx()) > MIN_VEL && std::abs(vel.omega()) > MIN_VEL) {
       Velocity2D tmp = vel;
