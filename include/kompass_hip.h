@@ -182,6 +182,10 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        rectangle of cells that can hold the trajectory's nearest obstacle are
  *                        broadcast to all of its points (obstacle_union_scan) instead of a ring walk
  *                        per point; rectangles with more obstacles than this fall back.  0: off
+ *   "box_cover"      (1) BOX robots at least twice as long as wide whose inscribed and circumscribed circles are
+ *                        4.5 voxels or more apart: the pose gate of the fused kernels looks up several circles
+ *                        laid along the long axis in the dilated sensor masks (2 .. 8 of them) instead of one
+ *                        around the centre; 0: the single look-up.  Takes effect with the next sensor update
  *   "cost_batch"     (1) the long-list cost kernel leaves the per-sample part (ordered sum, the end
  *                        point's index, weighted total, key) to a pass over 64 samples at once, a lane a
  *                        sample (sample_cost_batched_kernel), when the list fills several buffers per

@@ -40,6 +40,13 @@ struct CollDev {
   // between needs the exact test.
   const uint32_t *ginner, *gouter;
   int dil;                    // masks present
+  // Long boxes (one half extent at least twice the other): the masks are dilated for `cover` circles laid along the
+  // long axis instead of one around the centre -- the outer one with the radius hypot(A / cover, B) of a circle that
+  // covers its share of the box, the inner one with B as before -- and a pose looks all of them up: a 1.5 x 0.2 m
+  // box has a shell of 0.66 m between its inscribed and its circumscribed circle, in which every pose took the exact
+  // test (cycle kernel 44 us against 31 for a cylinder, tools/geometry_sweep.py); seven circles leave 5 cm.
+  // Low byte: the number of circles (0 / 1: the single look-up), bit 8: the long axis is the box's y axis.
+  int cover;
 };
 
 struct RollArgs {

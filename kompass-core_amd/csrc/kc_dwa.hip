@@ -759,6 +759,8 @@ int kc_dwa_set_option(kc_dwa *c, const char *name, double v) {
   } else if (n == "cost_batch") {
     c->cost_batch = on;
     c->cost_batch_forced = v == 2.0;
+  } else if (n == "box_cover") {
+    c->box_cover_on = on;  // (from the next sensor update on: the masks are dilated there)
   } else if (n == "obs_union") {
     if (!(v >= 0.0 && v <= 4096.0)) KC_FAIL(KC_ERR_RANGE, "obs_union %g outside [0, 4096]", v);
     c->obs_union = static_cast<int>(v);
@@ -796,6 +798,7 @@ int kc_dwa_get_option(kc_dwa *c, const char *name, double *v) {
   else if (n == "last_cycle_samples") *v = c->cycle_samples;  // read-only
   else if (n == "obs_near") *v = c->obs_near_opt ? c->onear_side : 0;
   else if (n == "cost_batch") *v = c->cost_batch ? (c->cost_batch_forced ? 2.0 : 1.0) : 0.0;
+  else if (n == "box_cover") *v = c->box_cover_on;
   else if (n == "obs_union") *v = c->obs_union;
   else if (n == "obs_near_rides") *v = static_cast<double>(c->onear_rides);    // read-only
   else if (n == "obs_near_builds") *v = static_cast<double>(c->onear_builds);  // read-only

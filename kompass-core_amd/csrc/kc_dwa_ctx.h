@@ -136,6 +136,8 @@ struct kc_dwa {
   bool trig_direct = false;             // host writes the trig table into device memory (large BAR)
   bool cost_batch_ok = false;           // sample_cost_batched_kernel may take kCostLdsBudget
   bool cost_batch_forced = false;       // ... value 2: for every list length (tests)
+  int dil_cover = 0;                    // CollDev::cover the masks of the last sensor update were dilated for
+  bool box_cover_on = true;             // option "box_cover": long boxes look several circles up in the dilated masks (CollDev::cover)
   bool cost_batch = true;               // option "cost_batch": the long-list cost kernel batches its per-sample part
   bool fold_publish = true;             // test hook KC_FOLD_PUBLISH=0: publish_kernel behind every cost kernel
   bool cost_obs_lds = true;             // tuning hook KC_COST_OBS_LDS=0: obstacle coordinates stay in global memory

@@ -64,6 +64,7 @@ int window_geometry(kc_dwa *c, double wx, double wy, double reach, CollDev &cd) 
     cd.ginner = c->d_ginner.p;
     cd.gouter = c->d_gouter.p;
     cd.dil = c->have_dil ? 1 : 0;
+    cd.cover = c->have_dil ? c->dil_cover : 0;
     cd.gkx0 = c->gkx0;
     cd.gky0 = c->gky0;
     cd.gH = c->gH;

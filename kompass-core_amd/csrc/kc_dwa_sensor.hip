@@ -36,6 +36,21 @@ inline void add_voxel(kc_dwa *c, float px, float py, float pz) {
   c->vox_ky.push_back(static_cast<int32_t>(fy));
 }
 
+// CollDev::cover of this robot: circles along a box at least twice as long as wide -- as many as keep the inner
+// circles (radius = the short half extent) inside the box, eight at most
+int box_cover(const kc_dwa *c) {
+  if (c->prm.shape != KC_BOX || !c->box_cover_on) return 0;
+  const double a = c->prm.dims[0] / 2.0, b = c->prm.dims[1] / 2.0;
+  const double A = std::max(a, b), B = std::min(a, b);
+  if (!(B > 0.0) || !(A >= 2.0 * B) || !std::isfinite(A / B)) return 0;
+  // (the shell between the two circles of the single look-up is A - B thick: below 4.5 voxels the look-ups of every
+  // pose cost what the exact tests of the shell's poses did -- tools/geometry_sweep.py mid boxes: 1.2 x 0.4 m at 10 cm
+  // voxels 32.9 / 34.4 us on / off in clutter, 17.5 / 15.6 where everything collides)
+  if ((A - B) / c->res < 4.5) return 0;
+  const int nc = static_cast<int>(std::min(8.0, std::floor(A / B)));
+  return nc > 1 ? (nc | (b > a ? 0x100 : 0)) : 0;
+}
+
 // dilation radii in cells (see dilate_kernel)
 struct DilGeom {
   double rho_in, rho_out;
@@ -58,6 +73,11 @@ DilGeom dil_geom(const kc_dwa *c) {
                    ? std::sqrt(std::pow(static_cast<double>(c->prm.dims[0]) / 2.0, 2) +
                                std::pow(static_cast<double>(c->prm.dims[1]) / 2.0, 2))
                    : c->radius) / c->res;
+  // a long box: the outer mask for one of the circles laid along it (CollDev::cover)
+  if (const int nc = box_cover(c) & 0xFF; nc > 1) {
+    const double A = std::max(c->prm.dims[0], c->prm.dims[1]) / 2.0, B = std::min(c->prm.dims[0], c->prm.dims[1]) / 2.0;
+    g.rho_out = std::sqrt((A / nc) * (A / nc) + B * B) * (1.0 + 1e-9) / c->res;
+  }
   g.R = static_cast<int>(std::floor(g.rho_out + 1e-6)) + 1;
   return g;
 }
@@ -69,6 +89,7 @@ int bitmap_extent(kc_dwa *c, int lox, int loy, int hix, int hiy, bool *fits) {
   const DilGeom dg = dil_geom(c);
   c->have_dil = (c->prm.shape != KC_SPHERE || c->sphere_ddz_max >= 0.0) && std::isfinite(dg.rho_out) &&
                 dg.R <= 30 && (dg.rho_in >= 0.0 || c->prm.shape == KC_SPHERE);
+  c->dil_cover = c->have_dil ? box_cover(c) : 0;
   if (c->have_dil) {
     const int pad = dg.R + 1;
     lox -= pad;

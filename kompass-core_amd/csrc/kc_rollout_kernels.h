@@ -620,7 +620,48 @@ __global__ __launch_bounds__(kFusedBlock) void rollout_collide_kernel(RollArgs a
         const double yf = a.c.r01 * dx + a.c.r11 * dy;
         const int cx = static_cast<int>(floor(xf * a.c.inv)) - a.c.kx0;
         const int cy = static_cast<int>(floor(yf * a.c.inv)) - a.c.ky0;
-        if (cx >= 0 && cx < a.c.W && cy >= 0 && cy < a.c.H) {
+        if ((a.c.cover & 0xFF) > 1) {
+          // a long box: circles along its long axis (CollDev::cover) -- any inner hit decides, all outer misses clear
+          const size_t e = (size_t)k * a.A + lrow[s];  // yaw_k
+          double cw, sw;
+          if (a.trig_dev) {
+            const double *tg = reinterpret_cast<const double *>(a.trig);
+            cw = __hip_atomic_load(tg + 2 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sw = __hip_atomic_load(tg + 2 * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            cw = a.trig[e].x;
+            sw = a.trig[e].y;
+          }
+          double ux = a.c.r00 * cw + a.c.r10 * sw, uy = a.c.r01 * cw + a.c.r11 * sw;  // the box's x axis, octree frame
+          if (a.c.cover >> 8) {
+            const double t = ux;
+            ux = -uy;
+            uy = t;
+          }
+          const int nc = a.c.cover & 0xFF;
+          const double step = 2.0 * fmax(a.c.a, a.c.b) / static_cast<double>(nc);
+          bool in = false, out = true;
+          for (int i = 0; i < nc; ++i) {
+            const double o = (static_cast<double>(i) - 0.5 * static_cast<double>(nc - 1)) * step;
+            const int qx = static_cast<int>(floor((xf + o * ux) * a.c.inv)) - a.c.kx0;
+            const int qy = static_cast<int>(floor((yf + o * uy) * a.c.inv)) - a.c.ky0;
+            if (qx >= 0 && qx < a.c.W && qy >= 0 && qy < a.c.H) {
+              const int w = qy * a.c.wpr + (qx >> 5);
+              const uint32_t bit = 1u << (qx & 31);
+              in = in || (linner[w] & bit) != 0u;
+              out = out && (louter[w] & bit) == 0u;
+            } else {
+              out = false;  // (outside the window: nothing known, the exact test decides)
+            }
+          }
+          if (in) {
+            if (a.freeze) atomicMin(&lhit[s], k);
+            else lhit[s] = 1;
+            exact = false;
+          } else if (out) {
+            exact = false;
+          }
+        } else if (cx >= 0 && cx < a.c.W && cy >= 0 && cy < a.c.H) {
           const int w = cy * a.c.wpr + (cx >> 5);
           const uint32_t bit = 1u << (cx & 31);
           if (linner[w] & bit) {

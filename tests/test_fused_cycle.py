@@ -413,3 +413,37 @@ def test_sphere_sensor_update_on_the_device(sensor_z):
         assert (h["res"]["found"], h["res"]["index"], h["res"]["n_admissible"]) == (g["res"]["found"], g["res"]["index"], g["res"]["n_admissible"])
     dev.close()
     host.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [[1.2, 0.3, 0.4], [0.2, 0.9, 0.3], [1.5, 0.2, 0.5], [0.8, 0.4, 0.4], [2.4, 0.2, 0.3]])
+@pytest.mark.parametrize("mode", ["cloud", "scan", "freeze"])
+def test_long_boxes_look_up_circles_along_their_axis(dims, mode):
+    """A box at least twice as long as wide: the pose gate looks `cover` circles up in the dilated masks (outer radius
+    hypot(A / cover, B), inner radius B, CollDev::cover) instead of one circle around the centre -- long axis along x or
+    along y, 2 .. 8 circles, point cloud / LaserScan / the freezing sampler; against the oracle, and against the single
+    look-up (option box_cover = 0), several yaws."""
+    inp = syn.make_controller_inputs("cfg2", seed=6, scale=0.25, scene="mid")
+    inp["robot"] = dict(shape=syn.BOX, dims=dims)
+    scan = None
+    if mode == "scan":
+        ang = np.linspace(-np.pi, np.pi, 720, endpoint=False)
+        scan = (2.2 + 0.9 * np.cos(3 * ang) + 0.2 * np.sin(11 * ang), ang)
+    for yaw in (0.0, 0.7, -2.1):
+        cur = dict(inp, state=(0.1, -0.2, yaw, 0.0))
+        o = oracle_cycle(cur, scan=scan) if mode != "freeze" else None
+        res = []
+        for cover in (1, 0):
+            ctx = hip_context(kh, cur)
+            ctx.set_option("box_cover", cover)
+            if mode == "freeze":
+                ctx.set_option("drop_samples", 0)
+            h = hip_cycle(kh, cur, scan=scan, ctx=ctx)
+            assert ctx.get_option("last_cycle_single_launch") == 1
+            if o is not None:
+                assert_cycle_equal(o, h)
+            res.append(h)
+            ctx.close()
+        assert res[0]["res"] == res[1]["res"]
+        np.testing.assert_array_equal(res[0]["raw"], res[1]["raw"])
+        np.testing.assert_array_equal(res[0]["costs"].view(np.uint32), res[1]["costs"].view(np.uint32))

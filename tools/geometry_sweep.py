@@ -1,6 +1,6 @@
 """The fresh-input cycle (kc_dwa_find_best_path, cfg2-sized window, survey / mid clouds) over the robot: shape, size
 (a 5 cm puck ... a 1.2 m platform), voxel size of the collision model (2 ... 25 cm) and where the sensor sits on the body.
-python tools/geometry_sweep.py [scene]"""
+python tools/geometry_sweep.py [scene] [boxes]"""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path[:0] = [ROOT, os.path.join(ROOT, "kompass-core_amd")]
@@ -18,10 +18,12 @@ seg = np.asarray(inp["seg_xyz"], np.float32)
 sacc = np.ascontiguousarray(inp["acc_at_seg"], np.float32)
 
 
-def run(label, shape, dims, res, sensor=(0, 0, 0), L=91, A=91):
+def run(label, shape, dims, res, sensor=(0, 0, 0), L=91, A=91, opts={}):
     ctx = kh.DwaContext(shape, dims, sensor, (0, 0, 0, 1), res, inp["dt"], max_samples=(L + 2) * (A + 2), max_points=P,
                         max_segment=len(seg), max_obstacles=len(pts), acc_limits=inp["acc_limits"])
     ctx.set_weights(kh.make_weights(*inp["weights"]))
+    for k, v in opts.items():
+        ctx.set_option(k, v)
     lat, ks = [], {}
     for i in range(420):
         st = (0.0, 0.0, 1e-3 * ((i % 7) - 3), 0.0)
@@ -43,6 +45,12 @@ def run(label, shape, dims, res, sensor=(0, 0, 0), L=91, A=91):
     ctx.close()
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "boxes":   # long boxes: circles along the axis (option box_cover) on / off
+    for d in ([1.5, 0.2, 0.5], [1.2, 0.4, 0.5], [1.0, 0.5, 0.5], [0.3, 1.2, 0.4]):
+        for res in (0.05, 0.1):
+            for cover in (1, 0):
+                run("box %s, voxels %.2f, box_cover %d" % (d, res, cover), kh.BOX, d, res, opts={"box_cover": cover})
+    sys.exit(0)
 for res in (0.02, 0.05, 0.1, 0.25):
     run("cylinder r 0.1 h 0.4, voxels %.2f" % res, kh.CYLINDER, [0.1, 0.4], res)
 for r_ in (0.05, 0.3, 0.6, 1.2):
