@@ -165,6 +165,9 @@ __device__ __forceinline__ long long cycle_costs(const RollArgs &a, const Tail &
     s_next = 0;
     s_bslot = -1;
   }
+#ifdef KC_PHASE_STAMPS
+  if (a.dbg && tid == 0 && blockIdx.x < 512) a.dbg[(size_t)blockIdx.x * 32 + 21] = static_cast<unsigned long long>(R) + 1ull;  // survivors + 1
+#endif
   const SegPairs seg{t.xy, t.za};
   // what the wavefront obstacle term reads: the scan block when there is a scan's near table, the buckets' arrays otherwise
   const float *const wobx = tail.t.onear != nullptr ? tail.t.osx : c.b.bx;

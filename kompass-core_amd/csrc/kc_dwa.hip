@@ -554,6 +554,19 @@ void kc_dwa_destroy(kc_dwa *c) {
         ++end_hist[std::min(std::max(e, 0), 63)];
         ++cost_hist[std::min(std::max(d, 0), 63)];
       }
+      {  // the cost phase by the number of survivors of the workgroup
+        double sum[34] = {0}, mx[34] = {0};
+        int cnt[34] = {0};
+        for (int b = 0; b < 512; ++b) {
+          if (!h[b * 32] || !h[b * 32 + 8] || !h[b * 32 + 6] || !h[b * 32 + 21]) continue;
+          const int R = std::min<int>(static_cast<int>(h[b * 32 + 21]) - 1, 33);
+          const double d = (h[b * 32 + 8] - h[b * 32 + 6]) / 100.0;
+          sum[R] += d; mx[R] = std::max(mx[R], d); ++cnt[R];
+        }
+        std::fprintf(stderr, "  cost phase by survivors of the workgroup, survivors:workgroups avg/max us:");
+        for (int R = 0; R < 34; ++R) if (cnt[R]) std::fprintf(stderr, " %d:%d %.1f/%.1f", R, cnt[R], sum[R] / cnt[R], mx[R]);
+        std::fprintf(stderr, "\n");
+      }
       std::fprintf(stderr, "  workgroups by end of epilogue (us):");
       for (int i = 0; i < 64; ++i) if (end_hist[i]) std::fprintf(stderr, " %d:%d", i, end_hist[i]);
       std::fprintf(stderr, "\n  workgroups by duration of the cost phase (us):");
