@@ -177,7 +177,7 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *                        From the second cycle on kc_dwa_set_scan builds the table for the pose it
  *                        is given inside the launch of the sensor tables; a cycle that starts
  *                        elsewhere (or reaches further) builds its own
- *   "obs_union"      (96) obstacle term of long admissible lists, point-cloud / costmap input: where a
+ *   "obs_union"     (512) obstacle term of long admissible lists, point-cloud / costmap input: where a
  *                        trajectory runs through occupied bucket cells, the obstacles of the ONE
  *                        rectangle of cells that can hold the trajectory's nearest obstacle are
  *                        broadcast to all of its points (obstacle_union_scan) instead of a ring walk

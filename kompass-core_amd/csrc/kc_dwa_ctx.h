@@ -328,7 +328,10 @@ struct kc_dwa {
   DevBuf<uint4> d_onear;
   float onear_x0 = 0.f, onear_y0 = 0.f, onear_g = 0.f;
   bool onear_ok = false;                 // the table covers the running cycle
-  int obs_union = 96;                    // option "obs_union": obstacle_union_scan up to this many obstacles (0: off)
+  int obs_union = 512;                   // option "obs_union": obstacle_union_scan up to this many obstacles (0: off).  (96 until a sweep over
+                                         // dense 3-D clouds, tools/big_cloud_sweep.py: clusters of a hundred points put more than that into the
+                                         // rectangle of every trajectory that passes them, and the ring walks behind the limit evaluate every
+                                         // one of them exactly per point -- 10 k points 97 -> 55 us of cycle kernel, 30 k points 129 -> 78)
   bool obs_near_ahead = true;            // test hook KC_OBS_NEAR_AHEAD=0: the cycle builds the table itself
   long long onear_rides = 0, onear_builds = 0;  // tables built in the sensor launch / by a launch of their own
   bool onear_ahead = false;              // kc_dwa_set_scan planned a table (onear_args) for the sensor build launch
