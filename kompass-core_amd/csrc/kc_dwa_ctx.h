@@ -363,7 +363,10 @@ struct kc_dwa {
 // about one obstacle per cell up to 4 k points, 64 per cell here); beyond: the host path, finer grid
 constexpr size_t kSensorDeviceMax = 262144;
 constexpr int kTiltCrop = 4000;                // half side of the kept window of a cropped tilted scan, in voxel columns
-constexpr size_t kSensorFusedMax = 32768;       // points up to which the one-launch sensor build is used
+constexpr size_t kSensorFusedMax = 32768;       // points up to which the one-launch sensor build CAN be used (spheres: it is their only device build)
+constexpr size_t kSensorFusedPays = 18432;      // ... and up to which it is ahead: every workgroup reads every point (tools/big_cloud_sweep.py,
+                                                // set_points + cycle with the one launch / the two: 10 k points 80.6 / 86.4 us, 16 k 161 / 160,
+                                                // 20 k 84.1 / 79.6, 24 k 91.7 / 84.4, 30 k 100.3 / 93.6)
 constexpr size_t kSensorFusedLds = 100 * 1024;  // dynamic LDS of sensor_fused_kernel (band rows; bucket tables + point ids)
 
 inline int use_device(const kc_dwa *c) {

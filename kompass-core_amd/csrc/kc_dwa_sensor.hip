@@ -639,9 +639,13 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
   std::vector<double> sph_lut;
   if (sphere) {
     if (c->sensor_two_launch || n > kSensorFusedMax || !c->sensor_fused_ok) return KC_OK;
-    const int k0 = key(lo[2]), k1 = key(hi[2]);
-    if (k1 - k0 + 1 > 36) return KC_OK;
+    // (only the layers that can touch the sphere: a 3-D cloud spans two metres of height, forty layers of 5 cm -- the
+    // rule below rejects a layer whose gap exceeds the radius, i.e. every layer outside [zc - r, zc + r] and a layer of
+    // slack; the kernel rejects whatever lies outside the table)
     const double zc = -static_cast<double>(c->frame.t[2]);
+    const int k0 = std::max(key(lo[2]), static_cast<int>(std::max(std::floor((zc - c->radius) * c->inv_res) - 1.0, -32768.0)));
+    const int k1 = std::min(key(hi[2]), static_cast<int>(std::min(std::floor((zc + c->radius) * c->inv_res) + 1.0, 32767.0)));
+    if (k1 - k0 + 1 > 36) return KC_OK;
     double gap[36];
     double gmax = -1.0;
     for (int kz = k0; kz <= k1; ++kz) {  // add_voxel, the sphere branch
@@ -663,7 +667,7 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
       if (gap[kz - k0] >= 0.0)
         sph_code[kz - k0] = static_cast<unsigned char>(std::lower_bound(sph_lut.begin(), sph_lut.end(), gap[kz - k0]) - sph_lut.begin() + 1);
     sph_kz0 = k0;
-    sph_nkz = k1 - k0 + 1;
+    sph_nkz = std::max(k1 - k0 + 1, 0);
     c->sphere_ddz_max = gmax;  // (dil_geom: -1 = no layer of the cloud can touch the sphere: no masks, no voxels)
   }
   bool fits = false;
@@ -787,7 +791,8 @@ int sensor_update_device_bounded(kc_dwa *c, const float *xyz, size_t n, const fl
     band_rows = (band_rows + 1) / 2;
   }
   nb = (c->gH + band_rows - 1) / band_rows;
-  const bool fused = !big_only && c->sensor_fused_ok && n <= kSensorFusedMax && band_bytes() <= kSensorFusedLds && nb <= 1024;
+  const bool fused = !big_only && c->sensor_fused_ok && n <= (sphere ? kSensorFusedMax : kSensorFusedPays) &&
+                     band_bytes() <= kSensorFusedLds && nb <= 1024;
   bool masks_built = false;
   if (fused) {
     SensorFusedArgs f{};

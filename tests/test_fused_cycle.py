@@ -411,6 +411,15 @@ def test_sphere_sensor_update_on_the_device(sensor_z):
         assert_cycle_equal(o, h)
         g = hip_cycle(kh, cur, sensor_pos=(0, 0, sensor_z), ctx=host)
         assert (h["res"]["found"], h["res"]["index"], h["res"]["n_admissible"]) == (g["res"]["found"], g["res"]["index"], g["res"]["n_admissible"])
+    # a 3-D cloud two and a half metres tall (fifty voxel layers: the layer table holds the ones that can touch the sphere)
+    pts = np.asarray(inp["points"], np.float32)[rng.choice(len(inp["points"]), 3000, replace=False)].copy()
+    pts[:, 2] = rng.uniform(-0.6, 1.9, len(pts)).astype(np.float32)
+    cur = dict(inp, points=pts)
+    o = oracle_cycle(cur, sensor_pos=(0, 0, sensor_z))
+    h = hip_cycle(kh, cur, sensor_pos=(0, 0, sensor_z), ctx=dev)
+    assert_cycle_equal(o, h)
+    g = hip_cycle(kh, cur, sensor_pos=(0, 0, sensor_z), ctx=host)
+    assert (h["res"]["found"], h["res"]["index"], h["res"]["n_admissible"]) == (g["res"]["found"], g["res"]["index"], g["res"]["n_admissible"])
     dev.close()
     host.close()
 
