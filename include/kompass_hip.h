@@ -170,7 +170,7 @@ int kc_dwa_set_weights(kc_dwa *ctx, const kc_weights *w);
  *   "num_ctrl_points" (0) numCtrlPoints_ = control_horizon / time_step as size_t (:88: the config-object
  *                        constructor's definition; the explicit-argument constructor leaves it
  *                        uninitialised)
- *   "obs_near"       (1) LaserScan input with finite ranges: consecutive beams are a polyline -- the
+ *   "obs_near"       (1) LaserScan input (beams without a return -- inf / NaN -- stay out of the boxes): consecutive beams are a polyline -- the
  *                        obstacle term of long admissible lists goes through a near table of the scan
  *                        (per cell of the reachable box: the beam chunks that can hold the nearest
  *                        obstacle, a seed, a floor; obs_near_kernel) instead of the bucket ring search

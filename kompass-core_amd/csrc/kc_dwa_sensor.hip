@@ -1170,9 +1170,14 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
   c->oscan_valid = false;
   c->onear_ok = false;
   if (c->obs_near_opt && n >= 64 && n <= 65536) {
-    // the boxes of the chunks of the scan polyline, for the near table of the scan; a non-finite range leaves the
-    // scan to the bucket search
-    if (finite) {
+    // the boxes of the chunks of the scan polyline, for the near table of the scan.  Beams without a return (inf / NaN
+    // ranges: what a real scanner reports beyond its range) have obstacles that never win a minimum: they stay in the
+    // list -- the indices are the scan's -- and out of the boxes.  (Until round 4 one such beam left the whole scan to
+    // the bucket search: 65-235 us of cycle kernel in a room against 25-45, tools/room_sweep.py ... obs_near=0.)
+    {
+      auto box_of = [&](size_t j0, size_t j1) {
+        return finite ? scantab::box_of(hx, hy, j0, j1) : scantab::box_of_finite(hx, hy, j0, j1);
+      };
       const int cs = static_cast<int>((n + 63) / 64);
       const int nch = static_cast<int>((n + cs - 1) / cs);
       // chunks of 32 obstacles and more also get the boxes of their four quarters (wave_sample_total prunes by them)
@@ -1189,13 +1194,13 @@ int kc_dwa_set_scan(kc_dwa *c, const kc_state *st, const double *ranges,
           scantab::Box whole = scantab::box_empty();
           for (int q = 0; q < 4; ++q) {
             const size_t q0 = std::min(j1, j0 + static_cast<size_t>(q) * scs), q1 = std::min(j1, q0 + static_cast<size_t>(scs));
-            const scantab::Box b = (k < nch) ? scantab::box_of(hx, hy, q0, q1) : scantab::box_empty();
+            const scantab::Box b = (k < nch) ? box_of(q0, q1) : scantab::box_empty();
             put(sub, 256, 4 * k + q, b);
             whole = scantab::box_join(whole, b);
           }
           put(box, 64, k, whole);
         } else {
-          put(box, 64, k, (k < nch) ? scantab::box_of(hx, hy, j0, j1) : scantab::box_empty());
+          put(box, 64, k, (k < nch) ? box_of(j0, j1) : scantab::box_empty());
         }
       }
       KC_TRY(c->d_oscan.reserve(2 * n + 256 + 1024));

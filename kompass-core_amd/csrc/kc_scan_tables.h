@@ -126,6 +126,19 @@ __attribute__((target("avx2"))) inline Box box_avx2(const float *hx, const float
 inline Box box_of(const float *hx, const float *hy, size_t j0, size_t j1) {
   return segtab::cpu_has_avx2() ? box_avx2(hx, hy, j0, j1) : box_scalar(hx, hy, j0, j1, box_empty());
 }
+// ... of the obstacles of [j0, j1) whose coordinates are both finite (a beam without a return: its range is inf or NaN,
+// its obstacle never wins `dist < minDist` -- it is not part of any box either)
+inline Box box_of_finite(const float *hx, const float *hy, size_t j0, size_t j1) {
+  Box b = box_empty();
+  for (size_t j = j0; j < j1; ++j) {
+    if (!std::isfinite(hx[j]) || !std::isfinite(hy[j])) continue;
+    b.x0 = std::min(b.x0, hx[j]);
+    b.x1 = std::max(b.x1, hx[j]);
+    b.y0 = std::min(b.y0, hy[j]);
+    b.y1 = std::max(b.y1, hy[j]);
+  }
+  return b;
+}
 inline Box box_join(const Box &a, const Box &b) {
   return Box{std::min(a.x0, b.x0), std::max(a.x1, b.x1), std::min(a.y0, b.y0), std::max(a.y1, b.y1)};
 }

@@ -456,3 +456,31 @@ def test_long_boxes_look_up_circles_along_their_axis(dims, mode):
         assert res[0]["res"] == res[1]["res"]
         np.testing.assert_array_equal(res[0]["raw"], res[1]["raw"])
         np.testing.assert_array_equal(res[0]["costs"].view(np.uint32), res[1]["costs"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beams", [360, 1440, 4096])
+def test_scans_with_beams_without_a_return_keep_their_near_table(beams):
+    """Real scanners report inf (or NaN) beyond their range.  Such a beam's obstacle never wins a minimum (cost side:
+    `dist < minDist` is false for it; collision side: add_voxel drops it), so it stays in the scan's list and
+    out of the chunk boxes -- the scan keeps its near table (until round 4 one such beam sent the whole scan to the bucket
+    search).  Runs of missing beams, isolated ones, a whole chunk without returns; against the oracle, near table on / off."""
+    inp = syn.make_controller_inputs("cfg2", seed=4, scale=0.3, scene="open")
+    ang = np.linspace(-np.pi, np.pi, beams, endpoint=False)
+    rng = 3.0 + 1.2 * np.cos(5 * ang) + 0.3 * np.sin(17 * ang)
+    r = np.random.default_rng(beams)
+    rng[r.random(beams) < 0.05] = np.inf
+    rng[r.integers(0, beams, 5)] = np.nan
+    a0 = beams // 3
+    rng[a0:a0 + beams // 20] = np.inf            # a doorway: a run longer than a chunk of the scan
+    cur = dict(inp, state=(0.3, -0.2, 0.4, 0.0))
+    o = oracle_cycle(cur, scan=(rng, ang))
+    assert len(o["raw"]) > 100
+    for opts in (dict(), dict(fused_cycle=0, cost_kernel=2, cost_batch=2), dict(obs_near=0)):
+        ctx = hip_context(kh, cur)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        assert_cycle_equal(o, hip_cycle(kh, cur, scan=(rng, ang), ctx=ctx))
+        if "obs_near" not in opts:
+            assert ctx.get_option("obs_near_rides") + ctx.get_option("obs_near_builds") >= 1
+        ctx.close()

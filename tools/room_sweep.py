@@ -34,6 +34,8 @@ for shape in ("round", "square", "corridor"):
         lat, ks = [], {}
         for i in range(400):
             r = np.minimum(r0 + rng.uniform(0.0, 0.02, beams), 9.9)
+            if os.environ.get("KC_TOOL_NO_RETURN"):   # every twentieth beam without a return
+                r[::20] = np.inf
             st = (0.0, 0.0, 1e-3 * ((i % 7) - 3), 0.0)
             if i == 250:
                 ctx.timing_enable(True)
