@@ -359,9 +359,10 @@ struct kc_dwa {
   bool freeze_valid = false;           // d_freeze describes the last roll-out
 };
 
-// largest point list the device-side sensor update takes (bucket grid of at most 64 x 64 cells:
-// about one obstacle per cell up to 4 k points, 64 per cell here); beyond: the host path, finer grid
-constexpr size_t kSensorDeviceMax = 262144;
+// largest point list the device-side sensor update takes (bucket grid of at most 64 x 64 cells: about one obstacle per
+// cell up to 4 k points, hundreds per cell here); beyond: the host path, finer grid.  (262144 until a raw depth image --
+// 307 200 points -- was priced: 6 ms of host build at 500 k points against 0.16 ms here, tools/big_cloud_sweep.py.)
+constexpr size_t kSensorDeviceMax = 1048576;
 constexpr int kTiltCrop = 4000;                // half side of the kept window of a cropped tilted scan, in voxel columns
 constexpr size_t kSensorFusedMax = 32768;       // points up to which the one-launch sensor build CAN be used (spheres: it is their only device build)
 constexpr size_t kSensorFusedPays = 18432;      // ... and up to which it is ahead: every workgroup reads every point (tools/big_cloud_sweep.py,

@@ -484,3 +484,28 @@ def test_scans_with_beams_without_a_return_keep_their_near_table(beams):
         if "obs_near" not in opts:
             assert ctx.get_option("obs_near_rides") + ctx.get_option("obs_near_builds") >= 1
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_clouds_of_several_hundred_thousand_points_on_the_device():
+    """A raw depth-camera cloud (640 x 480 = 307 200 points) or a 128-beam lidar sweep: the device-side sensor update
+    takes up to 2^20 points (262 144 until round 4; beyond it the host build took 6 ms at 500 k points).  Same admissible
+    set, costs and winner as the host build, NaN points included."""
+    inp = syn.make_controller_inputs("cfg2", seed=0, scale=0.35)
+    rng = np.random.default_rng(3)
+    n = 330_000
+    th, rad = rng.uniform(-np.pi, np.pi, n), rng.uniform(2.2, 9.0, n) ** 1.0
+    keep = rng.random(n) < np.clip((rad - 2.0) / 6.0, 0.02, 1.0)      # sparse near the robot, dense far out
+    pts = np.stack([rad * np.cos(th), rad * np.sin(th), rng.uniform(-0.2, 1.5, n)], 1).astype(np.float32)
+    pts[~keep, 2] = 5.0                                                # (above the robot: dropped by the voxel rule, still obstacles of the cost)
+    pts[::997, 0] = np.nan
+    out = []
+    for host in (0, 1):
+        ctx = hip_context(kh, dict(inp, points=pts), sensor_pos=(0, 0, 0.3))
+        ctx.set_option("sensor_on_host", host)
+        h = hip_cycle(kh, dict(inp, points=pts), sensor_pos=(0, 0, 0.3), ctx=ctx)
+        out.append(h)
+        ctx.close()
+    assert out[0]["res"] == out[1]["res"] and out[0]["res"]["n_admissible"] > 50
+    np.testing.assert_array_equal(out[0]["raw"], out[1]["raw"])
+    np.testing.assert_array_equal(out[0]["costs"].view(np.uint32), out[1]["costs"].view(np.uint32))
