@@ -462,10 +462,12 @@ __attribute__((target("avx512f"))) size_t bounds_copy_avx512(const float *src, f
     for (int q = 0; q < 3; ++q) {
       const __m512 v = _mm512_loadu_ps(src + i + 16 * q);
       _mm512_stream_ps(dst + i + 16 * q, v);
-      mn[q] = _mm512_min_ps(mn[q], v);
-      mx[q] = _mm512_max_ps(mx[q], v);
+      // (a value that is not finite -- a beam without a return, a NaN of a depth image -- leaves the bounds alone)
       const __m512 d = _mm512_sub_ps(v, v);
-      bad |= _mm512_cmp_ps_mask(d, d, _CMP_UNORD_Q);
+      const __mmask16 fin = _mm512_cmp_ps_mask(d, d, _CMP_ORD_Q);
+      mn[q] = _mm512_mask_min_ps(mn[q], fin, mn[q], v);
+      mx[q] = _mm512_mask_max_ps(mx[q], fin, mx[q], v);
+      bad |= static_cast<__mmask16>(~fin);
     }
   }
   // 64-byte vector q, 16-byte lane l = SSE vector (4 q + l) of the stream: period 3
@@ -533,13 +535,19 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
         v4 v;
         std::memcpy(&v, xyz + i + 4 * q, sizeof(v));
         __builtin_nontemporal_store(v, reinterpret_cast<v4 *>(dst + i + 4 * q));
-        mn[q] = __builtin_ia32_minps(mn[q], v);
-        mx[q] = __builtin_ia32_maxps(mx[q], v);
         const v4 dv = v - v;
-        ok &= (dv == zero);
+        const v4i fin = (dv == zero);  // (not finite: the element leaves the bounds alone)
+        mn[q] = __builtin_ia32_minps(mn[q], (v4)(((v4i)v & fin) | ((v4i)big & ~fin)));
+        mx[q] = __builtin_ia32_maxps(mx[q], (v4)(((v4i)v & fin) | ((v4i)(-big) & ~fin)));
+        ok &= fin;
       }
     }
-    if ((ok[0] & ok[1] & ok[2] & ok[3]) != 0) {
+    // (Round 4: values that are not finite no longer send the list to the scalar loop below -- a LaserScan with beams
+    // without a return, a depth image with holes: 22 us at 4096 beams.  The bounds are those of the finite VALUES: a
+    // point with one coordinate missing still widens the other two -- a looser box, which only sizes the tables; the
+    // kernels drop the point as before.)
+    (void)ok;
+    {
       // lanes: v0 = x0 y0 z0 x1 | v1 = y1 z1 x2 y2 | v2 = z2 x3 y3 z3
       static const int vec_of[3][4] = {{0, 0, 1, 2}, {0, 1, 1, 2}, {0, 1, 2, 2}};
       static const int lane_of[3][4] = {{0, 3, 2, 1}, {1, 0, 3, 2}, {2, 1, 0, 3}};
@@ -552,11 +560,12 @@ int sensor_update_device(kc_dwa *c, const float *xyz, size_t n, bool *done) {
       for (; i < total; ++i) {  // fewer than four points
         const float v = xyz[i];
         dst[i] = v;
-        tail_ok = tail_ok && std::isfinite(v);
+        if (!std::isfinite(v)) continue;
         lo[i % 3] = std::min(lo[i % 3], v);
         hi[i % 3] = std::max(hi[i % 3], v);
       }
       raw_copied = true;
+      tail_ok = lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2];  // (a finite value on every axis)
       if (tail_ok) {
         bounded = true;
         nfin = n;

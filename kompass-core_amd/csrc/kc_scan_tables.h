@@ -128,8 +128,7 @@ inline Box box_of(const float *hx, const float *hy, size_t j0, size_t j1) {
 }
 // ... of the obstacles of [j0, j1) whose coordinates are both finite (a beam without a return: its range is inf or NaN,
 // its obstacle never wins `dist < minDist` -- it is not part of any box either)
-inline Box box_of_finite(const float *hx, const float *hy, size_t j0, size_t j1) {
-  Box b = box_empty();
+inline Box box_finite_scalar(const float *hx, const float *hy, size_t j0, size_t j1, Box b) {
   for (size_t j = j0; j < j1; ++j) {
     if (!std::isfinite(hx[j]) || !std::isfinite(hy[j])) continue;
     b.x0 = std::min(b.x0, hx[j]);
@@ -138,6 +137,39 @@ inline Box box_of_finite(const float *hx, const float *hy, size_t j0, size_t j1)
     b.y1 = std::max(b.y1, hy[j]);
   }
   return b;
+}
+// (eight at a time: a lane whose x or y is not finite -- v - v is NaN then -- takes +inf into the minima and -inf
+// into the maxima, the neutral elements; min / max of finite floats do not depend on the order)
+__attribute__((target("avx2"))) inline Box box_finite_avx2(const float *hx, const float *hy, size_t j0, size_t j1) {
+  const __m256 pinf = _mm256_set1_ps(std::numeric_limits<float>::infinity());
+  const __m256 ninf = _mm256_set1_ps(-std::numeric_limits<float>::infinity());
+  __m256 x0 = pinf, x1 = ninf, y0 = pinf, y1 = ninf;
+  size_t j = j0;
+  for (; j + 8 <= j1; j += 8) {
+    const __m256 vx = _mm256_loadu_ps(hx + j), vy = _mm256_loadu_ps(hy + j);
+    const __m256 dx = _mm256_sub_ps(vx, vx), dy = _mm256_sub_ps(vy, vy);
+    const __m256 ok = _mm256_and_ps(_mm256_cmp_ps(dx, dx, _CMP_ORD_Q), _mm256_cmp_ps(dy, dy, _CMP_ORD_Q));
+    x0 = _mm256_min_ps(x0, _mm256_blendv_ps(pinf, vx, ok));
+    x1 = _mm256_max_ps(x1, _mm256_blendv_ps(ninf, vx, ok));
+    y0 = _mm256_min_ps(y0, _mm256_blendv_ps(pinf, vy, ok));
+    y1 = _mm256_max_ps(y1, _mm256_blendv_ps(ninf, vy, ok));
+  }
+  alignas(32) float a[4][8];
+  _mm256_store_ps(a[0], x0);
+  _mm256_store_ps(a[1], x1);
+  _mm256_store_ps(a[2], y0);
+  _mm256_store_ps(a[3], y1);
+  Box b = box_empty();
+  for (int k = 0; k < 8; ++k) {
+    b.x0 = std::min(b.x0, a[0][k]);
+    b.x1 = std::max(b.x1, a[1][k]);
+    b.y0 = std::min(b.y0, a[2][k]);
+    b.y1 = std::max(b.y1, a[3][k]);
+  }
+  return box_finite_scalar(hx, hy, j, j1, b);
+}
+inline Box box_of_finite(const float *hx, const float *hy, size_t j0, size_t j1) {
+  return segtab::cpu_has_avx2() ? box_finite_avx2(hx, hy, j0, j1) : box_finite_scalar(hx, hy, j0, j1, box_empty());
 }
 inline Box box_join(const Box &a, const Box &b) {
   return Box{std::min(a.x0, b.x0), std::max(a.x1, b.x1), std::min(a.y0, b.y0), std::max(a.y1, b.y1)};

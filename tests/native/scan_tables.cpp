@@ -51,6 +51,21 @@ int main() {
       ++bad;
       std::printf("points differ at n = %zu (finite %d / %d)\n", n, fa, fb);
     }
+    if (n > 0) {  // the boxes over the finite obstacles only (beams without a return), poisoned lists included
+      std::vector<float> px(hxb), py(hyb);
+      for (size_t i = 0; i < n; ++i)
+        if (g() % 9 == 0) (g() % 2 ? px : py)[i] = (g() % 2) ? std::numeric_limits<float>::infinity() : std::nanf("");
+      for (int k = 0; k < 20; ++k) {
+        const size_t j0 = g() % n, j1 = j0 + g() % (n - j0 + 1);
+        const scantab::Box a = scantab::box_finite_avx2(px.data(), py.data(), j0, j1);
+        const scantab::Box b = scantab::box_finite_scalar(px.data(), py.data(), j0, j1, scantab::box_empty());
+        ++cases;
+        if (std::memcmp(&a, &b, sizeof(a)) != 0) {
+          ++bad;
+          std::printf("finite box differs at [%zu, %zu)\n", j0, j1);
+        }
+      }
+    }
     if (!poison && n > 0) {
       for (int k = 0; k < 20; ++k) {
         const size_t j0 = g() % n, j1 = j0 + g() % (n - j0 + 1);
